@@ -1,0 +1,114 @@
+/* mi355q -- MI355X (gfx950) block-quantised linear / matmul hot path, C ABI.
+ *
+ * The reference (ChengZhang-98/llm-mixed-q) is pure Python/PyTorch and has NO FFI: its
+ * boundary for this path is a name-keyed registry of Python callables.  This header is the
+ * C-ABI layer the build adds underneath that registry (last row).  Each entry
+ * point names the reference callable whose arithmetic it replaces; the Python mirror in
+ * llm-mixed-q_amd/mi355q/quantize/ binds them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises the host;
+ *   - return value: 0 on success, a positive hipError_t, or a negative MI355Q_E_* code;
+ *     mi355q_error_string() explains either;
+ *   - tensors are contiguous row-major.  A quantiser input is described as `lead` planes of
+ *     `rows x cols` fp32 values tiled by `b0 x b1` blocks (blocks never straddle planes;
+ *     ragged edge blocks behave as if zero-padded on the right/bottom).  The reference's
+ *     five blocking cases (quantizers/utils.py:86-237, 261-284) map onto it as
+ *         bias   [O]      -> lead 1, rows 1, cols O, b0 1,  b1 B
+ *         act    [N,C]    -> lead 1, rows N, cols C, b0 1,  b1 B       (skip_first_dim)
+ *         weight [O,K]    -> lead 1, rows O, cols K, b0 B0, b1 B1
+ *         act    [B,T,C]  -> lead B, rows T, cols C, b0 B0, b1 B1      (skip_first_dim)
+ *     with (b0,b1) the reference's right-aligned, clamped block shape (utils.py:42-66).
+ *   - `workspace`: MI355Q_WORKSPACE_BYTES bytes of device memory, ZERO-INITIALISED once by
+ *     the caller, private to one stream; the library leaves it zeroed after every call.
+ */
+#ifndef MI355Q_H
+#define MI355Q_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355Q_ABI_VERSION 1
+#define MI355Q_WORKSPACE_BYTES 256
+
+/* negative error codes (positive values are hipError_t) */
+#define MI355Q_E_BADARG (-1)      /* null pointer, non-positive size, width out of range */
+#define MI355Q_E_UNSUPPORTED (-2) /* legal for the reference, not built here (message says what) */
+#define MI355Q_E_ALIGN (-3)       /* pointer / leading dimension alignment requirement violated */
+
+/* flags */
+#define MI355Q_ZERO_BLOCK_EXACT 0u /* default: all-zero blocks take the reference's global fill
+                                      (block_fp.py:54-58): second, usually empty, launch */
+#define MI355Q_ZERO_BLOCK_FAST 1u  /* all-zero blocks get mantissa 0 / the minimum exponent and
+                                      block_log zeros take the block's own bias: one launch */
+
+int mi355q_abi_version(void);
+const char* mi355q_error_string(int code);
+
+/* ---- block floating point ---------------------------------------------------------
+ * replaces: quantizers/block_fp.py:21-96  (_block_fp_quantize) behind
+ *           QUANTIZER_MAP["block_fp"] (quantizers/__init__.py:8-16).
+ * y    (nullable) fp32, same shape as x: the fake-quantised tensor the reference returns,
+ *      including the |x| <= 1e-8 pass-through (block_fp.py:93-94).
+ * mant (nullable) int8, same shape as x: sign(x+1e-9) * integer mantissa, |mant| <= 2^(width-1)-1.
+ * exp  (nullable, together with mant) uint8 [lead, ceil(rows/b0), ceil(cols/b1)]:
+ *      shared exponent + exponent_bias (the stored, biased code).
+ * width in [2,8] when mant is requested ([2,25] for y only); exponent_width in [1,8];
+ * exponent_bias < 0 selects the default 2^(exponent_width-1)-1 (block_fp.py:61-62). */
+int mi355q_block_fp_quantize(const float* x, float* y, int8_t* mant, uint8_t* exp,
+                             int64_t lead, int64_t rows, int64_t cols, int32_t b0, int32_t b1,
+                             int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                             uint32_t flags, void* workspace, void* stream);
+
+/* ---- block minifloat ----------------------------------------------------------------
+ * replaces: quantizers/block_minifloat.py:22-74 -> quantizers/minifloat.py:134-196 behind
+ *           QUANTIZER_MAP["block_minifloat"].   y: fake-quantised fp32 (required).
+ * bias (nullable) uint8 [n_blocks]: the shared exponent bias per block. */
+int mi355q_block_minifloat_quantize(const float* x, float* y, uint8_t* bias,
+                                    int64_t lead, int64_t rows, int64_t cols, int32_t b0, int32_t b1,
+                                    int32_t width, int32_t exponent_width,
+                                    int32_t exponent_bias_width,
+                                    uint32_t flags, void* workspace, void* stream);
+
+/* ---- block logarithmic ----------------------------------------------------------------
+ * replaces: quantizers/block_log.py:23-69 -> quantizers/log.py:22-56 behind
+ *           QUANTIZER_MAP["block_log"].   y: fake-quantised fp32 (required).
+ * bias (nullable) uint8 [n_blocks]. */
+int mi355q_block_log_quantize(const float* x, float* y, uint8_t* bias,
+                              int64_t lead, int64_t rows, int64_t cols, int32_t b0, int32_t b1,
+                              int32_t width, int32_t exponent_bias_width,
+                              uint32_t flags, void* workspace, void* stream);
+
+/* ---- integer fixed point (RoPE tables; quantizers/integer.py:25-58) -------------------- */
+int mi355q_integer_quantize(const float* x, float* y, int64_t n, int32_t width,
+                            int32_t frac_width, int32_t is_signed, void* stream);
+
+/* ---- block-fp GEMM: the contraction of a PTQ LinearBlockFP forward -----------------------
+ * replaces: F.linear(x_q, W_q, b_q) in quantized_modules/linear.py:71 when x and W are
+ *           block_fp with [1,16] blocks along in_features:
+ *   y[m,n] = sum_kb 2^(xe[m,kb]-x_bias-x_mbits + we[n,kb]-w_bias-w_mbits)
+ *                   * sum_{j<16} xm[m,16kb+j] * wm[n,16kb+j]          (+ bias[n])
+ * with the inner sum an exact int8 x int8 -> int32 MFMA dot and the outer sum in fp32.
+ * xm [M,K] int8, xe [M,K/16] uint8, wm [N,K] int8, we [N,K/16] uint8 as produced by
+ * mi355q_block_fp_quantize with b0=1, b1=16; K % 16 == 0; bias (nullable) fp32 [N],
+ * already quantised; y fp32 with leading dimension ldy >= N (ldy lets a rank write its
+ * column slice of a wider output).  x_mbits/w_mbits = width-1 of each operand. */
+int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const uint8_t* we,
+                    const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
+                    int32_t x_mbits, int32_t x_exp_bias, int32_t w_mbits, int32_t w_exp_bias,
+                    void* stream);
+
+/* Which GEMM kernel variant mi355q_bfp_gemm dispatches to (0 = automatic).  For A/B
+ * benchmarking and tests only; returns the previous value. */
+int mi355q_bfp_gemm_set_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355Q_H */

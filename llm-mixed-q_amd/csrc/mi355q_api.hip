@@ -1,0 +1,140 @@
+// C-ABI entry points declared in include/mi355q.h: argument validation and dispatch only.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+
+#include "mi355q.h"
+#include "mi355q_internal.h"
+
+using namespace mi355q;
+
+namespace {
+std::atomic<int> g_gemm_variant{0};
+
+bool bad_shape(int64_t lead, int64_t rows, int64_t cols, int32_t b0, int32_t b1) {
+    return lead < 0 || rows < 0 || cols < 0 || b0 < 1 || b1 < 1;
+}
+
+int fill_common(QuantArgs& a, const float* x, float* y, void* workspace, int64_t lead, int64_t rows,
+                int64_t cols, int32_t b0, int32_t b1, uint32_t flags) {
+    if (bad_shape(lead, rows, cols, b0, b1)) return MI355Q_E_BADARG;
+    a = QuantArgs{};
+    a.x = x;
+    a.y = y;
+    a.ws = static_cast<unsigned*>(workspace);
+    a.lead = lead; a.rows = rows; a.cols = cols;
+    a.b0 = b0; a.b1 = b1;
+    a.n_elems = lead * rows * cols;
+    a.nbr = (rows + b0 - 1) / b0;
+    a.nbc = (cols + b1 - 1) / b1;
+    a.n_blocks = lead * a.nbr * a.nbc;
+    a.flags = flags;
+    if (a.n_elems == 0) return 1 << 30;   // nothing to do (caller returns 0)
+    if (x == nullptr) return MI355Q_E_BADARG;
+    if ((flags & MI355Q_ZERO_BLOCK_FAST) == 0u && workspace == nullptr) return MI355Q_E_BADARG;
+    return 0;
+}
+void set_mantissa(QuantArgs& a, int mbits) {
+    a.shift = std::ldexp(1.0f, mbits);
+    a.inv_shift = std::ldexp(1.0f, -mbits);
+    a.mant_max = a.shift - 1.0f;
+}
+}  // namespace
+
+extern "C" {
+
+int mi355q_abi_version(void) { return MI355Q_ABI_VERSION; }
+
+const char* mi355q_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case MI355Q_E_BADARG: return "mi355q: bad argument (null pointer, negative size, or width out of range)";
+        case MI355Q_E_UNSUPPORTED: return "mi355q: configuration valid for the reference but not built here";
+        case MI355Q_E_ALIGN: return "mi355q: pointer or leading-dimension alignment requirement violated";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "mi355q: unknown error";
+    }
+}
+
+int mi355q_block_fp_quantize(const float* x, float* y, int8_t* mant, uint8_t* exp, int64_t lead, int64_t rows,
+                             int64_t cols, int32_t b0, int32_t b1, int32_t width, int32_t exponent_width,
+                             int32_t exponent_bias, uint32_t flags, void* workspace, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, y, workspace, lead, rows, cols, b0, b1, flags);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if ((mant == nullptr) != (exp == nullptr)) return MI355Q_E_BADARG;
+    if (y == nullptr && mant == nullptr) return MI355Q_E_BADARG;
+    if (exponent_width < 1 || exponent_width > 8) return MI355Q_E_BADARG;
+    if (width < 2 || width > (mant ? 8 : 25)) return MI355Q_E_BADARG;
+    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    a.mant = mant;
+    a.code = exp;
+    a.code_bias = exponent_bias;
+    a.e_min = -exponent_bias;
+    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    set_mantissa(a, width - 1);
+    return launch_quant(a, 0, /*needs_fixup=*/mant != nullptr, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_block_minifloat_quantize(const float* x, float* y, uint8_t* bias, int64_t lead, int64_t rows, int64_t cols,
+                                    int32_t b0, int32_t b1, int32_t width, int32_t exponent_width,
+                                    int32_t exponent_bias_width, uint32_t flags, void* workspace, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, y, workspace, lead, rows, cols, b0, b1, flags);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y == nullptr) return MI355Q_E_BADARG;
+    const int mbits = width - exponent_width - 1;
+    if (exponent_width < 1 || exponent_width > 8 || mbits < 0 || mbits > 23) return MI355Q_E_BADARG;
+    if (exponent_bias_width < 1 || exponent_bias_width > 8) return MI355Q_E_BADARG;
+    a.code = bias;
+    a.span = (1 << exponent_width) - 1;
+    a.bias_max = (1 << exponent_bias_width) - 1;
+    set_mantissa(a, mbits);
+    return launch_quant(a, 1, /*needs_fixup=*/bias != nullptr, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_block_log_quantize(const float* x, float* y, uint8_t* bias, int64_t lead, int64_t rows, int64_t cols,
+                              int32_t b0, int32_t b1, int32_t width, int32_t exponent_bias_width, uint32_t flags,
+                              void* workspace, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, y, workspace, lead, rows, cols, b0, b1, flags);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y == nullptr) return MI355Q_E_BADARG;
+    if (width < 2 || width > 9) return MI355Q_E_BADARG;       // exponent code of width-1 <= 8 bits
+    if (exponent_bias_width < 1 || exponent_bias_width > 8) return MI355Q_E_BADARG;
+    a.code = bias;
+    a.span = (1 << (width - 1)) - 1;
+    a.bias_max = (1 << exponent_bias_width) - 1;
+    set_mantissa(a, 0);
+    return launch_quant(a, 2, /*needs_fixup=*/true, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_integer_quantize(const float* x, float* y, int64_t n, int32_t width, int32_t frac_width,
+                            int32_t is_signed, void* stream) {
+    if (n < 0 || width < 1 || width > 24) return MI355Q_E_BADARG;
+    if (n == 0) return 0;
+    if (x == nullptr || y == nullptr) return MI355Q_E_BADARG;
+    const float lo = is_signed ? -std::ldexp(1.0f, width - 1) : 0.0f;
+    const float hi = is_signed ? std::ldexp(1.0f, width - 1) - 1.0f : std::ldexp(1.0f, width) - 1.0f;
+    return launch_integer(x, y, n, std::ldexp(1.0f, frac_width), lo, hi, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const uint8_t* we, const float* bias,
+                    float* y, int64_t M, int64_t N, int64_t K, int64_t ldy, int32_t x_mbits, int32_t x_exp_bias,
+                    int32_t w_mbits, int32_t w_exp_bias, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
+    if (M == 0 || N == 0) return 0;
+    if (!y || (K > 0 && (!xm || !xe || !wm || !we))) return MI355Q_E_BADARG;
+    if (K % 16 != 0) return MI355Q_E_UNSUPPORTED;
+    if (x_mbits < 1 || x_mbits > 7 || w_mbits < 1 || w_mbits > 7) return MI355Q_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(xm) | reinterpret_cast<uintptr_t>(wm)) % 16) return MI355Q_E_ALIGN;
+    GemmArgs a{xm, xe, wm, we, bias, y, M, N, K, ldy, x_exp_bias + x_mbits + w_exp_bias + w_mbits};
+    return launch_bfp_gemm(a, g_gemm_variant.load(), static_cast<hipStream_t>(stream));
+}
+
+int mi355q_bfp_gemm_set_variant(int variant) { return g_gemm_variant.exchange(variant); }
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Internal declarations shared by the kernel translation units and the C-ABI wrapper.
+#ifndef MI355Q_INTERNAL_H
+#define MI355Q_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355q {
+
+// One quantiser launch: `lead` planes of rows x cols fp32 tiled by b0 x b1 blocks.
+struct QuantArgs {
+    const float* x;
+    float* y;          // fake-quantised fp32 (nullable for block_fp)
+    int8_t* mant;      // block_fp signed mantissas (nullable)
+    uint8_t* code;     // per block: biased shared exponent (bfp) or shared bias (bm / bl); nullable
+    unsigned* ws;      // MI355Q_WORKSPACE_BYTES, zeroed
+    long long lead, rows, cols;
+    long long n_elems, n_blocks;
+    long long nbr, nbc;   // blocks per plane along rows / cols
+    int b0, b1;
+    int e_min, e_max;     // bfp: clamp range of the shared exponent
+    int code_bias;        // bfp: exponent_bias
+    int span;             // bm: 2^exponent_width - 1 ; bl: 2^(width-1) - 1
+    int bias_max;         // bm / bl: 2^exponent_bias_width - 1
+    float shift, inv_shift, mant_max;   // 2^mbits, 2^-mbits, 2^mbits - 1
+    unsigned flags;
+};
+
+int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
+int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
+
+struct GemmArgs {
+    const int8_t* xm;
+    const uint8_t* xe;
+    const int8_t* wm;
+    const uint8_t* we;
+    const float* bias;
+    float* y;
+    long long M, N, K, ldy;
+    int scale_bias;   // subtracted from xe + we to get the power of two of a block product
+};
+int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
+
+}  // namespace mi355q
+#endif

@@ -1,0 +1,420 @@
+// mi355q_quant.hip -- block quantisers for gfx950 (MI355X), HBM-bound streaming kernels.
+//
+// One pass over x produces, per block of b0 x b1 values, the shared exponent / bias and,
+// per element, the fake-quantised fp32 value and (block_fp) the packed int8 mantissa.
+//   block_fp        : reference quantizers/block_fp.py:21-96
+//   block_minifloat : reference quantizers/block_minifloat.py:22-74 + minifloat.py:134-196
+//   block_log       : reference quantizers/block_log.py:23-69 + log.py:22-56
+// Bit-exactness notes
+//   * every fp32 operation of the reference is done as the same IEEE fp32 operation here
+//     (scalings by 2^n through v_ldexp_f32, which rounds like the division/multiplication it
+//     replaces, subnormals included);
+//   * ceil/floor/rint of log2 are taken from integer threshold tables on the fp32 fraction
+//     (log2_tables.inc, tools/gen_log2_tables.py) -- no logarithm is evaluated on the device;
+//   * all-zero blocks take the reference's tensor-global fill (block_fp.py:54-58) in a second
+//     launch that returns immediately when kernel 1 met no such block.
+//
+// Data layout in HBM: x/y/mant are the caller's contiguous row-major tensors; one wave reads
+// 1 KiB of x per instruction (float4 per lane), a block of 16 values is held by 4 adjacent
+// lanes and its abs-max is formed by two DPP quad permutes -- no LDS traffic on the hot loop
+// except the threshold lookup for the block exponent.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi355q.h"
+#include "mi355q_internal.h"
+
+#define MI355Q_TABLE_QUAL __device__ const
+#include "log2_tables.inc"
+
+namespace mi355q {
+
+constexpr int FMT_BFP = 0, FMT_BM = 1, FMT_BL = 2;
+constexpr int LUT_N = MI355Q_LOG2_TABLE_SIZE;
+constexpr float EPS9 = 1e-9f;
+constexpr float ATOL = 1e-8f;
+
+// workspace words
+constexpr int WS_ZERO_FLAG = 0;   // kernel 1 met an all-zero block
+constexpr int WS_MINBITS_INV = 1; // max over non-zero blocks of ~bits(block max)
+constexpr int WS_BARRIER = 2;     // fix-up kernel grid barrier / exit ticket
+constexpr int WS_TIMEOUT = 3;     // a bounded spin gave up (reported by the next call)
+
+struct Lut {
+    unsigned a[LUT_N];  // bfp: ceil ; bm: floor ; bl: ceil
+    unsigned lo[LUT_N]; // bl: rnd_lo
+    unsigned hi[LUT_N]; // bl: rnd_hi
+};
+
+template <int FMT>
+__device__ __forceinline__ void load_lut(Lut& lut) {
+    for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
+        lut.a[i] = (FMT == FMT_BM) ? mi355q_log2_floor_thr[i] : mi355q_log2_ceil_thr[i];
+        if (FMT == FMT_BL) {
+            lut.lo[i] = mi355q_log2_rnd_lo[i];
+            lut.hi[i] = mi355q_log2_rnd_hi[i];
+        }
+    }
+    __syncthreads();
+}
+
+// v > 0 (finite or +inf): v = 2^k (1 + m 2^-23); subnormals normalised, inf -> k = 128, m = 0.
+__device__ __forceinline__ void split_pos(float v, int& k, unsigned& m) {
+    const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
+    const unsigned E = b >> 23, M = b & 0x7FFFFFu;
+    if (E == 0u) {
+        const int p = 31 - __clz((int)(M | 1u));
+        k = p - 149;
+        m = (M << (23 - p)) & 0x7FFFFFu;
+    } else {
+        k = (int)E - 127;
+        m = (E == 255u) ? 0u : M;
+    }
+}
+__device__ __forceinline__ int lut_index(int k) {
+    const int i = k + MI355Q_LOG2_K_OFFSET;
+    return i > LUT_N - 1 ? LUT_N - 1 : i;
+}
+__device__ __forceinline__ int ceil_log2(float v, const Lut& lut) {
+    int k; unsigned m;
+    split_pos(v, k, m);
+    return k + ((m != 0u && m >= lut.a[lut_index(k)]) ? 1 : 0);
+}
+__device__ __forceinline__ int floor_log2(float v, const Lut& lut) {
+    int k; unsigned m;
+    split_pos(v, k, m);
+    return k + ((k < 128 && m >= lut.a[lut_index(k)]) ? 1 : 0);
+}
+__device__ __forceinline__ int rint_log2(float v, const Lut& lut) {
+    int k; unsigned m;
+    split_pos(v, k, m);
+    if (k >= 128) return 128;
+    const int i = lut_index(k);
+    const int even = k + (k & 1);
+    return m < lut.lo[i] ? k : (m > lut.hi[i] ? k + 1 : even);
+}
+__device__ __forceinline__ float sgn(float t) { return t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+struct BlockParam {
+    int p;      // bfp: shared exponent e ; bm / bl: shared bias
+    float eps;  // bl: 0.1 * 2^-bias
+};
+
+// block max (> 0) -> block parameter and its stored byte
+template <int FMT>
+__device__ __forceinline__ BlockParam block_param(float bmax, const QuantArgs& a, const Lut& lut, unsigned& code) {
+    BlockParam bp;
+    bp.eps = 0.f;
+    if (FMT == FMT_BFP) {           // block_fp.py:72-73
+        bp.p = clampi(ceil_log2(bmax, lut), a.e_min, a.e_max);
+        code = (unsigned)(bp.p + a.code_bias);
+    } else if (FMT == FMT_BM) {     // block_minifloat.py:57-59
+        bp.p = clampi(floor_log2(bmax, lut), 0, a.bias_max);
+        code = (unsigned)bp.p;
+    } else {                        // block_log.py:55-58, log.py:45-48
+        bp.p = clampi(a.span - ceil_log2(bmax, lut), 0, a.bias_max);
+        bp.eps = __builtin_ldexpf(0.1f, -bp.p);
+        code = (unsigned)bp.p;
+    }
+    return bp;
+}
+
+// one element: returns the fake-quantised value, `mant` = signed integer mantissa (bfp only)
+template <int FMT>
+__device__ __forceinline__ float quant_elem(float x, const BlockParam& bp, const QuantArgs& a, const Lut& lut, int& mant) {
+    const float ax = fabsf(x);
+    if (FMT == FMT_BFP) {           // block_fp.py:69-82, 93-94
+        const float s = sgn(x + EPS9);
+        const float v = ax + EPS9;
+        const float r = __builtin_ldexpf(v, -bp.p) * a.shift;
+        const float m = clampf(__builtin_rintf(r), 0.f, a.mant_max);
+        mant = (int)(s * m);
+        const float q = __builtin_ldexpf(s, bp.p) * (m * a.inv_shift);
+        return ax <= ATOL ? x : q;
+    } else if (FMT == FMT_BM) {     // minifloat.py:165-194 with exponent_bias = bp.p
+        const float s = sgn(x + EPS9);
+        const int e_min = -bp.p, e_max = a.span - bp.p;
+        const int e = clampi(floor_log2(ax + EPS9, lut), e_min, e_max);
+        const float mn = __builtin_ldexpf(ax, -e);
+        const bool normal = e != e_min;
+        const float sm = normal ? clampf(__builtin_rintf(mn * a.shift - a.shift), 0.f, a.mant_max)
+                                : clampf(__builtin_rintf(mn * a.shift * 0.5f), 0.f, a.mant_max);
+        const float frac = normal ? (1.0f + sm * a.inv_shift) : (sm * a.inv_shift * 2.0f);
+        const float q = __builtin_ldexpf(s, e) * frac;
+        mant = 0;
+        return ax <= ATOL ? x : q;
+    } else {                        // log.py:47-56 with exponent_bias = bp.p
+        const float s = sgn(x + bp.eps);
+        const float v = ax + bp.eps;
+        const int e_min = -bp.p, e_max = a.span - bp.p;
+        const int r = v > 0.f ? rint_log2(v, lut) : e_min;
+        mant = 0;
+        return __builtin_ldexpf(s, clampi(r, e_min, e_max));
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// abs-max over the LPB adjacent lanes that hold one block
+template <int LPB>
+__device__ __forceinline__ float group_max(float v) {
+    if (LPB >= 2) v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+    if (LPB >= 4) v = fmaxf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int off = 4; off < LPB; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel 1, vector path: b0 == 1, cols % b1 == 0, b1 = 4 * LPB, 16-byte aligned x / y.
+// Flat over all elements: float4 slot i belongs to block i / LPB.
+// ---------------------------------------------------------------------------------------
+template <int FMT, int LPB>
+__global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
+    __shared__ Lut lut;
+    load_lut<FMT>(lut);
+    const long long n4 = a.n_elems >> 2;
+    const long long n4_pad = (n4 + 63) & ~63ll;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
+    float4* __restrict__ y4 = reinterpret_cast<float4*>(a.y);
+    unsigned* __restrict__ m4 = reinterpret_cast<unsigned*>(a.mant);
+    const bool exact = (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u;
+    bool saw_zero = false;
+
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4_pad; i += stride) {
+        const bool valid = i < n4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = x4[i];
+        float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        bmax = group_max<LPB>(bmax);
+        if (bmax == 0.f) {          // all-zero block: provisional fill 1.0 (what an all-zero tensor gets)
+            saw_zero = saw_zero || valid;
+            bmax = 1.0f;
+        }
+        unsigned code;
+        const BlockParam bp = block_param<FMT>(bmax, a, lut, code);
+        int q0, q1, q2, q3;
+        float4 o;
+        o.x = quant_elem<FMT>(v.x, bp, a, lut, q0);
+        o.y = quant_elem<FMT>(v.y, bp, a, lut, q1);
+        o.z = quant_elem<FMT>(v.z, bp, a, lut, q2);
+        o.w = quant_elem<FMT>(v.w, bp, a, lut, q3);
+        if (valid) {
+            if (a.y) y4[i] = o;
+            if (FMT == FMT_BFP && a.mant)
+                m4[i] = (unsigned)(q0 & 0xFF) | ((unsigned)(q1 & 0xFF) << 8) | ((unsigned)(q2 & 0xFF) << 16) |
+                        ((unsigned)(q3 & 0xFF) << 24);
+            if (a.code && (i & (LPB - 1)) == 0) a.code[i / LPB] = (uint8_t)code;
+        }
+    }
+    if (exact && saw_zero) a.ws[WS_ZERO_FLAG] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------
+// generic block walker: a 16-lane group owns one b0 x b1 block at a time (any layout).
+// ---------------------------------------------------------------------------------------
+struct BlockCursor {
+    long long base;   // element offset of the block's (0,0)
+    int h, w;         // valid rows / cols of this (possibly ragged) block
+};
+__device__ __forceinline__ BlockCursor locate(const QuantArgs& a, long long bid) {
+    const long long per_plane = a.nbr * a.nbc;
+    const long long l = bid / per_plane, r = bid - l * per_plane;
+    const long long br = r / a.nbc, bc = r - br * a.nbc;
+    BlockCursor c;
+    const long long r0 = br * a.b0, c0 = bc * a.b1;
+    c.base = (l * a.rows + r0) * a.cols + c0;
+    c.h = (int)((a.rows - r0) < a.b0 ? (a.rows - r0) : a.b0);
+    c.w = (int)((a.cols - c0) < a.b1 ? (a.cols - c0) : a.b1);
+    return c;
+}
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ float block_absmax16(const QuantArgs& a, const BlockCursor& c, int lane16) {
+    float m = 0.f;
+    const int n = c.h * c.w;
+    for (int i = lane16; i < n; i += 16) {
+        const int ii = i / c.w, jj = i - ii * c.w;
+        m = fmaxf(m, fabsf(a.x[c.base + (long long)ii * a.cols + jj]));
+    }
+    return group16_max(m);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void quant_generic_kernel(const QuantArgs a) {
+    __shared__ Lut lut;
+    load_lut<FMT>(lut);
+    const int lane16 = threadIdx.x & 15;
+    const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const bool exact = (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u;
+    bool saw_zero = false;
+    // every lane of a group runs the same trip count (bid is group-uniform)
+    for (long long bid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; bid < a.n_blocks; bid += groups) {
+        const BlockCursor c = locate(a, bid);
+        float bmax = block_absmax16(a, c, lane16);
+        if (bmax == 0.f) { saw_zero = true; bmax = 1.0f; }
+        unsigned code;
+        const BlockParam bp = block_param<FMT>(bmax, a, lut, code);
+        const int n = c.h * c.w;
+        for (int i = lane16; i < n; i += 16) {
+            const int ii = i / c.w, jj = i - ii * c.w;
+            const long long at = c.base + (long long)ii * a.cols + jj;
+            int q;
+            const float o = quant_elem<FMT>(a.x[at], bp, a, lut, q);
+            if (a.y) a.y[at] = o;
+            if (FMT == FMT_BFP && a.mant) a.mant[at] = (int8_t)q;
+        }
+        if (a.code && lane16 == 0) a.code[bid] = (uint8_t)code;
+    }
+    if (exact && saw_zero) a.ws[WS_ZERO_FLAG] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel 2: all-zero blocks take the tensor-global fill.  Returns at once when kernel 1 met
+// none.  Otherwise phase A = min over non-zero block maxes, grid barrier, phase B = rewrite the
+// zero blocks.  Grid is FIXUP_GRID workgroups (<= 1 per CU, co-resident); every spin is bounded.
+// ---------------------------------------------------------------------------------------
+constexpr int FIXUP_GRID = 128;
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
+    __shared__ Lut lut;
+    __shared__ unsigned s_red;
+    if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) return;    // uniform over the grid
+    load_lut<FMT>(lut);
+    if (threadIdx.x == 0) s_red = 0u;
+    __syncthreads();
+    const int lane16 = threadIdx.x & 15;
+    const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+
+    // phase A
+    unsigned inv = 0u;
+    for (long long bid = g0; bid < a.n_blocks; bid += groups) {
+        const float bmax = block_absmax16(a, locate(a, bid), lane16);
+        if (bmax != 0.f) { const unsigned v = ~__float_as_uint(bmax); inv = v > inv ? v : inv; }
+    }
+    atomicMax(&s_red, inv);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_max(&a.ws[WS_MINBITS_INV], s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&a.ws[WS_BARRIER], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (ld_agent(&a.ws[WS_BARRIER]) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) { a.ws[WS_TIMEOUT] = 1u; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const unsigned inv_all = ld_agent(&a.ws[WS_MINBITS_INV]);
+    const float fill = inv_all == 0u ? 1.0f : __uint_as_float(~inv_all);   // all blocks zero -> 1
+    unsigned code;
+    const BlockParam bp = block_param<FMT>(fill, a, lut, code);
+
+    // phase B
+    for (long long bid = g0; bid < a.n_blocks; bid += groups) {
+        const BlockCursor c = locate(a, bid);
+        if (block_absmax16(a, c, lane16) != 0.f) continue;
+        const int n = c.h * c.w;
+        for (int i = lane16; i < n; i += 16) {
+            const int ii = i / c.w, jj = i - ii * c.w;
+            const long long at = c.base + (long long)ii * a.cols + jj;
+            int q;
+            const float o = quant_elem<FMT>(a.x[at], bp, a, lut, q);
+            if (a.y) a.y[at] = o;
+            if (FMT == FMT_BFP && a.mant) a.mant[at] = (int8_t)q;
+        }
+        if (a.code && lane16 == 0) a.code[bid] = (uint8_t)code;
+    }
+    // exit ticket: the last workgroup out restores the workspace to zero for the next call
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(&a.ws[WS_BARRIER], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 2u * gridDim.x - 1u) {
+            __hip_atomic_store(&a.ws[WS_MINBITS_INV], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.ws[WS_BARRIER], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.ws[WS_ZERO_FLAG], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// integer fixed point (integer.py:49-52): clamp(rint(x * 2^f), lo, hi) / 2^f
+__global__ __launch_bounds__(256) void integer_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      long long n, float scale, float lo, float hi) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = clampf(__builtin_rintf(x[i] * scale), lo, hi) / scale;
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static int grid_for(long long work_items, int per_block) {
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;     // 256 CUs x 8 blocks, grid-stride beyond (guide: Guideline 11)
+    return (int)g;
+}
+
+template <int FMT>
+static int launch_format(const QuantArgs& a, bool needs_fixup, hipStream_t st) {
+    const bool vec_ok = a.b0 == 1 && (a.cols % a.b1) == 0 && (a.b1 % 4) == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.x) % 16) == 0 &&
+                        (a.y == nullptr || reinterpret_cast<uintptr_t>(a.y) % 16 == 0) &&
+                        (a.mant == nullptr || reinterpret_cast<uintptr_t>(a.mant) % 4 == 0);
+    const int lpb = a.b1 / 4;
+    if (vec_ok && (lpb == 1 || lpb == 2 || lpb == 4 || lpb == 8 || lpb == 16 || lpb == 32 || lpb == 64)) {
+        const int grid = grid_for(a.n_elems >> 2, 256);
+        switch (lpb) {
+            case 1: hipLaunchKernelGGL((quant_vec_kernel<FMT, 1>), grid, 256, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((quant_vec_kernel<FMT, 2>), grid, 256, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((quant_vec_kernel<FMT, 4>), grid, 256, 0, st, a); break;
+            case 8: hipLaunchKernelGGL((quant_vec_kernel<FMT, 8>), grid, 256, 0, st, a); break;
+            case 16: hipLaunchKernelGGL((quant_vec_kernel<FMT, 16>), grid, 256, 0, st, a); break;
+            case 32: hipLaunchKernelGGL((quant_vec_kernel<FMT, 32>), grid, 256, 0, st, a); break;
+            default: hipLaunchKernelGGL((quant_vec_kernel<FMT, 64>), grid, 256, 0, st, a); break;
+        }
+    } else {
+        const int grid = grid_for(a.n_blocks, 16);
+        hipLaunchKernelGGL((quant_generic_kernel<FMT>), grid, 256, 0, st, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (needs_fixup && (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u) {
+        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), FIXUP_GRID, 256, 0, st, a);
+        e = hipGetLastError();
+    }
+    return (int)e;
+}
+
+int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st) {
+    switch (fmt) {
+        case FMT_BFP: return launch_format<FMT_BFP>(a, needs_fixup, st);
+        case FMT_BM: return launch_format<FMT_BM>(a, needs_fixup, st);
+        default: return launch_format<FMT_BL>(a, needs_fixup, st);
+    }
+}
+
+int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st) {
+    hipLaunchKernelGGL(integer_kernel, grid_for(n, 256), 256, 0, st, x, y, n, scale, lo, hi);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mi355q

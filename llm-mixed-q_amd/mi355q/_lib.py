@@ -1,0 +1,62 @@
+"""ctypes binding of include/mi355q.h.  This file is the reference-side FFI stub a maintainer
+would add: plain pointers and sizes in, int status out."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+# name -> (restype, argtypes); must list every symbol include/mi355q.h declares
+_i32, _i64, _u32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_void_p
+SIGNATURES = {
+    "mi355q_abi_version": (C.c_int, []),
+    "mi355q_error_string": (C.c_char_p, [C.c_int]),
+    "mi355q_block_fp_quantize": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                           _i32, _i32, _i32, _u32, _vp, _vp]),
+    "mi355q_block_minifloat_quantize": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                                  _i32, _i32, _i32, _u32, _vp, _vp]),
+    "mi355q_block_log_quantize": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                            _i32, _i32, _u32, _vp, _vp]),
+    "mi355q_integer_quantize": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mi355q_bfp_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                  _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_bfp_gemm_set_variant": (C.c_int, [C.c_int]),
+}
+ABI_VERSION = 1
+WORKSPACE_BYTES = 256
+ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("MI355Q_LIBRARY", _HERE / "libmi355q.so"))
+
+
+def load_library() -> C.CDLL:
+    """Load libmi355q.so (built by `make -C llm-mixed-q_amd/csrc` or __graft_entry__.build()).
+    Raises -- never falls back -- when the library is missing or its ABI version differs."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise RuntimeError(
+            f"mi355q: HIP library not found at {path}. Build it with "
+            "`make -C llm-mixed-q_amd/csrc` (hipcc --offload-arch=gfx950); there is no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    got = lib.mi355q_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"mi355q: ABI version mismatch (library {got}, binding {ABI_VERSION})")
+    _LIB = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load_library().mi355q_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

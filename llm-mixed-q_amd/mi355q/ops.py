@@ -1,0 +1,189 @@
+"""Tensor-level entry points over the C ABI: shape resolution on the host, pointers and sizes
+to the library, current HIP stream.  torch is plumbing here (device memory, streams)."""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+
+from . import _lib
+
+_WORKSPACES: dict = {}
+
+
+# ---------------------------------------------------------------------------------------
+# host logic: the reference's block-shape rules (quantizers/utils.py:42-83, 261-284)
+# ---------------------------------------------------------------------------------------
+def _fit_block(shape: Sequence[int], block: Sequence[int]) -> list[int]:
+    nd = len(shape)
+    blk = list(block)[-nd:] if len(block) >= nd else [-1] * (nd - len(block)) + list(block)
+    return [shape[i] if blk[i] == -1 or blk[i] > shape[i] else blk[i] for i in range(nd)]
+
+
+def resolve_blocking(shape: Sequence[int], block_size, skip_first_dim: bool):
+    """-> (lead, rows, cols, b0, b1): `lead` planes of rows x cols tiled by b0 x b1 blocks.
+    Raises exactly where the reference's block() does (utils.py:267-284)."""
+    if isinstance(block_size, int):
+        block_size = [block_size]
+    block_size = [int(b) for b in block_size]
+    shape = [int(s) for s in shape]
+    nd = len(shape)
+    if nd == 1:
+        assert skip_first_dim is False, "skip_first_dim must be False for bias to be blocked"
+        (b,) = _fit_block(shape, block_size)
+        return 1, 1, shape[0], 1, b
+    if nd == 2:
+        if skip_first_dim:
+            b = _fit_block([1, shape[1]], block_size)
+            return 1, shape[0], shape[1], 1, b[1]
+        b = _fit_block(shape, block_size)
+        return 1, shape[0], shape[1], b[0], b[1]
+    if nd == 3:
+        if not skip_first_dim:
+            raise NotImplementedError("block 3d weight is not supported.")
+        b = _fit_block([1, shape[1], shape[2]], block_size)
+        return shape[0], shape[1], shape[2], b[1], b[2]
+    raise RuntimeError(f"Unsupported x.ndim = {nd}")
+
+
+def n_blocks(lead: int, rows: int, cols: int, b0: int, b1: int) -> int:
+    return lead * math.ceil(rows / b0) * math.ceil(cols / b1)
+
+
+# ---------------------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------------------
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"mi355q.{what}: tensor is on '{t.device}'. The block-quantised path runs only as HIP "
+            "kernels on an MI355X; there is no CPU fallback.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"mi355q.{what}: fp32 tensors only (got {t.dtype}); the reference's BASELINE "
+                        "configs are fp32 (SURVEY 8a quirk 11)")
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(device) -> torch.Tensor:
+    key = (device.index, _stream_ptr(device))
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.zeros(_lib.WORKSPACE_BYTES // 4, dtype=torch.int32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _default_bias(exponent_bias) -> int:
+    return -1 if exponent_bias in (None, "none", "None") else int(exponent_bias)
+
+
+# ---------------------------------------------------------------------------------------
+# quantisers
+# ---------------------------------------------------------------------------------------
+def block_fp_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, block_size,
+                      skip_first_dim: bool, *, want_fake: bool = True, want_packed: bool = False,
+                      fast_zero_blocks: bool = False):
+    """Returns y, or (y_or_None, mant int8 like x, exp uint8 [n_blocks]) when want_packed."""
+    _require_device(x, "block_fp_quantize")
+    lead, rows, cols, b0, b1 = resolve_blocking(x.shape, block_size, skip_first_dim)
+    xc = x.contiguous()
+    y = torch.empty_like(xc) if want_fake else None
+    mant = torch.empty(xc.shape, dtype=torch.int8, device=x.device) if want_packed else None
+    exp = (torch.empty(n_blocks(lead, rows, cols, b0, b1), dtype=torch.uint8, device=x.device)
+           if want_packed else None)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_block_fp_quantize(
+            _ptr(xc), _ptr(y), _ptr(mant), _ptr(exp), lead, rows, cols, b0, b1, int(width),
+            int(exponent_width), _default_bias(exponent_bias),
+            _lib.ZERO_BLOCK_FAST if fast_zero_blocks else _lib.ZERO_BLOCK_EXACT,
+            _ptr(_workspace(x.device)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_fp_quantize")
+    return (y, mant, exp) if want_packed else y
+
+
+def block_minifloat_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent_bias_width: int,
+                             block_size, skip_first_dim: bool, *, want_bias: bool = False):
+    _require_device(x, "block_minifloat_quantize")
+    lead, rows, cols, b0, b1 = resolve_blocking(x.shape, block_size, skip_first_dim)
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    bias = (torch.empty(n_blocks(lead, rows, cols, b0, b1), dtype=torch.uint8, device=x.device)
+            if want_bias else None)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_block_minifloat_quantize(
+            _ptr(xc), _ptr(y), _ptr(bias), lead, rows, cols, b0, b1, int(width), int(exponent_width),
+            int(exponent_bias_width), _lib.ZERO_BLOCK_EXACT, _ptr(_workspace(x.device)),
+            _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_minifloat_quantize")
+    return (y, bias) if want_bias else y
+
+
+def block_log_quantize(x: torch.Tensor, width: int, exponent_bias_width: int, block_size,
+                       skip_first_dim: bool, *, want_bias: bool = False):
+    _require_device(x, "block_log_quantize")
+    lead, rows, cols, b0, b1 = resolve_blocking(x.shape, block_size, skip_first_dim)
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    bias = (torch.empty(n_blocks(lead, rows, cols, b0, b1), dtype=torch.uint8, device=x.device)
+            if want_bias else None)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_block_log_quantize(
+            _ptr(xc), _ptr(y), _ptr(bias), lead, rows, cols, b0, b1, int(width),
+            int(exponent_bias_width), _lib.ZERO_BLOCK_EXACT, _ptr(_workspace(x.device)),
+            _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_log_quantize")
+    return (y, bias) if want_bias else y
+
+
+def integer_quantize(x: torch.Tensor, width: int, frac_width: int, is_signed: bool = True) -> torch.Tensor:
+    _require_device(x, "integer_quantize")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_integer_quantize(_ptr(xc), _ptr(y), xc.numel(), int(width), int(frac_width),
+                                         int(bool(is_signed)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_integer_quantize")
+    return y
+
+
+# ---------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------
+def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Tensor, bias,
+             x_mbits: int, x_exp_bias: int, w_mbits: int, w_exp_bias: int, out: torch.Tensor = None):
+    """y[M,N] = block-fp product of packed x [M,K] and packed w [N,K] (+ bias).  `out` may be a
+    column slice view of a wider row-major buffer (its stride(0) becomes ldy)."""
+    if not (xm.is_cuda and wm.is_cuda):
+        raise RuntimeError("mi355q.bfp_gemm: operands must be on a HIP device; there is no CPU fallback")
+    M, K = xm.shape
+    N = wm.shape[0]
+    assert wm.shape[1] == K and xm.dtype == torch.int8 and wm.dtype == torch.int8
+    assert xe.numel() == M * (K // 16) and we.numel() == N * (K // 16)
+    assert xm.is_contiguous() and wm.is_contiguous() and xe.is_contiguous() and we.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=xm.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    lib = _lib.load_library()
+    with torch.cuda.device(xm.device):
+        rc = lib.mi355q_bfp_gemm(_ptr(xm), _ptr(xe), _ptr(wm), _ptr(we), _ptr(bias), _ptr(out), M, N, K, ldy,
+                                 int(x_mbits), int(x_exp_bias), int(w_mbits), int(w_exp_bias),
+                                 _stream_ptr(xm.device))
+    _lib.check(rc, "mi355q_bfp_gemm")
+    return out
+
+
+def set_gemm_variant(variant: int) -> int:
+    return _lib.load_library().mi355q_bfp_gemm_set_variant(int(variant))

@@ -1,0 +1,99 @@
+"""GPU parity of the block-fp int8-MFMA GEMM (through the C ABI) against the oracle's exact
+integer contraction and against an fp32 GEMM on the fake-quantised operands (the reference's
+F.linear semantics).  Tolerance: BASELINE.json north_star, <= 1e-3 on the dequantised result
+(relative to the output scale); the integer block dots themselves are exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CFG6 = dict(name="block_fp", data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+            data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+            weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127,
+            bias_block_size=[16])
+
+
+def _cfg(wx, ww):
+    c = dict(CFG6)
+    c["data_in_width"], c["weight_width"] = wx, ww
+    return c
+
+
+def _inputs(M, N, K, seed, style):
+    r = np.random.default_rng(seed)
+    x = r.normal(size=(M, K)).astype(np.float32)
+    w = (r.normal(size=(N, K)) * 0.02).astype(np.float32)
+    b = (r.normal(size=(N,)) * 0.02).astype(np.float32)
+    if style == "rowscale":
+        x *= np.exp(r.normal(size=(M, 1))).astype(np.float32)
+    elif style == "outlier":                 # neighbouring K-blocks with far-apart exponents
+        x[:, ::53] *= 200.0
+        w[::7, 5::41] *= 64.0
+    elif style == "sparse":
+        x[r.random((M, K)) < 0.6] = 0
+        x[:, 32:80] = 0
+    return x, w, b
+
+
+def _run(x, w, b, cfg):
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    xt, wt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    _, xm, xe = ops.block_fp_quantize(xt, cfg["data_in_width"], 8, 127, [1, 16], True,
+                                      want_fake=False, want_packed=True, fast_zero_blocks=True)
+    _, wm, we = ops.block_fp_quantize(wt, cfg["weight_width"], 8, 127, [1, 16], False,
+                                      want_fake=False, want_packed=True, fast_zero_blocks=True)
+    bq = None
+    if b is not None:
+        bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), cfg["bias_width"], 8, 127, [16], False)
+    y = ops.bfp_gemm(xm, xe, wm, we, bq, cfg["data_in_width"] - 1, 127, cfg["weight_width"] - 1, 127)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (100, 72, 48), (1, 16, 16), (300, 130, 1024)])
+@pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
+@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
+def test_gemm_vs_oracle(M, N, K, style, wx, ww):
+    from oracle import np_oracle as O
+    x, w, b = _inputs(M, N, K, 1000 + M + N + K, style)
+    cfg = _cfg(wx, ww)
+    y = _run(x, w, b, cfg)
+    ref = O.bfp_linear_int(x, w, b, cfg)
+    scale = np.abs(ref).max() + 1e-30
+    # fp32 accumulation over K/16 block products: a few ulp of the output scale
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
+
+
+def test_gemm_no_bias_and_column_slice():
+    """ldy > N: a rank writes its column slice of a wider output (row-sharded linear)"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    x, w, _ = _inputs(64, 96, 128, 77, "rowscale")
+    cfg = _cfg(6, 6)
+    dev = torch.device("cuda:0")
+    _, xm, xe = ops.block_fp_quantize(torch.from_numpy(x).to(dev), 6, 8, 127, [1, 16], True, want_fake=False, want_packed=True)
+    full = torch.full((64, 96), float("nan"), device=dev)
+    for lo, hi in ((0, 48), (48, 96)):
+        _, wm, we = ops.block_fp_quantize(torch.from_numpy(w[lo:hi].copy()).to(dev), 6, 8, 127, [1, 16], False,
+                                          want_fake=False, want_packed=True)
+        ops.bfp_gemm(xm, xe, wm, we, None, 5, 127, 5, 127, out=full[:, lo:hi])
+    ref = O.bfp_linear_int(x, w, None, cfg)
+    np.testing.assert_allclose(full.cpu().numpy(), ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+
+
+def test_gemm_matches_reference_semantics_fp32_linear():
+    """F.linear on the fake-quantised operands (what the reference computes), tolerance 1e-3"""
+    import torch
+    from mi355q import ops
+    x, w, b = _inputs(512, 512, 2048, 9, "rowscale")
+    cfg = _cfg(6, 6)
+    y = _run(x, w, b, cfg)
+    dev = torch.device("cuda:0")
+    xq = ops.block_fp_quantize(torch.from_numpy(x).to(dev), 6, 8, 127, [1, 16], True)
+    wq = ops.block_fp_quantize(torch.from_numpy(w).to(dev), 6, 8, 127, [1, 16], False)
+    bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), 6, 8, 127, [16], False)
+    ref = (xq.double() @ wq.double().T + bq.double()).float().cpu().numpy()
+    np.testing.assert_allclose(y, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())

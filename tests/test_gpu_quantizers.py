@@ -1,0 +1,124 @@
+"""GPU parity, through the C ABI (ctypes -> libmi355q.so): HIP quantisers vs the golden vectors
+captured from the reference and vs the numpy oracle.  Bit-exact on every integer and on the
+fake-quantised fp32 values."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+_META = json.loads((GOLDEN / "quantizers.json").read_text())
+
+
+def _dev():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def _blocks_view(arr, shape, block_size, skip):
+    """tensor-shaped per-element array -> oracle block order [n_blocks, block_elems]"""
+    from oracle import np_oracle as O
+    meta = O.block_meta(shape, block_size, skip)
+    return O.to_blocks(np.asarray(arr, dtype=np.float32), meta)
+
+
+@pytest.mark.parametrize("tag", sorted(_META))
+def test_quantizer_golden(tag, golden_quantizers):
+    import torch
+    from mi355q import ops
+    meta, data = golden_quantizers
+    m = meta[tag]
+    p, skip = dict(m["params"]), m["skip_first_dim"]
+    x = torch.from_numpy(data[f"{tag}/x"]).to(_dev())
+    y_ref = data[f"{tag}/y"]
+    if m["quantizer"] == "block_fp":
+        y, mant, exp = ops.block_fp_quantize(x, p["width"], p["exponent_width"], p["exponent_bias"],
+                                             p["block_size"], skip, want_packed=True)
+        torch.cuda.synchronize()
+        assert _same(y.cpu().numpy(), y_ref), f"fake-quant differs, max {np.nanmax(np.abs(y.cpu().numpy() - y_ref))}"
+        bias = 2 ** (p["exponent_width"] - 1) - 1 if p["exponent_bias"] is None else p["exponent_bias"]
+        assert _same(exp.cpu().numpy().astype(np.int32) - bias, data[f"{tag}/exp"]), "shared exponents differ"
+        got = _blocks_view(mant.cpu().numpy(), x.shape, p["block_size"], skip).astype(np.int32)
+        ref = data[f"{tag}/mant"].astype(np.int32)
+        # padded tail elements of ragged blocks exist only in the reference's padded copy
+        pad = _blocks_view(np.ones(x.shape, np.float32), x.shape, p["block_size"], skip) == 0
+        assert _same(got[~pad], ref[~pad]), "mantissas differ"
+        # y-only call takes the single-launch path and must agree
+        y2 = ops.block_fp_quantize(x, p["width"], p["exponent_width"], p["exponent_bias"], p["block_size"], skip)
+        assert _same(y2.cpu().numpy(), y_ref)
+    elif m["quantizer"] == "block_minifloat":
+        y, bias = ops.block_minifloat_quantize(x, p["width"], p["exponent_width"], p["exponent_bias_width"],
+                                               p["block_size"], skip, want_bias=True)
+        assert _same(y.cpu().numpy(), y_ref), f"max {np.nanmax(np.abs(y.cpu().numpy() - y_ref))}"
+        assert _same(bias.cpu().numpy().astype(np.int32), data[f"{tag}/bias"])
+    else:
+        y, bias = ops.block_log_quantize(x, p["width"], p["exponent_bias_width"], p["block_size"], skip,
+                                         want_bias=True)
+        assert _same(y.cpu().numpy(), y_ref), f"max {np.nanmax(np.abs(y.cpu().numpy() - y_ref))}"
+        assert _same(bias.cpu().numpy().astype(np.int32), data[f"{tag}/bias"])
+
+
+@pytest.mark.parametrize("shape,style", [((64, 4096), "rowscale"), ((2, 33, 1024), "outlier"), ((257, 768), "sparse")])
+@pytest.mark.parametrize("fmt", ["bfp6", "bfp4", "bfp8", "bm", "bl"])
+def test_quantizer_vs_oracle_medium(shape, style, fmt):
+    """sizes the oracle finishes in seconds; seeded inputs; all three formats"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    r = np.random.default_rng(hash((shape, style, fmt)) % 2 ** 31)
+    x = r.normal(size=shape).astype(np.float32)
+    if style == "rowscale":
+        x *= np.exp(2 * r.normal(size=shape[:-1] + (1,))).astype(np.float32)
+    elif style == "outlier":
+        x[..., ::97] *= 50
+    else:
+        x[r.random(shape) < 0.5] = 0
+        x.reshape(-1)[: 16 * 40] = 0
+    xt = torch.from_numpy(x).to(_dev())
+    if fmt.startswith("bfp"):
+        w = int(fmt[3:])
+        y, mant, exp = ops.block_fp_quantize(xt, w, 8, 127, [1, 16], True, want_packed=True)
+        code = O.bfp_encode(x, w, 8, 127, [1, 16], True)
+        assert _same(exp.cpu().numpy().astype(np.int32) - 127, code.exp)
+        assert _same(mant.cpu().numpy().reshape(-1, 16).astype(np.int32), code.mant)
+        assert _same(y.cpu().numpy(), O.block_fp_quantize(x, w, 8, 127, [1, 16], True))
+    elif fmt == "bm":
+        xs = x * 37
+        y = ops.block_minifloat_quantize(torch.from_numpy(xs).to(_dev()), 8, 4, 8, [1, 16], True)
+        assert _same(y.cpu().numpy(), O.block_minifloat_quantize(xs, 8, 4, 8, [1, 16], True))
+    else:
+        y = ops.block_log_quantize(xt, 8, 8, [1, 16], True)
+        assert _same(y.cpu().numpy(), O.block_log_quantize(x, 8, 8, [1, 16], True))
+
+
+def test_fast_zero_block_mode_only_touches_zero_blocks():
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    r = np.random.default_rng(5)
+    x = r.normal(size=(32, 256)).astype(np.float32) * 1e-3
+    x[3, 32:64] = 0
+    x[9, :] = 0
+    xt = torch.from_numpy(x).to(_dev())
+    y, mant, exp = ops.block_fp_quantize(xt, 6, 8, 127, [1, 16], True, want_packed=True, fast_zero_blocks=True)
+    code = O.bfp_encode(x, 6, 8, 127, [1, 16], True)
+    zero = np.abs(x).reshape(-1, 16).max(1) == 0
+    e = exp.cpu().numpy().astype(np.int32) - 127
+    assert _same(e[~zero], code.exp[~zero]) and np.all(e[zero] == 0)
+    mg = mant.cpu().numpy().reshape(-1, 16).astype(np.int32)
+    assert _same(mg[~zero], code.mant[~zero]) and np.all(mg[zero] == 0)
+    assert _same(y.cpu().numpy(), O.block_fp_quantize(x, 6, 8, 127, [1, 16], True))
+
+
+def test_cpu_tensor_is_refused():
+    import torch
+    from mi355q import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.block_fp_quantize(torch.zeros(4, 16), 6, 8, 127, [1, 16], True)
