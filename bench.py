@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the block-quantised linear path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 4096 x 4096 x 4096 block_fp W6A6,
+block [1,16]; x = randn(seed 0) * exp(randn(M,1, seed 1)), w = randn(seed 2) * 0.02,
+b = randn(seed 3) * 0.02, fp32, resident in HBM before the timed region.
+One step = the steady-state PTQ LinearBlockFP forward (reference quantized_modules/linear.py:63-71
+after the first call): dynamic activation quantise+pack -> int8-MFMA block GEMM against
+pre-packed weights -> fp32 y (+bias).  FLOPs = 2*M*N*K per step.
+
+N > 1: one process per GPU; rows of x (tokens) are the independent units, each rank runs the same
+step on its own 4096 rows with replicated packed weights -- no data-path collective (weak
+scaling).  `--shard out_features` instead times the row-sharded GEMM + RCCL all-gather.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "llm-mixed-q_amd"))
+sys.path.insert(0, str(ROOT))
+
+M = N = K = 4096
+CFG = dict(name="block_fp", is_ptq=True, bypass=False,
+           data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127, data_in_block_size=[1, 16],
+           weight_width=6, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
+           bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+INT8_DENSE_PEAK_TFLOPS = 5000.0   # MI355X_MICROARCH.md: I8 MFMA = 2x the ~2.5 PF dense bf16 rate
+
+
+def make_inputs(torch, device, rank):
+    g = lambda s: torch.Generator().manual_seed(s)
+    x = torch.randn(M, K, generator=g(0 + 1000 * rank)) * torch.exp(torch.randn(M, 1, generator=g(1 + 1000 * rank)))
+    w = torch.randn(N, K, generator=g(2)) * 0.02
+    b = torch.randn(N, generator=g(3)) * 0.02
+    return x.to(device), w.to(device), b.to(device)
+
+
+def cpu_baseline(torch):
+    """The reference's CPU fake-quant path (torch-op-order port, oracle/torch_port.py) on this
+    box's host cores, bounded to ~10-20 s: steady-state PTQ linear at the full 4096^3 size."""
+    from oracle import torch_port as P
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x, w, b = make_inputs(torch, "cpu", 0)
+    wq = P.block_fp_quantize(w, 6, 8, 127, [1, 16], False)
+    bq = P.block_fp_quantize(b, 6, 8, 127, [16], False)
+    t0 = time.perf_counter()
+    P.linear_ptq_step(x, wq, bq, CFG)
+    first = time.perf_counter() - t0
+    iters = max(2, min(10, int(12.0 / max(first, 1e-3))))
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        P.linear_ptq_step(x, wq, bq, CFG)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(2.0 * M * N * K / med / 1e12, 4), "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": round(med * 1e3, 2),
+            "sample": f"full 4096x4096x4096 steady-state PTQ linear (fake-quant x + fp32 F.linear), median of {iters} iterations"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--shard", choices=["tokens", "out_features"], default="tokens")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="GEMM kernel variant (0 = automatic)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mi355q import ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the block-quantised path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    if args.variant:
+        ops.set_gemm_variant(args.variant)
+
+    x, w, b = make_inputs(torch, device, rank if args.shard == "tokens" else 0)
+    xw, ww = CFG["data_in_width"], CFG["weight_width"]
+    if args.shard == "out_features" and world > 1:
+        n_loc = N // world
+        w, b = w[rank * n_loc:(rank + 1) * n_loc].contiguous(), b[rank * n_loc:(rank + 1) * n_loc].contiguous()
+    # one-off weight / bias packing (first PTQ forward in the reference), not timed
+    _, wm, we = ops.block_fp_quantize(w, ww, 8, 127, [1, 16], False, want_fake=False, want_packed=True,
+                                      fast_zero_blocks=True)
+    bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
+    n_out = w.shape[0]
+    y = torch.empty(M, n_out, dtype=torch.float32, device=device)
+    gathered = torch.empty(world, M, n_out, dtype=torch.float32, device=device) if (args.shard == "out_features" and world > 1) else None
+
+    gemm_events = []
+
+    def step(record=False):
+        _, xm, xe = ops.block_fp_quantize(x, xw, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
+                                          fast_zero_blocks=True)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ops.bfp_gemm(xm, xe, wm, we, bq, xw - 1, 127, ww - 1, 127, out=y)
+        if record:
+            e1.record()
+            gemm_events.append((e0, e1))
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, y)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    gemm_ms = sorted(e0.elapsed_time(e1) for e0, e1 in gemm_events)
+    gemm_avg_ms = sum(gemm_ms) / len(gemm_ms)
+    flops_step = 2.0 * M * n_out * K
+    total_flops = flops_step * args.steps * world
+    value = total_flops / dt / 1e12
+
+    if rank == 0:
+        achieved = flops_step / (gemm_avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "quantised-GEMM TFLOP/s (4096^2, block=16, W6A6 BFP)",
+            "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak" if args.shard == "tokens" else "strong", "vs_baseline": None,
+            "dtype": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 block scaling",
+            "data": "synthetic",
+            "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> quantise+pack (W6, block [1,16]) "
+                                   "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32",
+                       "M_per_gpu": M, "N": N, "K": K, "shard": args.shard,
+                       "gemm_variant": ops.set_gemm_variant(args.variant)},
+            "roofline": {"bound": "mfma", "kernel": "bfp_gemm", "achieved": round(achieved, 2),
+                         "peak": INT8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / INT8_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(gemm_avg_ms, 4), "median_launch_ms": round(gemm_ms[len(gemm_ms) // 2], 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(torch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

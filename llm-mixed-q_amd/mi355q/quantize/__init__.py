@@ -1,0 +1,20 @@
+"""Drop-in for the reference's `llm_mixed_q.models.quantize` package (its `__init__.py:1-21`):
+the three registries and their getters, the config parser and the layer profiler."""
+from .quant_config_parser import parse_node_config
+from .quantized_functions import QUANTIZED_FUNC_MAP
+from .quantized_layer_profiler import (profile_linear_layer, profile_matmul_layer, register_a_stat_hook,
+                                       update_profile)
+from .quantized_modules import QUANTIZED_MODULE_MAP
+from .quantizers import QUANTIZER_MAP
+
+
+def get_quantized_cls(op: str, config: dict):
+    return QUANTIZED_MODULE_MAP[op][config["name"]]
+
+
+def get_quantized_func(op: str, config: dict):
+    return QUANTIZED_FUNC_MAP[op][config["name"]]
+
+
+def get_quantizer(op: str, config: dict):
+    return QUANTIZER_MAP[config["name"]]

@@ -1,0 +1,116 @@
+"""Quantised matmul / bmm / rotary-embedding functions, `f(x, y, config)` and
+`f(q, k, cos, sin, position_ids, config)` (reference quantized_functions/matmul.py:146-353,
+rotary_positional_encoding.py:59-248; registry keys as quantized_functions/__init__.py:14-42).
+
+Each operand is quantised along ITS OWN last dimension (matmul.py:166-195), so only x is blocked
+along the contraction: these products are not int8 block dots.  The operands go
+through the HIP fake-quant kernels and the contraction through the GPU's fp32 GEMM on exactly
+representable values.  Reference quirks kept: "log" maps to the block_log functions
+(__init__.py:20,29); block_log leaves y unquantised (matmul.py:278-297); the block_fp rotary
+function ignores `bypass` (rotary_positional_encoding.py:59-82)."""
+from __future__ import annotations
+
+import torch
+
+from ..quantizers import QUANTIZER_MAP
+
+_MATMUL = {"matmul": torch.matmul, "bmm": torch.bmm}
+_KEYS = {
+    "block_fp": ("width", "exponent_width", "exponent_bias", "block_size"),
+    "block_minifloat": ("width", "exponent_width", "exponent_bias_width", "block_size"),
+    "block_log": ("width", "exponent_bias_width", "block_size"),
+    "integer": ("width", "frac_width"),
+    "minifloat_ieee": ("width", "exponent_width", "exponent_bias"),
+    "minifloat_denorm": ("width", "exponent_width", "exponent_bias"),
+    "log": ("width", "exponent_bias"),
+}
+_BLOCKED = ("block_fp", "block_minifloat", "block_log")
+
+
+def _quantise_operand(t, arith, config, prefix):
+    kw = {k: config[f"{prefix}_{k}"] for k in _KEYS[arith]}
+    q = QUANTIZER_MAP[arith]
+    if arith not in _BLOCKED:
+        return q(t, **kw)
+    many = t.ndim > 2                    # matmul.py:166-167, 187-195
+    flat = torch.flatten(t, 0, -3) if many else t
+    return torch.reshape(q(flat, **kw, skip_first_dim=many), t.shape)
+
+
+def _generic_matmul(x, y, config, arith, style):
+    mm = _MATMUL[style]
+    if config.get("bypass", False):
+        return mm(x, y)
+    # read y's keys first-to-last like the reference does (KeyError parity) even where unused
+    for k in _KEYS[arith]:
+        config[f"data_in_{k}"], config[f"weight_{k}"]
+    xq = _quantise_operand(x, arith, config, "data_in")
+    yq = y if arith == "block_log" else _quantise_operand(y, arith, config, "weight")
+    return mm(xq, yq)
+
+
+def _make(arith, style):
+    def f(x, y, config):
+        return _generic_matmul(x, y, config, arith, style)
+    f.__name__ = f"{style}_{arith}"
+    return f
+
+
+matmul_integer, bmm_integer = _make("integer", "matmul"), _make("integer", "bmm")
+matmul_minifloat_denorm, bmm_minifloat_denorm = _make("minifloat_denorm", "matmul"), _make("minifloat_denorm", "bmm")
+matmul_minifloat_ieee, bmm_minifloat_ieee = _make("minifloat_ieee", "matmul"), _make("minifloat_ieee", "bmm")
+matmul_log, bmm_log = _make("log", "matmul"), _make("log", "bmm")
+matmul_block_fp, bmm_block_fp = _make("block_fp", "matmul"), _make("block_fp", "bmm")
+matmul_block_minifloat, bmm_block_minifloat = _make("block_minifloat", "matmul"), _make("block_minifloat", "bmm")
+matmul_block_log, bmm_block_log = _make("block_log", "matmul"), _make("block_log", "bmm")
+
+
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def _make_rope(arith, honours_bypass=True):
+    def f(q, k, cos, sin, position_ids, config):
+        if honours_bypass and config.get("bypass", False):
+            quant = lambda t: t
+        else:
+            kw = {key: config[f"data_in_{key}"] for key in _KEYS[arith]}
+            if arith in _BLOCKED:
+                kw["skip_first_dim"] = False
+            elif arith == "integer":
+                kw["is_signed"] = True
+            quant = lambda t: QUANTIZER_MAP[arith](t, **kw)
+        cos = quant(cos.squeeze(1).squeeze(0))[position_ids].unsqueeze(1)   # [bs, 1, seq, dim]
+        sin = quant(sin.squeeze(1).squeeze(0))[position_ids].unsqueeze(1)
+        return (q * cos) + (_rotate_half(q) * sin), (k * cos) + (_rotate_half(k) * sin)
+    f.__name__ = f"apply_rotary_pos_emb_{arith}"
+    return f
+
+
+apply_rotary_pos_emb_block_fp = _make_rope("block_fp", honours_bypass=False)
+apply_rotary_pos_emb_block_log = _make_rope("block_log")
+apply_rotary_pos_emb_block_minifloat = _make_rope("block_minifloat")
+apply_rotary_pos_emb_integer = _make_rope("integer")
+apply_rotary_pos_emb_log = _make_rope("log")
+apply_rotary_pos_emb_minifloat_denorm = _make_rope("minifloat_denorm")
+apply_rotary_pos_emb_minifloat_ieee = _make_rope("minifloat_ieee")
+
+QUANTIZED_FUNC_MAP = {
+    "matmul": {
+        "block_fp": matmul_block_fp, "block_log": matmul_block_log, "block_minifloat": matmul_block_minifloat,
+        "integer": matmul_integer, "log": matmul_block_log, "minifloat_denorm": matmul_minifloat_denorm,
+        "minifloat_ieee": matmul_minifloat_ieee,
+    },
+    "bmm": {
+        "block_fp": bmm_block_fp, "block_log": bmm_block_log, "block_minifloat": bmm_block_minifloat,
+        "integer": bmm_integer, "log": bmm_block_log, "minifloat_denorm": bmm_minifloat_denorm,
+        "minifloat_ieee": bmm_minifloat_ieee,
+    },
+    "rotary_positional_encoding": {
+        "block_fp": apply_rotary_pos_emb_block_fp, "block_log": apply_rotary_pos_emb_block_log,
+        "block_minifloat": apply_rotary_pos_emb_block_minifloat, "integer": apply_rotary_pos_emb_integer,
+        "log": apply_rotary_pos_emb_log, "minifloat_denorm": apply_rotary_pos_emb_minifloat_denorm,
+        "minifloat_ieee": apply_rotary_pos_emb_minifloat_ieee,
+    },
+}

@@ -1,0 +1,177 @@
+"""Quantised `nn.Linear` classes with the reference's contract
+(`models/quantize/quantized_modules/linear.py:31-101, 113-203`): subclass of nn.Linear, ctor
+`(in_features, out_features, bias, device, dtype, config)`, attributes `config, bypass, is_ptq,
+weight_requires_quantisation, x_quantizer, w_quantizer, b_quantizer`, `from_float`, `__repr__`.
+
+MI355X path of `LinearBlockFP` in PTQ mode (the hot path):
+  first forward : W <- Qw(W), b <- Qb(b) in place (as the reference, linear.py:66-70) AND the int8
+                  mantissas + uint8 shared exponents of W are packed once and kept on the module;
+  every forward : x -> quantise+pack kernel -> int8-MFMA block GEMM -> fp32 y (+ b), no fake-quant
+                  tensor and no fp32 GEMM.
+Formats whose contraction is not an int8 dot (block_minifloat, block_log, exotic block shapes,
+QAT) quantise with the HIP fake-quant kernels and contract with the stock fp32 GEMM on the GPU.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ..quantizers import QUANTIZER_MAP
+
+# config-key suffixes each quantiser takes, per operand prefix (linear.py:113-203)
+_PARAMS = {
+    "block_fp": dict(width="width", exponent_width="exponent_width", exponent_bias="exponent_bias",
+                     block_size="block_size"),
+    "block_minifloat": dict(width="width", exponent_width="exponent_width",
+                            exponent_bias_width="exponent_bias_width", block_size="block_size"),
+    "block_log": dict(width="width", exponent_bias_width="exponent_bias_width", block_size="block_size"),
+    "integer": dict(width="width", frac_width="frac_width"),
+    "minifloat_ieee": dict(width="width", exponent_width="exponent_width", exponent_bias="exponent_bias"),
+    "minifloat_denorm": dict(width="width", exponent_width="exponent_width", exponent_bias="exponent_bias"),
+    # the reference passes exponent_width to log_quantizer, which rejects it
+    "log": dict(width="width", exponent_width="exponent_width", exponent_bias="exponent_bias"),
+}
+_BLOCKED = ("block_fp", "block_minifloat", "block_log")
+
+
+def _make_quantizer(arith: str, config: dict, prefix: str, skip_first_dim: bool):
+    kw = {arg: config[f"{prefix}_{suffix}"] for arg, suffix in _PARAMS[arith].items()}
+    if arith in _BLOCKED:
+        kw["skip_first_dim"] = skip_first_dim
+    elif arith == "integer":
+        kw["is_signed"] = True
+    return partial(QUANTIZER_MAP[arith], **kw)
+
+
+class _LinearBase(nn.Linear):
+    arith: str = None
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 config: dict = None) -> None:
+        super().__init__(in_features, out_features, bias, device, dtype)
+        self.config = config
+        self.bypass = config.get("bypass", False)
+        self.is_ptq = config.get("is_ptq", False)
+        self.weight_requires_quantisation = True if self.is_ptq else False
+        self.x_quantizer = self.w_quantizer = self.b_quantizer = None
+        self._packed = None          # (wm, we, weight._version, bias._version) once W is packed
+        if not self.bypass:
+            self._setup_quantizers(config)
+
+    def _setup_quantizers(self, config: dict):
+        self.x_quantizer = _make_quantizer(self.arith, config, "data_in", True)
+        self.w_quantizer = _make_quantizer(self.arith, config, "weight", False)
+        self.b_quantizer = _make_quantizer(self.arith, config, "bias", False) if self.bias is not None else None
+
+    # -- int8 block GEMM eligibility ------------------------------------------------------
+    def _int8_plan(self, x: torch.Tensor):
+        """(x_mbits, w_mbits, x_bias, w_bias) when the contraction is an int8 x int8 block dot on
+        the MFMA path: block_fp both sides, [1,16] blocks along in_features, widths <= 8."""
+        if self.arith != "block_fp" or not x.is_cuda or x.dtype != torch.float32 or x.ndim < 2:
+            return None
+        c, K = self.config, self.in_features
+        if K % 16 or not (2 <= c["data_in_width"] <= 8 and 2 <= c["weight_width"] <= 8):
+            return None
+        if not (1 <= c["data_in_exponent_width"] <= 8 and 1 <= c["weight_exponent_width"] <= 8):
+            return None
+        xs = [1, K] if x.ndim == 2 else [1, x.shape[-2], K]
+        if x.ndim > 3:
+            return None
+        if ops.resolve_blocking(xs, c["data_in_block_size"], True)[3:] != (1, 16):
+            return None
+        if ops.resolve_blocking([self.out_features, K], c["weight_block_size"], False)[3:] != (1, 16):
+            return None
+        xb, wb = c["data_in_exponent_bias"], c["weight_exponent_bias"]
+        xb = 2 ** (c["data_in_exponent_width"] - 1) - 1 if xb in (None, "none", "None") else xb
+        wb = 2 ** (c["weight_exponent_width"] - 1) - 1 if wb in (None, "none", "None") else wb
+        return c["data_in_width"] - 1, c["weight_width"] - 1, xb, wb
+
+    @torch.no_grad()
+    def _quantise_weights_once(self, pack: bool):
+        """linear.py:66-70 plus the one-off packing of the int8 operand"""
+        c = self.config
+        if pack:
+            wq, wm, we = ops.block_fp_quantize(self.weight.data, c["weight_width"], c["weight_exponent_width"],
+                                               c["weight_exponent_bias"], c["weight_block_size"], False,
+                                               want_packed=True)
+            self.weight.copy_(wq)
+        else:
+            self.weight.copy_(self.w_quantizer(self.weight.data))
+        if self.bias is not None:
+            self.bias.copy_(self.b_quantizer(self.bias.data))
+        self.weight_requires_quantisation = False
+        if pack:
+            self._packed = (wm, we, self.weight._version, None if self.bias is None else self.bias._version)
+
+    def _packed_is_current(self) -> bool:
+        p = self._packed
+        return (p is not None and p[2] == self.weight._version and p[0].device == self.weight.device
+                and (self.bias is None or p[3] == self.bias._version))
+
+    def requantize(self):
+        """Search-loop helper: after loading new fp32 weights into .weight/.bias, make the
+        next forward quantise and pack them again instead of rebuilding the model."""
+        self.weight_requires_quantisation = True if self.is_ptq else False
+        self._packed = None
+
+    def forward(self, x):
+        if self.bypass:
+            return F.linear(x, self.weight, self.bias)
+        if self.is_ptq:
+            plan = self._int8_plan(x)
+            with torch.no_grad():
+                if self.weight_requires_quantisation:
+                    self._quantise_weights_once(pack=plan is not None)
+                if plan is not None and self._packed_is_current():
+                    return self._forward_int8(x, plan)
+                x = self.x_quantizer(x)
+            return F.linear(x, self.weight, self.bias)
+        x = self.x_quantizer(x)
+        w = self.w_quantizer(self.weight)
+        bias = self.b_quantizer(self.bias) if self.bias is not None else None
+        return F.linear(x, w, bias)
+
+    def _forward_int8(self, x, plan):
+        x_mbits, w_mbits, xb, wb = plan
+        c = self.config
+        x2 = x.reshape(-1, self.in_features)
+        _, xm, xe = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"],
+                                          c["data_in_exponent_bias"], [1, 16], True, want_fake=False,
+                                          want_packed=True, fast_zero_blocks=True)
+        wm, we = self._packed[0], self._packed[1]
+        y = ops.bfp_gemm(xm, xe, wm, we, self.bias, x_mbits, xb, w_mbits, wb)
+        return y.reshape(*x.shape[:-1], self.out_features)
+
+    @classmethod
+    def from_float(cls, linear_fp32: nn.Linear, config: dict):
+        linear = cls(linear_fp32.in_features, linear_fp32.out_features, bias=linear_fp32.bias is not None,
+                     config=config)
+        with torch.no_grad():
+            linear.weight.copy_(linear_fp32.weight)
+            if linear.bias is not None:
+                linear.bias.copy_(linear_fp32.bias)
+        return linear
+
+    def __repr__(self):
+        return "{}(in_features={}, out_features={}, bias={}, bypass={}, is_ptq={}, x/w/b-width={}/{}/{})".format(
+            self.__class__.__name__, self.in_features, self.out_features, self.bias is not None, self.bypass,
+            self.is_ptq, self.config["data_in_width"], self.config["weight_width"],
+            self.config.get("bias_width", "NA"))
+
+
+def _linear_class(name: str, arith: str):
+    return type(name, (_LinearBase,), {"arith": arith, "__module__": __name__,
+                                       "__doc__": f"nn.Linear with {arith} input / weight / bias quantisers"})
+
+
+LinearBlockFP = _linear_class("LinearBlockFP", "block_fp")
+LinearBlockMinifloat = _linear_class("LinearBlockMinifloat", "block_minifloat")
+LinearBlockLog = _linear_class("LinearBlockLog", "block_log")
+LinearInteger = _linear_class("LinearInteger", "integer")
+LinearLog = _linear_class("LinearLog", "log")
+LinearMinifloatDenorm = _linear_class("LinearMinifloatDenorm", "minifloat_denorm")
+LinearMinifloatIEEE = _linear_class("LinearMinifloatIEEE", "minifloat_ieee")

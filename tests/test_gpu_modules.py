@@ -1,0 +1,129 @@
+"""GPU parity of the registry-level API (Linear classes, matmul/bmm functions, quantiser autograd
+wrappers) against golden outputs of the reference's own modules (tests/golden/modules.npz)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TAGS = ["bfp_6bit", "bfp_4bit", "block_fp", "block_minifloat", "block_log"]
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("has_bias", [1, 0])
+def test_linear_ptq_golden(tag, has_bias, golden_modules):
+    import torch
+    import mi355q.quantize as Q
+    meta, data = golden_modules
+    cfg = meta[tag]["linear_config"]
+    k = f"{tag}/linear_bias{has_bias}"
+    fp = torch.nn.Linear(96, 48, bias=bool(has_bias))
+    with torch.no_grad():
+        fp.weight.copy_(torch.from_numpy(data[f"{k}/w"]))
+        if has_bias:
+            fp.bias.copy_(torch.from_numpy(data[f"{k}/b"]))
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    y1 = lin(_t(data[f"{k}/x1"]))
+    # first PTQ call overwrote the parameters with their quantised values, bit for bit
+    assert np.array_equal(lin.weight.detach().cpu().numpy(), data[f"{k}/wq"])
+    if has_bias:
+        assert np.array_equal(lin.bias.detach().cpu().numpy(), data[f"{k}/bq"])
+    assert lin.weight_requires_quantisation is False
+    y2 = lin(_t(data[f"{k}/x2"]))
+    for y, ref in ((y1, data[f"{k}/y1"]), (y2, data[f"{k}/y2"])):
+        assert y.shape == ref.shape
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+        # the int path is far tighter than the 1e-3 contract
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=3e-5 * np.abs(ref).max())
+    if tag in ("bfp_6bit", "bfp_4bit", "block_fp"):
+        assert lin._packed is not None, "int8 MFMA path was not taken"
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("op", ["bmm0", "bmm1", "mm4d", "mm2d"])
+def test_matmul_golden(tag, op, golden_modules):
+    import mi355q.quantize as Q
+    meta, data = golden_modules
+    cfg = meta[tag]["matmul_config"]
+    f = Q.get_quantized_func("bmm" if op.startswith("bmm") else "matmul", cfg)
+    out = f(_t(data[f"{tag}/{op}/x"]), _t(data[f"{tag}/{op}/y"]), cfg)
+    ref = data[f"{tag}/{op}/out"]
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * np.abs(ref).max())
+
+
+def test_qat_forward_backward_ste():
+    """is_ptq = False: all three operands re-quantised every call, identity backward (reference
+    linear.py:72-76, block_fp.py:119-124)"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="block_fp", is_ptq=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+               data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+               weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127,
+               bias_block_size=[16])
+    torch.manual_seed(0)
+    lin = Q.get_quantized_cls("linear", cfg)(64, 32, config=cfg).to("cuda:0")
+    w0 = lin.weight.detach().clone()
+    x = torch.randn(5, 64, device="cuda:0", requires_grad=True)
+    y = lin(x)
+    y.sum().backward()
+    assert torch.equal(lin.weight.detach(), w0), "QAT must not overwrite the weights"
+    ref, wq, bq = O.linear_ptq(x.detach().cpu().numpy(), w0.cpu().numpy(), lin.bias.detach().cpu().numpy(), cfg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    # STE: dL/dx = 1^T W_q, dL/dW = 1 x_q^T
+    np.testing.assert_allclose(x.grad.cpu().numpy(), np.tile(wq.sum(0), (5, 1)), rtol=1e-4, atol=1e-5)
+    xq = O.block_fp_quantize(x.detach().cpu().numpy(), 6, 8, 127, [1, 16], True)
+    np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), np.tile(xq.sum(0), (32, 1)), rtol=1e-4, atol=1e-5)
+
+
+def test_requantize_after_weight_reload():
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="block_fp", is_ptq=True, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+               data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+               weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127,
+               bias_block_size=[16])
+    torch.manual_seed(1)
+    lin = Q.get_quantized_cls("linear", cfg)(64, 48, config=cfg).to("cuda:0")
+    x = torch.randn(7, 64, device="cuda:0")
+    lin(x)
+    w_new = torch.randn(48, 64) * 0.05
+    with torch.no_grad():
+        lin.weight.copy_(w_new.to("cuda:0"))
+    # like the reference, a reload after the first call is used as is (not re-quantised) ...
+    y_raw = lin(x)
+    xq = O.block_fp_quantize(x.cpu().numpy(), 6, 8, 127, [1, 16], True)
+    np.testing.assert_allclose(y_raw.cpu().numpy(), xq @ w_new.numpy().T + lin.bias.detach().cpu().numpy(),
+                               rtol=1e-4, atol=1e-5)
+    # ... until requantize() asks for a fresh quantise + pack
+    lin.requantize()
+    y = lin(x)
+    ref, wq, _ = O.linear_ptq(x.cpu().numpy(), w_new.numpy(), None, cfg)
+    assert np.array_equal(lin.weight.detach().cpu().numpy(), wq)
+    np.testing.assert_allclose(y.cpu().numpy(), ref + lin.bias.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_rope_integer_quantised_tables():
+    """every shipped TOML quantises the RoPE tables with `integer` (bfp_6bit.toml:18-22)"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="integer", data_in_width=8, data_in_frac_width=7)
+    f = Q.get_quantized_func("rotary_positional_encoding", cfg)
+    T, hd = 12, 16
+    pos = torch.arange(T)[:, None] * (1.0 / 10000 ** (torch.arange(0, hd, 2) / hd))[None, :]
+    emb = torch.cat((pos, pos), -1)
+    cos, sin = emb.cos()[None, None].to("cuda:0"), emb.sin()[None, None].to("cuda:0")
+    q = torch.randn(1, 2, T, hd, device="cuda:0")
+    k = torch.randn(1, 2, T, hd, device="cuda:0")
+    ids = torch.arange(T, device="cuda:0")[None]
+    qe, ke = f(q, k, cos, sin, ids, cfg)
+    cq = O.integer_quantize(cos.cpu().numpy()[0, 0], 8, 7)
+    sq = O.integer_quantize(sin.cpu().numpy()[0, 0], 8, 7)
+    qn = q.cpu().numpy()
+    rot = np.concatenate((-qn[..., hd // 2:], qn[..., : hd // 2]), -1)
+    np.testing.assert_allclose(qe.cpu().numpy(), qn * cq + rot * sq, rtol=1e-6, atol=1e-6)

@@ -1,0 +1,132 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the header
+declares, the registry mirror has the reference's keys, the config parser and layer profiler
+reproduce the reference's outputs (golden, captured by tools/gen_golden.py), and the block-shape
+resolution agrees with the oracle's."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from mi355q import _lib
+    header = (ROOT / "include" / "mi355q.h").read_text()
+    declared = set(re.findall(r"\b(mi355q_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    lib = ctypes.CDLL(str(_lib.library_path()))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mi355q.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+    assert _lib.load_library().mi355q_abi_version() == int(re.search(r"MI355Q_ABI_VERSION (\d+)", header).group(1))
+    assert int(re.search(r"MI355Q_WORKSPACE_BYTES (\d+)", header).group(1)) == _lib.WORKSPACE_BYTES
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from mi355q import _lib
+    lib = _lib.load_library()
+    assert lib.mi355q_block_fp_quantize(None, None, None, None, 1, 4, 16, 1, 16, 6, 8, 127, 0, None, None) == -1
+    assert lib.mi355q_block_fp_quantize(None, None, None, None, 1, 0, 16, 1, 16, 6, 8, 127, 0, None, None) == 0  # empty
+    assert lib.mi355q_bfp_gemm(None, None, None, None, None, None, 4, 4, 24, 4, 5, 127, 5, 127, None) == -1
+    assert b"bad argument" in lib.mi355q_error_string(-1)
+
+
+def test_registry_keys_match_reference():
+    import mi355q.quantize as Q
+    names = {"block_fp", "block_log", "block_minifloat", "integer", "log", "minifloat_denorm", "minifloat_ieee"}
+    assert set(Q.QUANTIZER_MAP) == names
+    assert set(Q.QUANTIZED_MODULE_MAP) == {"linear"} and set(Q.QUANTIZED_MODULE_MAP["linear"]) == names
+    assert set(Q.QUANTIZED_FUNC_MAP) == {"matmul", "bmm", "rotary_positional_encoding"}
+    for op in Q.QUANTIZED_FUNC_MAP.values():
+        assert set(op) == names
+    # reference quirk: "log" is served by the block_log functions
+    assert Q.QUANTIZED_FUNC_MAP["matmul"]["log"] is Q.QUANTIZED_FUNC_MAP["matmul"]["block_log"]
+    assert Q.get_quantized_cls("linear", {"name": "block_fp"}).__name__ == "LinearBlockFP"
+    assert Q.get_quantizer("x", {"name": "block_log"}) is Q.QUANTIZER_MAP["block_log"]
+
+
+def test_parse_node_config_golden(golden_config_profile):
+    from mi355q.quantize import parse_node_config
+    cases = golden_config_profile["parse_node_config"]
+    assert len(cases) > 50
+    for key, c in cases.items():
+        op = key.split(":")[-1]
+        if "raises" in c:
+            with pytest.raises(Exception) as ei:
+                parse_node_config(dict(c["in"]), op, strict=True)
+            assert type(ei.value).__name__ == c["raises"], key
+        else:
+            assert parse_node_config(dict(c["in"]), op, strict=True) == c["out"], key
+
+
+def test_layer_profiler_golden(golden_config_profile):
+    from mi355q.quantize import profile_linear_layer, profile_matmul_layer, update_profile
+    for fn, key in ((profile_linear_layer, "profile_linear_layer"), (profile_matmul_layer, "profile_matmul_layer")):
+        for c in golden_config_profile[key]:
+            args = [tuple(a) if isinstance(a, list) else a for a in c["args"]]
+            if "raises" in c:
+                with pytest.raises(Exception) as ei:
+                    fn(dict(c["cfg"]), *args)
+                assert type(ei.value).__name__ == c["raises"]
+            else:
+                got = fn(dict(c["cfg"]), *args)
+                assert {k: int(v) for k, v in got.items()} == c["out"], (key, c["args"])
+    p = {k: 0 for k in ("num_params", "num_acts", "param_bits", "act_bits", "flops")}
+    d = {k: 3 for k in p}
+    assert update_profile(update_profile(p, d), d) == {k: 6 for k in p}
+
+
+@pytest.mark.parametrize("shape,block,skip", [
+    ((50,), [16], False), ((12, 80), [1, 16], True), ((5, 43), [1, 16], True), ((6, 40), [16], True),
+    ((24, 64), [1, 16], False), ((10, 24), [4, 8], False), ((6, 40), [16], False), ((3, 7, 48), [1, 16], True),
+    ((2, 6, 40), [2, 16], True), ((2, 5, 40), [16], True), ((4, 10), [1, 16], True), ((4, 10), 16, True),
+    ((7, 9), [3, 1, 16], False)])
+def test_resolve_blocking_matches_oracle(shape, block, skip):
+    from mi355q.ops import n_blocks, resolve_blocking
+    from oracle.np_oracle import block_meta
+    lead, rows, cols, b0, b1 = resolve_blocking(shape, block, skip)
+    m = block_meta(shape, block, skip)
+    assert (b0, b1) == (m.b0, m.b1)
+    assert n_blocks(lead, rows, cols, b0, b1) == m.n_blocks
+    assert lead * rows * cols == int(np.prod(shape))
+
+
+def test_resolve_blocking_errors_like_reference():
+    from mi355q.ops import resolve_blocking
+    with pytest.raises(NotImplementedError):
+        resolve_blocking((2, 3, 4), [1, 16], False)
+    with pytest.raises(RuntimeError):
+        resolve_blocking((2, 3, 4, 5), [1, 16], True)
+    with pytest.raises(AssertionError):
+        resolve_blocking((8,), [16], True)
+
+
+def test_linear_contract_on_cpu():
+    """construction, attributes, repr, from_float, bypass forward work without a GPU; the quantised
+    forward refuses a CPU tensor instead of silently computing elsewhere."""
+    import torch
+    import mi355q.quantize as Q
+    cfg = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8,
+               data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=4, weight_exponent_width=8,
+               weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8,
+               bias_exponent_bias=127, bias_block_size=[16])
+    cls = Q.get_quantized_cls("linear", cfg)
+    fp = torch.nn.Linear(32, 16)
+    lin = cls.from_float(fp, cfg)
+    assert isinstance(lin, torch.nn.Linear) and isinstance(lin.weight, torch.nn.Parameter)
+    assert torch.equal(lin.weight, fp.weight) and torch.equal(lin.bias, fp.bias)
+    assert lin.is_ptq and lin.weight_requires_quantisation and not lin.bypass
+    assert lin.x_quantizer.keywords["skip_first_dim"] is True and lin.w_quantizer.keywords["skip_first_dim"] is False
+    assert lin.x_quantizer.keywords["width"] == 6 and lin.w_quantizer.keywords["width"] == 4
+    assert repr(lin) == ("LinearBlockFP(in_features=32, out_features=16, bias=True, bypass=False, is_ptq=True, "
+                         "x/w/b-width=6/4/6)")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lin(torch.zeros(2, 32))
+    byp = cls(32, 16, config=dict(cfg, bypass=True))
+    x = torch.randn(3, 32)
+    assert torch.equal(byp(x), torch.nn.functional.linear(x, byp.weight, byp.bias))
+    with pytest.raises(KeyError):
+        cls(32, 16, config={"name": "block_fp", "is_ptq": True})

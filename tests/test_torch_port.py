@@ -1,0 +1,20 @@
+"""Pin oracle/torch_port.py (the cpu_baseline workload) against the golden vectors."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+_META = json.loads((GOLDEN / "quantizers.json").read_text())
+_BFP = sorted(t for t, m in _META.items() if m["quantizer"] == "block_fp")
+
+
+@pytest.mark.parametrize("tag", _BFP)
+def test_torch_port_block_fp(tag, golden_quantizers):
+    torch = pytest.importorskip("torch")
+    from oracle import torch_port as P
+    meta, data = golden_quantizers
+    m = meta[tag]
+    y = P.block_fp_quantize(torch.from_numpy(data[f"{tag}/x"].copy()), skip_first_dim=m["skip_first_dim"], **m["params"])
+    assert np.array_equal(y.numpy(), data[f"{tag}/y"], equal_nan=True)
