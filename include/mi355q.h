@@ -104,6 +104,24 @@ int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const
                     int32_t x_mbits, int32_t x_exp_bias, int32_t w_mbits, int32_t w_exp_bias,
                     void* stream);
 
+/* ---- exponent-aligned operands for the fast GEMM ------------------------------------------
+ * K is cut into groups of 16 blocks (256 values).  mi355q_bfp_align rewrites a packed operand so
+ * that, wherever every block of a (row, group) can be shifted left onto the group's smallest
+ * exponent without leaving int8, the row-group carries ONE effective exponent (rowflag 1);
+ * other row-groups are copied unchanged (rowflag 0).  The rewritten (mant, exp) denote exactly
+ * the same values, so results do not depend on the flags -- they only select the kernel path:
+ * flagged groups run one int32 MFMA chain per 256 values and are rescaled once.
+ * rowflag: uint8 [rows, ceil(K/256)].  In-place (mant_out == mant_in, exp_out == exp_in) is allowed. */
+size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K);
+int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, uint8_t* exp_out,
+                     uint8_t* rowflag, int64_t rows, int64_t K, void* stream);
+/* Same contraction and arguments as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align. */
+int mi355q_bfp_gemm_aligned(const int8_t* xm, const uint8_t* xe, const uint8_t* xflag,
+                            const int8_t* wm, const uint8_t* we, const uint8_t* wflag,
+                            const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
+                            int32_t x_mbits, int32_t x_exp_bias, int32_t w_mbits, int32_t w_exp_bias,
+                            void* stream);
+
 /* Which GEMM kernel variant mi355q_bfp_gemm dispatches to (0 = automatic).  For A/B
  * benchmarking and tests only; returns the previous value. */
 int mi355q_bfp_gemm_set_variant(int variant);

@@ -135,6 +135,35 @@ int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const
     return launch_bfp_gemm(a, g_gemm_variant.load(), static_cast<hipStream_t>(stream));
 }
 
+size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K) {
+    if (rows <= 0 || K <= 0) return 0;
+    return static_cast<size_t>(rows) * static_cast<size_t>((K + 255) / 256);
+}
+
+int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, uint8_t* exp_out,
+                     uint8_t* rowflag, int64_t rows, int64_t K, void* stream) {
+    if (rows < 0 || K < 0) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!mant_in || !exp_in || !mant_out || !exp_out || !rowflag) return MI355Q_E_BADARG;
+    if (K % 16 != 0) return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(mant_in) | reinterpret_cast<uintptr_t>(mant_out)) % 4) return MI355Q_E_ALIGN;
+    return launch_bfp_align(mant_in, exp_in, mant_out, exp_out, rowflag, rows, K, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_bfp_gemm_aligned(const int8_t* xm, const uint8_t* xe, const uint8_t* xflag, const int8_t* wm,
+                            const uint8_t* we, const uint8_t* wflag, const float* bias, float* y, int64_t M, int64_t N,
+                            int64_t K, int64_t ldy, int32_t x_mbits, int32_t x_exp_bias, int32_t w_mbits,
+                            int32_t w_exp_bias, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
+    if (M == 0 || N == 0) return 0;
+    if (!y || (K > 0 && (!xm || !xe || !wm || !we || !xflag || !wflag))) return MI355Q_E_BADARG;
+    if (K % 16 != 0) return MI355Q_E_UNSUPPORTED;
+    if (x_mbits < 1 || x_mbits > 7 || w_mbits < 1 || w_mbits > 7) return MI355Q_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(xm) | reinterpret_cast<uintptr_t>(wm)) % 16) return MI355Q_E_ALIGN;
+    GemmArgs a{xm, xe, wm, we, bias, y, M, N, K, ldy, x_exp_bias + x_mbits + w_exp_bias + w_mbits};
+    return launch_bfp_gemm_aligned(a, xflag, wflag, g_gemm_variant.load(), static_cast<hipStream_t>(stream));
+}
+
 int mi355q_bfp_gemm_set_variant(int variant) { return g_gemm_variant.exchange(variant); }
 
 }  // extern "C"

@@ -39,6 +39,9 @@ struct GemmArgs {
     int scale_bias;   // subtracted from xe + we to get the power of two of a block product
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
+int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, int variant, hipStream_t st);
+int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, long long rows,
+                     long long K, hipStream_t st);
 
 }  // namespace mi355q
 #endif

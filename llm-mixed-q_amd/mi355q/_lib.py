@@ -23,6 +23,10 @@ SIGNATURES = {
     "mi355q_integer_quantize": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                   _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_bfp_rowflag_bytes": (C.c_size_t, [_i64, _i64]),
+    "mi355q_bfp_align": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                          _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_gemm_set_variant": (C.c_int, [C.c_int]),
 }
 ABI_VERSION = 1

@@ -185,5 +185,47 @@ def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Ten
     return out
 
 
+def bfp_align(mant: torch.Tensor, exp: torch.Tensor, inplace: bool = False):
+    """Rewrite a packed [rows, K] operand into the exponent-aligned format of the fast GEMM.
+    -> (mant', exp', rowflag uint8 [rows, ceil(K/256)]); same values, see include/mi355q.h."""
+    if not mant.is_cuda:
+        raise RuntimeError("mi355q.bfp_align: operands must be on a HIP device; there is no CPU fallback")
+    rows, K = mant.shape
+    assert mant.dtype == torch.int8 and exp.dtype == torch.uint8 and mant.is_contiguous() and exp.is_contiguous()
+    assert exp.numel() == rows * (K // 16)
+    mo = mant if inplace else torch.empty_like(mant)
+    eo = exp if inplace else torch.empty_like(exp)
+    flag = torch.empty(rows, (K + 255) // 256, dtype=torch.uint8, device=mant.device)
+    lib = _lib.load_library()
+    with torch.cuda.device(mant.device):
+        rc = lib.mi355q_bfp_align(_ptr(mant), _ptr(exp), _ptr(mo), _ptr(eo), _ptr(flag), rows, K,
+                                  _stream_ptr(mant.device))
+    _lib.check(rc, "mi355q_bfp_align")
+    return mo, eo, flag
+
+
+def bfp_gemm_aligned(xm, xe, xf, wm, we, wf, bias, x_mbits: int, x_exp_bias: int, w_mbits: int, w_exp_bias: int,
+                     out: torch.Tensor = None):
+    """bfp_gemm on operands rewritten by bfp_align (flagged K-groups take the int32-chain path)."""
+    if not (xm.is_cuda and wm.is_cuda):
+        raise RuntimeError("mi355q.bfp_gemm_aligned: operands must be on a HIP device; there is no CPU fallback")
+    M, K = xm.shape
+    N = wm.shape[0]
+    assert wm.shape[1] == K and xm.dtype == torch.int8 and wm.dtype == torch.int8
+    assert xm.is_contiguous() and wm.is_contiguous() and xe.is_contiguous() and we.is_contiguous()
+    assert xf.shape == (M, (K + 255) // 256) and wf.shape == (N, (K + 255) // 256)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=xm.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    lib = _lib.load_library()
+    with torch.cuda.device(xm.device):
+        rc = lib.mi355q_bfp_gemm_aligned(_ptr(xm), _ptr(xe), _ptr(xf), _ptr(wm), _ptr(we), _ptr(wf), _ptr(bias),
+                                         _ptr(out), M, N, K, ldy, int(x_mbits), int(x_exp_bias), int(w_mbits),
+                                         int(w_exp_bias), _stream_ptr(xm.device))
+    _lib.check(rc, "mi355q_bfp_gemm_aligned")
+    return out
+
+
 def set_gemm_variant(variant: int) -> int:
     return _lib.load_library().mi355q_bfp_gemm_set_variant(int(variant))

@@ -6,7 +6,7 @@ weight_requires_quantisation, x_quantizer, w_quantizer, b_quantizer`, `from_floa
 MI355X path of `LinearBlockFP` in PTQ mode (the hot path):
   first forward : W <- Qw(W), b <- Qb(b) in place (as the reference, linear.py:66-70) AND the int8
                   mantissas + uint8 shared exponents of W are packed once and kept on the module;
-  every forward : x -> quantise+pack kernel -> int8-MFMA block GEMM -> fp32 y (+ b), no fake-quant
+  every forward : x -> quantise+pack kernel -> exponent-align -> int8-MFMA block GEMM -> fp32 y (+ b), no fake-quant
                   tensor and no fp32 GEMM.
 Formats whose contraction is not an int8 dot (block_minifloat, block_log, exotic block shapes,
 QAT) quantise with the HIP fake-quant kernels and contract with the stock fp32 GEMM on the GPU.
@@ -105,7 +105,8 @@ class _LinearBase(nn.Linear):
             self.bias.copy_(self.b_quantizer(self.bias.data))
         self.weight_requires_quantisation = False
         if pack:
-            self._packed = (wm, we, self.weight._version, None if self.bias is None else self.bias._version)
+            wm, we, wf = ops.bfp_align(wm, we, inplace=True)
+            self._packed = (wm, we, self.weight._version, None if self.bias is None else self.bias._version, wf)
 
     def _packed_is_current(self) -> bool:
         p = self._packed
@@ -142,8 +143,9 @@ class _LinearBase(nn.Linear):
         _, xm, xe = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"],
                                           c["data_in_exponent_bias"], [1, 16], True, want_fake=False,
                                           want_packed=True, fast_zero_blocks=True)
-        wm, we = self._packed[0], self._packed[1]
-        y = ops.bfp_gemm(xm, xe, wm, we, self.bias, x_mbits, xb, w_mbits, wb)
+        xm, xe, xf = ops.bfp_align(xm, xe, inplace=True)
+        wm, we, wf = self._packed[0], self._packed[1], self._packed[4]
+        y = ops.bfp_gemm_aligned(xm, xe, xf, wm, we, wf, self.bias, x_mbits, xb, w_mbits, wb)
         return y.reshape(*x.shape[:-1], self.out_features)
 
     @classmethod

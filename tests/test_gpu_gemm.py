@@ -35,7 +35,7 @@ def _inputs(M, N, K, seed, style):
     return x, w, b
 
 
-def _run(x, w, b, cfg):
+def _run(x, w, b, cfg, aligned=False):
     import torch
     from mi355q import ops
     dev = torch.device("cuda:0")
@@ -47,7 +47,14 @@ def _run(x, w, b, cfg):
     bq = None
     if b is not None:
         bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), cfg["bias_width"], 8, 127, [16], False)
-    y = ops.bfp_gemm(xm, xe, wm, we, bq, cfg["data_in_width"] - 1, 127, cfg["weight_width"] - 1, 127)
+    if aligned:
+        xm2, xe2, xf = ops.bfp_align(xm, xe)
+        wm2, we2, wf = ops.bfp_align(wm, we)
+        y = ops.bfp_gemm_aligned(xm2, xe2, xf, wm2, we2, wf, bq, cfg["data_in_width"] - 1, 127,
+                                 cfg["weight_width"] - 1, 127)
+        _run.last_flags = (float(xf.float().mean()), float(wf.float().mean()))
+    else:
+        y = ops.bfp_gemm(xm, xe, wm, we, bq, cfg["data_in_width"] - 1, 127, cfg["weight_width"] - 1, 127)
     torch.cuda.synchronize()
     return y.cpu().numpy()
 
@@ -97,3 +104,47 @@ def test_gemm_matches_reference_semantics_fp32_linear():
     bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), 6, 8, 127, [16], False)
     ref = (xq.double() @ wq.double().T + bq.double()).float().cpu().numpy()
     np.testing.assert_allclose(y, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 256), (256, 384, 512), (100, 72, 320), (33, 16, 64), (300, 130, 1024),
+                                   (64, 64, 48)])
+@pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
+@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
+def test_aligned_gemm_vs_oracle(M, N, K, style, wx, ww):
+    """the fast variant: flagged K-groups take the int32-chain path, the others the blockwise path;
+    `outlier` inputs force unflagged groups, W8 has no spare bits (flagged only when exponents agree)"""
+    from oracle import np_oracle as O
+    x, w, b = _inputs(M, N, K, 2000 + M + N + K, style)
+    cfg = _cfg(wx, ww)
+    y = _run(x, w, b, cfg, aligned=True)
+    ref = O.bfp_linear_int(x, w, b, cfg)
+    scale = np.abs(ref).max() + 1e-30
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
+
+
+def test_align_is_value_preserving_and_flags_make_sense():
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    x, _, _ = _inputs(96, 8, 1024, 5, "rowscale")
+    x[:, 256:272] *= 300.0            # one block per row of group 1 far above its neighbours
+    _, xm, xe = ops.block_fp_quantize(torch.from_numpy(x).to(dev), 6, 8, 127, [1, 16], True, want_fake=False,
+                                      want_packed=True)
+    xm2, xe2, xf = ops.bfp_align(xm, xe)
+    v1 = xm.cpu().numpy().reshape(96, 64, 16).astype(np.float64) * np.exp2(xe.cpu().numpy().reshape(96, 64, 1).astype(np.float64))
+    v2 = xm2.cpu().numpy().reshape(96, 64, 16).astype(np.float64) * np.exp2(xe2.cpu().numpy().reshape(96, 64, 1).astype(np.float64))
+    assert np.array_equal(v1, v2)
+    f = xf.cpu().numpy()
+    assert f.shape == (96, 4) and f[:, 1].sum() == 0 and f[:, [0, 2, 3]].mean() > 0.9
+    e2 = xe2.cpu().numpy().reshape(96, 4, 16)
+    for g in (0, 2, 3):
+        rows = f[:, g] == 1
+        assert np.all(e2[rows, g, :] == e2[rows, g, :1]), "flagged row-groups must carry one exponent"
+
+
+def test_aligned_gemm_uses_fast_path_on_benchmark_data():
+    """the synthetic BASELINE data must be (almost) entirely flagged"""
+    x, w, b = _inputs(256, 256, 1024, 3, "rowscale")
+    _run(x, w, b, _cfg(6, 6), aligned=True)
+    fx, fw = _run.last_flags
+    assert fx > 0.95 and fw > 0.95, (fx, fw)

@@ -35,9 +35,10 @@ def test_linear_ptq_golden(tag, has_bias, golden_modules):
     y2 = lin(_t(data[f"{k}/x2"]))
     for y, ref in ((y1, data[f"{k}/y1"]), (y2, data[f"{k}/y2"])):
         assert y.shape == ref.shape
-        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
-        # the int path is far tighter than the 1e-3 contract
-        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=3e-5 * np.abs(ref).max())
+        got = y.detach().cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+        # far tighter than the 1e-3 contract
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5 * np.abs(ref).max())
     if tag in ("bfp_6bit", "bfp_4bit", "block_fp"):
         assert lin._packed is not None, "int8 MFMA path was not taken"
 
@@ -51,7 +52,7 @@ def test_matmul_golden(tag, op, golden_modules):
     f = Q.get_quantized_func("bmm" if op.startswith("bmm") else "matmul", cfg)
     out = f(_t(data[f"{tag}/{op}/x"]), _t(data[f"{tag}/{op}/y"]), cfg)
     ref = data[f"{tag}/{op}/out"]
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * np.abs(ref).max())
 
 
 def test_qat_forward_backward_ste():
@@ -97,14 +98,14 @@ def test_requantize_after_weight_reload():
     # like the reference, a reload after the first call is used as is (not re-quantised) ...
     y_raw = lin(x)
     xq = O.block_fp_quantize(x.cpu().numpy(), 6, 8, 127, [1, 16], True)
-    np.testing.assert_allclose(y_raw.cpu().numpy(), xq @ w_new.numpy().T + lin.bias.detach().cpu().numpy(),
+    np.testing.assert_allclose(y_raw.detach().cpu().numpy(), xq @ w_new.numpy().T + lin.bias.detach().cpu().numpy(),
                                rtol=1e-4, atol=1e-5)
     # ... until requantize() asks for a fresh quantise + pack
     lin.requantize()
     y = lin(x)
     ref, wq, _ = O.linear_ptq(x.cpu().numpy(), w_new.numpy(), None, cfg)
     assert np.array_equal(lin.weight.detach().cpu().numpy(), wq)
-    np.testing.assert_allclose(y.cpu().numpy(), ref + lin.bias.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref + lin.bias.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_rope_integer_quantised_tables():
