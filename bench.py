@@ -107,7 +107,7 @@ def main():
     # one-off weight / bias packing (first PTQ forward in the reference), not timed
     _, wm, we = ops.block_fp_quantize(w, ww, 8, 127, [1, 16], False, want_fake=False, want_packed=True,
                                       fast_zero_blocks=True)
-    wm, we, wf = ops.bfp_align(wm, we, inplace=True)
+    wa = ops.bfp_align(wm, we, ww - 1, 127, inplace=True)
     bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
     n_out = w.shape[0]
     y = torch.empty(M, n_out, dtype=torch.float32, device=device)
@@ -118,11 +118,11 @@ def main():
     def step(record=False):
         _, xm, xe = ops.block_fp_quantize(x, xw, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
                                           fast_zero_blocks=True)
-        xm, xe, xf = ops.bfp_align(xm, xe, inplace=True)
+        xa = ops.bfp_align(xm, xe, xw - 1, 127, inplace=True)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        ops.bfp_gemm_aligned(xm, xe, xf, wm, we, wf, bq, xw - 1, 127, ww - 1, 127, out=y)
+        ops.bfp_gemm_aligned(xa, wa, bq, out=y)
         if record:
             e1.record()
             gemm_events.append((e0, e1))

@@ -109,17 +109,43 @@ int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const
  * that, wherever every block of a (row, group) can be shifted left onto the group's smallest
  * exponent without leaving int8, the row-group carries ONE effective exponent (rowflag 1);
  * other row-groups are copied unchanged (rowflag 0).  The rewritten (mant, exp) denote exactly
- * the same values, so results do not depend on the flags -- they only select the kernel path:
- * flagged groups run one int32 MFMA chain per 256 values and are rescaled once.
- * rowflag: uint8 [rows, ceil(K/256)].  In-place (mant_out == mant_in, exp_out == exp_in) is allowed. */
+ * the same values, so results never depend on the flags -- they only select the kernel path.
+ *   rowflag uint8 [rows, G], G = ceil(K/256)
+ *   gscale  fp32  [G, rows_pad] (nullable), rows_pad = mi355q_bfp_rows_pad(rows): per (group,row)
+ *           2^(effective exponent - exp_offset) where rowflag is 1, else 0;
+ *           exp_offset = exponent_bias + (width-1) of the operand
+ *   list    int32 [2 + 2*list_cap] (nullable): list[0] = number of rowflag-0 row-groups,
+ *           then (row, group) pairs for the first list_cap of them
+ *   mant_tiled int8 [mi355q_bfp_tiled_bytes(rows, K)] (nullable, needs K % 64 == 0): the aligned
+ *           mantissas in the tile order the GEMM kernels stream (1-KiB pieces of 16 rows x 64 bytes,
+ *           rows padded to 128) -- this is what mi355q_bfp_gemm_aligned reads;
+ *   mant_out int8 [rows, K] (nullable): the same mantissas row-major, for inspection / mi355q_bfp_gemm.
+ * In-place (mant_out == mant_in, exp_out == exp_in) is allowed. */
+size_t mi355q_bfp_tiled_bytes(int64_t rows, int64_t K);
 size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K);
-int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, uint8_t* exp_out,
-                     uint8_t* rowflag, int64_t rows, int64_t K, void* stream);
-/* Same contraction and arguments as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align. */
-int mi355q_bfp_gemm_aligned(const int8_t* xm, const uint8_t* xe, const uint8_t* xflag,
-                            const int8_t* wm, const uint8_t* we, const uint8_t* wflag,
+int64_t mi355q_bfp_rows_pad(int64_t rows);
+int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, int8_t* mant_tiled,
+                     uint8_t* exp_out, uint8_t* rowflag, float* gscale, int32_t* list, int32_t list_cap,
+                     int32_t exp_offset, int64_t rows, int64_t K, void* stream);
+
+/* An aligned operand as one argument */
+typedef struct mi355q_bfp_operand {
+    const int8_t* mant;     /* tiled mantissas (mant_tiled of mi355q_bfp_align) */
+    const uint8_t* exp;     /* [rows, K/16] */
+    const uint8_t* rowflag; /* [rows, G] */
+    const float* gscale;    /* [G, rows_pad] */
+    const int32_t* list;    /* [2 + 2*list_cap] */
+    int32_t list_cap;
+    int32_t mbits;          /* width - 1 */
+    int32_t exp_bias;
+} mi355q_bfp_operand;
+
+/* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align.
+ * When few row-groups are unflagged (both lists within capacity) the int32-chain kernel runs on
+ * the flagged data and a sparse kernel adds the unflagged row-groups exactly; otherwise the
+ * blockwise-fallback kernel runs.  The choice is made on the device. */
+int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
-                            int32_t x_mbits, int32_t x_exp_bias, int32_t w_mbits, int32_t w_exp_bias,
                             void* stream);
 
 /* Which GEMM kernel variant mi355q_bfp_gemm dispatches to (0 = automatic).  For A/B

@@ -140,28 +140,55 @@ size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K) {
     return static_cast<size_t>(rows) * static_cast<size_t>((K + 255) / 256);
 }
 
-int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, uint8_t* exp_out,
-                     uint8_t* rowflag, int64_t rows, int64_t K, void* stream) {
-    if (rows < 0 || K < 0) return MI355Q_E_BADARG;
-    if (rows == 0 || K == 0) return 0;
-    if (!mant_in || !exp_in || !mant_out || !exp_out || !rowflag) return MI355Q_E_BADARG;
-    if (K % 16 != 0) return MI355Q_E_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(mant_in) | reinterpret_cast<uintptr_t>(mant_out)) % 4) return MI355Q_E_ALIGN;
-    return launch_bfp_align(mant_in, exp_in, mant_out, exp_out, rowflag, rows, K, static_cast<hipStream_t>(stream));
+int64_t mi355q_bfp_rows_pad(int64_t rows) { return rows <= 0 ? 0 : (rows + 255) / 256 * 256 + 256; }
+
+size_t mi355q_bfp_tiled_bytes(int64_t rows, int64_t K) {
+    if (rows <= 0 || K <= 0) return 0;
+    return static_cast<size_t>((rows + 127) / 128 * 128) * static_cast<size_t>((K + 63) / 64 * 64);
 }
 
-int mi355q_bfp_gemm_aligned(const int8_t* xm, const uint8_t* xe, const uint8_t* xflag, const int8_t* wm,
-                            const uint8_t* we, const uint8_t* wflag, const float* bias, float* y, int64_t M, int64_t N,
-                            int64_t K, int64_t ldy, int32_t x_mbits, int32_t x_exp_bias, int32_t w_mbits,
-                            int32_t w_exp_bias, void* stream) {
-    if (M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
+int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, int8_t* mant_tiled,
+                     uint8_t* exp_out, uint8_t* rowflag, float* gscale, int32_t* list, int32_t list_cap,
+                     int32_t exp_offset, int64_t rows, int64_t K, void* stream) {
+    if (rows < 0 || K < 0 || list_cap < 0) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!mant_in || !exp_in || !exp_out || !rowflag || (!mant_out && !mant_tiled)) return MI355Q_E_BADARG;
+    if (K % 16 != 0 || (mant_tiled && K % 64 != 0)) return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(mant_in) | reinterpret_cast<uintptr_t>(mant_out) |
+         reinterpret_cast<uintptr_t>(mant_tiled)) % 4)
+        return MI355Q_E_ALIGN;
+    return launch_bfp_align(mant_in, exp_in, mant_out, exp_out, rowflag, gscale, mi355q_bfp_rows_pad(rows), exp_offset,
+                            list, list_cap, mant_tiled, rows, K, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
+                            int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
+    if (!x || !w || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
     if (M == 0 || N == 0) return 0;
-    if (!y || (K > 0 && (!xm || !xe || !wm || !we || !xflag || !wflag))) return MI355Q_E_BADARG;
-    if (K % 16 != 0) return MI355Q_E_UNSUPPORTED;
-    if (x_mbits < 1 || x_mbits > 7 || w_mbits < 1 || w_mbits > 7) return MI355Q_E_BADARG;
-    if ((reinterpret_cast<uintptr_t>(xm) | reinterpret_cast<uintptr_t>(wm)) % 16) return MI355Q_E_ALIGN;
-    GemmArgs a{xm, xe, wm, we, bias, y, M, N, K, ldy, x_exp_bias + x_mbits + w_exp_bias + w_mbits};
-    return launch_bfp_gemm_aligned(a, xflag, wflag, g_gemm_variant.load(), static_cast<hipStream_t>(stream));
+    if (!y || (K > 0 && (!x->mant || !x->exp || !w->mant || !w->exp || !x->rowflag || !w->rowflag)))
+        return MI355Q_E_BADARG;
+    if (K % 64 != 0) return MI355Q_E_UNSUPPORTED;   // tiled operands; use mi355q_bfp_gemm otherwise
+    if (x->mbits < 1 || x->mbits > 7 || w->mbits < 1 || w->mbits > 7) return MI355Q_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant)) % 16) return MI355Q_E_ALIGN;
+    GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
+               x->exp_bias + x->mbits + w->exp_bias + w->mbits};
+    const int variant = g_gemm_variant.load();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long mpad = mi355q_bfp_rows_pad(M), npad = mi355q_bfp_rows_pad(N);
+    const bool chain_ok = x->gscale && w->gscale && K % 256 == 0;
+    if (variant == 3 && chain_ok)   // int32-chain kernel alone, no correction (benchmarks only)
+        return launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
+    if (variant == 4 && chain_ok)
+        return launch_bfp_gemm_v4(a, x->gscale, w->gscale, mpad, npad, st);
+    if (variant == 2 || !chain_ok || !x->list || !w->list || x->list_cap != w->list_cap || x->list_cap <= 0)
+        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, nullptr, 0, st);
+    // default: int32-chain kernel + sparse correction; the blockwise-fallback kernel takes over (decided on
+    // the device) when either operand has more unaligned row-groups than the lists hold
+    int rc = launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, st);
+    if (rc) return rc;
+    rc = launch_bfp_sparse_fix(a, x->rowflag, x->list, w->list, x->list_cap, st);
+    if (rc) return rc;
+    return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
 }
 
 int mi355q_bfp_gemm_set_variant(int variant) { return g_gemm_variant.exchange(variant); }

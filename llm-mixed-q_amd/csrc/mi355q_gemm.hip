@@ -148,9 +148,21 @@ __global__ __launch_bounds__(256) void bfp_gemm_v1(const GemmArgs a) {
 // =======================================================================================
 constexpr int ALIGN_G = 16;
 
+// Tiled mantissa layout of an aligned operand: 1-KiB pieces of 16 rows x 64 K-bytes, piece index
+// (row/16) * (K/64) + k/64; inside a piece row r's 16-byte chunk c sits in slot c ^ ((row >> 2) & 3)
+// -- the LDS image of the GEMM kernels, so that one global_load_lds copies one piece linearly.
+__device__ __forceinline__ long long tiled_offset(long long row, long long k, long long K) {
+    const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
+    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ (int)((row >> 2) & 3);
+    return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
+}
+
 __global__ __launch_bounds__(256) void bfp_align_kernel(const int8_t* __restrict__ mi, const uint8_t* __restrict__ ei,
                                                         int8_t* __restrict__ mo, uint8_t* __restrict__ eo,
-                                                        uint8_t* __restrict__ flag, long long rows, long long K) {
+                                                        uint8_t* __restrict__ flag, float* __restrict__ gscale,
+                                                        long long rows_pad, int exp_offset, int* __restrict__ list,
+                                                        int list_cap, int8_t* __restrict__ mt, long long rows,
+                                                        long long K) {
     const long long nkb = K >> 4, ngroups = (nkb + ALIGN_G - 1) / ALIGN_G;
     const int lane = threadIdx.x & 63;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -181,10 +193,20 @@ __global__ __launch_bounds__(256) void bfp_align_kernel(const int8_t* __restrict
             eout = emin == (1 << 20) ? e : emin;
         }
         if (valid) {
-            *reinterpret_cast<unsigned*>(mo + moff) = out;
+            if (mo) *reinterpret_cast<unsigned*>(mo + moff) = out;
             if ((lane & 3) == 0) eo[row * nkb + kb] = (uint8_t)eout;
+            if (mt) *reinterpret_cast<unsigned*>(mt + tiled_offset(row, kb * 16 + (lane & 3) * 4, K)) = out;
         }
-        if (lane == 0) flag[row * ngroups + g] = all_ok ? 1 : 0;
+        if (lane == 0) {
+            flag[row * ngroups + g] = all_ok ? 1 : 0;
+            // fast-GEMM view: one fp32 scale per (group, row); 0 neutralises a row-group that could not
+            // be aligned (its exact contribution comes from the sparse correction kernel)
+            if (gscale) gscale[g * rows_pad + row] = all_ok ? __builtin_ldexpf(1.0f, eout - exp_offset) : 0.0f;
+            if (list && !all_ok) {
+                const int at = atomicAdd(&list[0], 1);
+                if (at < list_cap) { list[2 + 2 * at] = (int)row; list[3 + 2 * at] = (int)g; }
+            }
+        }
     }
 }
 
@@ -209,8 +231,11 @@ using lptr_t = __attribute__((address_space(3))) void*;
 __device__ __forceinline__ int v2_off(int r, int c) { return r * V2_BK + ((c ^ ((r >> 2) & 3)) << 4); }
 
 __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const uint8_t* __restrict__ xf,
-                                                      const uint8_t* __restrict__ wf) {
+                                                      const uint8_t* __restrict__ wf, const int* __restrict__ xlist,
+                                                      const int* __restrict__ wlist, int list_cap) {
     __shared__ V2Smem sm;
+    // as the fallback of the int32-chain kernel: run only when the unaligned lists overflowed
+    if (xlist && xlist[0] <= list_cap && wlist[0] <= list_cap) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
 
@@ -240,22 +265,21 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const ui
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // per-lane source rows of the two 1-KiB pieces this wave stages per operand per step
+    // the two 1-KiB pieces (tiled layout) this wave stages per operand per step
     long long srcA[2], srcB[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int j = wave + 4 * t, row = 16 * j + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
-        const long long ra = min(m0 + row, a.M - 1), rb = min(n0 + row, a.N - 1);
-        srcA[t] = ra * a.K + chunk * 16;
-        srcB[t] = rb * a.K + chunk * 16;
+        const int j = wave + 4 * t;
+        srcA[t] = ((m0 >> 4) + j) * (a.K >> 6) * 1024 + lane * 16;
+        srcB[t] = ((n0 >> 4) + j) * (a.K >> 6) * 1024 + lane * 16;
     }
     auto stage = [&](int step, int buf) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int j = wave + 4 * t;
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.xm + srcA[t] + (long long)step * V2_BK),
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.xm + srcA[t] + (long long)step * 1024),
                                              (lptr_t)(&sm.a[buf][j * 1024]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.wm + srcB[t] + (long long)step * V2_BK),
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.wm + srcB[t] + (long long)step * 1024),
                                              (lptr_t)(&sm.b[buf][j * 1024]), 16, 0, 0);
         }
     };
@@ -381,21 +405,26 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const ui
         }
 }
 
-int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, long long rows,
+int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
+                     long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
                      long long K, hipStream_t st) {
     const long long ngroups = ((K >> 4) + ALIGN_G - 1) / ALIGN_G;
     long long grid = (rows * ngroups + 3) / 4;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(bfp_align_kernel, (unsigned)grid, 256, 0, st, mi, ei, mo, eo, flag, rows, K);
+    if (list) {
+        const hipError_t e = hipMemsetAsync(list, 0, 16, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(bfp_align_kernel, (unsigned)grid, 256, 0, st, mi, ei, mo, eo, flag, gscale, rows_pad, exp_offset,
+                       list, list_cap, mt, rows, K);
     return (int)hipGetLastError();
 }
 
-int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
-int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, int variant, hipStream_t st) {
-    if (variant == 1 || (a.K % V2_BK) != 0) return launch_bfp_gemm(a, 1, st);
+int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
+                            const int* wlist, int list_cap, hipStream_t st) {
     const unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
-    hipLaunchKernelGGL(bfp_gemm_v2, tiles, 256, 0, st, a, xf, wf);
+    hipLaunchKernelGGL(bfp_gemm_v2, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap);
     return (int)hipGetLastError();
 }
 

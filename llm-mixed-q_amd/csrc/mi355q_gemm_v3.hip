@@ -1,0 +1,448 @@
+// mi355q_gemm_v3.hip -- the fast block-floating-point GEMM for gfx950: int32 MFMA chains over
+// exponent-aligned K-groups of 256 values.
+//
+//   y[m,n] = sum_g  gx[g][m] * gw[g][n] * ( sum_{k in group g} xm'[m,k] * wm'[n,k] )   (+ bias[n])
+//
+// xm'/wm' are the exponent-aligned int8 mantissas written by the align kernel, gx/gw the per
+// (group,row) scales 2^(effective exponent - bias) as fp32, group-major ([K/256][rows padded to 256]).
+// A (row, group) the align step could not shift onto one exponent has scale 0 here: its exact
+// contribution is added by the sparse correction kernel.  No data-dependent branch in this kernel.
+//
+// Structure: workgroup = 128 x 128 outputs, 4 waves as 2 x 2 (one per SIMD), wave tile 64 x 64 =
+// 2 x 2 MFMA tiles of 32 x 32; TWO workgroups per CU, so that while one folds a group's int32 tile
+// into fp32 (VALU) the other keeps the matrix pipe busy.
+//   * K-step 64: A 128x64 B + B 128x64 B = 16 KiB per stage, 4 stages in LDS, filled by
+//     global_load_lds (16 B / lane, 4 per wave per stage) three steps ahead; counted s_waitcnt vmcnt,
+//     one raw s_barrier per step; 64-byte LDS rows XOR-swizzled through the per-lane SOURCE address so
+//     the ds_read_b128 fragment reads are conflict-free;
+//   * per step and wave: 2 K-slices of 32, each 4 fragment reads and 4 x v_mfma_i32_32x32x32_i8;
+//   * once per group (4 steps): acc_f32 += float(acc_i32) * gx[m] * gw[n]; the group scales arrive by
+//     global_load_lds too (2 per wave per group) -- no VGPR loads in the loop, so the compiler never
+//     drains the pipeline.
+// Roofline: int8 MFMA (2 * M * N * K ops); HBM traffic is the operands once per tile pass through L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "mi355q.h"
+#include "mi355q_internal.h"
+
+namespace mi355q {
+
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+constexpr int V3_BM = 128, V3_BN = 128, V3_BK = 64, V3_S = 4;
+constexpr int V3_A_BYTES = V3_BM * V3_BK, V3_B_BYTES = V3_BN * V3_BK, V3_STAGE = V3_A_BYTES + V3_B_BYTES;
+constexpr int V3_GA = V3_S * V3_STAGE;          // float ga[2][256] (first 128 of each used)
+constexpr int V3_GB = V3_GA + 2 * 256 * 4;      // float gb[2][256]
+constexpr int V3_LDS = V3_GB + 2 * 256 * 4;
+static_assert(2 * V3_LDS <= 160 * 1024, "two workgroups per CU");
+
+// 16-byte chunk c (0..3) of the 64-byte row r sits in slot c ^ ((r >> 2) & 3)
+__device__ __forceinline__ int v3_off(int r, int c) { return r * V3_BK + ((c ^ ((r >> 2) & 3)) << 4); }
+
+#define V3_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void bfp_gemm_v3(const GemmArgs a, const float* __restrict__ gx,
+                                                      const float* __restrict__ gw, long long mpad, long long npad,
+                                                      const int* __restrict__ xlist, const int* __restrict__ wlist,
+                                                      int list_cap) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[V3_LDS];
+    // too many unaligned row-groups for the sparse correction: the blockwise-fallback kernel runs instead
+    if (xlist && (xlist[0] > list_cap || wlist[0] > list_cap)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+
+    const int tiles_m = (int)((a.M + V3_BM - 1) / V3_BM), tiles_n = (int)((a.N + V3_BN - 1) / V3_BN);
+    const int nwg = tiles_m * tiles_n;
+    int pid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int GM = 8, in_group = GM * tiles_n, group_id = pid / in_group, first_m = group_id * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (pid % in_group) % gsz, tn = (pid % in_group) / gsz;
+    const long long m0 = (long long)tm * V3_BM, n0 = (long long)tn * V3_BN;
+    const int nsteps = (int)(a.K >> 6), ngroups = nsteps >> 2;
+
+    float acc[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- staging: the operands are stored tiled (mi355q_gemm.hip: tiled_offset) in 1-KiB pieces of
+    // 16 rows x 64 B that are already the swizzled LDS image: one global_load_lds copies one piece.
+    // A and B have 8 pieces per stage each, 2 + 2 per wave.
+    const int8_t* srcA[2];
+    const int8_t* srcB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        srcA[t] = a.xm + ((m0 >> 4) + wave + 4 * t) * (a.K >> 6) * 1024 + lane * 16;
+        srcB[t] = a.wm + ((n0 >> 4) + wave + 4 * t) * (a.K >> 6) * 1024 + lane * 16;
+    }
+    auto stage = [&](int step) {
+        unsigned char* base = smem + (step & (V3_S - 1)) * V3_STAGE;
+        const long long ko = (long long)step * 1024;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[t] + ko), (lptr_t)(base + (wave + 4 * t) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[t] + ko), (lptr_t)(base + V3_A_BYTES + (wave + 4 * t) * 1024),
+                                             16, 0, 0);
+        }
+    };
+    // group scales: one 1-KiB piece (256 floats, the tile's 128 + the next tile's) per operand and group
+    const float* gxs = gx + m0 + lane * 4;
+    const float* gws = gw + n0 + lane * 4;
+    auto stage_scales = [&](int g) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(gxs + (long long)g * mpad), (lptr_t)(smem + V3_GA + (g & 1) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gws + (long long)g * npad), (lptr_t)(smem + V3_GB + (g & 1) * 1024), 16, 0, 0);
+    };
+
+    const int arow = wm * 64 + lr, brow = wn * 64 + lr;
+    const int sx_base = wm * 64 + 4 * lh, sw_base = wn * 64 + lr;
+
+    stage(0);
+    if (nsteps > 1) stage(1);
+    if (nsteps > 2) stage(2);
+
+    for (int g = 0; g < ngroups; ++g) {
+        i32x16 ci[2][2];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int t = 4 * g + st;
+            // stage t must have landed; the 8 (10 right after a scale issue) younger loads may stay in flight
+            if (t + 2 < nsteps) {
+                if (st == 1 || st == 2) V3_WAIT(10); else V3_WAIT(8);
+            } else {
+                V3_WAIT(0);
+            }
+            if (DBG != 4 && DBG != 6) __builtin_amdgcn_s_barrier();
+            if (st == 0) stage_scales(g);
+            if (t + 3 < nsteps && DBG != 1 && DBG != 6) stage(t + 3);
+            const unsigned char* sa = smem + (t & (V3_S - 1)) * V3_STAGE;
+            const unsigned char* sb = sa + V3_A_BYTES;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                i32x4 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (DBG == 5 || DBG == 6) {
+                        fa[i] = i32x4{lane, p, i, t};
+                        fb[i] = i32x4{lane, i, p, t};
+                        asm volatile("" : "+v"(fa[i]), "+v"(fb[i]));
+                    } else {
+                        fa[i] = *reinterpret_cast<const i32x4*>(sa + v3_off(arow + i * 32, 2 * p + lh));
+                        fb[i] = *reinterpret_cast<const i32x4*>(sb + v3_off(brow + i * 32, 2 * p + lh));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (DBG == 2) {
+                            ci[i][j][0] = fa[i][0] + fb[j][1];
+                        } else if (st == 0 && p == 0) {
+                            const i32x16 z = {0};
+                            ci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], z, 0, 0, 0);
+                        } else {
+                            ci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], ci[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+        // ---- fold the group: scales of group g landed before the wait of its 4th step
+        if ((DBG == 3 || DBG == 6) && g + 1 < ngroups) continue;
+        const float* ga = reinterpret_cast<const float*>(smem + V3_GA) + (g & 1) * 256;
+        const float* gb = reinterpret_cast<const float*>(smem + V3_GB) + (g & 1) * 256;
+        float sw[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) sw[j] = gb[sw_base + j * 32];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&ga[sx_base + i * 32 + 8 * q]);
+                const float sx[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] += (float)ci[i][j][4 * q + r] * sx[r] * sw[j];
+            }
+    }
+
+    // ---- store: C/D layout col = lane & 31, row = 8*(reg>>2) + 4*(lane>>5) + (reg&3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long col = n0 + wn * 64 + j * 32 + lr;
+            if (col >= a.N) continue;
+            const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                if (row < a.M) a.y[row * a.ldy + col] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+
+// =======================================================================================
+// Variant 4: 256 x 128 workgroup tile (CU ingest per MAC 25 % below the 128 x 128 tile: the L2 -> LDS
+// path, ~30 B/clk/CU, is what bounds this kernel), 8 waves as 4 x 2 with 64 x 64 wave tiles, ONE
+// workgroup per CU.  Waves 4-7 (the second wave of each SIMD) run two K-steps behind waves 0-3, so a
+// wave-set folds its int32 group tile into fp32 (VALU) while the other set keeps the matrix pipe busy.
+// Six 24-KiB stages: a stage is written 3 intervals ahead, read by waves 0-3 in interval t and by
+// waves 4-7 in interval t+2.
+// =======================================================================================
+constexpr int V4_BM = 256, V4_BN = 128, V4_S = 6, V4_LAG = 2;
+constexpr int V4_A_BYTES = V4_BM * 64, V4_B_BYTES = V4_BN * 64, V4_STAGE = V4_A_BYTES + V4_B_BYTES;
+constexpr int V4_GA = V4_S * V4_STAGE;          // float ga[2][256]
+constexpr int V4_GB = V4_GA + 2 * 256 * 4;      // float gb[2][256] (first 128 used)
+constexpr int V4_LDS = V4_GB + 2 * 256 * 4;
+static_assert(V4_LDS <= 160 * 1024, "LDS budget");
+
+template <bool FIRST>
+__device__ __forceinline__ void v4_cluster(i32x16 (&ci)[2][2], const unsigned char* sa, const unsigned char* sb,
+                                           int arow, int brow, int lh) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        i32x4 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = *reinterpret_cast<const i32x4*>(sa + v3_off(arow + i * 32, 2 * p + lh));
+            fb[i] = *reinterpret_cast<const i32x4*>(sb + v3_off(brow + i * 32, 2 * p + lh));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (FIRST && p == 0) {
+                    const i32x16 z = {0};
+                    ci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], z, 0, 0, 0);
+                } else {
+                    ci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], ci[i][j], 0, 0, 0);
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void bfp_gemm_v4(const GemmArgs a, const float* __restrict__ gx,
+                                                      const float* __restrict__ gw, long long mpad, long long npad) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[V4_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wave & 3;                       // position inside the wave-set
+    const int lag = (wave >> 2) * V4_LAG;          // waves 4..7 run two steps behind
+    const int wm = (wave >> 2) * 2 + (ws >> 1), wn = ws & 1;    // set 0: rows 0-127, set 1: rows 128-255
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const int tiles_m = (int)((a.M + V4_BM - 1) / V4_BM), tiles_n = (int)((a.N + V4_BN - 1) / V4_BN);
+    const int nwg = tiles_m * tiles_n;
+    int pid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int GM = 4, in_group = GM * tiles_n, group_id = pid / in_group, first_m = group_id * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (pid % in_group) % gsz, tn = (pid % in_group) / gsz;
+    const long long m0 = (long long)tm * V4_BM, n0 = (long long)tn * V4_BN;
+    const int nsteps = (int)(a.K >> 6), ngroups = nsteps >> 2;
+
+    float acc[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    i32x16 ci[2][2];
+
+    // staging: 16 A pieces + 8 B pieces of 1 KiB per stage; wave w copies A pieces {w, w+8} and B piece {w}
+    const int8_t* srcA0 = a.xm + ((m0 >> 4) + wave) * (a.K >> 6) * 1024 + lane * 16;
+    const int8_t* srcA1 = a.xm + ((m0 >> 4) + wave + 8) * (a.K >> 6) * 1024 + lane * 16;
+    const int8_t* srcB0 = a.wm + ((n0 >> 4) + wave) * (a.K >> 6) * 1024 + lane * 16;
+    auto stage = [&](int step, int buf) {
+        unsigned char* base = smem + buf * V4_STAGE;
+        const long long ko = (long long)step * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA0 + ko), (lptr_t)(base + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA1 + ko), (lptr_t)(base + (wave + 8) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB0 + ko), (lptr_t)(base + V4_A_BYTES + wave * 1024), 16, 0, 0);
+    };
+    const float* gxs = gx + m0 + lane * 4;
+    const float* gws = gw + n0 + lane * 4;
+    auto stage_scales = [&](int g) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(gxs + (long long)g * mpad), (lptr_t)(smem + V4_GA + (g & 1) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gws + (long long)g * npad), (lptr_t)(smem + V4_GB + (g & 1) * 1024), 16, 0, 0);
+    };
+
+    const int arow = wm * 64 + lr, brow = wn * 64 + lr;
+    const int sx_base = wm * 64 + 4 * lh, sw_base = wn * 64 + lr;
+
+    stage(0, 0);
+    if (nsteps > 1) stage(1, 1);
+    if (nsteps > 2) stage(2, 2);
+    int ibuf = 3;                    // ring slot of the stage issued next
+    int rbuf = (V4_S - lag) % V4_S;  // ring slot this wave reads in the current interval (slot of step tau - lag)
+
+    const int nint = nsteps + V4_LAG;
+    for (int tau = 0; tau < nint; ++tau) {
+        // stage tau must have landed (own loads); younger loads may stay in flight
+        if (tau + 2 < nsteps) {
+            const int ph = tau & 3;
+            if (ph == 1 || ph == 2) V3_WAIT(8); else V3_WAIT(6);
+        } else {
+            V3_WAIT(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        if ((tau & 3) == 0 && (tau >> 2) < ngroups) stage_scales(tau >> 2);
+        if (tau + 3 < nsteps) {
+            stage(tau + 3, ibuf);
+            ibuf = ibuf + 1 == V4_S ? 0 : ibuf + 1;
+        }
+        const int t = tau - lag;
+        if (t >= 0 && t < nsteps) {
+            const unsigned char* sa = smem + rbuf * V4_STAGE;
+            const unsigned char* sb = sa + V4_A_BYTES;
+            const int st = t & 3;
+            if (st == 0) v4_cluster<true>(ci, sa, sb, arow, brow, lh);
+            else v4_cluster<false>(ci, sa, sb, arow, brow, lh);
+            if (st == 3) {
+                const int g = t >> 2;
+                const float* ga = reinterpret_cast<const float*>(smem + V4_GA) + (g & 1) * 256;
+                const float* gb = reinterpret_cast<const float*>(smem + V4_GB) + (g & 1) * 256;
+                float sw[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) sw[j] = gb[sw_base + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(&ga[sx_base + i * 32 + 8 * q]);
+                        const float sx[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] += (float)ci[i][j][4 * q + r] * sx[r] * sw[j];
+                    }
+            }
+        }
+        rbuf = rbuf + 1 == V4_S ? 0 : rbuf + 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long col = n0 + wn * 64 + j * 32 + lr;
+            if (col >= a.N) continue;
+            const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                if (row < a.M) a.y[row * a.ldy + col] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+int launch_bfp_gemm_v4(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
+                       hipStream_t st) {
+    const unsigned tiles = (unsigned)(((a.M + V4_BM - 1) / V4_BM) * ((a.N + V4_BN - 1) / V4_BN));
+    hipLaunchKernelGGL(bfp_gemm_v4, tiles, 512, 0, st, a, gx, gw, mpad, npad);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Sparse correction: the (row, group) pairs the align step could not put on one exponent carry scale 0
+// in the fast kernel; their exact contribution is added here from the (mant, eff_exp) arrays, which
+// hold the true values of every row-group.  One workgroup = one list entry x 256 rows of the other
+// operand; each thread forms 16 exact int8 block dots (v_dot4) and adds one fp32 value to y.
+//   x entry (m, g): y[m, n] += sum_b 2^(xe[m,b] + we[n,b] - bias) * dot16        for every n
+//   w entry (n, g): the same for every m whose (m, g) is aligned (the others were added by their x entry)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ long long tiled_off(long long row, long long k, long long K) {
+    const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
+    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ (int)((row >> 2) & 3);
+    return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
+}
+
+__global__ __launch_bounds__(256) void bfp_sparse_fix(const GemmArgs a, const uint8_t* __restrict__ xflag,
+                                                      const int* __restrict__ xlist, const int* __restrict__ wlist,
+                                                      int list_cap) {
+    __shared__ __attribute__((aligned(16))) int8_t s_m[256];
+    __shared__ int s_e[16];
+    const int cx = xlist[0], cw = wlist[0];
+    if (cx > list_cap || cw > list_cap) return;
+    const long long nkb = a.K >> 4, ngroups = (nkb + 15) >> 4;
+    const int tid = threadIdx.x;
+    for (int item = blockIdx.x; item < cx + cw; item += gridDim.x) {     // uniform over the workgroup
+        const bool is_x = item < cx;
+        const int e = is_x ? item : item - cx;
+        const int* lst = is_x ? xlist : wlist;
+        const long long row = lst[2 + 2 * e], g = lst[3 + 2 * e];
+        const int8_t* pm = is_x ? a.xm : a.wm;             // the listed operand
+        const uint8_t* pe = is_x ? a.xe : a.we;
+        const int8_t* qm = is_x ? a.wm : a.xm;             // the operand swept over its rows
+        const uint8_t* qe = is_x ? a.we : a.xe;
+        const long long qrows = is_x ? a.N : a.M;
+        __syncthreads();
+        // stage the listed row-group: 256 mantissa bytes + 16 exponents
+        s_m[tid] = pm[tiled_off(row, g * 256 + tid, a.K)];
+        if (tid < 16) s_e[tid] = pe[row * nkb + g * 16 + tid];
+        __syncthreads();
+        for (long long q = (long long)blockIdx.y * 256 + tid; q < qrows; q += (long long)gridDim.y * 256) {
+            if (!is_x && xflag[q * ngroups + g] == 0) continue;  // added by that row-group's own x entry
+            float sum = 0.f;
+#pragma unroll 4
+            for (int b = 0; b < 16; ++b) {
+                const int4 qv = *reinterpret_cast<const int4*>(qm + tiled_off(q, g * 256 + b * 16, a.K));
+                const int4 pv = *reinterpret_cast<const int4*>(&s_m[b * 16]);
+                int d = __builtin_amdgcn_sdot4(qv.x, pv.x, 0, false);
+                d = __builtin_amdgcn_sdot4(qv.y, pv.y, d, false);
+                d = __builtin_amdgcn_sdot4(qv.z, pv.z, d, false);
+                d = __builtin_amdgcn_sdot4(qv.w, pv.w, d, false);
+                sum += __builtin_ldexpf((float)d, s_e[b] + (int)qe[q * nkb + g * 16 + b] - a.scale_bias);
+            }
+            const long long m = is_x ? row : q, n = is_x ? q : row;
+            atomicAdd(&a.y[m * a.ldy + n], sum);
+        }
+    }
+}
+
+int launch_bfp_sparse_fix(const GemmArgs& a, const uint8_t* xflag, const int* xlist, const int* wlist, int list_cap,
+                          hipStream_t st) {
+    const long long span = a.M > a.N ? a.M : a.N;
+    long long chunks = (span + 255) / 256;
+    if (chunks > 16) chunks = 16;
+    dim3 grid(64, (unsigned)chunks);
+    (void)list_cap;
+    hipLaunchKernelGGL(bfp_sparse_fix, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap);
+    return (int)hipGetLastError();
+}
+
+int launch_bfp_gemm_v3(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
+                       const int* xlist, const int* wlist, int list_cap, hipStream_t st) {
+    const unsigned tiles = (unsigned)(((a.M + V3_BM - 1) / V3_BM) * ((a.N + V3_BN - 1) / V3_BN));
+    const char* dbg = getenv("MI355Q_V3_DBG");
+    const int d = dbg ? atoi(dbg) : 0;
+    if (d == 1) hipLaunchKernelGGL(bfp_gemm_v3<1>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    else if (d == 2) hipLaunchKernelGGL(bfp_gemm_v3<2>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    else if (d == 3) hipLaunchKernelGGL(bfp_gemm_v3<3>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    else if (d == 4) hipLaunchKernelGGL(bfp_gemm_v3<4>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    else if (d == 5) hipLaunchKernelGGL(bfp_gemm_v3<5>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    else if (d == 6) hipLaunchKernelGGL(bfp_gemm_v3<6>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    else hipLaunchKernelGGL(bfp_gemm_v3<0>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mi355q

@@ -39,9 +39,17 @@ struct GemmArgs {
     int scale_bias;   // subtracted from xe + we to get the power of two of a block product
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
-int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, int variant, hipStream_t st);
-int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, long long rows,
+int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
+                            const int* wlist, int list_cap, hipStream_t st);
+int launch_bfp_sparse_fix(const GemmArgs& a, const uint8_t* xflag, const int* xlist, const int* wlist, int list_cap,
+                          hipStream_t st);
+int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
+                     long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
                      long long K, hipStream_t st);
+int launch_bfp_gemm_v3(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
+                       const int* xlist, const int* wlist, int list_cap, hipStream_t st);
+int launch_bfp_gemm_v4(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
+                       hipStream_t st);
 
 }  // namespace mi355q
 #endif

@@ -24,11 +24,20 @@ SIGNATURES = {
     "mi355q_bfp_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                   _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_rowflag_bytes": (C.c_size_t, [_i64, _i64]),
-    "mi355q_bfp_align": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
-                                          _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_bfp_rows_pad": (_i64, [_i64]),
+    "mi355q_bfp_tiled_bytes": (C.c_size_t, [_i64, _i64]),
+    "mi355q_bfp_align": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp]),
+    "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_bfp_gemm_set_variant": (C.c_int, [C.c_int]),
 }
+
+
+class BfpOperand(C.Structure):
+    """struct mi355q_bfp_operand"""
+    _fields_ = [("mant", _vp), ("exp", _vp), ("rowflag", _vp), ("gscale", _vp), ("list", _vp),
+                ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32)]
+
+
 ABI_VERSION = 1
 WORKSPACE_BYTES = 256
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1

@@ -185,44 +185,64 @@ def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Ten
     return out
 
 
-def bfp_align(mant: torch.Tensor, exp: torch.Tensor, inplace: bool = False):
-    """Rewrite a packed [rows, K] operand into the exponent-aligned format of the fast GEMM.
-    -> (mant', exp', rowflag uint8 [rows, ceil(K/256)]); same values, see include/mi355q.h."""
+SPARSE_LIST_CAP = 2048
+
+
+class AlignedOperand:
+    """A packed block-fp operand rewritten for the fast GEMM (include/mi355q.h, mi355q_bfp_align):
+    exponent-aligned mantissas, effective exponents, per (row, group) flags and fp32 group scales,
+    and the list of row-groups that could not be aligned."""
+
+    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias):
+        self.rows, self.K = int(rows), int(K)
+        self.mant, self.tiled = mant, tiled          # row-major (may be None) / tiled (what the GEMM reads)
+        self.exp, self.rowflag, self.gscale, self.sparse = exp, rowflag, gscale, sparse
+        self.mbits, self.exp_bias = int(mbits), int(exp_bias)
+
+    def c_struct(self):
+        return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
+                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias)
+
+
+def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
+              keep_row_major: bool = False) -> AlignedOperand:
+    """Rewrite a packed [rows, K] operand into the exponent-aligned, tiled format of the fast GEMM
+    (same values).  K % 64 == 0.  `keep_row_major` also returns the aligned mantissas row-major."""
     if not mant.is_cuda:
         raise RuntimeError("mi355q.bfp_align: operands must be on a HIP device; there is no CPU fallback")
     rows, K = mant.shape
     assert mant.dtype == torch.int8 and exp.dtype == torch.uint8 and mant.is_contiguous() and exp.is_contiguous()
     assert exp.numel() == rows * (K // 16)
-    mo = mant if inplace else torch.empty_like(mant)
-    eo = exp if inplace else torch.empty_like(exp)
-    flag = torch.empty(rows, (K + 255) // 256, dtype=torch.uint8, device=mant.device)
     lib = _lib.load_library()
+    mo = (mant if inplace else torch.empty_like(mant)) if keep_row_major else None
+    eo = exp if inplace else torch.empty_like(exp)
+    tiled = torch.empty(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=mant.device)
+    groups = (K + 255) // 256
+    flag = torch.empty(rows, groups, dtype=torch.uint8, device=mant.device)
+    gscale = torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=mant.device)
+    sparse = torch.empty(2 + 2 * SPARSE_LIST_CAP, dtype=torch.int32, device=mant.device)
     with torch.cuda.device(mant.device):
-        rc = lib.mi355q_bfp_align(_ptr(mant), _ptr(exp), _ptr(mo), _ptr(eo), _ptr(flag), rows, K,
+        rc = lib.mi355q_bfp_align(_ptr(mant), _ptr(exp), _ptr(mo), _ptr(tiled), _ptr(eo), _ptr(flag), _ptr(gscale),
+                                  _ptr(sparse), SPARSE_LIST_CAP, int(exp_bias) + int(mbits), rows, K,
                                   _stream_ptr(mant.device))
     _lib.check(rc, "mi355q_bfp_align")
-    return mo, eo, flag
+    return AlignedOperand(rows, K, mo, tiled, eo, flag, gscale, sparse, mbits, exp_bias)
 
 
-def bfp_gemm_aligned(xm, xe, xf, wm, we, wf, bias, x_mbits: int, x_exp_bias: int, w_mbits: int, w_exp_bias: int,
-                     out: torch.Tensor = None):
-    """bfp_gemm on operands rewritten by bfp_align (flagged K-groups take the int32-chain path)."""
-    if not (xm.is_cuda and wm.is_cuda):
-        raise RuntimeError("mi355q.bfp_gemm_aligned: operands must be on a HIP device; there is no CPU fallback")
-    M, K = xm.shape
-    N = wm.shape[0]
-    assert wm.shape[1] == K and xm.dtype == torch.int8 and wm.dtype == torch.int8
-    assert xm.is_contiguous() and wm.is_contiguous() and xe.is_contiguous() and we.is_contiguous()
-    assert xf.shape == (M, (K + 255) // 256) and wf.shape == (N, (K + 255) // 256)
+def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):
+    """bfp_gemm on operands rewritten by bfp_align."""
+    M, K, N = x.rows, x.K, w.rows
+    assert w.K == K
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32, device=xm.device)
+        out = torch.empty(M, N, dtype=torch.float32, device=x.tiled.device)
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
     lib = _lib.load_library()
-    with torch.cuda.device(xm.device):
-        rc = lib.mi355q_bfp_gemm_aligned(_ptr(xm), _ptr(xe), _ptr(xf), _ptr(wm), _ptr(we), _ptr(wf), _ptr(bias),
-                                         _ptr(out), M, N, K, ldy, int(x_mbits), int(x_exp_bias), int(w_mbits),
-                                         int(w_exp_bias), _stream_ptr(xm.device))
+    xs, ws = x.c_struct(), w.c_struct()
+    import ctypes
+    with torch.cuda.device(x.tiled.device):
+        rc = lib.mi355q_bfp_gemm_aligned(ctypes.addressof(xs), ctypes.addressof(ws), _ptr(bias), _ptr(out), M, N, K,
+                                         ldy, _stream_ptr(x.tiled.device))
     _lib.check(rc, "mi355q_bfp_gemm_aligned")
     return out
 

@@ -74,7 +74,7 @@ class _LinearBase(nn.Linear):
         if self.arith != "block_fp" or not x.is_cuda or x.dtype != torch.float32 or x.ndim < 2:
             return None
         c, K = self.config, self.in_features
-        if K % 16 or not (2 <= c["data_in_width"] <= 8 and 2 <= c["weight_width"] <= 8):
+        if K % 64 or not (2 <= c["data_in_width"] <= 8 and 2 <= c["weight_width"] <= 8):
             return None
         if not (1 <= c["data_in_exponent_width"] <= 8 and 1 <= c["weight_exponent_width"] <= 8):
             return None
@@ -105,12 +105,14 @@ class _LinearBase(nn.Linear):
             self.bias.copy_(self.b_quantizer(self.bias.data))
         self.weight_requires_quantisation = False
         if pack:
-            wm, we, wf = ops.bfp_align(wm, we, inplace=True)
-            self._packed = (wm, we, self.weight._version, None if self.bias is None else self.bias._version, wf)
+            wb = c["weight_exponent_bias"]
+            wb = 2 ** (c["weight_exponent_width"] - 1) - 1 if wb in (None, "none", "None") else wb
+            wa = ops.bfp_align(wm, we, c["weight_width"] - 1, wb, inplace=True)
+            self._packed = (wa, wa.tiled, self.weight._version, None if self.bias is None else self.bias._version)
 
     def _packed_is_current(self) -> bool:
         p = self._packed
-        return (p is not None and p[2] == self.weight._version and p[0].device == self.weight.device
+        return (p is not None and p[2] == self.weight._version and p[1].device == self.weight.device
                 and (self.bias is None or p[3] == self.bias._version))
 
     def requantize(self):
@@ -143,9 +145,8 @@ class _LinearBase(nn.Linear):
         _, xm, xe = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"],
                                           c["data_in_exponent_bias"], [1, 16], True, want_fake=False,
                                           want_packed=True, fast_zero_blocks=True)
-        xm, xe, xf = ops.bfp_align(xm, xe, inplace=True)
-        wm, we, wf = self._packed[0], self._packed[1], self._packed[4]
-        y = ops.bfp_gemm_aligned(xm, xe, xf, wm, we, wf, self.bias, x_mbits, xb, w_mbits, wb)
+        xa = ops.bfp_align(xm, xe, x_mbits, xb, inplace=True)
+        y = ops.bfp_gemm_aligned(xa, self._packed[0], self.bias)
         return y.reshape(*x.shape[:-1], self.out_features)
 
     @classmethod

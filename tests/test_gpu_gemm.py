@@ -48,11 +48,10 @@ def _run(x, w, b, cfg, aligned=False):
     if b is not None:
         bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), cfg["bias_width"], 8, 127, [16], False)
     if aligned:
-        xm2, xe2, xf = ops.bfp_align(xm, xe)
-        wm2, we2, wf = ops.bfp_align(wm, we)
-        y = ops.bfp_gemm_aligned(xm2, xe2, xf, wm2, we2, wf, bq, cfg["data_in_width"] - 1, 127,
-                                 cfg["weight_width"] - 1, 127)
-        _run.last_flags = (float(xf.float().mean()), float(wf.float().mean()))
+        xa = ops.bfp_align(xm, xe, cfg["data_in_width"] - 1, 127)
+        wa = ops.bfp_align(wm, we, cfg["weight_width"] - 1, 127)
+        y = ops.bfp_gemm_aligned(xa, wa, bq)
+        _run.last_flags = (float(xa.rowflag.float().mean()), float(wa.rowflag.float().mean()))
     else:
         y = ops.bfp_gemm(xm, xe, wm, we, bq, cfg["data_in_width"] - 1, 127, cfg["weight_width"] - 1, 127)
     torch.cuda.synchronize()
@@ -107,7 +106,7 @@ def test_gemm_matches_reference_semantics_fp32_linear():
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 256), (256, 384, 512), (100, 72, 320), (33, 16, 64), (300, 130, 1024),
-                                   (64, 64, 48)])
+                                   (64, 64, 192)])
 @pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
 @pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
 def test_aligned_gemm_vs_oracle(M, N, K, style, wx, ww):
@@ -130,7 +129,8 @@ def test_align_is_value_preserving_and_flags_make_sense():
     x[:, 256:272] *= 300.0            # one block per row of group 1 far above its neighbours
     _, xm, xe = ops.block_fp_quantize(torch.from_numpy(x).to(dev), 6, 8, 127, [1, 16], True, want_fake=False,
                                       want_packed=True)
-    xm2, xe2, xf = ops.bfp_align(xm, xe)
+    al = ops.bfp_align(xm, xe, 5, 127, keep_row_major=True)
+    xm2, xe2, xf = al.mant, al.exp, al.rowflag
     v1 = xm.cpu().numpy().reshape(96, 64, 16).astype(np.float64) * np.exp2(xe.cpu().numpy().reshape(96, 64, 1).astype(np.float64))
     v2 = xm2.cpu().numpy().reshape(96, 64, 16).astype(np.float64) * np.exp2(xe2.cpu().numpy().reshape(96, 64, 1).astype(np.float64))
     assert np.array_equal(v1, v2)
@@ -140,6 +140,13 @@ def test_align_is_value_preserving_and_flags_make_sense():
     for g in (0, 2, 3):
         rows = f[:, g] == 1
         assert np.all(e2[rows, g, :] == e2[rows, g, :1]), "flagged row-groups must carry one exponent"
+    # fast-GEMM view: group scales (0 where unflagged) and the list of unflagged row-groups
+    gs = al.gscale.cpu().numpy()[:, :96].T
+    assert np.all(gs[f == 0] == 0) and np.array_equal(gs[f == 1], np.exp2(e2[:, :, 0].astype(np.float64) - 132)[f == 1])
+    lst = al.sparse.cpu().numpy()
+    assert lst[0] == (f == 0).sum()
+    got = set(map(tuple, lst[2:2 + 2 * lst[0]].reshape(-1, 2)))
+    assert got == set(zip(*np.nonzero(f == 0)))
 
 
 def test_aligned_gemm_uses_fast_path_on_benchmark_data():
