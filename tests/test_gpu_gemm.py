@@ -155,3 +155,20 @@ def test_aligned_gemm_uses_fast_path_on_benchmark_data():
     _run(x, w, b, _cfg(6, 6), aligned=True)
     fx, fw = _run.last_flags
     assert fx > 0.95 and fw > 0.95, (fx, fw)
+
+
+def test_aligned_gemm_overflowing_lists_take_the_fallback_kernel():
+    """more unaligned row-groups than the sparse lists hold: decided on the device, same result"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    r = np.random.default_rng(11)
+    M, N, K = 2304, 128, 512
+    x = r.normal(size=(M, K)).astype(np.float32)
+    x[:, 7::64] *= 500.0                       # every row-group of every row has a far-off block
+    w = (r.normal(size=(N, K)) * 0.02).astype(np.float32)
+    cfg = _cfg(6, 6)
+    y = _run(x, w, None, cfg, aligned=True)
+    assert _run.last_flags[0] < 0.05
+    ref = O.bfp_linear_int(x, w, None, cfg)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=4e-6 * np.abs(ref).max())

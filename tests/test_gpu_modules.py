@@ -39,8 +39,39 @@ def test_linear_ptq_golden(tag, has_bias, golden_modules):
         np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
         # far tighter than the 1e-3 contract
         np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5 * np.abs(ref).max())
-    if tag in ("bfp_6bit", "bfp_4bit", "block_fp"):
+    # in_features = 96 is not a multiple of 64: this layer takes the fake-quant + fp32 GEMM route
+    assert lin._packed is None
+
+
+@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 6)])
+@pytest.mark.parametrize("has_bias", [True, False])
+def test_linear_int8_path_vs_oracle(wx, ww, has_bias):
+    """in_features % 64 == 0: quantise+pack -> align -> int8-MFMA GEMM; 3-D input; in-place weight
+    overwrite bit-exact; output vs the oracle's exact integer contraction"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=wx, data_in_exponent_width=8,
+               data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=ww, weight_exponent_width=8,
+               weight_exponent_bias=None, weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8,
+               bias_exponent_bias=127, bias_block_size=[16])
+    torch.manual_seed(3)
+    fp = torch.nn.Linear(320, 200, bias=has_bias)
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    w0 = fp.weight.detach().numpy().copy()
+    b0 = fp.bias.detach().numpy().copy() if has_bias else None
+    x = torch.randn(2, 37, 320) * torch.exp(torch.randn(2, 37, 1))
+    x[..., 100:104] *= 400.0                 # outlier channels: unaligned row-groups -> sparse correction
+    ocfg = dict(cfg, weight_exponent_bias=127)
+    for call in range(2):
+        y = lin(x.to("cuda:0"))
         assert lin._packed is not None, "int8 MFMA path was not taken"
+        ref = O.bfp_linear_int(x.numpy().reshape(-1, 320), w0, b0, ocfg).reshape(2, 37, 200)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+    _, wq, bq = O.linear_ptq(x.numpy().reshape(-1, 320), w0, b0, ocfg)
+    assert np.array_equal(lin.weight.detach().cpu().numpy(), wq)
+    if has_bias:
+        assert np.array_equal(lin.bias.detach().cpu().numpy(), bq)
 
 
 @pytest.mark.parametrize("tag", TAGS)
