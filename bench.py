@@ -52,14 +52,23 @@ def cpu_baseline(torch):
     box's host cores, bounded to ~10-20 s: steady-state PTQ linear at the full 4096^3 size."""
     from oracle import torch_port as P
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     x, w, b = make_inputs(torch, "cpu", 0)
     wq = P.block_fp_quantize(w, 6, 8, 127, [1, 16], False)
     bq = P.block_fp_quantize(b, 6, 8, 127, [16], False)
-    t0 = time.perf_counter()
-    P.linear_ptq_step(x, wq, bq, CFG)
-    first = time.perf_counter() - t0
-    iters = max(2, min(10, int(12.0 / max(first, 1e-3))))
+    # torch's elementwise ops stop scaling (and regress) far below the box's core count: try a few
+    # thread counts once and time the fastest -- the fairest baseline this CPU gives
+    best = None
+    for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
+        torch.set_num_threads(nt)
+        P.linear_ptq_step(x[:512], wq, bq, CFG)
+        t0 = time.perf_counter()
+        P.linear_ptq_step(x, wq, bq, CFG)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    first, nt = best
+    torch.set_num_threads(nt)
+    iters = max(2, min(10, int(10.0 / max(first, 1e-3))))
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter()
@@ -116,9 +125,7 @@ def main():
     gemm_events = []
 
     def step(record=False):
-        _, xm, xe = ops.block_fp_quantize(x, xw, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
-                                          fast_zero_blocks=True)
-        xa = ops.bfp_align(xm, xe, xw - 1, 127, inplace=True)
+        xa = ops.block_fp_quantize_aligned(x, xw, 8, 127)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -161,7 +168,7 @@ def main():
             "scaling": "weak" if args.shard == "tokens" else "strong", "vs_baseline": None,
             "dtype": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 block scaling",
             "data": "synthetic",
-            "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> quantise+pack (W6, block [1,16]) -> exponent-align "
+            "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> fused quantise+pack+align (W6, block [1,16]) "
                                    "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32",
                        "M_per_gpu": M, "N": N, "K": K, "shard": args.shard,
                        "gemm_variant": ops.set_gemm_variant(args.variant)},

@@ -128,6 +128,15 @@ int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_
                      uint8_t* exp_out, uint8_t* rowflag, float* gscale, int32_t* list, int32_t list_cap,
                      int32_t exp_offset, int64_t rows, int64_t K, void* stream);
 
+/* Fused activation path: block_fp quantise ([1,16] blocks, MI355Q_ZERO_BLOCK_FAST semantics) + pack +
+ * align + tile in ONE pass over x [rows, K] fp32, K % 256 == 0.  Produces exactly what
+ * mi355q_block_fp_quantize followed by mi355q_bfp_align would (mant_tiled, exp_out, rowflag, gscale,
+ * list).  `list` must hold list[0] == 0 on entry: mi355q_bfp_gemm_aligned leaves it so when the
+ * operand's list_reset is 1; zero it yourself otherwise. */
+int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
+                                     float* gscale, int32_t* list, int32_t list_cap, int64_t rows, int64_t K,
+                                     int32_t width, int32_t exponent_width, int32_t exponent_bias, void* stream);
+
 /* An aligned operand as one argument */
 typedef struct mi355q_bfp_operand {
     const int8_t* mant;     /* tiled mantissas (mant_tiled of mi355q_bfp_align) */
@@ -138,6 +147,7 @@ typedef struct mi355q_bfp_operand {
     int32_t list_cap;
     int32_t mbits;          /* width - 1 */
     int32_t exp_bias;
+    int32_t list_reset;     /* 1: the GEMM resets list[0..1] to 0 when done (per-call activation lists) */
 } mi355q_bfp_operand;
 
 /* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align.

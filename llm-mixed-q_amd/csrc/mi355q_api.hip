@@ -161,6 +161,33 @@ int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_
                             list, list_cap, mant_tiled, rows, K, static_cast<hipStream_t>(stream));
 }
 
+int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
+                                     float* gscale, int32_t* list, int32_t list_cap, int64_t rows, int64_t K,
+                                     int32_t width, int32_t exponent_width, int32_t exponent_bias, void* stream) {
+    if (rows < 0 || K < 0 || list_cap < 0) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!x || !mant_tiled || !exp_out || !rowflag || !gscale || !list) return MI355Q_E_BADARG;
+    if (K % 256 != 0) return MI355Q_E_UNSUPPORTED;
+    if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 8) return MI355Q_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(mant_tiled) % 16) return MI355Q_E_ALIGN;
+    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    QuantArgs a{};
+    a.x = x;
+    a.code = exp_out;
+    a.lead = 1; a.rows = rows; a.cols = K;
+    a.b0 = 1; a.b1 = 16;
+    a.n_elems = rows * K;
+    a.nbr = rows; a.nbc = K / 16;
+    a.n_blocks = rows * (K / 16);
+    a.flags = MI355Q_ZERO_BLOCK_FAST;
+    a.code_bias = exponent_bias;
+    a.e_min = -exponent_bias;
+    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    set_mantissa(a, width - 1);
+    return launch_quant_align(a, mant_tiled, rowflag, gscale, mi355q_bfp_rows_pad(rows), exponent_bias + width - 1, list,
+                              list_cap, static_cast<hipStream_t>(stream));
+}
+
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
                             int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     if (!x || !w || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
@@ -177,18 +204,17 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     const long long mpad = mi355q_bfp_rows_pad(M), npad = mi355q_bfp_rows_pad(N);
     const bool chain_ok = x->gscale && w->gscale && K % 256 == 0;
     if (variant == 3 && chain_ok)   // int32-chain kernel alone, no correction (benchmarks only)
-        return launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
+        return launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, nullptr, nullptr, st);
     if (variant == 4 && chain_ok)
         return launch_bfp_gemm_v4(a, x->gscale, w->gscale, mpad, npad, st);
     if (variant == 2 || !chain_ok || !x->list || !w->list || x->list_cap != w->list_cap || x->list_cap <= 0)
-        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, nullptr, 0, st);
-    // default: int32-chain kernel + sparse correction; the blockwise-fallback kernel takes over (decided on
-    // the device) when either operand has more unaligned row-groups than the lists hold
-    int rc = launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, st);
+        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, st);
+    // default: int32-chain kernel + sparse correction; the same launch runs the blockwise-fallback body
+    // (decided on the device) when either operand has more unaligned row-groups than the lists hold
+    const int rc = launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, x->rowflag,
+                                      w->rowflag, st);
     if (rc) return rc;
-    rc = launch_bfp_sparse_fix(a, x->rowflag, x->list, w->list, x->list_cap, st);
-    if (rc) return rc;
-    return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
+    return launch_bfp_sparse_fix(a, x->rowflag, const_cast<int*>(x->list), w->list, x->list_cap, x->list_reset, st);
 }
 
 int mi355q_bfp_gemm_set_variant(int variant) { return g_gemm_variant.exchange(variant); }

@@ -26,13 +26,9 @@
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
+#include "mi355q_gemm_v2.h"
 
 namespace mi355q {
-
-using i32x16 = __attribute__((ext_vector_type(16))) int;
-using i32x4 = __attribute__((ext_vector_type(4))) int;
-using gptr_t = const __attribute__((address_space(1))) void*;
-using lptr_t = __attribute__((address_space(3))) void*;
 
 constexpr int V3_BM = 128, V3_BN = 128, V3_BK = 64, V3_S = 4;
 constexpr int V3_A_BYTES = V3_BM * V3_BK, V3_B_BYTES = V3_BN * V3_BK, V3_STAGE = V3_A_BYTES + V3_B_BYTES;
@@ -50,10 +46,16 @@ template <int DBG>
 __global__ __launch_bounds__(256, 2) void bfp_gemm_v3(const GemmArgs a, const float* __restrict__ gx,
                                                       const float* __restrict__ gw, long long mpad, long long npad,
                                                       const int* __restrict__ xlist, const int* __restrict__ wlist,
-                                                      int list_cap) {
+                                                      int list_cap, const uint8_t* __restrict__ xf,
+                                                      const uint8_t* __restrict__ wf) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[V3_LDS];
-    // too many unaligned row-groups for the sparse correction: the blockwise-fallback kernel runs instead
-    if (xlist && (xlist[0] > list_cap || wlist[0] > list_cap)) return;
+    static_assert(sizeof(V2Smem) <= V3_LDS, "the fallback body reuses this kernel's LDS");
+    // too many unaligned row-groups for the sparse correction (decided on the device, uniform over the
+    // grid): this launch runs the blockwise-fallback body instead; same 128 x 128 tiling and grid
+    if (xlist && (xlist[0] > list_cap || wlist[0] > list_cap)) {
+        bfp_gemm_v2_body(a, xf, wf, *reinterpret_cast<V2Smem*>(smem));
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -370,78 +372,100 @@ int launch_bfp_gemm_v4(const GemmArgs& a, const float* gx, const float* gw, long
 //   x entry (m, g): y[m, n] += sum_b 2^(xe[m,b] + we[n,b] - bias) * dot16        for every n
 //   w entry (n, g): the same for every m whose (m, g) is aligned (the others were added by their x entry)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ long long tiled_off(long long row, long long k, long long K) {
-    const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
-    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ (int)((row >> 2) & 3);
-    return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
-}
-
+template <int DBGFIX>
 __global__ __launch_bounds__(256) void bfp_sparse_fix(const GemmArgs a, const uint8_t* __restrict__ xflag,
-                                                      const int* __restrict__ xlist, const int* __restrict__ wlist,
-                                                      int list_cap) {
+                                                      int* __restrict__ xlist, const int* __restrict__ wlist,
+                                                      int list_cap, int reset_x) {
     __shared__ __attribute__((aligned(16))) int8_t s_m[256];
     __shared__ int s_e[16];
     const int cx = xlist[0], cw = wlist[0];
-    if (cx > list_cap || cw > list_cap) return;
-    const long long nkb = a.K >> 4, ngroups = (nkb + 15) >> 4;
     const int tid = threadIdx.x;
-    for (int item = blockIdx.x; item < cx + cw; item += gridDim.x) {     // uniform over the workgroup
-        const bool is_x = item < cx;
-        const int e = is_x ? item : item - cx;
-        const int* lst = is_x ? xlist : wlist;
-        const long long row = lst[2 + 2 * e], g = lst[3 + 2 * e];
-        const int8_t* pm = is_x ? a.xm : a.wm;             // the listed operand
-        const uint8_t* pe = is_x ? a.xe : a.we;
-        const int8_t* qm = is_x ? a.wm : a.xm;             // the operand swept over its rows
-        const uint8_t* qe = is_x ? a.we : a.xe;
-        const long long qrows = is_x ? a.N : a.M;
-        __syncthreads();
-        // stage the listed row-group: 256 mantissa bytes + 16 exponents
-        s_m[tid] = pm[tiled_off(row, g * 256 + tid, a.K)];
-        if (tid < 16) s_e[tid] = pe[row * nkb + g * 16 + tid];
-        __syncthreads();
-        for (long long q = (long long)blockIdx.y * 256 + tid; q < qrows; q += (long long)gridDim.y * 256) {
-            if (!is_x && xflag[q * ngroups + g] == 0) continue;  // added by that row-group's own x entry
-            float sum = 0.f;
-#pragma unroll 4
-            for (int b = 0; b < 16; ++b) {
-                const int4 qv = *reinterpret_cast<const int4*>(qm + tiled_off(q, g * 256 + b * 16, a.K));
-                const int4 pv = *reinterpret_cast<const int4*>(&s_m[b * 16]);
-                int d = __builtin_amdgcn_sdot4(qv.x, pv.x, 0, false);
-                d = __builtin_amdgcn_sdot4(qv.y, pv.y, d, false);
-                d = __builtin_amdgcn_sdot4(qv.z, pv.z, d, false);
-                d = __builtin_amdgcn_sdot4(qv.w, pv.w, d, false);
-                sum += __builtin_ldexpf((float)d, s_e[b] + (int)qe[q * nkb + g * 16 + b] - a.scale_bias);
+    if (cx <= list_cap && cw <= list_cap) {
+        const long long nkb = a.K >> 4, ngroups = (nkb + 15) >> 4;
+        const int lo = DBGFIX == 2 ? cx : 0, hi = DBGFIX == 1 ? cx : cx + cw;
+        for (int item = lo + blockIdx.x; item < hi; item += gridDim.x) {     // uniform over the workgroup
+            const bool is_x = item < cx;
+            const int e = is_x ? item : item - cx;
+            const int* lst = is_x ? xlist : wlist;
+            const long long row = lst[2 + 2 * e], g = lst[3 + 2 * e];
+            const int8_t* pm = is_x ? a.xm : a.wm;             // the listed operand
+            const uint8_t* pe = is_x ? a.xe : a.we;
+            const int8_t* qm = is_x ? a.wm : a.xm;             // the operand swept over its rows
+            const uint8_t* qe = is_x ? a.we : a.xe;
+            const long long qrows = is_x ? a.N : a.M;
+            __syncthreads();
+            s_m[tid] = pm[tiled_offset(row, g * 256 + tid, a.K)];
+            if (tid < 16) s_e[tid] = pe[row * nkb + g * 16 + tid];
+            __syncthreads();
+            for (long long q = (long long)blockIdx.y * 256 + tid; q < qrows; q += (long long)gridDim.y * 256) {
+                if (!is_x && xflag[q * ngroups + g] == 0) continue;   // unflagged x rows: added by their own entry
+                int4 qv[16];
+                const uint4* qx4 = reinterpret_cast<const uint4*>(qe + q * nkb + g * 16);
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    qv[b] = *reinterpret_cast<const int4*>(qm + tiled_offset(q, g * 256 + b * 16, a.K));
+                const uint4 qx = *qx4;
+                const unsigned qw[4] = {qx.x, qx.y, qx.z, qx.w};
+                float sum = 0.f;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int4 pv = *reinterpret_cast<const int4*>(&s_m[b * 16]);
+                    int d = __builtin_amdgcn_sdot4(qv[b].x, pv.x, 0, false);
+                    d = __builtin_amdgcn_sdot4(qv[b].y, pv.y, d, false);
+                    d = __builtin_amdgcn_sdot4(qv[b].z, pv.z, d, false);
+                    d = __builtin_amdgcn_sdot4(qv[b].w, pv.w, d, false);
+                    const int ecode = (int)((qw[b >> 2] >> (8 * (b & 3))) & 0xFF);
+                    sum += __builtin_ldexpf((float)d, s_e[b] + ecode - a.scale_bias);
+                }
+                if (sum != 0.f) {
+                    const long long m = is_x ? row : q, n = is_x ? q : row;
+                    atomicAdd(&a.y[m * a.ldy + n], sum);
+                }
             }
-            const long long m = is_x ? row : q, n = is_x ? q : row;
-            atomicAdd(&a.y[m * a.ldy + n], sum);
+        }
+    }
+    // the activation list is per call: the last workgroup out leaves it empty for the next align
+    if (reset_x) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned total = gridDim.x * gridDim.y;
+            const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&xlist[1]), 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+            if (t == total - 1) {
+                __hip_atomic_store(&xlist[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xlist[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
-int launch_bfp_sparse_fix(const GemmArgs& a, const uint8_t* xflag, const int* xlist, const int* wlist, int list_cap,
-                          hipStream_t st) {
+int launch_bfp_sparse_fix(const GemmArgs& a, const uint8_t* xflag, int* xlist, const int* wlist, int list_cap,
+                          int reset_x, hipStream_t st) {
     const long long span = a.M > a.N ? a.M : a.N;
     long long chunks = (span + 255) / 256;
     if (chunks > 16) chunks = 16;
     dim3 grid(64, (unsigned)chunks);
-    (void)list_cap;
-    hipLaunchKernelGGL(bfp_sparse_fix, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap);
+    const char* dbg = getenv("MI355Q_FIX_DBG");
+    const int d = dbg ? atoi(dbg) : 0;
+    if (d == 1) hipLaunchKernelGGL(bfp_sparse_fix<1>, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap, reset_x);
+    else if (d == 2) hipLaunchKernelGGL(bfp_sparse_fix<2>, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap, reset_x);
+    else hipLaunchKernelGGL(bfp_sparse_fix<0>, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap, reset_x);
     return (int)hipGetLastError();
 }
 
 int launch_bfp_gemm_v3(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
-                       const int* xlist, const int* wlist, int list_cap, hipStream_t st) {
+                       const int* xlist, const int* wlist, int list_cap, const uint8_t* xf, const uint8_t* wf,
+                       hipStream_t st) {
     const unsigned tiles = (unsigned)(((a.M + V3_BM - 1) / V3_BM) * ((a.N + V3_BN - 1) / V3_BN));
     const char* dbg = getenv("MI355Q_V3_DBG");
     const int d = dbg ? atoi(dbg) : 0;
-    if (d == 1) hipLaunchKernelGGL(bfp_gemm_v3<1>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
-    else if (d == 2) hipLaunchKernelGGL(bfp_gemm_v3<2>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
-    else if (d == 3) hipLaunchKernelGGL(bfp_gemm_v3<3>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
-    else if (d == 4) hipLaunchKernelGGL(bfp_gemm_v3<4>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
-    else if (d == 5) hipLaunchKernelGGL(bfp_gemm_v3<5>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
-    else if (d == 6) hipLaunchKernelGGL(bfp_gemm_v3<6>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
-    else hipLaunchKernelGGL(bfp_gemm_v3<0>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap);
+    if (d == 1) hipLaunchKernelGGL(bfp_gemm_v3<1>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap, xf, wf);
+    else if (d == 2) hipLaunchKernelGGL(bfp_gemm_v3<2>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap, xf, wf);
+    else if (d == 3) hipLaunchKernelGGL(bfp_gemm_v3<3>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap, xf, wf);
+    else if (d == 4) hipLaunchKernelGGL(bfp_gemm_v3<4>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap, xf, wf);
+    else if (d == 5) hipLaunchKernelGGL(bfp_gemm_v3<5>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap, xf, wf);
+    else if (d == 6) hipLaunchKernelGGL(bfp_gemm_v3<6>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap, xf, wf);
+    else hipLaunchKernelGGL(bfp_gemm_v3<0>, tiles, 256, 0, st, a, gx, gw, mpad, npad, xlist, wlist, list_cap, xf, wf);
     return (int)hipGetLastError();
 }
 

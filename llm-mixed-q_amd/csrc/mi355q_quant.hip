@@ -404,6 +404,88 @@ static int launch_format(const QuantArgs& a, bool needs_fixup, hipStream_t st) {
     return (int)e;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Fused activation path of the fast GEMM: block_fp quantise + pack + exponent-align + tile, one pass
+// over x (b0 = 1, b1 = 16, cols % 256 == 0).  One wave iteration = one (row, 256-value group): lane l
+// holds elements 4l..4l+3, block = l / 4.  Outputs are exactly what mi355q_bfp_align would produce from
+// the packed tensor (tests compare the two), with MI355Q_ZERO_BLOCK_FAST semantics for all-zero blocks:
+//   mt      tiled aligned mantissas (see mi355q_gemm.hip: tiled_offset)
+//   eo      effective exponent code per block, rowflag per (row, group), gscale fp32 per (group, row)
+//   list    (row, group) pairs that could not be aligned (count in list[0]; zero before the call)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ long long tiled_offset_q(long long row, long long k, long long K) {
+    const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
+    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ (int)((row >> 2) & 3);
+    return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
+}
+
+__global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a, int8_t* __restrict__ mt,
+                                                              uint8_t* __restrict__ flag, float* __restrict__ gscale,
+                                                              long long rows_pad, int exp_offset, int* __restrict__ list,
+                                                              int list_cap) {
+    __shared__ Lut lut;
+    load_lut<FMT_BFP>(lut);
+    const int lane = threadIdx.x & 63;
+    const long long K = a.cols, ngroups = K >> 8, nkb = K >> 4;
+    const long long npairs = a.rows * ngroups;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
+    for (long long pair = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; pair < npairs; pair += nwaves) {
+        const long long row = pair / ngroups, g = pair - row * ngroups;
+        const long long k = g * 256 + lane * 4;
+        const float4 v = x4[(row * K + k) >> 2];
+        float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        bmax = group_max<4>(bmax);
+        if (bmax == 0.f) bmax = 1.0f;
+        unsigned code;
+        const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
+        int q0, q1, q2, q3;
+        (void)quant_elem<FMT_BFP>(v.x, bp, a, lut, q0);
+        (void)quant_elem<FMT_BFP>(v.y, bp, a, lut, q1);
+        (void)quant_elem<FMT_BFP>(v.z, bp, a, lut, q2);
+        (void)quant_elem<FMT_BFP>(v.w, bp, a, lut, q3);
+        int amax = max(max(abs(q0), abs(q1)), max(abs(q2), abs(q3)));
+        amax = max(amax, __shfl_xor(amax, 1));
+        amax = max(amax, __shfl_xor(amax, 2));
+        const int e = (int)code;
+        const bool nz = amax > 0;
+        int emin = nz ? e : (1 << 20);
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) emin = min(emin, __shfl_xor(emin, off));
+        const int sft = nz ? e - emin : 0;
+        const bool ok = !nz || (sft <= 7 && (amax << sft) <= 127);
+        const bool all_ok = __all(ok);
+        int eout = e;
+        if (all_ok) {
+            q0 <<= sft; q1 <<= sft; q2 <<= sft; q3 <<= sft;
+            eout = emin == (1 << 20) ? e : emin;
+        }
+        *reinterpret_cast<unsigned*>(mt + tiled_offset_q(row, k, K)) =
+            (unsigned)(q0 & 0xFF) | ((unsigned)(q1 & 0xFF) << 8) | ((unsigned)(q2 & 0xFF) << 16) | ((unsigned)(q3 & 0xFF) << 24);
+        if ((lane & 3) == 0) a.code[row * nkb + g * 16 + (lane >> 2)] = (uint8_t)eout;
+        if (lane == 0) {
+            flag[row * ngroups + g] = all_ok ? 1 : 0;
+            gscale[g * rows_pad + row] = all_ok ? __builtin_ldexpf(1.0f, eout - exp_offset) : 0.0f;
+            if (!all_ok) {
+                const int at = atomicAdd(&list[0], 1);
+                if (at < list_cap) { list[2 + 2 * at] = (int)row; list[3 + 2 * at] = (int)g; }
+            }
+        }
+    }
+}
+
+int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
+                       int* list, int list_cap, hipStream_t st) {
+    const long long pairs = a.rows * (a.cols >> 8);
+    long long grid = (pairs + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(bfp_quant_align_kernel, (unsigned)grid, 256, 0, st, a, mt, flag, gscale, rows_pad, exp_offset, list,
+                       list_cap);
+    return (int)hipGetLastError();
+}
+
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st) {
     switch (fmt) {
         case FMT_BFP: return launch_format<FMT_BFP>(a, needs_fixup, st);

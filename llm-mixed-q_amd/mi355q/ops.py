@@ -193,15 +193,16 @@ class AlignedOperand:
     exponent-aligned mantissas, effective exponents, per (row, group) flags and fp32 group scales,
     and the list of row-groups that could not be aligned."""
 
-    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias):
+    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias, per_call=False):
         self.rows, self.K = int(rows), int(K)
+        self.per_call = bool(per_call)               # activation operand: the GEMM empties its list after use
         self.mant, self.tiled = mant, tiled          # row-major (may be None) / tiled (what the GEMM reads)
         self.exp, self.rowflag, self.gscale, self.sparse = exp, rowflag, gscale, sparse
         self.mbits, self.exp_bias = int(mbits), int(exp_bias)
 
     def c_struct(self):
         return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
-                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias)
+                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, int(self.per_call))
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
@@ -227,6 +228,51 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
                                   _stream_ptr(mant.device))
     _lib.check(rc, "mi355q_bfp_align")
     return AlignedOperand(rows, K, mo, tiled, eo, flag, gscale, sparse, mbits, exp_bias)
+
+
+class _ActivationBuffers:
+    """Reusable device buffers of the fused activation path, keyed by (device, stream, rows, K).  The
+    unaligned list starts zeroed and is emptied again by every GEMM that consumes it."""
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, device, rows, K):
+        key = (device.index, _stream_ptr(device), rows, K)
+        buf = cls._cache.get(key)
+        if buf is None:
+            lib = _lib.load_library()
+            groups = K // 256
+            buf = dict(
+                tiled=torch.empty(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=device),
+                exp=torch.empty(rows * (K // 16), dtype=torch.uint8, device=device),
+                flag=torch.empty(rows, groups, dtype=torch.uint8, device=device),
+                gscale=torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
+                sparse=torch.zeros(2 + 2 * SPARSE_LIST_CAP, dtype=torch.int32, device=device))
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            cls._cache[key] = buf
+        return buf
+
+
+def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, exponent_bias) -> AlignedOperand:
+    """Fused activation path: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack + align + tile in one
+    kernel (K % 256 == 0).  The returned operand lives in buffers that the next call with the same
+    shape on the same stream reuses: consume it (bfp_gemm_aligned) before quantising again."""
+    _require_device(x, "block_fp_quantize_aligned")
+    assert x.ndim == 2 and x.shape[1] % 256 == 0
+    rows, K = x.shape
+    xc = x.contiguous()
+    buf = _ActivationBuffers.get(x.device, rows, K)
+    bias = _default_bias(exponent_bias)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_block_fp_quantize_aligned(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
+                                                  _ptr(buf["gscale"]), _ptr(buf["sparse"]), SPARSE_LIST_CAP, rows, K,
+                                                  int(width), int(exponent_width), bias, _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_fp_quantize_aligned")
+    eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
+    return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], buf["sparse"],
+                          int(width) - 1, eb, per_call=True)
 
 
 def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):

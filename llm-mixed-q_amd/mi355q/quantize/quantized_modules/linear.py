@@ -142,10 +142,14 @@ class _LinearBase(nn.Linear):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
         x2 = x.reshape(-1, self.in_features)
-        _, xm, xe = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"],
-                                          c["data_in_exponent_bias"], [1, 16], True, want_fake=False,
-                                          want_packed=True, fast_zero_blocks=True)
-        xa = ops.bfp_align(xm, xe, x_mbits, xb, inplace=True)
+        if self.in_features % 256 == 0:      # one fused kernel: quantise + pack + align + tile
+            xa = ops.block_fp_quantize_aligned(x2, c["data_in_width"], c["data_in_exponent_width"],
+                                               c["data_in_exponent_bias"])
+        else:
+            _, xm, xe = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"],
+                                              c["data_in_exponent_bias"], [1, 16], True, want_fake=False,
+                                              want_packed=True, fast_zero_blocks=True)
+            xa = ops.bfp_align(xm, xe, x_mbits, xb, inplace=True)
         y = ops.bfp_gemm_aligned(xa, self._packed[0], self.bias)
         return y.reshape(*x.shape[:-1], self.out_features)
 

@@ -172,3 +172,34 @@ def test_aligned_gemm_overflowing_lists_take_the_fallback_kernel():
     assert _run.last_flags[0] < 0.05
     ref = O.bfp_linear_int(x, w, None, cfg)
     np.testing.assert_allclose(y, ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("style", ["rowscale", "outlier", "sparse"])
+@pytest.mark.parametrize("width", [6, 4, 8])
+def test_fused_quantize_align_equals_two_step(style, width):
+    """mi355q_block_fp_quantize_aligned == mi355q_block_fp_quantize (fast zero blocks) + mi355q_bfp_align"""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    x, _, _ = _inputs(200, 8, 1024, 31 + width, style)
+    xt = torch.from_numpy(x).to(dev)
+    _, xm, xe = ops.block_fp_quantize(xt, width, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
+                                      fast_zero_blocks=True)
+    ref = ops.bfp_align(xm, xe, width - 1, 127)
+    got = ops.block_fp_quantize_aligned(xt, width, 8, 127)
+    torch.cuda.synchronize()
+    assert torch.equal(got.tiled[: 208 * 1024], ref.tiled[: 208 * 1024]) or \
+        torch.equal(got.tiled.view(-1, 1024)[: (200 // 16) * 16], ref.tiled.view(-1, 1024)[: (200 // 16) * 16])
+    assert torch.equal(got.exp, ref.exp.reshape(-1)) and torch.equal(got.rowflag, ref.rowflag)
+    assert torch.equal(got.gscale[:, :200], ref.gscale[:, :200])
+    n = int(ref.sparse[0])
+    assert int(got.sparse[0]) == n
+    a = set(map(tuple, got.sparse[2:2 + 2 * n].cpu().numpy().reshape(-1, 2)))
+    b = set(map(tuple, ref.sparse[2:2 + 2 * n].cpu().numpy().reshape(-1, 2)))
+    assert a == b
+    # consume it so that the per-call list is emptied, then check that it was
+    _, wm, we = ops.block_fp_quantize(torch.randn(64, 1024, device=dev) * 0.02, 6, 8, 127, [1, 16], False,
+                                      want_fake=False, want_packed=True)
+    ops.bfp_gemm_aligned(got, ops.bfp_align(wm, we, 5, 127))
+    torch.cuda.synchronize()
+    assert int(got.sparse[0]) == 0 and int(got.sparse[1]) == 0
