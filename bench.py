@@ -120,7 +120,7 @@ def main():
     bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
     n_out = w.shape[0]
     y = torch.empty(M, n_out, dtype=torch.float32, device=device)
-    gathered = torch.empty(world, M, n_out, dtype=torch.float32, device=device) if (args.shard == "out_features" and world > 1) else None
+    gathered = torch.empty(world * M, n_out, dtype=torch.float32, device=device) if (args.shard == "out_features" and world > 1) else None
 
     gemm_events = []
 

@@ -1,0 +1,64 @@
+"""Row-sharded quantised Linear over the GPUs of one node (BASELINE north_star:
+"partition the per-layer GEMMs row-wise across the 8 GPUs with RCCL all-gather only for OPT/Llama >= 1.3B").
+
+W [O, K] is split by ROWS (out_features): weight blocks are [1,16] along K, so a row split never cuts a
+block and every shard's exponents / mantissas are bit-identical to the unsharded layer's; bias blocks
+[16] along O stay whole when O / P is a multiple of the bias block.  The activation is replicated; each
+rank quantises it (O(M K), redundant) and computes y[:, shard] with the int8-MFMA path; ONE collective --
+all-gather of the fp32 output shards (torch.distributed backend "nccl" = RCCL over xGMI on ROCm; "gloo"
+in the CPU tests) -- rebuilds y.  Message size: M x O/P fp32 per rank (4096 x 512 x 4 B = 8 MiB at P = 8).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def shard_bounds(out_features: int, rank: int, world: int, multiple_of: int = 16) -> tuple[int, int]:
+    """[lo, hi) of rank's rows.  Shards must be equal and whole bias blocks (all BASELINE shapes are)."""
+    if out_features % world:
+        raise ValueError(f"out_features={out_features} is not divisible by world size {world}")
+    per = out_features // world
+    if per % multiple_of:
+        raise ValueError(f"shard of {per} rows would cut a bias block of {multiple_of}")
+    return rank * per, (rank + 1) * per
+
+
+class RowShardedLinear(nn.Module):
+    """Wraps this rank's shard of a (quantised) Linear.  `local` is any module mapping [..., K] -> [..., O/P]."""
+
+    def __init__(self, local: nn.Module, out_features: int, group=None):
+        super().__init__()
+        self.local = local
+        self.out_features = out_features
+        self.group = group
+
+    @classmethod
+    def from_full(cls, cls_quantized, linear_fp32: nn.Linear, config: dict, group=None):
+        """Build this rank's shard from the full-precision layer (every rank holds the checkpoint)."""
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        bias_block = 16
+        if linear_fp32.bias is not None and not config.get("bypass", False) and "bias_block_size" in config:
+            bs = config["bias_block_size"]
+            bias_block = int(bs[-1] if isinstance(bs, (list, tuple)) else bs)
+        lo, hi = shard_bounds(linear_fp32.out_features, rank, world, bias_block)
+        part = nn.Linear(linear_fp32.in_features, hi - lo, bias=linear_fp32.bias is not None)
+        with torch.no_grad():
+            part.weight.copy_(linear_fp32.weight[lo:hi])
+            if part.bias is not None:
+                part.bias.copy_(linear_fp32.bias[lo:hi])
+        local = cls_quantized.from_float(part, config).to(linear_fp32.weight.device)
+        return cls(local, linear_fp32.out_features, group)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y_loc = self.local(x)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return y_loc
+        lead = y_loc.shape[:-1]
+        y2 = y_loc.detach().reshape(-1, y_loc.shape[-1]).contiguous()     # inference path: no autograd through the collective
+        gathered = torch.empty(world * y2.shape[0], y2.shape[1], dtype=y2.dtype, device=y2.device)
+        dist.all_gather_into_tensor(gathered, y2, group=self.group)          # rank-major: [P * M, O/P]
+        return gathered.view(world, y2.shape[0], y2.shape[1]).permute(1, 0, 2).reshape(*lead, self.out_features)
