@@ -1,0 +1,136 @@
+"""Minimal OPT-style decoder harness over the registry API, and the perplexity loop.
+
+NOT a port of the reference's HF model files (those are callers of the path and out of scope,
+SURVEY.md section 2 rows 8-9): this is just enough model to drive the hot path the way
+`OPTQuantizedDecoderLayer` does -- q/k/v/out_proj, fc1, fc2 through `get_quantized_cls("linear")`,
+the two attention products through `get_quantized_func("bmm")`, 3-D inputs into the attention
+projections, 2-D into the MLP, an unquantised lm_head (reference modeling_opt.py:143-330, 333-441,
+934-1109) -- so that loss / perplexity parity of the HIP path can be checked on model-shaped random
+weights (no checkpoint or Wikitext2 copy exists in this environment).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .quantize import get_quantized_cls, get_quantized_func, parse_node_config
+
+
+@dataclass
+class TinyOPTConfig:
+    vocab_size: int = 512
+    hidden_size: int = 256
+    ffn_dim: int = 1024
+    num_layers: int = 2
+    num_heads: int = 4
+    max_positions: int = 128
+    init_std: float = 0.02        # HF OPT initializer range (modeling_opt.py:472-477)
+
+
+def expand_quant_config(default: dict, num_layers: int) -> dict:
+    """[default] -> model_layer_i x {q,k,v,out_proj,bmm_0,bmm_1,fc1,fc2}, each through parse_node_config
+    (what reference quant_config_opt.py:45-97 does for a TOML with only a [default] section)."""
+    out = {}
+    for i in range(num_layers):
+        attn = {k: parse_node_config(dict(default), "linear") for k in ("q_proj", "k_proj", "v_proj", "out_proj")}
+        attn["bmm_0"] = parse_node_config(dict(default), "bmm")
+        attn["bmm_1"] = parse_node_config(dict(default), "bmm")
+        out[f"model_layer_{i}"] = {"self_attn": attn, "fc1": parse_node_config(dict(default), "linear"),
+                                   "fc2": parse_node_config(dict(default), "linear")}
+    return out
+
+
+class _Attention(nn.Module):
+    def __init__(self, cfg: TinyOPTConfig, qc: dict):
+        super().__init__()
+        self.h, self.nh, self.hd = cfg.hidden_size, cfg.num_heads, cfg.hidden_size // cfg.num_heads
+        self.scaling = self.hd ** -0.5
+        self.qc = qc
+        for name in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            setattr(self, name, get_quantized_cls("linear", qc[name])(self.h, self.h, bias=True, config=qc[name]))
+
+    def forward(self, x, mask):
+        B, T, _ = x.shape
+        shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2).contiguous().view(B * self.nh, T, self.hd)
+        q = shape(self.q_proj(x) * self.scaling)
+        k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
+        w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
+        w = w.view(B, self.nh, T, T) + mask
+        w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device)).view(B * self.nh, T, T)
+        p = F.softmax(w, dim=-1)
+        o = get_quantized_func("bmm", self.qc["bmm_1"])(p, v, config=self.qc["bmm_1"])
+        o = o.view(B, self.nh, T, self.hd).transpose(1, 2).reshape(B, T, self.h)
+        return self.out_proj(o)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, cfg: TinyOPTConfig, qc: dict):
+        super().__init__()
+        self.self_attn = _Attention(cfg, qc["self_attn"])
+        self.self_attn_layer_norm = nn.LayerNorm(cfg.hidden_size)
+        self.final_layer_norm = nn.LayerNorm(cfg.hidden_size)
+        self.fc1 = get_quantized_cls("linear", qc["fc1"])(cfg.hidden_size, cfg.ffn_dim, bias=True, config=qc["fc1"])
+        self.fc2 = get_quantized_cls("linear", qc["fc2"])(cfg.ffn_dim, cfg.hidden_size, bias=True, config=qc["fc2"])
+
+    def forward(self, x, mask):
+        x = x + self.self_attn(self.self_attn_layer_norm(x), mask)
+        shape = x.shape
+        h = x.reshape(-1, shape[-1])                       # the MLP sees a 2-D activation (modeling_opt.py:412)
+        h = h + self.fc2(F.relu(self.fc1(self.final_layer_norm(h))))
+        return h.view(shape)
+
+
+class TinyOPTForCausalLM(nn.Module):
+    def __init__(self, cfg: TinyOPTConfig, quant_config: dict):
+        super().__init__()
+        self.cfg = cfg
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.embed_positions = nn.Embedding(cfg.max_positions, cfg.hidden_size)
+        self.layers = nn.ModuleList(_DecoderLayer(cfg, quant_config[f"model_layer_{i}"]) for i in range(cfg.num_layers))
+        self.final_layer_norm = nn.LayerNorm(cfg.hidden_size)
+        self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)     # not quantised (modeling_opt.py:942-944)
+        self.apply(self._init)
+
+    def _init(self, m):
+        if isinstance(m, nn.Linear):
+            m.weight.data.normal_(0.0, self.cfg.init_std)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, nn.Embedding):
+            m.weight.data.normal_(0.0, self.cfg.init_std)
+
+    def forward(self, input_ids, labels=None):
+        B, T = input_ids.shape
+        pos = torch.arange(T, device=input_ids.device)
+        x = self.embed_tokens(input_ids) + self.embed_positions(pos)[None]
+        mask = torch.full((T, T), torch.finfo(x.dtype).min, device=x.device).triu(1)[None, None]
+        for layer in self.layers:
+            x = layer(x, mask)
+        logits = self.lm_head(self.final_layer_norm(x))
+        loss = None
+        if labels is not None:
+            loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1))
+        return logits, loss
+
+
+@torch.no_grad()
+def eval_lm_perplexity(model, batches, device=None):
+    """Reference eval/eval_lm.py:41-63: per batch loss * batch * seq_len summed, ppl = exp(sum / tokens)."""
+    total, num_samples, seq_len, batch_size = 0.0, 0, None, None
+    for input_ids in batches:
+        if device is not None:
+            input_ids = input_ids.to(device)
+        batch_size, seq_len = input_ids.shape
+        _, loss = model(input_ids, labels=input_ids)
+        total += loss.item() * batch_size * seq_len
+        num_samples += batch_size
+    reduced = total / (seq_len * num_samples)
+    try:
+        ppl = math.exp(reduced)
+    except OverflowError:
+        ppl = float("inf")
+    return {"loss": reduced, "perplexity": ppl, "num_samples": num_samples, "seq_len": seq_len, "batch_size": batch_size}
