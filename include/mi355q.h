@@ -131,11 +131,14 @@ int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_
 /* Fused activation path: block_fp quantise ([1,16] blocks, MI355Q_ZERO_BLOCK_FAST semantics) + pack +
  * align + tile in ONE pass over x [rows, K] fp32, K % 256 == 0.  Produces exactly what
  * mi355q_block_fp_quantize followed by mi355q_bfp_align would (mant_tiled, exp_out, rowflag, gscale,
- * list).  `list` must hold list[0] == 0 on entry: mi355q_bfp_gemm_aligned leaves it so when the
- * operand's list_reset is 1; zero it yourself otherwise. */
+ * list).  `list` must hold list[0] == 0 on entry.  Two ways to keep it so without a memset per call:
+ * alternate between two lists and pass the OTHER one as `list_to_clear` (this kernel zeroes its count for
+ * the next call -- safe on one stream, where the previous consumer of that list has finished); or set
+ * the operand's list_reset = 1 so that mi355q_bfp_gemm_aligned empties the list it consumed. */
 int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
-                                     float* gscale, int32_t* list, int32_t list_cap, int64_t rows, int64_t K,
-                                     int32_t width, int32_t exponent_width, int32_t exponent_bias, void* stream);
+                                     float* gscale, int32_t* list, int32_t list_cap, int32_t* list_to_clear,
+                                     int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                     int32_t exponent_bias, void* stream);
 
 /* An aligned operand as one argument */
 typedef struct mi355q_bfp_operand {

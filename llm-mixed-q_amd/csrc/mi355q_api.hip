@@ -162,8 +162,9 @@ int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_
 }
 
 int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
-                                     float* gscale, int32_t* list, int32_t list_cap, int64_t rows, int64_t K,
-                                     int32_t width, int32_t exponent_width, int32_t exponent_bias, void* stream) {
+                                     float* gscale, int32_t* list, int32_t list_cap, int32_t* list_to_clear,
+                                     int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                     int32_t exponent_bias, void* stream) {
     if (rows < 0 || K < 0 || list_cap < 0) return MI355Q_E_BADARG;
     if (rows == 0 || K == 0) return 0;
     if (!x || !mant_tiled || !exp_out || !rowflag || !gscale || !list) return MI355Q_E_BADARG;
@@ -184,8 +185,9 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
     a.e_min = -exponent_bias;
     a.e_max = (1 << exponent_width) - 1 - exponent_bias;
     set_mantissa(a, width - 1);
+    if (list_to_clear == list) return MI355Q_E_BADARG;
     return launch_quant_align(a, mant_tiled, rowflag, gscale, mi355q_bfp_rows_pad(rows), exponent_bias + width - 1, list,
-                              list_cap, static_cast<hipStream_t>(stream));
+                              list_cap, list_to_clear, static_cast<hipStream_t>(stream));
 }
 
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
@@ -205,16 +207,29 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     const bool chain_ok = x->gscale && w->gscale && K % 256 == 0;
     if (variant == 3 && chain_ok)   // int32-chain kernel alone, no correction (benchmarks only)
         return launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, nullptr, nullptr, st);
+    if (variant == 7 && chain_ok)
+        return launch_bfp_gemm_v7(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
+    if (variant == 6 && chain_ok)
+        return launch_bfp_gemm_v6(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
+    if (variant == 5 && chain_ok)
+        return launch_bfp_gemm_v5(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
     if (variant == 4 && chain_ok)
         return launch_bfp_gemm_v4(a, x->gscale, w->gscale, mpad, npad, st);
     if (variant == 2 || !chain_ok || !x->list || !w->list || x->list_cap != w->list_cap || x->list_cap <= 0)
-        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, st);
-    // default: int32-chain kernel + sparse correction; the same launch runs the blockwise-fallback body
-    // (decided on the device) when either operand has more unaligned row-groups than the lists hold
-    const int rc = launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, x->rowflag,
-                                      w->rowflag, st);
+        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, nullptr, 0, st);
+    // default: int32-chain kernel + sparse correction.  When either operand has more unaligned row-groups than
+    // the lists hold, both return at once and the blockwise-fallback kernel does the whole product instead
+    // (the choice is made on the device, from the list counts; the fallback returns at once otherwise).
+    int rc;
+    if (variant == 30)      // 128 x 128 tile flavour with the fallback body in the same launch
+        rc = launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, x->rowflag,
+                                w->rowflag, st);
+    else
+        rc = launch_bfp_gemm_v6(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, st);
     if (rc) return rc;
-    return launch_bfp_sparse_fix(a, x->rowflag, const_cast<int*>(x->list), w->list, x->list_cap, x->list_reset, st);
+    rc = launch_bfp_sparse_fix(a, x->rowflag, const_cast<int*>(x->list), w->list, x->list_cap, x->list_reset, st);
+    if (rc || variant == 30) return rc;
+    return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
 }
 
 int mi355q_bfp_gemm_set_variant(int variant) { return g_gemm_variant.exchange(variant); }

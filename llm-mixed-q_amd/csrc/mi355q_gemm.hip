@@ -200,8 +200,11 @@ __global__ __launch_bounds__(256) void bfp_align_kernel(const int8_t* __restrict
 }
 
 __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const uint8_t* __restrict__ xf,
-                                                      const uint8_t* __restrict__ wf) {
+                                                      const uint8_t* __restrict__ wf, const int* __restrict__ xlist,
+                                                      const int* __restrict__ wlist, int list_cap) {
     __shared__ V2Smem sm;
+    // as the fallback of the int32-chain kernel: run only when an unaligned list overflowed
+    if (xlist && xlist[0] <= list_cap && wlist[0] <= list_cap) return;
     bfp_gemm_v2_body(a, xf, wf, sm);
 }
 
@@ -221,9 +224,10 @@ int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* e
     return (int)hipGetLastError();
 }
 
-int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, hipStream_t st) {
+int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
+                            const int* wlist, int list_cap, hipStream_t st) {
     const unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
-    hipLaunchKernelGGL(bfp_gemm_v2, tiles, 256, 0, st, a, xf, wf);
+    hipLaunchKernelGGL(bfp_gemm_v2, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap);
     return (int)hipGetLastError();
 }
 

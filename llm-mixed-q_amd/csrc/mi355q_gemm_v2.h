@@ -18,11 +18,12 @@ using lptr_t = __attribute__((address_space(3))) void*;
 constexpr int ALIGN_G = 16;   // blocks per alignment group (256 values)
 
 // Tiled mantissa layout of an aligned operand: 1-KiB pieces of 16 rows x 64 K-bytes, piece index
-// (row/16) * (K/64) + k/64; inside a piece row r's 16-byte chunk c sits in slot c ^ ((row >> 2) & 3)
+// (row/16) * (K/64) + k/64; inside a piece row r's 16-byte chunk c sits in slot c ^ h((row >> 2) & 3), h = [0,2,3,1]
+// (bank-conflict free for the ds_read_b128 fragment reads of both the 32x32x32 and the 16x16x64 MFMA)
 // -- the LDS image of the GEMM kernels, so that one global_load_lds copies one piece linearly.
 __device__ __forceinline__ long long tiled_offset(long long row, long long k, long long K) {
     const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
-    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ (int)((row >> 2) & 3);
+    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3);
     return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
 }
 
@@ -44,7 +45,7 @@ struct V2Smem {
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-__device__ __forceinline__ int v2_off(int r, int c) { return r * V2_BK + ((c ^ ((r >> 2) & 3)) << 4); }
+__device__ __forceinline__ int v2_off(int r, int c) { return r * V2_BK + ((c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 4); }
 
 __device__ __forceinline__ void bfp_gemm_v2_body(const GemmArgs& a, const uint8_t* __restrict__ xf,
                                                  const uint8_t* __restrict__ wf, V2Smem& sm) {

@@ -27,7 +27,7 @@ struct QuantArgs {
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
 int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
-                       int* list, int list_cap, hipStream_t st);
+                       int* list, int list_cap, int* list_to_clear, hipStream_t st);
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {
@@ -41,7 +41,8 @@ struct GemmArgs {
     int scale_bias;   // subtracted from xe + we to get the power of two of a block product
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
-int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, hipStream_t st);
+int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
+                            const int* wlist, int list_cap, hipStream_t st);
 int launch_bfp_sparse_fix(const GemmArgs& a, const uint8_t* xflag, int* xlist, const int* wlist, int list_cap,
                           int reset_x, hipStream_t st);
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
@@ -50,6 +51,12 @@ int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* e
 int launch_bfp_gemm_v3(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
                        const int* xlist, const int* wlist, int list_cap, const uint8_t* xf, const uint8_t* wf,
                        hipStream_t st);
+int launch_bfp_gemm_v5(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
+                       const int* xlist, const int* wlist, int list_cap, hipStream_t st);
+int launch_bfp_gemm_v6(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
+                       const int* xlist, const int* wlist, int list_cap, hipStream_t st);
+int launch_bfp_gemm_v7(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
+                       const int* xlist, const int* wlist, int list_cap, hipStream_t st);
 int launch_bfp_gemm_v4(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
                        hipStream_t st);
 

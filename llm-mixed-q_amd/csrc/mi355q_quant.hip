@@ -416,73 +416,108 @@ static int launch_format(const QuantArgs& a, bool needs_fixup, hipStream_t st) {
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ long long tiled_offset_q(long long row, long long k, long long K) {
     const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
-    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ (int)((row >> 2) & 3);
+    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3);
     return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
+}
+
+// DPP helpers on ints: rotate within a row of 16 lanes
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+
+// ceil(log2(v)) for finite v > 0 without branches: v_frexp splits normals and subnormals alike
+__device__ __forceinline__ int ceil_log2_frexp(float v, const Lut& lut) {
+    const int k = __builtin_amdgcn_frexp_expf(v) - 1;                                   // v = 2^k (1 + m 2^-23)
+    const unsigned m = __float_as_uint(__builtin_amdgcn_frexp_mantf(v)) & 0x7FFFFFu;
+    return k + ((m != 0u && m >= lut.a[lut_index(k)]) ? 1 : 0);
+}
+// signed integer mantissa of one element (block_fp.py:69-79): sign(x+1e-9) * min(rne((|x|+1e-9) 2^(mb-e)), 2^mb-1)
+__device__ __forceinline__ float mant_f(float x, int up, float mmax) {
+    const float t = x + EPS9;
+    const float m = fminf(__builtin_rintf(__builtin_ldexpf(fabsf(x) + EPS9, up)), mmax);
+    const float sm = __builtin_copysignf(m, t);
+    return t == 0.f ? 0.f : sm;
 }
 
 __global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                               uint8_t* __restrict__ flag, float* __restrict__ gscale,
                                                               long long rows_pad, int exp_offset, int* __restrict__ list,
-                                                              int list_cap) {
+                                                              int list_cap, int* __restrict__ list_to_clear) {
     __shared__ Lut lut;
     load_lut<FMT_BFP>(lut);
     const int lane = threadIdx.x & 63;
-    const long long K = a.cols, ngroups = K >> 8, nkb = K >> 4;
+    if (list_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { list_to_clear[0] = 0; list_to_clear[1] = 0; }
+    const long long K = a.cols;
+    const int ngroups = (int)(K >> 8), nkb = (int)(K >> 4), kpieces = (int)(K >> 6);
     const long long npairs = a.rows * ngroups;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
-    for (long long pair = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; pair < npairs; pair += nwaves) {
-        const long long row = pair / ngroups, g = pair - row * ngroups;
-        const long long k = g * 256 + lane * 4;
-        const float4 v = x4[(row * K + k) >> 2];
+    // One wave iteration = one (row, group) pair = 1 KiB of x; pair, row and g are wave-uniform (scalar
+    // registers), advanced without division; the next pair's load is issued before this pair's arithmetic.
+    long long pair = ((long long)blockIdx.x * (blockDim.x >> 6)) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    long long row = pair / ngroups;
+    int g = (int)(pair - row * ngroups);
+    const long long drow = nwaves / ngroups;
+    const int dg = (int)(nwaves - drow * ngroups);
+    // lane-constant part of the tiled address: chunk (lane >> 2) & 3 of piece lane >> 4, 4 bytes at (lane & 3) * 4
+    const int lane_chunk = (lane >> 2) & 3;
+    const int lane_off = (lane >> 4) * 1024 + (lane & 3) * 4;
+    const int mbits_int = (int)__builtin_log2f(a.shift);
+    float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pair < npairs) vnext = x4[pair * 64 + lane];
+    for (; pair < npairs; pair += nwaves) {
+        const float4 v = vnext;
+        if (pair + nwaves < npairs) vnext = x4[(pair + nwaves) * 64 + lane];
         float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         bmax = group_max<4>(bmax);
-        if (bmax == 0.f) bmax = 1.0f;
-        unsigned code;
-        const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
-        int q0, q1, q2, q3;
-        (void)quant_elem<FMT_BFP>(v.x, bp, a, lut, q0);
-        (void)quant_elem<FMT_BFP>(v.y, bp, a, lut, q1);
-        (void)quant_elem<FMT_BFP>(v.z, bp, a, lut, q2);
-        (void)quant_elem<FMT_BFP>(v.w, bp, a, lut, q3);
-        int amax = max(max(abs(q0), abs(q1)), max(abs(q2), abs(q3)));
-        amax = max(amax, __shfl_xor(amax, 1));
-        amax = max(amax, __shfl_xor(amax, 2));
-        const int e = (int)code;
-        const bool nz = amax > 0;
-        int emin = nz ? e : (1 << 20);
-#pragma unroll
-        for (int off = 4; off < 64; off <<= 1) emin = min(emin, __shfl_xor(emin, off));
-        const int sft = nz ? e - emin : 0;
-        const bool ok = !nz || (sft <= 7 && (amax << sft) <= 127);
+        const bool nz = bmax != 0.f;
+        const float bm1 = nz ? bmax : 1.0f;                     // all-zero block: fill 1 (MI355Q_ZERO_BLOCK_FAST)
+        const int e = clampi(ceil_log2_frexp(bm1, lut), a.e_min, a.e_max);
+        const int up = mbits_int - e;
+        const float f0 = mant_f(v.x, up, a.mant_max), f1 = mant_f(v.y, up, a.mant_max);
+        const float f2 = mant_f(v.z, up, a.mant_max), f3 = mant_f(v.w, up, a.mant_max);
+        // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone)
+        const int amax = nz ? (int)mant_f(bmax, up, a.mant_max) : 0;
+        const bool has = amax > 0;
+        const int code = e + a.code_bias;
+        int emin = has ? code : (1 << 20);
+        emin = min(emin, dpp_i<0x124>(emin));                   // row_ror:4
+        emin = min(emin, dpp_i<0x128>(emin));                   // row_ror:8
+        emin = min(emin, __shfl_xor(emin, 16));
+        emin = min(emin, __shfl_xor(emin, 32));
+        const int sft = has ? code - emin : 0;
+        const bool ok = !has || (sft <= 7 && (amax << sft) <= 127);
         const bool all_ok = __all(ok);
-        int eout = e;
-        if (all_ok) {
-            q0 <<= sft; q1 <<= sft; q2 <<= sft; q3 <<= sft;
-            eout = emin == (1 << 20) ? e : emin;
-        }
-        *reinterpret_cast<unsigned*>(mt + tiled_offset_q(row, k, K)) =
-            (unsigned)(q0 & 0xFF) | ((unsigned)(q1 & 0xFF) << 8) | ((unsigned)(q2 & 0xFF) << 16) | ((unsigned)(q3 & 0xFF) << 24);
+        const int sh = all_ok ? sft : 0;
+        const int eout = (all_ok && emin != (1 << 20)) ? emin : code;
+        const int q0 = (int)f0 << sh, q1 = (int)f1 << sh, q2 = (int)f2 << sh, q3 = (int)f3 << sh;
+        const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);   // bytes: q0.b0, q1.b0
+        const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);   // q2.b0 -> byte2, q3.b0 -> byte3
+        const int slot = lane_chunk ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3);
+        int8_t* prow = mt + ((row >> 4) * kpieces + g * 4) * 1024 + (row & 15) * 64;       // wave-uniform
+        *reinterpret_cast<unsigned*>(prow + lane_off + slot * 16) = lo | hi;
         if ((lane & 3) == 0) a.code[row * nkb + g * 16 + (lane >> 2)] = (uint8_t)eout;
         if (lane == 0) {
             flag[row * ngroups + g] = all_ok ? 1 : 0;
             gscale[g * rows_pad + row] = all_ok ? __builtin_ldexpf(1.0f, eout - exp_offset) : 0.0f;
             if (!all_ok) {
                 const int at = atomicAdd(&list[0], 1);
-                if (at < list_cap) { list[2 + 2 * at] = (int)row; list[3 + 2 * at] = (int)g; }
+                if (at < list_cap) { list[2 + 2 * at] = (int)row; list[3 + 2 * at] = g; }
             }
         }
+        row += drow;
+        g += dg;
+        if (g >= ngroups) { g -= ngroups; ++row; }
     }
 }
 
 int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
-                       int* list, int list_cap, hipStream_t st) {
+                       int* list, int list_cap, int* list_to_clear, hipStream_t st) {
     const long long pairs = a.rows * (a.cols >> 8);
     long long grid = (pairs + 3) / 4;
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(bfp_quant_align_kernel, (unsigned)grid, 256, 0, st, a, mt, flag, gscale, rows_pad, exp_offset, list,
-                       list_cap);
+                       list_cap, list_to_clear);
     return (int)hipGetLastError();
 }
 

@@ -231,8 +231,8 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
 
 
 class _ActivationBuffers:
-    """Reusable device buffers of the fused activation path, keyed by (device, stream, rows, K).  The
-    unaligned list starts zeroed and is emptied again by every GEMM that consumes it."""
+    """Reusable device buffers of the fused activation path, keyed by (device, stream, rows, K).  Two
+    unaligned lists alternate: each quantise call fills one and zeroes the other's count for the next call."""
     _cache: dict = {}
 
     @classmethod
@@ -247,7 +247,8 @@ class _ActivationBuffers:
                 exp=torch.empty(rows * (K // 16), dtype=torch.uint8, device=device),
                 flag=torch.empty(rows, groups, dtype=torch.uint8, device=device),
                 gscale=torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
-                sparse=torch.zeros(2 + 2 * SPARSE_LIST_CAP, dtype=torch.int32, device=device))
+                sparse=[torch.zeros(2 + 2 * SPARSE_LIST_CAP, dtype=torch.int32, device=device) for _ in range(2)],
+                calls=0)
             if len(cls._cache) > 64:
                 cls._cache.clear()
             cls._cache[key] = buf
@@ -265,14 +266,16 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
     buf = _ActivationBuffers.get(x.device, rows, K)
     bias = _default_bias(exponent_bias)
     lib = _lib.load_library()
+    cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
+    buf["calls"] += 1
     with torch.cuda.device(x.device):
         rc = lib.mi355q_block_fp_quantize_aligned(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
-                                                  _ptr(buf["gscale"]), _ptr(buf["sparse"]), SPARSE_LIST_CAP, rows, K,
+                                                  _ptr(buf["gscale"]), _ptr(cur), SPARSE_LIST_CAP, _ptr(nxt), rows, K,
                                                   int(width), int(exponent_width), bias, _stream_ptr(x.device))
     _lib.check(rc, "mi355q_block_fp_quantize_aligned")
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
-    return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], buf["sparse"],
-                          int(width) - 1, eb, per_call=True)
+    return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
+                          int(width) - 1, eb, per_call=False)
 
 
 def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):

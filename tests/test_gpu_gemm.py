@@ -197,9 +197,18 @@ def test_fused_quantize_align_equals_two_step(style, width):
     a = set(map(tuple, got.sparse[2:2 + 2 * n].cpu().numpy().reshape(-1, 2)))
     b = set(map(tuple, ref.sparse[2:2 + 2 * n].cpu().numpy().reshape(-1, 2)))
     assert a == b
-    # consume it so that the per-call list is emptied, then check that it was
+    # the two per-shape lists alternate: the next call's list was zeroed by this call, and calling again
+    # (same data) fills it with the same entries
+    again = ops.block_fp_quantize_aligned(xt, width, 8, 127)
+    torch.cuda.synchronize()
+    assert again.sparse.data_ptr() != got.sparse.data_ptr() and int(again.sparse[0]) == n
+    third = ops.block_fp_quantize_aligned(xt, width, 8, 127)
+    torch.cuda.synchronize()
+    assert third.sparse.data_ptr() == got.sparse.data_ptr() and int(third.sparse[0]) == n
+    # self-cleaning variant: an operand marked per_call is emptied by the GEMM that consumes it
     _, wm, we = ops.block_fp_quantize(torch.randn(64, 1024, device=dev) * 0.02, 6, 8, 127, [1, 16], False,
                                       want_fake=False, want_packed=True)
-    ops.bfp_gemm_aligned(got, ops.bfp_align(wm, we, 5, 127))
+    third.per_call = True
+    ops.bfp_gemm_aligned(third, ops.bfp_align(wm, we, 5, 127))
     torch.cuda.synchronize()
-    assert int(got.sparse[0]) == 0 and int(got.sparse[1]) == 0
+    assert int(third.sparse[0]) == 0 and int(third.sparse[1]) == 0
