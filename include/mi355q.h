@@ -106,21 +106,28 @@ int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const
 
 /* ---- exponent-aligned operands for the fast GEMM ------------------------------------------
  * K is cut into groups of 16 blocks (256 values).  mi355q_bfp_align rewrites a packed operand so
- * that, wherever every block of a (row, group) can be shifted left onto the group's smallest
- * exponent without leaving int8, the row-group carries ONE effective exponent (rowflag 1);
- * other row-groups are copied unchanged (rowflag 0).  The rewritten (mant, exp) denote exactly
- * the same values, so results never depend on the flags -- they only select the kernel path.
+ * that each (row, group) carries ONE effective exponent E (rowflag 1): blocks are shifted left onto
+ * E where that keeps their mantissas inside int8.  Blocks that cannot join (exponent below E, or too
+ * far above it) are EXCEPTIONS: they are zeroed in the rewritten operand and appended, exactly, to the
+ * operand's exception list; (rewritten operand) + (its exceptions) denotes the same values as the
+ * input.  E is the smallest exponent of the group when every block fits (no exceptions; the common
+ * case), otherwise the candidate that leaves the fewest exceptions.  A row-group whose exceptions do
+ * not fit the list any more is copied unchanged (rowflag 0, own exponents); list[0] then exceeds
+ * list_cap and mi355q_bfp_gemm_aligned takes its blockwise kernel.  Without a list (list == NULL)
+ * row-groups that would need exceptions are copied unchanged.
  *   rowflag uint8 [rows, G], G = ceil(K/256)
  *   gscale  fp32  [G, rows_pad] (nullable), rows_pad = mi355q_bfp_rows_pad(rows): per (group,row)
- *           2^(effective exponent - exp_offset) where rowflag is 1, else 0;
+ *           2^(E - exp_offset) where rowflag is 1, else 0;
  *           exp_offset = exponent_bias + (width-1) of the operand
- *   list    int32 [2 + 2*list_cap] (nullable): list[0] = number of rowflag-0 row-groups,
- *           then (row, group) pairs for the first list_cap of them
+ *   list    int32 [mi355q_bfp_list_bytes(list_cap) / 4] (nullable): list[0] = exception blocks
+ *           reserved (may exceed list_cap), list[1..7] spare, then 8 words per entry:
+ *           {row (-1 = void), block index (k/16), biased exponent, 0, 16 mantissa bytes}
  *   mant_tiled int8 [mi355q_bfp_tiled_bytes(rows, K)] (nullable, needs K % 64 == 0): the aligned
  *           mantissas in the tile order the GEMM kernels stream (1-KiB pieces of 16 rows x 64 bytes,
  *           rows padded to 128) -- this is what mi355q_bfp_gemm_aligned reads;
  *   mant_out int8 [rows, K] (nullable): the same mantissas row-major, for inspection / mi355q_bfp_gemm.
  * In-place (mant_out == mant_in, exp_out == exp_in) is allowed. */
+size_t mi355q_bfp_list_bytes(int32_t list_cap);
 size_t mi355q_bfp_tiled_bytes(int64_t rows, int64_t K);
 size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K);
 int64_t mi355q_bfp_rows_pad(int64_t rows);
@@ -133,8 +140,8 @@ int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_
  * mi355q_block_fp_quantize followed by mi355q_bfp_align would (mant_tiled, exp_out, rowflag, gscale,
  * list).  `list` must hold list[0] == 0 on entry.  Two ways to keep it so without a memset per call:
  * alternate between two lists and pass the OTHER one as `list_to_clear` (this kernel zeroes its count for
- * the next call -- safe on one stream, where the previous consumer of that list has finished); or set
- * the operand's list_reset = 1 so that mi355q_bfp_gemm_aligned empties the list it consumed. */
+ * the next call -- safe on one stream, where the previous consumer of that list has finished), or
+ * clear list[0] yourself (hipMemsetAsync of 4 bytes) and pass list_to_clear = NULL. */
 int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
                                      float* gscale, int32_t* list, int32_t list_cap, int32_t* list_to_clear,
                                      int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
@@ -146,20 +153,30 @@ typedef struct mi355q_bfp_operand {
     const uint8_t* exp;     /* [rows, K/16] */
     const uint8_t* rowflag; /* [rows, G] */
     const float* gscale;    /* [G, rows_pad] */
-    const int32_t* list;    /* [2 + 2*list_cap] */
+    const int32_t* list;    /* exception list, mi355q_bfp_list_bytes(list_cap) */
     int32_t list_cap;
     int32_t mbits;          /* width - 1 */
     int32_t exp_bias;
-    int32_t list_reset;     /* 1: the GEMM resets list[0..1] to 0 when done (per-call activation lists) */
+    int32_t list_reset;     /* reserved, must be 0 */
 } mi355q_bfp_operand;
 
-/* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align.
- * When few row-groups are unflagged (both lists within capacity) the int32-chain kernel runs on
- * the flagged data and a sparse kernel adds the unflagged row-groups exactly; otherwise the
- * blockwise-fallback kernel runs.  The choice is made on the device. */
+/* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align (K % 64 == 0).
+ * With both exception lists within capacity the int32-chain kernel (one int32 MFMA chain + one fp32
+ * rescale per 256-group) forms the product of the rewritten operands and a second, short launch adds
+ * the exception blocks back exactly (fp32 atomics on y).  If a list overflowed, the blockwise-exact
+ * kernel forms the whole product instead.  The choice is made on the device from the list counts.
+ * Both lists must have the same list_cap; operands without gscale / list (or K % 256 != 0) use the
+ * blockwise-exact kernel directly. */
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);
+
+/* Kernel timing for benchmarks: when enabled, mi355q_bfp_gemm_aligned brackets its MAIN kernel (the
+ * int32-chain GEMM, not the correction / fallback launches) with HIP events on the launch stream.
+ * mi355q_gemm_timing_read synchronises the recorded events, returns their count and average / minimum
+ * duration in milliseconds, and clears the record.  At most 4096 launches are recorded. */
+int mi355q_gemm_timing_enable(int enable);
+int mi355q_gemm_timing_read(int32_t* count, float* avg_ms, float* min_ms);
 
 /* Which GEMM kernel variant mi355q_bfp_gemm dispatches to (0 = automatic).  For A/B
  * benchmarking and tests only; returns the previous value. */

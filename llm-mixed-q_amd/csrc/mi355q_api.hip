@@ -3,6 +3,8 @@
 
 #include <atomic>
 #include <cmath>
+#include <utility>
+#include <vector>
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
@@ -11,6 +13,26 @@ using namespace mi355q;
 
 namespace {
 std::atomic<int> g_gemm_variant{0};
+
+// optional HIP-event bracket around the main GEMM kernel (benchmarks)
+struct GemmTiming {
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+    hipEvent_t begin(hipStream_t st) {
+        if (!enabled || used >= 4096) return nullptr;
+        if (used == pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+            pool.emplace_back(a, b);
+        }
+        (void)hipEventRecord(pool[used].first, st);
+        return pool[used].second;
+    }
+    void end(hipEvent_t e, hipStream_t st) {
+        if (e) { (void)hipEventRecord(e, st); ++used; }
+    }
+} g_timing;
 
 bool bad_shape(int64_t lead, int64_t rows, int64_t cols, int32_t b0, int32_t b1) {
     return lead < 0 || rows < 0 || cols < 0 || b0 < 1 || b1 < 1;
@@ -142,6 +164,8 @@ size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K) {
 
 int64_t mi355q_bfp_rows_pad(int64_t rows) { return rows <= 0 ? 0 : (rows + 255) / 256 * 256 + 256; }
 
+size_t mi355q_bfp_list_bytes(int32_t list_cap) { return list_cap < 0 ? 0 : (size_t)(8 + 8 * (size_t)list_cap) * 4; }
+
 size_t mi355q_bfp_tiled_bytes(int64_t rows, int64_t K) {
     if (rows <= 0 || K <= 0) return 0;
     return static_cast<size_t>((rows + 127) / 128 * 128) * static_cast<size_t>((K + 63) / 64 * 64);
@@ -198,6 +222,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         return MI355Q_E_BADARG;
     if (K % 64 != 0) return MI355Q_E_UNSUPPORTED;   // tiled operands; use mi355q_bfp_gemm otherwise
     if (x->mbits < 1 || x->mbits > 7 || w->mbits < 1 || w->mbits > 7) return MI355Q_E_BADARG;
+    if (x->list_reset || w->list_reset) return MI355Q_E_BADARG;      // reserved
+    if (x->list && w->list && x->list_cap != w->list_cap) return MI355Q_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant)) % 16) return MI355Q_E_ALIGN;
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
                x->exp_bias + x->mbits + w->exp_bias + w->mbits};
@@ -215,21 +241,45 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         return launch_bfp_gemm_v5(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
     if (variant == 4 && chain_ok)
         return launch_bfp_gemm_v4(a, x->gscale, w->gscale, mpad, npad, st);
-    if (variant == 2 || !chain_ok || !x->list || !w->list || x->list_cap != w->list_cap || x->list_cap <= 0)
-        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, nullptr, 0, st);
-    // default: int32-chain kernel + sparse correction.  When either operand has more unaligned row-groups than
-    // the lists hold, both return at once and the blockwise-fallback kernel does the whole product instead
-    // (the choice is made on the device, from the list counts; the fallback returns at once otherwise).
-    int rc;
-    if (variant == 30)      // 128 x 128 tile flavour with the fallback body in the same launch
-        rc = launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, x->rowflag,
-                                w->rowflag, st);
-    else
-        rc = launch_bfp_gemm_v6(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, st);
+    const bool lists_ok = x->list && w->list && x->list_cap > 0;
+    if (variant == 2 || !chain_ok || !lists_ok)     // blockwise-exact kernel alone (+ per-tile exception add-back)
+        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list,
+                                       x->list ? x->list_cap : w->list_cap, 0, st);
+    // default: int32-chain kernel, then one tail launch -- the exception add-back, or, when either operand has
+    // more exception blocks than its list holds, the whole product by the blockwise-exact body (the chain kernel
+    // returns at once then; the choice is made on the device from the list counts).
+    hipEvent_t te = g_timing.begin(st);
+    int rc = launch_bfp_gemm_v6(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, st);
+    g_timing.end(te, st);
     if (rc) return rc;
-    rc = launch_bfp_sparse_fix(a, x->rowflag, const_cast<int*>(x->list), w->list, x->list_cap, x->list_reset, st);
-    if (rc || variant == 30) return rc;
-    return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
+    return launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
+}
+
+int mi355q_gemm_timing_enable(int enable) {
+    const int prev = g_timing.enabled ? 1 : 0;
+    g_timing.enabled = enable != 0;
+    return prev;
+}
+
+int mi355q_gemm_timing_read(int32_t* count, float* avg_ms, float* min_ms) {
+    if (!count || !avg_ms || !min_ms) return MI355Q_E_BADARG;
+    double sum = 0.0;
+    float mn = 0.f;
+    int n = 0;
+    for (size_t i = 0; i < g_timing.used; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_timing.pool[i].second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_timing.pool[i].first, g_timing.pool[i].second);
+        if (e != hipSuccess) return (int)e;
+        sum += ms;
+        mn = (n == 0 || ms < mn) ? ms : mn;
+        ++n;
+    }
+    g_timing.used = 0;
+    *count = n;
+    *avg_ms = n ? (float)(sum / n) : 0.f;
+    *min_ms = mn;
+    return 0;
 }
 
 int mi355q_bfp_gemm_set_variant(int variant) { return g_gemm_variant.exchange(variant); }

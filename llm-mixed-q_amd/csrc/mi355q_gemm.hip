@@ -16,6 +16,8 @@
 #include "mi355q.h"
 #include "mi355q_internal.h"
 #include "mi355q_gemm_v2.h"
+#include "mi355q_align.h"
+#include "mi355q_fix.h"
 
 namespace mi355q {
 
@@ -161,51 +163,43 @@ __global__ __launch_bounds__(256) void bfp_align_kernel(const int8_t* __restrict
         const bool valid = kb < nkb;
         const long long moff = row * K + kb * 16 + (lane & 3) * 4;
         const unsigned v = valid ? *reinterpret_cast<const unsigned*>(mi + moff) : 0u;
-        const int b0 = (int)(int8_t)(v & 0xFF), b1 = (int)(int8_t)((v >> 8) & 0xFF);
-        const int b2 = (int)(int8_t)((v >> 16) & 0xFF), b3 = (int)(int8_t)(v >> 24);
-        int amax = max(max(abs(b0), abs(b1)), max(abs(b2), abs(b3)));
+        int q[4] = {(int)(int8_t)(v & 0xFF), (int)(int8_t)((v >> 8) & 0xFF), (int)(int8_t)((v >> 16) & 0xFF),
+                    (int)(int8_t)(v >> 24)};
+        int amax = max(max(abs(q[0]), abs(q[1])), max(abs(q[2]), abs(q[3])));
         amax = max(amax, __shfl_xor(amax, 1));
         amax = max(amax, __shfl_xor(amax, 2));
         const int e = valid ? (int)ei[row * nkb + kb] : 0;
-        const bool nz = amax > 0;
-        int emin = nz ? e : (1 << 20);
-#pragma unroll
-        for (int off = 4; off < 64; off <<= 1) emin = min(emin, __shfl_xor(emin, off));
-        const int s = nz ? e - emin : 0;
-        const bool ok = !nz || (s <= 7 && (amax << s) <= 127);
-        const bool all_ok = __all(ok);
-        unsigned out = v;
-        int eout = e;
-        if (all_ok) {
-            out = (unsigned)((b0 << s) & 0xFF) | ((unsigned)((b1 << s) & 0xFF) << 8) |
-                  ((unsigned)((b2 << s) & 0xFF) << 16) | ((unsigned)((b3 << s) & 0xFF) << 24);
-            eout = emin == (1 << 20) ? e : emin;
-        }
+        const AlignResult r = align_group(q, amax, e, valid, row, (int)kb, list, list_cap);
+        const unsigned out = (unsigned)(q[0] & 0xFF) | ((unsigned)(q[1] & 0xFF) << 8) | ((unsigned)(q[2] & 0xFF) << 16) |
+                             ((unsigned)(q[3] & 0xFF) << 24);
         if (valid) {
             if (mo) *reinterpret_cast<unsigned*>(mo + moff) = out;
-            if ((lane & 3) == 0) eo[row * nkb + kb] = (uint8_t)eout;
+            if ((lane & 3) == 0) eo[row * nkb + kb] = (uint8_t)r.eout;
             if (mt) *reinterpret_cast<unsigned*>(mt + tiled_offset(row, kb * 16 + (lane & 3) * 4, K)) = out;
         }
         if (lane == 0) {
-            flag[row * ngroups + g] = all_ok ? 1 : 0;
-            // fast-GEMM view: one fp32 scale per (group, row); 0 neutralises a row-group that could not
-            // be aligned (its exact contribution comes from the sparse correction kernel)
-            if (gscale) gscale[g * rows_pad + row] = all_ok ? __builtin_ldexpf(1.0f, eout - exp_offset) : 0.0f;
-            if (list && !all_ok) {
-                const int at = atomicAdd(&list[0], 1);
-                if (at < list_cap) { list[2 + 2 * at] = (int)row; list[3 + 2 * at] = (int)g; }
-            }
+            flag[row * ngroups + g] = r.flagged ? 1 : 0;
+            // fast-GEMM view: one fp32 scale per (group, row); 0 neutralises a row-group that stayed unaligned
+            if (gscale) gscale[g * rows_pad + row] = r.flagged ? __builtin_ldexpf(1.0f, r.eout - exp_offset) : 0.0f;
         }
     }
 }
 
+// Blockwise-exact GEMM over aligned operands.  guard != 0: act only as the fallback of the int32-chain kernel
+// (when an exception list overflowed).  Exception blocks of either operand are added back per tile.
 __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const uint8_t* __restrict__ xf,
                                                       const uint8_t* __restrict__ wf, const int* __restrict__ xlist,
-                                                      const int* __restrict__ wlist, int list_cap) {
+                                                      const int* __restrict__ wlist, int list_cap, int guard) {
     __shared__ V2Smem sm;
-    // as the fallback of the int32-chain kernel: run only when an unaligned list overflowed
-    if (xlist && xlist[0] <= list_cap && wlist[0] <= list_cap) return;
-    bfp_gemm_v2_body(a, xf, wf, sm);
+    if (guard && xlist[0] <= list_cap && wlist[0] <= list_cap) return;
+    bfp_gemm_v2_body(a, xf, wf, sm, blockIdx.x);
+    if (xlist || wlist) {
+        long long m0, n0;
+        v2_tile_origin(a, blockIdx.x, m0, n0);
+        __threadfence();
+        __syncthreads();
+        tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
+    }
 }
 
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
@@ -216,7 +210,7 @@ int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* e
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     if (list) {
-        const hipError_t e = hipMemsetAsync(list, 0, 16, st);
+        const hipError_t e = hipMemsetAsync(list, 0, 32, st);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(bfp_align_kernel, (unsigned)grid, 256, 0, st, mi, ei, mo, eo, flag, gscale, rows_pad, exp_offset,
@@ -225,9 +219,9 @@ int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* e
 }
 
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
-                            const int* wlist, int list_cap, hipStream_t st) {
+                            const int* wlist, int list_cap, int guard, hipStream_t st) {
     const unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
-    hipLaunchKernelGGL(bfp_gemm_v2, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap);
+    hipLaunchKernelGGL(bfp_gemm_v2, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap, guard);
     return (int)hipGetLastError();
 }
 

@@ -47,24 +47,30 @@ using lptr_t = __attribute__((address_space(3))) void*;
 
 __device__ __forceinline__ int v2_off(int r, int c) { return r * V2_BK + ((c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 4); }
 
-__device__ __forceinline__ void bfp_gemm_v2_body(const GemmArgs& a, const uint8_t* __restrict__ xf,
-                                                 const uint8_t* __restrict__ wf, V2Smem& sm) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-
-    // ---- XCD-aware tile order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous
-    //      chunk of the grouped (8 tile-rows at a time) tile sequence
+// XCD-aware tile order: blocks b, b+8, ... share an XCD (L2); each XCD gets a contiguous chunk of the grouped
+// (8 tile-rows at a time) tile sequence.
+__device__ __forceinline__ void v2_tile_origin(const GemmArgs& a, int tile_id, long long& m0, long long& n0) {
     const int tiles_m = (int)((a.M + V2_BM - 1) / V2_BM), tiles_n = (int)((a.N + V2_BN - 1) / V2_BN);
     const int nwg = tiles_m * tiles_n;
     int pid;
     {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int orig = tile_id, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     const int GM = 8, in_group = GM * tiles_n, group_id = pid / in_group, first_m = group_id * GM;
     const int gsz = min(tiles_m - first_m, GM);
     const int tm = first_m + (pid % in_group) % gsz, tn = (pid % in_group) / gsz;
-    const long long m0 = (long long)tm * V2_BM, n0 = (long long)tn * V2_BN;
+    m0 = (long long)tm * V2_BM;
+    n0 = (long long)tn * V2_BN;
+}
+
+__device__ __forceinline__ void bfp_gemm_v2_body(const GemmArgs& a, const uint8_t* __restrict__ xf,
+                                                 const uint8_t* __restrict__ wf, V2Smem& sm, int tile_id) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+
+    long long m0, n0;
+    v2_tile_origin(a, tile_id, m0, n0);
 
     const long long nkb = a.K >> 4;
     const int nsteps = (int)(a.K >> 6), ngroups = (int)((nkb + ALIGN_G - 1) / ALIGN_G);

@@ -27,6 +27,7 @@
 #include "mi355q.h"
 #include "mi355q_internal.h"
 #include "mi355q_gemm_v2.h"
+#include "mi355q_fix.h"
 
 namespace mi355q {
 
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_v3(const GemmArgs a, const fl
     // too many unaligned row-groups for the sparse correction (decided on the device, uniform over the
     // grid): this launch runs the blockwise-fallback body instead; same 128 x 128 tiling and grid
     if (xlist && (xlist[0] > list_cap || wlist[0] > list_cap)) {
-        bfp_gemm_v2_body(a, xf, wf, *reinterpret_cast<V2Smem*>(smem));
+        bfp_gemm_v2_body(a, xf, wf, *reinterpret_cast<V2Smem*>(smem), blockIdx.x);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -924,92 +925,37 @@ int launch_bfp_gemm_v7(const GemmArgs& a, const float* gx, const float* gw, long
 }
 
 // ---------------------------------------------------------------------------------------
-// Sparse correction: the (row, group) pairs the align step could not put on one exponent carry scale 0
-// in the fast kernel; their exact contribution is added here from the (mant, eff_exp) arrays, which
-// hold the true values of every row-group.  One workgroup = one list entry x 256 rows of the other
-// operand; each thread forms 16 exact int8 block dots (v_dot4) and adds one fp32 value to y.
-//   x entry (m, g): y[m, n] += sum_b 2^(xe[m,b] + we[n,b] - bias) * dot16        for every n
-//   w entry (n, g): the same for every m whose (m, g) is aligned (the others were added by their x entry)
+// Tail launch of the default path.  Normal case: add the exception blocks of both operands back (mi355q_fix.h).
+// If an exception list overflowed, the int32-chain kernel returned at once and this launch forms the whole
+// product with the blockwise-exact body instead, correcting each tile right after its stores.
 // ---------------------------------------------------------------------------------------
-template <int DBGFIX>
-__global__ __launch_bounds__(256) void bfp_sparse_fix(const GemmArgs a, const uint8_t* __restrict__ xflag,
-                                                      int* __restrict__ xlist, const int* __restrict__ wlist,
-                                                      int list_cap, int reset_x) {
-    __shared__ __attribute__((aligned(16))) int8_t s_m[256];
-    __shared__ int s_e[16];
-    const int cx = xlist[0], cw = wlist[0];
-    const int tid = threadIdx.x;
-    if (cx <= list_cap && cw <= list_cap) {
-        const long long nkb = a.K >> 4, ngroups = (nkb + 15) >> 4;
-        const int lo = DBGFIX == 2 ? cx : 0, hi = DBGFIX == 1 ? cx : cx + cw;
-        for (int item = lo + blockIdx.x; item < hi; item += gridDim.x) {     // uniform over the workgroup
-            const bool is_x = item < cx;
-            const int e = is_x ? item : item - cx;
-            const int* lst = is_x ? xlist : wlist;
-            const long long row = lst[2 + 2 * e], g = lst[3 + 2 * e];
-            const int8_t* pm = is_x ? a.xm : a.wm;             // the listed operand
-            const uint8_t* pe = is_x ? a.xe : a.we;
-            const int8_t* qm = is_x ? a.wm : a.xm;             // the operand swept over its rows
-            const uint8_t* qe = is_x ? a.we : a.xe;
-            const long long qrows = is_x ? a.N : a.M;
+__global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const uint8_t* __restrict__ xf,
+                                                        const uint8_t* __restrict__ wf, const int* __restrict__ xlist,
+                                                        const int* __restrict__ wlist, int list_cap) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(V2Smem)];
+    if (xlist[0] > list_cap || wlist[0] > list_cap) {
+        const int ntiles = (int)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            bfp_gemm_v2_body(a, xf, wf, *reinterpret_cast<V2Smem*>(smem), tile);
+            long long m0, n0;
+            v2_tile_origin(a, tile, m0, n0);
+            __threadfence();
             __syncthreads();
-            s_m[tid] = pm[tiled_offset(row, g * 256 + tid, a.K)];
-            if (tid < 16) s_e[tid] = pe[row * nkb + g * 16 + tid];
+            tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
             __syncthreads();
-            for (long long q = (long long)blockIdx.y * 256 + tid; q < qrows; q += (long long)gridDim.y * 256) {
-                if (!is_x && xflag[q * ngroups + g] == 0) continue;   // unflagged x rows: added by their own entry
-                int4 qv[16];
-                const uint4* qx4 = reinterpret_cast<const uint4*>(qe + q * nkb + g * 16);
-#pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    qv[b] = *reinterpret_cast<const int4*>(qm + tiled_offset(q, g * 256 + b * 16, a.K));
-                const uint4 qx = *qx4;
-                const unsigned qw[4] = {qx.x, qx.y, qx.z, qx.w};
-                float sum = 0.f;
-#pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const int4 pv = *reinterpret_cast<const int4*>(&s_m[b * 16]);
-                    int d = __builtin_amdgcn_sdot4(qv[b].x, pv.x, 0, false);
-                    d = __builtin_amdgcn_sdot4(qv[b].y, pv.y, d, false);
-                    d = __builtin_amdgcn_sdot4(qv[b].z, pv.z, d, false);
-                    d = __builtin_amdgcn_sdot4(qv[b].w, pv.w, d, false);
-                    const int ecode = (int)((qw[b >> 2] >> (8 * (b & 3))) & 0xFF);
-                    sum += __builtin_ldexpf((float)d, s_e[b] + ecode - a.scale_bias);
-                }
-                if (sum != 0.f && (DBGFIX != 3 || sum == 1.2345e-30f)) {
-                    const long long m = is_x ? row : q, n = is_x ? q : row;
-                    atomicAdd(&a.y[m * a.ldy + n], sum);
-                }
-            }
         }
+        return;
     }
-    // the activation list is per call: the last workgroup out leaves it empty for the next align
-    if (reset_x) {
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned total = gridDim.x * gridDim.y;
-            const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(&xlist[1]), 1u, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
-            if (t == total - 1) {
-                __hip_atomic_store(&xlist[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&xlist[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+    block_fix_body(a, xlist, wlist, list_cap, blockIdx.x, gridDim.x);
 }
 
-int launch_bfp_sparse_fix(const GemmArgs& a, const uint8_t* xflag, int* xlist, const int* wlist, int list_cap,
-                          int reset_x, hipStream_t st) {
-    const long long span = a.M > a.N ? a.M : a.N;
-    long long chunks = (span + 255) / 256;
-    if (chunks > 16) chunks = 16;
-    dim3 grid(64, (unsigned)chunks);
-    const char* dbg = getenv("MI355Q_FIX_DBG");
-    const int d = dbg ? atoi(dbg) : 0;
-    if (d == 1) hipLaunchKernelGGL(bfp_sparse_fix<1>, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap, reset_x);
-    else if (d == 2) hipLaunchKernelGGL(bfp_sparse_fix<2>, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap, reset_x);
-    else if (d == 3) hipLaunchKernelGGL(bfp_sparse_fix<3>, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap, reset_x);
-    else hipLaunchKernelGGL(bfp_sparse_fix<0>, grid, 256, 0, st, a, xflag, xlist, wlist, list_cap, reset_x);
+int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
+                         int list_cap, hipStream_t st) {
+    // two workgroups per CU: enough for the fallback GEMM (it walks the tiles) and cheap to dispatch when the
+    // launch only has the sparse correction to do
+    unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
+    if (tiles > 512) tiles = 512;
+    hipLaunchKernelGGL(bfp_gemm_tail, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap);
     return (int)hipGetLastError();
 }
 

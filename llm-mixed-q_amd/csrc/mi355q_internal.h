@@ -42,9 +42,9 @@ struct GemmArgs {
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
-                            const int* wlist, int list_cap, hipStream_t st);
-int launch_bfp_sparse_fix(const GemmArgs& a, const uint8_t* xflag, int* xlist, const int* wlist, int list_cap,
-                          int reset_x, hipStream_t st);
+                            const int* wlist, int list_cap, int guard, hipStream_t st);
+int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
+                         int list_cap, hipStream_t st);
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
                      long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
                      long long K, hipStream_t st);

@@ -23,6 +23,7 @@
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
+#include "mi355q_align.h"
 
 #define MI355Q_TABLE_QUAL __device__ const
 #include "log2_tables.inc"
@@ -477,19 +478,12 @@ __global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a,
         const float f2 = mant_f(v.z, up, a.mant_max), f3 = mant_f(v.w, up, a.mant_max);
         // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone)
         const int amax = nz ? (int)mant_f(bmax, up, a.mant_max) : 0;
-        const bool has = amax > 0;
         const int code = e + a.code_bias;
-        int emin = has ? code : (1 << 20);
-        emin = min(emin, dpp_i<0x124>(emin));                   // row_ror:4
-        emin = min(emin, dpp_i<0x128>(emin));                   // row_ror:8
-        emin = min(emin, __shfl_xor(emin, 16));
-        emin = min(emin, __shfl_xor(emin, 32));
-        const int sft = has ? code - emin : 0;
-        const bool ok = !has || (sft <= 7 && (amax << sft) <= 127);
-        const bool all_ok = __all(ok);
-        const int sh = all_ok ? sft : 0;
-        const int eout = (all_ok && emin != (1 << 20)) ? emin : code;
-        const int q0 = (int)f0 << sh, q1 = (int)f1 << sh, q2 = (int)f2 << sh, q3 = (int)f3 << sh;
+        int q[4] = {(int)f0, (int)f1, (int)f2, (int)f3};
+        const AlignResult r = align_group(q, amax, code, true, row, g * 16 + (lane >> 2), list, list_cap);
+        const bool all_ok = r.flagged;
+        const int eout = r.eout;
+        const int q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);   // bytes: q0.b0, q1.b0
         const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);   // q2.b0 -> byte2, q3.b0 -> byte3
         const int slot = lane_chunk ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3);
@@ -499,10 +493,6 @@ __global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a,
         if (lane == 0) {
             flag[row * ngroups + g] = all_ok ? 1 : 0;
             gscale[g * rows_pad + row] = all_ok ? __builtin_ldexpf(1.0f, eout - exp_offset) : 0.0f;
-            if (!all_ok) {
-                const int at = atomicAdd(&list[0], 1);
-                if (at < list_cap) { list[2 + 2 * at] = (int)row; list[3 + 2 * at] = g; }
-            }
         }
         row += drow;
         g += dg;

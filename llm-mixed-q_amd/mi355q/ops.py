@@ -185,28 +185,32 @@ def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Ten
     return out
 
 
-SPARSE_LIST_CAP = 2048
+SPARSE_LIST_CAP = 1024          # exception blocks an operand may carry before the GEMM falls back to its blockwise kernel
+
+
+def _new_exception_list(device):
+    n = _lib.load_library().mi355q_bfp_list_bytes(SPARSE_LIST_CAP) // 4
+    return torch.zeros(n, dtype=torch.int32, device=device)
 
 
 class AlignedOperand:
     """A packed block-fp operand rewritten for the fast GEMM (include/mi355q.h, mi355q_bfp_align):
     exponent-aligned mantissas, effective exponents, per (row, group) flags and fp32 group scales,
-    and the list of row-groups that could not be aligned."""
+    and the list of exception blocks (blocks outside their group's exponent window, kept aside exactly)."""
 
-    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias, per_call=False):
+    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias):
         self.rows, self.K = int(rows), int(K)
-        self.per_call = bool(per_call)               # activation operand: the GEMM empties its list after use
         self.mant, self.tiled = mant, tiled          # row-major (may be None) / tiled (what the GEMM reads)
         self.exp, self.rowflag, self.gscale, self.sparse = exp, rowflag, gscale, sparse
         self.mbits, self.exp_bias = int(mbits), int(exp_bias)
 
     def c_struct(self):
         return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
-                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, int(self.per_call))
+                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, 0)
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
-              keep_row_major: bool = False) -> AlignedOperand:
+              keep_row_major: bool = False, with_list: bool = True) -> AlignedOperand:
     """Rewrite a packed [rows, K] operand into the exponent-aligned, tiled format of the fast GEMM
     (same values).  K % 64 == 0.  `keep_row_major` also returns the aligned mantissas row-major."""
     if not mant.is_cuda:
@@ -221,7 +225,7 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
     groups = (K + 255) // 256
     flag = torch.empty(rows, groups, dtype=torch.uint8, device=mant.device)
     gscale = torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=mant.device)
-    sparse = torch.empty(2 + 2 * SPARSE_LIST_CAP, dtype=torch.int32, device=mant.device)
+    sparse = _new_exception_list(mant.device) if with_list else None
     with torch.cuda.device(mant.device):
         rc = lib.mi355q_bfp_align(_ptr(mant), _ptr(exp), _ptr(mo), _ptr(tiled), _ptr(eo), _ptr(flag), _ptr(gscale),
                                   _ptr(sparse), SPARSE_LIST_CAP, int(exp_bias) + int(mbits), rows, K,
@@ -232,7 +236,7 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
 
 class _ActivationBuffers:
     """Reusable device buffers of the fused activation path, keyed by (device, stream, rows, K).  Two
-    unaligned lists alternate: each quantise call fills one and zeroes the other's count for the next call."""
+    exception lists alternate: each quantise call fills one and zeroes the other's count for the next call."""
     _cache: dict = {}
 
     @classmethod
@@ -247,7 +251,7 @@ class _ActivationBuffers:
                 exp=torch.empty(rows * (K // 16), dtype=torch.uint8, device=device),
                 flag=torch.empty(rows, groups, dtype=torch.uint8, device=device),
                 gscale=torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
-                sparse=[torch.zeros(2 + 2 * SPARSE_LIST_CAP, dtype=torch.int32, device=device) for _ in range(2)],
+                sparse=[_new_exception_list(device) for _ in range(2)],
                 calls=0)
             if len(cls._cache) > 64:
                 cls._cache.clear()
@@ -275,7 +279,7 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
     _lib.check(rc, "mi355q_block_fp_quantize_aligned")
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
     return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
-                          int(width) - 1, eb, per_call=False)
+                          int(width) - 1, eb)
 
 
 def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):
@@ -298,3 +302,17 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
 
 def set_gemm_variant(variant: int) -> int:
     return _lib.load_library().mi355q_bfp_gemm_set_variant(int(variant))
+
+
+def gemm_timing(enable: bool) -> None:
+    """Bracket the main GEMM kernel of every bfp_gemm_aligned call with HIP events (benchmarks)."""
+    _lib.load_library().mi355q_gemm_timing_enable(int(bool(enable)))
+
+
+def gemm_timing_read():
+    """-> (count, avg_ms, min_ms) of the recorded main-kernel launches; clears the record."""
+    import ctypes
+    n, avg, mn = ctypes.c_int32(0), ctypes.c_float(0), ctypes.c_float(0)
+    rc = _lib.load_library().mi355q_gemm_timing_read(ctypes.addressof(n), ctypes.addressof(avg), ctypes.addressof(mn))
+    _lib.check(rc, "mi355q_gemm_timing_read")
+    return n.value, avg.value, mn.value
