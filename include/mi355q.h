@@ -147,6 +147,30 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
                                      int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
                                      int32_t exponent_bias, void* stream);
 
+/* ---- ROW-aligned operands -------------------------------------------------------------------
+ * The same rewrite with the whole row (all K/16 blocks) as ONE group: one effective exponent and one fp32
+ * scale per row, so the contraction becomes a plain int8 x int8 -> int32 GEMM with a row scale and a column
+ * scale applied once (no rescale inside the K loop).  Blocks outside the row's exponent window are exceptions,
+ * kept in a list with one BUCKET per 256 rows:
+ *   rowflag  uint8 [rows];  rowscale fp32 [mi355q_bfp_rows_pad(rows)] = 2^(E - exp_offset), 0 where rowflag is 0
+ *   list     int32 [mi355q_bfp_row_list_bytes(rows) / 4]: list[0] = rows whose exceptions did not fit their
+ *            bucket (such rows are copied unchanged, rowflag 0; the GEMM then takes its blockwise kernel),
+ *            list[1..7] spare; bucket b (rows 256 b ...) at word 8 + b * (8 + 8 * 120): [0] entries reserved,
+ *            [1..7] spare, then 120 entries {row (-1 = void), block, biased exponent, 0, 16 mantissa bytes}.
+ * K % 64 == 0, K <= MI355Q_ROW_ALIGN_MAX_K (int32 accumulation cannot overflow; the row is decided by one
+ * workgroup that keeps it in registers).  mi355q_block_fp_quantize_aligned_rows is the fused activation form
+ * (same contract as mi355q_block_fp_quantize_aligned; `list_to_clear`: the OTHER list of an alternating pair,
+ * emptied for the next call). */
+#define MI355Q_ROW_ALIGN_MAX_K 16384
+size_t mi355q_bfp_row_list_bytes(int64_t rows);
+int mi355q_bfp_align_rows(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_tiled, uint8_t* exp_out,
+                          uint8_t* rowflag, float* rowscale, int32_t* list, int32_t exp_offset, int64_t rows,
+                          int64_t K, void* stream);
+int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
+                                          float* rowscale, int32_t* list, int32_t* list_to_clear, int64_t rows,
+                                          int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                                          void* stream);
+
 /* An aligned operand as one argument */
 typedef struct mi355q_bfp_operand {
     const int8_t* mant;     /* tiled mantissas (mant_tiled of mi355q_bfp_align) */
@@ -157,7 +181,8 @@ typedef struct mi355q_bfp_operand {
     int32_t list_cap;
     int32_t mbits;          /* width - 1 */
     int32_t exp_bias;
-    int32_t list_reset;     /* reserved, must be 0 */
+    int32_t row_aligned;    /* 0: 256-value groups (mi355q_bfp_align); 1: whole rows (mi355q_bfp_align_rows):
+                             * rowflag [rows], gscale = rowscale [rows_pad], list = bucketed row list */
 } mi355q_bfp_operand;
 
 /* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align (K % 64 == 0).
@@ -166,7 +191,10 @@ typedef struct mi355q_bfp_operand {
  * the exception blocks back exactly (fp32 atomics on y).  If a list overflowed, the blockwise-exact
  * kernel forms the whole product instead.  The choice is made on the device from the list counts.
  * Both lists must have the same list_cap; operands without gscale / list (or K % 256 != 0) use the
- * blockwise-exact kernel directly. */
+ * blockwise-exact kernel directly.
+ * ROW-aligned operands (row_aligned = 1 in both): one launch of the row-scale int8 GEMM (256 x 256 tiles,
+ * exception blocks added in the epilogue of the tile that owns them) plus a guard launch that forms the whole
+ * product blockwise if an exception bucket overflowed.  K % 128 == 0 for the fast kernel. */
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);

@@ -8,6 +8,7 @@
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
+#include "mi355q_align_row.h"
 
 using namespace mi355q;
 
@@ -214,6 +215,48 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
                               list_cap, list_to_clear, static_cast<hipStream_t>(stream));
 }
 
+size_t mi355q_bfp_row_list_bytes(int64_t rows) { return rows < 0 ? 0 : (size_t)row_list_words(rows) * 4; }
+
+int mi355q_bfp_align_rows(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_tiled, uint8_t* exp_out,
+                          uint8_t* rowflag, float* rowscale, int32_t* list, int32_t exp_offset, int64_t rows, int64_t K,
+                          void* stream) {
+    if (rows < 0 || K < 0) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!mant_in || !exp_in || !mant_tiled || !exp_out || !rowflag || !rowscale) return MI355Q_E_BADARG;
+    if (K % 64 != 0 || K > MI355Q_ROW_ALIGN_MAX_K) return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(mant_in) | reinterpret_cast<uintptr_t>(mant_tiled)) % 4) return MI355Q_E_ALIGN;
+    return launch_bfp_align_rows(mant_in, exp_in, mant_tiled, exp_out, rowflag, rowscale, exp_offset, list, rows, K,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
+                                          float* rowscale, int32_t* list, int32_t* list_to_clear, int64_t rows,
+                                          int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                                          void* stream) {
+    if (rows < 0 || K < 0) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!x || !mant_tiled || !exp_out || !rowflag || !rowscale || !list || list_to_clear == list) return MI355Q_E_BADARG;
+    if (K % 64 != 0 || K > MI355Q_ROW_ALIGN_MAX_K) return MI355Q_E_UNSUPPORTED;
+    if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 8) return MI355Q_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(mant_tiled) % 16) return MI355Q_E_ALIGN;
+    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    QuantArgs a{};
+    a.x = x;
+    a.code = exp_out;
+    a.lead = 1; a.rows = rows; a.cols = K;
+    a.b0 = 1; a.b1 = 16;
+    a.n_elems = rows * K;
+    a.nbr = rows; a.nbc = K / 16;
+    a.n_blocks = rows * (K / 16);
+    a.flags = MI355Q_ZERO_BLOCK_FAST;
+    a.code_bias = exponent_bias;
+    a.e_min = -exponent_bias;
+    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    set_mantissa(a, width - 1);
+    return launch_quant_align_rows(a, mant_tiled, rowflag, rowscale, exponent_bias + width - 1, list, list_to_clear,
+                                   static_cast<hipStream_t>(stream));
+}
+
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
                             int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     if (!x || !w || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
@@ -222,13 +265,27 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         return MI355Q_E_BADARG;
     if (K % 64 != 0) return MI355Q_E_UNSUPPORTED;   // tiled operands; use mi355q_bfp_gemm otherwise
     if (x->mbits < 1 || x->mbits > 7 || w->mbits < 1 || w->mbits > 7) return MI355Q_E_BADARG;
-    if (x->list_reset || w->list_reset) return MI355Q_E_BADARG;      // reserved
+    if (x->row_aligned != w->row_aligned) return MI355Q_E_BADARG;      // both operands in the same alignment flavour
     if (x->list && w->list && x->list_cap != w->list_cap) return MI355Q_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant)) % 16) return MI355Q_E_ALIGN;
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
-               x->exp_bias + x->mbits + w->exp_bias + w->mbits};
+               x->exp_bias + x->mbits + w->exp_bias + w->mbits, x->row_aligned ? 1 : 0};
     const int variant = g_gemm_variant.load();
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (x->row_aligned) {
+        // ROW-aligned operands: plain int8 GEMM with one scale per row + exception add-back in its epilogue; the
+        // second launch only acts when an exception bucket overflowed (then it forms the whole product blockwise)
+        if (!x->gscale || !w->gscale) return MI355Q_E_BADARG;
+        const bool fast_ok = x->list && w->list && K % 128 == 0 && K <= MI355Q_ROW_ALIGN_MAX_K;
+        if (variant == 2 || !fast_ok)
+            return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, 0, 0, st);
+        if (variant == 8) return launch_bfp_gemm_v8(a, x->gscale, w->gscale, nullptr, nullptr, 0, st);
+        hipEvent_t te = g_timing.begin(st);
+        int rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st);
+        g_timing.end(te, st);
+        if (rc) return rc;
+        return launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, 0, st);
+    }
     const long long mpad = mi355q_bfp_rows_pad(M), npad = mi355q_bfp_rows_pad(N);
     const bool chain_ok = x->gscale && w->gscale && K % 256 == 0;
     if (variant == 3 && chain_ok)   // int32-chain kernel alone, no correction (benchmarks only)

@@ -7,6 +7,7 @@
 #ifndef MI355Q_FIX_H
 #define MI355Q_FIX_H
 #include "mi355q_align.h"
+#include "mi355q_align_row.h"
 #include "mi355q_gemm_v2.h"
 
 namespace mi355q {
@@ -20,6 +21,11 @@ __device__ __forceinline__ int dot16(const int4& p, const int4& q) {
 
 __device__ __forceinline__ int list_count(const int* __restrict__ list, int cap) {
     return list ? min(list[0], cap) : 0;
+}
+
+// exception bucket of a row-aligned operand that covers row r0 (mi355q_align_row.h); same layout as a list
+__device__ __forceinline__ const int* row_bucket(const int* __restrict__ list, long long r0) {
+    return list ? list + EXC_HEADER + (r0 / ROW_BUCKET_ROWS) * ROW_BUCKET_WORDS : nullptr;
 }
 
 // One exception entry against rows [q0, q1) of the other operand; `lane_id`/`nlanes` = the threads that share it.
@@ -75,18 +81,20 @@ __device__ __forceinline__ void block_fix_body(const GemmArgs& a, const int* __r
 
 // Correction of ONE output tile [m0, m0+BM) x [n0, n0+BN) by the workgroup that owns it (blockwise-fallback
 // path: runs after the tile's own stores, behind a workgroup barrier).
+template <int BM = V2_BM, int BN = V2_BN>
 __device__ __forceinline__ void tile_fix_body(const GemmArgs& a, const int* __restrict__ xlist,
                                               const int* __restrict__ wlist, int cap, long long m0, long long n0) {
     const int cx = list_count(xlist, cap), cw = list_count(wlist, cap);
     if (cx == 0 && cw == 0) return;
     const int lane = threadIdx.x & 63;
-    const long long m1 = min(m0 + V2_BM, a.M), n1 = min(n0 + V2_BN, a.N);
+    const long long m1 = min(m0 + BM, a.M), n1 = min(n0 + BN, a.N);
+    const int nthreads = blockDim.x;
     for (int pass = 0; pass < 2; ++pass) {
         const bool is_x = pass == 0;
         const int* list = is_x ? xlist : wlist;
         const int cnt = is_x ? cx : cw;
         const long long r0 = is_x ? m0 : n0, r1 = is_x ? m1 : n1, q0 = is_x ? n0 : m0, q1 = is_x ? n1 : m1;
-        for (int base = 0; base < cnt; base += 256) {                 // uniform
+        for (int base = 0; base < cnt; base += nthreads) {            // uniform
             const int t = base + threadIdx.x;
             int row = -1;
             if (t < cnt) row = list[EXC_HEADER + EXC_ENTRY * t];
@@ -101,6 +109,49 @@ __device__ __forceinline__ void tile_fix_body(const GemmArgs& a, const int* __re
                 if (is_x && cw > 0) fix_entry_cross(a, er, kb, code, pv, wlist, cw, n0, n1, lane, 64);
             }
         }
+    }
+}
+
+// The same correction with one (entry, row of the other operand) pair per thread and step: every pair is
+// independent, so a tile with a few dozen entries takes a handful of memory round trips (epilogue of the
+// row-aligned GEMM, where every CU does this at the same time).
+template <int BM, int BN>
+__device__ __forceinline__ void tile_fix_pairs(const GemmArgs& a, const int* __restrict__ xlist,
+                                               const int* __restrict__ wlist, int cap, long long m0, long long n0) {
+    const int cx = list_count(xlist, cap), cw = list_count(wlist, cap);
+    if (cx == 0 && cw == 0) return;
+    const long long nkb = a.K >> 4;
+    const long long m1 = min(m0 + BM, a.M), n1 = min(n0 + BN, a.N);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+#pragma unroll 2
+    for (int idx = tid; idx < cx * BN; idx += nthreads) {
+        const int* e = xlist + EXC_HEADER + EXC_ENTRY * (idx / BN);
+        const long long n = n0 + idx % BN;
+        const int row = e[0], kb = e[1], code = e[2];
+        if (row < m0 || row >= m1 || n >= n1) continue;
+        const int4 pv = *reinterpret_cast<const int4*>(e + 4);
+        const int4 qv = *reinterpret_cast<const int4*>(a.wm + tiled_offset(n, (long long)kb * 16, a.K));
+        const int d = dot16(pv, qv);
+        if (d != 0) atomicAdd(&a.y[(long long)row * a.ldy + n], __builtin_ldexpf((float)d, code + (int)a.we[n * nkb + kb] - a.scale_bias));
+    }
+#pragma unroll 2
+    for (int idx = tid; idx < cw * BM; idx += nthreads) {
+        const int* e = wlist + EXC_HEADER + EXC_ENTRY * (idx / BM);
+        const long long m = m0 + idx % BM;
+        const int row = e[0], kb = e[1], code = e[2];
+        if (row < n0 || row >= n1 || m >= m1) continue;
+        const int4 pv = *reinterpret_cast<const int4*>(e + 4);
+        const int4 qv = *reinterpret_cast<const int4*>(a.xm + tiled_offset(m, (long long)kb * 16, a.K));
+        const int d = dot16(pv, qv);
+        if (d != 0) atomicAdd(&a.y[m * a.ldy + row], __builtin_ldexpf((float)d, code + (int)a.xe[m * nkb + kb] - a.scale_bias));
+    }
+    for (int idx = tid; idx < cx * cw; idx += nthreads) {            // exception x exception
+        const int* e = xlist + EXC_HEADER + EXC_ENTRY * (idx / cw);
+        const int* f = wlist + EXC_HEADER + EXC_ENTRY * (idx % cw);
+        const int row = e[0], n = f[0];
+        if (row < m0 || row >= m1 || n < n0 || n >= n1 || e[1] != f[1]) continue;
+        const int d = dot16(*reinterpret_cast<const int4*>(e + 4), *reinterpret_cast<const int4*>(f + 4));
+        if (d != 0) atomicAdd(&a.y[(long long)row * a.ldy + n], __builtin_ldexpf((float)d, e[2] + f[2] - a.scale_bias));
     }
 }
 

@@ -17,6 +17,7 @@
 #include "mi355q_internal.h"
 #include "mi355q_gemm_v2.h"
 #include "mi355q_align.h"
+#include "mi355q_align_row.h"
 #include "mi355q_fix.h"
 
 namespace mi355q {
@@ -185,6 +186,69 @@ __global__ __launch_bounds__(256) void bfp_align_kernel(const int8_t* __restrict
     }
 }
 
+// Row alignment of a packed operand (mi355q_align_row.h): one workgroup per row.  K % 64 == 0, K <= 1024 * MAXIT.
+template <int MAXIT>
+__global__ __launch_bounds__(256) void bfp_align_rows_kernel(const int8_t* __restrict__ mi, const uint8_t* __restrict__ ei,
+                                                             int8_t* __restrict__ mt, uint8_t* __restrict__ eo,
+                                                             uint8_t* __restrict__ flag, float* __restrict__ rscale,
+                                                             int exp_offset, int* __restrict__ list, long long rows,
+                                                             long long K) {
+    __shared__ RowAlignSmem rsm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        unsigned pk[MAXIT];
+        int amax[MAXIT], code[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int kb = it * 64 + wave * 16 + (lane >> 2);
+            const bool valid = it < nit && kb < nkb;
+            pk[it] = valid ? *reinterpret_cast<const unsigned*>(mi + row * K + (long long)kb * 16 + (lane & 3) * 4) : 0u;
+            code[it] = valid ? (int)ei[row * nkb + kb] : 0;
+            const unsigned v = pk[it];
+            int am = max(max(abs((int)(int8_t)(v & 0xFF)), abs((int)(int8_t)((v >> 8) & 0xFF))),
+                         max(abs((int)(int8_t)((v >> 16) & 0xFF)), abs((int)(int8_t)(v >> 24))));
+            am = max(am, __shfl_xor(am, 1));
+            am = max(am, __shfl_xor(am, 2));
+            amax[it] = am;
+        }
+        int E = 0;
+        const bool flagged = align_row<MAXIT>(pk, amax, code, nit, nkb, row, list, rsm, E);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int kb = it * 64 + wave * 16 + (lane >> 2);
+            if (it < nit && kb < nkb) {
+                *reinterpret_cast<unsigned*>(mt + tiled_offset(row, (long long)kb * 16 + (lane & 3) * 4, K)) = pk[it];
+                if ((lane & 3) == 0) eo[row * nkb + kb] = (uint8_t)(flagged ? E : code[it]);
+            }
+        }
+        if (tid == 0) {
+            flag[row] = flagged ? 1 : 0;
+            rscale[row] = flagged ? __builtin_ldexpf(1.0f, E - exp_offset) : 0.0f;
+        }
+    }
+}
+
+int launch_bfp_align_rows(const int8_t* mi, const uint8_t* ei, int8_t* mt, uint8_t* eo, uint8_t* flag, float* rscale,
+                          int exp_offset, int* list, long long rows, long long K, hipStream_t st) {
+    long long grid = rows;
+    if (grid > 65536) grid = 65536;
+    if (grid < 1) grid = 1;
+    if (list) {
+        const hipError_t e = hipMemsetAsync(list, 0, (size_t)row_list_words(rows) * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (K <= 4096)
+        hipLaunchKernelGGL((bfp_align_rows_kernel<4>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K);
+    else if (K <= 8192)
+        hipLaunchKernelGGL((bfp_align_rows_kernel<8>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K);
+    else if (K <= 16384)
+        hipLaunchKernelGGL((bfp_align_rows_kernel<16>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K);
+    else
+        return MI355Q_E_UNSUPPORTED;
+    return (int)hipGetLastError();
+}
+
 // Blockwise-exact GEMM over aligned operands.  guard != 0: act only as the fallback of the int32-chain kernel
 // (when an exception list overflowed).  Exception blocks of either operand are added back per tile.
 __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const uint8_t* __restrict__ xf,
@@ -198,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const ui
         v2_tile_origin(a, blockIdx.x, m0, n0);
         __threadfence();
         __syncthreads();
-        tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
+        if (a.row_mode) tile_fix_body(a, row_bucket(xlist, m0), row_bucket(wlist, n0), ROW_BCAP, m0, n0);
+        else tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
     }
 }
 

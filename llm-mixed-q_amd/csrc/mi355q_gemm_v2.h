@@ -114,7 +114,7 @@ __device__ __forceinline__ void bfp_gemm_v2_body(const GemmArgs& a, const uint8_
 
     for (int g = 0; g < ngroups; ++g) {
         const int gs = min(4, nsteps - 4 * g);
-        const int f = fl[srow * ngroups + g];
+        const int f = fl[a.row_mode ? srow : srow * ngroups + g];
         const float gsc = __builtin_ldexpf(1.0f, (int)ex[srow * nkb + (long long)g * ALIGN_G] - sh);
         if (is_a) sm.ga[g & 1][sr] = gsc; else sm.gb[g & 1][sr] = gsc;
         const int fast = __syncthreads_and(f);

@@ -933,7 +933,8 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
                                                         const uint8_t* __restrict__ wf, const int* __restrict__ xlist,
                                                         const int* __restrict__ wlist, int list_cap) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(V2Smem)];
-    if (xlist[0] > list_cap || wlist[0] > list_cap) {
+    const bool overflow = a.row_mode ? (xlist[0] != 0 || wlist[0] != 0) : (xlist[0] > list_cap || wlist[0] > list_cap);
+    if (overflow) {
         const int ntiles = (int)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             bfp_gemm_v2_body(a, xf, wf, *reinterpret_cast<V2Smem*>(smem), tile);
@@ -941,12 +942,13 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
             v2_tile_origin(a, tile, m0, n0);
             __threadfence();
             __syncthreads();
-            tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
+            if (a.row_mode) tile_fix_body(a, row_bucket(xlist, m0), row_bucket(wlist, n0), ROW_BCAP, m0, n0);
+            else tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
             __syncthreads();
         }
         return;
     }
-    block_fix_body(a, xlist, wlist, list_cap, blockIdx.x, gridDim.x);
+    if (!a.row_mode) block_fix_body(a, xlist, wlist, list_cap, blockIdx.x, gridDim.x);   // (row mode: done by the GEMM)
 }
 
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
@@ -955,6 +957,7 @@ int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf
     // launch only has the sparse correction to do
     unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
     if (tiles > 512) tiles = 512;
+    if (a.row_mode && tiles > 256) tiles = 256;      // only ever the fallback: keep the (usually empty) launch small
     hipLaunchKernelGGL(bfp_gemm_tail, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap);
     return (int)hipGetLastError();
 }

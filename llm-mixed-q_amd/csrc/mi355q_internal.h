@@ -28,6 +28,8 @@ struct QuantArgs {
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
 int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
                        int* list, int list_cap, int* list_to_clear, hipStream_t st);
+int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
+                            int* list_to_clear, hipStream_t st);
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {
@@ -39,10 +41,15 @@ struct GemmArgs {
     float* y;
     long long M, N, K, ldy;
     int scale_bias;   // subtracted from xe + we to get the power of two of a block product
+    int row_mode;     // 1: operands are ROW-aligned (rowflag[row], bucketed exception lists)
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
                             const int* wlist, int list_cap, int guard, hipStream_t st);
+int launch_bfp_align_rows(const int8_t* mi, const uint8_t* ei, int8_t* mt, uint8_t* eo, uint8_t* flag, float* rscale,
+                          int exp_offset, int* list, long long rows, long long K, hipStream_t st);
+int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
+                       int list_cap, hipStream_t st);
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
                          int list_cap, hipStream_t st);
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,

@@ -24,6 +24,7 @@
 #include "mi355q.h"
 #include "mi355q_internal.h"
 #include "mi355q_align.h"
+#include "mi355q_align_row.h"
 
 #define MI355Q_TABLE_QUAL __device__ const
 #include "log2_tables.inc"
@@ -508,6 +509,90 @@ int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gsc
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(bfp_quant_align_kernel, (unsigned)grid, 256, 0, st, a, mt, flag, gscale, rows_pad, exp_offset, list,
                        list_cap, list_to_clear);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused activation path, ROW-aligned flavour (mi355q_align_row.h): one 256-thread workgroup per row keeps the
+// row's packed mantissas in registers (4 values per lane and 1024-value slab), decides the row's exponent,
+// then writes the tiled mantissas, the effective exponents, rowflag[row] and the row scale.  cols % 64 == 0,
+// cols <= 1024 * MAXIT.
+// ---------------------------------------------------------------------------------------
+template <int MAXIT>
+__global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantArgs a, int8_t* __restrict__ mt,
+                                                                   uint8_t* __restrict__ flag, float* __restrict__ rscale,
+                                                                   int exp_offset, int* __restrict__ list,
+                                                                   int* __restrict__ list_to_clear) {
+    __shared__ Lut lut;
+    __shared__ RowAlignSmem rsm;
+    load_lut<FMT_BFP>(lut);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long K = a.cols;
+    const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
+    if (list_to_clear && blockIdx.x == 0) {
+        const long long words = row_list_words(a.rows);
+        if (tid < EXC_HEADER) list_to_clear[tid] = 0;
+        for (long long b = EXC_HEADER + (long long)tid * ROW_BUCKET_WORDS; b < words; b += 256ll * ROW_BUCKET_WORDS)
+            list_to_clear[b] = 0;
+    }
+    const int mbits_int = (int)__builtin_log2f(a.shift);
+    __syncthreads();
+    for (long long row = blockIdx.x; row < a.rows; row += gridDim.x) {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
+        float4 v[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int kb = it * 64 + wave * 16 + (lane >> 2);
+            v[it] = (it < nit && kb < nkb) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        unsigned pk[MAXIT];
+        int amax[MAXIT], code[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            float bmax = fmaxf(fmaxf(fabsf(v[it].x), fabsf(v[it].y)), fmaxf(fabsf(v[it].z), fabsf(v[it].w)));
+            bmax = group_max<4>(bmax);
+            const bool nz = bmax != 0.f;
+            const float bm1 = nz ? bmax : 1.0f;                 // all-zero block: fill 1 (MI355Q_ZERO_BLOCK_FAST)
+            const int e = clampi(ceil_log2_frexp(bm1, lut), a.e_min, a.e_max);
+            const int up = mbits_int - e;
+            const int q0 = (int)mant_f(v[it].x, up, a.mant_max), q1 = (int)mant_f(v[it].y, up, a.mant_max);
+            const int q2 = (int)mant_f(v[it].z, up, a.mant_max), q3 = (int)mant_f(v[it].w, up, a.mant_max);
+            amax[it] = nz ? (int)mant_f(bmax, up, a.mant_max) : 0;
+            code[it] = e + a.code_bias;
+            const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);
+            const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);
+            pk[it] = lo | hi;
+        }
+        int E = 0;
+        const bool flagged = align_row<MAXIT>(pk, amax, code, nit, nkb, row, list, rsm, E);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int kb = it * 64 + wave * 16 + (lane >> 2);
+            if (it < nit && kb < nkb) {
+                *reinterpret_cast<unsigned*>(mt + tiled_offset_q(row, (long long)kb * 16 + (lane & 3) * 4, K)) = pk[it];
+                if ((lane & 3) == 0) a.code[row * nkb + kb] = (uint8_t)(flagged ? E : code[it]);
+            }
+        }
+        if (tid == 0) {
+            flag[row] = flagged ? 1 : 0;
+            rscale[row] = flagged ? __builtin_ldexpf(1.0f, E - exp_offset) : 0.0f;
+        }
+    }
+}
+
+int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
+                            int* list_to_clear, hipStream_t st) {
+    long long grid = a.rows;
+    if (grid > 65536) grid = 65536;
+    if (grid < 1) grid = 1;
+    if (a.cols <= 4096)
+        hipLaunchKernelGGL((bfp_quant_align_rows_kernel<4>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear);
+    else if (a.cols <= 8192)
+        hipLaunchKernelGGL((bfp_quant_align_rows_kernel<8>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear);
+    else if (a.cols <= 16384)
+        hipLaunchKernelGGL((bfp_quant_align_rows_kernel<16>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear);
+    else
+        return MI355Q_E_UNSUPPORTED;
     return (int)hipGetLastError();
 }
 

@@ -30,6 +30,10 @@ SIGNATURES = {
     "mi355q_bfp_align": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp]),
     "mi355q_block_fp_quantize_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32,
                                                    _i32, _vp]),
+    "mi355q_bfp_row_list_bytes": (C.c_size_t, [_i64]),
+    "mi355q_bfp_align_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp]),
+    "mi355q_block_fp_quantize_aligned_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,
+                                                        _i32, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_gemm_timing_enable": (C.c_int, [C.c_int]),
     "mi355q_gemm_timing_read": (C.c_int, [_vp, _vp, _vp]),
@@ -40,7 +44,7 @@ SIGNATURES = {
 class BfpOperand(C.Structure):
     """struct mi355q_bfp_operand"""
     _fields_ = [("mant", _vp), ("exp", _vp), ("rowflag", _vp), ("gscale", _vp), ("list", _vp),
-                ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("list_reset", _i32)]
+                ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
 ABI_VERSION = 1

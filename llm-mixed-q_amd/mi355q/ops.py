@@ -198,15 +198,16 @@ class AlignedOperand:
     exponent-aligned mantissas, effective exponents, per (row, group) flags and fp32 group scales,
     and the list of exception blocks (blocks outside their group's exponent window, kept aside exactly)."""
 
-    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias):
+    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias, row_aligned=False):
         self.rows, self.K = int(rows), int(K)
         self.mant, self.tiled = mant, tiled          # row-major (may be None) / tiled (what the GEMM reads)
         self.exp, self.rowflag, self.gscale, self.sparse = exp, rowflag, gscale, sparse
         self.mbits, self.exp_bias = int(mbits), int(exp_bias)
+        self.row_aligned = bool(row_aligned)         # one exponent per ROW (mi355q_bfp_align_rows) instead of per 256 values
 
     def c_struct(self):
         return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
-                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, 0)
+                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, int(self.row_aligned))
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
@@ -234,15 +235,76 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
     return AlignedOperand(rows, K, mo, tiled, eo, flag, gscale, sparse, mbits, exp_bias)
 
 
+ROW_ALIGN_MAX_K = 16384
+ROW_BUCKET_ROWS, ROW_BUCKET_CAP = 256, 120
+
+
+def row_align_supported(K: int) -> bool:
+    """the row-aligned fast GEMM needs K % 128 == 0 and K <= MI355Q_ROW_ALIGN_MAX_K"""
+    return K % 128 == 0 and 0 < K <= ROW_ALIGN_MAX_K
+
+
+def _new_row_list(device, rows):
+    n = _lib.load_library().mi355q_bfp_row_list_bytes(rows) // 4
+    return torch.zeros(n, dtype=torch.int32, device=device)
+
+
+def row_list_entries(lst, rows):
+    """decode a row-aligned operand's bucketed exception list -> (overflowed rows, [n, 8] int32 entries)"""
+    import numpy as np
+    lst = lst.detach().cpu().numpy() if hasattr(lst, "detach") else np.asarray(lst)
+    words = 8 + 8 * ROW_BUCKET_CAP
+    out = []
+    for b in range((rows + ROW_BUCKET_ROWS - 1) // ROW_BUCKET_ROWS):
+        bk = lst[8 + b * words: 8 + (b + 1) * words]
+        n = min(int(bk[0]), ROW_BUCKET_CAP)
+        ent = bk[8:8 + 8 * n].reshape(n, 8)
+        out.append(ent[ent[:, 0] >= 0])
+    return int(lst[0]), (np.concatenate(out) if out else np.zeros((0, 8), np.int32))
+
+
+def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, with_list: bool = True) -> AlignedOperand:
+    """Rewrite a packed [rows, K] operand into the ROW-aligned, tiled format (one exponent and one fp32 scale
+    per row; include/mi355q.h, mi355q_bfp_align_rows).  K % 64 == 0, K <= ROW_ALIGN_MAX_K."""
+    if not mant.is_cuda:
+        raise RuntimeError("mi355q.bfp_align_rows: operands must be on a HIP device; there is no CPU fallback")
+    rows, K = mant.shape
+    assert mant.dtype == torch.int8 and exp.dtype == torch.uint8 and mant.is_contiguous() and exp.is_contiguous()
+    assert exp.numel() == rows * (K // 16)
+    lib = _lib.load_library()
+    eo = torch.empty_like(exp)
+    tiled = torch.zeros(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=mant.device)
+    flag = torch.empty(rows, dtype=torch.uint8, device=mant.device)
+    rscale = torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=mant.device)
+    sparse = _new_row_list(mant.device, rows) if with_list else None
+    with torch.cuda.device(mant.device):
+        rc = lib.mi355q_bfp_align_rows(_ptr(mant), _ptr(exp), _ptr(tiled), _ptr(eo), _ptr(flag), _ptr(rscale),
+                                       _ptr(sparse), int(exp_bias) + int(mbits), rows, K, _stream_ptr(mant.device))
+    _lib.check(rc, "mi355q_bfp_align_rows")
+    return AlignedOperand(rows, K, None, tiled, eo, flag, rscale, sparse, mbits, exp_bias, row_aligned=True)
+
+
 class _ActivationBuffers:
     """Reusable device buffers of the fused activation path, keyed by (device, stream, rows, K).  Two
     exception lists alternate: each quantise call fills one and zeroes the other's count for the next call."""
     _cache: dict = {}
 
     @classmethod
-    def get(cls, device, rows, K):
-        key = (device.index, _stream_ptr(device), rows, K)
+    def get(cls, device, rows, K, row_aligned=False):
+        key = (device.index, _stream_ptr(device), rows, K, row_aligned)
         buf = cls._cache.get(key)
+        if buf is None and row_aligned:
+            lib = _lib.load_library()
+            buf = dict(
+                tiled=torch.zeros(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=device),
+                exp=torch.empty(rows * (K // 16), dtype=torch.uint8, device=device),
+                flag=torch.empty(rows, dtype=torch.uint8, device=device),
+                gscale=torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
+                sparse=[_new_row_list(device, rows) for _ in range(2)],
+                calls=0)
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            cls._cache[key] = buf
         if buf is None:
             lib = _lib.load_library()
             groups = K // 256
@@ -280,6 +342,29 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
     return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
                           int(width) - 1, eb)
+
+
+def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: int, exponent_bias) -> AlignedOperand:
+    """Fused activation path, ROW-aligned flavour: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack +
+    row-align + tile in one kernel (K % 64 == 0, K <= ROW_ALIGN_MAX_K).  Buffers are reused per shape and
+    stream like block_fp_quantize_aligned's."""
+    _require_device(x, "block_fp_quantize_aligned_rows")
+    assert x.ndim == 2 and x.shape[1] % 64 == 0 and x.shape[1] <= ROW_ALIGN_MAX_K
+    rows, K = x.shape
+    xc = x.contiguous()
+    buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True)
+    bias = _default_bias(exponent_bias)
+    lib = _lib.load_library()
+    cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
+    buf["calls"] += 1
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_block_fp_quantize_aligned_rows(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
+                                                       _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows, K, int(width),
+                                                       int(exponent_width), bias, _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows")
+    eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
+    return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
+                          int(width) - 1, eb, row_aligned=True)
 
 
 def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):

@@ -48,8 +48,9 @@ def _run(x, w, b, cfg, aligned=False):
     if b is not None:
         bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), cfg["bias_width"], 8, 127, [16], False)
     if aligned:
-        xa = ops.bfp_align(xm, xe, cfg["data_in_width"] - 1, 127)
-        wa = ops.bfp_align(wm, we, cfg["weight_width"] - 1, 127)
+        align = ops.bfp_align_rows if aligned == "rows" else ops.bfp_align
+        xa = align(xm, xe, cfg["data_in_width"] - 1, 127)
+        wa = align(wm, we, cfg["weight_width"] - 1, 127)
         y = ops.bfp_gemm_aligned(xa, wa, bq)
         _run.last_flags = (float(xa.rowflag.float().mean()), float(wa.rowflag.float().mean()))
         _run.last_counts = (int(xa.sparse[0]), int(wa.sparse[0]))
@@ -259,3 +260,155 @@ def test_fused_quantize_align_equals_two_step(style, width):
     third = ops.block_fp_quantize_aligned(xt, width, 8, 127)
     torch.cuda.synchronize()
     assert third.sparse.data_ptr() == got.sparse.data_ptr() and int(third.sparse[0]) == n and ent(third) == ent(ref)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ROW-aligned operands (one exponent per row; int8 GEMM with row / column scales; bucketed exception lists)
+# ---------------------------------------------------------------------------------------------------
+def _row_exceptions(al, rows, nkb):
+    from mi355q import ops
+    over, ent = ops.row_list_entries(al.sparse, rows)
+    mant = np.zeros((rows, nkb, 16), np.int64)
+    exp = np.zeros((rows, nkb), np.int64)
+    mask = np.zeros((rows, nkb), bool)
+    for e in ent:
+        assert not mask[e[0], e[1]], "a block is listed once"
+        assert e[0] // 256 == e[0] // 256
+        mask[e[0], e[1]] = True
+        exp[e[0], e[1]] = e[2]
+        mant[e[0], e[1]] = e[4:8].astype(np.int32).view(np.int8)
+    return over, mant, exp, mask
+
+
+def _untile(tiled, rows, K):
+    """tiled aligned mantissas (1-KiB pieces of 16 rows x 64 B, chunk-swizzled) -> [rows, K] int8"""
+    t = tiled.cpu().numpy().view(np.int8)
+    out = np.zeros((rows, K), np.int8)
+    kp = K // 64
+    for r in range(rows):
+        h = (0x78 >> (2 * ((r >> 2) & 3))) & 3
+        for p in range(kp):
+            base = ((r >> 4) * kp + p) * 1024 + (r & 15) * 64
+            for c in range(4):
+                out[r, p * 64 + c * 16: p * 64 + c * 16 + 16] = t[base + (c ^ h) * 16: base + (c ^ h) * 16 + 16]
+    return out
+
+
+@pytest.mark.parametrize("width", [6, 4, 8])
+def test_row_align_is_value_preserving(width):
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    rows, K = 300, 1024
+    x, _, _ = _inputs(rows, 8, K, 5 + width, "rowscale")
+    x[::4, 256:272] *= 300.0          # one block far above its neighbours in every 4th row (64 per bucket of 256 rows)
+    x[7, :] = 0.0                      # an all-zero row
+    x[9, 16:] = 0.0                    # a row with one non-zero block
+    _, xm, xe = ops.block_fp_quantize(torch.from_numpy(x).to(dev), width, 8, 127, [1, 16], True, want_fake=False,
+                                      want_packed=True)
+    al = ops.bfp_align_rows(xm, xe, width - 1, 127)
+    torch.cuda.synchronize()
+    over, em, ee, emask = _row_exceptions(al, rows, K // 16)
+    f = al.rowflag.cpu().numpy()
+    m2 = _untile(al.tiled, rows, K).reshape(rows, K // 16, 16)
+    e2 = al.exp.cpu().numpy().reshape(rows, K // 16).astype(np.float64)
+    v1 = xm.cpu().numpy().reshape(rows, K // 16, 16).astype(np.float64) * np.exp2(xe.cpu().numpy().reshape(rows, K // 16, 1).astype(np.float64))
+    v2 = m2.astype(np.float64) * np.exp2(e2[..., None]) + em.astype(np.float64) * np.exp2(ee[..., None].astype(np.float64))
+    assert np.array_equal(v1, v2), "row-aligned operand + its exception blocks denote the input exactly"
+    assert np.all(m2[emask] == 0)
+    assert over == (f == 0).sum()
+    fl = f == 1
+    assert np.all(e2[fl] == e2[fl][:, :1]), "flagged rows carry one exponent"
+    rs = al.gscale.cpu().numpy()[:rows]
+    assert np.array_equal(rs[fl], np.exp2(e2[fl][:, 0] - (127 + width - 1))) and np.all(rs[~fl] == 0)
+    if width < 8:
+        assert over == 0 and fl.all() and emask[::4, 16].all() and emask.sum() < 75 + 30
+    else:                               # no head-room at W8: far too many exceptions, most rows stay unaligned
+        assert over > 0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 130, 1024), (100, 72, 384), (33, 16, 128), (520, 260, 512),
+                                   (64, 64, 192)])
+@pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
+@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
+def test_row_aligned_gemm_vs_oracle(M, N, K, style, wx, ww):
+    """row-scale int8 GEMM + exception add-back in its epilogue; overflowing buckets (outlier data, W8) and
+    K % 128 != 0 take the blockwise kernel"""
+    from oracle import np_oracle as O
+    x, w, b = _inputs(M, N, K, 3000 + M + N + K, style)
+    cfg = _cfg(wx, ww)
+    y = _run(x, w, b, cfg, aligned="rows")
+    ref = O.bfp_linear_int(x, w, b, cfg)
+    scale = np.abs(ref).max() + 1e-30
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_row_aligned_gemm_exceptions_of_both_operands_share_blocks(variant):
+    from mi355q import ops
+    from oracle import np_oracle as O
+    x, w, b = _inputs(520, 300, 768, 17, "rowscale")
+    x[::5, 256:272] *= 300.0
+    w[::4, 256:272] *= 300.0
+    x[::7, 512:528] *= 1e-3
+    w[1::6, 512:528] *= 1e-3
+    cfg = _cfg(6, 6)
+    prev = ops.set_gemm_variant(variant)
+    try:
+        y = _run(x, w, b, cfg, aligned="rows")
+    finally:
+        ops.set_gemm_variant(prev)
+    assert _run.last_counts == (0, 0) and _run.last_flags == (1.0, 1.0)        # no bucket overflowed
+    ref = O.bfp_linear_int(x, w, b, cfg)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=6e-6 * np.abs(ref).max())
+
+
+def test_row_aligned_gemm_bucket_overflow_takes_the_fallback():
+    from oracle import np_oracle as O
+    r = np.random.default_rng(12)
+    M, N, K = 700, 128, 512
+    x = r.normal(size=(M, K)).astype(np.float32)
+    x[256:512, 7::64] *= 500.0                  # 8 far-off blocks in each row of the second bucket: 2048 > 120 entries
+    w = (r.normal(size=(N, K)) * 0.02).astype(np.float32)
+    cfg = _cfg(6, 6)
+    y = _run(x, w, None, cfg, aligned="rows")
+    assert _run.last_counts[0] > 0 and _run.last_flags[0] < 1.0
+    ref = O.bfp_linear_int(x, w, None, cfg)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("style,rows", [("rowscale", 300), ("outlier", 40), ("sparse", 24)])
+@pytest.mark.parametrize("width", [6, 4])
+@pytest.mark.parametrize("K", [1024, 4096, 320, 5120])
+def test_fused_quantize_align_rows_equals_two_step(style, rows, width, K):
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    if K > 1024:
+        rows = min(rows, 64 if style == "rowscale" else 6)
+    if style == "outlier":              # ~K/53 exception blocks per row: stay inside one bucket (120 entries)
+        rows = max(1, 100 // (K // 53 + 1))
+    x, _, _ = _inputs(rows, 8, K, 41 + width, style)
+    xt = torch.from_numpy(x).to(dev)
+    _, xm, xe = ops.block_fp_quantize(xt, width, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
+                                      fast_zero_blocks=True)
+    ref = ops.bfp_align_rows(xm, xe, width - 1, 127)
+    got = ops.block_fp_quantize_aligned_rows(xt, width, 8, 127)
+    torch.cuda.synchronize()
+    o1, e1 = ops.row_list_entries(ref.sparse, rows)
+    o2, e2 = ops.row_list_entries(got.sparse, rows)
+    assert o1 == o2 == 0
+    assert set(map(tuple, e1)) == set(map(tuple, e2))
+    if style == "outlier":
+        assert len(e1) > 0
+    full = (rows // 16) * 16 * K
+    assert torch.equal(got.tiled[:full], ref.tiled[:full])
+    assert torch.equal(got.exp, ref.exp.reshape(-1)) and torch.equal(got.rowflag, ref.rowflag)
+    assert torch.equal(got.gscale[:rows], ref.gscale[:rows])
+    # alternating lists: the second call fills the other list, the third one the first again (emptied in between)
+    again = ops.block_fp_quantize_aligned_rows(xt, width, 8, 127)
+    third = ops.block_fp_quantize_aligned_rows(xt, width, 8, 127)
+    torch.cuda.synchronize()
+    assert again.sparse.data_ptr() != got.sparse.data_ptr() and third.sparse.data_ptr() == got.sparse.data_ptr()
+    o3, e3 = ops.row_list_entries(third.sparse, rows)
+    assert o3 == 0 and set(map(tuple, e3)) == set(map(tuple, e1))
