@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--shard", choices=["tokens", "out_features"], default="tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="GEMM kernel variant (0 = automatic)")
+    ap.add_argument("--align", choices=["rows", "groups"], default="rows",
+                    help="exponent alignment of the packed operands: whole rows (row-scale int8 GEMM) or 256-value groups")
     args = ap.parse_args()
 
     import torch
@@ -116,14 +118,16 @@ def main():
     # one-off weight / bias packing (first PTQ forward in the reference), not timed
     _, wm, we = ops.block_fp_quantize(w, ww, 8, 127, [1, 16], False, want_fake=False, want_packed=True,
                                       fast_zero_blocks=True)
-    wa = ops.bfp_align(wm, we, ww - 1, 127, inplace=True)
+    rows_mode = args.align == "rows"
+    wa = ops.bfp_align_rows(wm, we, ww - 1, 127) if rows_mode else ops.bfp_align(wm, we, ww - 1, 127, inplace=True)
+    quantize_x = ops.block_fp_quantize_aligned_rows if rows_mode else ops.block_fp_quantize_aligned
     bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
     n_out = w.shape[0]
     y = torch.empty(M, n_out, dtype=torch.float32, device=device)
     gathered = torch.empty(world * M, n_out, dtype=torch.float32, device=device) if (args.shard == "out_features" and world > 1) else None
 
     def step():
-        xa = ops.block_fp_quantize_aligned(x, xw, 8, 127)
+        xa = quantize_x(x, xw, 8, 127)
         ops.bfp_gemm_aligned(xa, wa, bq, out=y)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered, y)
@@ -163,9 +167,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> fused quantise+pack+align (W6, block [1,16]) "
                                    "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32",
-                       "M_per_gpu": M, "N": N, "K": K, "shard": args.shard,
+                       "M_per_gpu": M, "N": N, "K": K, "shard": args.shard, "align": args.align,
                        "gemm_variant": ops.set_gemm_variant(args.variant)},
-            "roofline": {"bound": "mfma", "kernel": "bfp_gemm_v6 (int32-chain block GEMM)", "achieved": round(achieved, 2),
+            "roofline": {"bound": "mfma", "kernel": "bfp_gemm_v8 (row-scale int8 GEMM)" if rows_mode else "bfp_gemm_v6 (int32-chain block GEMM)", "achieved": round(achieved, 2),
                          "peak": INT8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / INT8_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(gemm_avg_ms, 4), "min_launch_ms": round(gemm_min_ms, 4), "launches_timed": n_timed},

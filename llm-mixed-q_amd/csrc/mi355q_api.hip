@@ -269,7 +269,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     if (x->list && w->list && x->list_cap != w->list_cap) return MI355Q_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant)) % 16) return MI355Q_E_ALIGN;
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
-               x->exp_bias + x->mbits + w->exp_bias + w->mbits, x->row_aligned ? 1 : 0};
+               x->exp_bias + x->mbits + w->exp_bias + w->mbits, x->row_aligned ? 1 : 0,
+               x->exp_bias + x->mbits, w->exp_bias + w->mbits};
     const int variant = g_gemm_variant.load();
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (x->row_aligned) {

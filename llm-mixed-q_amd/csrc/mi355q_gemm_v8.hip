@@ -1,16 +1,24 @@
 // mi355q_gemm_v8.hip -- block-floating-point GEMM over ROW-aligned operands (gfx950).
 //
-// When the align step can put every block of a row onto ONE exponent (whole-K window, exceptions kept
-// aside -- mi355q_align.h), the contraction is a plain int8 x int8 -> int32 GEMM with one scale per row of x
-// and one per row of w:
-//     y[m,n] = sx[m] * sw[n] * ( sum_k xm'[m,k] * wm'[n,k] )  (+ bias[n]),   K <= 131072 (int32 cannot overflow)
-// No rescale in the K loop, so the int32 accumulators are the only live tile: they sit in AccVGPRs and the wave
-// tile can be 128 x 128 (config <2>: 4 waves, one per SIMD) or 128 x 64 (config <4>: 8 waves, two per SIMD).
+// When the align step can put every block of a row onto ONE exponent (whole-K window, exceptions kept aside --
+// mi355q_align_row.h), the contraction is a plain int8 x int8 -> int32 GEMM with one scale per row of x and one
+// per row of w:
+//     y[m,n] = sx[m] * sw[n] * ( sum_k xm'[m,k] * wm'[n,k] )  (+ bias[n])  (+ exception blocks),  K <= 16384.
+// No rescale in the K loop: the int32 accumulators are the only live tile, so the wave tile is 128 x 64.
 //
-// Workgroup tile 256 x 256, K-step 64: one stage = A 16 KiB + B 16 KiB, 4 stages in LDS filled by
-// global_load_lds (1-KiB pre-swizzled pieces, mi355q_gemm_v2.h) two steps ahead; counted s_waitcnt vmcnt and ONE
-// s_barrier per step; v_mfma_i32_16x16x64_i8; fragments of step t+1 are read while the MFMAs of step t run.
-// Roofline: int8 MFMA, 2*M*N*K ops; LDS traffic 64 KiB (config <2>) per 256x256x64 step.
+// Workgroup = 256 x 256 outputs, 8 waves as 2 x 4 (two per SIMD), v_mfma_i32_16x16x64_i8.  K-step 64: one stage =
+// A 16 KiB + B 16 KiB of 1-KiB pre-swizzled pieces (mi355q_gemm_v2.h), three stages filled by global_load_lds two
+// steps ahead, counted s_waitcnt vmcnt, ONE s_barrier per step.  The scale / bias slices of the tile and its two
+// exception buckets ride in front of the operand stream (LDS-DMA too).
+//
+// Exceptions (blocks outside their row's exponent window; a few dozen per tile at most in the usual case) are
+// added back without leaving the kernel and without floating-point atomics: at the K-step that has an exception's
+// block resident in LDS, the wave that owns the entry forms its 256 dot products against the OTHER operand's
+// staged blocks and writes them as a correction vector (row vector for an x exception, column vector for a w
+// exception) to a spare LDS area; the store epilogue adds the vectors of the rows / columns it writes.  Tiles
+// with more entries than the spare area holds build the vectors after the K loop from global memory (stage area),
+// and beyond that add them with atomics after the stores.
+// Roofline: int8 MFMA, 2*M*N*K ops; y leaves as full fp32 (64 MiB at 4096^2: ~10 us of HBM write time).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -23,26 +31,96 @@
 namespace mi355q {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int V8_BM = 256, V8_BN = 256, V8_S = 4;
-constexpr int V8_HALF = 256 * 64, V8_STAGE = 2 * V8_HALF, V8_LDS = V8_S * V8_STAGE;
-static_assert(V8_LDS <= 160 * 1024, "LDS budget");
+constexpr int V8_BM = 256, V8_BN = 256, V8_S = 3, V8_NW = 8, V8_NT = V8_NW * 64;
+constexpr int V8_HALF = 256 * 64, V8_STAGE = 2 * V8_HALF;
+constexpr int V8_BUCKET = 4096;                     // LDS copy of one exception bucket (ROW_BUCKET_WORDS * 4 <= 4096)
+constexpr int V8_XB = V8_S * V8_STAGE, V8_WB = V8_XB + V8_BUCKET, V8_MAP = V8_WB + V8_BUCKET;
+constexpr int V8_SXT = V8_MAP + 2 * 256 * 4, V8_SWT = V8_SXT + 1024, V8_BIAS = V8_SWT + 1024;
+constexpr int V8_CORR = V8_BIAS + 1024;
+constexpr int V8_LDS = 160 * 1024;
+constexpr int V8_FAST_MAX = (V8_LDS - V8_CORR) / 1024;      // entries (x + w) whose vectors fit beside the stages
+constexpr int V8_SLOW_MAX = V8_S * V8_STAGE / 1024;         // ... that fit the stage area after the K loop
+constexpr int V8_OWN = (V8_FAST_MAX + V8_NW - 1) / V8_NW;   // entries one wave may own in the fast path
+static_assert(ROW_BUCKET_WORDS * 4 <= V8_BUCKET, "bucket copy");
+static_assert(V8_FAST_MAX >= 40, "spare LDS for correction vectors");
 
 __device__ __forceinline__ int v8_off(int r, int c) { return r * 64 + ((c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 4); }
 
 #define V8_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int WAVES_N, int PREFETCH>
-__global__ __launch_bounds__(WAVES_N * 128, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
-                                                                const float* __restrict__ sw,
-                                                                const int* __restrict__ xlist,
-                                                                const int* __restrict__ wlist, int list_cap) {
-    constexpr int NW = 2 * WAVES_N, TI = 8, TJ = 16 / WAVES_N, LPW = 32 / NW;
+// entry i of the combined list (x entries first, then w entries) in the LDS bucket copies
+__device__ __forceinline__ int* v8_entry(int* xb, int* wb, int cx, int i) {
+    return (i < cx ? xb + EXC_ENTRY * i : wb + EXC_ENTRY * (i - cx)) + EXC_HEADER;
+}
+
+// Correction vectors from global memory (tiles with more entries than the in-loop path holds): one work item =
+// (entry, 64 rows of the other operand), up to MAXI items requested by a wave before it consumes any.
+__device__ __forceinline__ void v8_corr_from_global(const GemmArgs& a, int* xb, int* wb, int cx, int cw, float* corr,
+                                                    const float* sxt, const float* swt, long long m0, long long n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int MAXI = 12;
+    const int nitems = (cx + cw) * 4;
+    for (int j0 = wave; j0 < nitems; j0 += V8_NW * MAXI) {
+        int4 qv[MAXI];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int j = min(j0 + u * V8_NW, nitems - 1);
+            const bool is_x = (j >> 2) < cx;
+            const int* e = v8_entry(xb, wb, cx, j >> 2);
+            const long long qq = min((is_x ? n0 : m0) + (j & 3) * 64 + lane, (is_x ? a.N : a.M) - 1);
+            qv[u] = *reinterpret_cast<const int4*>((is_x ? a.wm : a.xm) + tiled_offset(qq, (long long)e[1] * 16, a.K));
+        }
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int j = j0 + u * V8_NW;
+            if (j >= nitems) break;
+            const bool is_x = (j >> 2) < cx;
+            const int* e = v8_entry(xb, wb, cx, j >> 2);
+            const int rl = (j & 3) * 64 + lane;
+            const int d = dot16(*reinterpret_cast<const int4*>(e + 4), qv[u]);
+            corr[(j >> 2) * 256 + rl] = __builtin_ldexpf((float)d, e[2] - (is_x ? a.x_off : a.w_off)) * (is_x ? swt : sxt)[rl];
+        }
+    }
+}
+
+// Last resort (more entries than LDS holds): add the exception products to the tile after its stores.
+__device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* wb, int cx, int cw, const float* sxt,
+                                              const float* swt, long long m0, long long n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nitems = (cx + cw) * 4;
+    for (int j = wave; j < nitems; j += V8_NW) {
+        const bool is_x = (j >> 2) < cx;
+        const int* e = v8_entry(xb, wb, cx, j >> 2);
+        const int rl = (j & 3) * 64 + lane;
+        const long long q = (is_x ? n0 : m0) + rl, r = e[0];
+        if (e[3] == -2 || q >= (is_x ? a.N : a.M)) continue;
+        const int4 qv = *reinterpret_cast<const int4*>((is_x ? a.wm : a.xm) + tiled_offset(q, (long long)e[1] * 16, a.K));
+        const int d = dot16(*reinterpret_cast<const int4*>(e + 4), qv);
+        if (d != 0)
+            atomicAdd(&a.y[(is_x ? r : q) * a.ldy + (is_x ? q : r)],
+                      __builtin_ldexpf((float)d, e[2] - (is_x ? a.x_off : a.w_off)) * (is_x ? swt : sxt)[rl]);
+    }
+    for (int idx = tid; idx < cx * cw; idx += V8_NT) {
+        const int* e = xb + EXC_HEADER + EXC_ENTRY * (idx / cw);
+        const int* f = wb + EXC_HEADER + EXC_ENTRY * (idx % cw);
+        if (e[3] == -2 || f[3] == -2 || e[1] != f[1]) continue;
+        const int d = dot16(*reinterpret_cast<const int4*>(e + 4), *reinterpret_cast<const int4*>(f + 4));
+        if (d != 0) atomicAdd(&a.y[(long long)e[0] * a.ldy + f[0]], __builtin_ldexpf((float)d, e[2] + f[2] - a.scale_bias));
+    }
+}
+
+template <int FIXMODE>      // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back
+__global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
+                                                        const float* __restrict__ sw, const int* __restrict__ xlist,
+                                                        const int* __restrict__ wlist) {
+    constexpr int TI = 8, TJ = 4, LPW = 32 / V8_NW;
     __shared__ __attribute__((aligned(16))) unsigned char smem[V8_LDS];
-    if (xlist && (xlist[0] != 0 || wlist[0] != 0)) return;        // a bucket overflowed: the fallback launch runs
+    if (FIXMODE && (xlist[0] != 0 || wlist[0] != 0)) return;        // a bucket overflowed: the fallback launch runs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N, l16 = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
 
     const int tiles_m = (int)((a.M + V8_BM - 1) / V8_BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
     const int nwg = tiles_m * tiles_n;
@@ -57,14 +135,45 @@ __global__ __launch_bounds__(WAVES_N * 128, 1) void bfp_gemm_v8(const GemmArgs a
     const long long m0 = (long long)tm * V8_BM, n0 = (long long)tn * V8_BN;
     const int nsteps = (int)(a.K >> 6);
 
+    int* xb = reinterpret_cast<int*>(smem + V8_XB);
+    int* wb = reinterpret_cast<int*>(smem + V8_WB);
+    int* rowslot = reinterpret_cast<int*>(smem + V8_MAP);
+    int* colslot = rowslot + 256;
+    float* sxt = reinterpret_cast<float*>(smem + V8_SXT);
+    float* swt = reinterpret_cast<float*>(smem + V8_SWT);
+    float* bst = reinterpret_cast<float*>(smem + V8_BIAS);
+
+    // ---- in front of the operand stream (same LDS-DMA queue, so landed by the first counted wait): the tile's
+    //      scale slices and its two exception buckets; the bias slice goes through registers (no padding behind it)
+    if (wave == 0 || wave == 1) {
+        if (FIXMODE) {
+            const int* b = wave == 0 ? row_bucket(xlist, m0) : row_bucket(wlist, n0);
+            unsigned char* d = smem + (wave == 0 ? V8_XB : V8_WB);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q * 256 + lane * 4 < ROW_BUCKET_WORDS)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(b + q * 256 + lane * 4), (lptr_t)(d + q * 1024), 16, 0, 0);
+        }
+    } else if (wave == 2) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(sx + m0 + lane * 4), (lptr_t)(smem + V8_SXT), 16, 0, 0);
+    } else if (wave == 3) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(sw + n0 + lane * 4), (lptr_t)(smem + V8_SWT), 16, 0, 0);
+    } else if (wave == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long n = n0 + q * 64 + lane;
+            bst[q * 64 + lane] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+        }
+    }
+
     const long long kp = a.K >> 6;
     const long long pa_max = ((a.M + 127) / 128) * 8 - 1, pb_max = ((a.N + 127) / 128) * 8 - 1;
-    // piece p of a stage: p < 16 -> 16 rows of A, else 16 rows of B; this wave stages pieces wave + NW * q
+    // piece p of a stage: p < 16 -> 16 rows of A, else 16 rows of B; this wave stages pieces wave + 8 q
     const int8_t* src[LPW];
     int dst[LPW];
 #pragma unroll
     for (int q = 0; q < LPW; ++q) {
-        const int p = wave + NW * q;
+        const int p = wave + V8_NW * q;
         src[q] = p < 16 ? a.xm + min((m0 >> 4) + p, pa_max) * kp * 1024 + lane * 16
                         : a.wm + min((n0 >> 4) + (p - 16), pb_max) * kp * 1024 + lane * 16;
         dst[q] = p * 1024;
@@ -79,7 +188,7 @@ __global__ __launch_bounds__(WAVES_N * 128, 1) void bfp_gemm_v8(const GemmArgs a
 #pragma unroll
     for (int i = 0; i < TI; ++i) aoff[i] = v8_off(wm * 128 + i * 16 + l16, lq);
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) boff[j] = V8_HALF + v8_off(wn * (TJ * 16) + j * 16 + l16, lq);
+    for (int j = 0; j < TJ; ++j) boff[j] = V8_HALF + v8_off(wn * 64 + j * 16 + l16, lq);
 
     i32x4 acc[TI][TJ];
 #pragma unroll
@@ -87,127 +196,193 @@ __global__ __launch_bounds__(WAVES_N * 128, 1) void bfp_gemm_v8(const GemmArgs a
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
 
-    auto read_frags = [&](int slot, i32x4 (&fa)[TI], i32x4 (&fb)[TJ]) {
+    stage(0, 0);
+    if (nsteps > 1) stage(1, 1);
+
+    // exception bookkeeping of this tile (filled in at step 0, once the bucket copies are visible)
+    int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors built in the K loop, 2: after it, 3: atomics
+    int own_step[V8_OWN];                 // K-step at which each entry this wave owns has its block resident
+#pragma unroll
+    for (int q = 0; q < V8_OWN; ++q) own_step[q] = -1;
+    float* corr = reinterpret_cast<float*>(smem + V8_CORR);
+
+    int slot = 0, nslot = 2 % V8_S;
+    for (int t = 0; t < nsteps; ++t) {
+        // stage t landed (for every wave, after the barrier); stage t+1 may be in flight
+        if (t + 1 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nsteps) {
+            stage(t + 2, nslot);
+            nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
+        }
         const unsigned char* sbase = smem + slot * V8_STAGE;
+        i32x4 fa[TI], fb[TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
 #pragma unroll
         for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
-    };
-    auto mfmas = [&](const i32x4 (&fa)[TI], const i32x4 (&fb)[TJ]) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
 
-    stage(0, 0);
-    if (nsteps > 1) stage(1, 1);
-    if (nsteps > 2) stage(2, 2);
-
-    if (PREFETCH == 2) {
-        // as PREFETCH == 1, with the next step's fragment reads and the LDS-DMA loads issued BETWEEN the MFMAs of
-        // the current step (one row of MFMA tiles, then two reads / one load), so the matrix pipe never waits
-        // for their issue slots
-        i32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
-        if (nsteps > 2) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
-        __builtin_amdgcn_s_barrier();
-        read_frags(0, fa0, fb0);
-        auto body = [&](const i32x4 (&fa)[TI], const i32x4 (&fb)[TJ], i32x4 (&na)[TI], i32x4 (&nb)[TJ], int nslot,
-                        bool do_stage, int sstep, int sslot) {
-            const unsigned char* sbase = smem + nslot * V8_STAGE;
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                na[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
-                if (i < TJ) nb[i] = *reinterpret_cast<const i32x4*>(sbase + boff[i]);
-                if (do_stage && i >= TI - LPW) {
-                    const int q = i - (TI - LPW);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)sstep * 1024),
-                                                     (lptr_t)(smem + sslot * V8_STAGE + dst[q]), 16, 0, 0);
+        if (FIXMODE) {
+            if (t == 0) {
+                cx = __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+                cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
+                mode = cx + cw == 0 ? 0 : (cx + cw <= V8_FAST_MAX ? 1 : (cx + cw <= V8_SLOW_MAX ? 2 : 3));
+                if (mode) {
+                    rowslot[tid & 255] = -1;                    // tid < 256: rowslot, else colslot (contiguous)
+                    if (tid >= 256) colslot[tid & 255] = -1;
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, TJ, 0);     // TJ MFMA
-                if (i < TJ) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS reads
-                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (i >= TI - LPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM
+                if (mode == 1) {
+#pragma unroll
+                    for (int q = 0; q < V8_OWN; ++q) {
+                        const int idx = wave + V8_NW * q;
+                        own_step[q] = idx < cx + cw ? __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, idx)[1] >> 2) : -1;
+                    }
+                }
+            } else if (t == 1 && mode) {
+                // push every entry on the chain of its tile row / column (heads in rowslot / colslot, successor in word
+                // 3 of the entry's LDS copy; -2 marks a void entry)
+                for (int i = tid; i < cx + cw; i += V8_NT) {
+                    const bool is_x = i < cx;
+                    int* e = v8_entry(xb, wb, cx, i);
+                    const long long r = e[0], r0 = is_x ? m0 : n0, rmax = is_x ? a.M : a.N;
+                    const bool live = r >= r0 && r < min(r0 + 256, rmax);
+                    e[3] = live ? atomicExch(&(is_x ? rowslot : colslot)[r - r0], is_x ? i : i - cx) : -2;
+                }
             }
-        };
-        for (int t = 0; t < nsteps; t += 2) {
-            if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
-            __builtin_amdgcn_s_barrier();
-            body(fa0, fb0, fa1, fb1, (t + 1) & 3, t + 3 < nsteps, t + 3, (t + 3) & 3);
-            if (t + 3 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
-            __builtin_amdgcn_s_barrier();
-            body(fa1, fb1, fa0, fb0, (t + 2) & 3, t + 4 < nsteps, t + 4, t & 3);
+            if (mode == 1) {
+#pragma unroll
+                for (int q = 0; q < V8_OWN; ++q) {
+                    if (own_step[q] != t) continue;             // (uniform)
+                    const int idx = wave + V8_NW * q;
+                    const bool is_x = idx < cx;
+                    const int* e = v8_entry(xb, wb, cx, idx);
+                    const int4 pv = *reinterpret_cast<const int4*>(e + 4);
+                    const int chunk = e[1] & 3, shift = e[2] - (is_x ? a.x_off : a.w_off);
+                    const unsigned char* other = sbase + (is_x ? V8_HALF : 0);
+                    const float* sc = is_x ? swt : sxt;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int rl = c * 64 + lane;
+                        const int4 qv = *reinterpret_cast<const int4*>(other + v8_off(rl, chunk));
+                        corr[idx * 256 + rl] = __builtin_ldexpf((float)dot16(pv, qv), shift) * sc[rl];
+                    }
+                }
+            }
         }
-    } else if (PREFETCH) {
-        // fragments of step t+1 are requested before the MFMAs of step t are issued; two register sets, the
-        // loop is unrolled by two (nsteps is even: K % 128 == 0)
-        i32x4 fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
-        if (nsteps > 2) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
-        __builtin_amdgcn_s_barrier();
-        read_frags(0, fa0, fb0);
-        for (int t = 0; t < nsteps; t += 2) {
-            // stage t+1 landed (for every wave, after the barrier); stage t+2 may be in flight
-            if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
-            __builtin_amdgcn_s_barrier();
-            if (t + 3 < nsteps) stage(t + 3, (t + 3) & 3);
-            read_frags((t + 1) & 3, fa1, fb1);
-            mfmas(fa0, fb0);
-            if (t + 3 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
-            __builtin_amdgcn_s_barrier();
-            if (t + 4 < nsteps) stage(t + 4, t & 3);
-            read_frags((t + 2) & 3, fa0, fb0);          // past the end: stale data, never used
-            mfmas(fa1, fb1);
+        slot = slot + 1 == V8_S ? 0 : slot + 1;
+    }
+
+    if (FIXMODE && mode) {
+        if (nsteps < 2) mode = 3;                                // (chains were never pushed: K = 64 only)
+        __syncthreads();                                         // every wave is done with the stage area
+        if (mode == 2) {
+            corr = reinterpret_cast<float*>(smem);
+            v8_corr_from_global(a, xb, wb, cx, cw, corr, sxt, swt, m0, n0);
+            __syncthreads();
         }
-    } else {
-        for (int t = 0; t < nsteps; ++t) {
-            i32x4 fa[TI], fb[TJ];
-            if (t + 2 < nsteps) V8_WAIT(2 * LPW); else if (t + 1 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
-            __builtin_amdgcn_s_barrier();
-            if (t + 3 < nsteps) stage(t + 3, (t + 3) & 3);
-            read_frags(t & 3, fa, fb);
-            mfmas(fa, fb);
+        if (mode != 3) {
+            for (int idx = tid; idx < cx * cw; idx += V8_NT) {   // exception x exception: one (vector, element) each
+                const int ex = idx / cw;
+                const int* e = xb + EXC_HEADER + EXC_ENTRY * ex;
+                const int* f = wb + EXC_HEADER + EXC_ENTRY * (idx % cw);
+                if (e[3] == -2 || f[3] == -2 || e[1] != f[1]) continue;
+                const int d = dot16(*reinterpret_cast<const int4*>(e + 4), *reinterpret_cast<const int4*>(f + 4));
+                corr[ex * 256 + (int)(f[0] - n0)] += __builtin_ldexpf((float)d, e[2] + f[2] - a.scale_bias);
+            }
+            __syncthreads();
         }
     }
 
-    // ---- epilogue: y = float(acc) * sx[m] * sw[n] + bias[n]
+    // ---- epilogue: y = float(acc) * sx[m] * sw[n] + bias[n] (+ correction vectors).  Nothing is loaded from
+    //      global memory between the stores (vmcnt counts loads and stores alike: a load's wait would drain them).
+    const bool look = FIXMODE && (mode == 1 || mode == 2);
+    float val[TI][TJ][4];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        const long long col = n0 + wn * (TJ * 16) + j * 16 + l16;
-        const bool cok = col < a.N;
-        const float swv = cok ? sw[col] : 0.f;
-        const float bv = (cok && a.bias) ? a.bias[col] : 0.f;
+        const int cl = wn * 64 + j * 16 + l16;
+        const float swv = swt[cl], bv = bst[cl];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
+            const f32x4 sxv = *reinterpret_cast<const f32x4*>(&sxt[wm * 128 + i * 16 + lq * 4]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long row = m0 + wm * 128 + i * 16 + lq * 4 + r;
-                if (cok && row < a.M) a.y[row * a.ldy + col] = (float)acc[i][j][r] * sx[row] * swv + bv;
-            }
+            for (int r = 0; r < 4; ++r) val[i][j][r] = (float)acc[i][j][r] * sxv[r] * swv + bv;
         }
     }
-    // ---- exception blocks of this tile's rows / columns (usually a few dozen): added to the tile just stored
-    if (xlist) {
+    if (look) {
+        // column vectors (w exceptions): a lane's 32 rows of one column are 8 runs of 4 consecutive floats
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            int s = colslot[wn * 64 + j * 16 + l16];
+            while (__any(s >= 0)) {
+                if (s >= 0) {
+                    const float* v = corr + (cx + s) * 256 + wm * 128 + lq * 4;
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) {
+                        const f32x4 c4 = *reinterpret_cast<const f32x4*>(v + i * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) val[i][j][r] += c4[r];
+                    }
+                    s = wb[EXC_HEADER + EXC_ENTRY * s + 3];
+                }
+            }
+        }
+        // row vectors (x exceptions)
+        int sr[TI][4];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sr[i][r] = rowslot[wm * 128 + i * 16 + lq * 4 + r];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int s = sr[i][r];
+                while (__any(s >= 0)) {
+                    if (s >= 0) {
+                        const float* v = corr + s * 256 + wn * 64 + l16;
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) val[i][j][r] += v[j * 16];
+                        s = xb[EXC_HEADER + EXC_ENTRY * s + 3];
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long row = m0 + wm * 128 + i * 16 + lq * 4 + r;
+            float* yrow = a.y + row * a.ldy + n0 + wn * 64 + l16;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                if (n0 + wn * 64 + j * 16 + l16 < a.N && row < a.M) yrow[j * 16] = val[i][j][r];
+        }
+    }
+    if (FIXMODE && mode == 3) {
         V8_WAIT(0);
         __syncthreads();
-        tile_fix_pairs<V8_BM, V8_BN>(a, row_bucket(xlist, m0), row_bucket(wlist, n0), ROW_BCAP, m0, n0);
+        if (nsteps < 2) {                                        // void marks were never written
+            for (int i = tid; i < cx + cw; i += V8_NT) {
+                int* e = v8_entry(xb, wb, cx, i);
+                const long long r = e[0], r0 = i < cx ? m0 : n0, rmax = i < cx ? a.M : a.N;
+                e[3] = (r >= r0 && r < min(r0 + 256, rmax)) ? -1 : -2;
+            }
+            __syncthreads();
+        }
+        v8_fix_atomic(a, xb, wb, cx, cw, sxt, swt, m0, n0);
     }
 }
 
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st) {
+    (void)list_cap;
     const unsigned tiles = (unsigned)(((a.M + V8_BM - 1) / V8_BM) * ((a.N + V8_BN - 1) / V8_BN));
-    const char* dbg = getenv("MI355Q_V8_CFG");
-    const int d = dbg ? atoi(dbg) : 0;
-    if (d == 1) hipLaunchKernelGGL((bfp_gemm_v8<4, 0>), tiles, 512, 0, st, a, sx, sw, xlist, wlist, list_cap);
-    else if (d == 2) hipLaunchKernelGGL((bfp_gemm_v8<2, 0>), tiles, 256, 0, st, a, sx, sw, xlist, wlist, list_cap);
-    else if (d == 3) hipLaunchKernelGGL((bfp_gemm_v8<4, 1>), tiles, 512, 0, st, a, sx, sw, xlist, wlist, list_cap);
-    else if (d == 4) hipLaunchKernelGGL((bfp_gemm_v8<2, 2>), tiles, 256, 0, st, a, sx, sw, xlist, wlist, list_cap);
-    else if (d == 5) hipLaunchKernelGGL((bfp_gemm_v8<2, 1>), tiles, 256, 0, st, a, sx, sw, xlist, wlist, list_cap);
-    else hipLaunchKernelGGL((bfp_gemm_v8<4, 2>), tiles, 512, 0, st, a, sx, sw, xlist, wlist, list_cap);
+    if (xlist && wlist) hipLaunchKernelGGL((bfp_gemm_v8<1>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    else hipLaunchKernelGGL((bfp_gemm_v8<0>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
     return (int)hipGetLastError();
 }
 

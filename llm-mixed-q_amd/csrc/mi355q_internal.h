@@ -42,6 +42,7 @@ struct GemmArgs {
     long long M, N, K, ldy;
     int scale_bias;   // subtracted from xe + we to get the power of two of a block product
     int row_mode;     // 1: operands are ROW-aligned (rowflag[row], bucketed exception lists)
+    int x_off, w_off; // exponent_bias + mbits of each operand (scale_bias = x_off + w_off)
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
