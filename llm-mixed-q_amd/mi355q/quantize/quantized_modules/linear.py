@@ -58,7 +58,12 @@ class _LinearBase(nn.Linear):
         self.is_ptq = config.get("is_ptq", False)
         self.weight_requires_quantisation = True if self.is_ptq else False
         self.x_quantizer = self.w_quantizer = self.b_quantizer = None
-        self._packed = None          # (wm, we, weight._version, bias._version) once W is packed
+        self._packed = None          # (aligned W operand, its tiled mantissas, weight._version, bias._version)
+        # exponent alignment of the packed operands (an implementation knob, not part of the reference config):
+        # "rows" = one exponent per row (row-scale int8 GEMM), "groups" = per 256 values, "auto" = rows when the
+        # weights and the first activations fit it, re-checked on a doubling schedule
+        self.align = config.get("mi355q_align", "auto")
+        self._align_mode, self._canonical, self._calls, self._row_overflows = None, None, 0, 0
         if not self.bypass:
             self._setup_quantizers(config)
 
@@ -91,7 +96,7 @@ class _LinearBase(nn.Linear):
         return c["data_in_width"] - 1, c["weight_width"] - 1, xb, wb
 
     @torch.no_grad()
-    def _quantise_weights_once(self, pack: bool):
+    def _quantise_weights_once(self, pack: bool, x_sample=None):
         """linear.py:66-70 plus the one-off packing of the int8 operand"""
         c = self.config
         if pack:
@@ -105,10 +110,38 @@ class _LinearBase(nn.Linear):
             self.bias.copy_(self.b_quantizer(self.bias.data))
         self.weight_requires_quantisation = False
         if pack:
-            wb = c["weight_exponent_bias"]
-            wb = 2 ** (c["weight_exponent_width"] - 1) - 1 if wb in (None, "none", "None") else wb
-            wa = ops.bfp_align(wm, we, c["weight_width"] - 1, wb, inplace=True)
-            self._packed = (wa, wa.tiled, self.weight._version, None if self.bias is None else self.bias._version)
+            self._canonical = (wm, we) if self.align == "auto" else None
+            self._align_weights(wm, we, self._choose_align_mode(wm, we, x_sample))
+
+    def _weight_bias_value(self):
+        c = self.config
+        wb = c["weight_exponent_bias"]
+        return 2 ** (c["weight_exponent_width"] - 1) - 1 if wb in (None, "none", "None") else wb
+
+    def _choose_align_mode(self, wm, we, x_sample):
+        if self.align == "groups" or not ops.row_align_supported(self.in_features):
+            return "groups"
+        if self.align == "rows":
+            return "rows"
+        c = self.config
+        wa = ops.bfp_align_rows(wm, we, c["weight_width"] - 1, self._weight_bias_value())
+        if int(wa.sparse[0]) != 0:                 # (one-off host read at pack time)
+            return "groups"
+        if x_sample is not None:
+            xa = ops.block_fp_quantize_aligned_rows(x_sample.reshape(-1, self.in_features), c["data_in_width"],
+                                                    c["data_in_exponent_width"], c["data_in_exponent_bias"])
+            if int(xa.sparse[0]) != 0:
+                return "groups"
+        return "rows"
+
+    def _align_weights(self, wm, we, mode):
+        c = self.config
+        if mode == "rows":
+            wa = ops.bfp_align_rows(wm, we, c["weight_width"] - 1, self._weight_bias_value())
+        else:
+            wa = ops.bfp_align(wm, we, c["weight_width"] - 1, self._weight_bias_value(), inplace=self._canonical is None)
+        self._align_mode = mode
+        self._packed = (wa, wa.tiled, self.weight._version, None if self.bias is None else self.bias._version)
 
     def _packed_is_current(self) -> bool:
         p = self._packed
@@ -119,7 +152,7 @@ class _LinearBase(nn.Linear):
         """Search-loop helper: after loading new fp32 weights into .weight/.bias, make the
         next forward quantise and pack them again instead of rebuilding the model."""
         self.weight_requires_quantisation = True if self.is_ptq else False
-        self._packed = None
+        self._packed, self._canonical, self._align_mode, self._calls, self._row_overflows = None, None, None, 0, 0
 
     def forward(self, x):
         if self.bypass:
@@ -128,7 +161,7 @@ class _LinearBase(nn.Linear):
             plan = self._int8_plan(x)
             with torch.no_grad():
                 if self.weight_requires_quantisation:
-                    self._quantise_weights_once(pack=plan is not None)
+                    self._quantise_weights_once(pack=plan is not None, x_sample=x)
                 if plan is not None and self._packed_is_current():
                     return self._forward_int8(x, plan)
                 x = self.x_quantizer(x)
@@ -142,7 +175,10 @@ class _LinearBase(nn.Linear):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
         x2 = x.reshape(-1, self.in_features)
-        if self.in_features % 256 == 0:      # one fused kernel: quantise + pack + align + tile
+        if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
+            xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
+                                                    c["data_in_exponent_bias"])
+        elif self.in_features % 256 == 0:    # the same per 256-value group
             xa = ops.block_fp_quantize_aligned(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                c["data_in_exponent_bias"])
         else:
@@ -151,6 +187,14 @@ class _LinearBase(nn.Linear):
                                               want_packed=True, fast_zero_blocks=True)
             xa = ops.bfp_align(xm, xe, x_mbits, xb, inplace=True)
         y = ops.bfp_gemm_aligned(xa, self._packed[0], self.bias)
+        if self._align_mode == "rows" and self.align == "auto":
+            # results never depend on the mode (an overflowing exception bucket only sends the GEMM to its slow
+            # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats
+            self._calls += 1
+            if self._calls & (self._calls - 1) == 0 and int(xa.sparse[0]) != 0:
+                self._row_overflows += 1
+                if self._row_overflows >= 2 and self._canonical is not None:
+                    self._align_weights(*self._canonical, "groups")
         return y.reshape(*x.shape[:-1], self.out_features)
 
     @classmethod

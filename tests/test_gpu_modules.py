@@ -74,6 +74,60 @@ def test_linear_int8_path_vs_oracle(wx, ww, has_bias):
         assert np.array_equal(lin.bias.detach().cpu().numpy(), bq)
 
 
+@pytest.mark.parametrize("align", ["auto", "rows", "groups"])
+@pytest.mark.parametrize("outliers", [False, True])
+def test_linear_int8_align_modes(align, outliers):
+    """the exponent-alignment flavour of the packed operands is an implementation knob: every choice gives the
+    oracle's result; "auto" takes whole rows when weights and first activations fit them"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8,
+               data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8,
+               weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8,
+               bias_exponent_bias=127, bias_block_size=[16], mi355q_align=align)
+    torch.manual_seed(5)
+    fp = torch.nn.Linear(512, 192, bias=True)
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    w0, b0 = fp.weight.detach().numpy().copy(), fp.bias.detach().numpy().copy()
+    x = torch.randn(3, 100, 512) * torch.exp(torch.randn(3, 100, 1))
+    if outliers:
+        x[..., 100:104] *= 400.0             # an outlier channel: one exception block in EVERY row
+    for call in range(3):
+        y = lin(x.to("cuda:0"))
+        ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(3, 100, 192)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+    want = {"rows": "rows", "groups": "groups", "auto": "groups" if outliers else "rows"}[align]
+    assert lin._align_mode == want           # 300 rows x 1 exception overflow the 120-entry bucket of rows 0..255
+
+
+def test_linear_auto_align_leaves_row_mode_when_activations_stop_fitting():
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8,
+               data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8,
+               weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8,
+               bias_exponent_bias=127, bias_block_size=[16])
+    torch.manual_seed(6)
+    fp = torch.nn.Linear(256, 64, bias=False)
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    w0 = fp.weight.detach().numpy().copy()
+    calm = torch.randn(300, 256)
+    wild = calm.clone()
+    wild[:, 32:36] *= 500.0
+    lin(calm.to("cuda:0"))
+    assert lin._align_mode == "rows"
+    for call in range(4):                    # overflow seen at calls 2 and 4 of the doubling schedule -> groups
+        y = lin(wild.to("cuda:0"))
+        ref = O.bfp_linear_int(wild.numpy(), w0, None, cfg)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+    assert lin._align_mode == "groups"
+    y = lin(calm.to("cuda:0"))
+    ref = O.bfp_linear_int(calm.numpy(), w0, None, cfg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("tag", TAGS)
 @pytest.mark.parametrize("op", ["bmm0", "bmm1", "mm4d", "mm2d"])
 def test_matmul_golden(tag, op, golden_modules):
