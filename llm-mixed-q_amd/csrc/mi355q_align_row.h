@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned shl_packed(unsigned pk, int s) {
 
 // Returns true when the row carries one exponent (E); pk[] is rewritten in place (shifted / zeroed).
 // When it returns false nothing was changed.  All 256 threads must call it (workgroup barriers inside).
-template <int MAXIT>
+template <int MAXIT, bool FULL = false>
 __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&amax)[MAXIT], const int (&code)[MAXIT], int nit,
                                           int nkb, long long row, int* __restrict__ list, RowAlignSmem& sm, int& E) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,12 +56,16 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int kb = it * 64 + wave * 16 + (lane >> 2);
-        has[it] = it < nit && kb < nkb && amax[it] > 0;
+        has[it] = (FULL || (it < nit && kb < nkb)) && amax[it] > 0;
         head[it] = has[it] ? __clz(amax[it]) - 25 : 0;
         em = min(em, has[it] ? code[it] : BIG);
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) em = min(em, __shfl_xor(em, o));
+    em = min(em, __builtin_amdgcn_mov_dpp(em, 0x121, 0xF, 0xF, true));   // row_ror:1
+    em = min(em, __builtin_amdgcn_mov_dpp(em, 0x122, 0xF, 0xF, true));   // row_ror:2
+    em = min(em, __builtin_amdgcn_mov_dpp(em, 0x124, 0xF, 0xF, true));   // row_ror:4
+    em = min(em, __builtin_amdgcn_mov_dpp(em, 0x128, 0xF, 0xF, true));   // row_ror:8
+    em = min(min(__builtin_amdgcn_readlane(em, 0), __builtin_amdgcn_readlane(em, 16)),
+             min(__builtin_amdgcn_readlane(em, 32), __builtin_amdgcn_readlane(em, 48)));
     if (lane == 0) sm.emin[wave] = em;
     if (tid == 0) { sm.code0 = code[0]; sm.nexc = 0; }
     sm.cnt[tid] = 0;

@@ -38,17 +38,51 @@ constexpr int V8_HALF = 256 * 64, V8_STAGE = 2 * V8_HALF;
 constexpr int V8_BUCKET = 4096;                     // LDS copy of one exception bucket (ROW_BUCKET_WORDS * 4 <= 4096)
 constexpr int V8_XB = V8_S * V8_STAGE, V8_WB = V8_XB + V8_BUCKET, V8_MAP = V8_WB + V8_BUCKET;
 constexpr int V8_SXT = V8_MAP + 2 * 256 * 4, V8_SWT = V8_SXT + 1024, V8_BIAS = V8_SWT + 1024;
-constexpr int V8_CORR = V8_BIAS + 1024;
+constexpr int V8_PLAN = V8_BIAS + 1024;              // int plan[8 waves][8]: each wave's entries in K-step order
+constexpr int V8_CORR = V8_PLAN + 256;
 constexpr int V8_LDS = 160 * 1024;
 constexpr int V8_FAST_MAX = (V8_LDS - V8_CORR) / 1024;      // entries (x + w) whose vectors fit beside the stages
 constexpr int V8_SLOW_MAX = V8_S * V8_STAGE / 1024;         // ... that fit the stage area after the K loop
-constexpr int V8_OWN = (V8_FAST_MAX + V8_NW - 1) / V8_NW;   // entries one wave may own in the fast path
+static_assert((V8_FAST_MAX + V8_NW - 1) / V8_NW <= 8, "plan rows hold 8 entries");
 static_assert(ROW_BUCKET_WORDS * 4 <= V8_BUCKET, "bucket copy");
 static_assert(V8_FAST_MAX >= 40, "spare LDS for correction vectors");
 
 __device__ __forceinline__ int v8_off(int r, int c) { return r * 64 + ((c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 4); }
 
 #define V8_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// LDS accesses the compiler's wait-count pass must not see: beside LDS-DMA loads in flight it puts `s_waitcnt vmcnt(0)`
+// in front of any LDS access it cannot prove disjoint from their destinations, which drains the operand pipeline.
+// The caller orders these by hand (s_waitcnt lgkmcnt(0) before the next barrier; lds_settle() before first use).
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lptr_t)p; }
+__device__ __forceinline__ int4 lds_read16_raw(const void* p) {
+    int4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ int lds_read4_raw(const void* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ int lds_read4_now(const void* p) {          // the same, waited for
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ int4 global_read16_raw(const void* p) {
+    int4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write4_raw(void* p, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ int lds_settle(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int4 lds_settle(int4 v) { return int4{lds_settle(v.x), lds_settle(v.y), lds_settle(v.z), lds_settle(v.w)}; }
 
 // entry i of the combined list (x entries first, then w entries) in the LDS bucket copies
 __device__ __forceinline__ int* v8_entry(int* xb, int* wb, int cx, int i) {
@@ -111,13 +145,17 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
     }
 }
 
-template <int FIXMODE>      // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back
+template <int FIXMODE_, bool PHASED>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
+                            // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
                                                         const int* __restrict__ wlist) {
+    constexpr int FIXMODE = (FIXMODE_ == 1 || FIXMODE_ == 3) ? 1 : 0;      // 3: as 1, with phase timing printed by workgroup 0
     constexpr int TI = 8, TJ = 4, LPW = 32 / V8_NW;
     __shared__ __attribute__((aligned(16))) unsigned char smem[V8_LDS];
-    if (FIXMODE && (xlist[0] != 0 || wlist[0] != 0)) return;        // a bucket overflowed: the fallback launch runs
+    // a bucket overflowed: the fallback launch forms the product, this one must not write.  (Read now, looked at
+    // after the K loop: an early exit would put a memory round trip in front of every workgroup.)
+    const int overflowed = FIXMODE ? (xlist[0] | wlist[0]) : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
@@ -134,6 +172,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     const int tm = first_m + (pid % in_group) % gsz, tn = (pid % in_group) / gsz;
     const long long m0 = (long long)tm * V8_BM, n0 = (long long)tn * V8_BN;
     const int nsteps = (int)(a.K >> 6);
+    const long long Mrows = a.M, Ncols = a.N;
 
     int* xb = reinterpret_cast<int*>(smem + V8_XB);
     int* wb = reinterpret_cast<int*>(smem + V8_WB);
@@ -199,83 +238,202 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     stage(0, 0);
     if (nsteps > 1) stage(1, 1);
 
-    // exception bookkeeping of this tile (filled in at step 0, once the bucket copies are visible)
-    int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors built in the K loop, 2: after it, 3: atomics
-    int own_step[V8_OWN];                 // K-step at which each entry this wave owns has its block resident
-#pragma unroll
-    for (int q = 0; q < V8_OWN; ++q) own_step[q] = -1;
+    // ---- exception bookkeeping of this tile.  The bucket copies rode in front of the operand stream; once they have
+    //      landed (the first two stages stay in flight) the workgroup counts the entries, clears the row / column maps
+    //      and lays out, per wave, the entries that wave will handle in K-step order (entry i belongs to wave i & 7).
+    int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors built during the K loop, 2: after it, 3: atomics
     float* corr = reinterpret_cast<float*>(smem + V8_CORR);
-
-    int slot = 0, nslot = 2 % V8_S;
-    for (int t = 0; t < nsteps; ++t) {
-        // stage t landed (for every wave, after the barrier); stage t+1 may be in flight
-        if (t + 1 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
+    int* plan = reinterpret_cast<int*>(smem + V8_PLAN);
+    int plan_cnt = 0, plan_cur = 0, evt_step = -1, pending = -1, desc = 0, desc_next = 0;
+    if (FIXMODE) {
+        if (nsteps > 1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < nsteps) {
-            stage(t + 2, nslot);
-            nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
-        }
-        const unsigned char* sbase = smem + slot * V8_STAGE;
-        i32x4 fa[TI], fb[TJ];
-#pragma unroll
-        for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-
-        if (FIXMODE) {
-            if (t == 0) {
-                cx = __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
-                cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
-                mode = cx + cw == 0 ? 0 : (cx + cw <= V8_FAST_MAX ? 1 : (cx + cw <= V8_SLOW_MAX ? 2 : 3));
-                if (mode) {
-                    rowslot[tid & 255] = -1;                    // tid < 256: rowslot, else colslot (contiguous)
-                    if (tid >= 256) colslot[tid & 255] = -1;
+        cx = __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+        cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
+        const int n = cx + cw;
+        mode = n == 0 ? 0 : (n <= V8_FAST_MAX && nsteps >= 2) ? 1 : (n <= V8_SLOW_MAX ? 2 : 3);
+        if (mode) {
+            rowslot[tid & 255] = -1;                        // tid < 256: rowslot, else colslot (contiguous)
+            if (tid >= 256) colslot[tid & 255] = -1;
+            if (tid == 0) plan[7] = 0;                      // set when some row / column carries two or more entries
+            if (mode == 1 && tid < n) {
+                // descriptor = K-step << 16 | chunk of the 64-byte step << 13 | entry; rank among this wave's entries
+                const int kb = v8_entry(xb, wb, cx, tid)[1];
+                const int key = (kb >> 2) * 64 + tid;
+                int rank = 0;
+                for (int j = tid & 7; j < n; j += 8) {
+                    const int kj = (v8_entry(xb, wb, cx, j)[1] >> 2) * 64 + j;
+                    rank += kj < key ? 1 : 0;
                 }
-                if (mode == 1) {
-#pragma unroll
-                    for (int q = 0; q < V8_OWN; ++q) {
-                        const int idx = wave + V8_NW * q;
-                        own_step[q] = idx < cx + cw ? __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, idx)[1] >> 2) : -1;
-                    }
-                }
-            } else if (t == 1 && mode) {
-                // push every entry on the chain of its tile row / column (heads in rowslot / colslot, successor in word
-                // 3 of the entry's LDS copy; -2 marks a void entry)
-                for (int i = tid; i < cx + cw; i += V8_NT) {
-                    const bool is_x = i < cx;
-                    int* e = v8_entry(xb, wb, cx, i);
-                    const long long r = e[0], r0 = is_x ? m0 : n0, rmax = is_x ? a.M : a.N;
-                    const bool live = r >= r0 && r < min(r0 + 256, rmax);
-                    e[3] = live ? atomicExch(&(is_x ? rowslot : colslot)[r - r0], is_x ? i : i - cx) : -2;
-                }
+                plan[(tid & 7) * 8 + rank] = ((kb >> 2) << 16) | ((kb & 3) << 13) | tid;
+            }
+            __builtin_amdgcn_s_barrier();
+            // chains: every entry is pushed on the list of its tile row / column (heads in rowslot / colslot,
+            // successor in word 3 of the entry's LDS copy; -2 marks a void entry)
+            for (int i = tid; i < n; i += V8_NT) {
+                const bool is_x = i < cx;
+                int* e = v8_entry(xb, wb, cx, i);
+                const long long r = e[0];
+                const bool live = is_x ? (r >= m0 && r < m0 + 256 && r < Mrows) : (r >= n0 && r < n0 + 256 && r < Ncols);
+                const long long r0_ = is_x ? m0 : n0;
+                e[3] = live ? atomicExch(&(is_x ? rowslot : colslot)[r - r0_], is_x ? i : i - cx) : -2;
+                if (e[3] >= 0) plan[7] = 1;
             }
             if (mode == 1) {
-#pragma unroll
-                for (int q = 0; q < V8_OWN; ++q) {
-                    if (own_step[q] != t) continue;             // (uniform)
-                    const int idx = wave + V8_NW * q;
-                    const bool is_x = idx < cx;
-                    const int* e = v8_entry(xb, wb, cx, idx);
-                    const int4 pv = *reinterpret_cast<const int4*>(e + 4);
-                    const int chunk = e[1] & 3, shift = e[2] - (is_x ? a.x_off : a.w_off);
-                    const unsigned char* other = sbase + (is_x ? V8_HALF : 0);
-                    const float* sc = is_x ? swt : sxt;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int rl = c * 64 + lane;
-                        const int4 qv = *reinterpret_cast<const int4*>(other + v8_off(rl, chunk));
-                        corr[idx * 256 + rl] = __builtin_ldexpf((float)dot16(pv, qv), shift) * sc[rl];
-                    }
+                plan_cnt = n > wave ? (n - wave + 7) >> 3 : 0;
+                if (plan_cnt > 0) {
+                    desc = __builtin_amdgcn_readfirstlane(plan[wave * 8]);
+                    evt_step = desc >> 16;
                 }
             }
         }
-        slot = slot + 1 == V8_S ? 0 : slot + 1;
     }
 
+    unsigned long long c0 = 0, r0 = 0;
+    unsigned long long rt[6] = {0, 0, 0, 0, 0, 0};
+    if (FIXMODE_ == 2) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (FIXMODE_ == 3) rt[0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- exception side work inside the K loop (mode 1).  At the K-step that has an entry's block resident in
+    //      LDS, the owning wave REQUESTS the 256 blocks of the other operand it meets (4 LDS reads + scales, raw: see
+    //      lds_read16_raw); one step later, the data being in registers, it forms the dot products and writes the
+    //      correction vector.  Nothing waits, and a step without an event costs one scalar compare.
+    int4 pq[4], ppv = {0, 0, 0, 0};
+    int psc[4], pshift = 0, pend_off = 0;
+    auto side_consume = [&]() {
+        const int4 pv = lds_settle(ppv);
+        const int sh = lds_settle(pshift) - pend_off;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            lds_write4_raw(&corr[pending * 256 + c * 64 + lane],
+                           __builtin_ldexpf((float)dot16(pv, lds_settle(pq[c])), sh) * __int_as_float(lds_settle(psc[c])));
+        pending = -1;
+    };
+    const int lane_row_off = lane * 64;
+    const int lane_h = (0x78 >> (2 * ((lane >> 2) & 3))) & 3;
+    auto side_event = [&](int t, const unsigned char* sbase) {
+        if (pending >= 0) {                                  // requested at step t - 1
+            side_consume();
+            desc = __builtin_amdgcn_readfirstlane(lds_settle(desc_next));
+        }
+        while (plan_cur < plan_cnt && (desc >> 16) == t) {   // (a second entry of this wave at the same step: rare)
+            if (pending >= 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                side_consume();
+                desc = __builtin_amdgcn_readfirstlane(lds_settle(desc_next));
+                continue;
+            }
+            const int idx = desc & 0x1FFF, chunk = (desc >> 13) & 3;
+            const bool is_x = idx < cx;
+            const int* e = v8_entry(xb, wb, cx, idx);
+            const unsigned char* other = sbase + (is_x ? V8_HALF : 0) + lane_row_off + ((chunk ^ lane_h) << 4);
+            const float* sc = (is_x ? swt : sxt) + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                pq[c] = lds_read16_raw(other + c * 4096);
+                psc[c] = lds_read4_raw(sc + c * 64);
+            }
+            ppv = lds_read16_raw(e + 4);
+            pshift = lds_read4_raw(e + 2);
+            pend_off = is_x ? a.x_off : a.w_off;
+            pending = idx;
+            ++plan_cur;
+            desc_next = plan_cur < plan_cnt ? lds_read4_raw(&plan[wave * 8 + plan_cur]) : (-1 << 16);
+        }
+        evt_step = pending >= 0 ? t + 1 : (plan_cur < plan_cnt ? desc >> 16 : -1);
+    };
+
+    int slot = 0, nslot = 2 % V8_S;
+    if (PHASED) {
+        // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while a group issues its 16
+        // MFMAs between two barriers, the other reads its next fragments from LDS and issues its LDS-DMA loads.
+        // A K-step is two such phases (A rows 0-63, then 64-127 of the wave tile).  Reads are retired (lgkmcnt(0))
+        // before the barrier that ends their segment, so a stage is re-filled only after every read of it.
+        auto dma2 = [&](int step, int sl, int q0) {
+#pragma unroll
+            for (int q = q0; q < q0 + 2; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
+                                                 (lptr_t)(smem + sl * V8_STAGE + dst[q]), 16, 0, 0);
+        };
+        if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nsteps; ++t) {
+            const unsigned char* sbase = smem + slot * V8_STAGE;
+            i32x4 fa[4], fb[TJ];
+            // ---- phase 0
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
+            if (t + 2 < nsteps) dma2(t + 2, nslot, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[4 + i]);
+            if (t + 2 < nsteps) {
+                dma2(t + 2, nslot, 2);
+                nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
+            }
+            if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);      // this wave's pieces of step t+1 have landed
+            if (FIXMODE && t == evt_step) side_event(t, sbase);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == V8_S ? 0 : slot + 1;
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+    } else {
+        for (int t = 0; t < nsteps; ++t) {
+            // stage t landed (for every wave, after the barrier); stage t+1 may be in flight
+            if (t + 1 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < nsteps) {
+                stage(t + 2, nslot);
+                nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
+            }
+            const unsigned char* sbase = smem + slot * V8_STAGE;
+            i32x4 fa[TI], fb[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (FIXMODE && t == evt_step) side_event(t, sbase);
+            slot = slot + 1 == V8_S ? 0 : slot + 1;
+        }
+    }
+
+    if (FIXMODE && overflowed) return;
+    if (FIXMODE && pending >= 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        side_consume();
+    }
+    if (FIXMODE_ == 3) rt[1] = __builtin_amdgcn_s_memrealtime();
+    if (FIXMODE_ == 2) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((blockIdx.x == 0 || blockIdx.x == 77) && tid == 0)
+            printf("wg %d: K loop %llu shader clocks in %llu x 10 ns -> %.0f MHz, %.1f clocks per K-step\n", blockIdx.x, c1 - c0,
+                   r1 - r0, (double)(c1 - c0) / (double)(r1 - r0) * 100.0, (double)(c1 - c0) / nsteps);
+    }
     if (FIXMODE && mode) {
         if (nsteps < 2) mode = 3;                                // (chains were never pushed: K = 64 only)
         __syncthreads();                                         // every wave is done with the stage area
@@ -294,11 +452,43 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                 corr[ex * 256 + (int)(f[0] - n0)] += __builtin_ldexpf((float)d, e[2] + f[2] - a.scale_bias);
             }
             __syncthreads();
+            // rows / columns with two or more entries (flagged while the chains were pushed; uncommon): fold the
+            // vectors of a chain into its head's, so that the epilogue reads ONE vector per row / column
+            if (plan[7] != 0 && wave == 0) {
+                for (int base = 0; base < cx + cw; base += 64) {
+                    const int i = base + lane;
+                    bool hm = false;
+                    int succ = -1;
+                    if (i < cx + cw) {
+                        const int* e = v8_entry(xb, wb, cx, i);
+                        const bool is_x = i < cx;
+                        if (e[3] != -2) {
+                            const int head = (is_x ? rowslot : colslot)[e[0] - (is_x ? m0 : n0)];
+                            hm = head == (is_x ? i : i - cx) && e[3] >= 0;
+                            succ = e[3];
+                        }
+                    }
+                    unsigned long long todo = __ballot(hm);
+                    while (todo) {
+                        const int src = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const int u = base + src, off = u < cx ? 0 : cx;
+                        int sidx = __builtin_amdgcn_readlane(succ, src);
+                        while (sidx >= 0) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) corr[u * 256 + c * 64 + lane] += corr[(off + sidx) * 256 + c * 64 + lane];
+                            sidx = __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, off + sidx)[3]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 
     // ---- epilogue: y = float(acc) * sx[m] * sw[n] + bias[n] (+ correction vectors).  Nothing is loaded from
     //      global memory between the stores (vmcnt counts loads and stores alike: a load's wait would drain them).
+    if (FIXMODE_ == 3) rt[2] = __builtin_amdgcn_s_memrealtime();
     const bool look = FIXMODE && (mode == 1 || mode == 2);
     float val[TI][TJ][4];
 #pragma unroll
@@ -312,25 +502,22 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             for (int r = 0; r < 4; ++r) val[i][j][r] = (float)acc[i][j][r] * sxv[r] * swv + bv;
         }
     }
+    if (FIXMODE_ == 3) rt[3] = __builtin_amdgcn_s_memrealtime();
     if (look) {
-        // column vectors (w exceptions): a lane's 32 rows of one column are 8 runs of 4 consecutive floats
+        // one vector per row / column (chains were folded above): one predicated read each
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            int s = colslot[wn * 64 + j * 16 + l16];
-            while (__any(s >= 0)) {
-                if (s >= 0) {
-                    const float* v = corr + (cx + s) * 256 + wm * 128 + lq * 4;
+            const int sc_ = colslot[wn * 64 + j * 16 + l16];
+            if (__any(sc_ >= 0)) {
+                const float* v = corr + (cx + max(sc_, 0)) * 256 + wm * 128 + lq * 4;
 #pragma unroll
-                    for (int i = 0; i < TI; ++i) {
-                        const f32x4 c4 = *reinterpret_cast<const f32x4*>(v + i * 16);
+                for (int i = 0; i < TI; ++i) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(v + i * 16);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) val[i][j][r] += c4[r];
-                    }
-                    s = wb[EXC_HEADER + EXC_ENTRY * s + 3];
+                    for (int r = 0; r < 4; ++r) val[i][j][r] += sc_ >= 0 ? c4[r] : 0.f;
                 }
             }
         }
-        // row vectors (x exceptions)
         int sr[TI][4];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -339,18 +526,14 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int s = sr[i][r];
-                while (__any(s >= 0)) {
-                    if (s >= 0) {
-                        const float* v = corr + s * 256 + wn * 64 + l16;
+            for (int r = 0; r < 4; ++r)
+                if (__any(sr[i][r] >= 0)) {
+                    const float* v = corr + max(sr[i][r], 0) * 256 + wn * 64 + l16;
 #pragma unroll
-                        for (int j = 0; j < TJ; ++j) val[i][j][r] += v[j * 16];
-                        s = xb[EXC_HEADER + EXC_ENTRY * s + 3];
-                    }
+                    for (int j = 0; j < TJ; ++j) val[i][j][r] += sr[i][r] >= 0 ? v[j * 16] : 0.f;
                 }
-            }
     }
+    if (FIXMODE_ == 3) rt[4] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -361,6 +544,12 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             for (int j = 0; j < TJ; ++j)
                 if (n0 + wn * 64 + j * 16 + l16 < a.N && row < a.M) yrow[j * 16] = val[i][j][r];
         }
+    }
+    if (FIXMODE_ == 3) {
+        rt[5] = __builtin_amdgcn_s_memrealtime();
+        if ((blockIdx.x == 0 || blockIdx.x == 77) && (tid == 0 || tid == 448))
+            printf("wg %d wave %d: loop %llu | cross %llu | scale %llu | lookups %llu | stores %llu (x 10 ns) cx %d cw %d mode %d\n", blockIdx.x, wave,
+                   rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2], rt[4] - rt[3], rt[5] - rt[4], cx, cw, mode);
     }
     if (FIXMODE && mode == 3) {
         V8_WAIT(0);
@@ -381,8 +570,20 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
                        int list_cap, hipStream_t st) {
     (void)list_cap;
     const unsigned tiles = (unsigned)(((a.M + V8_BM - 1) / V8_BM) * ((a.N + V8_BN - 1) / V8_BN));
-    if (xlist && wlist) hipLaunchKernelGGL((bfp_gemm_v8<1>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    else hipLaunchKernelGGL((bfp_gemm_v8<0>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    const char* ph = getenv("MI355Q_V8_PHASED");
+    const bool phased = ph ? atoi(ph) != 0 : true;
+    if (xlist && wlist && getenv("MI355Q_V8_STAMPS")) {
+        hipLaunchKernelGGL((bfp_gemm_v8<3, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    } else if (xlist && wlist) {
+        if (phased) hipLaunchKernelGGL((bfp_gemm_v8<1, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+        else hipLaunchKernelGGL((bfp_gemm_v8<1, false>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    } else if (getenv("MI355Q_V8_CLOCK")) {
+        if (phased) hipLaunchKernelGGL((bfp_gemm_v8<2, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+        else hipLaunchKernelGGL((bfp_gemm_v8<2, false>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    } else {
+        if (phased) hipLaunchKernelGGL((bfp_gemm_v8<0, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+        else hipLaunchKernelGGL((bfp_gemm_v8<0, false>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    }
     return (int)hipGetLastError();
 }
 

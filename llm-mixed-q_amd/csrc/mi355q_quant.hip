@@ -518,7 +518,7 @@ int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gsc
 // then writes the tiled mantissas, the effective exponents, rowflag[row] and the row scale.  cols % 64 == 0,
 // cols <= 1024 * MAXIT.
 // ---------------------------------------------------------------------------------------
-template <int MAXIT>
+template <int MAXIT, bool FULL>
 __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                                    uint8_t* __restrict__ flag, float* __restrict__ rscale,
                                                                    int exp_offset, int* __restrict__ list,
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int kb = it * 64 + wave * 16 + (lane >> 2);
-            v[it] = (it < nit && kb < nkb) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[it] = (FULL || (it < nit && kb < nkb)) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         unsigned pk[MAXIT];
         int amax[MAXIT], code[MAXIT];
@@ -564,11 +564,11 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             pk[it] = lo | hi;
         }
         int E = 0;
-        const bool flagged = align_row<MAXIT>(pk, amax, code, nit, nkb, row, list, rsm, E);
+        const bool flagged = align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int kb = it * 64 + wave * 16 + (lane >> 2);
-            if (it < nit && kb < nkb) {
+            if (FULL || (it < nit && kb < nkb)) {
                 *reinterpret_cast<unsigned*>(mt + tiled_offset_q(row, (long long)kb * 16 + (lane & 3) * 4, K)) = pk[it];
                 if ((lane & 3) == 0) a.code[row * nkb + kb] = (uint8_t)(flagged ? E : code[it]);
             }
@@ -585,14 +585,18 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     long long grid = a.rows;
     if (grid > 65536) grid = 65536;
     if (grid < 1) grid = 1;
-    if (a.cols <= 4096)
-        hipLaunchKernelGGL((bfp_quant_align_rows_kernel<4>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear);
-    else if (a.cols <= 8192)
-        hipLaunchKernelGGL((bfp_quant_align_rows_kernel<8>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear);
-    else if (a.cols <= 16384)
-        hipLaunchKernelGGL((bfp_quant_align_rows_kernel<16>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear);
+#define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
+    hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
+                       exp_offset, list, list_to_clear)
+    if (a.cols == 4096) MI355Q_LAUNCH_ROWS(4, true);            // every lane holds a block in every slab: no guards
+    else if (a.cols <= 4096) MI355Q_LAUNCH_ROWS(4, false);
+    else if (a.cols == 8192) MI355Q_LAUNCH_ROWS(8, true);
+    else if (a.cols <= 8192) MI355Q_LAUNCH_ROWS(8, false);
+    else if (a.cols == 16384) MI355Q_LAUNCH_ROWS(16, true);
+    else if (a.cols <= 16384) MI355Q_LAUNCH_ROWS(16, false);
     else
         return MI355Q_E_UNSUPPORTED;
+#undef MI355Q_LAUNCH_ROWS
     return (int)hipGetLastError();
 }
 
