@@ -62,6 +62,9 @@ def load_library() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch first: the library must bind to the HIP runtime torch has loaded (a second copy of the runtime, loaded
+    # before torch's, would see no device)
+    import torch  # noqa: F401
     path = library_path()
     if not path.exists():
         raise RuntimeError(
