@@ -83,26 +83,27 @@ __device__ __forceinline__ void block_fix_body(const GemmArgs& a, const int* __r
 // path: runs after the tile's own stores, behind a workgroup barrier).
 template <int BM = V2_BM, int BN = V2_BN>
 __device__ __forceinline__ void tile_fix_body(const GemmArgs& a, const int* __restrict__ xlist,
-                                              const int* __restrict__ wlist, int cap, long long m0, long long n0) {
+                                              const int* __restrict__ wlist, int cap, long long m0, long long n0,
+                                              int tid = -1, int nthreads = 0) {
     const int cx = list_count(xlist, cap), cw = list_count(wlist, cap);
     if (cx == 0 && cw == 0) return;
-    const int lane = threadIdx.x & 63;
+    if (tid < 0) { tid = threadIdx.x; nthreads = blockDim.x; }       // default: the whole workgroup is the team
+    const int lane = tid & 63;
     const long long m1 = min(m0 + BM, a.M), n1 = min(n0 + BN, a.N);
-    const int nthreads = blockDim.x;
     for (int pass = 0; pass < 2; ++pass) {
         const bool is_x = pass == 0;
         const int* list = is_x ? xlist : wlist;
         const int cnt = is_x ? cx : cw;
         const long long r0 = is_x ? m0 : n0, r1 = is_x ? m1 : n1, q0 = is_x ? n0 : m0, q1 = is_x ? n1 : m1;
         for (int base = 0; base < cnt; base += nthreads) {            // uniform
-            const int t = base + threadIdx.x;
+            const int t = base + tid;
             int row = -1;
             if (t < cnt) row = list[EXC_HEADER + EXC_ENTRY * t];
             unsigned long long hit = __ballot(row >= r0 && row < r1);
             while (hit) {                                              // the wave works through its own hits
                 const int src = __builtin_ctzll(hit);
                 hit &= hit - 1;
-                const int* e = list + EXC_HEADER + EXC_ENTRY * (base + (threadIdx.x & ~63) + src);
+                const int* e = list + EXC_HEADER + EXC_ENTRY * (base + (tid & ~63) + src);
                 const int er = e[0], kb = e[1], code = e[2];
                 const int4 pv = *reinterpret_cast<const int4*>(e + 4);
                 fix_entry_sweep(a, is_x, er, kb, code, pv, q0, q1, lane, 64);

@@ -64,13 +64,14 @@ __device__ __forceinline__ void v2_tile_origin(const GemmArgs& a, int tile_id, l
     n0 = (long long)tn * V2_BN;
 }
 
-__device__ __forceinline__ void bfp_gemm_v2_body(const GemmArgs& a, const uint8_t* __restrict__ xf,
-                                                 const uint8_t* __restrict__ wf, V2Smem& sm, int tile_id) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One 128 x 128 tile by 256 threads (`tid` = 0..255 within the team).  A workgroup may run several teams side by
+// side on different tiles (each with its own V2Smem): the workgroup barriers inside are reached by every team the same
+// number of times (same K), and the all-flagged vote then spans the teams, which only makes it more conservative.
+__device__ __forceinline__ void bfp_gemm_v2_tile(const GemmArgs& a, const uint8_t* __restrict__ xf,
+                                                 const uint8_t* __restrict__ wf, V2Smem& sm, long long m0, long long n0,
+                                                 int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-
-    long long m0, n0;
-    v2_tile_origin(a, tile_id, m0, n0);
 
     const long long nkb = a.K >> 4;
     const int nsteps = (int)(a.K >> 6), ngroups = (int)((nkb + ALIGN_G - 1) / ALIGN_G);
@@ -224,6 +225,12 @@ __device__ __forceinline__ void bfp_gemm_v2_body(const GemmArgs& a, const uint8_
         }
 }
 
+__device__ __forceinline__ void bfp_gemm_v2_body(const GemmArgs& a, const uint8_t* __restrict__ xf,
+                                                 const uint8_t* __restrict__ wf, V2Smem& sm, int tile_id) {
+    long long m0, n0;
+    v2_tile_origin(a, tile_id, m0, n0);
+    bfp_gemm_v2_tile(a, xf, wf, sm, m0, n0, threadIdx.x);
+}
 
 }  // namespace mi355q
 #endif

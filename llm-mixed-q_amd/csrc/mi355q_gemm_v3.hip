@@ -957,7 +957,7 @@ int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf
     // launch only has the sparse correction to do
     unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
     if (tiles > 512) tiles = 512;
-    if (a.row_mode && tiles > 256) tiles = 256;      // only ever the fallback: keep the (usually empty) launch small
+    if (a.row_mode && tiles > 64) tiles = 64;        // only ever the fallback: keep the (usually empty) launch small
     hipLaunchKernelGGL(bfp_gemm_tail, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap);
     return (int)hipGetLastError();
 }

@@ -145,7 +145,7 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
     }
 }
 
-template <int FIXMODE_, bool PHASED>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
+template <int FIXMODE_, int PHASED>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         evt_step = pending >= 0 ? t + 1 : (plan_cur < plan_cnt ? desc >> 16 : -1);
     };
 
-    int slot = 0, nslot = 2 % V8_S;
+    int slot = 0, nslot = 2 % V8_S, pslot = 0;
     if (PHASED) {
         // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while a group issues its 16
         // MFMAs between two barriers, the other reads its next fragments from LDS and issues its LDS-DMA loads.
@@ -366,9 +366,17 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
-            if (t + 2 < nsteps) dma2(t + 2, nslot, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (PHASED == 1) {
+                if (t + 2 < nsteps) dma2(t + 2, nslot, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                // (late schedule: a stage is re-filled two barriers after its last read, so the reads may retire
+                //  behind the barrier, beside the other group's wait)
+                if (t >= 1 && t + 1 < nsteps) dma2(t + 1, pslot, 2);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -379,14 +387,26 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             // ---- phase 1
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[4 + i]);
-            if (t + 2 < nsteps) {
-                dma2(t + 2, nslot, 2);
-                nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
+            if (PHASED == 1) {
+                if (t + 2 < nsteps) {
+                    dma2(t + 2, nslot, 2);
+                    nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
+                }
+                if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);  // this wave's pieces of step t+1 have landed
+                if (FIXMODE && t == evt_step) side_event(t, sbase);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                if (t + 2 < nsteps) {
+                    dma2(t + 2, nslot, 0);
+                    pslot = nslot;
+                    nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
+                }
+                if (t + 2 < nsteps) V8_WAIT(2); else V8_WAIT(0);    // step t+1 complete (two newest pieces: step t+2)
+                if (FIXMODE && t == evt_step) side_event(t, sbase);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);      // this wave's pieces of step t+1 have landed
-            if (FIXMODE && t == evt_step) side_event(t, sbase);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -571,19 +591,18 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
     (void)list_cap;
     const unsigned tiles = (unsigned)(((a.M + V8_BM - 1) / V8_BM) * ((a.N + V8_BN - 1) / V8_BN));
     const char* ph = getenv("MI355Q_V8_PHASED");
-    const bool phased = ph ? atoi(ph) != 0 : true;
-    if (xlist && wlist && getenv("MI355Q_V8_STAMPS")) {
-        hipLaunchKernelGGL((bfp_gemm_v8<3, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    } else if (xlist && wlist) {
-        if (phased) hipLaunchKernelGGL((bfp_gemm_v8<1, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-        else hipLaunchKernelGGL((bfp_gemm_v8<1, false>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    } else if (getenv("MI355Q_V8_CLOCK")) {
-        if (phased) hipLaunchKernelGGL((bfp_gemm_v8<2, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-        else hipLaunchKernelGGL((bfp_gemm_v8<2, false>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    } else {
-        if (phased) hipLaunchKernelGGL((bfp_gemm_v8<0, true>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-        else hipLaunchKernelGGL((bfp_gemm_v8<0, false>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    }
+    const int phased = ph ? atoi(ph) : 2;
+#define MI355Q_V8_LAUNCH(FM)                                                                                          \
+    do {                                                                                                              \
+        if (phased == 2) hipLaunchKernelGGL((bfp_gemm_v8<FM, 2>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);      \
+        else if (phased == 1) hipLaunchKernelGGL((bfp_gemm_v8<FM, 1>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist); \
+        else hipLaunchKernelGGL((bfp_gemm_v8<FM, 0>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);                  \
+    } while (0)
+    if (xlist && wlist && getenv("MI355Q_V8_STAMPS")) MI355Q_V8_LAUNCH(3);
+    else if (xlist && wlist) MI355Q_V8_LAUNCH(1);
+    else if (getenv("MI355Q_V8_CLOCK")) MI355Q_V8_LAUNCH(2);
+    else MI355Q_V8_LAUNCH(0);
+#undef MI355Q_V8_LAUNCH
     return (int)hipGetLastError();
 }
 

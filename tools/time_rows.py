@@ -16,7 +16,7 @@ xe_, we_ = ops.bfp_align_rows(xm, xe, 5, 127), ops.bfp_align_rows(wm, we, 5, 127
 xe_.sparse.zero_(); we_.sparse.zero_()        # same operands, empty exception lists
 print("exceptions", len(ops.row_list_entries(xa.sparse, M)[1]), len(ops.row_list_entries(wa.sparse, N)[1]))
 y = torch.empty(M, N, device=dev)
-phased = sys.argv[1:] or ["1", "0"]
+phased = sys.argv[1:] or ["2", "1"]
 cases = [(p, c) for p in phased for c in ("full", "empty", "v8")]
 acc = {c: [] for c in cases}
 def timed(fn, n=30):
