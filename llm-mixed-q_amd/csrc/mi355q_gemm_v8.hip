@@ -244,7 +244,11 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors built during the K loop, 2: after it, 3: atomics
     float* corr = reinterpret_cast<float*>(smem + V8_CORR);
     int* plan = reinterpret_cast<int*>(smem + V8_PLAN);
-    int plan_cnt = 0, plan_cur = 0, evt_step = -1, pending = -1, desc = 0, desc_next = 0;
+    constexpr int kNoDesc = -65536;                      // (K-step -1: never due)
+    int plan_cnt = 0, plan_cur = 0, evt_step = -1, pending = -1;
+    int desc = kNoDesc, desc_after = kNoDesc;             // the next two entries of this wave's plan (scalars)
+    int desc_raw = 0;                                     // ... and the one after, still on its way from LDS
+    bool raw_due = false;
     if (FIXMODE) {
         if (nsteps > 1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
@@ -281,16 +285,17 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             }
             if (mode == 1) {
                 plan_cnt = n > wave ? (n - wave + 7) >> 3 : 0;
-                if (plan_cnt > 0) {
-                    desc = __builtin_amdgcn_readfirstlane(plan[wave * 8]);
-                    evt_step = desc >> 16;
-                }
+                desc = plan_cnt > 0 ? __builtin_amdgcn_readfirstlane(plan[wave * 8]) : kNoDesc;
+                desc_after = plan_cnt > 1 ? __builtin_amdgcn_readfirstlane(plan[wave * 8 + 1]) : kNoDesc;
+                plan_cur = 2;                                // next plan slot to fetch
+                evt_step = desc >> 16;
             }
         }
     }
 
     unsigned long long c0 = 0, r0 = 0;
-    unsigned long long rt[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long rt[6] = {0, 0, 0, 0, 0, 0}, ev_clk = 0;
+    int ev_n = 0;
     if (FIXMODE_ == 2) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (FIXMODE_ == 3) rt[0] = __builtin_amdgcn_s_memrealtime();
 
@@ -312,16 +317,19 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     const int lane_row_off = lane * 64;
     const int lane_h = (0x78 >> (2 * ((lane >> 2) & 3))) & 3;
     auto side_event = [&](int t, const unsigned char* sbase) {
-        if (pending >= 0) {                                  // requested at step t - 1
-            side_consume();
-            desc = __builtin_amdgcn_readfirstlane(lds_settle(desc_next));
+        if (raw_due) {                                       // requested at an earlier event: long since arrived
+            desc_after = __builtin_amdgcn_readfirstlane(lds_settle(desc_raw));
+            raw_due = false;
         }
-        while (plan_cur < plan_cnt && (desc >> 16) == t) {   // (a second entry of this wave at the same step: rare)
-            if (pending >= 0) {
+        if (pending >= 0) side_consume();                    // requested at step t - 1
+        while ((desc >> 16) == t) {
+            if (pending >= 0) {                              // a second entry of this wave at the same step (rare)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 side_consume();
-                desc = __builtin_amdgcn_readfirstlane(lds_settle(desc_next));
-                continue;
+                if (raw_due) {
+                    desc_after = __builtin_amdgcn_readfirstlane(lds_settle(desc_raw));
+                    raw_due = false;
+                }
             }
             const int idx = desc & 0x1FFF, chunk = (desc >> 13) & 3;
             const bool is_x = idx < cx;
@@ -337,10 +345,15 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             pshift = lds_read4_raw(e + 2);
             pend_off = is_x ? a.x_off : a.w_off;
             pending = idx;
-            ++plan_cur;
-            desc_next = plan_cur < plan_cnt ? lds_read4_raw(&plan[wave * 8 + plan_cur]) : (-1 << 16);
+            desc = desc_after;
+            desc_after = kNoDesc;
+            if (plan_cur < plan_cnt) {
+                desc_raw = lds_read4_raw(&plan[wave * 8 + plan_cur]);
+                raw_due = true;
+                ++plan_cur;
+            }
         }
-        evt_step = pending >= 0 ? t + 1 : (plan_cur < plan_cnt ? desc >> 16 : -1);
+        evt_step = pending >= 0 ? t + 1 : desc >> 16;
     };
 
     int slot = 0, nslot = 2 % V8_S, pslot = 0;
@@ -403,7 +416,12 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                     nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
                 }
                 if (t + 2 < nsteps) V8_WAIT(2); else V8_WAIT(0);    // step t+1 complete (two newest pieces: step t+2)
-                if (FIXMODE && t == evt_step) side_event(t, sbase);
+                if (FIXMODE && t == evt_step) {
+                    unsigned long long e0 = 0;
+                    if (FIXMODE_ == 3) e0 = __builtin_amdgcn_s_memtime();
+                    side_event(t, sbase);
+                    if (FIXMODE_ == 3) { ev_clk += __builtin_amdgcn_s_memtime() - e0; ++ev_n; }
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     if (FIXMODE_ == 3) {
         rt[5] = __builtin_amdgcn_s_memrealtime();
         if ((blockIdx.x == 0 || blockIdx.x == 77) && (tid == 0 || tid == 448))
-            printf("wg %d wave %d: loop %llu | cross %llu | scale %llu | lookups %llu | stores %llu (x 10 ns) cx %d cw %d mode %d\n", blockIdx.x, wave,
+            printf("wg %d wave %d: events %d, %llu clocks in them | loop %llu | cross %llu | scale %llu | lookups %llu | stores %llu (x 10 ns) cx %d cw %d mode %d\n", blockIdx.x, wave, ev_n, ev_clk,
                    rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2], rt[4] - rt[3], rt[5] - rt[4], cx, cw, mode);
     }
     if (FIXMODE && mode == 3) {
