@@ -39,7 +39,8 @@ constexpr int V8_BUCKET = 4096;                     // LDS copy of one exception
 constexpr int V8_XB = V8_S * V8_STAGE, V8_WB = V8_XB + V8_BUCKET, V8_MAP = V8_WB + V8_BUCKET;
 constexpr int V8_SXT = V8_MAP + 2 * 256 * 4, V8_SWT = V8_SXT + 1024, V8_BIAS = V8_SWT + 1024;
 constexpr int V8_PLAN = V8_BIAS + 1024;              // int plan[8 waves][8]: each wave's entries in K-step order
-constexpr int V8_CORR = V8_PLAN + 256;
+constexpr int V8_OVF = V8_PLAN + 256;                // LDS copies of the two lists' header words (word 0 = overflow)
+constexpr int V8_CORR = V8_OVF + 512;
 constexpr int V8_LDS = 160 * 1024;
 constexpr int V8_FAST_MAX = (V8_LDS - V8_CORR) / 1024;      // entries (x + w) whose vectors fit beside the stages
 constexpr int V8_SLOW_MAX = V8_S * V8_STAGE / 1024;         // ... that fit the stage area after the K loop
@@ -153,9 +154,6 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     constexpr int FIXMODE = (FIXMODE_ == 1 || FIXMODE_ == 3) ? 1 : 0;      // 3: as 1, with phase timing printed by workgroup 0
     constexpr int TI = 8, TJ = 4, LPW = 32 / V8_NW;
     __shared__ __attribute__((aligned(16))) unsigned char smem[V8_LDS];
-    // a bucket overflowed: the fallback launch forms the product, this one must not write.  (Read now, looked at
-    // after the K loop: an early exit would put a memory round trip in front of every workgroup.)
-    const int overflowed = FIXMODE ? (xlist[0] | wlist[0]) : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
@@ -203,6 +201,10 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             const long long n = n0 + q * 64 + lane;
             bst[q * 64 + lane] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
         }
+    } else if (FIXMODE && (wave == 5 || wave == 6)) {
+        // the lists' overflow words arrive the same way (a scalar load here would put a memory round trip in
+        // front of everything the workgroup does)
+        __builtin_amdgcn_global_load_lds((gptr_t)((wave == 5 ? xlist : wlist) + lane), (lptr_t)(smem + V8_OVF + (wave - 5) * 256), 4, 0, 0);
     }
 
     const long long kp = a.K >> 6;
@@ -252,6 +254,13 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     if (FIXMODE) {
         if (nsteps > 1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
+        // a bucket overflowed somewhere: the fallback launch forms the product, this one must not write (uniform
+        // over the grid).  The operand loads in flight land in LDS only; nothing else is pending.
+        const int* ovf = reinterpret_cast<const int*>(smem + V8_OVF);
+        if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
+            V8_WAIT(0);
+            return;
+        }
         cx = __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
         const int n = cx + cw;
@@ -460,7 +469,6 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         }
     }
 
-    if (FIXMODE && overflowed) return;
     if (FIXMODE && pending >= 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         side_consume();
