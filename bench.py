@@ -163,10 +163,11 @@ def main():
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak" if args.shard == "tokens" else "strong", "vs_baseline": None,
-            "dtype": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 block scaling",
+            "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> fused quantise+pack+align (W6, block [1,16]) "
                                    "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32",
+                       "arithmetic": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 row/block scaling, fp32 y",
                        "M_per_gpu": M, "N": N, "K": K, "shard": args.shard, "align": args.align,
                        "gemm_variant": ops.set_gemm_variant(args.variant)},
             "roofline": {"bound": "mfma", "kernel": "bfp_gemm_v8 (row-scale int8 GEMM)" if rows_mode else "bfp_gemm_v6 (int32-chain block GEMM)", "achieved": round(achieved, 2),
