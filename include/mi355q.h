@@ -206,8 +206,9 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
 int mi355q_gemm_timing_enable(int enable);
 int mi355q_gemm_timing_read(int32_t* count, float* avg_ms, float* min_ms);
 
-/* Which GEMM kernel variant mi355q_bfp_gemm dispatches to (0 = automatic).  For A/B
- * benchmarking and tests only; returns the previous value. */
+/* Which kernel mi355q_bfp_gemm_aligned dispatches to, for A/B benchmarking and tests only (returns the previous
+ * value): 0 automatic; 2 the blockwise-exact kernel alone; 6 / 8 the int32-chain (groups) / row-scale (rows)
+ * kernel alone, WITHOUT the exception add-back (timing the product of the rewritten operands). */
 int mi355q_bfp_gemm_set_variant(int variant);
 
 #ifdef __cplusplus

@@ -289,16 +289,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     }
     const long long mpad = mi355q_bfp_rows_pad(M), npad = mi355q_bfp_rows_pad(N);
     const bool chain_ok = x->gscale && w->gscale && K % 256 == 0;
-    if (variant == 3 && chain_ok)   // int32-chain kernel alone, no correction (benchmarks only)
-        return launch_bfp_gemm_v3(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, nullptr, nullptr, st);
-    if (variant == 7 && chain_ok)
-        return launch_bfp_gemm_v7(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
-    if (variant == 6 && chain_ok)
+    if (variant == 6 && chain_ok)   // int32-chain kernel alone, no exception add-back (benchmarks only)
         return launch_bfp_gemm_v6(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
-    if (variant == 5 && chain_ok)
-        return launch_bfp_gemm_v5(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
-    if (variant == 4 && chain_ok)
-        return launch_bfp_gemm_v4(a, x->gscale, w->gscale, mpad, npad, st);
     const bool lists_ok = x->list && w->list && x->list_cap > 0;
     if (variant == 2 || !chain_ok || !lists_ok)     // blockwise-exact kernel alone (+ per-tile exception add-back)
         return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list,

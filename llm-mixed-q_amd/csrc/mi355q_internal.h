@@ -56,17 +56,8 @@ int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
                      long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
                      long long K, hipStream_t st);
-int launch_bfp_gemm_v3(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
-                       const int* xlist, const int* wlist, int list_cap, const uint8_t* xf, const uint8_t* wf,
-                       hipStream_t st);
-int launch_bfp_gemm_v5(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
-                       const int* xlist, const int* wlist, int list_cap, hipStream_t st);
 int launch_bfp_gemm_v6(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
                        const int* xlist, const int* wlist, int list_cap, hipStream_t st);
-int launch_bfp_gemm_v7(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
-                       const int* xlist, const int* wlist, int list_cap, hipStream_t st);
-int launch_bfp_gemm_v4(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
-                       hipStream_t st);
 
 }  // namespace mi355q
 #endif
