@@ -7,17 +7,21 @@
 // No rescale in the K loop: the int32 accumulators are the only live tile, so the wave tile is 128 x 64.
 //
 // Workgroup = 256 x 256 outputs, 8 waves as 2 x 4 (two per SIMD), v_mfma_i32_16x16x64_i8.  K-step 64: one stage =
-// A 16 KiB + B 16 KiB of 1-KiB pre-swizzled pieces (mi355q_gemm_v2.h), three stages filled by global_load_lds two
-// steps ahead, counted s_waitcnt vmcnt, ONE s_barrier per step.  The scale / bias slices of the tile and its two
-// exception buckets ride in front of the operand stream (LDS-DMA too).
+// A 16 KiB + B 16 KiB of 1-KiB pre-swizzled pieces (mi355q_gemm_v2.h), three stages filled by global_load_lds,
+// counted s_waitcnt vmcnt, raw s_barriers.  The two waves of every SIMD run one barrier apart: while one issues 16
+// MFMAs the other reads its fragments and issues its LDS-DMA loads (two such phases per K-step).  The scale / bias
+// slices of the tile, its two exception buckets and the lists' overflow words ride in front of the operand stream.
 //
 // Exceptions (blocks outside their row's exponent window; a few dozen per tile at most in the usual case) are
-// added back without leaving the kernel and without floating-point atomics: at the K-step that has an exception's
-// block resident in LDS, the wave that owns the entry forms its 256 dot products against the OTHER operand's
-// staged blocks and writes them as a correction vector (row vector for an x exception, column vector for a w
-// exception) to a spare LDS area; the store epilogue adds the vectors of the rows / columns it writes.  Tiles
-// with more entries than the spare area holds build the vectors after the K loop from global memory (stage area),
-// and beyond that add them with atomics after the stores.
+// added back without leaving the kernel and without floating-point atomics.  Entry i of a tile belongs to wave
+// i & 7; a per-wave plan in LDS lists the wave's entries in K-step order.  At the K-step that has an entry's block
+// resident in LDS the wave requests the 256 opposite blocks from the stage (raw ds_reads, kept away from the
+// compiler's wait insertion: beside LDS-DMA in flight it would drain the pipeline), one step later it writes the 256
+// dot products as a correction vector (row vector for an x exception, column vector for a w exception) to spare
+// LDS.  After the loop exception x exception terms are added and chains of entries on one row / column are folded
+// into one vector; the store epilogue adds one vector per affected row / column.  Tiles with more entries than the
+// spare area holds build the vectors after the K loop from global memory (stage area); beyond that they are added
+// with atomics after the stores.  If a bucket overflowed anywhere the kernel leaves at once (fallback launch).
 // Roofline: int8 MFMA, 2*M*N*K ops; y leaves as full fp32 (64 MiB at 4096^2: ~10 us of HBM write time).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -146,7 +150,7 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
     }
 }
 
-template <int FIXMODE_, int PHASED>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
+template <int FIXMODE_>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
@@ -366,108 +370,66 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     };
 
     int slot = 0, nslot = 2 % V8_S, pslot = 0;
-    if (PHASED) {
-        // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while a group issues its 16
-        // MFMAs between two barriers, the other reads its next fragments from LDS and issues its LDS-DMA loads.
-        // A K-step is two such phases (A rows 0-63, then 64-127 of the wave tile).  Reads are retired (lgkmcnt(0))
-        // before the barrier that ends their segment, so a stage is re-filled only after every read of it.
-        auto dma2 = [&](int step, int sl, int q0) {
+    // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while a group issues its 16
+    // MFMAs between two barriers, the other reads its next fragments from LDS and issues its LDS-DMA loads.
+    // A K-step is two such phases (A rows 0-63, then 64-127 of the wave tile).  The pieces of step t+2 are
+    // requested in phase 1 of step t (two) and phase 0 of step t+1 (two): a stage is re-filled two barriers
+    // after its last read, so fragment reads may retire behind the barrier, beside the other group's wait.
+    auto dma2 = [&](int step, int sl, int q0) {
 #pragma unroll
-            for (int q = q0; q < q0 + 2; ++q)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
-                                                 (lptr_t)(smem + sl * V8_STAGE + dst[q]), 16, 0, 0);
-        };
-        if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
+        for (int q = q0; q < q0 + 2; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
+                                             (lptr_t)(smem + sl * V8_STAGE + dst[q]), 16, 0, 0);
+    };
+    if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nsteps; ++t) {
+        const unsigned char* sbase = smem + slot * V8_STAGE;
+        i32x4 fa[4], fb[TJ];
+        // ---- phase 0
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
+        if (t >= 1 && t + 1 < nsteps) dma2(t + 1, pslot, 2);
         __builtin_amdgcn_s_barrier();
-        if (wm == 1) __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < nsteps; ++t) {
-            const unsigned char* sbase = smem + slot * V8_STAGE;
-            i32x4 fa[4], fb[TJ];
-            // ---- phase 0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
-            if (PHASED == 1) {
-                if (t + 2 < nsteps) dma2(t + 2, nslot, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            } else {
-                // (late schedule: a stage is re-filled two barriers after its last read, so the reads may retire
-                //  behind the barrier, beside the other group's wait)
-                if (t >= 1 && t + 1 < nsteps) dma2(t + 1, pslot, 2);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_setprio(1);
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- phase 1
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[4 + i]);
-            if (PHASED == 1) {
-                if (t + 2 < nsteps) {
-                    dma2(t + 2, nslot, 2);
-                    nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
-                }
-                if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);  // this wave's pieces of step t+1 have landed
-                if (FIXMODE && t == evt_step) side_event(t, sbase);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            } else {
-                if (t + 2 < nsteps) {
-                    dma2(t + 2, nslot, 0);
-                    pslot = nslot;
-                    nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
-                }
-                if (t + 2 < nsteps) V8_WAIT(2); else V8_WAIT(0);    // step t+1 complete (two newest pieces: step t+2)
-                if (FIXMODE && t == evt_step) {
-                    unsigned long long e0 = 0;
-                    if (FIXMODE_ == 3) e0 = __builtin_amdgcn_s_memtime();
-                    side_event(t, sbase);
-                    if (FIXMODE_ == 3) { ev_clk += __builtin_amdgcn_s_memtime() - e0; ++ev_n; }
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[4 + i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_s_barrier();
-            slot = slot + 1 == V8_S ? 0 : slot + 1;
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[4 + i]);
+        if (t + 2 < nsteps) {
+            dma2(t + 2, nslot, 0);
+            pslot = nslot;
+            nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
         }
-        if (wm == 0) __builtin_amdgcn_s_barrier();
-    } else {
-        for (int t = 0; t < nsteps; ++t) {
-            // stage t landed (for every wave, after the barrier); stage t+1 may be in flight
-            if (t + 1 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < nsteps) {
-                stage(t + 2, nslot);
-                nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
-            }
-            const unsigned char* sbase = smem + slot * V8_STAGE;
-            i32x4 fa[TI], fb[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if (FIXMODE && t == evt_step) side_event(t, sbase);
-            slot = slot + 1 == V8_S ? 0 : slot + 1;
+        if (t + 2 < nsteps) V8_WAIT(2); else V8_WAIT(0);    // step t+1 complete (two newest pieces: step t+2)
+        if (FIXMODE && t == evt_step) {
+            unsigned long long e0 = 0;
+            if (FIXMODE_ == 3) e0 = __builtin_amdgcn_s_memtime();
+            side_event(t, sbase);
+            if (FIXMODE_ == 3) { ev_clk += __builtin_amdgcn_s_memtime() - e0; ++ev_n; }
         }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        slot = slot + 1 == V8_S ? 0 : slot + 1;
     }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
 
     if (FIXMODE && pending >= 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -616,19 +578,13 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
                        int list_cap, hipStream_t st) {
     (void)list_cap;
     const unsigned tiles = (unsigned)(((a.M + V8_BM - 1) / V8_BM) * ((a.N + V8_BN - 1) / V8_BN));
-    const char* ph = getenv("MI355Q_V8_PHASED");
-    const int phased = ph ? atoi(ph) : 2;
-#define MI355Q_V8_LAUNCH(FM)                                                                                          \
-    do {                                                                                                              \
-        if (phased == 2) hipLaunchKernelGGL((bfp_gemm_v8<FM, 2>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);      \
-        else if (phased == 1) hipLaunchKernelGGL((bfp_gemm_v8<FM, 1>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist); \
-        else hipLaunchKernelGGL((bfp_gemm_v8<FM, 0>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);                  \
-    } while (0)
-    if (xlist && wlist && getenv("MI355Q_V8_STAMPS")) MI355Q_V8_LAUNCH(3);
-    else if (xlist && wlist) MI355Q_V8_LAUNCH(1);
-    else if (getenv("MI355Q_V8_CLOCK")) MI355Q_V8_LAUNCH(2);
-    else MI355Q_V8_LAUNCH(0);
-#undef MI355Q_V8_LAUNCH
+    // diagnostic builds: MI355Q_V8_CLOCK prints the clock held over the K loop (no add-back),
+    // MI355Q_V8_STAMPS the duration of the kernel's phases
+    static const bool want_clock = getenv("MI355Q_V8_CLOCK") != nullptr, want_stamps = getenv("MI355Q_V8_STAMPS") != nullptr;
+    if (xlist && wlist && want_stamps) hipLaunchKernelGGL(bfp_gemm_v8<3>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    else if (xlist && wlist) hipLaunchKernelGGL(bfp_gemm_v8<1>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    else if (want_clock) hipLaunchKernelGGL(bfp_gemm_v8<2>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    else hipLaunchKernelGGL(bfp_gemm_v8<0>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
     return (int)hipGetLastError();
 }
 
