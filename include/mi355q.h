@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 1
+#define MI355Q_ABI_VERSION 2
 #define MI355Q_WORKSPACE_BYTES 256
 
 /* negative error codes (positive values are hipError_t) */
@@ -183,6 +183,9 @@ typedef struct mi355q_bfp_operand {
     int32_t exp_bias;
     int32_t row_aligned;    /* 0: 256-value groups (mi355q_bfp_align); 1: whole rows (mi355q_bfp_align_rows):
                              * rowflag [rows], gscale = rowscale [rows_pad], list = bucketed row list */
+    float* corr;            /* row-aligned operands: scratch for the correction vectors of this operand's exception
+                             * blocks, mi355q_bfp_corr_bytes(rows of this operand, rows of the other one); written and
+                             * read inside mi355q_bfp_gemm_aligned only (NULL for 256-value groups) */
 } mi355q_bfp_operand;
 
 /* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align (K % 64 == 0).
@@ -192,9 +195,11 @@ typedef struct mi355q_bfp_operand {
  * kernel forms the whole product instead.  The choice is made on the device from the list counts.
  * Both lists must have the same list_cap; operands without gscale / list (or K % 256 != 0) use the
  * blockwise-exact kernel directly.
- * ROW-aligned operands (row_aligned = 1 in both): one launch of the row-scale int8 GEMM (256 x 256 tiles,
- * exception blocks added in the epilogue of the tile that owns them) plus a guard launch that forms the whole
- * product blockwise if an exception bucket overflowed.  K % 128 == 0 for the fast kernel. */
+ * ROW-aligned operands (row_aligned = 1 in both): a short launch multiplies every exception block with the other
+ * operand (one fp32 vector of products per exception, in `corr`) -- or, if an exception bucket overflowed, forms the
+ * whole product blockwise-exact -- then the row-scale int8 GEMM (256 x 256 tiles) runs and adds the vectors of the
+ * rows / columns it stores.  No atomics: results are reproducible.  K % 128 == 0 for the fast kernel. */
+size_t mi355q_bfp_corr_bytes(int64_t rows, int64_t other_rows);
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);

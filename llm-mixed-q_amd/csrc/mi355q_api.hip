@@ -215,6 +215,11 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
                               list_cap, list_to_clear, static_cast<hipStream_t>(stream));
 }
 
+size_t mi355q_bfp_corr_bytes(int64_t rows, int64_t other_rows) {
+    if (rows <= 0 || other_rows <= 0) return 0;
+    return (size_t)((rows + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS) * ROW_BCAP * (size_t)((other_rows + 255) / 256 * 256) * 4;
+}
+
 size_t mi355q_bfp_row_list_bytes(int64_t rows) { return rows < 0 ? 0 : (size_t)row_list_words(rows) * 4; }
 
 int mi355q_bfp_align_rows(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_tiled, uint8_t* exp_out,
@@ -270,7 +275,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant)) % 16) return MI355Q_E_ALIGN;
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
                x->exp_bias + x->mbits + w->exp_bias + w->mbits, x->row_aligned ? 1 : 0,
-               x->exp_bias + x->mbits, w->exp_bias + w->mbits};
+               x->exp_bias + x->mbits, w->exp_bias + w->mbits,
+               x->corr, w->corr, (N + 255) / 256 * 256, (M + 255) / 256 * 256};
     const int variant = g_gemm_variant.load();
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (x->row_aligned) {
@@ -281,11 +287,16 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         if (variant == 2 || !fast_ok)
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, 0, 0, st);
         if (variant == 8) return launch_bfp_gemm_v8(a, x->gscale, w->gscale, nullptr, nullptr, 0, st);
-        hipEvent_t te = g_timing.begin(st);
-        int rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st);
-        g_timing.end(te, st);
+        if (!x->corr || !w->corr) return MI355Q_E_BADARG;
+        // first the short launch: one vector of products per exception block (or, if an exception bucket overflowed,
+        // the whole product blockwise-exact -- decided on the device); then the row-scale GEMM, which adds the vectors
+        // of the rows / columns it stores (and leaves at once in the overflow case)
+        int rc = launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, 0, st, x->gscale, w->gscale);
         if (rc) return rc;
-        return launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, 0, st);
+        hipEvent_t te = g_timing.begin(st);
+        rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st);
+        g_timing.end(te, st);
+        return rc;
     }
     const long long mpad = mi355q_bfp_rows_pad(M), npad = mi355q_bfp_rows_pad(N);
     const bool chain_ok = x->gscale && w->gscale && K % 256 == 0;

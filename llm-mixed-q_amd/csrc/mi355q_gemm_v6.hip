@@ -191,8 +191,21 @@ int launch_bfp_gemm_v6(const GemmArgs& a, const float* gx, const float* gw, long
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const uint8_t* __restrict__ xf,
                                                         const uint8_t* __restrict__ wf, const int* __restrict__ xlist,
-                                                        const int* __restrict__ wlist, int list_cap) {
+                                                        const int* __restrict__ wlist, int list_cap,
+                                                        const float* __restrict__ xscale, const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(V2Smem)];
+    // row mode: the first bucket this workgroup will need is requested together with the overflow words (one memory
+    // round trip instead of two on the normal path)
+    int4 first_piece = {0, 0, 0, 0};
+    if (a.row_mode && threadIdx.x < ROW_BUCKET_WORDS / 4) {
+        const int nbx = (int)((a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS), nbw = (int)((a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS);
+        const int wi = blockIdx.x;
+        if (wi < 2 * nbx * nbw) {
+            const bool is_x = wi < nbx * nbw;
+            const int bb = (is_x ? wi : wi - nbx * nbw) / (is_x ? nbw : nbx);
+            first_piece = reinterpret_cast<const int4*>(row_bucket(is_x ? xlist : wlist, (long long)bb * ROW_BUCKET_ROWS))[threadIdx.x];
+        }
+    }
     const bool overflow = a.row_mode ? (xlist[0] != 0 || wlist[0] != 0) : (xlist[0] > list_cap || wlist[0] > list_cap);
     if (overflow) {
         const int ntiles = (int)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
@@ -208,17 +221,69 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
         }
         return;
     }
-    if (!a.row_mode) block_fix_body(a, xlist, wlist, list_cap, blockIdx.x, gridDim.x);   // (row mode: done by the GEMM)
+    if (!a.row_mode) {
+        block_fix_body(a, xlist, wlist, list_cap, blockIdx.x, gridDim.x);
+        return;
+    }
+    // ---- row mode: one fp32 vector of products per exception block, for the row-scale GEMM to add.
+    //      x entry (row r, block kb), slot s of bucket b:  xcorr[(b * 120 + s) * ldxc + n] = 2^(code - x_off) * sw[n] *
+    //      dot16(entry, wm'[n, kb]) for every n;  w entries the mirror image over m (x as stored: its own exception
+    //      blocks are zero there; exception x exception terms are added by the GEMM from the lists).
+    //      Work item = (entry, 256 rows of the other operand); every row is flagged here (no overflow).
+    //      Workgroup = (bucket, 256 rows of the other operand): it copies the bucket to LDS (count and entries in one
+    //      round trip), requests the other operand's blocks for up to U entries together, writes U vector pieces.
+    int* s_bk = reinterpret_cast<int*>(smem);
+    const int nbx = (int)((a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS), nbw = (int)((a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS);
+    const int chx = nbw, chw = nbx;                                  // 256-row chunks of the OTHER operand
+    const int tid = threadIdx.x;
+    for (int wi = blockIdx.x; wi < nbx * chx + nbw * chw; wi += gridDim.x) {   // (normally one per workgroup)
+        const bool is_x = wi < nbx * chx;
+        const int li = is_x ? wi : wi - nbx * chx, nch = is_x ? chx : chw;
+        const int bb = li / nch, chunk = li - bb * nch;
+        const int* bk = row_bucket(is_x ? xlist : wlist, (long long)bb * ROW_BUCKET_ROWS);
+        __syncthreads();
+        if (tid < ROW_BUCKET_WORDS / 4)
+            reinterpret_cast<int4*>(s_bk)[tid] = wi == (int)blockIdx.x ? first_piece : reinterpret_cast<const int4*>(bk)[tid];
+        __syncthreads();
+        const int cnt = min(s_bk[0], ROW_BCAP);
+        const long long q = (long long)chunk * 256 + tid, qrows = is_x ? a.N : a.M;
+        const bool qok = q < qrows;
+        const float sc = qok ? (is_x ? wscale : xscale)[q] : 0.f;
+        const int8_t* qm = is_x ? a.wm : a.xm;
+        float* dst = (is_x ? a.xcorr + (long long)bb * ROW_BCAP * a.ldxc : a.wcorr + (long long)bb * ROW_BCAP * a.ldwc) + q;
+        const long long ld = is_x ? a.ldxc : a.ldwc;
+        const int off = is_x ? a.x_off : a.w_off;
+        constexpr int U = 12;
+        for (int e0 = 0; e0 < cnt; e0 += U) {
+            int4 qv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int* e = s_bk + EXC_HEADER + EXC_ENTRY * min(e0 + u, cnt - 1);
+                qv[u] = (qok && e[0] >= 0) ? *reinterpret_cast<const int4*>(qm + tiled_offset(q, (long long)e[1] * 16, a.K))
+                                           : int4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (e0 + u >= cnt) break;
+                const int* e = s_bk + EXC_HEADER + EXC_ENTRY * (e0 + u);
+                dst[(long long)(e0 + u) * ld] =
+                    __builtin_ldexpf((float)dot16(*reinterpret_cast<const int4*>(e + 4), qv[u]), e[2] - off) * sc;
+            }
+        }
+    }
 }
 
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
-                         int list_cap, hipStream_t st) {
+                         int list_cap, hipStream_t st, const float* xscale, const float* wscale) {
     // two workgroups per CU: enough for the fallback GEMM (it walks the tiles) and cheap to dispatch when the
     // launch only has the sparse correction to do
     unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
     if (tiles > 512) tiles = 512;
-    if (a.row_mode && tiles > 64) tiles = 64;        // only ever the fallback: keep the (usually empty) launch small
-    hipLaunchKernelGGL(bfp_gemm_tail, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap);
+    if (a.row_mode) {                                // one workgroup per (bucket, 256 rows of the other operand)
+        const long long nbx = (a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS, nbw = (a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS;
+        tiles = (unsigned)(2 * nbx * nbw > 2048 ? 2048 : 2 * nbx * nbw);
+    }
+    hipLaunchKernelGGL(bfp_gemm_tail, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap, xscale, wscale);
     return (int)hipGetLastError();
 }
 

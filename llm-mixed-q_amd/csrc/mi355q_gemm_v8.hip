@@ -13,15 +13,15 @@
 // slices of the tile, its two exception buckets and the lists' overflow words ride in front of the operand stream.
 //
 // Exceptions (blocks outside their row's exponent window; a few dozen per tile at most in the usual case) are
-// added back without leaving the kernel and without floating-point atomics.  Entry i of a tile belongs to wave
-// i & 7; a per-wave plan in LDS lists the wave's entries in K-step order.  At the K-step that has an entry's block
-// resident in LDS the wave requests the 256 opposite blocks from the stage (raw ds_reads, kept away from the
-// compiler's wait insertion: beside LDS-DMA in flight it would drain the pipeline), one step later it writes the 256
-// dot products as a correction vector (row vector for an x exception, column vector for a w exception) to spare
-// LDS.  After the loop exception x exception terms are added and chains of entries on one row / column are folded
-// into one vector; the store epilogue adds one vector per affected row / column.  Tiles with more entries than the
-// spare area holds build the vectors after the K loop from global memory (stage area); beyond that they are added
-// with atomics after the stores.  If a bucket overflowed anywhere the kernel leaves at once (fallback launch).
+// added back without floating-point atomics.  The short launch in front of this kernel (bfp_gemm_tail,
+// mi355q_gemm_v6.hip) has multiplied every exception block with the other operand: one vector of 256 products per
+// (entry, 256 rows of the other operand).  A tile fetches the vectors of its two buckets by ONE contiguous 1-KiB
+// LDS-DMA each, behind its buckets and in front of the operand stream, into spare LDS; links the entries of each
+// tile row / column into chains; after the K loop adds the exception x exception terms (same K position in both
+// lists), folds chains into their heads, and the store epilogue adds one vector per affected row / column.  Tiles
+// with more entries than the spare area holds fetch the vectors into the stage area after the K loop; beyond
+// that the products are added with atomics after the stores.  If a bucket overflowed anywhere the kernel leaves
+// at once (the launch in front formed the whole product blockwise-exact).
 // Roofline: int8 MFMA, 2*M*N*K ops; y leaves as full fp32 (64 MiB at 4096^2: ~10 us of HBM write time).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,13 +42,12 @@ constexpr int V8_HALF = 256 * 64, V8_STAGE = 2 * V8_HALF;
 constexpr int V8_BUCKET = 4096;                     // LDS copy of one exception bucket (ROW_BUCKET_WORDS * 4 <= 4096)
 constexpr int V8_XB = V8_S * V8_STAGE, V8_WB = V8_XB + V8_BUCKET, V8_MAP = V8_WB + V8_BUCKET;
 constexpr int V8_SXT = V8_MAP + 2 * 256 * 4, V8_SWT = V8_SXT + 1024, V8_BIAS = V8_SWT + 1024;
-constexpr int V8_PLAN = V8_BIAS + 1024;              // int plan[8 waves][8]: each wave's entries in K-step order
+constexpr int V8_PLAN = V8_BIAS + 1024;              // a few flag words
 constexpr int V8_OVF = V8_PLAN + 256;                // LDS copies of the two lists' header words (word 0 = overflow)
 constexpr int V8_CORR = V8_OVF + 512;
 constexpr int V8_LDS = 160 * 1024;
 constexpr int V8_FAST_MAX = (V8_LDS - V8_CORR) / 1024;      // entries (x + w) whose vectors fit beside the stages
 constexpr int V8_SLOW_MAX = V8_S * V8_STAGE / 1024;         // ... that fit the stage area after the K loop
-static_assert((V8_FAST_MAX + V8_NW - 1) / V8_NW <= 8, "plan rows hold 8 entries");
 static_assert(ROW_BUCKET_WORDS * 4 <= V8_BUCKET, "bucket copy");
 static_assert(V8_FAST_MAX >= 40, "spare LDS for correction vectors");
 
@@ -56,72 +55,9 @@ __device__ __forceinline__ int v8_off(int r, int c) { return r * 64 + ((c ^ ((0x
 
 #define V8_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-// LDS accesses the compiler's wait-count pass must not see: beside LDS-DMA loads in flight it puts `s_waitcnt vmcnt(0)`
-// in front of any LDS access it cannot prove disjoint from their destinations, which drains the operand pipeline.
-// The caller orders these by hand (s_waitcnt lgkmcnt(0) before the next barrier; lds_settle() before first use).
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lptr_t)p; }
-__device__ __forceinline__ int4 lds_read16_raw(const void* p) {
-    int4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
-    return v;
-}
-__device__ __forceinline__ int lds_read4_raw(const void* p) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
-    return v;
-}
-__device__ __forceinline__ int lds_read4_now(const void* p) {          // the same, waited for
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
-    return v;
-}
-__device__ __forceinline__ int4 global_read16_raw(const void* p) {
-    int4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_write4_raw(void* p, float v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
-}
-__device__ __forceinline__ int lds_settle(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ int4 lds_settle(int4 v) { return int4{lds_settle(v.x), lds_settle(v.y), lds_settle(v.z), lds_settle(v.w)}; }
-
 // entry i of the combined list (x entries first, then w entries) in the LDS bucket copies
 __device__ __forceinline__ int* v8_entry(int* xb, int* wb, int cx, int i) {
     return (i < cx ? xb + EXC_ENTRY * i : wb + EXC_ENTRY * (i - cx)) + EXC_HEADER;
-}
-
-// Correction vectors from global memory (tiles with more entries than the in-loop path holds): one work item =
-// (entry, 64 rows of the other operand), up to MAXI items requested by a wave before it consumes any.
-__device__ __forceinline__ void v8_corr_from_global(const GemmArgs& a, int* xb, int* wb, int cx, int cw, float* corr,
-                                                    const float* sxt, const float* swt, long long m0, long long n0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int MAXI = 12;
-    const int nitems = (cx + cw) * 4;
-    for (int j0 = wave; j0 < nitems; j0 += V8_NW * MAXI) {
-        int4 qv[MAXI];
-#pragma unroll
-        for (int u = 0; u < MAXI; ++u) {
-            const int j = min(j0 + u * V8_NW, nitems - 1);
-            const bool is_x = (j >> 2) < cx;
-            const int* e = v8_entry(xb, wb, cx, j >> 2);
-            const long long qq = min((is_x ? n0 : m0) + (j & 3) * 64 + lane, (is_x ? a.N : a.M) - 1);
-            qv[u] = *reinterpret_cast<const int4*>((is_x ? a.wm : a.xm) + tiled_offset(qq, (long long)e[1] * 16, a.K));
-        }
-#pragma unroll
-        for (int u = 0; u < MAXI; ++u) {
-            const int j = j0 + u * V8_NW;
-            if (j >= nitems) break;
-            const bool is_x = (j >> 2) < cx;
-            const int* e = v8_entry(xb, wb, cx, j >> 2);
-            const int rl = (j & 3) * 64 + lane;
-            const int d = dot16(*reinterpret_cast<const int4*>(e + 4), qv[u]);
-            corr[(j >> 2) * 256 + rl] = __builtin_ldexpf((float)d, e[2] - (is_x ? a.x_off : a.w_off)) * (is_x ? swt : sxt)[rl];
-        }
-    }
 }
 
 // Last resort (more entries than LDS holds): add the exception products to the tile after its stores.
@@ -235,31 +171,28 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 #pragma unroll
     for (int j = 0; j < TJ; ++j) boff[j] = V8_HALF + v8_off(wn * 64 + j * 16 + l16, lq);
 
-    i32x4 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
-
     stage(0, 0);
     if (nsteps > 1) stage(1, 1);
 
-    // ---- exception bookkeeping of this tile.  The bucket copies rode in front of the operand stream; once they have
-    //      landed (the first two stages stay in flight) the workgroup counts the entries, clears the row / column maps
-    //      and lays out, per wave, the entries that wave will handle in K-step order (entry i belongs to wave i & 7).
-    int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors built during the K loop, 2: after it, 3: atomics
-    float* corr = reinterpret_cast<float*>(smem + V8_CORR);
-    int* plan = reinterpret_cast<int*>(smem + V8_PLAN);
-    constexpr int kNoDesc = -65536;                      // (K-step -1: never due)
-    int plan_cnt = 0, plan_cur = 0, evt_step = -1, pending = -1;
-    int desc = kNoDesc, desc_after = kNoDesc;             // the next two entries of this wave's plan (scalars)
-    int desc_raw = 0;                                     // ... and the one after, still on its way from LDS
-    bool raw_due = false;
+    // ---- exception bookkeeping of this tile.  Its buckets rode in front of the operand stream; once they have landed
+    //      (the first two stages stay in flight) the workgroup counts the entries, clears the row / column maps, links
+    //      the entries of each tile row / column into a chain and requests every entry's correction vector -- 256
+    //      floats the short launch in front of this kernel formed (mi355q_gemm_v6.hip) -- by ONE 1-KiB LDS-DMA each.
+    int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors beside the stages, 2: in the stage area after
+    float* corr = reinterpret_cast<float*>(smem + V8_CORR);          // the K loop, 3: added with atomics after the stores
+    int* multi = reinterpret_cast<int*>(smem + V8_PLAN);             // set when a row / column carries several entries
+    auto request_vectors = [&](unsigned char* area) {
+        for (int i = wave; i < cx + cw; i += V8_NW) {
+            const float* v = i < cx ? a.xcorr + ((m0 >> 8) * ROW_BCAP + i) * a.ldxc + n0
+                                    : a.wcorr + ((n0 >> 8) * ROW_BCAP + (i - cx)) * a.ldwc + m0;
+            __builtin_amdgcn_global_load_lds((gptr_t)(v + lane * 4), (lptr_t)(area + i * 1024), 16, 0, 0);
+        }
+    };
     if (FIXMODE) {
         if (nsteps > 1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
-        // a bucket overflowed somewhere: the fallback launch forms the product, this one must not write (uniform
-        // over the grid).  The operand loads in flight land in LDS only; nothing else is pending.
+        // a bucket overflowed somewhere: the launch in front of this one formed the product, this one must not write
+        // (uniform over the grid).  The operand loads in flight land in LDS only; nothing else is pending.
         const int* ovf = reinterpret_cast<const int*>(smem + V8_OVF);
         if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
             V8_WAIT(0);
@@ -268,25 +201,14 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         cx = __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
         const int n = cx + cw;
-        mode = n == 0 ? 0 : (n <= V8_FAST_MAX && nsteps >= 2) ? 1 : (n <= V8_SLOW_MAX ? 2 : 3);
+        mode = n == 0 ? 0 : (n <= V8_FAST_MAX ? 1 : (n <= V8_SLOW_MAX ? 2 : 3));
         if (mode) {
             rowslot[tid & 255] = -1;                        // tid < 256: rowslot, else colslot (contiguous)
             if (tid >= 256) colslot[tid & 255] = -1;
-            if (tid == 0) plan[7] = 0;                      // set when some row / column carries two or more entries
-            if (mode == 1 && tid < n) {
-                // descriptor = K-step << 16 | chunk of the 64-byte step << 13 | entry; rank among this wave's entries
-                const int kb = v8_entry(xb, wb, cx, tid)[1];
-                const int key = (kb >> 2) * 64 + tid;
-                int rank = 0;
-                for (int j = tid & 7; j < n; j += 8) {
-                    const int kj = (v8_entry(xb, wb, cx, j)[1] >> 2) * 64 + j;
-                    rank += kj < key ? 1 : 0;
-                }
-                plan[(tid & 7) * 8 + rank] = ((kb >> 2) << 16) | ((kb & 3) << 13) | tid;
-            }
+            if (tid == 0) *multi = 0;
+            if (mode == 1) request_vectors(smem + V8_CORR);
             __builtin_amdgcn_s_barrier();
-            // chains: every entry is pushed on the list of its tile row / column (heads in rowslot / colslot,
-            // successor in word 3 of the entry's LDS copy; -2 marks a void entry)
+            // chains: heads in rowslot / colslot, successor in word 3 of the entry's LDS copy; -2 marks a void entry
             for (int i = tid; i < n; i += V8_NT) {
                 const bool is_x = i < cx;
                 int* e = v8_entry(xb, wb, cx, i);
@@ -294,80 +216,21 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                 const bool live = is_x ? (r >= m0 && r < m0 + 256 && r < Mrows) : (r >= n0 && r < n0 + 256 && r < Ncols);
                 const long long r0_ = is_x ? m0 : n0;
                 e[3] = live ? atomicExch(&(is_x ? rowslot : colslot)[r - r0_], is_x ? i : i - cx) : -2;
-                if (e[3] >= 0) plan[7] = 1;
-            }
-            if (mode == 1) {
-                plan_cnt = n > wave ? (n - wave + 7) >> 3 : 0;
-                desc = plan_cnt > 0 ? __builtin_amdgcn_readfirstlane(plan[wave * 8]) : kNoDesc;
-                desc_after = plan_cnt > 1 ? __builtin_amdgcn_readfirstlane(plan[wave * 8 + 1]) : kNoDesc;
-                plan_cur = 2;                                // next plan slot to fetch
-                evt_step = desc >> 16;
+                if (e[3] >= 0) *multi = 1;
             }
         }
     }
 
+    i32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+
     unsigned long long c0 = 0, r0 = 0;
-    unsigned long long rt[6] = {0, 0, 0, 0, 0, 0}, ev_clk = 0;
-    int ev_n = 0;
+    unsigned long long rt[6] = {0, 0, 0, 0, 0, 0};
     if (FIXMODE_ == 2) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (FIXMODE_ == 3) rt[0] = __builtin_amdgcn_s_memrealtime();
-
-    // ---- exception side work inside the K loop (mode 1).  At the K-step that has an entry's block resident in
-    //      LDS, the owning wave REQUESTS the 256 blocks of the other operand it meets (4 LDS reads + scales, raw: see
-    //      lds_read16_raw); one step later, the data being in registers, it forms the dot products and writes the
-    //      correction vector.  Nothing waits, and a step without an event costs one scalar compare.
-    int4 pq[4], ppv = {0, 0, 0, 0};
-    int psc[4], pshift = 0, pend_off = 0;
-    auto side_consume = [&]() {
-        const int4 pv = lds_settle(ppv);
-        const int sh = lds_settle(pshift) - pend_off;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            lds_write4_raw(&corr[pending * 256 + c * 64 + lane],
-                           __builtin_ldexpf((float)dot16(pv, lds_settle(pq[c])), sh) * __int_as_float(lds_settle(psc[c])));
-        pending = -1;
-    };
-    const int lane_row_off = lane * 64;
-    const int lane_h = (0x78 >> (2 * ((lane >> 2) & 3))) & 3;
-    auto side_event = [&](int t, const unsigned char* sbase) {
-        if (raw_due) {                                       // requested at an earlier event: long since arrived
-            desc_after = __builtin_amdgcn_readfirstlane(lds_settle(desc_raw));
-            raw_due = false;
-        }
-        if (pending >= 0) side_consume();                    // requested at step t - 1
-        while ((desc >> 16) == t) {
-            if (pending >= 0) {                              // a second entry of this wave at the same step (rare)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                side_consume();
-                if (raw_due) {
-                    desc_after = __builtin_amdgcn_readfirstlane(lds_settle(desc_raw));
-                    raw_due = false;
-                }
-            }
-            const int idx = desc & 0x1FFF, chunk = (desc >> 13) & 3;
-            const bool is_x = idx < cx;
-            const int* e = v8_entry(xb, wb, cx, idx);
-            const unsigned char* other = sbase + (is_x ? V8_HALF : 0) + lane_row_off + ((chunk ^ lane_h) << 4);
-            const float* sc = (is_x ? swt : sxt) + lane;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                pq[c] = lds_read16_raw(other + c * 4096);
-                psc[c] = lds_read4_raw(sc + c * 64);
-            }
-            ppv = lds_read16_raw(e + 4);
-            pshift = lds_read4_raw(e + 2);
-            pend_off = is_x ? a.x_off : a.w_off;
-            pending = idx;
-            desc = desc_after;
-            desc_after = kNoDesc;
-            if (plan_cur < plan_cnt) {
-                desc_raw = lds_read4_raw(&plan[wave * 8 + plan_cur]);
-                raw_due = true;
-                ++plan_cur;
-            }
-        }
-        evt_step = pending >= 0 ? t + 1 : desc >> 16;
-    };
 
     int slot = 0, nslot = 2 % V8_S, pslot = 0;
     // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while a group issues its 16
@@ -411,12 +274,6 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
         }
         if (t + 2 < nsteps) V8_WAIT(2); else V8_WAIT(0);    // step t+1 complete (two newest pieces: step t+2)
-        if (FIXMODE && t == evt_step) {
-            unsigned long long e0 = 0;
-            if (FIXMODE_ == 3) e0 = __builtin_amdgcn_s_memtime();
-            side_event(t, sbase);
-            if (FIXMODE_ == 3) { ev_clk += __builtin_amdgcn_s_memtime() - e0; ++ev_n; }
-        }
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
@@ -431,10 +288,6 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
 
-    if (FIXMODE && pending >= 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        side_consume();
-    }
     if (FIXMODE_ == 3) rt[1] = __builtin_amdgcn_s_memrealtime();
     if (FIXMODE_ == 2) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -443,11 +296,11 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                    r1 - r0, (double)(c1 - c0) / (double)(r1 - r0) * 100.0, (double)(c1 - c0) / nsteps);
     }
     if (FIXMODE && mode) {
-        if (nsteps < 2) mode = 3;                                // (chains were never pushed: K = 64 only)
         __syncthreads();                                         // every wave is done with the stage area
         if (mode == 2) {
             corr = reinterpret_cast<float*>(smem);
-            v8_corr_from_global(a, xb, wb, cx, cw, corr, sxt, swt, m0, n0);
+            request_vectors(smem);
+            V8_WAIT(0);
             __syncthreads();
         }
         if (mode != 3) {
@@ -462,7 +315,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             __syncthreads();
             // rows / columns with two or more entries (flagged while the chains were pushed; uncommon): fold the
             // vectors of a chain into its head's, so that the epilogue reads ONE vector per row / column
-            if (plan[7] != 0 && wave == 0) {
+            if (*multi != 0 && wave == 0) {
                 for (int base = 0; base < cx + cw; base += 64) {
                     const int i = base + lane;
                     bool hm = false;
@@ -556,20 +409,12 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     if (FIXMODE_ == 3) {
         rt[5] = __builtin_amdgcn_s_memrealtime();
         if ((blockIdx.x == 0 || blockIdx.x == 77) && (tid == 0 || tid == 448))
-            printf("wg %d wave %d: events %d, %llu clocks in them | loop %llu | cross %llu | scale %llu | lookups %llu | stores %llu (x 10 ns) cx %d cw %d mode %d\n", blockIdx.x, wave, ev_n, ev_clk,
+            printf("wg %d wave %d: loop %llu | cross %llu | scale %llu | lookups %llu | stores %llu (x 10 ns) cx %d cw %d mode %d\n", blockIdx.x, wave,
                    rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2], rt[4] - rt[3], rt[5] - rt[4], cx, cw, mode);
     }
     if (FIXMODE && mode == 3) {
         V8_WAIT(0);
         __syncthreads();
-        if (nsteps < 2) {                                        // void marks were never written
-            for (int i = tid; i < cx + cw; i += V8_NT) {
-                int* e = v8_entry(xb, wb, cx, i);
-                const long long r = e[0], r0 = i < cx ? m0 : n0, rmax = i < cx ? a.M : a.N;
-                e[3] = (r >= r0 && r < min(r0 + 256, rmax)) ? -1 : -2;
-            }
-            __syncthreads();
-        }
         v8_fix_atomic(a, xb, wb, cx, cw, sxt, swt, m0, n0);
     }
 }

@@ -43,6 +43,10 @@ struct GemmArgs {
     int scale_bias;   // subtracted from xe + we to get the power of two of a block product
     int row_mode;     // 1: operands are ROW-aligned (rowflag[row], bucketed exception lists)
     int x_off, w_off; // exponent_bias + mbits of each operand (scale_bias = x_off + w_off)
+    // row mode: correction vectors of the exception blocks (one row of ldxc / ldwc floats per bucket slot)
+    float* xcorr;
+    float* wcorr;
+    long long ldxc, ldwc;
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
@@ -52,7 +56,7 @@ int launch_bfp_align_rows(const int8_t* mi, const uint8_t* ei, int8_t* mt, uint8
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st);
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
-                         int list_cap, hipStream_t st);
+                         int list_cap, hipStream_t st, const float* xscale = nullptr, const float* wscale = nullptr);
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
                      long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
                      long long K, hipStream_t st);

@@ -205,9 +205,9 @@ class AlignedOperand:
         self.mbits, self.exp_bias = int(mbits), int(exp_bias)
         self.row_aligned = bool(row_aligned)         # one exponent per ROW (mi355q_bfp_align_rows) instead of per 256 values
 
-    def c_struct(self):
+    def c_struct(self, corr=None):
         return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
-                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, int(self.row_aligned))
+                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, int(self.row_aligned), _ptr(corr))
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
@@ -367,6 +367,24 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
                           int(width) - 1, eb, row_aligned=True)
 
 
+_CORR_CACHE: dict = {}
+
+
+def _corr_workspace(device, M, N):
+    """scratch for the correction vectors of a row-aligned GEMM (include/mi355q.h, mi355q_bfp_corr_bytes), reused per
+    (device, stream, M, N)"""
+    key = (device.index, _stream_ptr(device), M, N)
+    ws = _CORR_CACHE.get(key)
+    if ws is None:
+        lib = _lib.load_library()
+        ws = (torch.empty(lib.mi355q_bfp_corr_bytes(M, N) // 4, dtype=torch.float32, device=device),
+              torch.empty(lib.mi355q_bfp_corr_bytes(N, M) // 4, dtype=torch.float32, device=device))
+        if len(_CORR_CACHE) > 32:
+            _CORR_CACHE.clear()
+        _CORR_CACHE[key] = ws
+    return ws
+
+
 def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):
     """bfp_gemm on operands rewritten by bfp_align."""
     M, K, N = x.rows, x.K, w.rows
@@ -376,7 +394,10 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
     lib = _lib.load_library()
-    xs, ws = x.c_struct(), w.c_struct()
+    cx = cw = None
+    if x.row_aligned and w.row_aligned:
+        cx, cw = _corr_workspace(x.tiled.device, M, N)
+    xs, ws = x.c_struct(cx), w.c_struct(cw)
     import ctypes
     with torch.cuda.device(x.tiled.device):
         rc = lib.mi355q_bfp_gemm_aligned(ctypes.addressof(xs), ctypes.addressof(ws), _ptr(bias), _ptr(out), M, N, K,
