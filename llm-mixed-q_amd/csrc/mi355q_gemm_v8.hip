@@ -208,15 +208,32 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             if (tid == 0) *multi = 0;
             if (mode == 1) request_vectors(smem + V8_CORR);
             __builtin_amdgcn_s_barrier();
-            // chains: heads in rowslot / colslot, successor in word 3 of the entry's LDS copy; -2 marks a void entry
+            // chains: the entries of one tile row / column, linked by DESCENDING block index (head in rowslot /
+            // colslot, successor in word 3 of the entry's LDS copy, -2 marks a void entry).  The order is a property
+            // of the data, not of which workgroup reserved its list slots first: results are reproducible.
             for (int i = tid; i < n; i += V8_NT) {
                 const bool is_x = i < cx;
                 int* e = v8_entry(xb, wb, cx, i);
                 const long long r = e[0];
+                const int kb = e[1];
                 const bool live = is_x ? (r >= m0 && r < m0 + 256 && r < Mrows) : (r >= n0 && r < n0 + 256 && r < Ncols);
-                const long long r0_ = is_x ? m0 : n0;
-                e[3] = live ? atomicExch(&(is_x ? rowslot : colslot)[r - r0_], is_x ? i : i - cx) : -2;
-                if (e[3] >= 0) *multi = 1;
+                if (!live) {
+                    e[3] = -2;
+                    continue;
+                }
+                int pred = -1, predkb = -1;
+                bool head = true;
+                const int lo = is_x ? 0 : cx, hi = is_x ? cx : n;
+                for (int j = lo; j < hi; ++j) {
+                    const int* f = v8_entry(xb, wb, cx, j);
+                    if (f[0] != (int)r) continue;
+                    const int kj = f[1];
+                    if (kj < kb && kj > predkb) { pred = j; predkb = kj; }
+                    head = head && kj <= kb;
+                }
+                e[3] = pred >= 0 ? pred - lo : -1;
+                if (head) (is_x ? rowslot : colslot)[r - (is_x ? m0 : n0)] = i - lo;
+                if (pred >= 0) *multi = 1;
             }
         }
     }

@@ -412,3 +412,29 @@ def test_fused_quantize_align_rows_equals_two_step(style, rows, width, K):
     assert again.sparse.data_ptr() != got.sparse.data_ptr() and third.sparse.data_ptr() == got.sparse.data_ptr()
     o3, e3 = ops.row_list_entries(third.sparse, rows)
     assert o3 == 0 and set(map(tuple, e3)) == set(map(tuple, e1))
+
+
+def test_row_aligned_gemm_is_reproducible():
+    """no floating-point atomics on the row-aligned path (up to 96 exception blocks per 256 x 256 tile): the sum of a
+    row's correction vectors follows the blocks' K order, not the order in which workgroups reserved their list
+    slots, so repeated runs -- and repeated quantisations -- give bit-identical results"""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    M, N, K = 520, 300, 768
+    x, w, b = _inputs(M, N, K, 4321, "rowscale")
+    x[::12, 256:272] *= 300.0
+    w[::16, 256:272] *= 300.0
+    x[::28, 512:528] *= 1e-3
+    x[::36, 64:80] *= 300.0                    # rows with two or three exception blocks
+    xt = torch.from_numpy(x).to(dev)
+    _, wm, we = ops.block_fp_quantize(torch.from_numpy(w).to(dev), 6, 8, 127, [1, 16], False, want_fake=False,
+                                      want_packed=True, fast_zero_blocks=True)
+    wa = ops.bfp_align_rows(wm, we, 5, 127)
+    outs = []
+    for _ in range(4):
+        xa = ops.block_fp_quantize_aligned_rows(xt, 6, 8, 127)      # slot order inside the buckets differs run to run
+        outs.append(ops.bfp_gemm_aligned(xa, wa, None).clone())
+        outs.append(ops.bfp_gemm_aligned(xa, wa, None).clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
