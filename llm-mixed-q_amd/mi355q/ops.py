@@ -290,8 +290,8 @@ class _ActivationBuffers:
     _cache: dict = {}
 
     @classmethod
-    def get(cls, device, rows, K, row_aligned=False):
-        key = (device.index, _stream_ptr(device), rows, K, row_aligned)
+    def get(cls, device, rows, K, row_aligned=False, sp=None):
+        key = (device.index, _stream_ptr(device) if sp is None else sp, rows, K, row_aligned)
         buf = cls._cache.get(key)
         if buf is None and row_aligned:
             lib = _lib.load_library()
@@ -352,7 +352,8 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     assert x.ndim == 2 and x.shape[1] % 64 == 0 and x.shape[1] <= ROW_ALIGN_MAX_K
     rows, K = x.shape
     xc = x.contiguous()
-    buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True)
+    sp = _stream_ptr(x.device)
+    buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True, sp=sp)
     bias = _default_bias(exponent_bias)
     lib = _lib.load_library()
     cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
@@ -360,7 +361,7 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     with torch.cuda.device(x.device):
         rc = lib.mi355q_block_fp_quantize_aligned_rows(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
                                                        _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows, K, int(width),
-                                                       int(exponent_width), bias, _stream_ptr(x.device))
+                                                       int(exponent_width), bias, sp)
     _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows")
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
     return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
@@ -370,10 +371,10 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
 _CORR_CACHE: dict = {}
 
 
-def _corr_workspace(device, M, N):
+def _corr_workspace(device, M, N, sp=None):
     """scratch for the correction vectors of a row-aligned GEMM (include/mi355q.h, mi355q_bfp_corr_bytes), reused per
     (device, stream, M, N)"""
-    key = (device.index, _stream_ptr(device), M, N)
+    key = (device.index, _stream_ptr(device) if sp is None else sp, M, N)
     ws = _CORR_CACHE.get(key)
     if ws is None:
         lib = _lib.load_library()
@@ -394,14 +395,15 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
     lib = _lib.load_library()
+    sp = _stream_ptr(x.tiled.device)
     cx = cw = None
     if x.row_aligned and w.row_aligned:
-        cx, cw = _corr_workspace(x.tiled.device, M, N)
+        cx, cw = _corr_workspace(x.tiled.device, M, N, sp)
     xs, ws = x.c_struct(cx), w.c_struct(cw)
     import ctypes
     with torch.cuda.device(x.tiled.device):
         rc = lib.mi355q_bfp_gemm_aligned(ctypes.addressof(xs), ctypes.addressof(ws), _ptr(bias), _ptr(out), M, N, K,
-                                         ldy, _stream_ptr(x.tiled.device))
+                                         ldy, sp)
     _lib.check(rc, "mi355q_bfp_gemm_aligned")
     return out
 
