@@ -217,7 +217,8 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
 
 size_t mi355q_bfp_corr_bytes(int64_t rows, int64_t other_rows) {
     if (rows <= 0 || other_rows <= 0) return 0;
-    return (size_t)((rows + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS) * ROW_BCAP * (size_t)((other_rows + 255) / 256 * 256) * 4;
+    // (+1 KiB: a 128-row tile fetches 256 floats from its first row on)
+    return (size_t)((rows + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS) * ROW_BCAP * (size_t)((other_rows + 255) / 256 * 256) * 4 + 1024;
 }
 
 size_t mi355q_bfp_row_list_bytes(int64_t rows) { return rows < 0 ? 0 : (size_t)row_list_words(rows) * 4; }

@@ -62,7 +62,7 @@ __device__ __forceinline__ int* v8_entry(int* xb, int* wb, int cx, int i) {
 
 // Last resort (more entries than LDS holds): add the exception products to the tile after its stores.
 __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* wb, int cx, int cw, const float* sxt,
-                                              const float* swt, long long m0, long long n0) {
+                                              const float* swt, long long m0, long long n0, int bm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nitems = (cx + cw) * 4;
     for (int j = wave; j < nitems; j += V8_NW) {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
         const int* e = v8_entry(xb, wb, cx, j >> 2);
         const int rl = (j & 3) * 64 + lane;
         const long long q = (is_x ? n0 : m0) + rl, r = e[0];
-        if (e[3] == -2 || q >= (is_x ? a.N : a.M)) continue;
+        if (e[3] == -2 || q >= (is_x ? a.N : a.M) || (!is_x && rl >= bm)) continue;
         const int4 qv = *reinterpret_cast<const int4*>((is_x ? a.wm : a.xm) + tiled_offset(q, (long long)e[1] * 16, a.K));
         const int d = dot16(*reinterpret_cast<const int4*>(e + 4), qv);
         if (d != 0)
@@ -86,19 +86,24 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
     }
 }
 
-template <int FIXMODE_>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
+template <int FIXMODE_, int TI>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
                                                         const int* __restrict__ wlist) {
     constexpr int FIXMODE = (FIXMODE_ == 1 || FIXMODE_ == 3) ? 1 : 0;      // 3: as 1, with phase timing printed by workgroup 0
-    constexpr int TI = 8, TJ = 4, LPW = 32 / V8_NW;
+    // TI = 16-row MFMA tiles per wave along M.  8: 256 x 256 workgroup tile, two MFMA phases per K-step, three 32-KiB
+    // stages.  4: 128 x 256 tile (for shapes whose 256 x 256 tiles would leave compute units idle), one phase per K-step,
+    // four 24-KiB stages (the steps are half as long, so the loads run three steps ahead).
+    constexpr int TJ = 4, BM = 2 * TI * 16, WM = TI * 16, HALF = BM * 64, STAGE = HALF + 256 * 64;
+    constexpr int NS = V8_S * V8_STAGE / STAGE, NPIECE = BM / 16 + 16, LPW = NPIECE / V8_NW;
+    static_assert((TI == 8 && NS == 3) || (TI == 4 && NS == 4), "stage ring");
     __shared__ __attribute__((aligned(16))) unsigned char smem[V8_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
 
-    const int tiles_m = (int)((a.M + V8_BM - 1) / V8_BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
+    const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
     const int nwg = tiles_m * tiles_n;
     int pid;
     {
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     const int GM = 4, in_group = GM * tiles_n, group_id = pid / in_group, first_m = group_id * GM;
     const int gsz = min(tiles_m - first_m, GM);
     const int tm = first_m + (pid % in_group) % gsz, tn = (pid % in_group) / gsz;
-    const long long m0 = (long long)tm * V8_BM, n0 = (long long)tn * V8_BN;
+    const long long m0 = (long long)tm * BM, n0 = (long long)tn * V8_BN;
     const int nsteps = (int)(a.K >> 6);
     const long long Mrows = a.M, Ncols = a.N;
 
@@ -149,30 +154,31 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 
     const long long kp = a.K >> 6;
     const long long pa_max = ((a.M + 127) / 128) * 8 - 1, pb_max = ((a.N + 127) / 128) * 8 - 1;
-    // piece p of a stage: p < 16 -> 16 rows of A, else 16 rows of B; this wave stages pieces wave + 8 q
+    // piece p of a stage: p < BM / 16 -> 16 rows of A, else 16 rows of B; this wave stages pieces wave + 8 q
     const int8_t* src[LPW];
     int dst[LPW];
 #pragma unroll
     for (int q = 0; q < LPW; ++q) {
         const int p = wave + V8_NW * q;
-        src[q] = p < 16 ? a.xm + min((m0 >> 4) + p, pa_max) * kp * 1024 + lane * 16
-                        : a.wm + min((n0 >> 4) + (p - 16), pb_max) * kp * 1024 + lane * 16;
+        src[q] = p < BM / 16 ? a.xm + min((m0 >> 4) + p, pa_max) * kp * 1024 + lane * 16
+                             : a.wm + min((n0 >> 4) + (p - BM / 16), pb_max) * kp * 1024 + lane * 16;
         dst[q] = p * 1024;
     }
     auto stage = [&](int step, int slot) {
 #pragma unroll
         for (int q = 0; q < LPW; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
-                                             (lptr_t)(smem + slot * V8_STAGE + dst[q]), 16, 0, 0);
+                                             (lptr_t)(smem + slot * STAGE + dst[q]), 16, 0, 0);
     };
     int aoff[TI], boff[TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) aoff[i] = v8_off(wm * 128 + i * 16 + l16, lq);
+    for (int i = 0; i < TI; ++i) aoff[i] = v8_off(wm * WM + i * 16 + l16, lq);
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) boff[j] = V8_HALF + v8_off(wn * 64 + j * 16 + l16, lq);
+    for (int j = 0; j < TJ; ++j) boff[j] = HALF + v8_off(wn * 64 + j * 16 + l16, lq);
 
     stage(0, 0);
     if (nsteps > 1) stage(1, 1);
+    if (TI == 4 && nsteps > 2) stage(2, 2);
 
     // ---- exception bookkeeping of this tile.  Its buckets rode in front of the operand stream; once they have landed
     //      (the first two stages stay in flight) the workgroup counts the entries, clears the row / column maps, links
@@ -189,7 +195,8 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         }
     };
     if (FIXMODE) {
-        if (nsteps > 1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
+        // (the buckets are older than the operand stages requested above)
+        if (TI == 4 && nsteps > 2) V8_WAIT(3 * LPW); else if (nsteps > 1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
         // a bucket overflowed somewhere: the launch in front of this one formed the product, this one must not write
         // (uniform over the grid).  The operand loads in flight land in LDS only; nothing else is pending.
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                 int* e = v8_entry(xb, wb, cx, i);
                 const long long r = e[0];
                 const int kb = e[1];
-                const bool live = is_x ? (r >= m0 && r < m0 + 256 && r < Mrows) : (r >= n0 && r < n0 + 256 && r < Ncols);
+                const bool live = is_x ? (r >= m0 && r < m0 + BM && r < Mrows) : (r >= n0 && r < n0 + 256 && r < Ncols);
                 if (!live) {
                     e[3] = -2;
                     continue;
@@ -249,61 +256,106 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     if (FIXMODE_ == 2) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (FIXMODE_ == 3) rt[0] = __builtin_amdgcn_s_memrealtime();
 
-    int slot = 0, nslot = 2 % V8_S, pslot = 0;
     // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while a group issues its 16
     // MFMAs between two barriers, the other reads its next fragments from LDS and issues its LDS-DMA loads.
-    // A K-step is two such phases (A rows 0-63, then 64-127 of the wave tile).  The pieces of step t+2 are
-    // requested in phase 1 of step t (two) and phase 0 of step t+1 (two): a stage is re-filled two barriers
-    // after its last read, so fragment reads may retire behind the barrier, beside the other group's wait.
-    auto dma2 = [&](int step, int sl, int q0) {
+    // Rules both schedules below keep: a stage is re-filled only after a barrier that every wave reaches with its reads
+    // of that stage retired; and every wave has waited for its own pieces of a step before a barrier that every
+    // reader of that step passes first (LDS-DMA data are ordered by the issuing wave's vmcnt + a barrier only).
+    auto dma_pieces = [&](int step, int sl, int q0, int q1) {
 #pragma unroll
-        for (int q = q0; q < q0 + 2; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
-                                             (lptr_t)(smem + sl * V8_STAGE + dst[q]), 16, 0, 0);
+        for (int q = 0; q < LPW; ++q)
+            if (q >= q0 && q < q1)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
+                                                 (lptr_t)(smem + sl * STAGE + dst[q]), 16, 0, 0);
     };
-    if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nsteps; ++t) {
-        const unsigned char* sbase = smem + slot * V8_STAGE;
-        i32x4 fa[4], fb[TJ];
-        // ---- phase 0
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
-        if (t >= 1 && t + 1 < nsteps) dma2(t + 1, pslot, 2);
+    int slot = 0;
+    if (TI == 8) {
+        // A K-step is two phases (A rows 0-63, then 64-127 of the wave tile).  The pieces of step t+2 are requested in
+        // phase 1 of step t (two) and phase 0 of step t+1 (two): a stage is re-filled two barriers after its last read,
+        // so fragment reads may retire behind the barrier, beside the other group's wait.
+        int nslot = 2 % NS, pslot = 0;
+        if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nsteps; ++t) {
+            const unsigned char* sbase = smem + slot * STAGE;
+            i32x4 fa[4], fb[TJ];
+            // ---- phase 0
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 1
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
+            if (t >= 1 && t + 1 < nsteps) dma_pieces(t + 1, pslot, 2, 4);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[4 + i]);
-        if (t + 2 < nsteps) {
-            dma2(t + 2, nslot, 0);
-            pslot = nslot;
-            nslot = nslot + 1 == V8_S ? 0 : nslot + 1;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[TI - 4 + i]);
+            if (t + 2 < nsteps) {
+                dma_pieces(t + 2, nslot, 0, 2);
+                pslot = nslot;
+                nslot = nslot + 1 == NS ? 0 : nslot + 1;
+            }
+            if (t + 2 < nsteps) V8_WAIT(2); else V8_WAIT(0);    // step t+1 complete (two newest pieces: step t+2)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[TI - 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[TI - 4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == NS ? 0 : slot + 1;
         }
-        if (t + 2 < nsteps) V8_WAIT(2); else V8_WAIT(0);    // step t+1 complete (two newest pieces: step t+2)
+        if (wm == 0) __builtin_amdgcn_s_barrier();
+    } else {
+        // One phase per K-step; barriers G(2t) (before the leading group's MFMAs of step t) and G(2t+1) (behind them;
+        // the lagging group is one barrier later).  Step t+3 is requested once every read of step t-1 has retired:
+        // behind G(2t), i.e. after its own MFMAs for the leading group, before them for the lagging one.  Either way a
+        // wave then waits for its pieces of step t+1 (steps t+2 and t+3 stay in flight) before it arrives at G(2t+1),
+        // the barrier the leading group passes before it reads step t+1.
+        int nslot = 3 % NS;
+        if (nsteps > 2) V8_WAIT(2 * LPW); else if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        auto request_and_wait = [&](int t) {
+            if (t + 3 < nsteps) {
+                dma_pieces(t + 3, nslot, 0, LPW);
+                nslot = nslot + 1 == NS ? 0 : nslot + 1;
+            }
+            if (t + 3 < nsteps) V8_WAIT(2 * LPW); else if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
+        };
+        for (int t = 0; t < nsteps; ++t) {
+            const unsigned char* sbase = smem + slot * STAGE;
+            i32x4 fa[4], fb[TJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        slot = slot + 1 == V8_S ? 0 : slot + 1;
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
+            if (wm == 1) request_and_wait(t);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (wm == 0) request_and_wait(t);
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();
 
     if (FIXMODE_ == 3) rt[1] = __builtin_amdgcn_s_memrealtime();
     if (FIXMODE_ == 2) {
@@ -375,7 +427,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         const float swv = swt[cl], bv = bst[cl];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const f32x4 sxv = *reinterpret_cast<const f32x4*>(&sxt[wm * 128 + i * 16 + lq * 4]);
+            const f32x4 sxv = *reinterpret_cast<const f32x4*>(&sxt[wm * WM + i * 16 + lq * 4]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) val[i][j][r] = (float)acc[i][j][r] * sxv[r] * swv + bv;
         }
@@ -387,7 +439,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         for (int j = 0; j < TJ; ++j) {
             const int sc_ = colslot[wn * 64 + j * 16 + l16];
             if (__any(sc_ >= 0)) {
-                const float* v = corr + (cx + max(sc_, 0)) * 256 + wm * 128 + lq * 4;
+                const float* v = corr + (cx + max(sc_, 0)) * 256 + wm * WM + lq * 4;
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     const f32x4 c4 = *reinterpret_cast<const f32x4*>(v + i * 16);
@@ -400,7 +452,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sr[i][r] = rowslot[wm * 128 + i * 16 + lq * 4 + r];
+            for (int r = 0; r < 4; ++r) sr[i][r] = rowslot[wm * WM + i * 16 + lq * 4 + r];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -416,7 +468,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long long row = m0 + wm * 128 + i * 16 + lq * 4 + r;
+            const long long row = m0 + wm * WM + i * 16 + lq * 4 + r;
             float* yrow = a.y + row * a.ldy + n0 + wn * 64 + l16;
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
@@ -432,21 +484,33 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     if (FIXMODE && mode == 3) {
         V8_WAIT(0);
         __syncthreads();
-        v8_fix_atomic(a, xb, wb, cx, cw, sxt, swt, m0, n0);
+        v8_fix_atomic(a, xb, wb, cx, cw, sxt, swt, m0, n0, BM);
     }
 }
 
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st) {
     (void)list_cap;
-    const unsigned tiles = (unsigned)(((a.M + V8_BM - 1) / V8_BM) * ((a.N + V8_BN - 1) / V8_BN));
+    // 256 x 256 tiles unless they would leave too many of the 256 compute units idle: a 128 x 256 tile does half the
+    // work in 0.8 of the time (measured: 48 vs 58 us at 2048 x 4096 x 4096; the fragment reads and LDS-DMA issue of a
+    // K-step are shared by half as many MFMAs)
+    const long long tn = (a.N + V8_BN - 1) / V8_BN;
+    const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
+    const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost128 = (double)((t128 + 255) / 256) * 0.82;
+    const char* force = getenv("MI355Q_V8_TILE_ROWS");          // (tests pin either flavour)
+    const bool small = force && atoi(force) ? atoi(force) == 128 : cost128 < cost256;
+    const unsigned tiles = (unsigned)(small ? t128 : t256);
     // diagnostic builds: MI355Q_V8_CLOCK prints the clock held over the K loop (no add-back),
     // MI355Q_V8_STAMPS the duration of the kernel's phases
     static const bool want_clock = getenv("MI355Q_V8_CLOCK") != nullptr, want_stamps = getenv("MI355Q_V8_STAMPS") != nullptr;
-    if (xlist && wlist && want_stamps) hipLaunchKernelGGL(bfp_gemm_v8<3>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    else if (xlist && wlist) hipLaunchKernelGGL(bfp_gemm_v8<1>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    else if (want_clock) hipLaunchKernelGGL(bfp_gemm_v8<2>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    else hipLaunchKernelGGL(bfp_gemm_v8<0>, tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    const bool fix = xlist && wlist;
+    if (small) {
+        if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+        else hipLaunchKernelGGL((bfp_gemm_v8<0, 4>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    } else if (fix && want_stamps) hipLaunchKernelGGL((bfp_gemm_v8<3, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    else if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    else if (want_clock) hipLaunchKernelGGL((bfp_gemm_v8<2, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+    else hipLaunchKernelGGL((bfp_gemm_v8<0, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
     return (int)hipGetLastError();
 }
 

@@ -331,10 +331,12 @@ def test_row_align_is_value_preserving(width):
                                    (64, 64, 192)])
 @pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
 @pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
-def test_row_aligned_gemm_vs_oracle(M, N, K, style, wx, ww):
+@pytest.mark.parametrize("tile_rows", [256, 128])
+def test_row_aligned_gemm_vs_oracle(M, N, K, style, wx, ww, tile_rows, monkeypatch):
     """row-scale int8 GEMM + exception add-back in its epilogue; overflowing buckets (outlier data, W8) and
     K % 128 != 0 take the blockwise kernel"""
     from oracle import np_oracle as O
+    monkeypatch.setenv("MI355Q_V8_TILE_ROWS", str(tile_rows))      # both workgroup-tile flavours of the row-scale kernel
     x, w, b = _inputs(M, N, K, 3000 + M + N + K, style)
     cfg = _cfg(wx, ww)
     y = _run(x, w, b, cfg, aligned="rows")
@@ -343,9 +345,10 @@ def test_row_aligned_gemm_vs_oracle(M, N, K, style, wx, ww):
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
 
 
-@pytest.mark.parametrize("variant", [0, 2])
-def test_row_aligned_gemm_exceptions_of_both_operands_share_blocks(variant):
+@pytest.mark.parametrize("variant,tile_rows", [(0, 256), (0, 128), (2, 0)])
+def test_row_aligned_gemm_exceptions_of_both_operands_share_blocks(variant, tile_rows, monkeypatch):
     from mi355q import ops
+    monkeypatch.setenv("MI355Q_V8_TILE_ROWS", str(tile_rows))
     from oracle import np_oracle as O
     x, w, b = _inputs(520, 300, 768, 17, "rowscale")
     x[::5, 256:272] *= 300.0
@@ -414,12 +417,14 @@ def test_fused_quantize_align_rows_equals_two_step(style, rows, width, K):
     assert o3 == 0 and set(map(tuple, e3)) == set(map(tuple, e1))
 
 
-def test_row_aligned_gemm_is_reproducible():
+@pytest.mark.parametrize("tile_rows", [256, 128])
+def test_row_aligned_gemm_is_reproducible(tile_rows, monkeypatch):
     """no floating-point atomics on the row-aligned path (up to 96 exception blocks per 256 x 256 tile): the sum of a
     row's correction vectors follows the blocks' K order, not the order in which workgroups reserved their list
     slots, so repeated runs -- and repeated quantisations -- give bit-identical results"""
     import torch
     from mi355q import ops
+    monkeypatch.setenv("MI355Q_V8_TILE_ROWS", str(tile_rows))
     dev = torch.device("cuda:0")
     M, N, K = 520, 300, 768
     x, w, b = _inputs(M, N, K, 4321, "rowscale")
