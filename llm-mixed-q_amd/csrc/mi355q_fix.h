@@ -113,48 +113,5 @@ __device__ __forceinline__ void tile_fix_body(const GemmArgs& a, const int* __re
     }
 }
 
-// The same correction with one (entry, row of the other operand) pair per thread and step: every pair is
-// independent, so a tile with a few dozen entries takes a handful of memory round trips (epilogue of the
-// row-aligned GEMM, where every CU does this at the same time).
-template <int BM, int BN>
-__device__ __forceinline__ void tile_fix_pairs(const GemmArgs& a, const int* __restrict__ xlist,
-                                               const int* __restrict__ wlist, int cap, long long m0, long long n0) {
-    const int cx = list_count(xlist, cap), cw = list_count(wlist, cap);
-    if (cx == 0 && cw == 0) return;
-    const long long nkb = a.K >> 4;
-    const long long m1 = min(m0 + BM, a.M), n1 = min(n0 + BN, a.N);
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-#pragma unroll 2
-    for (int idx = tid; idx < cx * BN; idx += nthreads) {
-        const int* e = xlist + EXC_HEADER + EXC_ENTRY * (idx / BN);
-        const long long n = n0 + idx % BN;
-        const int row = e[0], kb = e[1], code = e[2];
-        if (row < m0 || row >= m1 || n >= n1) continue;
-        const int4 pv = *reinterpret_cast<const int4*>(e + 4);
-        const int4 qv = *reinterpret_cast<const int4*>(a.wm + tiled_offset(n, (long long)kb * 16, a.K));
-        const int d = dot16(pv, qv);
-        if (d != 0) atomicAdd(&a.y[(long long)row * a.ldy + n], __builtin_ldexpf((float)d, code + (int)a.we[n * nkb + kb] - a.scale_bias));
-    }
-#pragma unroll 2
-    for (int idx = tid; idx < cw * BM; idx += nthreads) {
-        const int* e = wlist + EXC_HEADER + EXC_ENTRY * (idx / BM);
-        const long long m = m0 + idx % BM;
-        const int row = e[0], kb = e[1], code = e[2];
-        if (row < n0 || row >= n1 || m >= m1) continue;
-        const int4 pv = *reinterpret_cast<const int4*>(e + 4);
-        const int4 qv = *reinterpret_cast<const int4*>(a.xm + tiled_offset(m, (long long)kb * 16, a.K));
-        const int d = dot16(pv, qv);
-        if (d != 0) atomicAdd(&a.y[m * a.ldy + row], __builtin_ldexpf((float)d, code + (int)a.xe[m * nkb + kb] - a.scale_bias));
-    }
-    for (int idx = tid; idx < cx * cw; idx += nthreads) {            // exception x exception
-        const int* e = xlist + EXC_HEADER + EXC_ENTRY * (idx / cw);
-        const int* f = wlist + EXC_HEADER + EXC_ENTRY * (idx % cw);
-        const int row = e[0], n = f[0];
-        if (row < m0 || row >= m1 || n < n0 || n >= n1 || e[1] != f[1]) continue;
-        const int d = dot16(*reinterpret_cast<const int4*>(e + 4), *reinterpret_cast<const int4*>(f + 4));
-        if (d != 0) atomicAdd(&a.y[(long long)row * a.ldy + n], __builtin_ldexpf((float)d, e[2] + f[2] - a.scale_bias));
-    }
-}
-
 }  // namespace mi355q
 #endif

@@ -42,8 +42,8 @@ constexpr int V8_HALF = 256 * 64, V8_STAGE = 2 * V8_HALF;
 constexpr int V8_BUCKET = 4096;                     // LDS copy of one exception bucket (ROW_BUCKET_WORDS * 4 <= 4096)
 constexpr int V8_XB = V8_S * V8_STAGE, V8_WB = V8_XB + V8_BUCKET, V8_MAP = V8_WB + V8_BUCKET;
 constexpr int V8_SXT = V8_MAP + 2 * 256 * 4, V8_SWT = V8_SXT + 1024, V8_BIAS = V8_SWT + 1024;
-constexpr int V8_PLAN = V8_BIAS + 1024;              // a few flag words
-constexpr int V8_OVF = V8_PLAN + 256;                // LDS copies of the two lists' header words (word 0 = overflow)
+constexpr int V8_FLAGS = V8_BIAS + 1024;             // a few flag words
+constexpr int V8_OVF = V8_FLAGS + 256;                // LDS copies of the two lists' header words (word 0 = overflow)
 constexpr int V8_CORR = V8_OVF + 512;
 constexpr int V8_LDS = 160 * 1024;
 constexpr int V8_FAST_MAX = (V8_LDS - V8_CORR) / 1024;      // entries (x + w) whose vectors fit beside the stages
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     //      floats the short launch in front of this kernel formed (mi355q_gemm_v6.hip) -- by ONE 1-KiB LDS-DMA each.
     int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors beside the stages, 2: in the stage area after
     float* corr = reinterpret_cast<float*>(smem + V8_CORR);          // the K loop, 3: added with atomics after the stores
-    int* multi = reinterpret_cast<int*>(smem + V8_PLAN);             // set when a row / column carries several entries
+    int* multi = reinterpret_cast<int*>(smem + V8_FLAGS);             // set when a row / column carries several entries
     auto request_vectors = [&](unsigned char* area) {
         for (int i = wave; i < cx + cw; i += V8_NW) {
             const float* v = i < cx ? a.xcorr + ((m0 >> 8) * ROW_BCAP + i) * a.ldxc + n0
