@@ -52,13 +52,14 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
     constexpr int BIG = 1 << 20;
     bool has[MAXIT];
     int head[MAXIT];
-    int em = BIG;
+    int em = BIG, lo = -BIG;            // smallest exponent; largest "lowest exponent a block can be shifted onto"
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int kb = it * 64 + wave * 16 + (lane >> 2);
         has[it] = (FULL || (it < nit && kb < nkb)) && amax[it] > 0;
         head[it] = has[it] ? __clz(amax[it]) - 25 : 0;
         em = min(em, has[it] ? code[it] : BIG);
+        lo = max(lo, has[it] ? code[it] - head[it] : -BIG);
     }
     em = min(em, __builtin_amdgcn_mov_dpp(em, 0x121, 0xF, 0xF, true));   // row_ror:1
     em = min(em, __builtin_amdgcn_mov_dpp(em, 0x122, 0xF, 0xF, true));   // row_ror:2
@@ -66,16 +67,21 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
     em = min(em, __builtin_amdgcn_mov_dpp(em, 0x128, 0xF, 0xF, true));   // row_ror:8
     em = min(min(__builtin_amdgcn_readlane(em, 0), __builtin_amdgcn_readlane(em, 16)),
              min(__builtin_amdgcn_readlane(em, 32), __builtin_amdgcn_readlane(em, 48)));
-    if (lane == 0) sm.emin[wave] = em;
+    lo = max(lo, __builtin_amdgcn_mov_dpp(lo, 0x121, 0xF, 0xF, true));
+    lo = max(lo, __builtin_amdgcn_mov_dpp(lo, 0x122, 0xF, 0xF, true));
+    lo = max(lo, __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, true));
+    lo = max(lo, __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, true));
+    lo = max(max(__builtin_amdgcn_readlane(lo, 0), __builtin_amdgcn_readlane(lo, 16)),
+             max(__builtin_amdgcn_readlane(lo, 32), __builtin_amdgcn_readlane(lo, 48)));
+    if (lane == 0) { sm.emin[wave] = em; sm.wkey[wave] = lo; }
     if (tid == 0) { sm.code0 = code[0]; sm.nexc = 0; }
     sm.cnt[tid] = 0;
     __syncthreads();
     const int emin = min(min(sm.emin[0], sm.emin[1]), min(sm.emin[2], sm.emin[3]));
+    const int lomax = max(max(sm.wkey[0], sm.wkey[1]), max(sm.wkey[2], sm.wkey[3]));
     const int code0 = sm.code0;
-    bool ok = true;
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) ok = ok && (!has[it] || code[it] - emin <= head[it]);
-    if (__syncthreads_and(ok)) {
+    // every block can be shifted onto emin  <=>  emin >= code - head-room for every block  (one barrier decides)
+    if (emin >= lomax) {
         E = emin == BIG ? code0 : emin;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)

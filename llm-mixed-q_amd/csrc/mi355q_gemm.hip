@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void bfp_align_rows_kernel(const int8_t* __res
             flag[row] = flagged ? 1 : 0;
             rscale[row] = flagged ? __builtin_ldexpf(1.0f, E - exp_offset) : 0.0f;
         }
+        if (row + gridDim.x < rows) __syncthreads();      // (the next row reuses the decision words in LDS)
     }
 }
 

@@ -577,6 +577,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             flag[row] = flagged ? 1 : 0;
             rscale[row] = flagged ? __builtin_ldexpf(1.0f, E - exp_offset) : 0.0f;
         }
+        if (row + gridDim.x < a.rows) __syncthreads();      // (the next row reuses the decision words in LDS)
     }
 }
 
