@@ -439,6 +439,12 @@ __device__ __forceinline__ float mant_f(float x, int up, float mmax) {
     const float sm = __builtin_copysignf(m, t);
     return t == 0.f ? 0.f : sm;
 }
+// The same without the x + 1e-9 == 0 special case, valid when up < 28: there x = -1e-9 gives m = rne(2e-9 * 2^up) = 0
+// anyway, so the sign carrier being zero changes nothing.
+__device__ __forceinline__ float mant_f_small_up(float x, int up, float mmax) {
+    const float m = fminf(__builtin_rintf(__builtin_ldexpf(fabsf(x) + EPS9, up)), mmax);
+    return __builtin_copysignf(m, x + EPS9);
+}
 
 __global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                               uint8_t* __restrict__ flag, float* __restrict__ gscale,
@@ -477,8 +483,10 @@ __global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a,
         const int up = mbits_int - e;
         const float f0 = mant_f(v.x, up, a.mant_max), f1 = mant_f(v.y, up, a.mant_max);
         const float f2 = mant_f(v.z, up, a.mant_max), f3 = mant_f(v.w, up, a.mant_max);
-        // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone)
-        const int amax = nz ? (int)mant_f(bmax, up, a.mant_max) : 0;
+        // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone) -- except that an
+        // element equal to -1e-9 has mantissa 0 whatever the scale (blocks below 2^-23 only: take the formed maximum)
+        int amax = nz ? (int)mant_f(bmax, up, a.mant_max) : 0;
+        if (__any(up >= 28)) amax = (int)group_max<4>(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3))));
         const int code = e + a.code_bias;
         int q[4] = {(int)f0, (int)f1, (int)f2, (int)f3};
         const AlignResult r = align_group(q, amax, code, true, row, g * 16 + (lane >> 2), list, list_cap);
@@ -555,9 +563,19 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             const float bm1 = nz ? bmax : 1.0f;                 // all-zero block: fill 1 (MI355Q_ZERO_BLOCK_FAST)
             const int e = clampi(ceil_log2_frexp(bm1, lut), a.e_min, a.e_max);
             const int up = mbits_int - e;
-            const int q0 = (int)mant_f(v[it].x, up, a.mant_max), q1 = (int)mant_f(v[it].y, up, a.mant_max);
-            const int q2 = (int)mant_f(v[it].z, up, a.mant_max), q3 = (int)mant_f(v[it].w, up, a.mant_max);
-            amax[it] = nz ? (int)mant_f(bmax, up, a.mant_max) : 0;
+            int q0, q1, q2, q3, am;
+            if (__any(up >= 28)) {                                // (blocks below 2^-23: keep the exact zero rule)
+                q0 = (int)mant_f(v[it].x, up, a.mant_max); q1 = (int)mant_f(v[it].y, up, a.mant_max);
+                q2 = (int)mant_f(v[it].z, up, a.mant_max); q3 = (int)mant_f(v[it].w, up, a.mant_max);
+                // (an element equal to -1e-9 has mantissa 0 whatever its magnitude: take the maximum of what was formed)
+                am = (int)group_max<4>((float)max(max(abs(q0), abs(q1)), max(abs(q2), abs(q3))));
+            } else {
+                q0 = (int)mant_f_small_up(v[it].x, up, a.mant_max); q1 = (int)mant_f_small_up(v[it].y, up, a.mant_max);
+                q2 = (int)mant_f_small_up(v[it].z, up, a.mant_max); q3 = (int)mant_f_small_up(v[it].w, up, a.mant_max);
+                // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone)
+                am = (int)fminf(__builtin_rintf(__builtin_ldexpf(bmax + EPS9, up)), a.mant_max);
+            }
+            amax[it] = nz ? am : 0;
             code[it] = e + a.code_bias;
             const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);
             const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);

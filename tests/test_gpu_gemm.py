@@ -443,3 +443,31 @@ def test_row_aligned_gemm_is_reproducible(tile_rows, monkeypatch):
         outs.append(ops.bfp_gemm_aligned(xa, wa, None).clone())
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_fused_quantize_align_rows_tiny_blocks_keep_the_zero_rule():
+    """blocks below 2^-23 with elements equal to -1e-9 (sign(x + 1e-9) = 0 there: block_fp.py:69) and |x| <= 1e-8:
+    the fused kernel's shortcut for normal magnitudes must not change them"""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    r = np.random.default_rng(3)
+    rows, K = 16, 1024                      # (six tiny blocks per row: 96 exception entries fit one bucket)
+    x = (r.normal(size=(rows, K)) * np.exp(r.normal(size=(rows, 1)))).astype(np.float32)
+    eps = np.float32(1e-9)
+    x[:, 0:64] = (r.integers(-40, 40, size=(rows, 64)) * eps).astype(np.float32)      # multiples of 1e-9, incl. -1e-9 and 0
+    x[::2, 64:80] = -eps
+    x[1::2, 80:96] = (r.normal(size=(rows // 2, 16)) * 3e-9).astype(np.float32)
+    assert (x == -eps).any()
+    xt = torch.from_numpy(x).to(dev)
+    for width in (6, 4):                    # (W8 has no head-room: its rows overflow the bucket)
+        _, xm, xe = ops.block_fp_quantize(xt, width, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
+                                          fast_zero_blocks=True)
+        ref = ops.bfp_align_rows(xm, xe, width - 1, 127)
+        got = ops.block_fp_quantize_aligned_rows(xt, width, 8, 127)
+        torch.cuda.synchronize()
+        o1, e1 = ops.row_list_entries(ref.sparse, rows)
+        o2, e2 = ops.row_list_entries(got.sparse, rows)
+        assert o1 == o2 == 0 and set(map(tuple, e1)) == set(map(tuple, e2))
+        assert torch.equal(got.tiled[: rows * K], ref.tiled[: rows * K])
+        assert torch.equal(got.exp, ref.exp.reshape(-1)) and torch.equal(got.gscale[:rows], ref.gscale[:rows])
