@@ -86,7 +86,7 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
     }
 }
 
-template <int FIXMODE_, int TI>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
+template <int FIXMODE_, int TI, bool ONEPHASE = (TI == 4)>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                                                  (lptr_t)(smem + sl * STAGE + dst[q]), 16, 0, 0);
     };
     int slot = 0;
-    if (TI == 8) {
+    if (!ONEPHASE) {
         // A K-step is two phases (A rows 0-63, then 64-127 of the wave tile).  The pieces of step t+2 are requested in
         // phase 1 of step t (two) and phase 0 of step t+1 (two): a stage is re-filled two barriers after its last read,
         // so fragment reads may retire behind the barrier, beside the other group's wait.
@@ -319,34 +319,39 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         if (wm == 0) __builtin_amdgcn_s_barrier();
     } else {
         // One phase per K-step; barriers G(2t) (before the leading group's MFMAs of step t) and G(2t+1) (behind them;
-        // the lagging group is one barrier later).  Step t+3 is requested once every read of step t-1 has retired:
-        // behind G(2t), i.e. after its own MFMAs for the leading group, before them for the lagging one.  Either way a
-        // wave then waits for its pieces of step t+1 (steps t+2 and t+3 stay in flight) before it arrives at G(2t+1),
-        // the barrier the leading group passes before it reads step t+1.
-        int nslot = 3 % NS;
-        if (nsteps > 2) V8_WAIT(2 * LPW); else if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
+        // the lagging group is one barrier later).  Step t+D (D = stages - 1) is requested once every read of step t-1
+        // has retired: behind G(2t), i.e. after its own MFMAs for the leading group, before them for the lagging one.
+        // Either way a wave then waits for its pieces of step t+1 (the later steps stay in flight) before it arrives at
+        // G(2t+1), the barrier the leading group passes before it reads step t+1.
+        constexpr int D = NS - 1;
+        int nslot = D % NS;
+        if (D == 3 && nsteps > 2) V8_WAIT(2 * LPW); else if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();
         auto request_and_wait = [&](int t) {
-            if (t + 3 < nsteps) {
-                dma_pieces(t + 3, nslot, 0, LPW);
+            if (t + D < nsteps) {
+                dma_pieces(t + D, nslot, 0, LPW);
                 nslot = nslot + 1 == NS ? 0 : nslot + 1;
             }
-            if (t + 3 < nsteps) V8_WAIT(2 * LPW); else if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
+            if (D == 3) {
+                if (t + 3 < nsteps) V8_WAIT(2 * LPW); else if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
+            } else {
+                if (t + 2 < nsteps) V8_WAIT(LPW); else V8_WAIT(0);
+            }
         };
         for (int t = 0; t < nsteps; ++t) {
             const unsigned char* sbase = smem + slot * STAGE;
-            i32x4 fa[4], fb[TJ];
+            i32x4 fa[TI], fb[TJ];
 #pragma unroll
             for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sbase + boff[j]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
+            for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sbase + aoff[i]);
             if (wm == 1) request_and_wait(t);
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
