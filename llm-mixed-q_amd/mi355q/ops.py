@@ -249,6 +249,18 @@ def _new_row_list(device, rows):
     return torch.zeros(n, dtype=torch.int32, device=device)
 
 
+ROW_TILE_ENTRIES_FAST = 48      # entries of one tile (x bucket + w bucket) the row-scale GEMM adds back from spare LDS
+
+
+def row_list_fill(lst, rows):
+    """(rows that overflowed their bucket, entries in the fullest bucket) of a row-aligned operand's list (host read)"""
+    nb = (rows + ROW_BUCKET_ROWS - 1) // ROW_BUCKET_ROWS
+    words = 8 + 8 * ROW_BUCKET_CAP
+    head = lst[: 8 + nb * words].detach().cpu()
+    counts = head[8::words][:nb]
+    return int(head[0]), int(counts.max()) if nb else 0
+
+
 def row_list_entries(lst, rows):
     """decode a row-aligned operand's bucketed exception list -> (overflowed rows, [n, 8] int32 entries)"""
     import numpy as np

@@ -124,15 +124,20 @@ class _LinearBase(nn.Linear):
         if self.align == "rows":
             return "rows"
         c = self.config
+        # one-off host reads at pack time: overflow words and the fullest exception bucket of either operand.  Rows pay
+        # off while a 256 x 256 tile's entries (x bucket + w bucket) fit the GEMM's in-LDS add-back.
         wa = ops.bfp_align_rows(wm, we, c["weight_width"] - 1, self._weight_bias_value())
-        if int(wa.sparse[0]) != 0:                 # (one-off host read at pack time)
+        w_over, w_max = ops.row_list_fill(wa.sparse, self.out_features)
+        if w_over != 0:
             return "groups"
+        x_max = 0
         if x_sample is not None:
             xa = ops.block_fp_quantize_aligned_rows(x_sample.reshape(-1, self.in_features), c["data_in_width"],
                                                     c["data_in_exponent_width"], c["data_in_exponent_bias"])
-            if int(xa.sparse[0]) != 0:
+            x_over, x_max = ops.row_list_fill(xa.sparse, xa.rows)
+            if x_over != 0:
                 return "groups"
-        return "rows"
+        return "rows" if w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST else "groups"
 
     def _align_weights(self, wm, we, mode):
         c = self.config
