@@ -583,12 +583,17 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
         }
         int E = 0;
         const bool flagged = align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E);
+        // tiled address of this lane's 4 bytes in slab 0 (block 16 wave + lane / 4: K-step 4 wave + lane / 16, 16-byte
+        // chunk (lane / 4) & 3, swizzled by the row); a slab further on is 16 K-steps = 16 KiB further
+        int8_t* dst = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + (row & 15) * 64 +
+                      ((((lane >> 2) & 3) ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3)) << 4) + (lane & 3) * 4;
+        uint8_t* cdst = a.code + row * nkb + wave * 16 + (lane >> 2);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int kb = it * 64 + wave * 16 + (lane >> 2);
             if (FULL || (it < nit && kb < nkb)) {
-                *reinterpret_cast<unsigned*>(mt + tiled_offset_q(row, (long long)kb * 16 + (lane & 3) * 4, K)) = pk[it];
-                if ((lane & 3) == 0) a.code[row * nkb + kb] = (uint8_t)(flagged ? E : code[it]);
+                *reinterpret_cast<unsigned*>(dst + it * 16384) = pk[it];
+                if ((lane & 3) == 0) cdst[it * 64] = (uint8_t)(flagged ? E : code[it]);
             }
         }
         if (tid == 0) {
