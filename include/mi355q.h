@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 2
+#define MI355Q_ABI_VERSION 3
 #define MI355Q_WORKSPACE_BYTES 256
 
 /* negative error codes (positive values are hipError_t) */
@@ -153,23 +153,27 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
  * scale applied once (no rescale inside the K loop).  Blocks outside the row's exponent window are exceptions,
  * kept in a list with one BUCKET per 256 rows:
  *   rowflag  uint8 [rows];  rowscale fp32 [mi355q_bfp_rows_pad(rows)] = 2^(E - exp_offset), 0 where rowflag is 0
- *   list     int32 [mi355q_bfp_row_list_bytes(rows) / 4]: list[0] = rows whose exceptions did not fit their
+ *   list     int32 [mi355q_bfp_row_list_bytes(rows, cap) / 4]: list[0] = rows whose exceptions did not fit their
  *            bucket (such rows are copied unchanged, rowflag 0; the GEMM then takes its blockwise kernel),
- *            list[1..7] spare; bucket b (rows 256 b ...) at word 8 + b * (8 + 8 * 120): [0] entries reserved,
- *            [1..7] spare, then 120 entries {row (-1 = void), block, biased exponent, 0, 16 mantissa bytes}.
+ *            list[1..7] spare; bucket b (rows 256 b ...) at word 8 + b * (8 + 8 * cap): [0] entries reserved,
+ *            [1..7] spare, then cap entries {row (-1 = void), block, biased exponent, 0, 16 mantissa bytes}.
+ *            `bucket_cap` = cap, 0 = the default 120 (what the GEMM can hold in LDS: required of the WEIGHT operand);
+ *            an ACTIVATION operand may use up to MI355Q_ROW_BUCKET_CAP_MAX -- its exception blocks are then added
+ *            by a row post-pass after the GEMM (see mi355q_bfp_gemm_aligned), which has no per-tile limit.
  * K % 64 == 0, K <= MI355Q_ROW_ALIGN_MAX_K (int32 accumulation cannot overflow; the row is decided by one
  * workgroup that keeps it in registers).  mi355q_block_fp_quantize_aligned_rows is the fused activation form
  * (same contract as mi355q_block_fp_quantize_aligned; `list_to_clear`: the OTHER list of an alternating pair,
  * emptied for the next call). */
 #define MI355Q_ROW_ALIGN_MAX_K 16384
-size_t mi355q_bfp_row_list_bytes(int64_t rows);
+#define MI355Q_ROW_BUCKET_CAP_MAX 1016
+size_t mi355q_bfp_row_list_bytes(int64_t rows, int32_t bucket_cap);
 int mi355q_bfp_align_rows(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_tiled, uint8_t* exp_out,
                           uint8_t* rowflag, float* rowscale, int32_t* list, int32_t exp_offset, int64_t rows,
-                          int64_t K, void* stream);
+                          int64_t K, int32_t bucket_cap, void* stream);
 int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
                                           float* rowscale, int32_t* list, int32_t* list_to_clear, int64_t rows,
                                           int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias,
-                                          void* stream);
+                                          int32_t bucket_cap, void* stream);
 
 /* An aligned operand as one argument */
 typedef struct mi355q_bfp_operand {
@@ -178,7 +182,7 @@ typedef struct mi355q_bfp_operand {
     const uint8_t* rowflag; /* [rows, G] */
     const float* gscale;    /* [G, rows_pad] */
     const int32_t* list;    /* exception list, mi355q_bfp_list_bytes(list_cap) */
-    int32_t list_cap;
+    int32_t list_cap;       /* groups: entries of the list; rows: entries per bucket (0 = 120) */
     int32_t mbits;          /* width - 1 */
     int32_t exp_bias;
     int32_t row_aligned;    /* 0: 256-value groups (mi355q_bfp_align); 1: whole rows (mi355q_bfp_align_rows):
@@ -198,7 +202,11 @@ typedef struct mi355q_bfp_operand {
  * ROW-aligned operands (row_aligned = 1 in both): a short launch multiplies every exception block with the other
  * operand (one fp32 vector of products per exception, in `corr`) -- or, if an exception bucket overflowed, forms the
  * whole product blockwise-exact -- then the row-scale int8 GEMM (256 x 256 tiles) runs and adds the vectors of the
- * rows / columns it stores.  No atomics: results are reproducible.  K % 128 == 0 for the fast kernel. */
+ * rows / columns it stores.  No atomics: results are reproducible.  K % 128 == 0 for the fast kernel.
+ * If x has no `corr` scratch or uses buckets larger than 120 entries, x's exception blocks are instead added by a ROW
+ * POST-PASS after the GEMM (one workgroup per (bucket, 256 columns) owns the y rows it updates: plain read-add-write,
+ * entries taken in (row, block) order -- reproducible too, and without a per-tile limit; meant for post-activation
+ * inputs).  The weight operand always uses the in-LDS vectors (bucket_cap 120, `corr` required). */
 size_t mi355q_bfp_corr_bytes(int64_t rows, int64_t other_rows);
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,

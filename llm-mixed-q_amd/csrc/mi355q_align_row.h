@@ -12,8 +12,9 @@
 //     the overflow word list[0]: the GEMM then takes its blockwise-exact kernel.
 // Exception list of a row-aligned operand (int32 words):
 //   [0] rows that could not store their exceptions (0 = the fast GEMM applies), [1..7] spare,
-//   then one bucket per 256 rows (bucket b covers rows 256 b .. 256 b + 255), ROW_BUCKET_WORDS words each:
-//   [0] entries reserved, [1..7] spare, then ROW_BCAP entries of 8 words
+//   then one bucket per 256 rows (bucket b covers rows 256 b .. 256 b + 255), 8 + 8 * bcap words each
+//   (bcap = the operand's entries per bucket, 120 unless stated):
+//   [0] entries reserved, [1..7] spare, then bcap entries of 8 words
 //   {row (-1 = void), block, exponent, 0, 16 mantissa bytes}  -- the entry layout of mi355q_align.h.
 #ifndef MI355Q_ALIGN_ROW_H
 #define MI355Q_ALIGN_ROW_H
@@ -25,8 +26,13 @@ namespace mi355q {
 constexpr int ROW_BUCKET_ROWS = 256, ROW_BCAP = 120;
 constexpr int ROW_BUCKET_WORDS = EXC_HEADER + EXC_ENTRY * ROW_BCAP;
 
-__host__ __device__ inline long long row_list_words(long long rows) {
-    return EXC_HEADER + ((rows + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS) * ROW_BUCKET_WORDS;
+// ROW_BCAP is the bucket size the row-scale GEMM can take into LDS (weights; activations of the in-LDS add-back).
+// An operand whose exceptions are added by the row post-pass instead (mi355q_gemm_post.hip) may use larger buckets:
+// every function below takes the operand's entries-per-bucket `bcap`.
+constexpr int ROW_BCAP_MAX = 1016;
+__host__ __device__ inline long long row_bucket_words(int bcap) { return EXC_HEADER + (long long)EXC_ENTRY * bcap; }
+__host__ __device__ inline long long row_list_words(long long rows, int bcap = ROW_BCAP) {
+    return EXC_HEADER + ((rows + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS) * row_bucket_words(bcap);
 }
 
 struct RowAlignSmem {
@@ -47,7 +53,8 @@ __device__ __forceinline__ unsigned shl_packed(unsigned pk, int s) {
 // When it returns false nothing was changed.  All 256 threads must call it (workgroup barriers inside).
 template <int MAXIT, bool FULL = false>
 __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&amax)[MAXIT], const int (&code)[MAXIT], int nit,
-                                          int nkb, long long row, int* __restrict__ list, RowAlignSmem& sm, int& E) {
+                                          int nkb, long long row, int* __restrict__ list, RowAlignSmem& sm, int& E,
+                                          int bcap = ROW_BCAP) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int BIG = 1 << 20;
     bool has[MAXIT];
@@ -112,16 +119,16 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
     }
     __syncthreads();
     const int k = sm.nexc;
-    int* bucket = list ? list + EXC_HEADER + (row / ROW_BUCKET_ROWS) * ROW_BUCKET_WORDS : nullptr;
-    if (tid == 0) sm.base = bucket ? atomicAdd(&bucket[0], k) : ROW_BCAP;
+    int* bucket = list ? list + EXC_HEADER + (row / ROW_BUCKET_ROWS) * row_bucket_words(bcap) : nullptr;
+    if (tid == 0) sm.base = bucket ? atomicAdd(&bucket[0], k) : bcap;
     __syncthreads();
     const int base = sm.base;
-    if (base + k > ROW_BCAP) {
+    if (base + k > bcap) {
         if (tid == 0 && list) atomicAdd(&list[0], 1);
         if (bucket) {
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it)
-                if (exc[it] && (lane & 3) == 0 && base + slot[it] < ROW_BCAP)
+                if (exc[it] && (lane & 3) == 0 && base + slot[it] < bcap)
                     bucket[EXC_HEADER + EXC_ENTRY * (base + slot[it])] = -1;
         }
         return false;

@@ -221,25 +221,30 @@ size_t mi355q_bfp_corr_bytes(int64_t rows, int64_t other_rows) {
     return (size_t)((rows + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS) * ROW_BCAP * (size_t)((other_rows + 255) / 256 * 256) * 4 + 1024;
 }
 
-size_t mi355q_bfp_row_list_bytes(int64_t rows) { return rows < 0 ? 0 : (size_t)row_list_words(rows) * 4; }
+static int bucket_cap_of(int32_t cap) { return cap == 0 ? ROW_BCAP : cap; }
+
+size_t mi355q_bfp_row_list_bytes(int64_t rows, int32_t bucket_cap) {
+    if (rows < 0 || bucket_cap < 0 || bucket_cap > ROW_BCAP_MAX) return 0;
+    return (size_t)row_list_words(rows, bucket_cap_of(bucket_cap)) * 4;
+}
 
 int mi355q_bfp_align_rows(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_tiled, uint8_t* exp_out,
                           uint8_t* rowflag, float* rowscale, int32_t* list, int32_t exp_offset, int64_t rows, int64_t K,
-                          void* stream) {
-    if (rows < 0 || K < 0) return MI355Q_E_BADARG;
+                          int32_t bucket_cap, void* stream) {
+    if (rows < 0 || K < 0 || bucket_cap < 0 || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
     if (rows == 0 || K == 0) return 0;
     if (!mant_in || !exp_in || !mant_tiled || !exp_out || !rowflag || !rowscale) return MI355Q_E_BADARG;
     if (K % 64 != 0 || K > MI355Q_ROW_ALIGN_MAX_K) return MI355Q_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(mant_in) | reinterpret_cast<uintptr_t>(mant_tiled)) % 4) return MI355Q_E_ALIGN;
     return launch_bfp_align_rows(mant_in, exp_in, mant_tiled, exp_out, rowflag, rowscale, exp_offset, list, rows, K,
-                                 static_cast<hipStream_t>(stream));
+                                 static_cast<hipStream_t>(stream), bucket_cap_of(bucket_cap));
 }
 
 int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
                                           float* rowscale, int32_t* list, int32_t* list_to_clear, int64_t rows,
                                           int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias,
-                                          void* stream) {
-    if (rows < 0 || K < 0) return MI355Q_E_BADARG;
+                                          int32_t bucket_cap, void* stream) {
+    if (rows < 0 || K < 0 || bucket_cap < 0 || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
     if (rows == 0 || K == 0) return 0;
     if (!x || !mant_tiled || !exp_out || !rowflag || !rowscale || !list || list_to_clear == list) return MI355Q_E_BADARG;
     if (K % 64 != 0 || K > MI355Q_ROW_ALIGN_MAX_K) return MI355Q_E_UNSUPPORTED;
@@ -260,7 +265,7 @@ int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, ui
     a.e_max = (1 << exponent_width) - 1 - exponent_bias;
     set_mantissa(a, width - 1);
     return launch_quant_align_rows(a, mant_tiled, rowflag, rowscale, exponent_bias + width - 1, list, list_to_clear,
-                                   static_cast<hipStream_t>(stream));
+                                   static_cast<hipStream_t>(stream), bucket_cap_of(bucket_cap));
 }
 
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
@@ -272,23 +277,28 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     if (K % 64 != 0) return MI355Q_E_UNSUPPORTED;   // tiled operands; use mi355q_bfp_gemm otherwise
     if (x->mbits < 1 || x->mbits > 7 || w->mbits < 1 || w->mbits > 7) return MI355Q_E_BADARG;
     if (x->row_aligned != w->row_aligned) return MI355Q_E_BADARG;      // both operands in the same alignment flavour
-    if (x->list && w->list && x->list_cap != w->list_cap) return MI355Q_E_BADARG;
+    if (!x->row_aligned && x->list && w->list && x->list_cap != w->list_cap) return MI355Q_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant)) % 16) return MI355Q_E_ALIGN;
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
                x->exp_bias + x->mbits + w->exp_bias + w->mbits, x->row_aligned ? 1 : 0,
                x->exp_bias + x->mbits, w->exp_bias + w->mbits,
-               x->corr, w->corr, (N + 255) / 256 * 256, (M + 255) / 256 * 256};
+               x->corr, w->corr, (N + 255) / 256 * 256, (M + 255) / 256 * 256, ROW_BCAP, ROW_BCAP, 0};
     const int variant = g_gemm_variant.load();
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (x->row_aligned) {
         // ROW-aligned operands: plain int8 GEMM with one scale per row + exception add-back in its epilogue; the
         // second launch only acts when an exception bucket overflowed (then it forms the whole product blockwise)
         if (!x->gscale || !w->gscale) return MI355Q_E_BADARG;
-        const bool fast_ok = x->list && w->list && K % 128 == 0 && K <= MI355Q_ROW_ALIGN_MAX_K;
+        if (x->list_cap < 0 || x->list_cap > ROW_BCAP_MAX || w->list_cap < 0 || w->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
+        a.x_bcap = bucket_cap_of(x->list_cap);
+        a.w_bcap = bucket_cap_of(w->list_cap);
+        // x's exception blocks: in-LDS vectors of the GEMM (needs x->corr and the 120-entry buckets) or the row post-pass
+        a.x_post = (a.x_bcap != ROW_BCAP || !x->corr) ? 1 : 0;
+        const bool fast_ok = x->list && w->list && K % 128 == 0 && K <= MI355Q_ROW_ALIGN_MAX_K && a.w_bcap == ROW_BCAP;
         if (variant == 2 || !fast_ok)
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, 0, 0, st);
         if (variant == 8) return launch_bfp_gemm_v8(a, x->gscale, w->gscale, nullptr, nullptr, 0, st);
-        if (!x->corr || !w->corr) return MI355Q_E_BADARG;
+        if (!w->corr) return MI355Q_E_BADARG;
         // first the short launch: one vector of products per exception block (or, if an exception bucket overflowed,
         // the whole product blockwise-exact -- decided on the device); then the row-scale GEMM, which adds the vectors
         // of the rows / columns it stores (and leaves at once in the overflow case)
@@ -297,6 +307,7 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         hipEvent_t te = g_timing.begin(st);
         rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st);
         g_timing.end(te, st);
+        if (rc == 0 && a.x_post) rc = launch_bfp_gemm_rowpost(a, x->list, w->list, x->gscale, w->gscale, st);
         return rc;
     }
     const long long mpad = mi355q_bfp_rows_pad(M), npad = mi355q_bfp_rows_pad(N);

@@ -24,8 +24,8 @@ __device__ __forceinline__ int list_count(const int* __restrict__ list, int cap)
 }
 
 // exception bucket of a row-aligned operand that covers row r0 (mi355q_align_row.h); same layout as a list
-__device__ __forceinline__ const int* row_bucket(const int* __restrict__ list, long long r0) {
-    return list ? list + EXC_HEADER + (r0 / ROW_BUCKET_ROWS) * ROW_BUCKET_WORDS : nullptr;
+__device__ __forceinline__ const int* row_bucket(const int* __restrict__ list, long long r0, int bcap = ROW_BCAP) {
+    return list ? list + EXC_HEADER + (r0 / ROW_BUCKET_ROWS) * row_bucket_words(bcap) : nullptr;
 }
 
 // One exception entry against rows [q0, q1) of the other operand; `lane_id`/`nlanes` = the threads that share it.
@@ -83,9 +83,9 @@ __device__ __forceinline__ void block_fix_body(const GemmArgs& a, const int* __r
 // path: runs after the tile's own stores, behind a workgroup barrier).
 template <int BM = V2_BM, int BN = V2_BN>
 __device__ __forceinline__ void tile_fix_body(const GemmArgs& a, const int* __restrict__ xlist,
-                                              const int* __restrict__ wlist, int cap, long long m0, long long n0,
-                                              int tid = -1, int nthreads = 0) {
-    const int cx = list_count(xlist, cap), cw = list_count(wlist, cap);
+                                              const int* __restrict__ wlist, int capx, int capw, long long m0,
+                                              long long n0, int tid = -1, int nthreads = 0) {
+    const int cx = list_count(xlist, capx), cw = list_count(wlist, capw);
     if (cx == 0 && cw == 0) return;
     if (tid < 0) { tid = threadIdx.x; nthreads = blockDim.x; }       // default: the whole workgroup is the team
     const int lane = tid & 63;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void bfp_align_rows_kernel(const int8_t* __res
                                                              int8_t* __restrict__ mt, uint8_t* __restrict__ eo,
                                                              uint8_t* __restrict__ flag, float* __restrict__ rscale,
                                                              int exp_offset, int* __restrict__ list, long long rows,
-                                                             long long K) {
+                                                             long long K, int bcap) {
     __shared__ RowAlignSmem rsm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bfp_align_rows_kernel(const int8_t* __res
             amax[it] = am;
         }
         int E = 0;
-        const bool flagged = align_row<MAXIT>(pk, amax, code, nit, nkb, row, list, rsm, E);
+        const bool flagged = align_row<MAXIT>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int kb = it * 64 + wave * 16 + (lane >> 2);
@@ -231,20 +231,20 @@ __global__ __launch_bounds__(256) void bfp_align_rows_kernel(const int8_t* __res
 }
 
 int launch_bfp_align_rows(const int8_t* mi, const uint8_t* ei, int8_t* mt, uint8_t* eo, uint8_t* flag, float* rscale,
-                          int exp_offset, int* list, long long rows, long long K, hipStream_t st) {
+                          int exp_offset, int* list, long long rows, long long K, hipStream_t st, int bcap) {
     long long grid = rows;
     if (grid > 65536) grid = 65536;
     if (grid < 1) grid = 1;
     if (list) {
-        const hipError_t e = hipMemsetAsync(list, 0, (size_t)row_list_words(rows) * 4, st);
+        const hipError_t e = hipMemsetAsync(list, 0, (size_t)row_list_words(rows, bcap) * 4, st);
         if (e != hipSuccess) return (int)e;
     }
     if (K <= 4096)
-        hipLaunchKernelGGL((bfp_align_rows_kernel<4>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K);
+        hipLaunchKernelGGL((bfp_align_rows_kernel<4>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K, bcap);
     else if (K <= 8192)
-        hipLaunchKernelGGL((bfp_align_rows_kernel<8>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K);
+        hipLaunchKernelGGL((bfp_align_rows_kernel<8>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K, bcap);
     else if (K <= 16384)
-        hipLaunchKernelGGL((bfp_align_rows_kernel<16>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K);
+        hipLaunchKernelGGL((bfp_align_rows_kernel<16>), (unsigned)grid, 256, 0, st, mi, ei, mt, eo, flag, rscale, exp_offset, list, rows, K, bcap);
     else
         return MI355Q_E_UNSUPPORTED;
     return (int)hipGetLastError();
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const ui
         v2_tile_origin(a, blockIdx.x, m0, n0);
         __threadfence();
         __syncthreads();
-        if (a.row_mode) tile_fix_body(a, row_bucket(xlist, m0), row_bucket(wlist, n0), ROW_BCAP, m0, n0);
-        else tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
+        if (a.row_mode) tile_fix_body(a, row_bucket(xlist, m0, a.x_bcap), row_bucket(wlist, n0, a.w_bcap), a.x_bcap, a.w_bcap, m0, n0);
+        else tile_fix_body(a, xlist, wlist, list_cap, list_cap, m0, n0);
     }
 }
 

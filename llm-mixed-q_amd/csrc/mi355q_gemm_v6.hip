@@ -199,10 +199,10 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
     int4 first_piece = {0, 0, 0, 0};
     if (a.row_mode && threadIdx.x < ROW_BUCKET_WORDS / 4) {
         const int nbx = (int)((a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS), nbw = (int)((a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS);
-        const int wi = blockIdx.x;
-        if (wi < 2 * nbx * nbw) {
-            const bool is_x = wi < nbx * nbw;
-            const int bb = (is_x ? wi : wi - nbx * nbw) / (is_x ? nbw : nbx);
+        const int wi = blockIdx.x, xitems = a.x_post ? 0 : nbx * nbw;
+        if (wi < xitems + nbx * nbw) {
+            const bool is_x = wi < xitems;
+            const int bb = (is_x ? wi : wi - xitems) / (is_x ? nbw : nbx);
             first_piece = reinterpret_cast<const int4*>(row_bucket(is_x ? xlist : wlist, (long long)bb * ROW_BUCKET_ROWS))[threadIdx.x];
         }
     }
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
             v2_tile_origin(a, tile, m0, n0);
             __threadfence();
             __syncthreads();
-            if (a.row_mode) tile_fix_body(a, row_bucket(xlist, m0), row_bucket(wlist, n0), ROW_BCAP, m0, n0);
-            else tile_fix_body(a, xlist, wlist, list_cap, m0, n0);
+            if (a.row_mode) tile_fix_body(a, row_bucket(xlist, m0, a.x_bcap), row_bucket(wlist, n0, a.w_bcap), a.x_bcap, a.w_bcap, m0, n0);
+            else tile_fix_body(a, xlist, wlist, list_cap, list_cap, m0, n0);
             __syncthreads();
         }
         return;
@@ -235,10 +235,11 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
     int* s_bk = reinterpret_cast<int*>(smem);
     const int nbx = (int)((a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS), nbw = (int)((a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS);
     const int chx = nbw, chw = nbx;                                  // 256-row chunks of the OTHER operand
+    const int xitems = a.x_post ? 0 : nbx * chx;                     // (x's entries wait for the row post-pass)
     const int tid = threadIdx.x;
-    for (int wi = blockIdx.x; wi < nbx * chx + nbw * chw; wi += gridDim.x) {   // (normally one per workgroup)
-        const bool is_x = wi < nbx * chx;
-        const int li = is_x ? wi : wi - nbx * chx, nch = is_x ? chx : chw;
+    for (int wi = blockIdx.x; wi < xitems + nbw * chw; wi += gridDim.x) {      // (normally one per workgroup)
+        const bool is_x = wi < xitems;
+        const int li = is_x ? wi : wi - xitems, nch = is_x ? chx : chw;
         const int bb = li / nch, chunk = li - bb * nch;
         const int* bk = row_bucket(is_x ? xlist : wlist, (long long)bb * ROW_BUCKET_ROWS);
         __syncthreads();
@@ -281,7 +282,8 @@ int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf
     if (tiles > 512) tiles = 512;
     if (a.row_mode) {                                // one workgroup per (bucket, 256 rows of the other operand)
         const long long nbx = (a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS, nbw = (a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS;
-        tiles = (unsigned)(2 * nbx * nbw > 2048 ? 2048 : 2 * nbx * nbw);
+        const long long items = (a.x_post ? 1 : 2) * nbx * nbw;
+        tiles = (unsigned)(items > 2048 ? 2048 : items);
     }
     hipLaunchKernelGGL(bfp_gemm_tail, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap, xscale, wscale);
     return (int)hipGetLastError();

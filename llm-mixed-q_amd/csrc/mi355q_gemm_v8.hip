@@ -128,7 +128,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     // ---- in front of the operand stream (same LDS-DMA queue, so landed by the first counted wait): the tile's
     //      scale slices and its two exception buckets; the bias slice goes through registers (no padding behind it)
     if (wave == 0 || wave == 1) {
-        if (FIXMODE) {
+        if (FIXMODE && !(wave == 0 && a.x_post)) {
             const int* b = wave == 0 ? row_bucket(xlist, m0) : row_bucket(wlist, n0);
             unsigned char* d = smem + (wave == 0 ? V8_XB : V8_WB);
 #pragma unroll
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             V8_WAIT(0);
             return;
         }
-        cx = __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+        cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
         const int n = cx + cw;
         mode = n == 0 ? 0 : (n <= V8_FAST_MAX ? 1 : (n <= V8_SLOW_MAX ? 2 : 3));

@@ -29,7 +29,7 @@ int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
 int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
                        int* list, int list_cap, int* list_to_clear, hipStream_t st);
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
-                            int* list_to_clear, hipStream_t st);
+                            int* list_to_clear, hipStream_t st, int bcap);
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {
@@ -47,12 +47,17 @@ struct GemmArgs {
     float* xcorr;
     float* wcorr;
     long long ldxc, ldwc;
+    // row mode: entries per exception bucket of each operand; x_post = x's entries are added by the row post-pass
+    // (mi355q_gemm_post.hip) instead of the GEMM's in-LDS vectors
+    int x_bcap, w_bcap, x_post;
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
                             const int* wlist, int list_cap, int guard, hipStream_t st);
 int launch_bfp_align_rows(const int8_t* mi, const uint8_t* ei, int8_t* mt, uint8_t* eo, uint8_t* flag, float* rscale,
-                          int exp_offset, int* list, long long rows, long long K, hipStream_t st);
+                          int exp_offset, int* list, long long rows, long long K, hipStream_t st, int bcap);
+int launch_bfp_gemm_rowpost(const GemmArgs& a, const int* xlist, const int* wlist, const float* xscale, const float* wscale,
+                            hipStream_t st);
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st);
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,

@@ -530,7 +530,7 @@ template <int MAXIT, bool FULL>
 __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                                    uint8_t* __restrict__ flag, float* __restrict__ rscale,
                                                                    int exp_offset, int* __restrict__ list,
-                                                                   int* __restrict__ list_to_clear) {
+                                                                   int* __restrict__ list_to_clear, int bcap) {
     __shared__ Lut lut;
     __shared__ RowAlignSmem rsm;
     load_lut<FMT_BFP>(lut);
@@ -538,9 +538,9 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     const long long K = a.cols;
     const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
     if (list_to_clear && blockIdx.x == 0) {
-        const long long words = row_list_words(a.rows);
+        const long long words = row_list_words(a.rows, bcap), bw = row_bucket_words(bcap);
         if (tid < EXC_HEADER) list_to_clear[tid] = 0;
-        for (long long b = EXC_HEADER + (long long)tid * ROW_BUCKET_WORDS; b < words; b += 256ll * ROW_BUCKET_WORDS)
+        for (long long b = EXC_HEADER + (long long)tid * bw; b < words; b += 256ll * bw)
             list_to_clear[b] = 0;
     }
     const int mbits_int = (int)__builtin_log2f(a.shift);
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             pk[it] = lo | hi;
         }
         int E = 0;
-        const bool flagged = align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E);
+        const bool flagged = align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap);
         // tiled address of this lane's 4 bytes in slab 0 (block 16 wave + lane / 4: K-step 4 wave + lane / 16, 16-byte
         // chunk (lane / 4) & 3, swizzled by the row); a slab further on is 16 K-steps = 16 KiB further
         int8_t* dst = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + (row & 15) * 64 +
@@ -605,13 +605,13 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
 }
 
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
-                            int* list_to_clear, hipStream_t st) {
+                            int* list_to_clear, hipStream_t st, int bcap) {
     long long grid = a.rows;
     if (grid > 65536) grid = 65536;
     if (grid < 1) grid = 1;
 #define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
     hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
-                       exp_offset, list, list_to_clear)
+                       exp_offset, list, list_to_clear, bcap)
     if (a.cols == 4096) MI355Q_LAUNCH_ROWS(4, true);            // every lane holds a block in every slab: no guards
     else if (a.cols <= 4096) MI355Q_LAUNCH_ROWS(4, false);
     else if (a.cols == 8192) MI355Q_LAUNCH_ROWS(8, true);

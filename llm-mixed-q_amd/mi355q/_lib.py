@@ -30,11 +30,11 @@ SIGNATURES = {
     "mi355q_bfp_align": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp]),
     "mi355q_block_fp_quantize_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32,
                                                    _i32, _vp]),
-    "mi355q_bfp_row_list_bytes": (C.c_size_t, [_i64]),
+    "mi355q_bfp_row_list_bytes": (C.c_size_t, [_i64, _i32]),
     "mi355q_bfp_corr_bytes": (C.c_size_t, [_i64, _i64]),
-    "mi355q_bfp_align_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp]),
+    "mi355q_bfp_align_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp]),
     "mi355q_block_fp_quantize_aligned_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,
-                                                        _i32, _vp]),
+                                                        _i32, _i32, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_gemm_timing_enable": (C.c_int, [C.c_int]),
     "mi355q_gemm_timing_read": (C.c_int, [_vp, _vp, _vp]),
@@ -48,7 +48,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32), ("corr", _vp)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 WORKSPACE_BYTES = 256
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

@@ -198,16 +198,19 @@ class AlignedOperand:
     exponent-aligned mantissas, effective exponents, per (row, group) flags and fp32 group scales,
     and the list of exception blocks (blocks outside their group's exponent window, kept aside exactly)."""
 
-    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias, row_aligned=False):
+    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias, row_aligned=False,
+                 bucket_cap=None):
         self.rows, self.K = int(rows), int(K)
         self.mant, self.tiled = mant, tiled          # row-major (may be None) / tiled (what the GEMM reads)
         self.exp, self.rowflag, self.gscale, self.sparse = exp, rowflag, gscale, sparse
         self.mbits, self.exp_bias = int(mbits), int(exp_bias)
         self.row_aligned = bool(row_aligned)         # one exponent per ROW (mi355q_bfp_align_rows) instead of per 256 values
+        # entries the list holds: per 256-row bucket (rows) / in all (groups)
+        self.list_cap = int(bucket_cap) if bucket_cap else (ROW_BUCKET_CAP if row_aligned else SPARSE_LIST_CAP)
 
     def c_struct(self, corr=None):
         return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
-                               _ptr(self.sparse), SPARSE_LIST_CAP, self.mbits, self.exp_bias, int(self.row_aligned), _ptr(corr))
+                               _ptr(self.sparse), self.list_cap, self.mbits, self.exp_bias, int(self.row_aligned), _ptr(corr))
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
@@ -236,7 +239,11 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
 
 
 ROW_ALIGN_MAX_K = 16384
-ROW_BUCKET_ROWS, ROW_BUCKET_CAP = 256, 120
+ROW_BUCKET_ROWS, ROW_BUCKET_CAP, ROW_BUCKET_CAP_MAX = 256, 120, 1016
+# exception entries per 256 rows of a fused-quantised ACTIVATION operand.  120: the GEMM adds them from LDS (at most
+# ~96 per tile together with the weights'); larger: the row post-pass adds them after the GEMM, without a tile limit.
+import os as _os
+ACTIVATION_BUCKET_CAP = int(_os.environ.get("MI355Q_X_BUCKET_CAP", ROW_BUCKET_CAP))
 
 
 def row_align_supported(K: int) -> bool:
@@ -244,38 +251,40 @@ def row_align_supported(K: int) -> bool:
     return K % 128 == 0 and 0 < K <= ROW_ALIGN_MAX_K
 
 
-def _new_row_list(device, rows):
-    n = _lib.load_library().mi355q_bfp_row_list_bytes(rows) // 4
+def _new_row_list(device, rows, bucket_cap=0):
+    n = _lib.load_library().mi355q_bfp_row_list_bytes(rows, int(bucket_cap)) // 4
     return torch.zeros(n, dtype=torch.int32, device=device)
 
 
 ROW_TILE_ENTRIES_FAST = 48      # entries of one tile (x bucket + w bucket) the row-scale GEMM adds back from spare LDS
 
 
-def row_list_fill(lst, rows):
+def row_list_fill(lst, rows, bucket_cap=None):
     """(rows that overflowed their bucket, entries in the fullest bucket) of a row-aligned operand's list (host read)"""
     nb = (rows + ROW_BUCKET_ROWS - 1) // ROW_BUCKET_ROWS
-    words = 8 + 8 * ROW_BUCKET_CAP
+    words = 8 + 8 * (bucket_cap or ROW_BUCKET_CAP)
     head = lst[: 8 + nb * words].detach().cpu()
     counts = head[8::words][:nb]
     return int(head[0]), int(counts.max()) if nb else 0
 
 
-def row_list_entries(lst, rows):
+def row_list_entries(lst, rows, bucket_cap=None):
     """decode a row-aligned operand's bucketed exception list -> (overflowed rows, [n, 8] int32 entries)"""
     import numpy as np
     lst = lst.detach().cpu().numpy() if hasattr(lst, "detach") else np.asarray(lst)
-    words = 8 + 8 * ROW_BUCKET_CAP
+    cap = bucket_cap or ROW_BUCKET_CAP
+    words = 8 + 8 * cap
     out = []
     for b in range((rows + ROW_BUCKET_ROWS - 1) // ROW_BUCKET_ROWS):
         bk = lst[8 + b * words: 8 + (b + 1) * words]
-        n = min(int(bk[0]), ROW_BUCKET_CAP)
+        n = min(int(bk[0]), cap)
         ent = bk[8:8 + 8 * n].reshape(n, 8)
         out.append(ent[ent[:, 0] >= 0])
     return int(lst[0]), (np.concatenate(out) if out else np.zeros((0, 8), np.int32))
 
 
-def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, with_list: bool = True) -> AlignedOperand:
+def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, with_list: bool = True,
+                   bucket_cap: int = 0) -> AlignedOperand:
     """Rewrite a packed [rows, K] operand into the ROW-aligned, tiled format (one exponent and one fp32 scale
     per row; include/mi355q.h, mi355q_bfp_align_rows).  K % 64 == 0, K <= ROW_ALIGN_MAX_K."""
     if not mant.is_cuda:
@@ -288,12 +297,14 @@ def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: 
     tiled = torch.zeros(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=mant.device)
     flag = torch.empty(rows, dtype=torch.uint8, device=mant.device)
     rscale = torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=mant.device)
-    sparse = _new_row_list(mant.device, rows) if with_list else None
+    sparse = _new_row_list(mant.device, rows, bucket_cap) if with_list else None
     with torch.cuda.device(mant.device):
         rc = lib.mi355q_bfp_align_rows(_ptr(mant), _ptr(exp), _ptr(tiled), _ptr(eo), _ptr(flag), _ptr(rscale),
-                                       _ptr(sparse), int(exp_bias) + int(mbits), rows, K, _stream_ptr(mant.device))
+                                       _ptr(sparse), int(exp_bias) + int(mbits), rows, K, int(bucket_cap),
+                                       _stream_ptr(mant.device))
     _lib.check(rc, "mi355q_bfp_align_rows")
-    return AlignedOperand(rows, K, None, tiled, eo, flag, rscale, sparse, mbits, exp_bias, row_aligned=True)
+    return AlignedOperand(rows, K, None, tiled, eo, flag, rscale, sparse, mbits, exp_bias, row_aligned=True,
+                          bucket_cap=bucket_cap)
 
 
 class _ActivationBuffers:
@@ -302,8 +313,8 @@ class _ActivationBuffers:
     _cache: dict = {}
 
     @classmethod
-    def get(cls, device, rows, K, row_aligned=False, sp=None):
-        key = (device.index, _stream_ptr(device) if sp is None else sp, rows, K, row_aligned)
+    def get(cls, device, rows, K, row_aligned=False, sp=None, bucket_cap=0):
+        key = (device.index, _stream_ptr(device) if sp is None else sp, rows, K, row_aligned, bucket_cap)
         buf = cls._cache.get(key)
         if buf is None and row_aligned:
             lib = _lib.load_library()
@@ -312,7 +323,7 @@ class _ActivationBuffers:
                 exp=torch.empty(rows * (K // 16), dtype=torch.uint8, device=device),
                 flag=torch.empty(rows, dtype=torch.uint8, device=device),
                 gscale=torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
-                sparse=[_new_row_list(device, rows) for _ in range(2)],
+                sparse=[_new_row_list(device, rows, bucket_cap) for _ in range(2)],
                 calls=0)
             if len(cls._cache) > 64:
                 cls._cache.clear()
@@ -356,16 +367,19 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
                           int(width) - 1, eb)
 
 
-def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: int, exponent_bias) -> AlignedOperand:
+def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: int, exponent_bias,
+                                   bucket_cap: int = None) -> AlignedOperand:
     """Fused activation path, ROW-aligned flavour: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack +
     row-align + tile in one kernel (K % 64 == 0, K <= ROW_ALIGN_MAX_K).  Buffers are reused per shape and
-    stream like block_fp_quantize_aligned's."""
+    stream like block_fp_quantize_aligned's.  `bucket_cap`: exception entries per 256 rows (default
+    ACTIVATION_BUCKET_CAP); anything but 120 makes the GEMM add x's exceptions in its row post-pass."""
+    bucket_cap = ACTIVATION_BUCKET_CAP if bucket_cap is None else int(bucket_cap)
     _require_device(x, "block_fp_quantize_aligned_rows")
     assert x.ndim == 2 and x.shape[1] % 64 == 0 and x.shape[1] <= ROW_ALIGN_MAX_K
     rows, K = x.shape
     xc = x.contiguous()
     sp = _stream_ptr(x.device)
-    buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True, sp=sp)
+    buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True, sp=sp, bucket_cap=bucket_cap)
     bias = _default_bias(exponent_bias)
     lib = _lib.load_library()
     cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
@@ -373,11 +387,11 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     with torch.cuda.device(x.device):
         rc = lib.mi355q_block_fp_quantize_aligned_rows(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
                                                        _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows, K, int(width),
-                                                       int(exponent_width), bias, sp)
+                                                       int(exponent_width), bias, bucket_cap, sp)
     _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows")
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
     return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
-                          int(width) - 1, eb, row_aligned=True)
+                          int(width) - 1, eb, row_aligned=True, bucket_cap=bucket_cap)
 
 
 _CORR_CACHE: dict = {}
@@ -411,6 +425,8 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     cx = cw = None
     if x.row_aligned and w.row_aligned:
         cx, cw = _corr_workspace(x.tiled.device, M, N, sp)
+        if x.list_cap != ROW_BUCKET_CAP:
+            cx = None                    # x's exception blocks go through the row post-pass
     xs, ws = x.c_struct(cx), w.c_struct(cw)
     import ctypes
     with torch.cuda.device(x.tiled.device):

@@ -64,6 +64,7 @@ class _LinearBase(nn.Linear):
         # weights and the first activations fit it, re-checked on a doubling schedule
         self.align = config.get("mi355q_align", "auto")
         self._align_mode, self._canonical, self._calls, self._row_overflows = None, None, 0, 0
+        self._x_cap = ops.ROW_BUCKET_CAP_MAX if self.align == "rows_post" else ops.ACTIVATION_BUCKET_CAP
         if not self.bypass:
             self._setup_quantizers(config)
 
@@ -121,7 +122,7 @@ class _LinearBase(nn.Linear):
     def _choose_align_mode(self, wm, we, x_sample):
         if self.align == "groups" or not ops.row_align_supported(self.in_features):
             return "groups"
-        if self.align == "rows":
+        if self.align in ("rows", "rows_post"):
             return "rows"
         c = self.config
         # one-off host reads at pack time: overflow words and the fullest exception bucket of either operand.  Rows pay
@@ -130,14 +131,19 @@ class _LinearBase(nn.Linear):
         w_over, w_max = ops.row_list_fill(wa.sparse, self.out_features)
         if w_over != 0:
             return "groups"
-        x_max = 0
+        if w_max > ops.ROW_TILE_ENTRIES_FAST:
+            return "groups"
         if x_sample is not None:
+            # activations: the GEMM's in-LDS add-back while a tile's entries fit it, else large buckets + the row
+            # post-pass (no per-tile limit: post-activation inputs); groups only if even those overflow
             xa = ops.block_fp_quantize_aligned_rows(x_sample.reshape(-1, self.in_features), c["data_in_width"],
-                                                    c["data_in_exponent_width"], c["data_in_exponent_bias"])
-            x_over, x_max = ops.row_list_fill(xa.sparse, xa.rows)
+                                                    c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                                    bucket_cap=ops.ROW_BUCKET_CAP_MAX)
+            x_over, x_max = ops.row_list_fill(xa.sparse, xa.rows, xa.list_cap)
             if x_over != 0:
                 return "groups"
-        return "rows" if w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST else "groups"
+            self._x_cap = ops.ROW_BUCKET_CAP if w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST else ops.ROW_BUCKET_CAP_MAX
+        return "rows"
 
     def _align_weights(self, wm, we, mode):
         c = self.config
@@ -182,7 +188,7 @@ class _LinearBase(nn.Linear):
         x2 = x.reshape(-1, self.in_features)
         if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
-                                                    c["data_in_exponent_bias"])
+                                                    c["data_in_exponent_bias"], bucket_cap=self._x_cap)
         elif self.in_features % 256 == 0:    # the same per 256-value group
             xa = ops.block_fp_quantize_aligned(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                c["data_in_exponent_bias"])
@@ -197,9 +203,12 @@ class _LinearBase(nn.Linear):
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats
             self._calls += 1
             if self._calls & (self._calls - 1) == 0 and int(xa.sparse[0]) != 0:
-                self._row_overflows += 1
-                if self._row_overflows >= 2 and self._canonical is not None:
-                    self._align_weights(*self._canonical, "groups")
+                if self._x_cap != ops.ROW_BUCKET_CAP_MAX:
+                    self._x_cap = ops.ROW_BUCKET_CAP_MAX          # first: larger buckets + the row post-pass
+                else:
+                    self._row_overflows += 1
+                    if self._row_overflows >= 2 and self._canonical is not None:
+                        self._align_weights(*self._canonical, "groups")
         return y.reshape(*x.shape[:-1], self.out_features)
 
     @classmethod

@@ -35,7 +35,7 @@ def _inputs(M, N, K, seed, style):
     return x, w, b
 
 
-def _run(x, w, b, cfg, aligned=False):
+def _run(x, w, b, cfg, aligned=False, x_cap=0):
     import torch
     from mi355q import ops
     dev = torch.device("cuda:0")
@@ -49,7 +49,8 @@ def _run(x, w, b, cfg, aligned=False):
         bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), cfg["bias_width"], 8, 127, [16], False)
     if aligned:
         align = ops.bfp_align_rows if aligned == "rows" else ops.bfp_align
-        xa = align(xm, xe, cfg["data_in_width"] - 1, 127)
+        xa = (align(xm, xe, cfg["data_in_width"] - 1, 127, bucket_cap=x_cap) if x_cap
+              else align(xm, xe, cfg["data_in_width"] - 1, 127))
         wa = align(wm, we, cfg["weight_width"] - 1, 127)
         y = ops.bfp_gemm_aligned(xa, wa, bq)
         _run.last_flags = (float(xa.rowflag.float().mean()), float(wa.rowflag.float().mean()))
@@ -267,7 +268,7 @@ def test_fused_quantize_align_equals_two_step(style, width):
 # ---------------------------------------------------------------------------------------------------
 def _row_exceptions(al, rows, nkb):
     from mi355q import ops
-    over, ent = ops.row_list_entries(al.sparse, rows)
+    over, ent = ops.row_list_entries(al.sparse, rows, al.list_cap)
     mant = np.zeros((rows, nkb, 16), np.int64)
     exp = np.zeros((rows, nkb), np.int64)
     mask = np.zeros((rows, nkb), bool)
@@ -331,22 +332,23 @@ def test_row_align_is_value_preserving(width):
                                    (64, 64, 192)])
 @pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
 @pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
-@pytest.mark.parametrize("tile_rows", [256, 128])
-def test_row_aligned_gemm_vs_oracle(M, N, K, style, wx, ww, tile_rows, monkeypatch):
+@pytest.mark.parametrize("tile_rows,x_cap", [(256, 0), (128, 0), (256, 1016), (128, 40)])
+def test_row_aligned_gemm_vs_oracle(M, N, K, style, wx, ww, tile_rows, x_cap, monkeypatch):
     """row-scale int8 GEMM + exception add-back in its epilogue; overflowing buckets (outlier data, W8) and
     K % 128 != 0 take the blockwise kernel"""
     from oracle import np_oracle as O
     monkeypatch.setenv("MI355Q_V8_TILE_ROWS", str(tile_rows))      # both workgroup-tile flavours of the row-scale kernel
     x, w, b = _inputs(M, N, K, 3000 + M + N + K, style)
     cfg = _cfg(wx, ww)
-    y = _run(x, w, b, cfg, aligned="rows")
+    y = _run(x, w, b, cfg, aligned="rows", x_cap=x_cap)       # x_cap != 0: x's exceptions through the row post-pass
     ref = O.bfp_linear_int(x, w, b, cfg)
     scale = np.abs(ref).max() + 1e-30
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
 
 
-@pytest.mark.parametrize("variant,tile_rows", [(0, 256), (0, 128), (2, 0)])
-def test_row_aligned_gemm_exceptions_of_both_operands_share_blocks(variant, tile_rows, monkeypatch):
+@pytest.mark.parametrize("variant,tile_rows,x_cap", [(0, 256, 0), (0, 128, 0), (2, 0, 0), (0, 256, 1016), (0, 128, 504),
+                                                     (2, 0, 1016)])
+def test_row_aligned_gemm_exceptions_of_both_operands_share_blocks(variant, tile_rows, x_cap, monkeypatch):
     from mi355q import ops
     monkeypatch.setenv("MI355Q_V8_TILE_ROWS", str(tile_rows))
     from oracle import np_oracle as O
@@ -358,12 +360,52 @@ def test_row_aligned_gemm_exceptions_of_both_operands_share_blocks(variant, tile
     cfg = _cfg(6, 6)
     prev = ops.set_gemm_variant(variant)
     try:
-        y = _run(x, w, b, cfg, aligned="rows")
+        y = _run(x, w, b, cfg, aligned="rows", x_cap=x_cap)
     finally:
         ops.set_gemm_variant(prev)
     assert _run.last_counts == (0, 0) and _run.last_flags == (1.0, 1.0)        # no bucket overflowed
     ref = O.bfp_linear_int(x, w, b, cfg)
     np.testing.assert_allclose(y, ref, rtol=0, atol=6e-6 * np.abs(ref).max())
+
+
+def test_row_post_pass_takes_what_the_tile_cannot():
+    """post-activation input (half zeros, block maxima spread over many exponents): ~2 exception blocks per row, far
+    beyond what a GEMM tile adds from LDS; with 1016-entry buckets nothing overflows and the row post-pass adds
+    them -- exact against the oracle, bit-identical between runs and re-quantisations"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    r = np.random.default_rng(5)
+    M, N, K = 600, 200, 3072
+    x = np.maximum(r.normal(size=(M, K)), 0).astype(np.float32) * np.exp(r.normal(size=(M, 1))).astype(np.float32)
+    x[:, ::7] *= np.float32(0.01)
+    w = (r.normal(size=(N, K)) * 0.02).astype(np.float32)
+    w[::9, 512:528] *= 300.0                    # weight exceptions, some in blocks where x has one too
+    b = r.normal(size=N).astype(np.float32)
+    cfg = _cfg(6, 6)
+    y = _run(x, w, b, cfg, aligned="rows", x_cap=1016)
+    assert _run.last_counts == (0, 0) and _run.last_flags == (1.0, 1.0)
+    ref = O.bfp_linear_int(x, w, b, cfg)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * np.abs(ref).max() * (K // 256))
+    dev = torch.device("cuda:0")
+    xt = torch.from_numpy(x).to(dev)
+    _, wm, we = ops.block_fp_quantize(torch.from_numpy(w).to(dev), 6, 8, 127, [1, 16], False, want_fake=False,
+                                      want_packed=True, fast_zero_blocks=True)
+    wa = ops.bfp_align_rows(wm, we, 5, 127)
+    bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), 6, 8, 127, [16], False)
+    outs = []
+    for _ in range(3):
+        xa = ops.block_fp_quantize_aligned_rows(xt, 6, 8, 127, bucket_cap=1016)
+        outs.append(ops.bfp_gemm_aligned(xa, wa, bq).clone())
+    torch.cuda.synchronize()
+    over, fullest = ops.row_list_fill(xa.sparse, M, 1016)
+    assert over == 0 and fullest > 200, fullest
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref, rtol=0, atol=2e-6 * np.abs(ref).max() * (K // 256))
+    # the same input with the default buckets overflows them: blockwise fallback, same values within rounding
+    y2 = _run(x, w, b, cfg, aligned="rows")
+    assert _run.last_counts[0] > 0
+    np.testing.assert_allclose(y2, ref, rtol=0, atol=2e-6 * np.abs(ref).max() * (K // 256))
 
 
 def test_row_aligned_gemm_bucket_overflow_takes_the_fallback():

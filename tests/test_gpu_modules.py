@@ -74,11 +74,12 @@ def test_linear_int8_path_vs_oracle(wx, ww, has_bias):
         assert np.array_equal(lin.bias.detach().cpu().numpy(), bq)
 
 
-@pytest.mark.parametrize("align", ["auto", "rows", "groups"])
+@pytest.mark.parametrize("align", ["auto", "rows", "rows_post", "groups"])
 @pytest.mark.parametrize("outliers", [False, True])
 def test_linear_int8_align_modes(align, outliers):
     """the exponent-alignment flavour of the packed operands is an implementation knob: every choice gives the
-    oracle's result; "auto" takes whole rows when weights and first activations fit them"""
+    oracle's result; "auto" takes whole rows when weights and first activations fit them, with the activations'
+    exceptions in the GEMM's LDS add-back while a tile's share fits it and through the row post-pass otherwise"""
     import torch
     import mi355q.quantize as Q
     from oracle import np_oracle as O
@@ -97,8 +98,12 @@ def test_linear_int8_align_modes(align, outliers):
         y = lin(x.to("cuda:0"))
         ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(3, 100, 192)
         np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
-    want = {"rows": "rows", "groups": "groups", "auto": "groups" if outliers else "rows"}[align]
-    assert lin._align_mode == want           # 300 rows x 1 exception overflow the 120-entry bucket of rows 0..255
+    want = {"rows": "rows", "rows_post": "rows", "groups": "groups", "auto": "rows"}[align]
+    assert lin._align_mode == want
+    if align == "auto":                      # 300 rows x 1 exception: too many for a tile's LDS add-back -> post-pass
+        assert lin._x_cap == (1016 if outliers else 120)
+    if align == "rows_post":
+        assert lin._x_cap == 1016
 
 
 def test_linear_auto_align_leaves_row_mode_when_activations_stop_fitting():
@@ -116,11 +121,19 @@ def test_linear_auto_align_leaves_row_mode_when_activations_stop_fitting():
     calm = torch.randn(300, 256)
     wild = calm.clone()
     wild[:, 32:36] *= 500.0
+    wilder = calm.clone()
+    for c0 in (32, 80, 128, 176, 224):       # five far-off blocks per row: 1280 entries in rows 0..255 > 1016
+        wilder[:, c0:c0 + 4] *= 500.0
     lin(calm.to("cuda:0"))
-    assert lin._align_mode == "rows"
-    for call in range(4):                    # overflow seen at calls 2 and 4 of the doubling schedule -> groups
+    assert lin._align_mode == "rows" and lin._x_cap == 120
+    for call in range(3):                    # overflow of the 120-entry bucket seen at call 2 -> large buckets + post-pass
         y = lin(wild.to("cuda:0"))
         ref = O.bfp_linear_int(wild.numpy(), w0, None, cfg)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+    assert lin._align_mode == "rows" and lin._x_cap == 1016
+    for call in range(12):                   # overflow of those seen at calls 8 and 16 of the doubling schedule -> groups
+        y = lin(wilder.to("cuda:0"))
+        ref = O.bfp_linear_int(wilder.numpy(), w0, None, cfg)
         np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
     assert lin._align_mode == "groups"
     y = lin(calm.to("cuda:0"))
