@@ -81,6 +81,16 @@ def cpu_baseline(torch):
             "sample": f"full 4096x4096x4096 steady-state PTQ linear (fake-quant x + fp32 F.linear), median of {iters} iterations"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (counters cannot be read inside a
+    timed run: one counter per rocprofv3 pass, tools/cdriver/step_driver runs the same step through the C ABI)"""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +168,7 @@ def main():
 
     if rank == 0:
         achieved = flops_step / (gemm_avg_ms * 1e-3) / 1e12
+        traffic = pmc_traffic("mi355q::bfp_gemm_v8<1, 8, false>") if rows_mode and (M, N, K) == (4096, 4096, 4096) else None
         out = {
             "metric": "quantised-GEMM TFLOP/s (4096^2, block=16, W6A6 BFP)",
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +183,9 @@ def main():
                        "gemm_variant": ops.set_gemm_variant(args.variant)},
             "roofline": {"bound": "mfma", "kernel": "bfp_gemm_v8 (row-scale int8 GEMM)" if rows_mode else "bfp_gemm_v6 (int32-chain block GEMM)", "achieved": round(achieved, 2),
                          "peak": INT8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / INT8_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / INT8_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over "
+                                         "tools/cdriver/step_driver; profiles/r01_pmc_traffic.json)" if traffic else None,
                          "avg_launch_ms": round(gemm_avg_ms, 4), "min_launch_ms": round(gemm_min_ms, 4), "launches_timed": n_timed},
         }
         if not args.no_cpu_baseline and world == 1:
