@@ -212,6 +212,19 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);
 
+/* ---- block_fp quantised batched matmul ------------------------------------------------------------
+ * replaces: quantized_functions/matmul.py:146-196 (generic_matmul_block_fp behind matmul_block_fp / bmm_block_fp,
+ *           :300-353) for operands flattened to 3-D:  out[b] = Qx(x[b]) @ Qy(y[b]),
+ *   x fp32 [B, M, K] quantised in [1,16] blocks along K (data_in_* parameters), y fp32 [B, K, N] in [1,16] blocks along
+ *   N (weight_* parameters), out fp32 [B, M, N]; all contiguous.  x is read once and quantised in registers on its way
+ *   into bf16 MFMAs (exact: widths <= 9); y is quantised into `workspace` (mi355q_bfp_matmul_workspace_bytes) first.
+ *   fp32 accumulation.  K % 16 == 0, N % 16 == 0, widths <= 9, B <= 65535, else MI355Q_E_UNSUPPORTED (callers then
+ *   use mi355q_block_fp_quantize on both operands + their own GEMM). */
+size_t mi355q_bfp_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N);
+int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
+                      int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
+                      int32_t y_exponent_width, int32_t y_exponent_bias, void* stream);
+
 /* Kernel timing for benchmarks: when enabled, mi355q_bfp_gemm_aligned brackets its MAIN kernel (the
  * int32-chain GEMM, not the correction / fallback launches) with HIP events on the launch stream.
  * mi355q_gemm_timing_read synchronises the recorded events, returns their count and average / minimum

@@ -328,6 +328,39 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     return launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
 }
 
+size_t mi355q_bfp_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N) {
+    if (B <= 0 || K <= 0 || N <= 0) return 0;
+    return (size_t)B * (size_t)((K + 63) / 64 * 64) * (size_t)N * 2 + 64;
+}
+
+int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
+                      int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
+                      int32_t y_exponent_width, int32_t y_exponent_bias, void* stream) {
+    if (B < 0 || M < 0 || K < 0 || N < 0) return MI355Q_E_BADARG;
+    if (B == 0 || M == 0 || N == 0) return 0;
+    if (!out || B > 65535) return MI355Q_E_BADARG;
+    if (K == 0) return (int)hipMemsetAsync(out, 0, (size_t)B * M * N * 4, static_cast<hipStream_t>(stream));
+    if (!x || !y || !workspace) return MI355Q_E_BADARG;
+    if (x_exponent_width < 1 || x_exponent_width > 8 || y_exponent_width < 1 || y_exponent_width > 8) return MI355Q_E_BADARG;
+    if (x_width < 2 || y_width < 2) return MI355Q_E_BADARG;
+    // blocks of 16 along K (x) and N (y) must tile the operands; a quantised value must fit bf16's 8 significant bits
+    if (K % 16 != 0 || N % 16 != 0 || x_width > 9 || y_width > 9) return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(workspace)) % 16)
+        return MI355Q_E_ALIGN;
+    QuantArgs ax{}, ay{};
+    auto fill = [](QuantArgs& a, int width, int ew, int bias) {
+        if (bias < 0) bias = (1 << (ew - 1)) - 1;
+        a.b0 = 1; a.b1 = 16;
+        a.code_bias = bias;
+        a.e_min = -bias;
+        a.e_max = (1 << ew) - 1 - bias;
+        set_mantissa(a, width - 1);
+    };
+    fill(ax, x_width, x_exponent_width, x_exponent_bias);
+    fill(ay, y_width, y_exponent_width, y_exponent_bias);
+    return launch_bfp_qmatmul(ax, ay, x, y, out, workspace, B, M, K, N, static_cast<hipStream_t>(stream));
+}
+
 int mi355q_gemm_timing_enable(int enable) {
     const int prev = g_timing.enabled ? 1 : 0;
     g_timing.enabled = enable != 0;

@@ -1,0 +1,250 @@
+// mi355q_matmul.hip -- block_fp quantised batched matmul  out[b] = Qx(x[b]) @ Qy(y[b])  (reference
+// quantized_functions/matmul.py:146-196: x quantised along its last dim = the contraction, y along ITS last dim = the
+// output columns, then torch.matmul / torch.bmm on the fake-quantised fp32 tensors).
+//
+// The large operand is x (attention probabilities [heads, T, T], 4 B per element): the reference writes its
+// fake-quantised copy and reads it again for the product.  Here it is read ONCE:
+//   kernel 1 (small operand)  y fp32 [B, K, N] -> fake-quantise along N ([1,16] blocks) -> yt bf16 [B, N, K up to 64]
+//                             (transposed: contraction-contiguous, what an MFMA B fragment holds);
+//   kernel 2                  one workgroup per 16 rows of x: every lane loads 16 consecutive floats of its row (one whole
+//                             [1,16] block: block maxima need no cross-lane step), quantises them in registers --
+//                             the same device arithmetic as the streaming quantiser, bit for bit -- truncates the
+//                             results to bf16 (exact: a block_fp value of width <= 9 has <= 8 significant bits) and
+//                             feeds v_mfma_f32_16x16x32_bf16 against yt fragments read straight from L2/L1.
+// The K index inside a 64-step is permuted (lane group g owns k = 16 g .. 16 g + 15, MFMA t takes 8 t .. 8 t + 7 of
+// them); A and B use the same permutation, so the sum is the same.  Products of two such values are exact in fp32;
+// accumulation is fp32 like the reference's GEMM (order differs: tolerance of the matmul tests, 1e-3).
+// All-zero blocks quantise to zeros whatever their exponent (block_fp.py:54-58 only changes the stored code).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi355q.h"
+#include "mi355q_internal.h"
+#include "mi355q_quant_dev.h"
+
+namespace mi355q {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int MM_NCHUNK = 64;            // output columns per accumulator set (4 MFMA tiles)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {       // two exact-in-bf16 floats -> one dword
+    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+}
+
+// position of contraction index k (inside its 64-group) in yt and in the MFMA operands: lane group g of kernel 2 holds
+// elements 4 g .. 4 g + 3 of each of the four [1,16] blocks (so that one load instruction reads 64 contiguous bytes of
+// every row); MFMA t takes blocks 2 t and 2 t + 1.  k = 16 (2 t + h) + 4 g + e  ->  32 t + 8 g + 4 h + e.
+__host__ __device__ constexpr int mm_kperm(int k) {
+    return ((k >> 5) & 1) * 32 + ((k >> 2) & 3) * 8 + ((k >> 4) & 1) * 4 + (k & 3);
+}
+
+// ---- kernel 1: y [B, K, N] fp32 -> fake-quantise along N -> yt [B, N, K] bf16 ------------------------------------
+__global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a, const float* __restrict__ y,
+                                                               uint16_t* __restrict__ yt, long long K, long long Kp, long long N) {
+    __shared__ Lut lut;
+    __shared__ uint16_t tile[64][64 + 8];                 // [n][k], row padded against bank conflicts
+    load_lut<FMT_BFP>(lut);
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.z, k0 = (long long)blockIdx.y * 64, n0 = (long long)blockIdx.x * 64;
+    const int n4 = tid & 15, kr = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long k = k0 + kr + 16 * i, n = n0 + n4 * 4;
+        const bool ok = k < K && n < N;                   // (N % 16 == 0: a float4 is inside or outside as a whole)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(y + (b * K + k) * N + n);
+        float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        bmax = group_max<4>(bmax);                        // 4 adjacent lanes = one [1,16] block along N
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bmax != 0.f) {
+            unsigned code;
+            const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
+            int mant;
+            q[0] = quant_elem<FMT_BFP>(v.x, bp, a, lut, mant);
+            q[1] = quant_elem<FMT_BFP>(v.y, bp, a, lut, mant);
+            q[2] = quant_elem<FMT_BFP>(v.z, bp, a, lut, mant);
+            q[3] = quant_elem<FMT_BFP>(v.w, bp, a, lut, mant);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[n4 * 4 + j][mm_kperm(kr + 16 * i)] = (uint16_t)(__float_as_uint(q[j]) >> 16);
+    }
+    __syncthreads();
+    // 64 rows (n) x 64 k: thread writes 16 bytes (8 k) of one row
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = tid + 256 * i, n = slot >> 3, k8 = (slot & 7) * 8;
+        if (n0 + n < N)                                   // (whole 64-groups: zeros behind K)
+            *reinterpret_cast<uint4*>(yt + (b * N + n0 + n) * Kp + k0 + k8) = *reinterpret_cast<const uint4*>(&tile[n][k8]);
+    }
+}
+
+// ---- kernel 2 -----------------------------------------------------------------------------------------------------
+// Workgroup = 16 rows of x, 4 waves.  A wave step covers 64 contraction elements = four [1,16] blocks of each row: lane
+// (r = lane % 16, g = lane / 16) loads float4 number g of every block (one load instruction = 64 contiguous bytes of
+// each of the 16 rows), block maxima are completed across the four lane groups with two shuffles, every lane quantises
+// its 16 values; MFMA t takes the lane's values of blocks 2 t and 2 t + 1 (mm_kperm).  The roles of the MFMA operands
+// are swapped (yt fragment as A, x fragment as B) so that a lane ends up with FOUR CONSECUTIVE columns of one output
+// row: 16-byte stores.  Long contractions (probs x V) are SPLIT over the waves (each streams a quarter of K; partial
+// tiles are summed through LDS in wave order); short ones (Q x K^T) keep the quantised row block in registers and
+// split the column chunks instead.
+struct XBlk { float4 v[4]; };
+
+__device__ __forceinline__ void load_xblk(XBlk& s, const float* __restrict__ row, long long k0, int g, long long K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)                           // (K % 16 == 0: a block is inside or outside as a whole)
+        s.v[i] = (k0 + 16 * i < K) ? *reinterpret_cast<const float4*>(row + k0 + 16 * i + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a, const Lut& lut, bf16x8 (&afr)[2]) {
+    float q[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = s.v[i];
+        float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 16));         // the block's other three float4s live in lanes ^16, ^32, ^48
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
+        if (bmax != 0.f) {
+            unsigned code;
+            const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
+            int mant;
+            q[4 * i + 0] = quant_elem<FMT_BFP>(v.x, bp, a, lut, mant);
+            q[4 * i + 1] = quant_elem<FMT_BFP>(v.y, bp, a, lut, mant);
+            q[4 * i + 2] = quant_elem<FMT_BFP>(v.z, bp, a, lut, mant);
+            q[4 * i + 3] = quant_elem<FMT_BFP>(v.w, bp, a, lut, mant);
+        } else {
+            q[4 * i + 0] = q[4 * i + 1] = q[4 * i + 2] = q[4 * i + 3] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        uint4 p;
+        p.x = pack_bf16(q[8 * t + 0], q[8 * t + 1]);
+        p.y = pack_bf16(q[8 * t + 2], q[8 * t + 3]);
+        p.z = pack_bf16(q[8 * t + 4], q[8 * t + 5]);
+        p.w = pack_bf16(q[8 * t + 6], q[8 * t + 7]);
+        afr[t] = __builtin_bit_cast(bf16x8, p);
+    }
+}
+
+// acc[tile] += Y(step, columns n0 + 16 tile ...) * X(step)^T: acc[tile][i] = out[row lane % 16][column 4 (lane / 16) + i]
+// yt fragments straight from L1 / L2; k0 = first contraction index of the step
+// AHEAD tiles' fragments are requested together (4: all up front; 1: just in time, for the register-lean streaming kernel
+// whose 6 waves per SIMD hide the L1 / L2 latency instead)
+template <int AHEAD, int NT>
+__device__ __forceinline__ void mma_step(const bf16x8 (&afr)[2], const uint16_t* __restrict__ ytb, long long n0, long long k0,
+                                         long long K, long long N, int lane, f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += AHEAD) {
+        uint4 bv[AHEAD][2];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const long long n = min(n0 + 16 * (t0 + u) + (lane & 15), N - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)                   // (positions inside a 64-group are permuted: the group is whole in yt)
+                bv[u][t] = *reinterpret_cast<const uint4*>(ytb + n * K + k0 + 32 * t + 8 * (lane >> 4));
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            if (n0 + 16 * (t0 + u) >= N) break;           // (uniform; N % 16 == 0)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv[u][t]), afr[t], acc[t0 + u], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__ outb, long long m0, long long n, long long M,
+                                           long long N, int lane) {
+    const long long m = m0 + (lane & 15);
+    if (m < M) *reinterpret_cast<float4*>(outb + m * N + n + 4 * (lane >> 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+constexpr int MM_RESIDENT_STEPS = 3;     // contraction steps (of 64) whose quantised x stays in registers
+
+// (two instantiations: the short-contraction one keeps quantised x in registers, the streaming one stays lean)
+template <bool RESIDENT, int NT>
+__global__ __launch_bounds__(256, RESIDENT ? 4 : 6) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
+                                                          const uint16_t* __restrict__ yt, float* __restrict__ out,
+                                                          long long M, long long K, long long Kp, long long N) {
+    __shared__ Lut lut;
+    __shared__ f32x4 red[4][NT][64];                      // [wave][tile][lane]: split-K partial tiles
+    load_lut<FMT_BFP>(lut);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const long long b = blockIdx.y, m0 = (long long)blockIdx.x * 16;
+    const long long mrow = min(m0 + (lane & 15), M - 1);                 // (rows past M: loaded again, never stored)
+    const float* __restrict__ row = x + (b * M + mrow) * K;
+    const uint16_t* __restrict__ ytb = yt + b * N * Kp;
+    float* __restrict__ outb = out + b * M * N;
+    const long long nsteps = Kp / 64;
+    bf16x8 afr[2];
+    if (RESIDENT) {                      // short contraction (Q K^T): quantise the row block once, waves share the columns
+        bf16x8 res[MM_RESIDENT_STEPS][2];
+#pragma unroll
+        for (int st = 0; st < MM_RESIDENT_STEPS; ++st) {
+            XBlk s;
+            load_xblk(s, row, st < nsteps ? st * 64 : K, g, K);
+            quantise_xblk(s, a, lut, res[st]);
+        }
+        for (long long n0 = (long long)wave * MM_NCHUNK; n0 < N; n0 += 4 * MM_NCHUNK) {
+            f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int st = 0; st < MM_RESIDENT_STEPS; ++st)
+                if (st < nsteps) mma_step<4, 4>(res[st], ytb, n0, st * 64, Kp, N, lane, acc);
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile)
+                if (n0 + 16 * tile < N) store_tile(acc[tile], outb, m0, n0 + 16 * tile, M, N, lane);
+        }
+        return;
+    }
+    // long contraction: wave w streams steps w, w + 4, w + 8, ... of every column chunk (the four waves read adjacent
+    // 256-byte pieces of each row: 1 KiB runs per row and DRAM page while they move in step)
+    for (long long n0 = 0; n0 < N; n0 += 16 * NT) {                     // (probs x V: one chunk, x streamed once)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int tile = 0; tile < NT; ++tile) acc[tile] = f32x4{0, 0, 0, 0};
+        XBlk cur, nxt;
+        if (wave < nsteps) load_xblk(cur, row, (long long)wave * 64, g, K);
+        for (long long st = wave; st < nsteps; st += 4) {
+            if (st + 4 < nsteps) load_xblk(nxt, row, (st + 4) * 64, g, K);   // next step's x in flight under this one's work
+            quantise_xblk(cur, a, lut, afr);
+            mma_step<1, NT>(afr, ytb, n0, st * 64, Kp, N, lane, acc);
+            cur = nxt;
+        }
+        __syncthreads();                                   // (previous chunk's partials have been read)
+#pragma unroll
+        for (int tile = 0; tile < NT; ++tile) red[wave][tile][lane] = acc[tile];
+        __syncthreads();
+#pragma unroll
+        for (int tile = wave; tile < NT; tile += 4) {      // wave w sums tiles w, w + 4 of the four partials, in wave order
+            if (n0 + 16 * tile >= N) break;
+            f32x4 sum = red[0][tile][lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 p = red[w][tile][lane];
+                sum += p;
+            }
+            store_tile(sum, outb, m0, n0 + 16 * tile, M, N, lane);
+        }
+    }
+}
+
+int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
+                       long long B, long long M, long long K, long long N, hipStream_t st) {
+    dim3 g1((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)B);
+    const long long Kp = (K + 63) / 64 * 64;               // yt rows hold whole 64-groups (permuted inside, zero-padded)
+    hipLaunchKernelGGL(bfp_quant_pack_t_kernel, g1, 256, 0, st, ay, y, static_cast<uint16_t*>(yt), K, Kp, N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    dim3 g2((unsigned)((M + 15) / 16), (unsigned)B);
+    if (Kp / 64 <= MM_RESIDENT_STEPS)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    else    // (64 columns per pass over x; 128 per pass -- NT = 8 -- measured no faster at head_dim 128: the yt fragments
+            // every 16-row workgroup pulls through L1, 2 bytes per byte of x and 64 columns, bound this kernel)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mi355q

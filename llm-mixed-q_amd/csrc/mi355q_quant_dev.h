@@ -1,0 +1,158 @@
+// mi355q_quant_dev.h -- device-side arithmetic of the block quantisers, shared by the streaming kernels
+// (mi355q_quant.hip) and the fused quantise + matmul kernels (mi355q_matmul.hip): threshold tables for exact
+// ceil / floor / rint of log2, the block parameter and the per-element fake-quantisation of each format.
+#ifndef MI355Q_QUANT_DEV_H
+#define MI355Q_QUANT_DEV_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi355q.h"
+#include "mi355q_internal.h"
+
+#define MI355Q_TABLE_QUAL static __device__ const
+#include "log2_tables.inc"
+
+namespace mi355q {
+
+constexpr int FMT_BFP = 0, FMT_BM = 1, FMT_BL = 2;
+constexpr int LUT_N = MI355Q_LOG2_TABLE_SIZE;
+constexpr float EPS9 = 1e-9f;
+constexpr float ATOL = 1e-8f;
+
+// workspace words
+constexpr int WS_ZERO_FLAG = 0;   // kernel 1 met an all-zero block
+constexpr int WS_MINBITS_INV = 1; // max over non-zero blocks of ~bits(block max)
+constexpr int WS_BARRIER = 2;     // fix-up kernel grid barrier / exit ticket
+constexpr int WS_TIMEOUT = 3;     // a bounded spin gave up (reported by the next call)
+
+struct Lut {
+    unsigned a[LUT_N];  // bfp: ceil ; bm: floor ; bl: ceil
+    unsigned lo[LUT_N]; // bl: rnd_lo
+    unsigned hi[LUT_N]; // bl: rnd_hi
+};
+
+template <int FMT>
+__device__ __forceinline__ void load_lut(Lut& lut) {
+    for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
+        lut.a[i] = (FMT == FMT_BM) ? mi355q_log2_floor_thr[i] : mi355q_log2_ceil_thr[i];
+        if (FMT == FMT_BL) {
+            lut.lo[i] = mi355q_log2_rnd_lo[i];
+            lut.hi[i] = mi355q_log2_rnd_hi[i];
+        }
+    }
+    __syncthreads();
+}
+
+// v > 0 (finite or +inf): v = 2^k (1 + m 2^-23); subnormals normalised, inf -> k = 128, m = 0.
+__device__ __forceinline__ void split_pos(float v, int& k, unsigned& m) {
+    const unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
+    const unsigned E = b >> 23, M = b & 0x7FFFFFu;
+    if (E == 0u) {
+        const int p = 31 - __clz((int)(M | 1u));
+        k = p - 149;
+        m = (M << (23 - p)) & 0x7FFFFFu;
+    } else {
+        k = (int)E - 127;
+        m = (E == 255u) ? 0u : M;
+    }
+}
+__device__ __forceinline__ int lut_index(int k) {
+    const int i = k + MI355Q_LOG2_K_OFFSET;
+    return i > LUT_N - 1 ? LUT_N - 1 : i;
+}
+__device__ __forceinline__ int ceil_log2(float v, const Lut& lut) {
+    int k; unsigned m;
+    split_pos(v, k, m);
+    return k + ((m != 0u && m >= lut.a[lut_index(k)]) ? 1 : 0);
+}
+__device__ __forceinline__ int floor_log2(float v, const Lut& lut) {
+    int k; unsigned m;
+    split_pos(v, k, m);
+    return k + ((k < 128 && m >= lut.a[lut_index(k)]) ? 1 : 0);
+}
+__device__ __forceinline__ int rint_log2(float v, const Lut& lut) {
+    int k; unsigned m;
+    split_pos(v, k, m);
+    if (k >= 128) return 128;
+    const int i = lut_index(k);
+    const int even = k + (k & 1);
+    return m < lut.lo[i] ? k : (m > lut.hi[i] ? k + 1 : even);
+}
+__device__ __forceinline__ float sgn(float t) { return t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+struct BlockParam {
+    int p;      // bfp: shared exponent e ; bm / bl: shared bias
+    float eps;  // bl: 0.1 * 2^-bias
+};
+
+// block max (> 0) -> block parameter and its stored byte
+template <int FMT>
+__device__ __forceinline__ BlockParam block_param(float bmax, const QuantArgs& a, const Lut& lut, unsigned& code) {
+    BlockParam bp;
+    bp.eps = 0.f;
+    if (FMT == FMT_BFP) {           // block_fp.py:72-73
+        bp.p = clampi(ceil_log2(bmax, lut), a.e_min, a.e_max);
+        code = (unsigned)(bp.p + a.code_bias);
+    } else if (FMT == FMT_BM) {     // block_minifloat.py:57-59
+        bp.p = clampi(floor_log2(bmax, lut), 0, a.bias_max);
+        code = (unsigned)bp.p;
+    } else {                        // block_log.py:55-58, log.py:45-48
+        bp.p = clampi(a.span - ceil_log2(bmax, lut), 0, a.bias_max);
+        bp.eps = __builtin_ldexpf(0.1f, -bp.p);
+        code = (unsigned)bp.p;
+    }
+    return bp;
+}
+
+// one element: returns the fake-quantised value, `mant` = signed integer mantissa (bfp only)
+template <int FMT>
+__device__ __forceinline__ float quant_elem(float x, const BlockParam& bp, const QuantArgs& a, const Lut& lut, int& mant) {
+    const float ax = fabsf(x);
+    if (FMT == FMT_BFP) {           // block_fp.py:69-82, 93-94
+        const float s = sgn(x + EPS9);
+        const float v = ax + EPS9;
+        const float r = __builtin_ldexpf(v, -bp.p) * a.shift;
+        const float m = clampf(__builtin_rintf(r), 0.f, a.mant_max);
+        mant = (int)(s * m);
+        const float q = __builtin_ldexpf(s, bp.p) * (m * a.inv_shift);
+        return ax <= ATOL ? x : q;
+    } else if (FMT == FMT_BM) {     // minifloat.py:165-194 with exponent_bias = bp.p
+        const float s = sgn(x + EPS9);
+        const int e_min = -bp.p, e_max = a.span - bp.p;
+        const int e = clampi(floor_log2(ax + EPS9, lut), e_min, e_max);
+        const float mn = __builtin_ldexpf(ax, -e);
+        const bool normal = e != e_min;
+        const float sm = normal ? clampf(__builtin_rintf(mn * a.shift - a.shift), 0.f, a.mant_max)
+                                : clampf(__builtin_rintf(mn * a.shift * 0.5f), 0.f, a.mant_max);
+        const float frac = normal ? (1.0f + sm * a.inv_shift) : (sm * a.inv_shift * 2.0f);
+        const float q = __builtin_ldexpf(s, e) * frac;
+        mant = 0;
+        return ax <= ATOL ? x : q;
+    } else {                        // log.py:47-56 with exponent_bias = bp.p
+        const float s = sgn(x + bp.eps);
+        const float v = ax + bp.eps;
+        const int e_min = -bp.p, e_max = a.span - bp.p;
+        const int r = v > 0.f ? rint_log2(v, lut) : e_min;
+        mant = 0;
+        return __builtin_ldexpf(s, clampi(r, e_min, e_max));
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// abs-max over the LPB adjacent lanes that hold one block
+template <int LPB>
+__device__ __forceinline__ float group_max(float v) {
+    if (LPB >= 2) v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+    if (LPB >= 4) v = fmaxf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int off = 4; off < LPB; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+}  // namespace mi355q
+#endif

@@ -436,6 +436,43 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     return out
 
 
+_MATMUL_WS: dict = {}
+
+
+def bfp_matmul_supported(x: torch.Tensor, y: torch.Tensor, x_width: int, y_width: int) -> bool:
+    """shapes / widths the fused quantise + matmul kernel takes (include/mi355q.h, mi355q_bfp_matmul)"""
+    return (x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.ndim == 3
+            and y.ndim == 3 and x.shape[0] == y.shape[0] and x.shape[2] == y.shape[1] and x.shape[0] <= 65535
+            and x.shape[2] % 16 == 0 and y.shape[2] % 16 == 0 and x.shape[2] > 0 and 2 <= int(x_width) <= 9
+            and 2 <= int(y_width) <= 9)
+
+
+def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width: int, x_exponent_bias, y_width: int,
+               y_exponent_width: int, y_exponent_bias) -> torch.Tensor:
+    """out[b] = Qx(x[b]) @ Qy(y[b]) for x [B, M, K], y [B, K, N] fp32: block_fp [1,16] blocks along each operand's last
+    dim (reference matmul.py:146-196), x quantised on its way into the MFMAs (one pass over x, no fake-quantised copy)"""
+    _require_device(x, "bfp_matmul")
+    assert bfp_matmul_supported(x, y, x_width, y_width)
+    B, M, K = x.shape
+    N = y.shape[2]
+    xc, yc = x.contiguous(), y.contiguous()
+    out = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
+    lib = _lib.load_library()
+    sp = _stream_ptr(x.device)
+    key = (x.device.index, sp, B, K, N)
+    ws = _MATMUL_WS.get(key)
+    if ws is None:
+        if len(_MATMUL_WS) > 16:
+            _MATMUL_WS.clear()
+        ws = _MATMUL_WS[key] = torch.empty(lib.mi355q_bfp_matmul_workspace_bytes(B, K, N), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_bfp_matmul(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), B, M, K, N, int(x_width), int(x_exponent_width),
+                                   _default_bias(x_exponent_bias), int(y_width), int(y_exponent_width),
+                                   _default_bias(y_exponent_bias), sp)
+    _lib.check(rc, "mi355q_bfp_matmul")
+    return out
+
+
 def set_gemm_variant(variant: int) -> int:
     return _lib.load_library().mi355q_bfp_gemm_set_variant(int(variant))
 

@@ -37,6 +37,31 @@ def _quantise_operand(t, arith, config, prefix):
     return torch.reshape(q(flat, **kw, skip_first_dim=many), t.shape)
 
 
+def _fused_block_fp_matmul(x, y, config, style):
+    """one pass over x: quantise inside the product kernel (ops.bfp_matmul) where shapes, block sizes and widths
+    allow; None -> the caller takes the two-quantisers + GEMM route.  Autograd (QAT) stays on that route too."""
+    from .. import quantizers as _q                                   # noqa: F401  (registry import order)
+    from ... import ops
+    if not (x.is_cuda and y.is_cuda) or x.dtype != torch.float32 or y.dtype != torch.float32:
+        return None
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        return None
+    if x.ndim != y.ndim or x.ndim < 2 or x.shape[:-2] != y.shape[:-2] or x.shape[-1] != y.shape[-2]:
+        return None                                                   # (broadcasting products: general route)
+    x3 = x.reshape(-1, *x.shape[-2:]) if x.ndim != 3 else x
+    y3 = y.reshape(-1, *y.shape[-2:]) if y.ndim != 3 else y
+    many = x.ndim > 2
+    for t, prefix in ((x3, "data_in"), (y3, "weight")):
+        shape = t.shape if many else t.shape[-2:]
+        if ops.resolve_blocking(list(shape), config[f"{prefix}_block_size"], many)[3:] != (1, 16):
+            return None
+    if not ops.bfp_matmul_supported(x3, y3, config["data_in_width"], config["weight_width"]):
+        return None
+    out = ops.bfp_matmul(x3, y3, config["data_in_width"], config["data_in_exponent_width"], config["data_in_exponent_bias"],
+                         config["weight_width"], config["weight_exponent_width"], config["weight_exponent_bias"])
+    return out.reshape(*x.shape[:-1], y.shape[-1])
+
+
 def _generic_matmul(x, y, config, arith, style):
     mm = _MATMUL[style]
     if config.get("bypass", False):
@@ -44,6 +69,10 @@ def _generic_matmul(x, y, config, arith, style):
     # read y's keys first-to-last like the reference does (KeyError parity) even where unused
     for k in _KEYS[arith]:
         config[f"data_in_{k}"], config[f"weight_{k}"]
+    if arith == "block_fp" and config.get("mi355q_fused_matmul", True):
+        out = _fused_block_fp_matmul(x, y, config, style)
+        if out is not None:
+            return out
     xq = _quantise_operand(x, arith, config, "data_in")
     yq = y if arith == "block_log" else _quantise_operand(y, arith, config, "weight")
     return mm(xq, yq)

@@ -226,3 +226,60 @@ def test_rope_integer_quantised_tables():
     qn = q.cpu().numpy()
     rot = np.concatenate((-qn[..., hd // 2:], qn[..., : hd // 2]), -1)
     np.testing.assert_allclose(qe.cpu().numpy(), qn * cq + rot * sq, rtol=1e-6, atol=1e-6)
+
+
+def _mm_cfg(wx, wy, fused=True):
+    return dict(name="block_fp", bypass=False, data_in_width=wx, data_in_exponent_width=8, data_in_exponent_bias=127,
+                data_in_block_size=[1, 16], weight_width=wy, weight_exponent_width=8, weight_exponent_bias=127,
+                weight_block_size=[1, 16], mi355q_fused_matmul=fused)
+
+
+@pytest.mark.parametrize("shape", [((3, 100, 256), (3, 256, 64)),      # probs x V: long contraction, head_dim columns
+                                   ((3, 100, 64), (3, 64, 272)),       # Q x K^T: one K step, many column chunks
+                                   ((2, 33, 48), (2, 48, 16)),         # K % 128 != 0, ragged rows
+                                   ((1, 16, 400), (1, 400, 80)),       # several steps + a partial one, partial chunk
+                                   ((2, 2, 5, 128), (2, 2, 128, 32)),  # 4-D operands (flattened leading dims)
+                                   ((40, 144), (144, 48))])            # 2-D operands
+@pytest.mark.parametrize("wx,wy", [(6, 6), (4, 8), (8, 4)])
+def test_fused_block_fp_matmul_vs_oracle_and_two_step(shape, wx, wy):
+    """quantise-in-registers + bf16 MFMA product (mi355q_bfp_matmul) against the oracle's restatement of
+    matmul.py:146-196 and against the two-quantisers + GEMM route of the same registry function"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    r = np.random.default_rng(sum(shape[0]) + wx)
+    x = (r.normal(size=shape[0]) * np.exp(r.normal(size=shape[0][:-1] + (1,)))).astype(np.float32)
+    y = r.normal(size=shape[1]).astype(np.float32)
+    x[..., :16] = 0.0                                   # all-zero blocks
+    x.reshape(-1)[5] = 3e-9                             # |x| <= 1e-8 passes through unquantised
+    if x.ndim == 3:
+        x[0] = np.maximum(x[0], 0)                      # softmax-like: many exact zeros
+    style = "matmul" if x.ndim != 3 else "bmm"
+    fused = Q.get_quantized_func(style, _mm_cfg(wx, wy))(_t(x), _t(y), _mm_cfg(wx, wy))
+    plain = Q.get_quantized_func(style, _mm_cfg(wx, wy, False))(_t(x), _t(y), _mm_cfg(wx, wy, False))
+    ref = O.matmul_quantized(x, y, _mm_cfg(wx, wy))
+    scale = np.abs(ref).max() + 1e-30
+    assert fused.shape == plain.shape == ref.shape
+    np.testing.assert_allclose(fused.cpu().numpy(), ref, rtol=0, atol=2e-6 * scale * max(1, shape[0][-1] // 64))
+    np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=0, atol=2e-6 * scale * max(1, shape[0][-1] // 64))
+
+
+def test_fused_block_fp_matmul_falls_back_where_it_does_not_apply():
+    """odd sizes, broadcasting, wide mantissas and autograd keep the two-quantisers route (same results as before)"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q.quantize import quantized_functions as F_
+    from oracle import np_oracle as O
+    r = np.random.default_rng(9)
+    for xs, ys, wx in (((2, 7, 24), (2, 24, 10), 6), ((3, 8, 32), (3, 32, 16), 12)):
+        x, y = r.normal(size=xs).astype(np.float32), r.normal(size=ys).astype(np.float32)
+        cfg = _mm_cfg(wx, 6)
+        assert F_._fused_block_fp_matmul(_t(x), _t(y), cfg, "bmm") is None
+        out = Q.get_quantized_func("bmm", cfg)(_t(x), _t(y), cfg)
+        ref = O.matmul_quantized(x, y, cfg)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * np.abs(ref).max())
+    xg = _t(r.normal(size=(2, 16, 32)).astype(np.float32)).requires_grad_(True)
+    yg = _t(r.normal(size=(2, 32, 16)).astype(np.float32))
+    assert F_._fused_block_fp_matmul(xg, yg, _mm_cfg(6, 6), "bmm") is None
+    Q.get_quantized_func("bmm", _mm_cfg(6, 6))(xg, yg, _mm_cfg(6, 6)).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()

@@ -71,6 +71,16 @@ def test_aligned_operand_entry_points_validate_without_a_gpu():
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 48, 4, None) == E_UNSUPPORTED
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 0, 4, 128, 4, None) == 0
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 2, None) == E_BADARG       # ldy < N
+    # fused quantise + matmul: blocks of 16 must tile K and N, widths must fit bf16, pointers
+    assert lib.mi355q_bfp_matmul_workspace_bytes(12, 2048, 64) == 12 * 2048 * 64 * 2 + 64 and lib.mi355q_bfp_matmul_workspace_bytes(1, 80, 16) == 128 * 16 * 2 + 64 and lib.mi355q_bfp_matmul_workspace_bytes(0, 4, 4) == 0
+    mm = lambda *a: lib.mi355q_bfp_matmul(*a)
+    assert mm(p, p, p, p, 2, 8, 24, 16, 6, 8, 127, 6, 8, 127, None) == E_UNSUPPORTED      # K % 16
+    assert mm(p, p, p, p, 2, 8, 32, 10, 6, 8, 127, 6, 8, 127, None) == E_UNSUPPORTED      # N % 16
+    assert mm(p, p, p, p, 2, 8, 32, 16, 12, 8, 127, 6, 8, 127, None) == E_UNSUPPORTED     # width > 9
+    assert mm(p, p, p, None, 2, 8, 32, 16, 6, 8, 127, 6, 8, 127, None) == E_BADARG        # workspace
+    assert mm(p, p, p, p, 2, 8, 32, 16, 6, 9, 127, 6, 8, 127, None) == E_BADARG           # exponent width
+    assert mm(p, p + 4, p, p, 2, 8, 32, 16, 6, 8, 127, 6, 8, 127, None) == E_ALIGN
+    assert mm(p, p, p, p, 0, 8, 32, 16, 6, 8, 127, 6, 8, 127, None) == 0
 
 
 def test_registry_keys_match_reference():
