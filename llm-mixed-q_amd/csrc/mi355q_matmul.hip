@@ -91,10 +91,19 @@ __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a
 // split the column chunks instead.
 struct XBlk { float4 v[4]; };
 
+// (loads are UNCONDITIONAL -- a block behind K is read from the row's first block and zeroed afterwards: a load inside a
+// branch makes the compiler's vmcnt bookkeeping drain everything in flight, the prefetch included)
 __device__ __forceinline__ void load_xblk(XBlk& s, const float* __restrict__ row, long long k0, int g, long long K) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)                           // (K % 16 == 0: a block is inside or outside as a whole)
-        s.v[i] = (k0 + 16 * i < K) ? *reinterpret_cast<const float4*>(row + k0 + 16 * i + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) {                         // (K % 16 == 0: a block is inside or outside as a whole)
+        const long long k = k0 + 16 * i;
+        s.v[i] = *reinterpret_cast<const float4*>(row + (k < K ? k : 0) + 4 * g);
+    }
+}
+__device__ __forceinline__ void mask_xblk(XBlk& s, long long k0, long long K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (k0 + 16 * i >= K) s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a, const Lut& lut, bf16x8 (&afr)[2]) {
@@ -128,30 +137,30 @@ __device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a,
     }
 }
 
-// acc[tile] += Y(step, columns n0 + 16 tile ...) * X(step)^T: acc[tile][i] = out[row lane % 16][column 4 (lane / 16) + i]
-// yt fragments straight from L1 / L2; k0 = first contraction index of the step
-// AHEAD tiles' fragments are requested together (4: all up front; 1: just in time, for the register-lean streaming kernel
-// whose 6 waves per SIMD hide the L1 / L2 latency instead)
-template <int AHEAD, int NT>
-__device__ __forceinline__ void mma_step(const bf16x8 (&afr)[2], const uint16_t* __restrict__ ytb, long long n0, long long k0,
-                                         long long K, long long N, int lane, f32x4 (&acc)[NT]) {
+// yt fragments of one step for NT column tiles (straight from L1 / L2; positions inside a 64-group are permuted and the
+// group is whole in yt), and their use: acc[tile] += Y(step, columns n0 + 16 tile ...) * X(step)^T, i.e.
+// acc[tile][i] = out[row lane % 16][column 4 (lane / 16) + i].  Requested BEFORE the next step's x: vmcnt counts in
+// order, so fragments requested behind the x prefetch could only be consumed once that whole HBM round trip is back.
+template <int NT> struct BFrag { uint4 v[NT][2]; };
+template <int NT>
+__device__ __forceinline__ void load_bfrag(BFrag<NT>& bf, const uint16_t* __restrict__ ytb, long long n0, long long k0, long long K,
+                                           long long N, int lane) {
 #pragma unroll
-    for (int t0 = 0; t0 < NT; t0 += AHEAD) {
-        uint4 bv[AHEAD][2];
+    for (int tile = 0; tile < NT; ++tile) {
+        const long long n = min(n0 + 16 * tile + (lane & 15), N - 1);
 #pragma unroll
-        for (int u = 0; u < AHEAD; ++u) {
-            const long long n = min(n0 + 16 * (t0 + u) + (lane & 15), N - 1);
+        for (int t = 0; t < 2; ++t)
+            bf.v[tile][t] = *reinterpret_cast<const uint4*>(ytb + n * K + k0 + 32 * t + 8 * (lane >> 4));
+    }
+}
+template <int NT>
+__device__ __forceinline__ void mma_step(const bf16x8 (&afr)[2], const BFrag<NT>& bf, long long n0, long long N, f32x4 (&acc)[NT]) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)                   // (positions inside a 64-group are permuted: the group is whole in yt)
-                bv[u][t] = *reinterpret_cast<const uint4*>(ytb + n * K + k0 + 32 * t + 8 * (lane >> 4));
-        }
+    for (int tile = 0; tile < NT; ++tile) {
+        if (n0 + 16 * tile >= N) break;                   // (uniform; N % 16 == 0)
 #pragma unroll
-        for (int u = 0; u < AHEAD; ++u) {
-            if (n0 + 16 * (t0 + u) >= N) break;           // (uniform; N % 16 == 0)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv[u][t]), afr[t], acc[t0 + u], 0, 0, 0);
-        }
+        for (int t = 0; t < 2; ++t)
+            acc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf.v[tile][t]), afr[t], acc[tile], 0, 0, 0);
     }
 }
 
@@ -165,7 +174,7 @@ constexpr int MM_RESIDENT_STEPS = 3;     // contraction steps (of 64) whose quan
 
 // (two instantiations: the short-contraction one keeps quantised x in registers, the streaming one stays lean)
 template <bool RESIDENT, int NT>
-__global__ __launch_bounds__(256, RESIDENT ? 4 : 6) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
                                                           const uint16_t* __restrict__ yt, float* __restrict__ out,
                                                           long long M, long long K, long long Kp, long long N) {
     __shared__ Lut lut;
@@ -186,13 +195,19 @@ __global__ __launch_bounds__(256, RESIDENT ? 4 : 6) void bfp_qmatmul_kernel(cons
         for (int st = 0; st < MM_RESIDENT_STEPS; ++st) {
             XBlk s;
             load_xblk(s, row, st < nsteps ? st * 64 : K, g, K);
+            mask_xblk(s, st < nsteps ? st * 64 : K, K);
             quantise_xblk(s, a, lut, res[st]);
         }
         for (long long n0 = (long long)wave * MM_NCHUNK; n0 < N; n0 += 4 * MM_NCHUNK) {
             f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-            for (int st = 0; st < MM_RESIDENT_STEPS; ++st)
-                if (st < nsteps) mma_step<4, 4>(res[st], ytb, n0, st * 64, Kp, N, lane, acc);
+            for (int st = 0; st < MM_RESIDENT_STEPS; ++st) {
+                if (st < nsteps) {
+                    BFrag<4> bf;
+                    load_bfrag<4>(bf, ytb, n0, st * 64, Kp, N, lane);
+                    mma_step<4>(res[st], bf, n0, N, acc);
+                }
+            }
 #pragma unroll
             for (int tile = 0; tile < 4; ++tile)
                 if (n0 + 16 * tile < N) store_tile(acc[tile], outb, m0, n0 + 16 * tile, M, N, lane);
@@ -206,11 +221,14 @@ __global__ __launch_bounds__(256, RESIDENT ? 4 : 6) void bfp_qmatmul_kernel(cons
 #pragma unroll
         for (int tile = 0; tile < NT; ++tile) acc[tile] = f32x4{0, 0, 0, 0};
         XBlk cur, nxt;
-        if (wave < nsteps) load_xblk(cur, row, (long long)wave * 64, g, K);
+        load_xblk(cur, row, (long long)wave * 64, g, K);
         for (long long st = wave; st < nsteps; st += 4) {
-            if (st + 4 < nsteps) load_xblk(nxt, row, (st + 4) * 64, g, K);   // next step's x in flight under this one's work
+            BFrag<NT> bf;
+            load_bfrag<NT>(bf, ytb, n0, st * 64, Kp, N, lane);
+            load_xblk(nxt, row, (st + 4) * 64, g, K);      // next step's x in flight under this one's work (behind K: a re-read)
+            mask_xblk(cur, st * 64, K);
             quantise_xblk(cur, a, lut, afr);
-            mma_step<1, NT>(afr, ytb, n0, st * 64, Kp, N, lane, acc);
+            mma_step<NT>(afr, bf, n0, N, acc);
             cur = nxt;
         }
         __syncthreads();                                   // (previous chunk's partials have been read)
