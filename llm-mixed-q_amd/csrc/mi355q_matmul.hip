@@ -72,11 +72,15 @@ __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a
     }
     __syncthreads();
     // 64 rows (n) x 64 k: thread writes 16 bytes (8 k) of one row
+    // FRAGMENT ORDER: the 16 bytes lane (c, g) of kernel 2 takes for (16-column tile, 64-step, MFMA t) lie at lane * 16
+    // inside a 1-KiB piece, pieces ordered [tile][step][t]: a wave's fragment load is one contiguous KiB (8 cache lines
+    // instead of 16 half lines -- the fragment loads are L1-access bound).  Kp = number of 64-steps here.
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int slot = tid + 256 * i, n = slot >> 3, k8 = (slot & 7) * 8;
-        if (n0 + n < N)                                   // (whole 64-groups: zeros behind K)
-            *reinterpret_cast<uint4*>(yt + (b * N + n0 + n) * Kp + k0 + k8) = *reinterpret_cast<const uint4*>(&tile[n][k8]);
+        const int slot = tid + 256 * i, ntl = slot >> 7, t = (slot >> 6) & 1, ln = slot & 63;
+        if (n0 + 16 * ntl < N)                            // (whole 64-groups: zeros behind K)
+            *reinterpret_cast<uint4*>(yt + ((((b * (N >> 4) + (n0 >> 4) + ntl) * Kp + blockIdx.y) * 2 + t) * 64 + ln) * 8) =
+                *reinterpret_cast<const uint4*>(&tile[16 * ntl + (ln & 15)][32 * t + 8 * (ln >> 4)]);
     }
 }
 
@@ -106,34 +110,54 @@ __device__ __forceinline__ void mask_xblk(XBlk& s, long long k0, long long K) {
         if (k0 + 16 * i >= K) s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-__device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a, const Lut& lut, bf16x8 (&afr)[2]) {
-    float q[16];
+// One block_fp element given its block's exponent p, in 8 VALU operations instead of quant_elem's 14, with the same
+// result for every input (mi355q_quant_dev.h, block_fp.py:69-94):
+//   * sign(x + 1e-9) is only used where |x| > 1e-8 (smaller |x| pass through as x), and there it is the sign of x;
+//   * ldexp(v, -p) * 2^mb = ldexp(v, mb - p): where the first product would round (a subnormal intermediate), both are
+//     far below 0.5 and round to mantissa 0;  rint of a positive number needs no lower clamp;
+//   * sign * 2^p * (m * 2^-mb) = copysign(ldexp(m, p - mb), x): m 2^(p - mb) is a multiple of 2^-149 and below 2^128,
+//     so both forms are exact.
+__device__ __forceinline__ float quant_elem_fused(float x, int up, int down, float mant_max) {
+    const float m = fminf(__builtin_rintf(__builtin_ldexpf(fabsf(x) + EPS9, up)), mant_max);
+    const float q = __builtin_copysignf(__builtin_ldexpf(m, down), x);
+    return fabsf(x) <= ATOL ? x : q;
+}
+
+// quantise the wave's step: lane (r, g) holds float4 g of blocks 0..3 of row r.  The shared exponent of block i is
+// worked out by lane group i only (threshold lookup and clamp once per block, not four times) and fetched by the others.
+__device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a, const Lut& lut, int mbits, int lane,
+                                              bf16x8 (&afr)[2]) {
+    const int g = lane >> 4;
+    float bm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 v = s.v[i];
         float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         bmax = fmaxf(bmax, __shfl_xor(bmax, 16));         // the block's other three float4s live in lanes ^16, ^32, ^48
-        bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
-        if (bmax != 0.f) {
-            unsigned code;
-            const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
-            int mant;
-            q[4 * i + 0] = quant_elem<FMT_BFP>(v.x, bp, a, lut, mant);
-            q[4 * i + 1] = quant_elem<FMT_BFP>(v.y, bp, a, lut, mant);
-            q[4 * i + 2] = quant_elem<FMT_BFP>(v.z, bp, a, lut, mant);
-            q[4 * i + 3] = quant_elem<FMT_BFP>(v.w, bp, a, lut, mant);
-        } else {
-            q[4 * i + 0] = q[4 * i + 1] = q[4 * i + 2] = q[4 * i + 3] = 0.f;
-        }
+        bm[i] = fmaxf(bmax, __shfl_xor(bmax, 32));
+    }
+    const float mine = g == 0 ? bm[0] : (g == 1 ? bm[1] : (g == 2 ? bm[2] : bm[3]));
+    unsigned code;
+    const int pmine = block_param<FMT_BFP>(mine, a, lut, code).p;         // (an all-zero block: any exponent, see below)
+    float q[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = __shfl(pmine, (lane & 15) + 16 * i);
+        const float4 v = s.v[i];
+        // (elements of an all-zero block are <= 1e-8 and pass through as zeros)
+        q[4 * i + 0] = quant_elem_fused(v.x, mbits - p, p - mbits, a.mant_max);
+        q[4 * i + 1] = quant_elem_fused(v.y, mbits - p, p - mbits, a.mant_max);
+        q[4 * i + 2] = quant_elem_fused(v.z, mbits - p, p - mbits, a.mant_max);
+        q[4 * i + 3] = quant_elem_fused(v.w, mbits - p, p - mbits, a.mant_max);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        uint4 p;
-        p.x = pack_bf16(q[8 * t + 0], q[8 * t + 1]);
-        p.y = pack_bf16(q[8 * t + 2], q[8 * t + 3]);
-        p.z = pack_bf16(q[8 * t + 4], q[8 * t + 5]);
-        p.w = pack_bf16(q[8 * t + 6], q[8 * t + 7]);
-        afr[t] = __builtin_bit_cast(bf16x8, p);
+        uint4 pk;
+        pk.x = pack_bf16(q[8 * t + 0], q[8 * t + 1]);
+        pk.y = pack_bf16(q[8 * t + 2], q[8 * t + 3]);
+        pk.z = pack_bf16(q[8 * t + 4], q[8 * t + 5]);
+        pk.w = pack_bf16(q[8 * t + 6], q[8 * t + 7]);
+        afr[t] = __builtin_bit_cast(bf16x8, pk);
     }
 }
 
@@ -147,10 +171,10 @@ __device__ __forceinline__ void load_bfrag(BFrag<NT>& bf, const uint16_t* __rest
                                            long long N, int lane) {
 #pragma unroll
     for (int tile = 0; tile < NT; ++tile) {
-        const long long n = min(n0 + 16 * tile + (lane & 15), N - 1);
+        const long long nt = min((n0 >> 4) + tile, (N >> 4) - 1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            bf.v[tile][t] = *reinterpret_cast<const uint4*>(ytb + n * K + k0 + 32 * t + 8 * (lane >> 4));
+        for (int t = 0; t < 2; ++t)                       // (K = number of 64-steps; k0 = 64 * step)
+            bf.v[tile][t] = *reinterpret_cast<const uint4*>(ytb + (((nt * K + (k0 >> 6)) * 2 + t) * 64 + lane) * 8);
     }
 }
 template <int NT>
@@ -174,7 +198,7 @@ constexpr int MM_RESIDENT_STEPS = 3;     // contraction steps (of 64) whose quan
 
 // (two instantiations: the short-contraction one keeps quantised x in registers, the streaming one stays lean)
 template <bool RESIDENT, int NT>
-__global__ __launch_bounds__(256, 4) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
                                                           const uint16_t* __restrict__ yt, float* __restrict__ out,
                                                           long long M, long long K, long long Kp, long long N) {
     __shared__ Lut lut;
@@ -185,9 +209,10 @@ __global__ __launch_bounds__(256, 4) void bfp_qmatmul_kernel(const QuantArgs a, 
     const long long b = blockIdx.y, m0 = (long long)blockIdx.x * 16;
     const long long mrow = min(m0 + (lane & 15), M - 1);                 // (rows past M: loaded again, never stored)
     const float* __restrict__ row = x + (b * M + mrow) * K;
-    const uint16_t* __restrict__ ytb = yt + b * N * Kp;
+    const uint16_t* __restrict__ ytb = yt + b * (N >> 4) * Kp * 1024;   // (Kp = 64-steps per row of tiles)
     float* __restrict__ outb = out + b * M * N;
-    const long long nsteps = Kp / 64;
+    const long long nsteps = (K + 63) / 64;                // (= Kp: yt is stored in fragment order)
+    const int mbits = (int)__builtin_log2f(a.shift);
     bf16x8 afr[2];
     if (RESIDENT) {                      // short contraction (Q K^T): quantise the row block once, waves share the columns
         bf16x8 res[MM_RESIDENT_STEPS][2];
@@ -196,7 +221,7 @@ __global__ __launch_bounds__(256, 4) void bfp_qmatmul_kernel(const QuantArgs a, 
             XBlk s;
             load_xblk(s, row, st < nsteps ? st * 64 : K, g, K);
             mask_xblk(s, st < nsteps ? st * 64 : K, K);
-            quantise_xblk(s, a, lut, res[st]);
+            quantise_xblk(s, a, lut, mbits, lane, res[st]);
         }
         for (long long n0 = (long long)wave * MM_NCHUNK; n0 < N; n0 += 4 * MM_NCHUNK) {
             f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -220,16 +245,32 @@ __global__ __launch_bounds__(256, 4) void bfp_qmatmul_kernel(const QuantArgs a, 
         f32x4 acc[NT];
 #pragma unroll
         for (int tile = 0; tile < NT; ++tile) acc[tile] = f32x4{0, 0, 0, 0};
-        XBlk cur, nxt;
-        load_xblk(cur, row, (long long)wave * 64, g, K);
-        for (long long st = wave; st < nsteps; st += 4) {
-            BFrag<NT> bf;
-            load_bfrag<NT>(bf, ytb, n0, st * 64, Kp, N, lane);
-            load_xblk(nxt, row, (st + 4) * 64, g, K);      // next step's x in flight under this one's work (behind K: a re-read)
-            mask_xblk(cur, st * 64, K);
-            quantise_xblk(cur, a, lut, afr);
-            mma_step<NT>(afr, bf, n0, N, acc);
-            cur = nxt;
+        // two x buffers used alternately (a register copy would wait for the prefetch at the end of every step); the
+        // scheduling barriers keep the request order yt fragments -> next x, which the counted waits rely on
+        XBlk xa, xb;
+        load_xblk(xa, row, (long long)wave * 64, g, K);
+        for (long long st = wave; st < nsteps; st += 8) {
+            {
+                BFrag<NT> bf;
+                load_bfrag<NT>(bf, ytb, n0, st * 64, Kp, N, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                load_xblk(xb, row, (st + 4) * 64, g, K);   // next step's x in flight under this one's work (behind K: a re-read)
+                __builtin_amdgcn_sched_barrier(0);
+                if ((st + 1) * 64 > K) mask_xblk(xa, st * 64, K);          // (uniform: the last, partial step only)
+                quantise_xblk(xa, a, lut, mbits, lane, afr);
+                mma_step<NT>(afr, bf, n0, N, acc);
+            }
+            if (st + 4 >= nsteps) break;
+            {
+                BFrag<NT> bf;
+                load_bfrag<NT>(bf, ytb, n0, (st + 4) * 64, Kp, N, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                load_xblk(xa, row, (st + 8) * 64, g, K);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((st + 5) * 64 > K) mask_xblk(xb, (st + 4) * 64, K);
+                quantise_xblk(xb, a, lut, mbits, lane, afr);
+                mma_step<NT>(afr, bf, n0, N, acc);
+            }
         }
         __syncthreads();                                   // (previous chunk's partials have been read)
 #pragma unroll
@@ -252,16 +293,17 @@ __global__ __launch_bounds__(256, 4) void bfp_qmatmul_kernel(const QuantArgs a, 
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
                        long long B, long long M, long long K, long long N, hipStream_t st) {
     dim3 g1((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)B);
-    const long long Kp = (K + 63) / 64 * 64;               // yt rows hold whole 64-groups (permuted inside, zero-padded)
+    const long long Kp = (K + 63) / 64;                    // 64-steps: yt is stored in fragment order (kernel 1)
     hipLaunchKernelGGL(bfp_quant_pack_t_kernel, g1, 256, 0, st, ay, y, static_cast<uint16_t*>(yt), K, Kp, N);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     dim3 g2((unsigned)((M + 15) / 16), (unsigned)B);
-    if (Kp / 64 <= MM_RESIDENT_STEPS)
+    if ((K + 63) / 64 <= MM_RESIDENT_STEPS)
         hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
-    else    // (64 columns per pass over x; 128 per pass -- NT = 8 -- measured no faster at head_dim 128: the yt fragments
-            // every 16-row workgroup pulls through L1, 2 bytes per byte of x and 64 columns, bound this kernel)
+    else if (N <= 64)
         hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    else    // (head_dim 128: both halves of the columns in one pass over x)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
     return (int)hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "mi355q.h"
@@ -23,6 +24,25 @@ template <class T> static T* dalloc(size_t n, bool zero = false) {
 
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? std::atoi(argv[1]) : 3;
+    if (argc > 2 && std::string(argv[2]) == "matmul") {      // attention-shaped fused quantise + matmul instead of the Linear step
+        const int64_t B = 12, M = 2048, K = 2048, N = 64;
+        std::mt19937 gen(1);
+        std::uniform_real_distribution<float> ud(0.f, 1.f);
+        std::normal_distribution<float> nd(0.f, 1.f);
+        std::vector<float> hx(B * M * K), hy(B * K * N);
+        for (auto& v : hx) v = ud(gen);
+        for (auto& v : hy) v = nd(gen);
+        float *x = dalloc<float>(hx.size()), *y = dalloc<float>(hy.size()), *out = dalloc<float>(B * M * N);
+        void* ws = dalloc<unsigned char>(mi355q_bfp_matmul_workspace_bytes(B, K, N));
+        HIP_OK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(y, hy.data(), hy.size() * 4, hipMemcpyHostToDevice));
+        for (int s = 0; s < steps; ++s) Q_OK(mi355q_bfp_matmul(x, y, out, ws, B, M, K, N, 6, 8, 127, 6, 8, 127, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        float h[4];
+        HIP_OK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost));
+        std::printf("step_driver matmul: %d calls, out[0..3] = %g %g %g %g\n", steps, h[0], h[1], h[2], h[3]);
+        return 0;
+    }
     const int64_t M = 4096, N = 4096, K = 4096;
     std::mt19937 gen(0);
     std::normal_distribution<float> nd(0.f, 1.f);
