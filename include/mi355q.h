@@ -218,7 +218,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
  *   x fp32 [B, M, K] quantised in [1,16] blocks along K (data_in_* parameters), y fp32 [B, K, N] in [1,16] blocks along
  *   N (weight_* parameters), out fp32 [B, M, N]; all contiguous.  x is read once and quantised in registers on its way
  *   into bf16 MFMAs (exact: widths <= 9); y is quantised into `workspace` (mi355q_bfp_matmul_workspace_bytes) first.
- *   fp32 accumulation.  K % 16 == 0, N % 16 == 0, widths <= 9, B <= 65535, else MI355Q_E_UNSUPPORTED (callers then
+ *   fp32 accumulation; elements |x| <= 1e-8 (passed through unquantised by the reference) enter the product rounded
+ *   to bf16, at most 2e-11 absolute each.  K % 16 == 0, N % 16 == 0, widths <= 9, B <= 65535, else MI355Q_E_UNSUPPORTED (callers then
  *   use mi355q_block_fp_quantize on both operands + their own GEMM). */
 size_t mi355q_bfp_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N);
 int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
