@@ -3,9 +3,10 @@
 rotary_positional_encoding.py:59-248; registry keys as quantized_functions/__init__.py:14-42).
 
 Each operand is quantised along ITS OWN last dimension (matmul.py:166-195), so only x is blocked
-along the contraction: these products are not int8 block dots.  The operands go
-through the HIP fake-quant kernels and the contraction through the GPU's fp32 GEMM on exactly
-representable values.  Reference quirks kept: "log" maps to the block_log functions
+along the contraction: these products are not int8 block dots.  block_fp products
+whose blocks tile K and N go through the fused kernel (`ops.bfp_matmul`: x quantised in registers on
+its way into bf16 MFMAs, one pass over x); everything else through the HIP fake-quant kernels and
+the GPU's fp32 GEMM on exactly representable values.  Reference quirks kept: "log" maps to the block_log functions
 (__init__.py:20,29); block_log leaves y unquantised (matmul.py:278-297); the block_fp rotary
 function ignores `bypass` (rotary_positional_encoding.py:59-82)."""
 from __future__ import annotations
