@@ -221,28 +221,42 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
     const int mbits = (int)__builtin_log2f(a.shift);
     bf16x8 afr[2];
     if (RESIDENT) {                      // short contraction (Q K^T): quantise the row block once, waves share the columns
-        bf16x8 res[MM_RESIDENT_STEPS][2];
+        // (NT = the number of 64-steps here, 1..3: everything below is branch-free so that the counted waits stay exact)
+        constexpr int NS = NT;
+        bf16x8 res[NS][2];
 #pragma unroll
-        for (int st = 0; st < MM_RESIDENT_STEPS; ++st) {
+        for (int st = 0; st < NS; ++st) {
             XBlk s;
-            load_xblk(s, row, st < nsteps ? st * 64 : K, g, K);
-            mask_xblk(s, st < nsteps ? st * 64 : K, K);
+            load_xblk(s, row, st * 64, g, K);
+            mask_xblk(s, st * 64, K);
             quantise_xblk(s, a, lut, mbits, lane, res[st]);
         }
-        for (long long n0 = (long long)wave * MM_NCHUNK; n0 < N; n0 += 4 * MM_NCHUNK) {
-            f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        // Two fragment sets used alternately: the next chunk's yt fragments are requested BEFORE this chunk's stores --
+        // vmcnt counts loads and stores in one queue, so fragments requested behind the stores could only be used once
+        // those writes were acknowledged.
+        BFrag<4> b0[NS], b1[NS];
+        const long long step = 4 * MM_NCHUNK, nlast = ((N - 1) / MM_NCHUNK) * MM_NCHUNK;
+        long long n0 = (long long)wave * MM_NCHUNK;
 #pragma unroll
-            for (int st = 0; st < MM_RESIDENT_STEPS; ++st) {
-                if (st < nsteps) {
-                    BFrag<4> bf;
-                    load_bfrag<4>(bf, ytb, n0, st * 64, Kp, N, lane);
-                    mma_step<4>(res[st], bf, n0, N, acc);
-                }
-            }
-#pragma unroll
-            for (int tile = 0; tile < 4; ++tile)
-                if (n0 + 16 * tile < N) store_tile(acc[tile], outb, m0, n0 + 16 * tile, M, N, lane);
+        for (int st = 0; st < NS; ++st) load_bfrag<4>(b0[st], ytb, min(n0, nlast), st * 64, Kp, N, lane);
+#define MI355Q_MM_CHUNK(USE_, FILL_)                                                                         \
+        {                                                                                                   \
+            f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};                          \
+            _Pragma("unroll") for (int st = 0; st < NS; ++st) mma_step<4>(res[st], USE_[st], n0, N, acc);   \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            _Pragma("unroll") for (int st = 0; st < NS; ++st)                                               \
+                load_bfrag<4>(FILL_[st], ytb, min(n0 + step, nlast), st * 64, Kp, N, lane);                 \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            _Pragma("unroll") for (int tile = 0; tile < 4; ++tile)                                          \
+                if (n0 + 16 * tile < N) store_tile(acc[tile], outb, m0, n0 + 16 * tile, M, N, lane);       \
+            n0 += step;                                                                                     \
         }
+        while (n0 < N) {
+            MI355Q_MM_CHUNK(b0, b1)
+            if (n0 >= N) break;
+            MI355Q_MM_CHUNK(b1, b0)
+        }
+#undef MI355Q_MM_CHUNK
         return;
     }
     // long contraction: wave w streams steps w, w + 4, w + 8, ... of every column chunk (the four waves read adjacent
@@ -304,8 +318,12 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     dim3 g2((unsigned)((M + 15) / 16), (unsigned)B);
-    if ((K + 63) / 64 <= MM_RESIDENT_STEPS)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    if (Kp == 1)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 1>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    else if (Kp == 2)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 2>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    else if (Kp == 3)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 3>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
     else if (N <= 64)
         hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
     else    // (head_dim 128: both halves of the columns in one pass over x)
