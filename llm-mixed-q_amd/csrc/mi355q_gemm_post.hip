@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void bfp_gemm_rowpost(const GemmArgs a, const 
         const int p0 = sm.start[own], p1 = sm.start[own + 15] + sm.cnt[own + 15];
         const long long n = (long long)chunk * 64 + lane;
         const bool nok = n < a.N;
+        const long long nc = nok ? n : a.N - 1;
         const float sc = nok ? wscale[n] : 0.f;
         float acc = 0.f;
         for (int e0 = p0; e0 < p1; e0 += RP_U) {                     // (wave-uniform bounds)
@@ -113,8 +114,10 @@ __global__ __launch_bounds__(256) void bfp_gemm_rowpost(const GemmArgs a, const 
 #pragma unroll
             for (int u = 0; u < RP_U; ++u) {
                 const int* e = sm.ent + EXC_ENTRY * sm.order[min(e0 + u, p1 - 1)];
-                qv[u] = nok ? *reinterpret_cast<const int4*>(a.wm + tiled_offset(n, (long long)e[1] * 16, a.K)) : int4{0, 0, 0, 0};
-                yv[u] = nok ? a.y[(long long)e[0] * a.ldy + n] : 0.f;
+                // (unconditional, columns behind N read column N - 1: a load inside a branch makes the counted waits drain
+                // everything in flight)
+                qv[u] = *reinterpret_cast<const int4*>(a.wm + tiled_offset(nc, (long long)e[1] * 16, a.K));
+                yv[u] = a.y[(long long)e[0] * a.ldy + nc];
             }
 #pragma unroll
             for (int u = 0; u < RP_U; ++u) {

@@ -255,21 +255,26 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
         const long long ld = is_x ? a.ldxc : a.ldwc;
         const int off = is_x ? a.x_off : a.w_off;
         constexpr int U = 12;
+        // (gathers UNCONDITIONAL -- rows behind the operand read its last row -- and all results formed before the first
+        // store: a load inside a branch, or a store between loads, makes the counted waits drain the whole queue, and
+        // loads and stores share it; every entry is live here, void entries exist only in the overflow case)
+        const long long qc = min(q, qrows - 1);
         for (int e0 = 0; e0 < cnt; e0 += U) {
             int4 qv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int* e = s_bk + EXC_HEADER + EXC_ENTRY * min(e0 + u, cnt - 1);
-                qv[u] = (qok && e[0] >= 0) ? *reinterpret_cast<const int4*>(qm + tiled_offset(q, (long long)e[1] * 16, a.K))
-                                           : int4{0, 0, 0, 0};
+                qv[u] = *reinterpret_cast<const int4*>(qm + tiled_offset(qc, (long long)e[1] * 16, a.K));
             }
+            float rv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (e0 + u >= cnt) break;
-                const int* e = s_bk + EXC_HEADER + EXC_ENTRY * (e0 + u);
-                dst[(long long)(e0 + u) * ld] =
-                    __builtin_ldexpf((float)dot16(*reinterpret_cast<const int4*>(e + 4), qv[u]), e[2] - off) * sc;
+                const int* e = s_bk + EXC_HEADER + EXC_ENTRY * min(e0 + u, cnt - 1);
+                rv[u] = __builtin_ldexpf((float)dot16(*reinterpret_cast<const int4*>(e + 4), qv[u]), e[2] - off) * sc;
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e0 + u < cnt) dst[(long long)(e0 + u) * ld] = rv[u];            // (columns behind the operand: sc = 0)
         }
     }
 }
