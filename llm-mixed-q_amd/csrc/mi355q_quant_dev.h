@@ -65,14 +65,22 @@ __device__ __forceinline__ int ceil_log2(float v, const Lut& lut) {
     split_pos(v, k, m);
     return k + ((m != 0u && m >= lut.a[lut_index(k)]) ? 1 : 0);
 }
+// (per-ELEMENT uses: the table matters only within a few ulps of the next power of two -- M >= FLOOR_THR_MIN over all
+// binades -- so the lookup, an LDS read whose address depends on the exponent, is skipped unless some lane of the wave
+// is that close; both paths give the same value for every lane)
 __device__ __forceinline__ int floor_log2(float v, const Lut& lut) {
     int k; unsigned m;
     split_pos(v, k, m);
+    if (!__any(m >= MI355Q_LOG2_FLOOR_THR_MIN)) return k;
     return k + ((k < 128 && m >= lut.a[lut_index(k)]) ? 1 : 0);
 }
+// (the tie bands of all binades lie in [RND_LO_MIN, RND_HI_MAX], 125 fraction values around sqrt(2): no lookup unless
+// some lane of the wave falls in there)
 __device__ __forceinline__ int rint_log2(float v, const Lut& lut) {
     int k; unsigned m;
     split_pos(v, k, m);
+    if (!__any(m >= MI355Q_LOG2_RND_LO_MIN && m <= MI355Q_LOG2_RND_HI_MAX))
+        return k >= 128 ? 128 : k + (m > MI355Q_LOG2_RND_HI_MAX ? 1 : 0);
     if (k >= 128) return 128;
     const int i = lut_index(k);
     const int even = k + (k & 1);
