@@ -1,4 +1,4 @@
-"""Minimal OPT-style decoder harness over the registry API, and the perplexity loop.
+"""Minimal OPT-style and Llama-style decoder harnesses over the registry API, and the perplexity loop.
 
 NOT a port of the reference's HF model files (those are callers of the path and out of scope,
 SURVEY.md section 2 rows 8-9): this is just enough model to drive the hot path the way
@@ -111,6 +111,117 @@ class TinyOPTForCausalLM(nn.Module):
         for layer in self.layers:
             x = layer(x, mask)
         logits = self.lm_head(self.final_layer_norm(x))
+        loss = None
+        if labels is not None:
+            loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1))
+        return logits, loss
+
+
+@dataclass
+class TinyLlamaConfig:
+    vocab_size: int = 512
+    hidden_size: int = 256
+    intermediate_size: int = 512
+    num_layers: int = 2
+    num_heads: int = 4
+    max_positions: int = 128
+    rms_eps: float = 1e-6
+    init_std: float = 0.02
+
+
+def expand_llama_quant_config(default: dict, num_layers: int) -> dict:
+    """[default] -> model_layer_i x {q,k,v,o_proj, rotary_positional_encoding, matmul_0, matmul_1, gate/up/down_proj}
+    (what the reference's quant_config_llama.py builds from a TOML with only a [default] section)."""
+    out = {}
+    for i in range(num_layers):
+        attn = {k: parse_node_config(dict(default), "linear") for k in ("q_proj", "k_proj", "v_proj", "o_proj")}
+        attn["rotary_positional_encoding"] = parse_node_config(dict(default), "rotary_positional_encoding")
+        attn["matmul_0"] = parse_node_config(dict(default), "matmul")
+        attn["matmul_1"] = parse_node_config(dict(default), "matmul")
+        mlp = {k: parse_node_config(dict(default), "linear") for k in ("gate_proj", "up_proj", "down_proj")}
+        out[f"model_layer_{i}"] = {"self_attn": attn, "mlp": mlp}
+    return out
+
+
+class _RMSNorm(nn.Module):
+    def __init__(self, n, eps):
+        super().__init__()
+        self.weight, self.eps = nn.Parameter(torch.ones(n)), eps
+
+    def forward(self, x):
+        v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        return self.weight * (x * torch.rsqrt(v + self.eps)).to(x.dtype)
+
+
+class _LlamaAttention(nn.Module):
+    """Llama-style attention over the registry API the way the reference's LlamaQuantizedAttention drives it
+    (modeling_llama.py:289-344): bias-free projections, rotary embedding through
+    get_quantized_func("rotary_positional_encoding"), 4-D products through get_quantized_func("matmul")."""
+
+    def __init__(self, cfg: TinyLlamaConfig, qc: dict):
+        super().__init__()
+        self.h, self.nh, self.hd = cfg.hidden_size, cfg.num_heads, cfg.hidden_size // cfg.num_heads
+        self.qc = qc
+        for name in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            setattr(self, name, get_quantized_cls("linear", qc[name])(self.h, self.h, bias=False, config=qc[name]))
+        inv = 1.0 / (10000.0 ** (torch.arange(0, self.hd, 2).float() / self.hd))
+        t = torch.arange(cfg.max_positions).float()
+        emb = torch.cat([torch.outer(t, inv)] * 2, dim=-1)
+        self.register_buffer("cos", emb.cos()[None, None], persistent=False)       # [1, 1, pos, hd]
+        self.register_buffer("sin", emb.sin()[None, None], persistent=False)
+
+    def forward(self, x, mask, position_ids):
+        B, T, _ = x.shape
+        shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
+        q, k, v = shape(self.q_proj(x)), shape(self.k_proj(x)), shape(self.v_proj(x))
+        rc = self.qc["rotary_positional_encoding"]
+        q, k = get_quantized_func("rotary_positional_encoding", rc)(q, k, self.cos[:, :, :T], self.sin[:, :, :T],
+                                                                   position_ids, config=rc)
+        w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])
+        w = w / math.sqrt(self.hd) + mask
+        w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+        p = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = get_quantized_func("matmul", self.qc["matmul_1"])(p, v, config=self.qc["matmul_1"])
+        return self.o_proj(o.transpose(1, 2).reshape(B, T, self.h))
+
+
+class _LlamaLayer(nn.Module):
+    def __init__(self, cfg: TinyLlamaConfig, qc: dict):
+        super().__init__()
+        self.self_attn = _LlamaAttention(cfg, qc["self_attn"])
+        self.input_layernorm = _RMSNorm(cfg.hidden_size, cfg.rms_eps)
+        self.post_attention_layernorm = _RMSNorm(cfg.hidden_size, cfg.rms_eps)
+        lin = lambda name, i, o: get_quantized_cls("linear", qc["mlp"][name])(i, o, bias=False, config=qc["mlp"][name])
+        self.gate_proj = lin("gate_proj", cfg.hidden_size, cfg.intermediate_size)
+        self.up_proj = lin("up_proj", cfg.hidden_size, cfg.intermediate_size)
+        self.down_proj = lin("down_proj", cfg.intermediate_size, cfg.hidden_size)
+
+    def forward(self, x, mask, position_ids):
+        x = x + self.self_attn(self.input_layernorm(x), mask, position_ids)
+        h = self.post_attention_layernorm(x)
+        return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))     # (modeling_llama.py:208-240)
+
+
+class TinyLlamaForCausalLM(nn.Module):
+    def __init__(self, cfg: TinyLlamaConfig, quant_config: dict):
+        super().__init__()
+        self.cfg = cfg
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList(_LlamaLayer(cfg, quant_config[f"model_layer_{i}"]) for i in range(cfg.num_layers))
+        self.norm = _RMSNorm(cfg.hidden_size, cfg.rms_eps)
+        self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                m.weight.data.normal_(0.0, cfg.init_std)
+
+    def forward(self, input_ids, labels=None):
+        B, T = input_ids.shape
+        position_ids = torch.arange(T, device=input_ids.device)[None].expand(B, T)
+        x = self.embed_tokens(input_ids)
+        mask = torch.full((T, T), torch.finfo(x.dtype).min, device=x.device).triu(1)[None, None]
+        for layer in self.layers:
+            x = layer(x, mask, position_ids)
+        logits = self.lm_head(self.norm(x))
         loss = None
         if labels is not None:
             loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1))
