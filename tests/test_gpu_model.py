@@ -111,11 +111,12 @@ def _oracle_llama_forward(model, cfg_default, ids):
         h = t.shape[-1] // 2
         return np.concatenate([-t[..., h:], t[..., :h]], axis=-1)
 
-    inv = (1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / f32(hd)))).astype(np.float32)
-    emb = np.concatenate([np.outer(np.arange(c.max_positions, dtype=np.float32), inv)] * 2, axis=-1).astype(np.float32)
+    # the model's own fp32 cos / sin tables (buffers, not in the state dict): the quantised tables are what is compared
+    cos_t = model.layers[0].self_attn.cos.detach().cpu().numpy()[0, 0, :T].astype(np.float32)
+    sin_t = model.layers[0].self_attn.sin.detach().cpu().numpy()[0, 0, :T].astype(np.float32)
     kw = {k: cfg_default[f"data_in_{k}"] for k in ("width", "exponent_width", "exponent_bias", "block_size")}
-    cos = O.block_fp_quantize(np.cos(emb).astype(np.float32)[:T], **kw, skip_first_dim=False)[None, None]
-    sin = O.block_fp_quantize(np.sin(emb).astype(np.float32)[:T], **kw, skip_first_dim=False)[None, None]
+    cos = O.block_fp_quantize(cos_t, **kw, skip_first_dim=False)[None, None]
+    sin = O.block_fp_quantize(sin_t, **kw, skip_first_dim=False)[None, None]
     x = sd["embed_tokens.weight"][ids]
     mask = np.triu(np.full((T, T), np.finfo(np.float32).min, np.float32), 1)[None, None]
     for i in range(c.num_layers):

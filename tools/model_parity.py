@@ -3,23 +3,30 @@
 minutes.  GPU = registry API on the HIP path (int8-MFMA Linear, HIP fake-quant matmuls); CPU = the oracle's
 quantisers in numpy (tests/test_gpu_model.py::_oracle_forward).  Also times the GPU forward at T = 2048.
 
-    python tools/model_parity.py [layers=2] [T=512]
+    python tools/model_parity.py [layers=2] [T=512] [opt|llama]     (llama: Llama-160m width, H 768, I 2048, 12 heads)
 """
 import json, math, sys, time
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import torch
-from mi355q.harness import TinyOPTConfig, TinyOPTForCausalLM, eval_lm_perplexity, expand_quant_config
-from test_gpu_model import _oracle_forward
+from mi355q.harness import (TinyOPTConfig, TinyOPTForCausalLM, TinyLlamaConfig, TinyLlamaForCausalLM, eval_lm_perplexity,
+                            expand_quant_config, expand_llama_quant_config)
+from test_gpu_model import _oracle_forward, _oracle_llama_forward
 
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+family = sys.argv[3] if len(sys.argv) > 3 else "opt"
 W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
 torch.manual_seed(0)
-cfg = TinyOPTConfig(vocab_size=2048, hidden_size=768, ffn_dim=3072, num_layers=layers, num_heads=12, max_positions=2048)
-model = TinyOPTForCausalLM(cfg, expand_quant_config(W6A6, cfg.num_layers))
+if family == "llama":
+    cfg = TinyLlamaConfig(vocab_size=2048, hidden_size=768, intermediate_size=2048, num_layers=layers, num_heads=12, max_positions=2048)
+    model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(W6A6, cfg.num_layers))
+    _oracle_forward = _oracle_llama_forward
+else:
+    cfg = TinyOPTConfig(vocab_size=2048, hidden_size=768, ffn_dim=3072, num_layers=layers, num_heads=12, max_positions=2048)
+    model = TinyOPTForCausalLM(cfg, expand_quant_config(W6A6, cfg.num_layers))
 with torch.no_grad():
     for n, p in model.named_parameters():
         if p.ndim == 2 and "embed" not in n:
@@ -32,8 +39,9 @@ dev = torch.device("cuda:0")
 model = model.to(dev)
 with torch.no_grad():
     loss = float(model(ids.to(dev), labels=ids.to(dev))[1])
-modes = sorted({m._align_mode for m in model.modules() if hasattr(m, "_align_mode") and m._align_mode})
-out = {"shape": f"OPT-125m width, {layers} layers, T={T}", "gpu_loss": loss, "oracle_loss": ref, "abs_diff": abs(loss - ref),
+modes = sorted({m._align_mode + ("+post-pass" if getattr(m, "_x_cap", 120) != 120 and m._align_mode == "rows" else "")
+                for m in model.modules() if hasattr(m, "_align_mode") and m._align_mode})
+out = {"shape": f"{'Llama-160m' if family == 'llama' else 'OPT-125m'} width, {layers} layers, T={T}", "gpu_loss": loss, "oracle_loss": ref, "abs_diff": abs(loss - ref),
        "ppl_gpu": round(math.exp(loss), 3), "ppl_oracle": round(math.exp(ref), 3), "oracle_seconds": round(t_cpu, 1),
        "linear_align_modes": modes}
 # GPU timing at the perplexity-run shape (B=1, T=2048)
