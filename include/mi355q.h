@@ -166,6 +166,8 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
  * emptied for the next call). */
 #define MI355Q_ROW_ALIGN_MAX_K 16384
 #define MI355Q_ROW_BUCKET_CAP_MAX 1016
+#define MI355Q_ROW_NO_ALIGN (-1)   /* bucket_cap of mi355q_block_fp_quantize_aligned_rows: tiled row format, every block keeps
+                                    * its own exponent (rowflag 0, rowscale 0, list untouched / may be NULL) */
 size_t mi355q_bfp_row_list_bytes(int64_t rows, int32_t bucket_cap);
 int mi355q_bfp_align_rows(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_tiled, uint8_t* exp_out,
                           uint8_t* rowflag, float* rowscale, int32_t* list, int32_t exp_offset, int64_t rows,
@@ -185,7 +187,8 @@ typedef struct mi355q_bfp_operand {
     int32_t list_cap;       /* groups: entries of the list; rows: entries per bucket (0 = 120) */
     int32_t mbits;          /* width - 1 */
     int32_t exp_bias;
-    int32_t row_aligned;    /* 0: 256-value groups (mi355q_bfp_align); 1: whole rows (mi355q_bfp_align_rows):
+    int32_t row_aligned;    /* 0: 256-value groups (mi355q_bfp_align); 2: row format, nothing aligned (x only: MI355Q_ROW_NO_ALIGN;
+                             * the GEMM takes its blockwise-exact kernel: inputs no row window fits); 1: whole rows (mi355q_bfp_align_rows):
                              * rowflag [rows], gscale = rowscale [rows_pad], list = bucketed row list */
     float* corr;            /* row-aligned operands: scratch for the correction vectors of this operand's exception
                              * blocks, mi355q_bfp_corr_bytes(rows of this operand, rows of the other one); written and

@@ -244,9 +244,10 @@ int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, ui
                                           float* rowscale, int32_t* list, int32_t* list_to_clear, int64_t rows,
                                           int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias,
                                           int32_t bucket_cap, void* stream) {
-    if (rows < 0 || K < 0 || bucket_cap < 0 || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
+    if (rows < 0 || K < 0 || bucket_cap < MI355Q_ROW_NO_ALIGN || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
     if (rows == 0 || K == 0) return 0;
-    if (!x || !mant_tiled || !exp_out || !rowflag || !rowscale || !list || list_to_clear == list) return MI355Q_E_BADARG;
+    if (!x || !mant_tiled || !exp_out || !rowflag || !rowscale || (!list && bucket_cap >= 0) || (list && list_to_clear == list))
+        return MI355Q_E_BADARG;
     if (K % 64 != 0 || K > MI355Q_ROW_ALIGN_MAX_K) return MI355Q_E_UNSUPPORTED;
     if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 8) return MI355Q_E_BADARG;
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(mant_tiled) % 16) return MI355Q_E_ALIGN;
@@ -265,7 +266,7 @@ int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, ui
     a.e_max = (1 << exponent_width) - 1 - exponent_bias;
     set_mantissa(a, width - 1);
     return launch_quant_align_rows(a, mant_tiled, rowflag, rowscale, exponent_bias + width - 1, list, list_to_clear,
-                                   static_cast<hipStream_t>(stream), bucket_cap_of(bucket_cap));
+                                   static_cast<hipStream_t>(stream), bucket_cap < 0 ? -1 : bucket_cap_of(bucket_cap));
 }
 
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
@@ -276,7 +277,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         return MI355Q_E_BADARG;
     if (K % 64 != 0) return MI355Q_E_UNSUPPORTED;   // tiled operands; use mi355q_bfp_gemm otherwise
     if (x->mbits < 1 || x->mbits > 7 || w->mbits < 1 || w->mbits > 7) return MI355Q_E_BADARG;
-    if (x->row_aligned != w->row_aligned) return MI355Q_E_BADARG;      // both operands in the same alignment flavour
+    // both operands in the same alignment flavour; x may also be in row format with NOTHING aligned (row_aligned = 2)
+    if (x->row_aligned != w->row_aligned && !(x->row_aligned == 2 && w->row_aligned == 1)) return MI355Q_E_BADARG;
     if (!x->row_aligned && x->list && w->list && x->list_cap != w->list_cap) return MI355Q_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant)) % 16) return MI355Q_E_ALIGN;
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
@@ -289,6 +291,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         // ROW-aligned operands: plain int8 GEMM with one scale per row + exception add-back in its epilogue; the
         // second launch only acts when an exception bucket overflowed (then it forms the whole product blockwise)
         if (!x->gscale || !w->gscale) return MI355Q_E_BADARG;
+        if (x->row_aligned == 2)            // unaligned activations: the blockwise-exact kernel, w's exception blocks per tile
+            return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, w->list, 0, 0, st);
         if (x->list_cap < 0 || x->list_cap > ROW_BCAP_MAX || w->list_cap < 0 || w->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
         a.x_bcap = bucket_cap_of(x->list_cap);
         a.w_bcap = bucket_cap_of(w->list_cap);

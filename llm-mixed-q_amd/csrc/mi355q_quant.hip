@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     const long long K = a.cols;
     const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
     if (list_to_clear && blockIdx.x == 0) {
-        const long long words = row_list_words(a.rows, bcap), bw = row_bucket_words(bcap);
+        const int cb = bcap < 0 ? ROW_BCAP : bcap;
+        const long long words = row_list_words(a.rows, cb), bw = row_bucket_words(cb);
         if (tid < EXC_HEADER) list_to_clear[tid] = 0;
         for (long long b = EXC_HEADER + (long long)tid * bw; b < words; b += 256ll * bw)
             list_to_clear[b] = 0;
@@ -441,7 +442,9 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             pk[it] = lo | hi;
         }
         int E = 0;
-        const bool flagged = align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap);
+        // bcap < 0: no alignment at all -- every block keeps its own exponent, rowflag 0 (operands for the blockwise
+        // kernel: inputs whose block exponents spread too far for any row window, e.g. SiLU-gated MLP activations)
+        const bool flagged = bcap < 0 ? false : align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap);
         // tiled address of this lane's 4 bytes in slab 0 (block 16 wave + lane / 4: K-step 4 wave + lane / 16, 16-byte
         // chunk (lane / 4) & 3, swizzled by the row); a slab further on is 16 K-steps = 16 KiB further
         int8_t* dst = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + (row & 15) * 64 +

@@ -206,11 +206,14 @@ class AlignedOperand:
         self.mbits, self.exp_bias = int(mbits), int(exp_bias)
         self.row_aligned = bool(row_aligned)         # one exponent per ROW (mi355q_bfp_align_rows) instead of per 256 values
         # entries the list holds: per 256-row bucket (rows) / in all (groups)
-        self.list_cap = int(bucket_cap) if bucket_cap else (ROW_BUCKET_CAP if row_aligned else SPARSE_LIST_CAP)
+        self.unaligned = bool(row_aligned) and bucket_cap is not None and int(bucket_cap) < 0   # row format, own exponents
+        self.list_cap = (int(bucket_cap) if bucket_cap and int(bucket_cap) > 0
+                         else (ROW_BUCKET_CAP if row_aligned else SPARSE_LIST_CAP))
 
     def c_struct(self, corr=None):
         return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
-                               _ptr(self.sparse), self.list_cap, self.mbits, self.exp_bias, int(self.row_aligned), _ptr(corr))
+                               _ptr(self.sparse), self.list_cap, self.mbits, self.exp_bias,
+                               2 if self.unaligned else int(self.row_aligned), _ptr(corr))
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
@@ -239,7 +242,7 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
 
 
 ROW_ALIGN_MAX_K = 16384
-ROW_BUCKET_ROWS, ROW_BUCKET_CAP, ROW_BUCKET_CAP_MAX = 256, 120, 1016
+ROW_BUCKET_ROWS, ROW_BUCKET_CAP, ROW_BUCKET_CAP_MAX, ROW_NO_ALIGN = 256, 120, 1016, -1
 # exception entries per 256 rows of a fused-quantised ACTIVATION operand.  120: the GEMM adds them from LDS (at most
 # ~96 per tile together with the weights'); larger: the row post-pass adds them after the GEMM, without a tile limit.
 import os as _os
@@ -323,7 +326,7 @@ class _ActivationBuffers:
                 exp=torch.empty(rows * (K // 16), dtype=torch.uint8, device=device),
                 flag=torch.empty(rows, dtype=torch.uint8, device=device),
                 gscale=torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
-                sparse=[_new_row_list(device, rows, bucket_cap) for _ in range(2)],
+                sparse=[_new_row_list(device, rows, bucket_cap) for _ in range(2)] if bucket_cap >= 0 else [None, None],
                 calls=0)
             if len(cls._cache) > 64:
                 cls._cache.clear()
@@ -372,7 +375,8 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     """Fused activation path, ROW-aligned flavour: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack +
     row-align + tile in one kernel (K % 64 == 0, K <= ROW_ALIGN_MAX_K).  Buffers are reused per shape and
     stream like block_fp_quantize_aligned's.  `bucket_cap`: exception entries per 256 rows (default
-    ACTIVATION_BUCKET_CAP); anything but 120 makes the GEMM add x's exceptions in its row post-pass."""
+    ACTIVATION_BUCKET_CAP); anything but 120 makes the GEMM add x's exceptions in its row post-pass; ROW_NO_ALIGN (-1):
+    no alignment at all, every block keeps its exponent and the GEMM takes its blockwise-exact kernel."""
     bucket_cap = ACTIVATION_BUCKET_CAP if bucket_cap is None else int(bucket_cap)
     _require_device(x, "block_fp_quantize_aligned_rows")
     assert x.ndim == 2 and x.shape[1] % 64 == 0 and x.shape[1] <= ROW_ALIGN_MAX_K
@@ -425,7 +429,7 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     cx = cw = None
     if x.row_aligned and w.row_aligned:
         cx, cw = _corr_workspace(x.tiled.device, M, N, sp)
-        if x.list_cap != ROW_BUCKET_CAP:
+        if x.list_cap != ROW_BUCKET_CAP or x.unaligned:
             cx = None                    # x's exception blocks go through the row post-pass
     xs, ws = x.c_struct(cx), w.c_struct(cw)
     import ctypes

@@ -64,7 +64,8 @@ class _LinearBase(nn.Linear):
         # weights and the first activations fit it, re-checked on a doubling schedule
         self.align = config.get("mi355q_align", "auto")
         self._align_mode, self._canonical, self._calls, self._row_overflows = None, None, 0, 0
-        self._x_cap = ops.ROW_BUCKET_CAP_MAX if self.align == "rows_post" else ops.ACTIVATION_BUCKET_CAP
+        self._w_bf16 = None
+        self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
         if not self.bypass:
             self._setup_quantizers(config)
 
@@ -122,7 +123,7 @@ class _LinearBase(nn.Linear):
     def _choose_align_mode(self, wm, we, x_sample):
         if self.align == "groups" or not ops.row_align_supported(self.in_features):
             return "groups"
-        if self.align in ("rows", "rows_post"):
+        if self.align in ("rows", "rows_post", "blocks"):
             return "rows"
         c = self.config
         # one-off host reads at pack time: overflow words and the fullest exception bucket of either operand.  Rows pay
@@ -140,9 +141,10 @@ class _LinearBase(nn.Linear):
                                                     c["data_in_exponent_width"], c["data_in_exponent_bias"],
                                                     bucket_cap=ops.ROW_BUCKET_CAP_MAX)
             x_over, x_max = ops.row_list_fill(xa.sparse, xa.rows, xa.list_cap)
-            if x_over != 0:
-                return "groups"
-            self._x_cap = ops.ROW_BUCKET_CAP if w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST else ops.ROW_BUCKET_CAP_MAX
+            if x_over != 0:             # no row window fits these activations (SiLU-gated MLP inputs): blockwise kernel
+                self._x_cap = ops.ROW_NO_ALIGN
+            else:
+                self._x_cap = ops.ROW_BUCKET_CAP if w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST else ops.ROW_BUCKET_CAP_MAX
         return "rows"
 
     def _align_weights(self, wm, we, mode):
@@ -164,6 +166,7 @@ class _LinearBase(nn.Linear):
         next forward quantise and pack them again instead of rebuilding the model."""
         self.weight_requires_quantisation = True if self.is_ptq else False
         self._packed, self._canonical, self._align_mode, self._calls, self._row_overflows = None, None, None, 0, 0
+        self._w_bf16 = None
 
     def forward(self, x):
         if self.bypass:
@@ -186,6 +189,21 @@ class _LinearBase(nn.Linear):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
         x2 = x.reshape(-1, self.in_features)
+        if (self._align_mode == "rows" and self._x_cap == ops.ROW_NO_ALIGN
+                and c.get("mi355q_blocks_gemm", "bf16") == "bf16" and c["data_in_width"] <= 9 and c["weight_width"] <= 9):
+            # Activations no row window fits (SiLU-gated MLP inputs): every block keeps its exponent.  A block_fp value of
+            # width <= 9 is exact in bf16, so the product is a plain bf16 GEMM with fp32 accumulation and fp32 output on
+            # the library's MFMA kernel (x through the HIP fake-quantiser; the in-place quantised weights cast once).
+            # |x| <= 1e-8 pass-through elements are rounded to bf16 there (<= 2e-11 each).  "int8": the blockwise-exact
+            # int8 kernel instead (mi355q_bfp_gemm_aligned with row_aligned = 2), exact integer block dots, ~5x slower.
+            xq = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                       [1, 16], True)
+            if self._w_bf16 is None or self._w_bf16[1] != self.weight._version:
+                self._w_bf16 = (self.weight.detach().to(torch.bfloat16), self.weight._version)
+            y = torch.mm(xq.to(torch.bfloat16), self._w_bf16[0].t(), out_dtype=torch.float32)
+            if self.bias is not None:
+                y += self.bias
+            return y.reshape(*x.shape[:-1], self.out_features)
         if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                     c["data_in_exponent_bias"], bucket_cap=self._x_cap)
@@ -198,7 +216,7 @@ class _LinearBase(nn.Linear):
                                               want_packed=True, fast_zero_blocks=True)
             xa = ops.bfp_align(xm, xe, x_mbits, xb, inplace=True)
         y = ops.bfp_gemm_aligned(xa, self._packed[0], self.bias)
-        if self._align_mode == "rows" and self.align == "auto":
+        if self._align_mode == "rows" and self.align == "auto" and self._x_cap != ops.ROW_NO_ALIGN:
             # results never depend on the mode (an overflowing exception bucket only sends the GEMM to its slow
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats
             self._calls += 1
@@ -207,8 +225,8 @@ class _LinearBase(nn.Linear):
                     self._x_cap = ops.ROW_BUCKET_CAP_MAX          # first: larger buckets + the row post-pass
                 else:
                     self._row_overflows += 1
-                    if self._row_overflows >= 2 and self._canonical is not None:
-                        self._align_weights(*self._canonical, "groups")
+                    if self._row_overflows >= 2:
+                        self._x_cap = ops.ROW_NO_ALIGN            # then none at all: the blockwise-exact kernel
         return y.reshape(*x.shape[:-1], self.out_features)
 
     @classmethod

@@ -408,6 +408,40 @@ def test_row_post_pass_takes_what_the_tile_cannot():
     np.testing.assert_allclose(y2, ref, rtol=0, atol=2e-6 * np.abs(ref).max() * (K // 256))
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 130, 1024), (64, 48, 128), (520, 260, 512)])
+@pytest.mark.parametrize("wx", [6, 4])
+def test_unaligned_activations_take_the_blockwise_kernel(M, N, K, wx):
+    """inputs no row window fits (SiLU-gated products: block exponents spread over ~20 values in every row): the fused
+    quantiser can leave the row format unaligned (bucket_cap = ROW_NO_ALIGN) and the GEMM runs blockwise-exact against
+    row-aligned weights, whose own exception blocks are added per tile"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    r = np.random.default_rng(M + K)
+    g, u = r.normal(size=(M, K)), r.normal(size=(M, K))
+    x = ((g / (1 + np.exp(-g))) * u * np.exp(3 * r.normal(size=(M, K // 16, 1)).repeat(16, 2).reshape(M, K))).astype(np.float32)
+    w = (r.normal(size=(N, K)) * 0.02).astype(np.float32)
+    w[::7, 256 % K: 256 % K + 16] *= 300.0
+    b = r.normal(size=N).astype(np.float32)
+    cfg = _cfg(wx, 6)
+    dev = torch.device("cuda:0")
+    _, wm, we = ops.block_fp_quantize(torch.from_numpy(w).to(dev), 6, 8, 127, [1, 16], False, want_fake=False,
+                                      want_packed=True, fast_zero_blocks=True)
+    wa = ops.bfp_align_rows(wm, we, 5, 127)
+    bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), 6, 8, 127, [16], False)
+    xa = ops.block_fp_quantize_aligned_rows(torch.from_numpy(x).to(dev), wx, 8, 127, bucket_cap=ops.ROW_NO_ALIGN)
+    assert xa.unaligned and not bool(xa.rowflag.any()) and xa.sparse is None
+    y = ops.bfp_gemm_aligned(xa, wa, bq).cpu().numpy()
+    ref = O.bfp_linear_int(x, w, b, cfg)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * np.abs(ref).max() * max(1, K // 256))
+    # the same input through row alignment overflows even the large buckets (and still gives the same values)
+    xr = ops.block_fp_quantize_aligned_rows(torch.from_numpy(x).to(dev), wx, 8, 127, bucket_cap=1016)
+    if M >= 256 and K >= 512:
+        assert ops.row_list_fill(xr.sparse, M, 1016)[0] > 0
+    y2 = ops.bfp_gemm_aligned(xr, wa, bq).cpu().numpy()
+    np.testing.assert_allclose(y2, ref, rtol=0, atol=2e-6 * np.abs(ref).max() * max(1, K // 256))
+
+
 def test_row_aligned_gemm_bucket_overflow_takes_the_fallback():
     from oracle import np_oracle as O
     r = np.random.default_rng(12)

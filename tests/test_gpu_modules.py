@@ -74,7 +74,7 @@ def test_linear_int8_path_vs_oracle(wx, ww, has_bias):
         assert np.array_equal(lin.bias.detach().cpu().numpy(), bq)
 
 
-@pytest.mark.parametrize("align", ["auto", "rows", "rows_post", "groups"])
+@pytest.mark.parametrize("align", ["auto", "rows", "rows_post", "blocks", "groups"])
 @pytest.mark.parametrize("outliers", [False, True])
 def test_linear_int8_align_modes(align, outliers):
     """the exponent-alignment flavour of the packed operands is an implementation knob: every choice gives the
@@ -98,12 +98,19 @@ def test_linear_int8_align_modes(align, outliers):
         y = lin(x.to("cuda:0"))
         ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(3, 100, 192)
         np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
-    want = {"rows": "rows", "rows_post": "rows", "groups": "groups", "auto": "rows"}[align]
+    want = {"rows": "rows", "rows_post": "rows", "blocks": "rows", "groups": "groups", "auto": "rows"}[align]
     assert lin._align_mode == want
     if align == "auto":                      # 300 rows x 1 exception: too many for a tile's LDS add-back -> post-pass
         assert lin._x_cap == (1016 if outliers else 120)
     if align == "rows_post":
         assert lin._x_cap == 1016
+    if align == "blocks":                    # nothing aligned: bf16 GEMM on the exactly representable quantised values
+        assert lin._x_cap == -1 and lin._w_bf16 is not None
+        cfg2 = dict(cfg, mi355q_blocks_gemm="int8")          # ... or the blockwise-exact int8 kernel
+        lin2 = Q.get_quantized_cls("linear", cfg2).from_float(fp, cfg2).to("cuda:0")
+        y2 = lin2(x.to("cuda:0"))
+        assert lin2._w_bf16 is None
+        np.testing.assert_allclose(y2.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
 
 
 def test_linear_auto_align_leaves_row_mode_when_activations_stop_fitting():
@@ -131,11 +138,11 @@ def test_linear_auto_align_leaves_row_mode_when_activations_stop_fitting():
         ref = O.bfp_linear_int(wild.numpy(), w0, None, cfg)
         np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
     assert lin._align_mode == "rows" and lin._x_cap == 1016
-    for call in range(12):                   # overflow of those seen at calls 8 and 16 of the doubling schedule -> groups
+    for call in range(12):                   # overflow of those seen at calls 8 and 16 of the doubling schedule -> no alignment
         y = lin(wilder.to("cuda:0"))
         ref = O.bfp_linear_int(wilder.numpy(), w0, None, cfg)
         np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
-    assert lin._align_mode == "groups"
+    assert lin._align_mode == "rows" and lin._x_cap == -1
     y = lin(calm.to("cuda:0"))
     ref = O.bfp_linear_int(calm.numpy(), w0, None, cfg)
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())

@@ -57,7 +57,8 @@ def test_aligned_operand_entry_points_validate_without_a_gpu():
     assert lib.mi355q_bfp_align_rows(p, p, p, p, p, p, None, 132, 0, 64, 0, None) == 0
     assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, p, p, 4, 64, 6, 8, 127, 0, None) == E_BADARG   # list == list_to_clear
     assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, p, None, 4, 64, 9, 8, 127, 0, None) == E_BADARG  # width
-    assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, p, None, 4, 64, 6, 8, 127, -1, None) == E_BADARG  # bucket_cap
+    assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, p, None, 4, 64, 6, 8, 127, -2, None) == E_BADARG  # bucket_cap
+    assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, None, None, 4, 64, 6, 8, 127, 0, None) == E_BADARG   # list required unless NO_ALIGN
     assert lib.mi355q_block_fp_quantize_aligned_rows(p + 4, p, p, p, p, p, None, 4, 64, 6, 8, 127, 0, None) == E_ALIGN
     assert lib.mi355q_block_fp_quantize_aligned(p, p, p, p, p, p, 8, None, 4, 192, 6, 8, 127, None) == E_UNSUPPORTED  # K % 256
     # GEMM: both operands in the same flavour, scratch for the row flavour, K % 64

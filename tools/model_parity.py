@@ -39,7 +39,7 @@ dev = torch.device("cuda:0")
 model = model.to(dev)
 with torch.no_grad():
     loss = float(model(ids.to(dev), labels=ids.to(dev))[1])
-modes = sorted({m._align_mode + ("+post-pass" if getattr(m, "_x_cap", 120) != 120 and m._align_mode == "rows" else "")
+modes = sorted({m._align_mode + ({120: "", -1: "+blockwise"}.get(getattr(m, "_x_cap", 120), "+post-pass") if m._align_mode == "rows" else "")
                 for m in model.modules() if hasattr(m, "_align_mode") and m._align_mode})
 out = {"shape": f"{'Llama-160m' if family == 'llama' else 'OPT-125m'} width, {layers} layers, T={T}", "gpu_loss": loss, "oracle_loss": ref, "abs_diff": abs(loss - ref),
        "ppl_gpu": round(math.exp(loss), 3), "ppl_oracle": round(math.exp(ref), 3), "oracle_seconds": round(t_cpu, 1),
