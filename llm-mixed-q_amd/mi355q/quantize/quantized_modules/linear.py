@@ -130,10 +130,11 @@ class _LinearBase(nn.Linear):
         # off while a 256 x 256 tile's entries (x bucket + w bucket) fit the GEMM's in-LDS add-back.
         wa = ops.bfp_align_rows(wm, we, c["weight_width"] - 1, self._weight_bias_value())
         w_over, w_max = ops.row_list_fill(wa.sparse, self.out_features)
-        if w_over != 0:
-            return "groups"
-        if w_max > ops.ROW_TILE_ENTRIES_FAST:
-            return "groups"
+        if w_over != 0 or w_max > ops.ROW_TILE_ENTRIES_FAST:
+            # weights whose exception blocks do not fit a tile's LDS add-back (outlier input channels put one in every
+            # row): no alignment -- the blockwise / bf16 product does not care how exponents are distributed
+            self._x_cap = ops.ROW_NO_ALIGN
+            return "rows"
         if x_sample is not None:
             # activations: the GEMM's in-LDS add-back while a tile's entries fit it, else large buckets + the row
             # post-pass (no per-tile limit: post-activation inputs); groups only if even those overflow

@@ -290,3 +290,29 @@ def test_fused_block_fp_matmul_falls_back_where_it_does_not_apply():
     assert F_._fused_block_fp_matmul(xg, yg, _mm_cfg(6, 6), "bmm") is None
     Q.get_quantized_func("bmm", _mm_cfg(6, 6))(xg, yg, _mm_cfg(6, 6)).sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_linear_auto_takes_blocks_for_weights_with_outlier_input_channels():
+    """an outlier input channel puts one exception block into EVERY weight row (256 per bucket, far beyond a tile's LDS
+    add-back): auto leaves alignment alone and multiplies the exactly representable quantised values (bf16 MFMA GEMM,
+    fp32 accumulation) -- same values as the oracle's exact block dots"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8,
+               data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8,
+               weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8,
+               bias_exponent_bias=127, bias_block_size=[16])
+    torch.manual_seed(8)
+    fp = torch.nn.Linear(512, 320, bias=True)
+    with torch.no_grad():
+        fp.weight[:, 40] *= 300.0
+        fp.weight[:, 333] *= 300.0
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    w0, b0 = fp.weight.detach().numpy().copy(), fp.bias.detach().numpy().copy()
+    x = torch.randn(2, 70, 512) * torch.exp(torch.randn(2, 70, 1))
+    for _ in range(2):
+        y = lin(x.to("cuda:0"))
+    assert lin._align_mode == "rows" and lin._x_cap == -1 and lin._w_bf16 is not None
+    ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(2, 70, 320)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
