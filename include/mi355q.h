@@ -66,6 +66,13 @@ int mi355q_block_fp_quantize(const float* x, float* y, int8_t* mant, uint8_t* ex
                              int32_t width, int32_t exponent_width, int32_t exponent_bias,
                              uint32_t flags, void* workspace, void* stream);
 
+/* The fake-quantised values as bf16 (exact for width <= 9; elements |x| <= 1e-8, which pass through unquantised,
+ * are rounded to bf16): the operand format of a bf16 MFMA GEMM on quantised values.  Row-vector blocks only
+ * (b0 == 1, cols % b1 == 0, b1 % 4 == 0), else MI355Q_E_UNSUPPORTED.  y 8-byte aligned. */
+int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int64_t rows, int64_t cols,
+                                  int32_t b0, int32_t b1, int32_t width, int32_t exponent_width,
+                                  int32_t exponent_bias, void* workspace, void* stream);
+
 /* ---- block minifloat ----------------------------------------------------------------
  * replaces: quantizers/block_minifloat.py:22-74 -> quantizers/minifloat.py:134-196 behind
  *           QUANTIZER_MAP["block_minifloat"].   y: fake-quantised fp32 (required).

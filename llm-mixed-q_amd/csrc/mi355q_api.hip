@@ -100,6 +100,25 @@ int mi355q_block_fp_quantize(const float* x, float* y, int8_t* mant, uint8_t* ex
     return launch_quant(a, 0, /*needs_fixup=*/mant != nullptr, static_cast<hipStream_t>(stream));
 }
 
+int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int64_t rows, int64_t cols, int32_t b0,
+                                  int32_t b1, int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                                  void* workspace, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, nullptr, workspace, lead, rows, cols, b0, b1, MI355Q_ZERO_BLOCK_FAST);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y == nullptr) return MI355Q_E_BADARG;
+    if (exponent_width < 1 || exponent_width > 8 || width < 2) return MI355Q_E_BADARG;
+    if (width > 9) return MI355Q_E_UNSUPPORTED;            // a quantised value must fit bf16's 8 significant bits
+    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    a.ybf = y;
+    a.code_bias = exponent_bias;
+    a.e_min = -exponent_bias;
+    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    set_mantissa(a, width - 1);
+    return launch_quant(a, 0, /*needs_fixup=*/false, static_cast<hipStream_t>(stream));
+}
+
 int mi355q_block_minifloat_quantize(const float* x, float* y, uint8_t* bias, int64_t lead, int64_t rows, int64_t cols,
                                     int32_t b0, int32_t b1, int32_t width, int32_t exponent_width,
                                     int32_t exponent_bias_width, uint32_t flags, void* workspace, void* stream) {

@@ -10,6 +10,7 @@ namespace mi355q {
 struct QuantArgs {
     const float* x;
     float* y;          // fake-quantised fp32 (nullable for block_fp)
+    uint16_t* ybf;     // the same as bf16 (block_fp vector path only; exact for widths <= 9), nullable
     int8_t* mant;      // block_fp signed mantissas (nullable)
     uint8_t* code;     // per block: biased shared exponent (bfp) or shared bias (bm / bl); nullable
     unsigned* ws;      // MI355Q_WORKSPACE_BYTES, zeroed

@@ -30,15 +30,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int MM_NCHUNK = 64;            // output columns per accumulator set (4 MFMA tiles)
 
-// two floats -> one dword of bf16 (v_cvt_pk_bf16_f32, round to nearest even).  Quantised values are exact in bf16; the
-// only inexact inputs are elements |x| <= 1e-8, which the reference passes through unquantised (block_fp.py:93-94): they
-// enter the product with a relative error of 2^-9 of themselves, at most 2e-11 absolute each.
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, v);
-}
-
 // position of contraction index k (inside its 64-group) in yt and in the MFMA operands: lane group g of kernel 2 holds
 // elements 4 g .. 4 g + 3 of each of the four [1,16] blocks (so that one load instruction reads 64 contiguous bytes of
 // every row); MFMA t takes blocks 2 t and 2 t + 1.  k = 16 (2 t + h) + 4 g + e  ->  32 t + 8 g + 4 h + e.

@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
         o.w = quant_elem<FMT>(v.w, bp, a, lut, q3);
         if (valid) {
             if (a.y) y4[i] = o;
+            if (FMT == FMT_BFP && a.ybf)
+                reinterpret_cast<uint2*>(a.ybf)[i] = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
             if (FMT == FMT_BFP && a.mant)
                 m4[i] = (unsigned)(q0 & 0xFF) | ((unsigned)(q1 & 0xFF) << 8) | ((unsigned)(q2 & 0xFF) << 16) |
                         ((unsigned)(q3 & 0xFF) << 24);
@@ -239,6 +241,7 @@ static int launch_format(const QuantArgs& a, bool needs_fixup, hipStream_t st) {
     const bool vec_ok = a.b0 == 1 && (a.cols % a.b1) == 0 && (a.b1 % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(a.x) % 16) == 0 &&
                         (a.y == nullptr || reinterpret_cast<uintptr_t>(a.y) % 16 == 0) &&
+                        (a.ybf == nullptr || reinterpret_cast<uintptr_t>(a.ybf) % 8 == 0) &&
                         (a.mant == nullptr || reinterpret_cast<uintptr_t>(a.mant) % 4 == 0);
     const int lpb = a.b1 / 4;
     if (vec_ok && (lpb == 1 || lpb == 2 || lpb == 4 || lpb == 8 || lpb == 16 || lpb == 32 || lpb == 64)) {
@@ -253,6 +256,7 @@ static int launch_format(const QuantArgs& a, bool needs_fixup, hipStream_t st) {
             default: hipLaunchKernelGGL((quant_vec_kernel<FMT, 64>), grid, 256, 0, st, a); break;
         }
     } else {
+        if (a.ybf) return MI355Q_E_UNSUPPORTED;            // bf16 output: vector path only
         const int grid = grid_for(a.n_blocks, 16);
         hipLaunchKernelGGL((quant_generic_kernel<FMT>), grid, 256, 0, st, a);
     }

@@ -162,5 +162,14 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// two floats -> one dword of bf16 (v_cvt_pk_bf16_f32, round to nearest even).  Quantised values are exact in bf16; the
+// only inexact inputs are elements |x| <= 1e-8, which the reference passes through unquantised (block_fp.py:93-94): they
+// enter the product with a relative error of 2^-9 of themselves, at most 2e-11 absolute each.
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 }  // namespace mi355q
 #endif

@@ -14,6 +14,7 @@ _i32, _i64, _u32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_void_p
 SIGNATURES = {
     "mi355q_abi_version": (C.c_int, []),
     "mi355q_error_string": (C.c_char_p, [C.c_int]),
+    "mi355q_block_fp_quantize_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                            _i32, _i32, _i32, _u32, _vp, _vp]),
     "mi355q_block_minifloat_quantize": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,

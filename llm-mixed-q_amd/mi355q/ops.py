@@ -110,6 +110,26 @@ def block_fp_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent
     return (y, mant, exp) if want_packed else y
 
 
+def block_fp_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, block_size,
+                           skip_first_dim: bool) -> torch.Tensor:
+    """block_fp fake-quantisation straight to bf16 (exact for width <= 9): the operand of a bf16 MFMA GEMM on quantised
+    values.  Blocks that are row vectors tiling the last dim go through one kernel (4 B read + 2 B written per element);
+    anything else through the fp32 quantiser and a cast."""
+    _require_device(x, "block_fp_quantize_bf16")
+    assert int(width) <= 9, "a block_fp value wider than 9 bits is not exact in bf16"
+    lead, rows, cols, b0, b1 = resolve_blocking(x.shape, block_size, skip_first_dim)
+    if b0 != 1 or cols % b1 != 0 or b1 % 4 != 0:
+        return block_fp_quantize(x, width, exponent_width, exponent_bias, block_size, skip_first_dim).to(torch.bfloat16)
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_block_fp_quantize_bf16(_ptr(xc), _ptr(y), lead, rows, cols, b0, b1, int(width), int(exponent_width),
+                                               _default_bias(exponent_bias), _ptr(_workspace(x.device)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_fp_quantize_bf16")
+    return y
+
+
 def block_minifloat_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent_bias_width: int,
                              block_size, skip_first_dim: bool, *, want_bias: bool = False):
     _require_device(x, "block_minifloat_quantize")

@@ -197,11 +197,11 @@ class _LinearBase(nn.Linear):
             # the library's MFMA kernel (x through the HIP fake-quantiser; the in-place quantised weights cast once).
             # |x| <= 1e-8 pass-through elements are rounded to bf16 there (<= 2e-11 each).  "int8": the blockwise-exact
             # int8 kernel instead (mi355q_bfp_gemm_aligned with row_aligned = 2), exact integer block dots, ~5x slower.
-            xq = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
-                                       [1, 16], True)
+            xq = ops.block_fp_quantize_bf16(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                            [1, 16], True)
             if self._w_bf16 is None or self._w_bf16[1] != self.weight._version:
                 self._w_bf16 = (self.weight.detach().to(torch.bfloat16), self.weight._version)
-            y = torch.mm(xq.to(torch.bfloat16), self._w_bf16[0].t(), out_dtype=torch.float32)
+            y = torch.mm(xq, self._w_bf16[0].t(), out_dtype=torch.float32)
             if self.bias is not None:
                 y += self.bias
             return y.reshape(*x.shape[:-1], self.out_features)

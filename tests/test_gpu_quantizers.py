@@ -122,3 +122,23 @@ def test_cpu_tensor_is_refused():
     from mi355q import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.block_fp_quantize(torch.zeros(4, 16), 6, 8, 127, [1, 16], True)
+
+
+@pytest.mark.parametrize("shape,skip", [((300, 1024), True), ((3, 50, 64), True), ((64, 48), False), ((7, 40), True)])
+@pytest.mark.parametrize("width", [4, 6, 9])
+def test_block_fp_quantize_bf16_equals_fp32_quantiser_cast(shape, skip, width):
+    """bf16 output of the block_fp quantiser (operand of the bf16 GEMM in the unaligned Linear mode): the fp32 fake-quant
+    values are exact in bf16, so both routes give identical bits; |x| <= 1e-8 elements are rounded"""
+    import torch
+    from mi355q import ops
+    r = np.random.default_rng(sum(shape) + width)
+    x = (r.normal(size=shape) * np.exp(2 * r.normal(size=shape[:-1] + (1,)))).astype(np.float32)
+    x[..., :16] = 0.0
+    x.reshape(-1)[3] = 3e-9
+    xt = torch.from_numpy(x).to("cuda:0")
+    a = ops.block_fp_quantize_bf16(xt, width, 8, 127, [1, 16], skip)
+    b = ops.block_fp_quantize(xt, width, 8, 127, [1, 16], skip)
+    assert a.dtype == torch.bfloat16 and a.shape == xt.shape
+    assert torch.equal(a, b.to(torch.bfloat16))
+    big = b.abs() > 1e-8
+    assert torch.equal(a.float()[big], b[big])               # quantised values survive the format exactly

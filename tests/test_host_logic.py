@@ -72,6 +72,9 @@ def test_aligned_operand_entry_points_validate_without_a_gpu():
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 48, 4, None) == E_UNSUPPORTED
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 0, 4, 128, 4, None) == 0
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 2, None) == E_BADARG       # ldy < N
+    assert lib.mi355q_block_fp_quantize_bf16(p, p, 1, 4, 64, 1, 16, 12, 8, 127, p, None) == E_UNSUPPORTED   # width > 9
+    assert lib.mi355q_block_fp_quantize_bf16(p, None, 1, 4, 64, 1, 16, 6, 8, 127, p, None) == E_BADARG
+    assert lib.mi355q_block_fp_quantize_bf16(p, p, 1, 0, 64, 1, 16, 6, 8, 127, p, None) == 0
     # fused quantise + matmul: blocks of 16 must tile K and N, widths must fit bf16, pointers
     assert lib.mi355q_bfp_matmul_workspace_bytes(12, 2048, 64) == 12 * 2048 * 64 * 2 + 64 and lib.mi355q_bfp_matmul_workspace_bytes(1, 80, 16) == 128 * 16 * 2 + 64 and lib.mi355q_bfp_matmul_workspace_bytes(0, 4, 4) == 0
     mm = lambda *a: lib.mi355q_bfp_matmul(*a)

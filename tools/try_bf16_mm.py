@@ -23,4 +23,5 @@ for (M, N, K) in ((2048, 768, 2048), (2048, 4096, 11008), (4096, 4096, 4096)):
     t_mm = t(lambda: torch.mm(xb, wb.t(), out_dtype=torch.float32))
     t_q = t(lambda: ops.block_fp_quantize(x, 6, 8, 127, [1, 16], True).bfloat16())
     t_f32 = t(lambda: xq @ wq.t())
-    print(M, N, K, "bf16 mm->fp32", round(t_mm, 1), "us", round(2 * M * N * K / t_mm / 1e6), "TFLOP/s | quant+cast", round(t_q, 1), "us | fp32 mm", round(t_f32, 1), "us | rel err", err)
+    t_qb = t(lambda: ops.block_fp_quantize_bf16(x, 6, 8, 127, [1, 16], True))
+    print(M, N, K, "bf16 mm->fp32", round(t_mm, 1), "us", round(2 * M * N * K / t_mm / 1e6), "TFLOP/s | quant+cast", round(t_q, 1), "us | quant->bf16 direct", round(t_qb, 1), "us | fp32 mm", round(t_f32, 1), "us | rel err", err)
