@@ -136,16 +136,16 @@ class _LinearBase(nn.Linear):
             self._x_cap = ops.ROW_NO_ALIGN
             return "rows"
         if x_sample is not None:
-            # activations: the GEMM's in-LDS add-back while a tile's entries fit it, else large buckets + the row
-            # post-pass (no per-tile limit: post-activation inputs); groups only if even those overflow
+            # activations: the GEMM's in-LDS add-back while a tile's entries fit it; otherwise (post-activation inputs:
+            # hundreds of exception blocks per 256 rows after a ReLU, no usable row window at all after a SiLU gate) no
+            # alignment -- measured faster than the row post-pass wherever that one applies (tools/time_linear_modes.py;
+            # "rows_post" remains available explicitly)
             xa = ops.block_fp_quantize_aligned_rows(x_sample.reshape(-1, self.in_features), c["data_in_width"],
                                                     c["data_in_exponent_width"], c["data_in_exponent_bias"],
                                                     bucket_cap=ops.ROW_BUCKET_CAP_MAX)
             x_over, x_max = ops.row_list_fill(xa.sparse, xa.rows, xa.list_cap)
-            if x_over != 0:             # no row window fits these activations (SiLU-gated MLP inputs): blockwise kernel
-                self._x_cap = ops.ROW_NO_ALIGN
-            else:
-                self._x_cap = ops.ROW_BUCKET_CAP if w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST else ops.ROW_BUCKET_CAP_MAX
+            fits = x_over == 0 and w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST
+            self._x_cap = ops.ROW_BUCKET_CAP if fits else ops.ROW_NO_ALIGN
         return "rows"
 
     def _align_weights(self, wm, we, mode):
@@ -222,12 +222,9 @@ class _LinearBase(nn.Linear):
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats
             self._calls += 1
             if self._calls & (self._calls - 1) == 0 and int(xa.sparse[0]) != 0:
-                if self._x_cap != ops.ROW_BUCKET_CAP_MAX:
-                    self._x_cap = ops.ROW_BUCKET_CAP_MAX          # first: larger buckets + the row post-pass
-                else:
-                    self._row_overflows += 1
-                    if self._row_overflows >= 2:
-                        self._x_cap = ops.ROW_NO_ALIGN            # then none at all: the blockwise-exact kernel
+                self._row_overflows += 1
+                if self._row_overflows >= 2:
+                    self._x_cap = ops.ROW_NO_ALIGN                # activations stopped fitting: no alignment from now on
         return y.reshape(*x.shape[:-1], self.out_features)
 
     @classmethod
