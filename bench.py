@@ -81,6 +81,27 @@ def cpu_baseline(torch):
             "sample": f"full 4096x4096x4096 steady-state PTQ linear (fake-quant x + fp32 F.linear), median of {iters} iterations"}
 
 
+def verify(torch, ops, x, w, b, y, rows=64):
+    """Outside the timed region: (1) the activation quantiser's shared exponents and mantissas at the FULL
+    4096 x 4096 size, bit for bit against the oracle (BASELINE config 2); (2) `rows` sampled rows x all columns of
+    the step's y against the oracle's exact integer contraction.  -> dict; "ok" False makes bench.py exit 1."""
+    import numpy as np
+    from oracle import np_oracle as O
+    xs, ws, bs = x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy()
+    _, xm, xe = ops.block_fp_quantize(x, CFG["data_in_width"], 8, 127, [1, 16], True, want_fake=False, want_packed=True)
+    code = O.bfp_encode(xs, CFG["data_in_width"], 8, 127, [1, 16], True)
+    exp_ok = bool(np.array_equal(xe.cpu().numpy().astype(np.int32) - 127, code.exp))
+    mant_ok = bool(np.array_equal(xm.cpu().numpy().reshape(-1, 16).astype(np.int32), code.mant))
+    pick = np.sort(np.random.default_rng(5).choice(xs.shape[0], size=rows, replace=False))
+    ref = O.bfp_linear_int(xs[pick], ws, bs, CFG)
+    got = y[torch.from_numpy(pick).to(y.device)].cpu().numpy()
+    err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    tol = 1e-5            # north_star allows 1e-3 on the dequantised GEMM result; the int path is held to 1e-5
+    return {"ok": exp_ok and mant_ok and err <= tol, "exponents_bit_exact": exp_ok, "mantissas_bit_exact": mant_ok,
+            "blocks_checked": int(code.exp.size), "gemm_rows_checked": int(rows), "gemm_cols_checked": int(ref.shape[1]),
+            "gemm_max_rel_err": err, "gemm_tol": tol}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (counters cannot be read inside a
     timed run: one counter per rocprofv3 pass, tools/cdriver/step_driver runs the same step through the C ABI)"""
@@ -98,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shard", choices=["tokens", "out_features"], default="tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed step's output")
     ap.add_argument("--variant", type=int, default=0, help="GEMM kernel variant (0 = automatic)")
     ap.add_argument("--align", choices=["rows", "groups"], default="rows",
                     help="exponent alignment of the packed operands: whole rows (row-scale int8 GEMM) or 256-value groups")
@@ -166,6 +188,7 @@ def main():
     total_flops = flops_step * args.steps * world
     value = total_flops / dt / 1e12
 
+    failed = False
     if rank == 0:
         achieved = flops_step / (gemm_avg_ms * 1e-3) / 1e12
         traffic = pmc_traffic("mi355q::bfp_gemm_v8<1, 8, false>") if rows_mode and (M, N, K) == (4096, 4096, 4096) else None
@@ -188,11 +211,17 @@ def main():
                                          "tools/cdriver/step_driver; profiles/r01_pmc_traffic.json)" if traffic else None,
                          "avg_launch_ms": round(gemm_avg_ms, 4), "min_launch_ms": round(gemm_min_ms, 4), "launches_timed": n_timed},
         }
+        if not args.no_verify:
+            out["verify"] = verify(torch, ops, x, w, b, y)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(out), flush=True)
+        if not args.no_verify and not out["verify"]["ok"]:
+            failed = True
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: the timed step's output does not match the oracle")
 
 
 if __name__ == "__main__":

@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .quantize import get_quantized_cls, get_quantized_func, parse_node_config
+from .quantize import get_quantized_cls, get_quantized_func
+from .quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
 
 
 @dataclass
@@ -31,17 +32,13 @@ class TinyOPTConfig:
     init_std: float = 0.02        # HF OPT initializer range (modeling_opt.py:472-477)
 
 
-def expand_quant_config(default: dict, num_layers: int) -> dict:
-    """[default] -> model_layer_i x {q,k,v,out_proj,bmm_0,bmm_1,fc1,fc2}, each through parse_node_config
-    (what reference quant_config_opt.py:45-97 does for a TOML with only a [default] section)."""
-    out = {}
-    for i in range(num_layers):
-        attn = {k: parse_node_config(dict(default), "linear") for k in ("q_proj", "k_proj", "v_proj", "out_proj")}
-        attn["bmm_0"] = parse_node_config(dict(default), "bmm")
-        attn["bmm_1"] = parse_node_config(dict(default), "bmm")
-        out[f"model_layer_{i}"] = {"self_attn": attn, "fc1": parse_node_config(dict(default), "linear"),
-                                   "fc2": parse_node_config(dict(default), "linear")}
-    return out
+def expand_quant_config(config: dict, num_layers: int) -> dict:
+    """TOML-level dict -> per-layer node configs, as the reference's `parse_opt_quantized_config`
+    (quant_config_opt.py:61-113: [default], optional [linear] / [bmm], [model_layer], [model_layer_<i>]).  A bare
+    [default] body (a dict with a "name" key) is accepted as shorthand for {"default": body}."""
+    if "default" not in config and "name" in config:
+        config = {"default": dict(config)}
+    return parse_opt_quantized_config(config, num_layers)
 
 
 class _Attention(nn.Module):
@@ -103,6 +100,28 @@ class TinyOPTForCausalLM(nn.Module):
         elif isinstance(m, nn.Embedding):
             m.weight.data.normal_(0.0, self.cfg.init_std)
 
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd: dict):
+        """load a state dict with the reference's (HF OPT) names: `model.decoder.` prefix, learned positions stored
+        with an offset of 2 (modeling_opt.py:115-140)"""
+        own = {}
+        for k, v in sd.items():
+            k = k.removeprefix("model.decoder.")
+            v = torch.as_tensor(v)
+            own[k] = v[2:2 + self.cfg.max_positions] if k == "embed_positions.weight" else v
+        self.load_state_dict(own, strict=True)
+        return self
+
+    def reference_state_dict(self) -> dict:
+        """this model's parameters under the reference's names (inverse of load_reference_state_dict)"""
+        out = {}
+        for k, v in self.state_dict().items():
+            v = v.detach()
+            if k == "embed_positions.weight":
+                v = torch.cat([torch.zeros(2, v.shape[1], dtype=v.dtype, device=v.device), v])
+            out[k if k.startswith("lm_head") else "model.decoder." + k] = v
+        return out
+
     def forward(self, input_ids, labels=None):
         B, T = input_ids.shape
         pos = torch.arange(T, device=input_ids.device)
@@ -129,18 +148,11 @@ class TinyLlamaConfig:
     init_std: float = 0.02
 
 
-def expand_llama_quant_config(default: dict, num_layers: int) -> dict:
-    """[default] -> model_layer_i x {q,k,v,o_proj, rotary_positional_encoding, matmul_0, matmul_1, gate/up/down_proj}
-    (what the reference's quant_config_llama.py builds from a TOML with only a [default] section)."""
-    out = {}
-    for i in range(num_layers):
-        attn = {k: parse_node_config(dict(default), "linear") for k in ("q_proj", "k_proj", "v_proj", "o_proj")}
-        attn["rotary_positional_encoding"] = parse_node_config(dict(default), "rotary_positional_encoding")
-        attn["matmul_0"] = parse_node_config(dict(default), "matmul")
-        attn["matmul_1"] = parse_node_config(dict(default), "matmul")
-        mlp = {k: parse_node_config(dict(default), "linear") for k in ("gate_proj", "up_proj", "down_proj")}
-        out[f"model_layer_{i}"] = {"self_attn": attn, "mlp": mlp}
-    return out
+def expand_llama_quant_config(config: dict, num_layers: int) -> dict:
+    """the same through `parse_llama_quantized_config` (quant_config_llama.py:70-130)"""
+    if "default" not in config and "name" in config:
+        config = {"default": dict(config)}
+    return parse_llama_quantized_config(config, num_layers)
 
 
 class _RMSNorm(nn.Module):
@@ -213,6 +225,27 @@ class TinyLlamaForCausalLM(nn.Module):
         for m in self.modules():
             if isinstance(m, (nn.Linear, nn.Embedding)):
                 m.weight.data.normal_(0.0, cfg.init_std)
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd: dict):
+        """load a state dict with the reference's (HF Llama) names: `model.` prefix, `layers.i.mlp.*` projections,
+        `rotary_emb.inv_freq` buffers skipped (the tables are rebuilt from the same formula)"""
+        own = {}
+        for k, v in sd.items():
+            k = k.removeprefix("model.").replace(".mlp.", ".")
+            if k.endswith("rotary_emb.inv_freq"):
+                continue
+            own[k] = torch.as_tensor(v)
+        self.load_state_dict(own, strict=True)
+        return self
+
+    def reference_state_dict(self) -> dict:
+        out = {}
+        for k, v in self.state_dict().items():
+            for proj in ("gate_proj", "up_proj", "down_proj"):
+                k = k.replace("." + proj, ".mlp." + proj)
+            out[k if k.startswith("lm_head") else "model." + k] = v.detach()
+        return out
 
     def forward(self, input_ids, labels=None):
         B, T = input_ids.shape

@@ -11,45 +11,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _oracle_forward(model, cfg_default, ids):
-    """numpy/float64 evaluation of TinyOPTForCausalLM with oracle quantisers (PTQ semantics)"""
-    import torch
-    from oracle import np_oracle as O
-    sd = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in model.state_dict().items()}
-    c = model.cfg
-    B, T = ids.shape
-    nh, hd = c.num_heads, c.hidden_size // c.num_heads
-
-    def ln(x, p):
-        mu = x.mean(-1, keepdims=True)
-        var = ((x - mu) ** 2).mean(-1, keepdims=True)
-        return ((x - mu) / np.sqrt(var + 1e-5) * sd[p + ".weight"] + sd[p + ".bias"]).astype(np.float32)
-
-    def lin(x, p):
-        y, _, _ = O.linear_ptq(x, sd[p + ".weight"], sd[p + ".bias"], cfg_default)
-        return y
-
-    x = sd["embed_tokens.weight"][ids] + sd["embed_positions.weight"][np.arange(T)][None]
-    mask = np.triu(np.full((T, T), np.finfo(np.float32).min, np.float32), 1)[None, None]
-    for i in range(c.num_layers):
-        pre = f"layers.{i}."
-        h = ln(x, pre + "self_attn_layer_norm")
-        shape = lambda t: t.reshape(B, T, nh, hd).transpose(0, 2, 1, 3).reshape(B * nh, T, hd)
-        q = shape(lin(h, pre + "self_attn.q_proj") * np.float32(hd ** -0.5))
-        k, v = shape(lin(h, pre + "self_attn.k_proj")), shape(lin(h, pre + "self_attn.v_proj"))
-        w = O.matmul_quantized(q, np.ascontiguousarray(k.transpose(0, 2, 1)), cfg_default)
-        w = np.maximum(w.reshape(B, nh, T, T) + mask, np.finfo(np.float32).min).reshape(B * nh, T, T)
-        w = w - w.max(-1, keepdims=True)
-        p = (np.exp(w) / np.exp(w).sum(-1, keepdims=True)).astype(np.float32)
-        o = O.matmul_quantized(p, v, cfg_default).reshape(B, nh, T, hd).transpose(0, 2, 1, 3).reshape(B, T, c.hidden_size)
-        x = x + lin(o, pre + "self_attn.out_proj")
-        h2 = x.reshape(-1, c.hidden_size)
-        f = lin(np.maximum(lin(ln(h2, pre + "final_layer_norm"), pre + "fc1"), 0), pre + "fc2")
-        x = (h2 + f).reshape(B, T, c.hidden_size)
-    logits = ln(x, "final_layer_norm").astype(np.float64) @ sd["lm_head.weight"].astype(np.float64).T
-    lg = logits[:, :-1].reshape(-1, c.vocab_size)
-    tgt = ids[:, 1:].reshape(-1)
-    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
-    return float((lse - lg[np.arange(tgt.size), tgt]).mean())
+    """numpy evaluation of the harness model with the oracle's quantisers (oracle/np_models.py, itself pinned against
+    the reference's own model classes by tests/test_oracle_models.py)"""
+    from oracle import np_models as NM
+    from mi355q.harness import expand_quant_config
+    sd = {k: v.cpu().numpy().astype(np.float32) for k, v in model.reference_state_dict().items()}
+    return NM.opt_forward(sd, expand_quant_config(cfg_default, model.cfg.num_layers), ids, model.cfg.num_heads)[1]
 
 
 @pytest.mark.parametrize("toml_default", [
@@ -90,56 +57,11 @@ def test_tiny_opt_loss_parity(toml_default):
 
 
 def _oracle_llama_forward(model, cfg_default, ids):
-    """numpy evaluation of TinyLlamaForCausalLM with the oracle's quantisers: RMSNorm, rotary embedding with
-    quantised cos / sin tables (rotary_positional_encoding.py:59-82), 4-D quantised products (matmul.py:146-196),
-    SiLU-gated MLP, all Linear layers bias-free (PTQ semantics)"""
-    from oracle import np_oracle as O
-    sd = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in model.state_dict().items()}
-    c = model.cfg
-    B, T = ids.shape
-    nh, hd = c.num_heads, c.hidden_size // c.num_heads
-    f32 = np.float32
-
-    def rms(x, p):
-        v = (x.astype(np.float32) ** 2).mean(-1, keepdims=True)
-        return (sd[p + ".weight"] * (x * (f32(1.0) / np.sqrt(v + f32(c.rms_eps)))).astype(np.float32)).astype(np.float32)
-
-    def lin(x, p):
-        return O.linear_ptq(x, sd[p + ".weight"], None, cfg_default)[0]
-
-    def rot_half(t):
-        h = t.shape[-1] // 2
-        return np.concatenate([-t[..., h:], t[..., :h]], axis=-1)
-
-    # the model's own fp32 cos / sin tables (buffers, not in the state dict): the quantised tables are what is compared
-    cos_t = model.layers[0].self_attn.cos.detach().cpu().numpy()[0, 0, :T].astype(np.float32)
-    sin_t = model.layers[0].self_attn.sin.detach().cpu().numpy()[0, 0, :T].astype(np.float32)
-    kw = {k: cfg_default[f"data_in_{k}"] for k in ("width", "exponent_width", "exponent_bias", "block_size")}
-    cos = O.block_fp_quantize(cos_t, **kw, skip_first_dim=False)[None, None]
-    sin = O.block_fp_quantize(sin_t, **kw, skip_first_dim=False)[None, None]
-    x = sd["embed_tokens.weight"][ids]
-    mask = np.triu(np.full((T, T), np.finfo(np.float32).min, np.float32), 1)[None, None]
-    for i in range(c.num_layers):
-        pre = f"layers.{i}."
-        h = rms(x, pre + "input_layernorm")
-        shape = lambda t: t.reshape(B, T, nh, hd).transpose(0, 2, 1, 3)
-        q, k, v = (shape(lin(h, pre + f"self_attn.{n}_proj")) for n in "qkv")
-        q, k = (q * cos + rot_half(q) * sin).astype(np.float32), (k * cos + rot_half(k) * sin).astype(np.float32)
-        w = O.matmul_quantized(q, np.ascontiguousarray(k.transpose(0, 1, 3, 2)), cfg_default)
-        w = np.maximum((w / f32(math.sqrt(hd))).astype(np.float32) + mask, np.finfo(np.float32).min)
-        w = w - w.max(-1, keepdims=True)
-        p = (np.exp(w) / np.exp(w).sum(-1, keepdims=True)).astype(np.float32)
-        o = O.matmul_quantized(p, np.ascontiguousarray(v), cfg_default).transpose(0, 2, 1, 3).reshape(B, T, c.hidden_size)
-        x = x + lin(o, pre + "self_attn.o_proj")
-        h2 = rms(x, pre + "post_attention_layernorm")
-        g = lin(h2, pre + "gate_proj")
-        act = (g / (f32(1.0) + np.exp(-g))).astype(np.float32) * lin(h2, pre + "up_proj")
-        x = x + lin(act.astype(np.float32), pre + "down_proj")
-    logits = rms(x, "norm").astype(np.float64) @ sd["lm_head.weight"].astype(np.float64).T
-    lg = logits[:, :-1].reshape(-1, c.vocab_size)
-    tgt = ids[:, 1:].reshape(-1)
-    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
-    return float((lse - lg[np.arange(tgt.size), tgt]).mean())
+    from oracle import np_models as NM
+    from mi355q.harness import expand_llama_quant_config
+    sd = {k: v.cpu().numpy().astype(np.float32) for k, v in model.reference_state_dict().items()}
+    return NM.llama_forward(sd, expand_llama_quant_config(cfg_default, model.cfg.num_layers), ids, model.cfg.num_heads,
+                            model.cfg.rms_eps)[1]
 
 
 @pytest.mark.parametrize("width", [6, 4])
@@ -168,3 +90,42 @@ def test_tiny_llama_loss_parity(width):
     assert model.layers[0].down_proj._packed is not None, "int8-MFMA path not taken by the MLP"
     res2 = eval_lm_perplexity(model, [ids], device="cuda:0")
     assert abs(res2["loss"] - res["loss"]) < 1e-6
+
+
+# ---- G5: fixtures from the REFERENCE's own model classes (tools/gen_golden_models.py) -------------------------------
+import json as _json
+from tests.conftest import GOLDEN as _GOLDEN
+_G5 = _json.loads((_GOLDEN / "models.json").read_text())
+
+
+@pytest.mark.parametrize("tag", sorted(_G5))
+def test_reference_model_fixture(tag):
+    """weights + token ids + logits + loss of the reference's OPTQuantizedForCausalLM / LlamaQuantizedForCausalLM
+    (2 layers; W6A6, W4A4, mixed per-layer widths, K % 128 == 0 variants that take the int8 GEMM): the harness on the
+    GPU, driven through the registry API with the reference's per-layer config, must reproduce them."""
+    import torch
+    from mi355q import harness as H
+    from oracle import np_models as NM
+    data = np.load(_GOLDEN / "models.npz")
+    sd, _, ids, ref_logits, ref_loss, m = NM.load_fixture(_G5, data, tag)
+    if m["family"] == "opt":
+        cfg = H.TinyOPTConfig(vocab_size=m["vocab_size"], hidden_size=m["hidden_size"], ffn_dim=m["ffn_dim"],
+                              num_layers=m["num_layers"], num_heads=m["num_heads"], max_positions=m["max_positions"])
+        model = H.TinyOPTForCausalLM(cfg, H.expand_quant_config(m["quant_config"], cfg.num_layers))
+    else:
+        cfg = H.TinyLlamaConfig(vocab_size=m["vocab_size"], hidden_size=m["hidden_size"],
+                                intermediate_size=m["intermediate_size"], num_layers=m["num_layers"],
+                                num_heads=m["num_heads"], max_positions=m["max_positions"], rms_eps=m["rms_eps"])
+        model = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(m["quant_config"], cfg.num_layers))
+    model.load_reference_state_dict(sd).to("cuda:0").eval()
+    t = torch.from_numpy(ids).to("cuda:0")
+    with torch.no_grad():
+        logits, loss = model(t, labels=t)
+    err = float(np.abs(logits.cpu().numpy() - ref_logits).max())
+    dl = abs(float(loss) - ref_loss)
+    print(f"{tag}: max|dlogit| {err:.2e}  |dloss| {dl:.2e}  ppl {math.exp(float(loss)):.4f} vs {math.exp(ref_loss):.4f}")
+    assert err < 1e-3 * max(1.0, float(np.abs(ref_logits).max())), err          # north_star: fp tolerance <= 1e-3
+    assert dl < 2e-5, (float(loss), ref_loss)
+    if "k128" in tag:
+        lin = model.layers[0].fc2 if m["family"] == "opt" else model.layers[0].down_proj
+        assert lin._packed is not None, "K % 128 == 0 layer did not take the int8 path"

@@ -1,0 +1,81 @@
+"""The row-sharded quantised Linear on the GPU with backend "nccl" (= RCCL): world size 1 always, world size 2 when
+the box has two GPUs.  Quantised path (W4A4 and W6A6), result == the unsharded layer bit for bit (a row split never
+cuts a [1,16] weight block)."""
+import os
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cfg(width):
+    return dict(name="block_fp", is_ptq=True, bypass=False,
+                data_in_width=width, data_in_exponent_width=8, data_in_exponent_bias=127, data_in_block_size=[1, 16],
+                weight_width=width, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
+                bias_width=width, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import mi355q.quantize as Q
+        from mi355q.sharded import RowShardedLinear
+        from oracle import np_oracle as O
+        res = []
+        for width, (K, N, M) in ((4, (2048, 8192, 256)), (6, (1024, 1024, 300))):     # OPT-1.3B fc1 shape, W4A4 (config 4)
+            cfg = _cfg(width)
+            torch.manual_seed(7)
+            full = torch.nn.Linear(K, N)
+            x = (torch.randn(2, M // 2, K) * torch.exp(torch.randn(2, M // 2, 1))).to(dev)
+            cls = Q.get_quantized_cls("linear", cfg)
+            sh = RowShardedLinear.from_full(cls, full.to(dev), cfg)
+            y = sh(x)
+            whole = cls.from_float(full, cfg).to(dev)
+            y_ref = whole(x)
+            same = bool(torch.equal(y, y_ref))
+            ref = O.bfp_linear_int(x[0, :16].cpu().numpy(), full.weight.detach().cpu().numpy(),
+                                   full.bias.detach().cpu().numpy(), cfg)
+            err = float((y[0, :16].cpu() - torch.from_numpy(ref)).abs().max() / abs(ref).max())
+            res.append((width, same, err, tuple(y.shape), sh.local._packed is not None))
+        q.put((rank, res))
+    except Exception as e:
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(e))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_row_sharded_linear_nccl(world):
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert not isinstance(res, str), res
+        for width, same, err, shape, packed in res:
+            assert same, f"rank {rank} W{width}: sharded output differs from the unsharded layer"
+            assert err < 1e-5, (rank, width, err)
+            assert packed, "the shard did not take the int8 path"

@@ -1,0 +1,45 @@
+"""G5: the model-level oracle (oracle/np_models.py) and the per-layer config expansion against fixtures generated
+from the REFERENCE's own model classes (tools/gen_golden_models.py -> tests/golden/models.*): tiny OPT / Llama,
+W6A6, W4A4, mixed per-layer widths ([model_layer_i] sections), K % 128 == 0 variants."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+from oracle import np_models as NM
+
+META = json.loads((GOLDEN / "models.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def data():
+    return np.load(GOLDEN / "models.npz")
+
+
+@pytest.mark.parametrize("tag", sorted(META))
+def test_config_expansion_matches_reference(tag):
+    from mi355q.quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
+    m = META[tag]
+    parse = parse_opt_quantized_config if m["family"] == "opt" else parse_llama_quantized_config
+    mine = parse(json.loads(json.dumps(m["quant_config"])), m["num_layers"])
+    assert mine == m["parsed_quant_config"]
+
+
+def test_mixed_config_really_is_mixed():
+    qc = META["opt_mixed"]["parsed_quant_config"]
+    assert qc["model_layer_0"]["fc2"]["weight_width"] == 2 and qc["model_layer_1"]["fc2"]["weight_width"] == 6
+    assert qc["model_layer_0"]["self_attn"]["bmm_0"]["data_in_width"] == 5
+    assert qc["model_layer_0"]["fc1"]["data_in_exponent_bias"] is None          # "NA" -> None
+
+
+@pytest.mark.parametrize("tag", sorted(META))
+def test_oracle_model_forward_matches_reference(tag, data):
+    sd, qc, ids, ref_logits, ref_loss, m = NM.load_fixture(META, data, tag)
+    if m["family"] == "opt":
+        logits, loss = NM.opt_forward(sd, qc, ids, m["num_heads"])
+    else:
+        logits, loss = NM.llama_forward(sd, qc, ids, m["num_heads"], m["rms_eps"])
+    assert np.abs(logits - ref_logits).max() < 1e-5
+    assert abs(loss - ref_loss) < 2e-6
+    assert round(float(np.exp(loss)), 3) == round(float(np.exp(ref_loss)), 3)

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""G5 golden fixtures: tiny OPT / Llama models built from the REFERENCE's own model classes
+(`models/opt_quantized/modeling_opt.py`, `models/llama_quantized/modeling_llama.py`) and its own per-layer
+quant-config expansion (`quant_config_opt.py:61-97`, `quant_config_llama.py:70-116`), run here on CPU.
+
+Run in the build container only (needs /root/reference).  Writes tests/golden/models.npz + models.json:
+the (fp32, un-quantised) weights, the token ids, the quant config as the TOML-level dict the reference
+parser takes, the reference's PARSED per-layer config, and the reference's logits + loss.  Data only.
+
+    python tools/gen_golden_models.py
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.util
+import json
+import logging
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+SRC = Path("/root/reference/src/llm_mixed_q")
+OUT = ROOT / "tests" / "golden"
+
+
+def _stub_third_party():
+    """optuna / toml / colorlog are absent from the image and are not on the forward path"""
+    if "optuna" not in sys.modules:
+        opt = types.ModuleType("optuna")
+        opt.Trial = opt.Study = object
+        opt.trial = types.ModuleType("optuna.trial")
+        opt.trial.FrozenTrial = object
+        sys.modules["optuna"], sys.modules["optuna.trial"] = opt, opt.trial
+    if "toml" not in sys.modules:
+        import tomli
+        t = types.ModuleType("toml")
+        t.load = lambda p: tomli.loads(Path(p).read_text())
+        t.loads = tomli.loads
+        sys.modules["toml"] = t
+    if "colorlog" not in sys.modules:
+        c = types.ModuleType("colorlog")
+
+        class ColoredFormatter(logging.Formatter):
+            def __init__(self, fmt=None, *a, **k):
+                import re
+                super().__init__(re.sub(r"%\((log_color|reset)\)s", "", fmt or "%(message)s"))
+        c.ColoredFormatter = ColoredFormatter
+        sys.modules["colorlog"] = c
+
+
+def load_reference_models():
+    """llm_mixed_q / llm_mixed_q.models as bare namespace packages (models/__init__.py pulls in a BERT file
+    that does not import under transformers 5.x), then the two model sub-packages by their real names."""
+    _stub_third_party()
+    for name, path in (("llm_mixed_q", SRC), ("llm_mixed_q.models", SRC / "models")):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [str(path)]
+            sys.modules[name] = m
+    opt = importlib.import_module("llm_mixed_q.models.opt_quantized.modeling_opt")
+    optc = importlib.import_module("llm_mixed_q.models.opt_quantized.configuration_opt")
+    llama = importlib.import_module("llm_mixed_q.models.llama_quantized.modeling_llama")
+    llamac = importlib.import_module("llm_mixed_q.models.llama_quantized.configuration_llama")
+    return opt, optc, llama, llamac
+
+
+def bfp_default(x_w, w_w, b_w=None):
+    """[default] section in the shipped TOMLs' form (configs/quantization/bfp_6bit.toml:5-16)"""
+    b_w = w_w if b_w is None else b_w
+    return dict(name="block_fp", bypass=False, is_ptq=True,
+                data_in_width=x_w, data_in_exponent_width=8, data_in_exponent_bias=127, data_in_block_size=[1, 16],
+                weight_width=w_w, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
+                bias_width=b_w, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+
+
+def mixed_opt_config():
+    """per-layer mixed widths the way the search writes them (search.py save_best -> TOML with model_layer_i
+    sections): layer 0 overrides some nodes, layer 1 falls back to [default]; exponent_bias None -> 127."""
+    d = bfp_default(6, 6)
+    for k in ("data_in_exponent_bias", "weight_exponent_bias", "bias_exponent_bias"):
+        d[k] = "NA"                                  # the TOML spelling of None (utils/config_load.py)
+    def node(xw, ww):
+        n = dict(d)
+        n.update(data_in_width=xw, weight_width=ww, bias_width=ww)
+        return n
+    return {"default": d,
+            "model_layer_0": {"self_attn": {"q_proj": node(4, 5), "k_proj": node(5, 3), "v_proj": node(6, 4),
+                                            "out_proj": node(3, 4), "bmm_0": node(5, 4), "bmm_1": node(4, 6)},
+                              "fc1": node(4, 4), "fc2": node(5, 2)}}
+
+
+def mixed_llama_config():
+    d = bfp_default(6, 6)
+    def node(xw, ww):
+        n = dict(d)
+        n.update(data_in_width=xw, weight_width=ww, bias_width=ww)
+        return n
+    return {"default": d,
+            "model_layer_1": {"self_attn": {"q_proj": node(4, 5), "k_proj": node(5, 3), "v_proj": node(6, 4),
+                                            "o_proj": node(3, 4), "rotary_positional_encoding": node(5, 5),
+                                            "matmul_0": node(5, 4), "matmul_1": node(4, 6)},
+                              "mlp": {"gate_proj": node(4, 4), "up_proj": node(5, 3), "down_proj": node(4, 5)}}}
+
+
+def _jsonable(o):
+    if isinstance(o, dict):
+        return {k: _jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_jsonable(v) for v in o]
+    return o
+
+
+def run_opt(opt, optc, tag, qcfg, arrays, meta, hidden=64, ffn=256, layers=2, heads=4, vocab=128, T=24, B=2, seed=0):
+    torch.manual_seed(seed)
+    cfg = optc.OPTQuantizedConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, ffn_dim=ffn,
+                                  max_position_embeddings=64, num_attention_heads=heads, dropout=0.0,
+                                  word_embed_proj_dim=hidden, quant_config=json.loads(json.dumps(qcfg)))
+    model = opt.OPTQuantizedForCausalLM(cfg).eval()
+    # random weights with some spread (HF init is N(0, 0.02) with zero biases: give biases and norms life)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.08 if "embed" not in n else 0.5))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ids = torch.randint(3, vocab, (B, T), generator=g)
+    with torch.no_grad():
+        out = model(input_ids=ids, labels=ids)
+    for k, v in sd.items():
+        arrays[f"{tag}/w/{k}"] = v.numpy()
+    arrays[f"{tag}/input_ids"] = ids.numpy()
+    arrays[f"{tag}/logits"] = out.logits.numpy()
+    meta[tag] = dict(family="opt", hidden_size=hidden, ffn_dim=ffn, num_layers=layers, num_heads=heads, vocab_size=vocab,
+                     max_positions=64, loss=float(out.loss), quant_config=_jsonable(qcfg),
+                     parsed_quant_config=_jsonable({k: v for k, v in cfg.quant_config.items()}))
+    print(f"{tag}: loss {float(out.loss):.6f}")
+
+
+def run_llama(llama, llamac, tag, qcfg, arrays, meta, hidden=64, inter=128, layers=2, heads=4, vocab=128, T=24, B=2, seed=0):
+    torch.manual_seed(seed)
+    cfg = llamac.LlamaQuantizedConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=inter,
+                                      num_hidden_layers=layers, num_attention_heads=heads, max_position_embeddings=64,
+                                      quant_config=json.loads(json.dumps(qcfg)))
+    model = llama.LlamaQuantizedForCausalLM(cfg).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.08 if "embed" not in n else 0.5))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ids = torch.randint(3, vocab, (B, T), generator=g)
+    with torch.no_grad():
+        out = model(input_ids=ids, labels=ids)
+    for k, v in sd.items():
+        arrays[f"{tag}/w/{k}"] = v.numpy()
+    arrays[f"{tag}/input_ids"] = ids.numpy()
+    arrays[f"{tag}/logits"] = out.logits.numpy()
+    meta[tag] = dict(family="llama", hidden_size=hidden, intermediate_size=inter, num_layers=layers, num_heads=heads,
+                     vocab_size=vocab, max_positions=64, rms_eps=float(cfg.rms_norm_eps), loss=float(out.loss),
+                     quant_config=_jsonable(qcfg),
+                     parsed_quant_config=_jsonable({k: v for k, v in cfg.quant_config.items()}))
+    print(f"{tag}: loss {float(out.loss):.6f}")
+
+
+def main():
+    torch.set_num_threads(4)
+    opt, optc, llama, llamac = load_reference_models()
+    arrays, meta = {}, {}
+    run_opt(opt, optc, "opt_w6a6", {"default": bfp_default(6, 6)}, arrays, meta, seed=0)
+    run_opt(opt, optc, "opt_w4a4", {"default": bfp_default(4, 4)}, arrays, meta, seed=10)
+    run_opt(opt, optc, "opt_mixed", mixed_opt_config(), arrays, meta, seed=20)
+    # a K % 128 == 0 model so that the reference's outputs check the int8 GEMM path directly
+    run_opt(opt, optc, "opt_w6a6_k128", {"default": bfp_default(6, 6)}, arrays, meta, hidden=128, ffn=256, heads=2, seed=30)
+    run_llama(llama, llamac, "llama_w6a6", {"default": bfp_default(6, 6)}, arrays, meta, seed=40)
+    run_llama(llama, llamac, "llama_w4a4", {"default": bfp_default(4, 4)}, arrays, meta, seed=50)
+    run_llama(llama, llamac, "llama_mixed", mixed_llama_config(), arrays, meta, seed=60)
+    run_llama(llama, llamac, "llama_w6a6_k128", {"default": bfp_default(6, 6)}, arrays, meta, hidden=128, inter=256, heads=2, seed=70)
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / "models.npz", **arrays)
+    (OUT / "models.json").write_text(json.dumps(meta, indent=1))
+    print(f"models: {len(meta)} cases, {sum(a.nbytes for a in arrays.values()) / 1e6:.2f} MB raw")
+
+
+if __name__ == "__main__":
+    main()
