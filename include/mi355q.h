@@ -34,13 +34,16 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 3
+#define MI355Q_ABI_VERSION 4
 #define MI355Q_WORKSPACE_BYTES 256
 
 /* negative error codes (positive values are hipError_t) */
 #define MI355Q_E_BADARG (-1)      /* null pointer, non-positive size, width out of range */
 #define MI355Q_E_UNSUPPORTED (-2) /* legal for the reference, not built here (message says what) */
 #define MI355Q_E_ALIGN (-3)       /* pointer / leading dimension alignment requirement violated */
+
+/* exponent_bias argument: "none given" (the reference's exponent_bias=None -> 2^(exponent_width-1)-1) */
+#define MI355Q_BIAS_DEFAULT INT32_MIN
 
 /* flags */
 #define MI355Q_ZERO_BLOCK_EXACT 0u /* default: all-zero blocks take the reference's global fill
@@ -60,7 +63,10 @@ const char* mi355q_error_string(int code);
  * exp  (nullable, together with mant) uint8 [lead, ceil(rows/b0), ceil(cols/b1)]:
  *      shared exponent + exponent_bias (the stored, biased code).
  * width in [2,8] when mant is requested ([2,25] for y only); exponent_width in [1,8];
- * exponent_bias < 0 selects the default 2^(exponent_width-1)-1 (block_fp.py:61-62). */
+ * exponent_bias == MI355Q_BIAS_DEFAULT selects the default 2^(exponent_width-1)-1 (the reference's
+ * exponent_bias=None, block_fp.py:61-62); any other value, negative ones included, is used literally
+ * (e_min = -bias, e_max = 2^exponent_width - 1 - bias).  The packed / aligned operand entry points
+ * (mant + biased uint8 exponent codes) take non-negative biases only. */
 int mi355q_block_fp_quantize(const float* x, float* y, int8_t* mant, uint8_t* exp,
                              int64_t lead, int64_t rows, int64_t cols, int32_t b0, int32_t b1,
                              int32_t width, int32_t exponent_width, int32_t exponent_bias,

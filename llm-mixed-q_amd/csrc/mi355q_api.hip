@@ -90,7 +90,7 @@ int mi355q_block_fp_quantize(const float* x, float* y, int8_t* mant, uint8_t* ex
     if (y == nullptr && mant == nullptr) return MI355Q_E_BADARG;
     if (exponent_width < 1 || exponent_width > 8) return MI355Q_E_BADARG;
     if (width < 2 || width > (mant ? 8 : 25)) return MI355Q_E_BADARG;
-    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
     a.mant = mant;
     a.code = exp;
     a.code_bias = exponent_bias;
@@ -110,7 +110,7 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
     if (y == nullptr) return MI355Q_E_BADARG;
     if (exponent_width < 1 || exponent_width > 8 || width < 2) return MI355Q_E_BADARG;
     if (width > 9) return MI355Q_E_UNSUPPORTED;            // a quantised value must fit bf16's 8 significant bits
-    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
     a.ybf = y;
     a.code_bias = exponent_bias;
     a.e_min = -exponent_bias;
@@ -215,7 +215,8 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
     if (K % 256 != 0) return MI355Q_E_UNSUPPORTED;
     if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 8) return MI355Q_E_BADARG;
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(mant_tiled) % 16) return MI355Q_E_ALIGN;
-    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias < 0) return MI355Q_E_UNSUPPORTED;          // biased uint8 exponent codes: non-negative biases only
     QuantArgs a{};
     a.x = x;
     a.code = exp_out;
@@ -270,7 +271,8 @@ int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, ui
     if (K % 64 != 0 || K > MI355Q_ROW_ALIGN_MAX_K) return MI355Q_E_UNSUPPORTED;
     if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 8) return MI355Q_E_BADARG;
     if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(mant_tiled) % 16) return MI355Q_E_ALIGN;
-    if (exponent_bias < 0) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias < 0) return MI355Q_E_UNSUPPORTED;          // biased uint8 exponent codes: non-negative biases only
     QuantArgs a{};
     a.x = x;
     a.code = exp_out;
@@ -310,11 +312,12 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         // ROW-aligned operands: plain int8 GEMM with one scale per row + exception add-back in its epilogue; the
         // second launch only acts when an exception bucket overflowed (then it forms the whole product blockwise)
         if (!x->gscale || !w->gscale) return MI355Q_E_BADARG;
+        if (w->list_cap < 0 || w->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
+        a.w_bcap = bucket_cap_of(w->list_cap);          // (before the early return: the kernel below indexes w's buckets)
         if (x->row_aligned == 2)            // unaligned activations: the blockwise-exact kernel, w's exception blocks per tile
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, w->list, 0, 0, st);
-        if (x->list_cap < 0 || x->list_cap > ROW_BCAP_MAX || w->list_cap < 0 || w->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
+        if (x->list_cap < 0 || x->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
         a.x_bcap = bucket_cap_of(x->list_cap);
-        a.w_bcap = bucket_cap_of(w->list_cap);
         // x's exception blocks: in-LDS vectors of the GEMM (needs x->corr and the 120-entry buckets) or the row post-pass
         a.x_post = (a.x_bcap != ROW_BCAP || !x->corr) ? 1 : 0;
         const bool fast_ok = x->list && w->list && K % 128 == 0 && K <= MI355Q_ROW_ALIGN_MAX_K && a.w_bcap == ROW_BCAP;
@@ -372,7 +375,7 @@ int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspac
         return MI355Q_E_ALIGN;
     QuantArgs ax{}, ay{};
     auto fill = [](QuantArgs& a, int width, int ew, int bias) {
-        if (bias < 0) bias = (1 << (ew - 1)) - 1;
+        if (bias == MI355Q_BIAS_DEFAULT) bias = (1 << (ew - 1)) - 1;
         a.b0 = 1; a.b1 = 16;
         a.code_bias = bias;
         a.e_min = -bias;

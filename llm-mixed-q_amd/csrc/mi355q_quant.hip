@@ -30,6 +30,24 @@
 
 namespace mi355q {
 
+// One wave-reduced atomic max per wave (exact zero-block mode only): the tensor's smallest non-zero block max, kept as
+// max(~bits), and the "met an all-zero block" flag, for the fix-up launch that follows on the same stream.
+__device__ __forceinline__ void publish_zero_state(unsigned* ws, bool saw_zero, unsigned inv) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)inv, o);
+        inv = other > inv ? other : inv;
+    }
+    const bool any_zero = __any(saw_zero);
+    if ((threadIdx.x & 63) == 0) {
+        // (read first: after a few waves have reported, hardly any wave still lowers the minimum -- the word sees a
+        //  handful of atomics per launch instead of one per wave)
+        if (inv > __hip_atomic_load(&ws[WS_MINBITS_INV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(&ws[WS_MINBITS_INV], inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (any_zero) __hip_atomic_store(&ws[WS_ZERO_FLAG], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // kernel 1, vector path: b0 == 1, cols % b1 == 0, b1 = 4 * LPB, 16-byte aligned x / y.
 // Flat over all elements: float4 slot i belongs to block i / LPB.
@@ -46,6 +64,7 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
     unsigned* __restrict__ m4 = reinterpret_cast<unsigned*>(a.mant);
     const bool exact = (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u;
     bool saw_zero = false;
+    unsigned inv = 0u;          // max over non-zero blocks of ~bits(block max) = the smallest non-zero block max
 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4_pad; i += stride) {
         const bool valid = i < n4;
@@ -56,6 +75,9 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
         if (bmax == 0.f) {          // all-zero block: provisional fill 1.0 (what an all-zero tensor gets)
             saw_zero = saw_zero || valid;
             bmax = 1.0f;
+        } else if (exact) {
+            const unsigned v = ~__float_as_uint(bmax);
+            inv = v > inv ? v : inv;
         }
         unsigned code;
         const BlockParam bp = block_param<FMT>(bmax, a, lut, code);
@@ -75,7 +97,7 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
             if (a.code && (i & (LPB - 1)) == 0) a.code[i / LPB] = (uint8_t)code;
         }
     }
-    if (exact && saw_zero) a.ws[WS_ZERO_FLAG] = 1u;
+    if (exact) publish_zero_state(a.ws, saw_zero, inv);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -121,11 +143,13 @@ __global__ __launch_bounds__(256) void quant_generic_kernel(const QuantArgs a) {
     const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
     const bool exact = (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u;
     bool saw_zero = false;
+    unsigned inv = 0u;
     // every lane of a group runs the same trip count (bid is group-uniform)
     for (long long bid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; bid < a.n_blocks; bid += groups) {
         const BlockCursor c = locate(a, bid);
         float bmax = block_absmax16(a, c, lane16);
         if (bmax == 0.f) { saw_zero = true; bmax = 1.0f; }
+        else if (exact) { const unsigned v = ~__float_as_uint(bmax); inv = v > inv ? v : inv; }
         unsigned code;
         const BlockParam bp = block_param<FMT>(bmax, a, lut, code);
         const int n = c.h * c.w;
@@ -139,15 +163,16 @@ __global__ __launch_bounds__(256) void quant_generic_kernel(const QuantArgs a) {
         }
         if (a.code && lane16 == 0) a.code[bid] = (uint8_t)code;
     }
-    if (exact && saw_zero) a.ws[WS_ZERO_FLAG] = 1u;
+    if (exact) publish_zero_state(a.ws, saw_zero, inv);
 }
 
 // ---------------------------------------------------------------------------------------
-// kernel 2: all-zero blocks take the tensor-global fill.  Returns at once when kernel 1 met
-// none.  Otherwise phase A = min over non-zero block maxes, grid barrier, phase B = rewrite the
-// zero blocks.  Grid is FIXUP_GRID workgroups (<= 1 per CU, co-resident); every spin is bounded.
+// kernel 2: all-zero blocks take the tensor-global fill (block_fp.py:54-58).  Kernel 1 has left, in the
+// workspace, whether it met an all-zero block and the smallest non-zero block max of the whole tensor
+// (publish_zero_state); the stream orders the two launches, so there is no in-kernel grid barrier.
+// Returns at once when kernel 1 met no zero block.  The last workgroup out clears the workspace.
 // ---------------------------------------------------------------------------------------
-constexpr int FIXUP_GRID = 128;
+constexpr int FIXUP_GRID = 256;
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -156,42 +181,21 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
 template <int FMT>
 __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
     __shared__ Lut lut;
-    __shared__ unsigned s_red;
-    if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) return;    // uniform over the grid
+    if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) {           // uniform over the grid: nothing to rewrite
+        if (blockIdx.x == 0 && threadIdx.x == 0)          // (nobody reads this word on this path)
+            __hip_atomic_store(&a.ws[WS_MINBITS_INV], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     load_lut<FMT>(lut);
-    if (threadIdx.x == 0) s_red = 0u;
     __syncthreads();
     const int lane16 = threadIdx.x & 15;
     const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
     const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-
-    // phase A
-    unsigned inv = 0u;
-    for (long long bid = g0; bid < a.n_blocks; bid += groups) {
-        const float bmax = block_absmax16(a, locate(a, bid), lane16);
-        if (bmax != 0.f) { const unsigned v = ~__float_as_uint(bmax); inv = v > inv ? v : inv; }
-    }
-    atomicMax(&s_red, inv);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_max(&a.ws[WS_MINBITS_INV], s_red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&a.ws[WS_BARRIER], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (ld_agent(&a.ws[WS_BARRIER]) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 22)) { a.ws[WS_TIMEOUT] = 1u; break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
     const unsigned inv_all = ld_agent(&a.ws[WS_MINBITS_INV]);
     const float fill = inv_all == 0u ? 1.0f : __uint_as_float(~inv_all);   // all blocks zero -> 1
     unsigned code;
     const BlockParam bp = block_param<FMT>(fill, a, lut, code);
 
-    // phase B
     for (long long bid = g0; bid < a.n_blocks; bid += groups) {
         const BlockCursor c = locate(a, bid);
         if (block_absmax16(a, c, lane16) != 0.f) continue;
@@ -206,13 +210,14 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
         }
         if (a.code && lane16 == 0) a.code[bid] = (uint8_t)code;
     }
-    // exit ticket: the last workgroup out restores the workspace to zero for the next call
+    // exit ticket: the last workgroup out restores the workspace to zero for the next call (every workgroup has read
+    // the two words before it takes its ticket)
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(&a.ws[WS_BARRIER], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == 2u * gridDim.x - 1u) {
+        const unsigned t = __hip_atomic_fetch_add(&a.ws[WS_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1u) {
             __hip_atomic_store(&a.ws[WS_MINBITS_INV], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.ws[WS_BARRIER], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.ws[WS_TICKET], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.ws[WS_ZERO_FLAG], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -237,7 +242,10 @@ static int grid_for(long long work_items, int per_block) {
 }
 
 template <int FMT>
-static int launch_format(const QuantArgs& a, bool needs_fixup, hipStream_t st) {
+static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st) {
+    // kernel 1 leaves the zero-block state in the workspace only when the fix-up launch follows (and clears it)
+    QuantArgs a = a_in;
+    if (!needs_fixup) a.flags |= MI355Q_ZERO_BLOCK_FAST;
     const bool vec_ok = a.b0 == 1 && (a.cols % a.b1) == 0 && (a.b1 % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(a.x) % 16) == 0 &&
                         (a.y == nullptr || reinterpret_cast<uintptr_t>(a.y) % 16 == 0) &&

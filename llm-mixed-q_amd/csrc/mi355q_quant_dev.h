@@ -22,8 +22,7 @@ constexpr float ATOL = 1e-8f;
 // workspace words
 constexpr int WS_ZERO_FLAG = 0;   // kernel 1 met an all-zero block
 constexpr int WS_MINBITS_INV = 1; // max over non-zero blocks of ~bits(block max)
-constexpr int WS_BARRIER = 2;     // fix-up kernel grid barrier / exit ticket
-constexpr int WS_TIMEOUT = 3;     // a bounded spin gave up (reported by the next call)
+constexpr int WS_TICKET = 2;      // fix-up kernel exit ticket (the last workgroup out clears the workspace)
 
 struct Lut {
     unsigned a[LUT_N];  // bfp: ceil ; bm: floor ; bl: ceil

@@ -51,7 +51,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32), ("corr", _vp)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 WORKSPACE_BYTES = 256
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

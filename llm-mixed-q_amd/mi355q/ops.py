@@ -81,8 +81,13 @@ def _ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+BIAS_DEFAULT = -(2 ** 31)        # MI355Q_BIAS_DEFAULT: the reference's exponent_bias=None
+
+
 def _default_bias(exponent_bias) -> int:
-    return -1 if exponent_bias in (None, "none", "None") else int(exponent_bias)
+    """None -> the ABI's "default" sentinel; anything else, negative values included, is passed literally
+    (block_fp.py:61-62 uses a given bias as it is)"""
+    return BIAS_DEFAULT if exponent_bias in (None, "none", "None") else int(exponent_bias)
 
 
 # ---------------------------------------------------------------------------------------
@@ -385,7 +390,7 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
                                                   _ptr(buf["gscale"]), _ptr(cur), SPARSE_LIST_CAP, _ptr(nxt), rows, K,
                                                   int(width), int(exponent_width), bias, _stream_ptr(x.device))
     _lib.check(rc, "mi355q_block_fp_quantize_aligned")
-    eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
+    eb = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
     return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
                           int(width) - 1, eb)
 
@@ -413,7 +418,7 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
                                                        _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows, K, int(width),
                                                        int(exponent_width), bias, bucket_cap, sp)
     _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows")
-    eb = 2 ** (int(exponent_width) - 1) - 1 if bias < 0 else bias
+    eb = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
     return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
                           int(width) - 1, eb, row_aligned=True, bucket_cap=bucket_cap)
 

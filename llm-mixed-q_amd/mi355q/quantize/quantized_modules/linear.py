@@ -95,6 +95,8 @@ class _LinearBase(nn.Linear):
         xb, wb = c["data_in_exponent_bias"], c["weight_exponent_bias"]
         xb = 2 ** (c["data_in_exponent_width"] - 1) - 1 if xb in (None, "none", "None") else xb
         wb = 2 ** (c["weight_exponent_width"] - 1) - 1 if wb in (None, "none", "None") else wb
+        if xb < 0 or wb < 0:
+            return None                  # packed operands store biased uint8 exponent codes: non-negative biases only
         return c["data_in_width"] - 1, c["weight_width"] - 1, xb, wb
 
     @torch.no_grad()

@@ -142,3 +142,16 @@ def test_block_fp_quantize_bf16_equals_fp32_quantiser_cast(shape, skip, width):
     assert torch.equal(a, b.to(torch.bfloat16))
     big = b.abs() > 1e-8
     assert torch.equal(a.float()[big], b[big])               # quantised values survive the format exactly
+
+
+@pytest.mark.parametrize("bias,ew", [(-3, 4), (-20, 8), (0, 3), (None, 5)])
+def test_block_fp_explicit_bias_is_literal(bias, ew):
+    """a given exponent_bias, negative ones included, is used as it is (block_fp.py:61-62: e in [-bias, 2^ew-1-bias]);
+    only None selects the default"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    r = np.random.default_rng(3)
+    x = (r.normal(size=(37, 96)) * np.exp(3 * r.normal(size=(37, 1)))).astype(np.float32)
+    y = ops.block_fp_quantize(torch.from_numpy(x).to(_dev()), 6, ew, bias, [1, 16], True)
+    assert _same(y.cpu().numpy(), O.block_fp_quantize(x, 6, ew, bias, [1, 16], True))
