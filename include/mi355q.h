@@ -136,8 +136,10 @@ int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const
  *           reserved (may exceed list_cap), list[1..7] spare, then 8 words per entry:
  *           {row (-1 = void), block index (k/16), biased exponent, 0, 16 mantissa bytes}
  *   mant_tiled int8 [mi355q_bfp_tiled_bytes(rows, K)] (nullable, needs K % 64 == 0): the aligned
- *           mantissas in the tile order the GEMM kernels stream (1-KiB pieces of 16 rows x 64 bytes,
- *           rows padded to 128) -- this is what mi355q_bfp_gemm_aligned reads;
+ *           mantissas in the tile order the GEMM kernels stream: 1-KiB pieces of 16 rows x 64 K-bytes, piece
+ *           (row / 16) * (K / 64) + k / 64, laid out [block (k / 16) % 4][row % 16][16 bytes] inside (the LDS image
+ *           of the kernels; the 16 rows' blocks at one K position are 256 contiguous bytes); rows padded to 128
+ *           -- this is what mi355q_bfp_gemm_aligned reads;
  *   mant_out int8 [rows, K] (nullable): the same mantissas row-major, for inspection / mi355q_bfp_gemm.
  * In-place (mant_out == mant_in, exp_out == exp_in) is allowed. */
 size_t mi355q_bfp_list_bytes(int32_t list_cap);
@@ -203,9 +205,6 @@ typedef struct mi355q_bfp_operand {
     int32_t row_aligned;    /* 0: 256-value groups (mi355q_bfp_align); 2: row format, nothing aligned (x only: MI355Q_ROW_NO_ALIGN;
                              * the GEMM takes its blockwise-exact kernel: inputs no row window fits); 1: whole rows (mi355q_bfp_align_rows):
                              * rowflag [rows], gscale = rowscale [rows_pad], list = bucketed row list */
-    float* corr;            /* row-aligned operands: scratch for the correction vectors of this operand's exception
-                             * blocks, mi355q_bfp_corr_bytes(rows of this operand, rows of the other one); written and
-                             * read inside mi355q_bfp_gemm_aligned only (NULL for 256-value groups) */
 } mi355q_bfp_operand;
 
 /* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align (K % 64 == 0).
@@ -215,15 +214,16 @@ typedef struct mi355q_bfp_operand {
  * kernel forms the whole product instead.  The choice is made on the device from the list counts.
  * Both lists must have the same list_cap; operands without gscale / list (or K % 256 != 0) use the
  * blockwise-exact kernel directly.
- * ROW-aligned operands (row_aligned = 1 in both): a short launch multiplies every exception block with the other
- * operand (one fp32 vector of products per exception, in `corr`) -- or, if an exception bucket overflowed, forms the
- * whole product blockwise-exact -- then the row-scale int8 GEMM (256 x 256 tiles) runs and adds the vectors of the
- * rows / columns it stores.  No atomics: results are reproducible.  K % 128 == 0 for the fast kernel.
- * If x has no `corr` scratch or uses buckets larger than 120 entries, x's exception blocks are instead added by a ROW
- * POST-PASS after the GEMM (one workgroup per (bucket, 256 columns) owns the y rows it updates: plain read-add-write,
- * entries taken in (row, block) order -- reproducible too, and without a per-tile limit; meant for post-activation
- * inputs).  The weight operand always uses the in-LDS vectors (bucket_cap 120, `corr` required). */
-size_t mi355q_bfp_corr_bytes(int64_t rows, int64_t other_rows);
+ * ROW-aligned operands (row_aligned = 1 in both): the row-scale int8 GEMM (256 x 256 or 128 x 256 tiles, whole K in
+ * int32, one fp32 scale per row and per column).  Each tile multiplies the exception blocks of its own rows / columns
+ * with the other operand itself (one fp32 vector of products per exception, kept in LDS) and adds them in its store
+ * epilogue.  No atomics: results are reproducible.  K % 128 == 0 for the fast kernel.  A second launch leaves at once
+ * unless an exception bucket overflowed; then the GEMM has written nothing and this launch forms the whole product
+ * blockwise-exact (decided on the device).
+ * If x uses buckets larger than 120 entries, x's exception blocks are instead added by a ROW POST-PASS after the GEMM
+ * (one workgroup per (bucket, 64 columns) owns the y rows it updates: plain read-add-write, entries taken in
+ * (row, block) order -- reproducible too, and without a per-tile limit; meant for post-activation inputs).  The
+ * weight operand always uses the in-LDS vectors (bucket_cap 120). */
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);

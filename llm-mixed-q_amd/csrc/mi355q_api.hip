@@ -235,11 +235,6 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
                               list_cap, list_to_clear, static_cast<hipStream_t>(stream));
 }
 
-size_t mi355q_bfp_corr_bytes(int64_t rows, int64_t other_rows) {
-    if (rows <= 0 || other_rows <= 0) return 0;
-    // (+1 KiB: a 128-row tile fetches 256 floats from its first row on)
-    return (size_t)((rows + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS) * ROW_BCAP * (size_t)((other_rows + 255) / 256 * 256) * 4 + 1024;
-}
 
 static int bucket_cap_of(int32_t cap) { return cap == 0 ? ROW_BCAP : cap; }
 
@@ -305,7 +300,7 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, y, M, N, K, ldy,
                x->exp_bias + x->mbits + w->exp_bias + w->mbits, x->row_aligned ? 1 : 0,
                x->exp_bias + x->mbits, w->exp_bias + w->mbits,
-               x->corr, w->corr, (N + 255) / 256 * 256, (M + 255) / 256 * 256, ROW_BCAP, ROW_BCAP, 0};
+               ROW_BCAP, ROW_BCAP, 0};
     const int variant = g_gemm_variant.load();
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (x->row_aligned) {
@@ -318,20 +313,18 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, w->list, 0, 0, st);
         if (x->list_cap < 0 || x->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
         a.x_bcap = bucket_cap_of(x->list_cap);
-        // x's exception blocks: in-LDS vectors of the GEMM (needs x->corr and the 120-entry buckets) or the row post-pass
-        a.x_post = (a.x_bcap != ROW_BCAP || !x->corr) ? 1 : 0;
+        // x's exception blocks: in-LDS vectors of the GEMM (120-entry buckets) or the row post-pass (larger buckets)
+        a.x_post = a.x_bcap != ROW_BCAP ? 1 : 0;
         const bool fast_ok = x->list && w->list && K % 128 == 0 && K <= MI355Q_ROW_ALIGN_MAX_K && a.w_bcap == ROW_BCAP;
         if (variant == 2 || !fast_ok)
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, 0, 0, st);
         if (variant == 8) return launch_bfp_gemm_v8(a, x->gscale, w->gscale, nullptr, nullptr, 0, st);
-        if (!w->corr) return MI355Q_E_BADARG;
-        // first the short launch: one vector of products per exception block (or, if an exception bucket overflowed,
-        // the whole product blockwise-exact -- decided on the device); then the row-scale GEMM, which adds the vectors
-        // of the rows / columns it stores (and leaves at once in the overflow case)
-        int rc = launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, 0, st, x->gscale, w->gscale);
-        if (rc) return rc;
+        // ONE launch: the row-scale GEMM forms the correction vectors of its tile's exception blocks itself and adds them
+        // in its epilogue; if an exception bucket overflowed anywhere its tiles leave at once and the fallback workgroups
+        // that ride behind them -- which leave at once otherwise -- form the whole product blockwise-exact (decided on
+        // the device)
         hipEvent_t te = g_timing.begin(st);
-        rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st);
+        int rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st, x->rowflag, w->rowflag);
         g_timing.end(te, st);
         if (rc == 0 && a.x_post) rc = launch_bfp_gemm_rowpost(a, x->list, w->list, x->gscale, w->gscale, st);
         return rc;

@@ -18,14 +18,17 @@ using lptr_t = __attribute__((address_space(3))) void*;
 constexpr int ALIGN_G = 16;   // blocks per alignment group (256 values)
 
 // Tiled mantissa layout of an aligned operand: 1-KiB pieces of 16 rows x 64 K-bytes, piece index
-// (row/16) * (K/64) + k/64; inside a piece row r's 16-byte chunk c sits in slot c ^ h((row >> 2) & 3), h = [0,2,3,1]
-// (bank-conflict free for the ds_read_b128 fragment reads of both the 32x32x32 and the 16x16x64 MFMA)
-// -- the LDS image of the GEMM kernels, so that one global_load_lds copies one piece linearly.
+// (row/16) * (K/64) + k/64; inside a piece the four 16-byte blocks of a row are 256 bytes apart -- the piece is
+// [block 0..3][row 0..15][16 bytes].  This is the LDS image of the GEMM kernels (one global_load_lds copies one piece
+// linearly); the ds_read_b128 fragment reads of both the 32x32x32 and the 16x16x64 MFMA (lane = row, block) touch every
+// bank once per 16-lane group without any swizzle, and the 16 rows' blocks at one K position -- what the exception
+// add-back gathers -- are 256 contiguous bytes.
 __device__ __forceinline__ long long tiled_offset(long long row, long long k, long long K) {
     const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
-    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3);
-    return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
+    return piece * 1024 + ((k >> 4) & 3) * 256 + (row & 15) * 16 + (k & 15);
 }
+// the same inside an LDS image of consecutive pieces of one K-step: row r, block c
+__device__ __forceinline__ int piece_lds_off(int r, int c) { return (r >> 4) * 1024 + c * 256 + (r & 15) * 16; }
 
 // ---------------------------------------------------------------------------------------
 // Variant 2: 128 x 128 tile, 4 waves x (64 x 64), K-step 64 staged by global_load_lds (16 B/lane)
@@ -45,7 +48,7 @@ struct V2Smem {
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-__device__ __forceinline__ int v2_off(int r, int c) { return r * V2_BK + ((c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 4); }
+__device__ __forceinline__ int v2_off(int r, int c) { return piece_lds_off(r, c); }
 
 // XCD-aware tile order: blocks b, b+8, ... share an XCD (L2); each XCD gets a contiguous chunk of the grouped
 // (8 tile-rows at a time) tile sequence.

@@ -41,7 +41,7 @@ constexpr int V6_GA = V6_S * V6_STAGE, V6_GB = V6_GA + 2 * 256 * 4, V6_LDS = V6_
 static_assert(V6_LDS <= 160 * 1024, "LDS budget");
 
 // 16-byte chunk c (0..3) of the 64-byte row r sits in slot c ^ h((r >> 2) & 3), h = [0,2,3,1]
-__device__ __forceinline__ int v6_off(int r, int c) { return r * 64 + ((c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 4); }
+__device__ __forceinline__ int v6_off(int r, int c) { return piece_lds_off(r, c); }
 
 #define V6_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
@@ -194,18 +194,8 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
                                                         const int* __restrict__ wlist, int list_cap,
                                                         const float* __restrict__ xscale, const float* __restrict__ wscale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(V2Smem)];
-    // row mode: the first bucket this workgroup will need is requested together with the overflow words (one memory
-    // round trip instead of two on the normal path)
-    int4 first_piece = {0, 0, 0, 0};
-    if (a.row_mode && threadIdx.x < ROW_BUCKET_WORDS / 4) {
-        const int nbx = (int)((a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS), nbw = (int)((a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS);
-        const int wi = blockIdx.x, xitems = a.x_post ? 0 : nbx * nbw;
-        if (wi < xitems + nbx * nbw) {
-            const bool is_x = wi < xitems;
-            const int bb = (is_x ? wi : wi - xitems) / (is_x ? nbw : nbx);
-            first_piece = reinterpret_cast<const int4*>(row_bucket(is_x ? xlist : wlist, (long long)bb * ROW_BUCKET_ROWS))[threadIdx.x];
-        }
-    }
+    // row mode (behind the row-scale GEMM, which forms its own correction vectors): this launch only acts when an
+    // exception bucket overflowed -- it then forms the whole product blockwise -- and leaves at once otherwise
     const bool overflow = a.row_mode ? (xlist[0] != 0 || wlist[0] != 0) : (xlist[0] > list_cap || wlist[0] > list_cap);
     if (overflow) {
         const int ntiles = (int)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
@@ -221,62 +211,7 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_tail(const GemmArgs a, const 
         }
         return;
     }
-    if (!a.row_mode) {
-        block_fix_body(a, xlist, wlist, list_cap, blockIdx.x, gridDim.x);
-        return;
-    }
-    // ---- row mode: one fp32 vector of products per exception block, for the row-scale GEMM to add.
-    //      x entry (row r, block kb), slot s of bucket b:  xcorr[(b * 120 + s) * ldxc + n] = 2^(code - x_off) * sw[n] *
-    //      dot16(entry, wm'[n, kb]) for every n;  w entries the mirror image over m (x as stored: its own exception
-    //      blocks are zero there; exception x exception terms are added by the GEMM from the lists).
-    //      Work item = (entry, 256 rows of the other operand); every row is flagged here (no overflow).
-    //      Workgroup = (bucket, 256 rows of the other operand): it copies the bucket to LDS (count and entries in one
-    //      round trip), requests the other operand's blocks for up to U entries together, writes U vector pieces.
-    int* s_bk = reinterpret_cast<int*>(smem);
-    const int nbx = (int)((a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS), nbw = (int)((a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS);
-    const int chx = nbw, chw = nbx;                                  // 256-row chunks of the OTHER operand
-    const int xitems = a.x_post ? 0 : nbx * chx;                     // (x's entries wait for the row post-pass)
-    const int tid = threadIdx.x;
-    for (int wi = blockIdx.x; wi < xitems + nbw * chw; wi += gridDim.x) {      // (normally one per workgroup)
-        const bool is_x = wi < xitems;
-        const int li = is_x ? wi : wi - xitems, nch = is_x ? chx : chw;
-        const int bb = li / nch, chunk = li - bb * nch;
-        const int* bk = row_bucket(is_x ? xlist : wlist, (long long)bb * ROW_BUCKET_ROWS);
-        __syncthreads();
-        if (tid < ROW_BUCKET_WORDS / 4)
-            reinterpret_cast<int4*>(s_bk)[tid] = wi == (int)blockIdx.x ? first_piece : reinterpret_cast<const int4*>(bk)[tid];
-        __syncthreads();
-        const int cnt = min(s_bk[0], ROW_BCAP);
-        const long long q = (long long)chunk * 256 + tid, qrows = is_x ? a.N : a.M;
-        const bool qok = q < qrows;
-        const float sc = qok ? (is_x ? wscale : xscale)[q] : 0.f;
-        const int8_t* qm = is_x ? a.wm : a.xm;
-        float* dst = (is_x ? a.xcorr + (long long)bb * ROW_BCAP * a.ldxc : a.wcorr + (long long)bb * ROW_BCAP * a.ldwc) + q;
-        const long long ld = is_x ? a.ldxc : a.ldwc;
-        const int off = is_x ? a.x_off : a.w_off;
-        constexpr int U = 12;
-        // (gathers UNCONDITIONAL -- rows behind the operand read its last row -- and all results formed before the first
-        // store: a load inside a branch, or a store between loads, makes the counted waits drain the whole queue, and
-        // loads and stores share it; every entry is live here, void entries exist only in the overflow case)
-        const long long qc = min(q, qrows - 1);
-        for (int e0 = 0; e0 < cnt; e0 += U) {
-            int4 qv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int* e = s_bk + EXC_HEADER + EXC_ENTRY * min(e0 + u, cnt - 1);
-                qv[u] = *reinterpret_cast<const int4*>(qm + tiled_offset(qc, (long long)e[1] * 16, a.K));
-            }
-            float rv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int* e = s_bk + EXC_HEADER + EXC_ENTRY * min(e0 + u, cnt - 1);
-                rv[u] = __builtin_ldexpf((float)dot16(*reinterpret_cast<const int4*>(e + 4), qv[u]), e[2] - off) * sc;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (e0 + u < cnt) dst[(long long)(e0 + u) * ld] = rv[u];            // (columns behind the operand: sc = 0)
-        }
-    }
+    if (!a.row_mode) block_fix_body(a, xlist, wlist, list_cap, blockIdx.x, gridDim.x);
 }
 
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
@@ -285,11 +220,6 @@ int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf
     // launch only has the sparse correction to do
     unsigned tiles = (unsigned)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
     if (tiles > 512) tiles = 512;
-    if (a.row_mode) {                                // one workgroup per (bucket, 256 rows of the other operand)
-        const long long nbx = (a.M + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS, nbw = (a.N + ROW_BUCKET_ROWS - 1) / ROW_BUCKET_ROWS;
-        const long long items = (a.x_post ? 1 : 2) * nbx * nbw;
-        tiles = (unsigned)(items > 2048 ? 2048 : items);
-    }
     hipLaunchKernelGGL(bfp_gemm_tail, tiles, 256, 0, st, a, xf, wf, xlist, wlist, list_cap, xscale, wscale);
     return (int)hipGetLastError();
 }

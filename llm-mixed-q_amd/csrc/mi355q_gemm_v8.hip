@@ -7,7 +7,7 @@
 // No rescale in the K loop: the int32 accumulators are the only live tile, so the wave tile is 128 x 64.
 //
 // Workgroup = 256 x 256 outputs, 8 waves as 2 x 4 (two per SIMD), v_mfma_i32_16x16x64_i8.  K-step 64: one stage =
-// A 16 KiB + B 16 KiB of 1-KiB pre-swizzled pieces (mi355q_gemm_v2.h), three stages filled by global_load_lds,
+// A 16 KiB + B 16 KiB of 1-KiB pieces (block-major inside, mi355q_gemm_v2.h), three stages filled by global_load_lds,
 // counted s_waitcnt vmcnt, raw s_barriers.  The two waves of every SIMD run one barrier apart: while one issues 16
 // MFMAs the other reads its fragments and issues its LDS-DMA loads (two such phases per K-step).  The scale / bias
 // slices of the tile, its two exception buckets and the lists' overflow words ride in front of the operand stream.
@@ -45,13 +45,13 @@ constexpr int V8_SXT = V8_MAP + 2 * 256 * 4, V8_SWT = V8_SXT + 1024, V8_BIAS = V
 constexpr int V8_FLAGS = V8_BIAS + 1024;             // a few flag words
 constexpr int V8_OVF = V8_FLAGS + 256;                // LDS copies of the two lists' header words (word 0 = overflow)
 constexpr int V8_CORR = V8_OVF + 512;
-constexpr int V8_LDS = 160 * 1024;
+constexpr int V8_LDS = 159 * 1024;            // (the blockwise body of the fallback workgroups keeps a few words of its own)
 constexpr int V8_FAST_MAX = (V8_LDS - V8_CORR) / 1024;      // entries (x + w) whose vectors fit beside the stages
 constexpr int V8_SLOW_MAX = V8_S * V8_STAGE / 1024;         // ... that fit the stage area after the K loop
 static_assert(ROW_BUCKET_WORDS * 4 <= V8_BUCKET, "bucket copy");
 static_assert(V8_FAST_MAX >= 40, "spare LDS for correction vectors");
 
-__device__ __forceinline__ int v8_off(int r, int c) { return r * 64 + ((c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 4); }
+__device__ __forceinline__ int v8_off(int r, int c) { return piece_lds_off(r, c); }
 
 #define V8_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
@@ -86,11 +86,36 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
     }
 }
 
+// Workgroups behind the tiles (blockIdx >= number of tiles) are the FALLBACK of the launch: they leave at once unless an
+// exception bucket overflowed somewhere (a row that could not store its exception blocks keeps its own exponents,
+// rowflag 0); then the tile workgroups have left without writing and these form the whole product with the
+// blockwise-exact body (128 x 128 tiles, one 256-thread team per workgroup) and add each tile's exception blocks right
+// after its stores.  One launch either way: no second kernel on the stream for a case that hardly ever happens.
+__device__ __forceinline__ void v8_fallback(const GemmArgs& a, const uint8_t* __restrict__ xf, const uint8_t* __restrict__ wf,
+                                         const int* __restrict__ xlist, const int* __restrict__ wlist, unsigned char* smem,
+                                         int wg, int nwg) {
+    if (xlist[0] == 0 && wlist[0] == 0) return;
+    if (threadIdx.x >= 256) return;                  // (terminated waves do not take part in the barriers below)
+    const int ntiles = (int)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
+    for (int tile = wg; tile < ntiles; tile += nwg) {
+        bfp_gemm_v2_body(a, xf, wf, *reinterpret_cast<V2Smem*>(smem), tile);
+        long long m0, n0;
+        v2_tile_origin(a, tile, m0, n0);
+        __threadfence();
+        __syncthreads();
+        tile_fix_body(a, row_bucket(xlist, m0, a.x_bcap), row_bucket(wlist, n0, a.w_bcap), a.x_bcap, a.w_bcap, m0, n0,
+                      (int)threadIdx.x, 256);
+        __syncthreads();
+    }
+}
+constexpr int V8_FALLBACK_WGS = 256;
+
 template <int FIXMODE_, int TI, bool ONEPHASE = (TI == 4)>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
-                                                        const int* __restrict__ wlist) {
+                                                        const int* __restrict__ wlist, const uint8_t* __restrict__ xf,
+                                                        const uint8_t* __restrict__ wf) {
     constexpr int FIXMODE = (FIXMODE_ == 1 || FIXMODE_ == 3) ? 1 : 0;      // 3: as 1, with phase timing printed by workgroup 0
     // TI = 16-row MFMA tiles per wave along M.  8: 256 x 256 workgroup tile, two MFMA phases per K-step, three 32-KiB
     // stages.  4: 128 x 256 tile (for shapes whose 256 x 256 tiles would leave compute units idle), one phase per K-step,
@@ -105,6 +130,10 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 
     const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
     const int nwg = tiles_m * tiles_n;
+    if (FIXMODE && (int)blockIdx.x >= nwg) {
+        v8_fallback(a, xf, wf, xlist, wlist, smem, (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
+        return;
+    }
     int pid;
     {
         const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
@@ -187,11 +216,43 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors beside the stages, 2: in the stage area after
     float* corr = reinterpret_cast<float*>(smem + V8_CORR);          // the K loop, 3: added with atomics after the stores
     int* multi = reinterpret_cast<int*>(smem + V8_FLAGS);             // set when a row / column carries several entries
-    auto request_vectors = [&](unsigned char* area) {
-        for (int i = wave; i < cx + cw; i += V8_NW) {
-            const float* v = i < cx ? a.xcorr + ((m0 >> 8) * ROW_BCAP + i) * a.ldxc + n0
-                                    : a.wcorr + ((n0 >> 8) * ROW_BCAP + (i - cx)) * a.ldwc + m0;
-            __builtin_amdgcn_global_load_lds((gptr_t)(v + lane * 4), (lptr_t)(area + i * 1024), 16, 0, 0);
+    // The correction vector of an entry: 256 floats, element p = the entry's block times the other operand's block at
+    // the same K position in tile row / column p, scaled -- x entry (row r, block kb):
+    //     v[p] = 2^(code - x_off) * sw[n0 + p] * dot16(entry, wm'[n0 + p, kb])          (w as stored: its own exceptions
+    // are zero there and come in through the exception x exception terms); w entries the mirror image over the tile's
+    // rows.  Formed HERE, by the tile that adds them: wave w takes entries w, w + 8, ...; a lane gathers the 16-byte
+    // blocks of four tile rows / columns per entry (unconditional loads, clamped addresses), two entries in flight.
+    auto compute_vectors = [&](float* area) {
+        const int n = cx + cw;
+        constexpr int U = 2;
+        for (int i0 = wave; i0 < n; i0 += V8_NW * U) {                 // wave-uniform
+            int4 qv[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(i0 + V8_NW * u, n - 1);
+                const bool is_x = i < cx;
+                const int* e = v8_entry(xb, wb, cx, i);
+                const long long kcol = (long long)e[1] * 16;
+                const int8_t* qm = is_x ? a.wm : a.xm;
+                const long long q0 = is_x ? n0 : m0, qmax = (is_x ? Ncols : Mrows) - 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    qv[u][c] = *reinterpret_cast<const int4*>(qm + tiled_offset(min(q0 + c * 64 + lane, qmax), kcol, a.K));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + V8_NW * u;
+                if (i < n) {
+                    const bool is_x = i < cx;
+                    const int* e = v8_entry(xb, wb, cx, i);
+                    const int4 pv = *reinterpret_cast<const int4*>(e + 4);
+                    const int sh = e[2] - (is_x ? a.x_off : a.w_off);
+                    const float* sc = is_x ? swt : sxt;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        area[i * 256 + c * 64 + lane] = __builtin_ldexpf((float)dot16(pv, qv[u][c]), sh) * sc[c * 64 + lane];
+                }
+            }
         }
     };
     if (FIXMODE) {
@@ -213,7 +274,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             rowslot[tid & 255] = -1;                        // tid < 256: rowslot, else colslot (contiguous)
             if (tid >= 256) colslot[tid & 255] = -1;
             if (tid == 0) *multi = 0;
-            if (mode == 1) request_vectors(smem + V8_CORR);
+            if (mode == 1) compute_vectors(reinterpret_cast<float*>(smem + V8_CORR));
             __builtin_amdgcn_s_barrier();
             // chains: the entries of one tile row / column, linked by DESCENDING block index (head in rowslot /
             // colslot, successor in word 3 of the entry's LDS copy, -2 marks a void entry).  The order is a property
@@ -373,8 +434,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         __syncthreads();                                         // every wave is done with the stage area
         if (mode == 2) {
             corr = reinterpret_cast<float*>(smem);
-            request_vectors(smem);
-            V8_WAIT(0);
+            compute_vectors(corr);
             __syncthreads();
         }
         if (mode != 3) {
@@ -494,7 +554,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 }
 
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
-                       int list_cap, hipStream_t st) {
+                       int list_cap, hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
     (void)list_cap;
     // 256 x 256 tiles unless they would leave too many of the 256 compute units idle: a 128 x 256 tile does half the
     // work in 0.8 of the time (measured: 48 vs 58 us at 2048 x 4096 x 4096; the fragment reads and LDS-DMA issue of a
@@ -509,13 +569,15 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
     // MI355Q_V8_STAMPS the duration of the kernel's phases
     static const bool want_clock = getenv("MI355Q_V8_CLOCK") != nullptr, want_stamps = getenv("MI355Q_V8_STAMPS") != nullptr;
     const bool fix = xlist && wlist;
+    if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
+    const unsigned grid = tiles + (fix ? V8_FALLBACK_WGS : 0);          // the fallback workgroups ride behind the tiles
     if (small) {
-        if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-        else hipLaunchKernelGGL((bfp_gemm_v8<0, 4>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    } else if (fix && want_stamps) hipLaunchKernelGGL((bfp_gemm_v8<3, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    else if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    else if (want_clock) hipLaunchKernelGGL((bfp_gemm_v8<2, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
-    else hipLaunchKernelGGL((bfp_gemm_v8<0, 8>), tiles, V8_NT, 0, st, a, sx, sw, xlist, wlist);
+        if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+        else hipLaunchKernelGGL((bfp_gemm_v8<0, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    } else if (fix && want_stamps) hipLaunchKernelGGL((bfp_gemm_v8<3, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (want_clock) hipLaunchKernelGGL((bfp_gemm_v8<2, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else hipLaunchKernelGGL((bfp_gemm_v8<0, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();
 }
 

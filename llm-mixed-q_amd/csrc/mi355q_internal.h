@@ -46,10 +46,6 @@ struct GemmArgs {
     int scale_bias;   // subtracted from xe + we to get the power of two of a block product
     int row_mode;     // 1: operands are ROW-aligned (rowflag[row], bucketed exception lists)
     int x_off, w_off; // exponent_bias + mbits of each operand (scale_bias = x_off + w_off)
-    // row mode: correction vectors of the exception blocks (one row of ldxc / ldwc floats per bucket slot)
-    float* xcorr;
-    float* wcorr;
-    long long ldxc, ldwc;
     // row mode: entries per exception bucket of each operand; x_post = x's entries are added by the row post-pass
     // (mi355q_gemm_post.hip) instead of the GEMM's in-LDS vectors
     int x_bcap, w_bcap, x_post;
@@ -62,7 +58,7 @@ int launch_bfp_align_rows(const int8_t* mi, const uint8_t* ei, int8_t* mt, uint8
 int launch_bfp_gemm_rowpost(const GemmArgs& a, const int* xlist, const int* wlist, const float* xscale, const float* wscale,
                             hipStream_t st);
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
-                       int list_cap, hipStream_t st);
+                       int list_cap, hipStream_t st, const uint8_t* xf = nullptr, const uint8_t* wf = nullptr);
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
                          int list_cap, hipStream_t st, const float* xscale = nullptr, const float* wscale = nullptr);
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,

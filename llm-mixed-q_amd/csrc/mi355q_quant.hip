@@ -289,8 +289,7 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ long long tiled_offset_q(long long row, long long k, long long K) {
     const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
-    const int chunk = (int)((k >> 4) & 3), slot = chunk ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3);
-    return piece * 1024 + (row & 15) * 64 + slot * 16 + (k & 15);
+    return piece * 1024 + ((k >> 4) & 3) * 256 + (row & 15) * 16 + (k & 15);
 }
 
 // DPP helpers on ints: rotate within a row of 16 lanes
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a,
     const int dg = (int)(nwaves - drow * ngroups);
     // lane-constant part of the tiled address: chunk (lane >> 2) & 3 of piece lane >> 4, 4 bytes at (lane & 3) * 4
     const int lane_chunk = (lane >> 2) & 3;
-    const int lane_off = (lane >> 4) * 1024 + (lane & 3) * 4;
+    const int lane_off = (lane >> 4) * 1024 + lane_chunk * 256 + (lane & 3) * 4;
     const int mbits_int = (int)__builtin_log2f(a.shift);
     float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pair < npairs) vnext = x4[pair * 64 + lane];
@@ -366,9 +365,8 @@ __global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a,
         const int q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);   // bytes: q0.b0, q1.b0
         const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);   // q2.b0 -> byte2, q3.b0 -> byte3
-        const int slot = lane_chunk ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3);
-        int8_t* prow = mt + ((row >> 4) * kpieces + g * 4) * 1024 + (row & 15) * 64;       // wave-uniform
-        *reinterpret_cast<unsigned*>(prow + lane_off + slot * 16) = lo | hi;
+        int8_t* prow = mt + ((row >> 4) * kpieces + g * 4) * 1024 + (row & 15) * 16;       // wave-uniform
+        *reinterpret_cast<unsigned*>(prow + lane_off) = lo | hi;
         if ((lane & 3) == 0) a.code[row * nkb + g * 16 + (lane >> 2)] = (uint8_t)eout;
         if (lane == 0) {
             flag[row * ngroups + g] = all_ok ? 1 : 0;
@@ -417,7 +415,17 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     }
     const int mbits_int = (int)__builtin_log2f(a.shift);
     __syncthreads();
-    for (long long row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    // Workgroup -> row: the 16 rows of one piece row (they share every 1-KiB piece they write, 16 bytes each per block)
+    // go to workgroups b, b + 8, b + 16, ... -- the ones that share an XCD and therefore an L2, which merges their
+    // partial-line stores (consecutive workgroup ids are dealt round-robin over the 8 XCDs, whose L2s are not coherent:
+    // lines written from two of them leave as two masked partial writes).  Speed only; any mapping is correct.
+    const long long rows16 = a.rows & ~127ll;               // rows covered by whole groups of 8 piece rows
+    for (long long wi = blockIdx.x; wi < a.rows; wi += gridDim.x) {
+        long long row = wi;
+        if (wi < rows16) {
+            const long long grp = wi >> 7, in = wi & 127;   // 128 rows = 8 piece rows, one per XCD
+            row = (grp << 7) + ((in & 7) << 4) + (in >> 3);
+        }
         const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
         float4 v[MAXIT];
 #pragma unroll
@@ -458,9 +466,9 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
         // kernel: inputs whose block exponents spread too far for any row window, e.g. SiLU-gated MLP activations)
         const bool flagged = bcap < 0 ? false : align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap);
         // tiled address of this lane's 4 bytes in slab 0 (block 16 wave + lane / 4: K-step 4 wave + lane / 16, 16-byte
-        // chunk (lane / 4) & 3, swizzled by the row); a slab further on is 16 K-steps = 16 KiB further
-        int8_t* dst = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + (row & 15) * 64 +
-                      ((((lane >> 2) & 3) ^ ((0x78 >> (2 * (int)((row >> 2) & 3))) & 3)) << 4) + (lane & 3) * 4;
+        // block (lane / 4) & 3 of the piece, 256 bytes apart); a slab further on is 16 K-steps = 16 KiB further
+        int8_t* dst = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + ((lane >> 2) & 3) * 256 +
+                      (row & 15) * 16 + (lane & 3) * 4;
         uint8_t* cdst = a.code + row * nkb + wave * 16 + (lane >> 2);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             flag[row] = flagged ? 1 : 0;
             rscale[row] = flagged ? __builtin_ldexpf(1.0f, E - exp_offset) : 0.0f;
         }
-        if (row + gridDim.x < a.rows) __syncthreads();      // (the next row reuses the decision words in LDS)
+        if (wi + gridDim.x < a.rows) __syncthreads();       // (the next row reuses the decision words in LDS)
     }
 }
 

@@ -32,7 +32,6 @@ SIGNATURES = {
     "mi355q_block_fp_quantize_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32,
                                                    _i32, _vp]),
     "mi355q_bfp_row_list_bytes": (C.c_size_t, [_i64, _i32]),
-    "mi355q_bfp_corr_bytes": (C.c_size_t, [_i64, _i64]),
     "mi355q_bfp_align_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp]),
     "mi355q_block_fp_quantize_aligned_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,
                                                         _i32, _i32, _vp]),
@@ -48,7 +47,7 @@ SIGNATURES = {
 class BfpOperand(C.Structure):
     """struct mi355q_bfp_operand"""
     _fields_ = [("mant", _vp), ("exp", _vp), ("rowflag", _vp), ("gscale", _vp), ("list", _vp),
-                ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32), ("corr", _vp)]
+                ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
 ABI_VERSION = 4

@@ -235,10 +235,10 @@ class AlignedOperand:
         self.list_cap = (int(bucket_cap) if bucket_cap and int(bucket_cap) > 0
                          else (ROW_BUCKET_CAP if row_aligned else SPARSE_LIST_CAP))
 
-    def c_struct(self, corr=None):
+    def c_struct(self):
         return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
                                _ptr(self.sparse), self.list_cap, self.mbits, self.exp_bias,
-                               2 if self.unaligned else int(self.row_aligned), _ptr(corr))
+                               2 if self.unaligned else int(self.row_aligned))
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
@@ -423,24 +423,6 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
                           int(width) - 1, eb, row_aligned=True, bucket_cap=bucket_cap)
 
 
-_CORR_CACHE: dict = {}
-
-
-def _corr_workspace(device, M, N, sp=None):
-    """scratch for the correction vectors of a row-aligned GEMM (include/mi355q.h, mi355q_bfp_corr_bytes), reused per
-    (device, stream, M, N)"""
-    key = (device.index, _stream_ptr(device) if sp is None else sp, M, N)
-    ws = _CORR_CACHE.get(key)
-    if ws is None:
-        lib = _lib.load_library()
-        ws = (torch.empty(lib.mi355q_bfp_corr_bytes(M, N) // 4, dtype=torch.float32, device=device),
-              torch.empty(lib.mi355q_bfp_corr_bytes(N, M) // 4, dtype=torch.float32, device=device))
-        if len(_CORR_CACHE) > 32:
-            _CORR_CACHE.clear()
-        _CORR_CACHE[key] = ws
-    return ws
-
-
 def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):
     """bfp_gemm on operands rewritten by bfp_align."""
     M, K, N = x.rows, x.K, w.rows
@@ -451,12 +433,7 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
     lib = _lib.load_library()
     sp = _stream_ptr(x.tiled.device)
-    cx = cw = None
-    if x.row_aligned and w.row_aligned:
-        cx, cw = _corr_workspace(x.tiled.device, M, N, sp)
-        if x.list_cap != ROW_BUCKET_CAP or x.unaligned:
-            cx = None                    # x's exception blocks go through the row post-pass
-    xs, ws = x.c_struct(cx), w.c_struct(cw)
+    xs, ws = x.c_struct(), w.c_struct()
     import ctypes
     with torch.cuda.device(x.tiled.device):
         rc = lib.mi355q_bfp_gemm_aligned(ctypes.addressof(xs), ctypes.addressof(ws), _ptr(bias), _ptr(out), M, N, K,

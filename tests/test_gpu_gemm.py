@@ -282,17 +282,12 @@ def _row_exceptions(al, rows, nkb):
 
 
 def _untile(tiled, rows, K):
-    """tiled aligned mantissas (1-KiB pieces of 16 rows x 64 B, chunk-swizzled) -> [rows, K] int8"""
+    """tiled aligned mantissas (1-KiB pieces of 16 rows x 64 B laid out [block 0..3][row 0..15][16 B]) -> [rows, K] int8"""
     t = tiled.cpu().numpy().view(np.int8)
-    out = np.zeros((rows, K), np.int8)
     kp = K // 64
-    for r in range(rows):
-        h = (0x78 >> (2 * ((r >> 2) & 3))) & 3
-        for p in range(kp):
-            base = ((r >> 4) * kp + p) * 1024 + (r & 15) * 64
-            for c in range(4):
-                out[r, p * 64 + c * 16: p * 64 + c * 16 + 16] = t[base + (c ^ h) * 16: base + (c ^ h) * 16 + 16]
-    return out
+    rp = (t.size // (kp * 1024)) * 16
+    return np.ascontiguousarray(t[: (rp // 16) * kp * 1024].reshape(rp // 16, kp, 4, 16, 16).transpose(0, 3, 1, 2, 4)
+                                ).reshape(rp, K)[:rows]
 
 
 @pytest.mark.parametrize("width", [6, 4, 8])

@@ -46,7 +46,6 @@ def test_aligned_operand_entry_points_validate_without_a_gpu():
     assert lib.mi355q_bfp_list_bytes(1024) == (8 + 8 * 1024) * 4
     assert lib.mi355q_bfp_row_list_bytes(4096, 0) == (8 + 16 * (8 + 8 * 120)) * 4 and lib.mi355q_bfp_row_list_bytes(1, 120) == (8 + 968) * 4
     assert lib.mi355q_bfp_row_list_bytes(512, 1016) == (8 + 2 * (8 + 8 * 1016)) * 4 and lib.mi355q_bfp_row_list_bytes(512, 1017) == 0
-    assert lib.mi355q_bfp_corr_bytes(4096, 4096) == 16 * 120 * 4096 * 4 + 1024 and lib.mi355q_bfp_corr_bytes(0, 5) == 0
     one = C.create_string_buffer(64)
     p = C.addressof(one)
     # row alignment: K % 64, K <= 16384, pointers
@@ -61,12 +60,10 @@ def test_aligned_operand_entry_points_validate_without_a_gpu():
     assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, None, None, 4, 64, 6, 8, 127, 0, None) == E_BADARG   # list required unless NO_ALIGN
     assert lib.mi355q_block_fp_quantize_aligned_rows(p + 4, p, p, p, p, p, None, 4, 64, 6, 8, 127, 0, None) == E_ALIGN
     assert lib.mi355q_block_fp_quantize_aligned(p, p, p, p, p, p, 8, None, 4, 192, 6, 8, 127, None) == E_UNSUPPORTED  # K % 256
-    # GEMM: both operands in the same flavour, scratch for the row flavour, K % 64
-    x, w = _lib.BfpOperand(p, p, p, p, p, 0, 5, 127, 1, None), _lib.BfpOperand(p, p, p, p, p, 8, 5, 127, 0, None)
+    # GEMM: both operands in the same flavour, K % 64
+    x, w = _lib.BfpOperand(p, p, p, p, p, 0, 5, 127, 1), _lib.BfpOperand(p, p, p, p, p, 8, 5, 127, 0)
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 4, None) == E_BADARG
-    w.row_aligned, w.list_cap = 1, 0
-    assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 4, None) == E_BADARG       # w's corr missing
-    w.list_cap = 2000
+    w.row_aligned, w.list_cap = 1, 2000
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 4, None) == E_BADARG       # bucket cap
     w.list_cap = 0
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 48, 4, None) == E_UNSUPPORTED

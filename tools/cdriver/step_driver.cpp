@@ -73,12 +73,10 @@ int main(int argc, char** argv) {
     uint8_t *xe = dalloc<uint8_t>(M * K / 16), *xflag = dalloc<uint8_t>(M);
     float* xscale = dalloc<float>(mi355q_bfp_rows_pad(M), true);
     int32_t* xlist[2] = {dalloc<int32_t>(mi355q_bfp_row_list_bytes(M, 0) / 4, true), dalloc<int32_t>(mi355q_bfp_row_list_bytes(M, 0) / 4, true)};
-    float* xcorr = dalloc<float>(mi355q_bfp_corr_bytes(M, N) / 4);
-    float* wcorr = dalloc<float>(mi355q_bfp_corr_bytes(N, M) / 4);
     for (int s = 0; s < steps; ++s) {
         Q_OK(mi355q_block_fp_quantize_aligned_rows(x, xt, xe, xflag, xscale, xlist[s & 1], xlist[(s + 1) & 1], M, K, 6, 8, 127, 0, st));
-        mi355q_bfp_operand xo{xt, xe, xflag, xscale, xlist[s & 1], 0, 5, 127, 1, xcorr};
-        mi355q_bfp_operand wo{wt, we, wflag, wscale, wlist, 0, 5, 127, 1, wcorr};
+        mi355q_bfp_operand xo{xt, xe, xflag, xscale, xlist[s & 1], 0, 5, 127, 1};
+        mi355q_bfp_operand wo{wt, we, wflag, wscale, wlist, 0, 5, 127, 1};
         Q_OK(mi355q_bfp_gemm_aligned(&xo, &wo, bias, y, M, N, K, N, st));
     }
     HIP_OK(hipDeviceSynchronize());
