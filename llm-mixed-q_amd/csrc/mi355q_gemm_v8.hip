@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
@@ -110,7 +111,7 @@ __device__ __forceinline__ void v8_fallback(const GemmArgs& a, const uint8_t* __
 }
 constexpr int V8_FALLBACK_WGS = 256;
 
-template <int FIXMODE_, int TI, bool ONEPHASE = (TI == 4)>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
+template <int FIXMODE_, int TI, int SCHED = (TI == 4 ? 1 : 0)>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
 
+    const unsigned long long kernel_t0 = FIXMODE_ == 3 ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
     const int nwg = tiles_m * tiles_n;
     if (FIXMODE && (int)blockIdx.x >= nwg) {
@@ -205,14 +207,18 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 #pragma unroll
     for (int j = 0; j < TJ; ++j) boff[j] = HALF + v8_off(wn * 64 + j * 16 + l16, lq);
 
+    // Pipelined schedule with the add-back: the second stage is requested behind the gathers of the correction vectors
+    // (a wave's memory operations return in issue order: in front of them the gathers would queue behind 32 KiB more)
+    constexpr bool LATE_STAGE1 = SCHED == 2 && FIXMODE;
     stage(0, 0);
-    if (nsteps > 1) stage(1, 1);
+    if (!LATE_STAGE1 && nsteps > 1) stage(1, 1);
     if (TI == 4 && nsteps > 2) stage(2, 2);
 
     // ---- exception bookkeeping of this tile.  Its buckets rode in front of the operand stream; once they have landed
     //      (the first two stages stay in flight) the workgroup counts the entries, clears the row / column maps, links
     //      the entries of each tile row / column into a chain and requests every entry's correction vector -- 256
     //      floats the short launch in front of this kernel formed (mi355q_gemm_v6.hip) -- by ONE 1-KiB LDS-DMA each.
+    unsigned long long pst[3] = {0, 0, 0};
     int cx = 0, cw = 0, mode = 0;         // mode 0: none, 1: vectors beside the stages, 2: in the stage area after
     float* corr = reinterpret_cast<float*>(smem + V8_CORR);          // the K loop, 3: added with atomics after the stores
     int* multi = reinterpret_cast<int*>(smem + V8_FLAGS);             // set when a row / column carries several entries
@@ -222,43 +228,50 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     // are zero there and come in through the exception x exception terms); w entries the mirror image over the tile's
     // rows.  Formed HERE, by the tile that adds them: wave w takes entries w, w + 8, ...; a lane gathers the 16-byte
     // blocks of four tile rows / columns per entry (unconditional loads, clamped addresses), two entries in flight.
-    auto compute_vectors = [&](float* area) {
+    // Two halves, so that other work can sit between request and use (the gathers cost a memory round trip): entries
+    // base + wave + 8 u, u < U, of the combined list.
+    auto gather_issue = [&](auto& qv, int base, auto ucount) {
+        constexpr int U = decltype(ucount)::value;
         const int n = cx + cw;
-        constexpr int U = 2;
-        for (int i0 = wave; i0 < n; i0 += V8_NW * U) {                 // wave-uniform
-            int4 qv[U][4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = min(i0 + V8_NW * u, n - 1);
+        for (int u = 0; u < U; ++u) {
+            const int i = base + wave + V8_NW * u;
+            if (i >= n) break;                                          // wave-uniform
+            const bool is_x = i < cx;
+            const int* e = v8_entry(xb, wb, cx, i);
+            const long long kcol = (long long)e[1] * 16;
+            const int8_t* qm = is_x ? a.wm : a.xm;
+            const long long q0 = is_x ? n0 : m0, qmax = (is_x ? Ncols : Mrows) - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                qv[u][c] = *reinterpret_cast<const int4*>(qm + tiled_offset(min(q0 + c * 64 + lane, qmax), kcol, a.K));
+        }
+    };
+    auto gather_finish = [&](auto& qv, float* area, int base, auto ucount) {
+        constexpr int U = decltype(ucount)::value;
+        const int n = cx + cw;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + wave + V8_NW * u;
+            if (i < n) {
                 const bool is_x = i < cx;
                 const int* e = v8_entry(xb, wb, cx, i);
-                const long long kcol = (long long)e[1] * 16;
-                const int8_t* qm = is_x ? a.wm : a.xm;
-                const long long q0 = is_x ? n0 : m0, qmax = (is_x ? Ncols : Mrows) - 1;
+                const int4 pv = *reinterpret_cast<const int4*>(e + 4);
+                const int sh = e[2] - (is_x ? a.x_off : a.w_off);
+                const float* sc = is_x ? swt : sxt;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    qv[u][c] = *reinterpret_cast<const int4*>(qm + tiled_offset(min(q0 + c * 64 + lane, qmax), kcol, a.K));
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + V8_NW * u;
-                if (i < n) {
-                    const bool is_x = i < cx;
-                    const int* e = v8_entry(xb, wb, cx, i);
-                    const int4 pv = *reinterpret_cast<const int4*>(e + 4);
-                    const int sh = e[2] - (is_x ? a.x_off : a.w_off);
-                    const float* sc = is_x ? swt : sxt;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        area[i * 256 + c * 64 + lane] = __builtin_ldexpf((float)dot16(pv, qv[u][c]), sh) * sc[c * 64 + lane];
-                }
+                    area[i * 256 + c * 64 + lane] = __builtin_ldexpf((float)dot16(pv, qv[u][c]), sh) * sc[c * 64 + lane];
             }
         }
     };
+    constexpr int U_PRO = (V8_FAST_MAX + V8_NW - 1) / V8_NW;        // all of a tile's entries in ONE round trip
     if (FIXMODE) {
         // (the buckets are older than the operand stages requested above)
-        if (TI == 4 && nsteps > 2) V8_WAIT(3 * LPW); else if (nsteps > 1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
+        if (FIXMODE_ == 3) pst[0] = __builtin_amdgcn_s_memrealtime();
+        if (TI == 4 && nsteps > 2) V8_WAIT(3 * LPW); else if (nsteps > 1 && !LATE_STAGE1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
+        if (FIXMODE_ == 3) pst[1] = __builtin_amdgcn_s_memrealtime();
         // a bucket overflowed somewhere: the launch in front of this one formed the product, this one must not write
         // (uniform over the grid).  The operand loads in flight land in LDS only; nothing else is pending.
         const int* ovf = reinterpret_cast<const int*>(smem + V8_OVF);
@@ -274,35 +287,50 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             rowslot[tid & 255] = -1;                        // tid < 256: rowslot, else colslot (contiguous)
             if (tid >= 256) colslot[tid & 255] = -1;
             if (tid == 0) *multi = 0;
-            if (mode == 1) compute_vectors(reinterpret_cast<float*>(smem + V8_CORR));
-            __builtin_amdgcn_s_barrier();
-            // chains: the entries of one tile row / column, linked by DESCENDING block index (head in rowslot /
-            // colslot, successor in word 3 of the entry's LDS copy, -2 marks a void entry).  The order is a property
-            // of the data, not of which workgroup reserved its list slots first: results are reproducible.
-            for (int i = tid; i < n; i += V8_NT) {
+            int4 qv[U_PRO][4];
+            if (mode == 1) gather_issue(qv, 0, std::integral_constant<int, U_PRO>{});
+            if (LATE_STAGE1 && nsteps > 1) stage(1, 1);
+            __builtin_amdgcn_s_barrier();                   // (maps cleared before the chain heads are written)
+            // chains, while the gathers are in flight: the entries of one tile row / column, linked by DESCENDING block
+            // index (head in rowslot / colslot, successor in word 3 of the entry's LDS copy, -2 marks a void entry).
+            // The order is a property of the data, not of which workgroup reserved its list slots first: results are
+            // reproducible.  16 lanes share an entry (each scans every 16th entry of the same operand).
+            for (int i0 = 0; i0 < n; i0 += V8_NT / 16) {               // uniform
+                const int i = i0 + (tid >> 4), sub = tid & 15;
+                const bool valid = i < n;
                 const bool is_x = i < cx;
-                int* e = v8_entry(xb, wb, cx, i);
-                const long long r = e[0];
-                const int kb = e[1];
-                const bool live = is_x ? (r >= m0 && r < m0 + BM && r < Mrows) : (r >= n0 && r < n0 + 256 && r < Ncols);
-                if (!live) {
-                    e[3] = -2;
-                    continue;
-                }
-                int pred = -1, predkb = -1;
-                bool head = true;
+                int* e = v8_entry(xb, wb, cx, valid ? i : 0);
+                const int r = e[0], kb = e[1];
+                const bool live = valid && (is_x ? (r >= m0 && r < m0 + BM && r < Mrows) : (r >= n0 && r < n0 + 256 && r < Ncols));
                 const int lo = is_x ? 0 : cx, hi = is_x ? cx : n;
-                for (int j = lo; j < hi; ++j) {
-                    const int* f = v8_entry(xb, wb, cx, j);
-                    if (f[0] != (int)r) continue;
-                    const int kj = f[1];
-                    if (kj < kb && kj > predkb) { pred = j; predkb = kj; }
-                    head = head && kj <= kb;
+                int key = -1, later = 0;                                // key = (block << 8 | index) of the best predecessor
+                if (live)
+                    for (int j = lo + sub; j < hi; j += 16) {
+                        const int* f = v8_entry(xb, wb, cx, j);
+                        if (f[0] != r) continue;
+                        const int kj = f[1];
+                        if (kj < kb) key = max(key, (kj << 8) | (j - lo));
+                        later |= kj > kb ? 1 : 0;
+                    }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    key = max(key, __shfl_xor(key, o));
+                    later |= __shfl_xor(later, o);
                 }
-                e[3] = pred >= 0 ? pred - lo : -1;
-                if (head) (is_x ? rowslot : colslot)[r - (is_x ? m0 : n0)] = i - lo;
-                if (pred >= 0) *multi = 1;
+                if (valid && sub == 0) {
+                    if (!live) {
+                        e[3] = -2;
+                    } else {
+                        e[3] = key >= 0 ? (key & 255) : -1;
+                        if (!later) (is_x ? rowslot : colslot)[r - (int)(is_x ? m0 : n0)] = i - lo;
+                        if (key >= 0) *multi = 1;
+                    }
+                }
             }
+            if (mode == 1) gather_finish(qv, reinterpret_cast<float*>(smem + V8_CORR), 0, std::integral_constant<int, U_PRO>{});
+            if (FIXMODE_ == 3) pst[2] = __builtin_amdgcn_s_memrealtime();
+        } else if (LATE_STAGE1 && nsteps > 1) {
+            stage(1, 1);
         }
     }
 
@@ -314,8 +342,9 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 
     unsigned long long c0 = 0, r0 = 0;
     unsigned long long rt[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long rt_start = kernel_t0;
     if (FIXMODE_ == 2) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    if (FIXMODE_ == 3) rt[0] = __builtin_amdgcn_s_memrealtime();
+    if (FIXMODE_ == 3) { rt[0] = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_amdgcn_s_memtime(); }
 
     // Two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while a group issues its 16
     // MFMAs between two barriers, the other reads its next fragments from LDS and issues its LDS-DMA loads.
@@ -330,7 +359,69 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                                                  (lptr_t)(smem + sl * STAGE + dst[q]), 16, 0, 0);
     };
     int slot = 0;
-    if (!ONEPHASE) {
+    constexpr bool ONEPHASE = SCHED == 1;
+    if (SCHED == 2) {
+        // PIPELINED schedule: ONE barrier per K-step, no staggered wave groups.  Every wave keeps its MFMA stream fed from
+        // registers: while the 4 MFMAs of A fragment i issue, fragment i + 2 is being read (the last two reads of a step
+        // and the four B reads fetch step t + 1, from the next stage), and the wave's LDS-DMA pieces of step t + 2 go out
+        // one per MFMA group.  Both waves of a SIMD run the same stream; the matrix pipe alternates between them and
+        // either one's LDS / DMA issue slots hide behind the other's MFMAs.
+        //   barrier(t): every wave has waited for its own pieces of step t + 1 (requested a whole step earlier) and has
+        //   finished every read of step t - 1 (all consumed by MFMAs it has issued)  =>  behind it stage t + 1 may be read
+        //   and stage t - 1 = stage t + 2 of the ring of three may be re-filled.
+        static_assert(SCHED != 2 || (NS == 3 && TI == 8 && LPW == 4), "pipelined schedule: 256 x 256 tile, ring of three");
+        i32x4 fa[4], fb0[TJ], fb1[TJ];
+        // Fragment reads are inline assembly with hand-counted waits (LDS reads of a wave return in issue order): left to
+        // the compiler every read sinks to just in front of its first use behind an lgkmcnt(0).  Lane-constant part of
+        // the addresses; fragment i is i KiB further (immediate offset), a stage STAGE bytes further.
+        const int va = piece_lds_off(wm * WM + l16, lq), vb = HALF + piece_lds_off(wn * 64 + l16, lq);
+#define V8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define V8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n))
+        if (nsteps > 1) V8_WAIT(LPW); else V8_WAIT(0);
+        __builtin_amdgcn_s_barrier();
+        V8_DSR(fb0[0], vb, 0); V8_DSR(fb0[1], vb, 1024); V8_DSR(fb0[2], vb, 2048); V8_DSR(fb0[3], vb, 3072);
+        V8_DSR(fa[0], va, 0); V8_DSR(fa[1], va, 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        // reads issued in MFMA group i of a step:  i < 6: A(i+2);  i = 6, 7: A(0), A(1) of the next step;  i = 2..5 also
+        // B(i-2) of the next step.  Reads still in flight when group i's MFMAs need A(i) -- the counted waits below.
+        // ONE body for every step (two instances: the B fragment sets swap roles): the last step reads its "successor"
+        // fragments from the stage it is on (unused values: the hand-counted waits stay the same) and the last two steps
+        // request the final step once more (into the free stage of the ring; drained behind the loop, never read).
+        auto body = [&](i32x4 (&fb)[TJ], i32x4 (&fbn)[TJ], int t, int sc, int sn, int dslot) {
+            V8_WAIT(0);
+            __builtin_amdgcn_s_barrier();
+            const int ac = va + sc, an = va + sn, bn = vb + sn;
+            const long long dstep = (long long)min(t + 2, nsteps - 1) * 1024;
+#define V8_GROUP(i, wait)                                                                                              \
+            if (i < TI - 2) V8_DSR(fa[(i + 2) & 3], ac, (i + 2) * 1024);                                               \
+            else V8_DSR(fa[(i + 2) & 3], an, (i + 2 - TI) * 1024);                                                     \
+            if (i >= 2 && i < 2 + TJ) V8_DSR(fbn[(i - 2) & 3], bn, ((i - 2) & 3) * 1024);                              \
+            if (i < LPW)                                                                                               \
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[i & 3] + dstep), (lptr_t)(smem + dslot * STAGE + dst[i & 3]), \
+                                                 16, 0, 0);                                                            \
+            V8_LGKM(wait);                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                             \
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i & 3], fb[j], acc[i][j], 0, 0, 0);                \
+            __builtin_amdgcn_sched_barrier(0);
+            V8_GROUP(0, 2) V8_GROUP(1, 2) V8_GROUP(2, 3) V8_GROUP(3, 4) V8_GROUP(4, 5) V8_GROUP(5, 5) V8_GROUP(6, 4) V8_GROUP(7, 3)
+#undef V8_GROUP
+        };
+        int s0 = 0, s1 = 1, s2 = 2;
+        auto rot = [&]() { const int o = s0; s0 = s1; s1 = s2; s2 = o; };
+        for (int t = 0; t < nsteps; t += 2) {                // (nsteps is even: K % 128 == 0)
+            body(fb0, fb1, t, s0 * STAGE, s1 * STAGE, s2);
+            rot();
+            body(fb1, fb0, t + 1, s0 * STAGE, (t + 2 < nsteps ? s1 : s0) * STAGE, s2);
+            rot();
+        }
+        V8_WAIT(0);
+        V8_LGKM(0);                                          // (the compiler does not know these reads are in flight)
+        __builtin_amdgcn_sched_barrier(0);
+#undef V8_DSR
+#undef V8_LGKM
+        __builtin_amdgcn_s_barrier();                   // (the epilogue's LDS areas: every wave is out of the stages)
+    } else if (!ONEPHASE) {
         // A K-step is two phases (A rows 0-63, then 64-127 of the wave tile).  The pieces of step t+2 are requested in
         // phase 1 of step t (two) and phase 0 of step t+1 (two): a stage is re-filled two barriers after its last read,
         // so fragment reads may retire behind the barrier, beside the other group's wait.
@@ -423,7 +514,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         if (wm == 0) __builtin_amdgcn_s_barrier();
     }
 
-    if (FIXMODE_ == 3) rt[1] = __builtin_amdgcn_s_memrealtime();
+    if (FIXMODE_ == 3) { rt[1] = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_amdgcn_s_memtime() - c0; }
     if (FIXMODE_ == 2) {
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if ((blockIdx.x == 0 || blockIdx.x == 77) && tid == 0)
@@ -434,7 +525,11 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         __syncthreads();                                         // every wave is done with the stage area
         if (mode == 2) {
             corr = reinterpret_cast<float*>(smem);
-            compute_vectors(corr);
+            for (int base = 0; base < cx + cw; base += 2 * V8_NW) {        // (two entries a wave and round: the
+                int4 qv2[2][4];                                             //  accumulators are live here)
+                gather_issue(qv2, base, std::integral_constant<int, 2>{});
+                gather_finish(qv2, corr, base, std::integral_constant<int, 2>{});
+            }
             __syncthreads();
         }
         if (mode != 3) {
@@ -543,8 +638,9 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     if (FIXMODE_ == 3) {
         rt[5] = __builtin_amdgcn_s_memrealtime();
         if ((blockIdx.x == 0 || blockIdx.x == 77) && (tid == 0 || tid == 448))
-            printf("wg %d wave %d: loop %llu | cross %llu | scale %llu | lookups %llu | stores %llu (x 10 ns) cx %d cw %d mode %d\n", blockIdx.x, wave,
-                   rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2], rt[4] - rt[3], rt[5] - rt[4], cx, cw, mode);
+            printf("wg %d wave %d: [issue %llu, buckets %llu, vectors %llu, chains+stage0 %llu] prologue %llu | loop %llu | cross %llu | scale %llu | lookups %llu | stores %llu (x 10 ns) cx %d cw %d mode %d; loop %.0f MHz, %.0f clocks per K-step\n", blockIdx.x, wave,
+                   pst[0] - rt_start, pst[1] - pst[0], pst[2] - pst[1], rt[0] - pst[2], rt[0] - rt_start, rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2], rt[4] - rt[3], rt[5] - rt[4], cx, cw, mode,
+                   (double)c0 / (double)(rt[1] - rt[0]) * 100.0, (double)c0 / nsteps);
     }
     if (FIXMODE && mode == 3) {
         V8_WAIT(0);
@@ -570,13 +666,20 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
     static const bool want_clock = getenv("MI355Q_V8_CLOCK") != nullptr, want_stamps = getenv("MI355Q_V8_STAMPS") != nullptr;
     const bool fix = xlist && wlist;
     if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
+    // K-loop schedule of the 256 x 256 tile: 2 = pipelined (one barrier per K-step, default: 71.0 vs 72.8 us at 4096^3),
+    // 0 = two staggered wave groups, four barriers per K-step (kept for A/B runs: MI355Q_V8_SCHED=0)
+    static const int sched = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
     const unsigned grid = tiles + (fix ? V8_FALLBACK_WGS : 0);          // the fallback workgroups ride behind the tiles
     if (small) {
         if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
         else hipLaunchKernelGGL((bfp_gemm_v8<0, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-    } else if (fix && want_stamps) hipLaunchKernelGGL((bfp_gemm_v8<3, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    } else if (fix && want_stamps && sched == 2) hipLaunchKernelGGL((bfp_gemm_v8<3, 8, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (fix && want_stamps) hipLaunchKernelGGL((bfp_gemm_v8<3, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (fix && sched == 2) hipLaunchKernelGGL((bfp_gemm_v8<1, 8, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (want_clock && sched == 2) hipLaunchKernelGGL((bfp_gemm_v8<2, 8, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else if (want_clock) hipLaunchKernelGGL((bfp_gemm_v8<2, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (sched == 2 && a.K % 128 == 0) hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else hipLaunchKernelGGL((bfp_gemm_v8<0, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();
 }
