@@ -402,10 +402,32 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
                                                                    int* __restrict__ list_to_clear, int bcap) {
     __shared__ Lut lut;
     __shared__ RowAlignSmem rsm;
-    load_lut<FMT_BFP>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long K = a.cols;
     const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
+    const long long rows16 = a.rows & ~127ll;               // rows covered by whole groups of 8 piece rows
+    // Workgroup -> row: the 16 rows of one piece row (they share every 1-KiB piece they write, 16 bytes each per block)
+    // go to workgroups b, b + 8, b + 16, ... -- the ones that share an XCD and therefore an L2, which merges their
+    // partial-line stores (consecutive workgroup ids are dealt round-robin over the 8 XCDs, whose L2s are not coherent:
+    // lines written from two of them leave as two masked partial writes).  Speed only; any mapping is correct.
+    auto row_of = [&](long long wi) {
+        if (wi >= rows16) return wi;
+        const long long grp = wi >> 7, in = wi & 127;       // 128 rows = 8 piece rows, one per XCD
+        return (grp << 7) + ((in & 7) << 4) + (in >> 3);
+    };
+    auto load_row = [&](float4 (&v)[MAXIT], long long row) {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int kb = it * 64 + wave * 16 + (lane >> 2);
+            v[it] = (FULL || (it < nit && kb < nkb)) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // the first row is requested before anything else: the threshold table's own round trip (global -> LDS) and the
+    // list clearing below run while it is in flight (a workgroup usually has exactly one row)
+    float4 v[MAXIT];
+    if ((long long)blockIdx.x < a.rows) load_row(v, row_of(blockIdx.x));
+    load_lut<FMT_BFP>(lut);
     if (list_to_clear && blockIdx.x == 0) {
         const int cb = bcap < 0 ? ROW_BCAP : bcap;
         const long long words = row_list_words(a.rows, cb), bw = row_bucket_words(cb);
@@ -415,51 +437,69 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     }
     const int mbits_int = (int)__builtin_log2f(a.shift);
     __syncthreads();
-    // Workgroup -> row: the 16 rows of one piece row (they share every 1-KiB piece they write, 16 bytes each per block)
-    // go to workgroups b, b + 8, b + 16, ... -- the ones that share an XCD and therefore an L2, which merges their
-    // partial-line stores (consecutive workgroup ids are dealt round-robin over the 8 XCDs, whose L2s are not coherent:
-    // lines written from two of them leave as two masked partial writes).  Speed only; any mapping is correct.
-    const long long rows16 = a.rows & ~127ll;               // rows covered by whole groups of 8 piece rows
     for (long long wi = blockIdx.x; wi < a.rows; wi += gridDim.x) {
-        long long row = wi;
-        if (wi < rows16) {
-            const long long grp = wi >> 7, in = wi & 127;   // 128 rows = 8 piece rows, one per XCD
-            row = (grp << 7) + ((in & 7) << 4) + (in >> 3);
-        }
-        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
-        float4 v[MAXIT];
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            const int kb = it * 64 + wave * 16 + (lane >> 2);
-            v[it] = (FULL || (it < nit && kb < nkb)) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const long long row = row_of(wi);
+        if (wi != (long long)blockIdx.x) load_row(v, row);
         unsigned pk[MAXIT];
         int amax[MAXIT], code[MAXIT];
+        // Pass 1: block maxima, shared exponents, scale exponents (the threshold table is read unconditionally: no
+        // branch around an LDS read).  Block maxima are compared as unsigned bit patterns of |x| (monotone for floats).
+        unsigned bmb[MAXIT];
+        int up[MAXIT];
+        bool big = false;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            float bmax = fmaxf(fmaxf(fabsf(v[it].x), fabsf(v[it].y)), fmaxf(fabsf(v[it].z), fabsf(v[it].w)));
-            bmax = group_max<4>(bmax);
-            const bool nz = bmax != 0.f;
-            const float bm1 = nz ? bmax : 1.0f;                 // all-zero block: fill 1 (MI355Q_ZERO_BLOCK_FAST)
-            const int e = clampi(ceil_log2_frexp(bm1, lut), a.e_min, a.e_max);
-            const int up = mbits_int - e;
-            int q0, q1, q2, q3, am;
-            if (__any(up >= 28)) {                                // (blocks below 2^-23: keep the exact zero rule)
-                q0 = (int)mant_f(v[it].x, up, a.mant_max); q1 = (int)mant_f(v[it].y, up, a.mant_max);
-                q2 = (int)mant_f(v[it].z, up, a.mant_max); q3 = (int)mant_f(v[it].w, up, a.mant_max);
-                // (an element equal to -1e-9 has mantissa 0 whatever its magnitude: take the maximum of what was formed)
-                am = (int)group_max<4>((float)max(max(abs(q0), abs(q1)), max(abs(q2), abs(q3))));
-            } else {
-                q0 = (int)mant_f_small_up(v[it].x, up, a.mant_max); q1 = (int)mant_f_small_up(v[it].y, up, a.mant_max);
-                q2 = (int)mant_f_small_up(v[it].z, up, a.mant_max); q3 = (int)mant_f_small_up(v[it].w, up, a.mant_max);
-                // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone)
-                am = (int)fminf(__builtin_rintf(__builtin_ldexpf(bmax + EPS9, up)), a.mant_max);
-            }
-            amax[it] = nz ? am : 0;
+            const unsigned b0 = __float_as_uint(v[it].x) & 0x7FFFFFFFu, b1 = __float_as_uint(v[it].y) & 0x7FFFFFFFu;
+            const unsigned b2 = __float_as_uint(v[it].z) & 0x7FFFFFFFu, b3 = __float_as_uint(v[it].w) & 0x7FFFFFFFu;
+            unsigned m = max(max(b0, b1), max(b2, b3));
+            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+            bmb[it] = m;
+            const float bm1 = m != 0u ? __uint_as_float(m) : 1.0f;     // all-zero block: fill 1 (MI355Q_ZERO_BLOCK_FAST)
+            const int k = __builtin_amdgcn_frexp_expf(bm1) - 1;        // bm1 = 2^k (1 + f 2^-23)
+            const unsigned f = __float_as_uint(__builtin_amdgcn_frexp_mantf(bm1)) & 0x7FFFFFu;
+            const unsigned thr = lut.a[lut_index(k)];
+            const int e = clampi(k + ((f != 0u && f >= thr) ? 1 : 0), a.e_min, a.e_max);
+            up[it] = mbits_int - e;
             code[it] = e + a.code_bias;
-            const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);
-            const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);
-            pk[it] = lo | hi;
+            big = big || up[it] >= 28;
+        }
+        if (__any(big)) {
+            // some block of the row lies below 2^-23: the exact rule (an element equal to -1e-9 has mantissa 0 whatever
+            // its magnitude, block_fp.py:69) for the whole row
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int q0 = (int)mant_f(v[it].x, up[it], a.mant_max), q1 = (int)mant_f(v[it].y, up[it], a.mant_max);
+                const int q2 = (int)mant_f(v[it].z, up[it], a.mant_max), q3 = (int)mant_f(v[it].w, up[it], a.mant_max);
+                const int am = (int)group_max<4>((float)max(max(abs(q0), abs(q1)), max(abs(q2), abs(q3))));
+                amax[it] = bmb[it] != 0u ? am : 0;
+                const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);
+                const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);
+                pk[it] = lo | hi;
+            }
+        } else {
+            // Fast path (every scale exponent < 28).  Signed mantissa of x:  sign(x + 1e-9) min(rne((|x| + 1e-9) 2^up), mmax)
+            //   = rne(clamp(fma(x, 2^up, copysign(1e-9 * 2^up, x)), -mmax, mmax)):  scaling by a power of two commutes
+            //   with the fp32 rounding of |x| + 1e-9, an element in [-1e-9, 0) rounds to 0 here whatever sign it carries,
+            //   clamping to an integer bound commutes with rounding.  The rounding itself is the fp32 add of 1.5 * 2^23,
+            //   which leaves the two's-complement mantissa in the low byte of the sum's bit pattern (|m| <= 127).
+            constexpr float MAGIC = 12582912.0f;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const float sc = __builtin_ldexpf(1.0f, up[it]);
+                const float es = EPS9 * sc;                             // (exact: a power-of-two multiple of 1e-9f)
+                auto mant_bits = [&](float x) {
+                    const float r = __builtin_fmaf(x, sc, __builtin_copysignf(es, x));
+                    return __float_as_uint(__builtin_amdgcn_fmed3f(r, -a.mant_max, a.mant_max) + MAGIC);
+                };
+                const unsigned t0 = mant_bits(v[it].x), t1 = mant_bits(v[it].y), t2 = mant_bits(v[it].z), t3 = mant_bits(v[it].w);
+                // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone)
+                amax[it] = (int)(mant_bits(__uint_as_float(bmb[it])) - 0x4B400000u);
+                if (bmb[it] == 0u) amax[it] = 0;
+                const unsigned lo = __builtin_amdgcn_perm(t1, t0, 0x0c0c0400u);
+                const unsigned hi = __builtin_amdgcn_perm(t3, t2, 0x04000c0cu);
+                pk[it] = lo | hi;
+            }
         }
         int E = 0;
         // bcap < 0: no alignment at all -- every block keeps its own exponent, rowflag 0 (operands for the blockwise
