@@ -79,6 +79,23 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
                                   int32_t b0, int32_t b1, int32_t width, int32_t exponent_width,
                                   int32_t exponent_bias, void* workspace, void* stream);
 
+/* ---- operands whose blocks keep their own exponents: bf16 flavour of the tile GEMM ----------------
+ * replaces: quantized_modules/linear.py:59-76 for inputs no row window fits (post-SiLU / post-ReLU activations, weights
+ * with outlier input channels) -- the reference's x_q @ W_q^T on values that are exact in bf16 (width <= 9), products
+ * exact in fp32, fp32 accumulation as in its F.linear.
+ * mi355q_block_fp_quantize_bf16_tiled: x fp32 [rows, K], [1,16] blocks along K -> y_tiled bf16 in the GEMM's tile
+ *   order (mi355q_bfp_tiled_bytes(rows, 2 K) bytes: 1-KiB pieces of 16 rows x 32 values, [8 values][row][16 bytes]
+ *   inside) and, if y != NULL, the fp32 fake-quantised values (y == x allowed: the weights' in-place overwrite,
+ *   linear.py:66-70).  K % 32 == 0, width <= 9.  All-zero blocks quantise to zeros (MI355Q_ZERO_BLOCK_FAST).
+ * mi355q_bf16_gemm_tiled: y[M, N] = x . w^T (+ bias), fp32, ldy >= N; the same 256 x 256 / 128 x 256 tile kernel as the
+ *   row-scale int8 GEMM with v_mfma_f32_16x16x32_bf16. */
+int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
+                                        int32_t exponent_width, int32_t exponent_bias, void* workspace, void* stream);
+/* values that are already quantised (exact in bf16), fp32 [rows, K] -> the same tiled bf16 (a cast; K % 32 == 0) */
+int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, void* stream);
+int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
+                           int64_t K, int64_t ldy, void* stream);
+
 /* ---- block minifloat ----------------------------------------------------------------
  * replaces: quantizers/block_minifloat.py:22-74 -> quantizers/minifloat.py:134-196 behind
  *           QUANTIZER_MAP["block_minifloat"].   y: fake-quantised fp32 (required).

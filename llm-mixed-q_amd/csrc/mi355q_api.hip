@@ -119,6 +119,57 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
     return launch_quant(a, 0, /*needs_fixup=*/false, static_cast<hipStream_t>(stream));
 }
 
+int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
+                                        int32_t exponent_width, int32_t exponent_bias, void* workspace, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, y, workspace, 1, rows, K, 1, 16, MI355Q_ZERO_BLOCK_FAST);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y_tiled == nullptr) return MI355Q_E_BADARG;
+    if (exponent_width < 1 || exponent_width > 8 || width < 2) return MI355Q_E_BADARG;
+    if (width > 9 || K % 32 != 0) return MI355Q_E_UNSUPPORTED;   // bf16's 8 significant bits; whole 64-byte K-steps
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_tiled)) % 16) return MI355Q_E_ALIGN;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    a.code_bias = exponent_bias;
+    a.e_min = -exponent_bias;
+    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    set_mantissa(a, width - 1);
+    return launch_quant_bf16_tiled(a, y_tiled, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, nullptr, nullptr, 1, rows, K, 1, 16, MI355Q_ZERO_BLOCK_FAST);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y_tiled == nullptr) return MI355Q_E_BADARG;
+    if (K % 32 != 0) return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y_tiled)) % 16) return MI355Q_E_ALIGN;
+    a.code_bias = 127; a.e_min = -127; a.e_max = 128;
+    set_mantissa(a, 7);
+    return launch_quant_bf16_tiled(a, y_tiled, static_cast<hipStream_t>(stream), /*cast_only=*/true);
+}
+
+int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
+                           int64_t K, int64_t ldy, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
+    if (M == 0 || N == 0) return 0;
+    if (!y || (K > 0 && (!x_tiled || !w_tiled))) return MI355Q_E_BADARG;
+    if (K % 32 != 0 || K == 0) return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x_tiled) | reinterpret_cast<uintptr_t>(w_tiled)) % 16) return MI355Q_E_ALIGN;
+    GemmArgs a{};
+    a.xm = reinterpret_cast<const int8_t*>(x_tiled);
+    a.wm = reinterpret_cast<const int8_t*>(w_tiled);
+    a.bias = bias;
+    a.y = y;
+    a.M = M; a.N = N; a.K = 2 * K; a.ldy = ldy;      // (the tile kernel counts the contraction in bytes)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t te = g_timing.begin(st);
+    const int rc = launch_bf16_gemm_tiled(a, st);
+    g_timing.end(te, st);
+    return rc;
+}
+
 int mi355q_block_minifloat_quantize(const float* x, float* y, uint8_t* bias, int64_t lead, int64_t rows, int64_t cols,
                                     int32_t b0, int32_t b1, int32_t width, int32_t exponent_width,
                                     int32_t exponent_bias_width, uint32_t flags, void* workspace, void* stream) {

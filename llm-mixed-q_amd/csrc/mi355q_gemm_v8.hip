@@ -111,7 +111,18 @@ __device__ __forceinline__ void v8_fallback(const GemmArgs& a, const uint8_t* __
 }
 constexpr int V8_FALLBACK_WGS = 256;
 
-template <int FIXMODE_, int TI, int SCHED = (TI == 4 ? 1 : 0)>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
+// the two arithmetics of the tile kernel: int8 mantissas -> int32 (row-scale block-fp GEMM), or bf16 values -> fp32
+// (operands that keep every block's own exponent: a block_fp value of width <= 9 is exact in bf16 and a product of two
+// of them is exact in fp32).  Same fragment geometry: one 16-byte read per lane = 16 int8 or 8 bf16 of one row.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x4 v8_mma(const i32x4& fa, const i32x4& fb, const i32x4& c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, fb, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 v8_mma(const i32x4& fa, const i32x4& fb, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb), c, 0, 0, 0);
+}
+
+template <int FIXMODE_, int TI, int SCHED = (TI == 4 ? 1 : 0), bool BF16 = false>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
 __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
                                                         const float* __restrict__ sw, const int* __restrict__ xlist,
@@ -167,9 +178,9 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                 if (q * 256 + lane * 4 < ROW_BUCKET_WORDS)
                     __builtin_amdgcn_global_load_lds((gptr_t)(b + q * 256 + lane * 4), (lptr_t)(d + q * 1024), 16, 0, 0);
         }
-    } else if (wave == 2) {
+    } else if (!BF16 && wave == 2) {
         __builtin_amdgcn_global_load_lds((gptr_t)(sx + m0 + lane * 4), (lptr_t)(smem + V8_SXT), 16, 0, 0);
-    } else if (wave == 3) {
+    } else if (!BF16 && wave == 3) {
         __builtin_amdgcn_global_load_lds((gptr_t)(sw + n0 + lane * 4), (lptr_t)(smem + V8_SWT), 16, 0, 0);
     } else if (wave == 4) {
 #pragma unroll
@@ -334,11 +345,13 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         }
     }
 
-    i32x4 acc[TI][TJ];
+    static_assert(!BF16 || FIXMODE_ == 0, "the bf16 arithmetic has no exception lists");
+    using acc_t = typename std::conditional<BF16, f32x4, i32x4>::type;
+    acc_t acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
     unsigned long long c0 = 0, r0 = 0;
     unsigned long long rt[6] = {0, 0, 0, 0, 0, 0};
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             V8_LGKM(wait);                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                             \
-                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i & 3], fb[j], acc[i][j], 0, 0, 0);                \
+                acc[i][j] = v8_mma(fa[i & 3], fb[j], acc[i][j]);                                                                        \
             __builtin_amdgcn_sched_barrier(0);
             V8_GROUP(0, 2) V8_GROUP(1, 2) V8_GROUP(2, 3) V8_GROUP(3, 4) V8_GROUP(4, 5) V8_GROUP(5, 5) V8_GROUP(6, 4) V8_GROUP(7, 3)
 #undef V8_GROUP
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = v8_mma(fa[i], fb[j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---- phase 1
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[TI - 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[TI - 4 + i][j], 0, 0, 0);
+                    acc[TI - 4 + i][j] = v8_mma(fa[i], fb[j], acc[TI - 4 + i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             slot = slot + 1 == NS ? 0 : slot + 1;
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = v8_mma(fa[i], fb[j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             if (wm == 0) request_and_wait(t);
             __builtin_amdgcn_s_barrier();
@@ -589,7 +602,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         for (int i = 0; i < TI; ++i) {
             const f32x4 sxv = *reinterpret_cast<const f32x4*>(&sxt[wm * WM + i * 16 + lq * 4]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) val[i][j][r] = (float)acc[i][j][r] * sxv[r] * swv + bv;
+            for (int r = 0; r < 4; ++r) val[i][j][r] = BF16 ? (float)acc[i][j][r] + bv : (float)acc[i][j][r] * sxv[r] * swv + bv;
         }
     }
     if (FIXMODE_ == 3) rt[3] = __builtin_amdgcn_s_memrealtime();
@@ -681,6 +694,20 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
     else if (want_clock) hipLaunchKernelGGL((bfp_gemm_v8<2, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else if (sched == 2 && a.K % 128 == 0) hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else hipLaunchKernelGGL((bfp_gemm_v8<0, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    return (int)hipGetLastError();
+}
+
+// y = x . w^T (+ bias) on TILED bf16 operands (the same 1-KiB pieces: 16 rows x 32 values): a.xm / a.wm point at the
+// bf16 pieces and a.K is the contraction length IN BYTES (2 K).  K % 32 == 0.
+int launch_bf16_gemm_tiled(const GemmArgs& a, hipStream_t st) {
+    const long long tn = (a.N + V8_BN - 1) / V8_BN;
+    const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
+    const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost128 = (double)((t128 + 255) / 256) * 0.82;
+    const bool small = cost128 < cost256;
+    const unsigned tiles = (unsigned)(small ? t128 : t256);
+    if (small) hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 1, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else if (a.K % 128 == 0) hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 0, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     return (int)hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ struct QuantArgs {
 };
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
+int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only = false);
 int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
                        int* list, int list_cap, int* list_to_clear, hipStream_t st);
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
@@ -59,6 +60,7 @@ int launch_bfp_gemm_rowpost(const GemmArgs& a, const int* xlist, const int* wlis
                             hipStream_t st);
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st, const uint8_t* xf = nullptr, const uint8_t* wf = nullptr);
+int launch_bf16_gemm_tiled(const GemmArgs& a, hipStream_t st);
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
                          int list_cap, hipStream_t st, const float* xscale = nullptr, const float* wscale = nullptr);
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,

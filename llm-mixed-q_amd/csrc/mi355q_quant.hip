@@ -546,6 +546,56 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// block_fp quantise ([1,16] blocks along the last dim) straight into TILED bf16: the operand of the bf16 flavour of the
+// tile GEMM (mi355q_gemm_v8.hip) -- operands whose blocks keep their own exponents.  1-KiB pieces of 16 rows x 32 values,
+// [8-value group 0..3][row 0..15][16 bytes] inside (mi355q_gemm_v2.h with K counted in bytes).  One workgroup per row;
+// optionally also the fp32 fake-quantised values in place of / next to x (the weights' first-forward overwrite).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantArgs a, uint16_t* __restrict__ yt, int cast_only) {
+    __shared__ Lut lut;
+    load_lut<FMT_BFP>(lut);
+    const long long K = a.cols, kp = (K * 2) >> 6;
+    const int nslots = (int)(K >> 2);
+    for (long long row = blockIdx.x; row < a.rows; row += gridDim.x) {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
+        float4* __restrict__ y4 = a.y ? reinterpret_cast<float4*>(a.y + row * K) : nullptr;
+        unsigned char* prow = reinterpret_cast<unsigned char*>(yt) + (row >> 4) * kp * 1024 + (row & 15) * 16;
+        for (int j0 = 0; j0 < nslots; j0 += 256) {                    // uniform trip count (quad reductions inside)
+            const int j = j0 + (int)threadIdx.x;
+            const bool valid = j < nslots;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) v = x4[j];
+            float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            bmax = group_max<4>(bmax);
+            if (bmax == 0.f) bmax = 1.0f;
+            unsigned code;
+            const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
+            int q;
+            float4 o;
+            o.x = quant_elem<FMT_BFP>(v.x, bp, a, lut, q);
+            o.y = quant_elem<FMT_BFP>(v.y, bp, a, lut, q);
+            o.z = quant_elem<FMT_BFP>(v.z, bp, a, lut, q);
+            o.w = quant_elem<FMT_BFP>(v.w, bp, a, lut, q);
+            if (cast_only) o = v;                                      // (values that are already quantised: tile them)
+            if (valid) {
+                if (y4) y4[j] = o;
+                const int kb = j * 8;                                  // byte offset of these 4 values in the bf16 row
+                *reinterpret_cast<uint2*>(prow + (long long)(kb >> 6) * 1024 + ((kb >> 4) & 3) * 256 + (kb & 15)) =
+                    make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+            }
+        }
+    }
+}
+
+int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only) {
+    long long grid = a.rows;
+    if (grid > 65536) grid = 65536;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(bfp_quant_bf16_tiled_kernel, (unsigned)grid, 256, 0, st, a, yt, cast_only ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st) {
     switch (fmt) {
         case FMT_BFP: return launch_format<FMT_BFP>(a, needs_fixup, st);

@@ -135,6 +135,66 @@ def block_fp_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exp
     return y
 
 
+_BF16_TILED_BUFFERS: dict = {}
+
+
+def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, *, out_fake: torch.Tensor = None,
+                                 reuse: bool = True) -> torch.Tensor:
+    """x [rows, K] fp32 ([1,16] blocks along K) -> bf16 in the tile order of `bf16_gemm_tiled` (a flat int8 buffer of
+    mi355q_bfp_tiled_bytes(rows, 2 K) bytes).  `out_fake`: also write the fp32 fake-quantised values there (may be x
+    itself).  `reuse`: the buffer is shared by calls with the same shape on the same stream (activations; consume it
+    before quantising again), else freshly allocated (weights)."""
+    _require_device(x, "block_fp_quantize_bf16_tiled")
+    assert x.ndim == 2 and x.shape[1] % 32 == 0 and int(width) <= 9 and x.is_contiguous()
+    rows, K = x.shape
+    lib = _lib.load_library()
+    nbytes = lib.mi355q_bfp_tiled_bytes(rows, 2 * K)
+    if reuse:
+        key = (x.device.index, _stream_ptr(x.device), rows, K)
+        yt = _BF16_TILED_BUFFERS.get(key)
+        if yt is None:
+            if len(_BF16_TILED_BUFFERS) > 64:
+                _BF16_TILED_BUFFERS.clear()
+            yt = _BF16_TILED_BUFFERS[key] = torch.empty(nbytes, dtype=torch.int8, device=x.device)
+    else:
+        yt = torch.empty(nbytes, dtype=torch.int8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_block_fp_quantize_bf16_tiled(_ptr(x), _ptr(out_fake), _ptr(yt), rows, K, int(width), int(exponent_width),
+                                                     _default_bias(exponent_bias), _ptr(_workspace(x.device)),
+                                                     _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_fp_quantize_bf16_tiled")
+    return yt
+
+
+def bf16_tile(x: torch.Tensor) -> torch.Tensor:
+    """already-quantised fp32 values [rows, K] -> tiled bf16 (a cast into the tile order; exact for widths <= 9)"""
+    _require_device(x, "bf16_tile")
+    assert x.ndim == 2 and x.shape[1] % 32 == 0 and x.is_contiguous()
+    rows, K = x.shape
+    lib = _lib.load_library()
+    yt = torch.empty(lib.mi355q_bfp_tiled_bytes(rows, 2 * K), dtype=torch.int8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.mi355q_bf16_tile(_ptr(x), _ptr(yt), rows, K, _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_bf16_tile")
+    return yt
+
+
+def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, bias=None, out: torch.Tensor = None):
+    """y[M, N] = x . w^T (+ bias) on tiled bf16 operands (block_fp_quantize_bf16_tiled), fp32 accumulation and output:
+    the tile GEMM's bf16 arithmetic -- operands whose blocks keep their own exponents."""
+    if not (xt.is_cuda and wt.is_cuda):
+        raise RuntimeError("mi355q.bf16_gemm_tiled: operands must be on a HIP device; there is no CPU fallback")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=xt.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    with torch.cuda.device(xt.device):
+        rc = _lib.load_library().mi355q_bf16_gemm_tiled(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy,
+                                                       _stream_ptr(xt.device))
+    _lib.check(rc, "mi355q_bf16_gemm_tiled")
+    return out
+
+
 def block_minifloat_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent_bias_width: int,
                              block_size, skip_first_dim: bool, *, want_bias: bool = False):
     _require_device(x, "block_minifloat_quantize")

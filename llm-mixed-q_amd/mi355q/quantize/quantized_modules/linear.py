@@ -7,7 +7,9 @@ MI355X path of `LinearBlockFP` in PTQ mode (the hot path):
   first forward : W <- Qw(W), b <- Qb(b) in place (as the reference, linear.py:66-70) AND the int8
                   mantissas + uint8 shared exponents of W are packed once and kept on the module;
   every forward : x -> quantise+pack kernel -> exponent-align -> int8-MFMA block GEMM -> fp32 y (+ b), no fake-quant
-                  tensor and no fp32 GEMM.
+                  tensor and no fp32 GEMM.  Operands no row window fits (post-activation inputs, weights with outlier
+                  input channels) keep every block's exponent: x -> quantise straight into tiled bf16 -> the bf16
+                  flavour of the same tile GEMM (values exact in bf16, products exact in fp32).
 Formats whose contraction is not an int8 dot (block_minifloat, block_log, exotic block shapes,
 QAT) quantise with the HIP fake-quant kernels and contract with the stock fp32 GEMM on the GPU.
 """
@@ -63,8 +65,8 @@ class _LinearBase(nn.Linear):
         # "rows" = one exponent per row (row-scale int8 GEMM), "groups" = per 256 values, "auto" = rows when the
         # weights and the first activations fit it, re-checked on a doubling schedule
         self.align = config.get("mi355q_align", "auto")
-        self._align_mode, self._canonical, self._calls, self._row_overflows = None, None, 0, 0
-        self._w_bf16 = None
+        self._align_mode, self._calls, self._row_overflows = None, 0, 0
+        self._w_bf16 = None          # (tiled bf16 weights, weight._version) of the per-block-exponent route
         self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
         if not self.bypass:
             self._setup_quantizers(config)
@@ -114,8 +116,13 @@ class _LinearBase(nn.Linear):
             self.bias.copy_(self.b_quantizer(self.bias.data))
         self.weight_requires_quantisation = False
         if pack:
-            self._canonical = (wm, we) if self.align == "auto" else None
             self._align_weights(wm, we, self._choose_align_mode(wm, we, x_sample))
+            if self._uses_bf16_route():
+                # per-block exponents: the quantised weights (already in .weight) as tiled bf16; the int8 operand is not
+                # needed on this route (the exact-integer blockwise kernel, mi355q_blocks_gemm = "int8", keeps it)
+                self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+                self._packed = (None, self._w_bf16[0], self.weight._version,
+                                None if self.bias is None else self.bias._version)
 
     def _weight_bias_value(self):
         c = self.config
@@ -150,12 +157,17 @@ class _LinearBase(nn.Linear):
             self._x_cap = ops.ROW_BUCKET_CAP if fits else ops.ROW_NO_ALIGN
         return "rows"
 
+    def _uses_bf16_route(self) -> bool:
+        c = self.config
+        return (self._align_mode == "rows" and self._x_cap == ops.ROW_NO_ALIGN and self.in_features % 32 == 0
+                and c.get("mi355q_blocks_gemm", "bf16") == "bf16" and c["data_in_width"] <= 9 and c["weight_width"] <= 9)
+
     def _align_weights(self, wm, we, mode):
         c = self.config
         if mode == "rows":
             wa = ops.bfp_align_rows(wm, we, c["weight_width"] - 1, self._weight_bias_value())
         else:
-            wa = ops.bfp_align(wm, we, c["weight_width"] - 1, self._weight_bias_value(), inplace=self._canonical is None)
+            wa = ops.bfp_align(wm, we, c["weight_width"] - 1, self._weight_bias_value(), inplace=True)
         self._align_mode = mode
         self._packed = (wa, wa.tiled, self.weight._version, None if self.bias is None else self.bias._version)
 
@@ -164,12 +176,27 @@ class _LinearBase(nn.Linear):
         return (p is not None and p[2] == self.weight._version and p[1].device == self.weight.device
                 and (self.bias is None or p[3] == self.bias._version))
 
+    @torch.no_grad()
+    def _repack_quantised_weights(self, x_sample):
+        """the module was moved to another device after its first forward: pack again from .weight, which holds the
+        quantised values -- a quantised tensor re-encodes exactly only through a cast (the quantiser is not idempotent,
+        SURVEY 8a quirk 7), so the route from here on is the per-block-exponent one (tiled bf16).  Weights edited in
+        place after the first forward are NOT repacked: like the reference they are used as they are (fp32 GEMM) until
+        requantize()."""
+        if self.in_features % 32 or self.config["weight_width"] > 9 or self.config["data_in_width"] > 9:
+            return False
+        self._align_mode, self._x_cap = "rows", ops.ROW_NO_ALIGN
+        self._w_bf16 = (ops.bf16_tile(self.weight.data.contiguous()), self.weight._version)
+        self._packed = (None, self._w_bf16[0], self.weight._version, None if self.bias is None else self.bias._version)
+        return True
+
     def requantize(self):
         """Search-loop helper: after loading new fp32 weights into .weight/.bias, make the
         next forward quantise and pack them again instead of rebuilding the model."""
         self.weight_requires_quantisation = True if self.is_ptq else False
-        self._packed, self._canonical, self._align_mode, self._calls, self._row_overflows = None, None, None, 0, 0
+        self._packed, self._align_mode, self._calls, self._row_overflows = None, None, 0, 0
         self._w_bf16 = None
+        self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
 
     def forward(self, x):
         if self.bypass:
@@ -179,6 +206,10 @@ class _LinearBase(nn.Linear):
             with torch.no_grad():
                 if self.weight_requires_quantisation:
                     self._quantise_weights_once(pack=plan is not None, x_sample=x)
+                p = self._packed
+                if (plan is not None and p is not None and p[1].device != self.weight.device
+                        and p[2] == self.weight._version and (self.bias is None or p[3] == self.bias._version)):
+                    self._repack_quantised_weights(x)        # the module was moved: same (quantised) values, new device
                 if plan is not None and self._packed_is_current():
                     return self._forward_int8(x, plan)
                 x = self.x_quantizer(x)
@@ -192,20 +223,18 @@ class _LinearBase(nn.Linear):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
         x2 = x.reshape(-1, self.in_features)
-        if (self._align_mode == "rows" and self._x_cap == ops.ROW_NO_ALIGN
-                and c.get("mi355q_blocks_gemm", "bf16") == "bf16" and c["data_in_width"] <= 9 and c["weight_width"] <= 9):
-            # Activations no row window fits (SiLU-gated MLP inputs): every block keeps its exponent.  A block_fp value of
-            # width <= 9 is exact in bf16, so the product is a plain bf16 GEMM with fp32 accumulation and fp32 output on
-            # the library's MFMA kernel (x through the HIP fake-quantiser; the in-place quantised weights cast once).
-            # |x| <= 1e-8 pass-through elements are rounded to bf16 there (<= 2e-11 each).  "int8": the blockwise-exact
-            # int8 kernel instead (mi355q_bfp_gemm_aligned with row_aligned = 2), exact integer block dots, ~5x slower.
-            xq = ops.block_fp_quantize_bf16(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
-                                            [1, 16], True)
-            if self._w_bf16 is None or self._w_bf16[1] != self.weight._version:
-                self._w_bf16 = (self.weight.detach().to(torch.bfloat16), self.weight._version)
-            y = torch.mm(xq, self._w_bf16[0].t(), out_dtype=torch.float32)
-            if self.bias is not None:
-                y += self.bias
+        if self._uses_bf16_route():
+            # Activations (or weights) no row window fits: every block keeps its exponent.  A block_fp value of width <= 9
+            # is exact in bf16 and a product of two of them exact in fp32, so the product is the bf16 flavour of the tile
+            # GEMM (fp32 accumulation, fp32 output): x through the HIP quantiser straight into tiled bf16, the in-place
+            # quantised weights tiled once.  |x| <= 1e-8 pass-through elements are rounded to bf16 there (<= 2e-11 each).
+            # config["mi355q_blocks_gemm"] = "int8": the blockwise-exact int8 kernel instead (exact integer block dots,
+            # several times slower).
+            if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:
+                self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+            xt = ops.block_fp_quantize_bf16_tiled(x2.contiguous(), c["data_in_width"], c["data_in_exponent_width"],
+                                                  c["data_in_exponent_bias"])
+            y = ops.bf16_gemm_tiled(xt, self._w_bf16[0], x2.shape[0], self.out_features, self.in_features, self.bias)
             return y.reshape(*x.shape[:-1], self.out_features)
         if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],

@@ -542,3 +542,26 @@ def test_fused_quantize_align_rows_tiny_blocks_keep_the_zero_rule():
         assert o1 == o2 == 0 and set(map(tuple, e1)) == set(map(tuple, e2))
         assert torch.equal(got.tiled[: rows * K], ref.tiled[: rows * K])
         assert torch.equal(got.exp, ref.exp.reshape(-1)) and torch.equal(got.gscale[:rows], ref.gscale[:rows])
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 130, 1024), (100, 72, 96), (33, 16, 32), (520, 260, 4096), (1024, 768, 3072)])
+@pytest.mark.parametrize("style", ["rowscale", "outlier", "sparse"])
+@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 6)])
+def test_bf16_tiled_gemm_vs_oracle(M, N, K, style, wx, ww):
+    """operands whose blocks keep their own exponents: quantise straight into tiled bf16, bf16 flavour of the tile GEMM
+    (fp32 accumulation of exact products, like the reference's F.linear on the fake-quantised values)"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    x, w, b = _inputs(M, N, K, 4000 + M + N + K, style)
+    cfg = _cfg(wx, ww)
+    dev = torch.device("cuda:0")
+    xt = ops.block_fp_quantize_bf16_tiled(torch.from_numpy(x).to(dev), wx, 8, 127)
+    wdev = torch.from_numpy(w).to(dev)
+    wt = ops.block_fp_quantize_bf16_tiled(wdev, ww, 8, 127, out_fake=wdev, reuse=False)
+    assert np.array_equal(wdev.cpu().numpy(), O.block_fp_quantize(w, ww, 8, 127, [1, 16], False))   # in-place fake-quant
+    bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), ww, 8, 127, [16], False)
+    y = ops.bf16_gemm_tiled(xt, wt, M, N, K, bq).cpu().numpy()
+    ref = O.linear_ptq(x, w, b, dict(cfg, bias_width=ww))[0]
+    scale = np.abs(ref).max() + 1e-30
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
