@@ -26,7 +26,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
@@ -142,7 +145,8 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 
     const unsigned long long kernel_t0 = FIXMODE_ == 3 ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
-    const int nwg = tiles_m * tiles_n;
+    const int S = a.splits > 1 ? a.splits : 1;                 // workgroups per tile (split-K)
+    const int nwg = tiles_m * tiles_n * S;
     if (FIXMODE && (int)blockIdx.x >= nwg) {
         v8_fallback(a, xf, wf, xlist, wlist, smem, (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
         return;
@@ -152,11 +156,14 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int GM = 4, in_group = GM * tiles_n, group_id = pid / in_group, first_m = group_id * GM;
+    const int split = pid % S, tile_id = pid / S;               // (a tile's slices are neighbours: same XCD, speed only)
+    const int GM = 4, in_group = GM * tiles_n, group_id = tile_id / in_group, first_m = group_id * GM;
     const int gsz = min(tiles_m - first_m, GM);
-    const int tm = first_m + (pid % in_group) % gsz, tn = (pid % in_group) / gsz;
+    const int tm = first_m + (tile_id % in_group) % gsz, tn = (tile_id % in_group) / gsz;
     const long long m0 = (long long)tm * BM, n0 = (long long)tn * V8_BN;
-    const int nsteps = (int)(a.K >> 6);
+    const int nsteps_all = (int)(a.K >> 6);
+    const int kstep0 = (int)((long long)nsteps_all * split / S);          // this workgroup's slice of the K-steps
+    const int nsteps = (int)((long long)nsteps_all * (split + 1) / S) - kstep0;
     const long long Mrows = a.M, Ncols = a.N;
 
     int* xb = reinterpret_cast<int*>(smem + V8_XB);
@@ -202,8 +209,8 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
 #pragma unroll
     for (int q = 0; q < LPW; ++q) {
         const int p = wave + V8_NW * q;
-        src[q] = p < BM / 16 ? a.xm + min((m0 >> 4) + p, pa_max) * kp * 1024 + lane * 16
-                             : a.wm + min((n0 >> 4) + (p - BM / 16), pb_max) * kp * 1024 + lane * 16;
+        src[q] = (p < BM / 16 ? a.xm + min((m0 >> 4) + p, pa_max) * kp * 1024 + lane * 16
+                              : a.wm + min((n0 >> 4) + (p - BM / 16), pb_max) * kp * 1024 + lane * 16) + (long long)kstep0 * 1024;
         dst[q] = p * 1024;
     }
     auto stage = [&](int step, int slot) {
@@ -293,7 +300,8 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
         const int n = cx + cw;
-        mode = n == 0 ? 0 : (n <= V8_FAST_MAX ? 1 : (n <= V8_SLOW_MAX ? 2 : 3));
+        // (split-K: only the tile's last arriver adds exceptions, so their vectors are formed behind the K loop)
+        mode = n == 0 ? 0 : (n <= V8_FAST_MAX && S == 1 ? 1 : (n <= V8_SLOW_MAX ? 2 : 3));
         if (mode) {
             rowslot[tid & 255] = -1;                        // tid < 256: rowslot, else colslot (contiguous)
             if (tid >= 256) colslot[tid & 255] = -1;
@@ -534,6 +542,48 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             printf("wg %d: K loop %llu shader clocks in %llu x 10 ns -> %.0f MHz, %.1f clocks per K-step\n", blockIdx.x, c1 - c0,
                    r1 - r0, (double)(c1 - c0) / (double)(r1 - r0) * 100.0, (double)(c1 - c0) / nsteps);
     }
+    if (S > 1) {
+        // ---- split-K: every slice leaves its raw accumulators in its slab (16 bytes a lane, 1 KiB a wave instruction);
+        //      the slice that arrives last at the tile's ticket sums all slabs IN SLICE ORDER (reproducible for the fp32
+        //      flavour too; the int32 sums are exact in any order) and goes on to the epilogue, the others leave.
+        //      Hand-off: plain stores, every wave's vmcnt(0), workgroup barrier, agent-scope release by one lane, relaxed
+        //      ticket; the reducer acquires once, then loads plainly (cdna guide, Guideline 16).
+        constexpr long long SLAB = (long long)BM * 256 * 4;
+        acc_t* slab = reinterpret_cast<acc_t*>(static_cast<unsigned char*>(a.slabs) + ((long long)tile_id * S + split) * SLAB);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) slab[((wave * TI + i) * TJ + j) * 64 + lane] = acc[i][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flagw = reinterpret_cast<int*>(smem + V8_FLAGS) + 8;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t = __hip_atomic_fetch_add(&a.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == S - 1 ? 1 : 0;
+            if (last) {
+                __hip_atomic_store(&a.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle again
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flagw = last;
+        }
+        __syncthreads();
+        if (*flagw == 0) return;
+        const acc_t* tslabs = reinterpret_cast<const acc_t*>(static_cast<unsigned char*>(a.slabs) + (long long)tile_id * S * SLAB);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+        for (int sl = 0; sl < S; ++sl) {
+            const acc_t* sp = tslabs + (long long)sl * (SLAB / 16);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] += sp[((wave * TI + i) * TJ + j) * 64 + lane];
+        }
+    }
     if (FIXMODE && mode) {
         __syncthreads();                                         // every wave is done with the stage area
         if (mode == 2) {
@@ -662,9 +712,60 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     }
 }
 
-int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
+
+// ---- split-K workspace: raw accumulator slabs + one ticket per tile, owned by the library, one per (device, stream),
+//      grow-only; tickets are zero whenever no launch is in flight (the reducer of a tile clears its ticket).
+struct SplitWorkspace {
+    void* slabs = nullptr;
+    int* tickets = nullptr;
+    size_t slab_bytes = 0;
+    int ntickets = 0;
+};
+static SplitWorkspace* split_workspace(hipStream_t st, size_t slab_bytes, int ntickets) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SplitWorkspace> all;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SplitWorkspace& w = all[{dev, st}];
+    if (w.slab_bytes < slab_bytes) {
+        if (w.slabs) (void)hipFree(w.slabs);              // (synchronises: nothing of this workspace is in flight after)
+        w.slabs = nullptr;
+        w.slab_bytes = 0;
+        if (hipMalloc(&w.slabs, slab_bytes) != hipSuccess) return nullptr;
+        w.slab_bytes = slab_bytes;
+    }
+    if (w.ntickets < ntickets) {
+        if (w.tickets) (void)hipFree(w.tickets);
+        w.tickets = nullptr;
+        w.ntickets = 0;
+        const int n = (ntickets + 1023) / 1024 * 1024;
+        if (hipMalloc(reinterpret_cast<void**>(&w.tickets), (size_t)n * 4) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(w.tickets, 0, (size_t)n * 4, st) != hipSuccess) return nullptr;
+        w.ntickets = n;
+    }
+    return &w;
+}
+// slices per tile for an under-filled grid: the largest S with tiles * S <= 256 (one workgroup per compute unit), whole
+// and, where the schedule needs it, even numbers of K-steps per slice, at least 8 of them
+static int choose_splits(long long tiles, int nsteps_all, bool need_even) {
+    static const int forced = getenv("MI355Q_V8_SPLITS") ? atoi(getenv("MI355Q_V8_SPLITS")) : 0;
+    int best = 1;
+    for (int S = 2; S <= 16; ++S) {
+        if (nsteps_all % S) continue;
+        const int steps = nsteps_all / S;
+        if (steps < 8) break;
+        if (need_even && (steps & 1)) continue;
+        if (forced ? S > forced : tiles * S > 256) break;
+        best = S;
+    }
+    return best;
+}
+
+int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
     (void)list_cap;
+    GemmArgs a = a_in;
     // 256 x 256 tiles unless they would leave too many of the 256 compute units idle: a 128 x 256 tile does half the
     // work in 0.8 of the time (measured: 48 vs 58 us at 2048 x 4096 x 4096; the fragment reads and LDS-DMA issue of a
     // K-step are shared by half as many MFMAs)
@@ -673,7 +774,20 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
     const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost128 = (double)((t128 + 255) / 256) * 0.82;
     const char* force = getenv("MI355Q_V8_TILE_ROWS");          // (tests pin either flavour)
     const bool small = force && atoi(force) ? atoi(force) == 128 : cost128 < cost256;
-    const unsigned tiles = (unsigned)(small ? t128 : t256);
+    unsigned tiles = (unsigned)(small ? t128 : t256);
+    {   // under-filled grid: split K (the 128-row tile's schedule takes any slice length, the 256-row one even ones)
+        static const int sched_ = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
+        const int S = choose_splits(tiles, (int)(a.K >> 6), !small && sched_ == 2);
+        a.splits = 1;
+        if (S > 1) {
+            SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * (small ? 128 : 256) * 256 * 4, (int)tiles);
+            if (!w) return (int)hipErrorOutOfMemory;
+            a.splits = S;
+            a.slabs = w->slabs;
+            a.tickets = w->tickets;
+            tiles *= S;
+        }
+    }
     // diagnostic builds: MI355Q_V8_CLOCK prints the clock held over the K loop (no add-back),
     // MI355Q_V8_STAMPS the duration of the kernel's phases
     static const bool want_clock = getenv("MI355Q_V8_CLOCK") != nullptr, want_stamps = getenv("MI355Q_V8_STAMPS") != nullptr;
@@ -699,12 +813,25 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
 
 // y = x . w^T (+ bias) on TILED bf16 operands (the same 1-KiB pieces: 16 rows x 32 values): a.xm / a.wm point at the
 // bf16 pieces and a.K is the contraction length IN BYTES (2 K).  K % 32 == 0.
-int launch_bf16_gemm_tiled(const GemmArgs& a, hipStream_t st) {
+int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
     const long long tn = (a.N + V8_BN - 1) / V8_BN;
     const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
     const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost128 = (double)((t128 + 255) / 256) * 0.82;
     const bool small = cost128 < cost256;
-    const unsigned tiles = (unsigned)(small ? t128 : t256);
+    unsigned tiles = (unsigned)(small ? t128 : t256);
+    {
+        const int S = choose_splits(tiles, (int)(a.K >> 6), !small && a.K % 128 == 0);
+        a.splits = 1;
+        if (S > 1) {
+            SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * (small ? 128 : 256) * 256 * 4, (int)tiles);
+            if (!w) return (int)hipErrorOutOfMemory;
+            a.splits = S;
+            a.slabs = w->slabs;
+            a.tickets = w->tickets;
+            tiles *= S;
+        }
+    }
     if (small) hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 1, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else if (a.K % 128 == 0) hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 0, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);

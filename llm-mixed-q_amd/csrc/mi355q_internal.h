@@ -50,6 +50,11 @@ struct GemmArgs {
     // row mode: entries per exception bucket of each operand; x_post = x's entries are added by the row post-pass
     // (mi355q_gemm_post.hip) instead of the GEMM's in-LDS vectors
     int x_bcap, w_bcap, x_post;
+    // split-K of the tile GEMM (under-filled grids): `splits` workgroups share a tile, each over a slice of K; raw
+    // accumulator slabs [tile][split] and one arrival ticket per tile in a library-owned workspace (zero when idle)
+    int splits;
+    void* slabs;
+    int* tickets;
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,

@@ -556,33 +556,63 @@ __global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantAr
     __shared__ Lut lut;
     load_lut<FMT_BFP>(lut);
     const long long K = a.cols, kp = (K * 2) >> 6;
-    const int nslots = (int)(K >> 2);
-    for (long long row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    const int nhalf = (int)(K >> 3);                      // 8-value half blocks: one lane each, 16 bytes of bf16
+    const int mbits_int = (int)__builtin_log2f(a.shift);
+    const long long rows16 = a.rows & ~127ll;
+    for (long long wi = blockIdx.x; wi < a.rows; wi += gridDim.x) {
+        // (rows of one 16-row piece row on workgroups that share an XCD: bfp_quant_align_rows_kernel)
+        long long row = wi;
+        if (wi < rows16) {
+            const long long grp = wi >> 7, in = wi & 127;
+            row = (grp << 7) + ((in & 7) << 4) + (in >> 3);
+        }
         const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
         float4* __restrict__ y4 = a.y ? reinterpret_cast<float4*>(a.y + row * K) : nullptr;
         unsigned char* prow = reinterpret_cast<unsigned char*>(yt) + (row >> 4) * kp * 1024 + (row & 15) * 16;
-        for (int j0 = 0; j0 < nslots; j0 += 256) {                    // uniform trip count (quad reductions inside)
+        for (int j0 = 0; j0 < nhalf; j0 += 256) {                     // uniform trip count (pair exchange inside)
             const int j = j0 + (int)threadIdx.x;
-            const bool valid = j < nslots;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) v = x4[j];
-            float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-            bmax = group_max<4>(bmax);
-            if (bmax == 0.f) bmax = 1.0f;
-            unsigned code;
-            const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
-            int q;
-            float4 o;
-            o.x = quant_elem<FMT_BFP>(v.x, bp, a, lut, q);
-            o.y = quant_elem<FMT_BFP>(v.y, bp, a, lut, q);
-            o.z = quant_elem<FMT_BFP>(v.z, bp, a, lut, q);
-            o.w = quant_elem<FMT_BFP>(v.w, bp, a, lut, q);
-            if (cast_only) o = v;                                      // (values that are already quantised: tile them)
+            const bool valid = j < nhalf;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (valid) { v0 = x4[2 * j]; v1 = x4[2 * j + 1]; }
+            float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (!cast_only) {
+                unsigned m = 0u;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) m = max(m, __float_as_uint(o[t]) & 0x7FFFFFFFu);
+                m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true));   // the block's other half
+                const float bm1 = m != 0u ? __uint_as_float(m) : 1.0f;
+                const int k = __builtin_amdgcn_frexp_expf(bm1) - 1;
+                const unsigned f = __float_as_uint(__builtin_amdgcn_frexp_mantf(bm1)) & 0x7FFFFFu;
+                const int e = clampi(k + ((f != 0u && f >= lut.a[lut_index(k)]) ? 1 : 0), a.e_min, a.e_max);
+                const int up = mbits_int - e;
+                if (__any(up >= 28)) {                                  // blocks below 2^-23: the general rule
+                    BlockParam bp;
+                    bp.p = e;
+                    bp.eps = 0.f;
+                    int q;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) o[t] = quant_elem<FMT_BFP>(o[t], bp, a, lut, q);
+                } else {
+                    // m = rne(clamp(fma(x, 2^up, copysign(1e-9 2^up, x)))) as in bfp_quant_align_rows_kernel; value = m 2^-up
+                    constexpr float MAGIC = 12582912.0f;
+                    const float sc = __builtin_ldexpf(1.0f, up), es = EPS9 * sc, inv = __builtin_ldexpf(1.0f, -up);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float x = o[t];
+                        const float r = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, sc, __builtin_copysignf(es, x)), -a.mant_max, a.mant_max);
+                        const float q = __builtin_fmaf(r + MAGIC, inv, -MAGIC * inv);
+                        o[t] = fabsf(x) <= ATOL ? x : q;
+                    }
+                }
+            }
             if (valid) {
-                if (y4) y4[j] = o;
-                const int kb = j * 8;                                  // byte offset of these 4 values in the bf16 row
-                *reinterpret_cast<uint2*>(prow + (long long)(kb >> 6) * 1024 + ((kb >> 4) & 3) * 256 + (kb & 15)) =
-                    make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
+                if (y4) {
+                    y4[2 * j] = make_float4(o[0], o[1], o[2], o[3]);
+                    y4[2 * j + 1] = make_float4(o[4], o[5], o[6], o[7]);
+                }
+                const int kb = j * 16;                                 // byte offset of these 8 values in the bf16 row
+                *reinterpret_cast<uint4*>(prow + (long long)(kb >> 6) * 1024 + ((kb >> 4) & 3) * 256) =
+                    make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
             }
         }
     }
