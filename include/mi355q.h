@@ -91,6 +91,26 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
  *   row-scale int8 GEMM with v_mfma_f32_16x16x32_bf16. */
 int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
                                         int32_t exponent_width, int32_t exponent_bias, void* workspace, void* stream);
+/* ---- true width-bit weight storage ---------------------------------------------------
+ * replaces: nothing the reference executes -- it realises the storage its profiler accounts for
+ * (quantized_layer_profiler.py:18-27: width bits per value + exponent_width bits per block; README.md:11, 5x memory
+ * density at 6 bits).
+ * mi355q_bfp_pack_bits: mant int8 [rows, K] (canonical: |m| < 2^(width-1), as mi355q_block_fp_quantize writes them)
+ *   -> packed [mi355q_bfp_packed_bytes(rows, K, width)]: per row a dense little-endian bit string of width-bit
+ *   two's-complement values (a 16-block is 2 * width bytes).  K % 16 == 0.
+ * mi355q_bfp_expand: packed + one code byte per block -> a tiled GEMM operand, a pure streaming pass:
+ *   mode 0: int8 row-scale operand (mi355q_bfp_tiled_bytes(rows, K)); code = the block's left shift onto its row's
+ *           exponent, 0xFF = exception block (zero in the operand, kept in the row's exception list); K % 64 == 0;
+ *           with row_exp [rows] / exp_out [rows, K/16] (both or neither) also the operand's per-block exponent bytes
+ *           (every block carries its row's);
+ *   mode 1: tiled bf16 values m * 2^(code - exp_offset), exp_offset = exponent_bias + width - 1
+ *           (mi355q_bfp_tiled_bytes(rows, 2 K)); code = the block's biased exponent; K % 32 == 0.
+ * At rest: width + 0.5 bits per value. */
+size_t mi355q_bfp_packed_bytes(int64_t rows, int64_t K, int32_t width);
+int mi355q_bfp_pack_bits(const int8_t* mant, uint8_t* packed, int64_t rows, int64_t K, int32_t width, void* stream);
+int mi355q_bfp_expand(const uint8_t* packed, const uint8_t* codes, void* out_tiled, int64_t rows, int64_t K, int32_t width,
+                      int32_t mode, int32_t exp_offset, const uint8_t* row_exp, uint8_t* exp_out, void* stream);
+
 /* values that are already quantised (exact in bf16), fp32 [rows, K] -> the same tiled bf16 (a cast; K % 32 == 0) */
 int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, void* stream);
 int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,

@@ -137,6 +137,30 @@ int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_ti
     return launch_quant_bf16_tiled(a, y_tiled, static_cast<hipStream_t>(stream));
 }
 
+size_t mi355q_bfp_packed_bytes(int64_t rows, int64_t K, int32_t width) {
+    return (rows <= 0 || K <= 0 || width < 2 || width > 8) ? 0 : (size_t)rows * (size_t)(K / 16) * (size_t)width * 2;
+}
+
+int mi355q_bfp_pack_bits(const int8_t* mant, uint8_t* packed, int64_t rows, int64_t K, int32_t width, void* stream) {
+    if (rows < 0 || K < 0 || width < 2 || width > 8) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!mant || !packed) return MI355Q_E_BADARG;
+    if (K % 16 != 0) return MI355Q_E_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(mant) % 16 || reinterpret_cast<uintptr_t>(packed) % 2) return MI355Q_E_ALIGN;
+    return launch_bfp_pack_bits(mant, reinterpret_cast<uint16_t*>(packed), rows, K, width, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_bfp_expand(const uint8_t* packed, const uint8_t* codes, void* out_tiled, int64_t rows, int64_t K, int32_t width,
+                      int32_t mode, int32_t exp_offset, const uint8_t* row_exp, uint8_t* exp_out, void* stream) {
+    if (rows < 0 || K < 0 || width < 2 || width > 8 || (mode != 0 && mode != 1)) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!packed || !codes || !out_tiled || ((exp_out != nullptr) != (row_exp != nullptr))) return MI355Q_E_BADARG;
+    if (K % (mode == 0 ? 64 : 32) != 0) return MI355Q_E_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(packed) % 2 || reinterpret_cast<uintptr_t>(out_tiled) % 16) return MI355Q_E_ALIGN;
+    return launch_bfp_expand(mode, reinterpret_cast<const uint16_t*>(packed), codes, out_tiled, rows, K, width, exp_offset,
+                             static_cast<hipStream_t>(stream), row_exp, exp_out);
+}
+
 int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, void* stream) {
     QuantArgs a;
     const int rc = fill_common(a, x, nullptr, nullptr, 1, rows, K, 1, 16, MI355Q_ZERO_BLOCK_FAST);

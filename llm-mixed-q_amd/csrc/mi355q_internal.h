@@ -65,6 +65,9 @@ int launch_bfp_gemm_rowpost(const GemmArgs& a, const int* xlist, const int* wlis
                             hipStream_t st);
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st, const uint8_t* xf = nullptr, const uint8_t* wf = nullptr);
+int launch_bfp_pack_bits(const int8_t* mant, uint16_t* out, long long rows, long long K, int width, hipStream_t st);
+int launch_bfp_expand(int mode, const uint16_t* packed, const uint8_t* codes, void* out, long long rows, long long K, int width,
+                      int off, hipStream_t st, const uint8_t* rowexp = nullptr, uint8_t* exp_out = nullptr);
 int launch_bf16_gemm_tiled(const GemmArgs& a, hipStream_t st);
 int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
                          int list_cap, hipStream_t st, const float* xscale = nullptr, const float* wscale = nullptr);

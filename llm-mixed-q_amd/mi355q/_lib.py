@@ -16,6 +16,9 @@ SIGNATURES = {
     "mi355q_error_string": (C.c_char_p, [C.c_int]),
     "mi355q_block_fp_quantize_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize_bf16_tiled": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "mi355q_bfp_packed_bytes": (C.c_size_t, [_i64, _i64, _i32]),
+    "mi355q_bfp_pack_bits": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
+    "mi355q_bfp_expand": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mi355q_bf16_tile": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "mi355q_bf16_gemm_tiled": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_block_fp_quantize": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,

@@ -166,6 +166,94 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
     return yt
 
 
+# ---------------------------------------------------------------------------------------
+# true width-bit weight storage (include/mi355q.h: mi355q_bfp_pack_bits / mi355q_bfp_expand)
+# ---------------------------------------------------------------------------------------
+def bfp_pack_bits(mant: torch.Tensor, width: int) -> torch.Tensor:
+    """canonical int8 mantissas [rows, K] -> [rows, K * width / 8] uint8 (dense width-bit two's complement)"""
+    assert mant.is_cuda and mant.dtype == torch.int8 and mant.ndim == 2 and mant.is_contiguous() and mant.shape[1] % 16 == 0
+    rows, K = mant.shape
+    out = torch.empty(rows, K * int(width) // 8, dtype=torch.uint8, device=mant.device)
+    with torch.cuda.device(mant.device):
+        rc = _lib.load_library().mi355q_bfp_pack_bits(_ptr(mant), _ptr(out), rows, K, int(width), _stream_ptr(mant.device))
+    _lib.check(rc, "mi355q_bfp_pack_bits")
+    return out
+
+
+_EXPAND_SCRATCH: dict = {}
+
+
+def _expand_scratch(device, nbytes, tag):
+    key = (device.index, _stream_ptr(device), tag)
+    buf = _EXPAND_SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _EXPAND_SCRATCH[key] = torch.empty(nbytes, dtype=torch.int8, device=device)
+    return buf
+
+
+class PackedWeights:
+    """A weight operand at rest: width-bit mantissas + one code byte per block (width + 0.5 bits per value) and the few
+    per-row words of its flavour; `expand()` streams it into a scratch operand shared by every layer on the stream
+    (consume it -- run the GEMM -- before the next layer expands)."""
+
+    def __init__(self, packed, codes, rows, K, width, exp_bias, *, rowflag=None, rowscale=None, rowexp=None, sparse=None):
+        self.packed, self.codes = packed, codes
+        self.rows, self.K, self.width, self.exp_bias = int(rows), int(K), int(width), int(exp_bias)
+        self.rowflag, self.rowscale, self.rowexp, self.sparse = rowflag, rowscale, rowexp, sparse
+        self.row_scale_flavour = rowscale is not None
+
+    def bits_per_value(self) -> float:
+        n = self.packed.numel() + self.codes.numel()
+        for t in (self.rowflag, self.rowscale, self.rowexp, self.sparse):
+            n += 0 if t is None else t.numel() * t.element_size()
+        return 8.0 * n / (self.rows * self.K)
+
+    def expand(self):
+        lib = _lib.load_library()
+        dev = self.packed.device
+        off = self.exp_bias + self.width - 1
+        if self.row_scale_flavour:                      # int8 row-scale operand
+            tiled = _expand_scratch(dev, lib.mi355q_bfp_tiled_bytes(self.rows, self.K), "i8")
+            exp = _expand_scratch(dev, self.rows * (self.K // 16), "exp").view(torch.uint8)
+            with torch.cuda.device(dev):
+                rc = lib.mi355q_bfp_expand(_ptr(self.packed), _ptr(self.codes), _ptr(tiled), self.rows, self.K, self.width, 0, off,
+                                           _ptr(self.rowexp), _ptr(exp), _stream_ptr(dev))
+            _lib.check(rc, "mi355q_bfp_expand")
+            return AlignedOperand(self.rows, self.K, None, tiled, exp, self.rowflag, self.rowscale, self.sparse,
+                                  self.width - 1, self.exp_bias, row_aligned=True, bucket_cap=0)
+        tiled = _expand_scratch(dev, lib.mi355q_bfp_tiled_bytes(self.rows, 2 * self.K), "bf16")
+        with torch.cuda.device(dev):
+            rc = lib.mi355q_bfp_expand(_ptr(self.packed), _ptr(self.codes), _ptr(tiled), self.rows, self.K, self.width, 1, off,
+                                       0, 0, _stream_ptr(dev))
+        _lib.check(rc, "mi355q_bfp_expand")
+        return tiled
+
+
+def pack_row_aligned_weights(wm: torch.Tensor, we: torch.Tensor, wa: "AlignedOperand", width: int, exp_bias: int) -> PackedWeights:
+    """the at-rest form of a row-aligned weight operand (one-off, at pack time): packed canonical mantissas; per block its
+    left shift onto the row's exponent, 0xFF for the exception blocks (listed in wa.sparse), 0 for all-zero blocks"""
+    rows, K = wm.shape
+    nkb = K // 16
+    eo = wa.exp.view(rows, nkb).to(torch.int16)
+    shift = we.view(rows, nkb).to(torch.int16) - eo
+    zero_blk = (wm.view(rows, nkb, 16) == 0).all(-1)
+    shift[zero_blk] = 0
+    _, ent = row_list_entries(wa.sparse, rows, wa.list_cap)
+    if len(ent):
+        e = torch.from_numpy(ent[:, :2].astype("int64")).to(wm.device)
+        shift[e[:, 0], e[:, 1]] = 255
+    assert int(((shift < 0) | ((shift > 7) & (shift != 255))).sum()) == 0, "row-aligned operand with a block outside its window"
+    rowexp = eo[:, 0].to(torch.uint8).contiguous()
+    return PackedWeights(bfp_pack_bits(wm, width), shift.to(torch.uint8).contiguous(), rows, K, width, exp_bias,
+                         rowflag=wa.rowflag, rowscale=wa.gscale, rowexp=rowexp, sparse=wa.sparse)
+
+
+def pack_block_exponent_weights(wm: torch.Tensor, we: torch.Tensor, width: int, exp_bias: int) -> PackedWeights:
+    """the at-rest form of a per-block-exponent (bf16 flavour) weight operand: packed mantissas + biased exponents"""
+    rows, K = wm.shape
+    return PackedWeights(bfp_pack_bits(wm, width), we.contiguous().view(rows, K // 16), rows, K, width, exp_bias)
+
+
 def bf16_tile(x: torch.Tensor) -> torch.Tensor:
     """already-quantised fp32 values [rows, K] -> tiled bf16 (a cast into the tile order; exact for widths <= 9)"""
     _require_device(x, "bf16_tile")

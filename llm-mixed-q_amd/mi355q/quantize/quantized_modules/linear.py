@@ -67,6 +67,14 @@ class _LinearBase(nn.Linear):
         self.align = config.get("mi355q_align", "auto")
         self._align_mode, self._calls, self._row_overflows = None, 0, 0
         self._w_bf16 = None          # (tiled bf16 weights, weight._version) of the per-block-exponent route
+        # implementation knobs next to "mi355q_align" (not part of the reference config):
+        #   mi355q_weight_storage = "packed": keep the weights at rest as width-bit mantissas + one byte per block
+        #       (width + 0.5 bits per value, ops.PackedWeights) and stream them into a shared scratch operand every forward;
+        #   mi355q_keep_master = True: keep the fp32 weights / bias the layer was given, so that requantize() can quantise
+        #       them again (other widths included) without a checkpoint reload (the search loop)
+        self._w_packed = None
+        self._master = None
+        self._fp32_released = False
         self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
         if not self.bypass:
             self._setup_quantizers(config)
@@ -105,6 +113,8 @@ class _LinearBase(nn.Linear):
     def _quantise_weights_once(self, pack: bool, x_sample=None):
         """linear.py:66-70 plus the one-off packing of the int8 operand"""
         c = self.config
+        if c.get("mi355q_keep_master", False) and self._master is None:
+            self._master = (self.weight.detach().clone(), None if self.bias is None else self.bias.detach().clone())
         if pack:
             wq, wm, we = ops.block_fp_quantize(self.weight.data, c["weight_width"], c["weight_exponent_width"],
                                                c["weight_exponent_bias"], c["weight_block_size"], False,
@@ -117,12 +127,20 @@ class _LinearBase(nn.Linear):
         self.weight_requires_quantisation = False
         if pack:
             self._align_weights(wm, we, self._choose_align_mode(wm, we, x_sample))
+            versions = (self.weight._version, None if self.bias is None else self.bias._version)
+            packed_storage = c.get("mi355q_weight_storage", "int8") == "packed" and self._align_mode == "rows"
             if self._uses_bf16_route():
                 # per-block exponents: the quantised weights (already in .weight) as tiled bf16; the int8 operand is not
                 # needed on this route (the exact-integer blockwise kernel, mi355q_blocks_gemm = "int8", keeps it)
-                self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
-                self._packed = (None, self._w_bf16[0], self.weight._version,
-                                None if self.bias is None else self.bias._version)
+                if packed_storage:
+                    self._w_packed = ops.pack_block_exponent_weights(wm, we, c["weight_width"], self._weight_bias_value())
+                    self._packed = (None, self._w_packed.packed, *versions)
+                else:
+                    self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+                    self._packed = (None, self._w_bf16[0], *versions)
+            elif packed_storage and self._x_cap != ops.ROW_NO_ALIGN:
+                self._w_packed = ops.pack_row_aligned_weights(wm, we, self._packed[0], c["weight_width"], self._weight_bias_value())
+                self._packed = (None, self._w_packed.packed, *versions)
 
     def _weight_bias_value(self):
         c = self.config
@@ -190,13 +208,71 @@ class _LinearBase(nn.Linear):
         self._packed = (None, self._w_bf16[0], self.weight._version, None if self.bias is None else self.bias._version)
         return True
 
-    def requantize(self):
-        """Search-loop helper: after loading new fp32 weights into .weight/.bias, make the
-        next forward quantise and pack them again instead of rebuilding the model."""
+    def requantize(self, config: dict = None):
+        """Search-loop helper (the reference rebuilds the model and reloads the checkpoint for every trial,
+        search/search.py:753-763): make the next forward quantise and pack the weights again.  With
+        config["mi355q_keep_master"] the fp32 weights / bias the layer was first given are restored here, so the caller
+        reloads nothing; `config` switches the layer to another quantisation config (other widths) on the way.  Without a
+        master copy the caller loads new fp32 values into .weight / .bias first (after a first forward they hold
+        quantised values)."""
+        if config is not None:
+            keep = {k: v for k, v in self.config.items() if k.startswith("mi355q_") and k not in config}
+            self.config = dict(config, **keep)
+            self.bypass = self.config.get("bypass", False)
+            self.is_ptq = self.config.get("is_ptq", False)
+            self.align = self.config.get("mi355q_align", "auto")
+            if not self.bypass:
+                self._setup_quantizers(self.config)
+        if self._master is not None:
+            with torch.no_grad():
+                if self._fp32_released:
+                    self.weight.data = torch.empty_like(self._master[0])
+                    self._fp32_released = False
+                self.weight.copy_(self._master[0])
+                if self.bias is not None:
+                    self.bias.copy_(self._master[1])
+        elif self._fp32_released:
+            raise RuntimeError("mi355q: requantize() needs fp32 weights: they were released and no master copy is kept")
         self.weight_requires_quantisation = True if self.is_ptq else False
         self._packed, self._align_mode, self._calls, self._row_overflows = None, None, 0, 0
-        self._w_bf16 = None
+        self._w_bf16, self._w_packed = None, None
         self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
+
+    @torch.no_grad()
+    def pack_now(self, x_sample=None):
+        """Quantise and pack the weights NOW instead of at the first forward (a loader calls this right after it filled
+        .weight / .bias: pack at load).  Without an activation sample the activation route is decided at
+        the first forward."""
+        if self.bypass or not self.is_ptq or not self.weight_requires_quantisation:
+            return self
+        probe = x_sample if x_sample is not None else torch.empty(1, self.in_features, device=self.weight.device)
+        self._quantise_weights_once(pack=self._int8_plan(probe) is not None, x_sample=x_sample)
+        return self
+
+    def release_fp32_weight(self):
+        """Drop the fp32 copy of the (already packed) weights: what stays resident is the packed operand -- with
+        config["mi355q_weight_storage"] = "packed" width + 0.5 bits per value.  .weight becomes an empty Parameter;
+        only the packed routes work afterwards (requantize() brings the weights back if a master copy is kept)."""
+        if self._packed is None:
+            raise RuntimeError("mi355q: nothing packed yet (run a forward or pack_now() first)")
+        self.weight.data = torch.empty(0, dtype=self.weight.dtype, device=self.weight.device)
+        self._packed = (self._packed[0], self._packed[1], self.weight._version, self._packed[3])
+        if self._w_bf16 is not None:
+            self._w_bf16 = (self._w_bf16[0], self.weight._version)
+        self._fp32_released = True
+        return self
+
+    def weight_storage_bits(self) -> float:
+        """bits per weight value of what the layer keeps packed (excluding the fp32 Parameter, see release_fp32_weight)"""
+        if self._w_packed is not None:
+            return self._w_packed.bits_per_value()
+        if self._packed is None:
+            return 32.0
+        n = self.out_features * self.in_features
+        if self._packed[0] is not None:
+            wa = self._packed[0]
+            return 8.0 * (wa.tiled.numel() + wa.exp.numel()) / n
+        return 8.0 * self._packed[1].numel() / n
 
     def forward(self, x):
         if self.bypass:
@@ -230,11 +306,17 @@ class _LinearBase(nn.Linear):
             # quantised weights tiled once.  |x| <= 1e-8 pass-through elements are rounded to bf16 there (<= 2e-11 each).
             # config["mi355q_blocks_gemm"] = "int8": the blockwise-exact int8 kernel instead (exact integer block dots,
             # several times slower).
-            if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:
-                self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+            if self._w_packed is not None and not self._w_packed.row_scale_flavour:
+                wt = self._w_packed.expand()                 # width-bit storage -> scratch tiled bf16
+            else:
+                if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:
+                    if self._fp32_released:
+                        raise RuntimeError("mi355q: the fp32 weights were released; this layer cannot switch routes any more")
+                    self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+                wt = self._w_bf16[0]
             xt = ops.block_fp_quantize_bf16_tiled(x2.contiguous(), c["data_in_width"], c["data_in_exponent_width"],
                                                   c["data_in_exponent_bias"])
-            y = ops.bf16_gemm_tiled(xt, self._w_bf16[0], x2.shape[0], self.out_features, self.in_features, self.bias)
+            y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias)
             return y.reshape(*x.shape[:-1], self.out_features)
         if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
@@ -247,7 +329,8 @@ class _LinearBase(nn.Linear):
                                               c["data_in_exponent_bias"], [1, 16], True, want_fake=False,
                                               want_packed=True, fast_zero_blocks=True)
             xa = ops.bfp_align(xm, xe, x_mbits, xb, inplace=True)
-        y = ops.bfp_gemm_aligned(xa, self._packed[0], self.bias)
+        wa = self._w_packed.expand() if self._w_packed is not None else self._packed[0]
+        y = ops.bfp_gemm_aligned(xa, wa, self.bias)
         if self._align_mode == "rows" and self.align == "auto" and self._x_cap != ops.ROW_NO_ALIGN:
             # results never depend on the mode (an overflowing exception bucket only sends the GEMM to its slow
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats

@@ -315,3 +315,66 @@ def test_linear_auto_takes_blocks_for_weights_with_outlier_input_channels():
     assert lin._align_mode == "rows" and lin._x_cap == -1 and lin._w_bf16 is not None
     ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(2, 70, 320)
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+
+
+def _lin_cfg(width, **extra):
+    return dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=width, data_in_exponent_width=8,
+                data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=width, weight_exponent_width=8,
+                weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=width, bias_exponent_width=8,
+                bias_exponent_bias=127, bias_block_size=[16], **extra)
+
+
+@pytest.mark.parametrize("width,act", [(6, "plain"), (4, "plain"), (6, "silu"), (5, "relu")])
+def test_packed_weight_storage(width, act):
+    """true width-bit weight storage: width + 0.5 bits per value at rest, expanded into a scratch operand
+    every forward; outputs bit-identical to the int8 / bf16 resident operands, memory density vs fp32 >= 32 / (width + 0.55);
+    the fp32 Parameter can be released afterwards"""
+    import torch
+    import mi355q.quantize as Q
+    torch.manual_seed(3)
+    K, N, M = 1024, 512, 300
+    fp = torch.nn.Linear(K, N)
+    h = torch.randn(M, K) * torch.exp(torch.randn(M, 1))
+    x = {"plain": h, "relu": torch.relu(h), "silu": torch.nn.functional.silu(h) * torch.randn(M, K)}[act].to("cuda:0")
+    ref_cfg, cfg = _lin_cfg(width), _lin_cfg(width, mi355q_weight_storage="packed")
+    ref = Q.get_quantized_cls("linear", ref_cfg).from_float(fp, ref_cfg).to("cuda:0")
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    y_ref = ref(x)
+    y = lin(x)
+    assert lin._w_packed is not None
+    if act != "relu":                                       # (post-ReLU rows fit a window of 4 exponents, W5 has one)
+        assert lin._w_packed.row_scale_flavour == (act == "plain")
+    assert torch.equal(y, y_ref)
+    bits = lin.weight_storage_bits()
+    pw = lin._w_packed
+    assert 8.0 * (pw.packed.numel() + pw.codes.numel()) / (K * N) == width + 0.5      # the format's own density
+    # (+ per-row scales and the fixed-size exception buckets: 62 KB per 4096 rows, 0.03 bits at 4096 x 4096; this layer
+    #  is small).  W6: 32 / 6.5 = 4.9x fp32, the README's "5x memory density" (README.md:11)
+    assert bits <= width + 0.75, bits
+    assert torch.equal(lin.weight, ref.weight)              # (the in-place fake-quantised fp32 values, as the reference)
+    lin.release_fp32_weight()
+    assert lin.weight.numel() == 0
+    assert torch.equal(lin(x), y_ref)
+
+
+def test_pack_now_and_master_requantize():
+    """pack at load (no forward needed) and the search loop's re-quantise-in-place with kept fp32 master weights: another
+    width is applied without reloading anything, results equal a freshly built layer's"""
+    import torch
+    import mi355q.quantize as Q
+    torch.manual_seed(4)
+    fp = torch.nn.Linear(512, 256)
+    x = (torch.randn(100, 512) * torch.exp(torch.randn(100, 1))).to("cuda:0")
+    cfg6, cfg4 = _lin_cfg(6, mi355q_keep_master=True), _lin_cfg(4)
+    lin = Q.get_quantized_cls("linear", cfg6).from_float(fp, cfg6).to("cuda:0")
+    lin.pack_now()
+    assert not lin.weight_requires_quantisation and lin._packed is not None
+    y6 = lin(x)
+    fresh6 = Q.get_quantized_cls("linear", _lin_cfg(6)).from_float(fp, _lin_cfg(6)).to("cuda:0")
+    assert torch.equal(y6, fresh6(x))
+    lin.requantize(cfg4)                                     # trial 2: W4A4, nothing reloaded
+    y4 = lin(x)
+    fresh4 = Q.get_quantized_cls("linear", cfg4).from_float(fp, cfg4).to("cuda:0")
+    assert torch.equal(y4, fresh4(x)) and torch.equal(lin.weight, fresh4.weight)
+    lin.requantize(_lin_cfg(6))                              # and back
+    assert torch.equal(lin(x), y6)
