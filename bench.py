@@ -12,11 +12,18 @@ One step = the steady-state PTQ LinearBlockFP forward (reference quantized_modul
 after the first call): dynamic activation quantise+pack -> int8-MFMA block GEMM against
 pre-packed weights -> fp32 y (+bias).  FLOPs = 2*M*N*K per step.
 
-N > 1: one process per GPU; rows of x (tokens) are the independent units, each rank runs the same
-step on its own 4096 rows with replicated packed weights -- no data-path collective (weak
-scaling).  `--shard out_features` instead times the row-sharded GEMM + RCCL all-gather.
+N > 1 (one process per GPU, RCCL): the partition BASELINE.json's north_star names -- W split by rows
+(out_features) over the ranks, x replicated, each rank computes y[:, shard], ONE all-gather of the fp32
+shards and the layout fix-up the sharded module does (mi355q/sharded.py) -- the same 4096^3 layer on
+N GPUs: "scaling": "strong".  `--shard tokens` times independent replicas instead (each rank its own
+4096 rows, no collective: weak scaling); the default N > 1 run reports that number too ("replicas").
 
-Prints ONE JSON line on rank 0.
+`--workload quantizers` (BASELINE config 5): the memory-bound fake-quantisers (block_fp, block_minifloat,
+block_log) at the Llama-7B activation / weight shapes, GB/s at 8 B per element against the HBM roofline.
+
+After the timed region the step's output is checked against the oracle (64 sampled rows x all columns of y; the
+activation quantiser's exponents and mantissas over the whole 4096 x 4096 tensor, bit for bit): exit code 1 on
+mismatch.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -37,6 +44,7 @@ CFG = dict(name="block_fp", is_ptq=True, bypass=False,
            weight_width=6, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
            bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
 INT8_DENSE_PEAK_TFLOPS = 5000.0   # MI355X_MICROARCH.md: I8 MFMA = 2x the ~2.5 PF dense bf16 rate
+HBM_PEAK_GBS = 8000.0             # HBM3E spec; ~6300 achievable by a copy (MI355X_MICROARCH.md)
 
 
 def make_inputs(torch, device, rank):
@@ -102,14 +110,76 @@ def verify(torch, ops, x, w, b, y, rows=64):
             "gemm_max_rel_err": err, "gemm_tol": tol}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (counters cannot be read inside a
-    timed run: one counter per rocprofv3 pass, tools/cdriver/step_driver runs the same step through the C ABI)"""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-            return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+def committed_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (counters cannot be read inside a timed
+    run: one counter per rocprofv3 pass over tools/cdriver/step_driver, which runs the same step through the C ABI)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(ROOT / "profiles" / name) as f:
+                return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def timed(torch, dist, world, device, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def quantizer_workload(torch, ops, args, device):
+    """BASELINE config 5: fake-quantisers at the Llama-7B shapes, 8 B per element (fp32 in, fp32 out)."""
+    shapes = {"act[2048,4096]": (2048, 4096), "act[2048,11008]": (2048, 11008), "probs[32,2048,2048]": (32, 2048, 2048),
+              "w[4096,4096]": (4096, 4096), "w[11008,4096]": (11008, 4096)}
+    fns = {"block_fp_w6": lambda t, skip: ops.block_fp_quantize(t, 6, 8, 127, [1, 16], skip),
+           "block_minifloat_w8e4": lambda t, skip: ops.block_minifloat_quantize(t, 8, 4, 8, [1, 16], skip),
+           "block_log_w8": lambda t, skip: ops.block_log_quantize(t, 8, 8, [1, 16], skip)}
+    rows, tot_bytes, tot_t = [], 0.0, 0.0
+    for sname, shp in shapes.items():
+        skip = not sname.startswith("w[")
+        x = torch.randn(*shp, generator=torch.Generator().manual_seed(7)).to(device) * 4.0
+        for fname, fn in fns.items():
+            for _ in range(args.warmup):
+                fn(x, skip)
+            torch.cuda.synchronize()
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.steps):
+                fn(x, skip)
+            e.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(e) / args.steps
+            gbs = 8.0 * x.numel() / (ms * 1e-3) / 1e9
+            rows.append({"quantizer": fname, "shape": sname, "us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
+                         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 3)})
+            tot_bytes += 8.0 * x.numel()
+            tot_t += ms * 1e-3
+    worst = min(rows, key=lambda r: r["GB/s"])
+    agg = tot_bytes / tot_t / 1e9
+    return {"metric": "fake-quantiser HBM GB/s (Llama-7B shapes, block=16, 8 B/element)", "value": round(agg, 1), "unit": "GB/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tot_t * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "block_fp W6 / block_minifloat (8,4,8) / block_log (8,8) fake-quantise, [1,16] blocks, "
+                                   "Llama-7B activation, attention-probability and weight shapes, fp32 in -> fp32 out"},
+            "roofline": {"bound": "hbm", "kernel": f"quant_vec_kernel ({worst['quantizer']} at {worst['shape']}: the slowest case)",
+                         "achieved": worst["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(worst["GB/s"] / HBM_PEAK_GBS, 4),
+                         "traffic": None},
+            "cases": rows}
 
 
 def main():
@@ -117,7 +187,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--shard", choices=["tokens", "out_features"], default="tokens")
+    ap.add_argument("--shard", choices=["out_features", "tokens"], default="out_features",
+                    help="N > 1: the row-wise partition of W + all-gather (north_star), or independent replicas")
+    ap.add_argument("--workload", choices=["gemm", "quantizers"], default="gemm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed step's output")
     ap.add_argument("--variant", type=int, default=0, help="GEMM kernel variant (0 = automatic)")
@@ -136,89 +208,114 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the block-quantised path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # (MI355Q_BENCH_FORCE_DIST=1: take the sharded code path -- process group, all-gather, layout fix-up -- at world size 1,
+    #  so that a 1-GPU box can exercise it)
+    force_dist = world == 1 and os.environ.get("MI355Q_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
     if args.variant:
         ops.set_gemm_variant(args.variant)
 
-    x, w, b = make_inputs(torch, device, rank if args.shard == "tokens" else 0)
+    if args.workload == "quantizers":
+        out = quantizer_workload(torch, ops, args, device)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    sharded = args.shard == "out_features" and (world > 1 or force_dist)
     xw, ww = CFG["data_in_width"], CFG["weight_width"]
-    if args.shard == "out_features" and world > 1:
-        n_loc = N // world
-        w, b = w[rank * n_loc:(rank + 1) * n_loc].contiguous(), b[rank * n_loc:(rank + 1) * n_loc].contiguous()
-    # one-off weight / bias packing (first PTQ forward in the reference), not timed
-    _, wm, we = ops.block_fp_quantize(w, ww, 8, 127, [1, 16], False, want_fake=False, want_packed=True,
-                                      fast_zero_blocks=True)
     rows_mode = args.align == "rows"
-    wa = ops.bfp_align_rows(wm, we, ww - 1, 127) if rows_mode else ops.bfp_align(wm, we, ww - 1, 127, inplace=True)
     quantize_x = ops.block_fp_quantize_aligned_rows if rows_mode else ops.block_fp_quantize_aligned
-    bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
-    n_out = w.shape[0]
-    y = torch.empty(M, n_out, dtype=torch.float32, device=device)
-    gathered = torch.empty(world * M, n_out, dtype=torch.float32, device=device) if (args.shard == "out_features" and world > 1) else None
 
-    def step():
-        xa = quantize_x(x, xw, 8, 127)
-        ops.bfp_gemm_aligned(xa, wa, bq, out=y)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, y)
+    def build(shard_w: bool, x_rank: int):
+        """(step, x, w_local, b_local, y_local) of one mode; weight / bias packing is the one-off first PTQ forward of the
+        reference and stays outside the timed region"""
+        x, w, b = make_inputs(torch, device, x_rank)
+        if shard_w:
+            n_loc = N // world
+            w, b = w[rank * n_loc:(rank + 1) * n_loc].contiguous(), b[rank * n_loc:(rank + 1) * n_loc].contiguous()
+        _, wm, we = ops.block_fp_quantize(w, ww, 8, 127, [1, 16], False, want_fake=False, want_packed=True, fast_zero_blocks=True)
+        wa = ops.bfp_align_rows(wm, we, ww - 1, 127) if rows_mode else ops.bfp_align(wm, we, ww - 1, 127, inplace=True)
+        bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
+        n_out = w.shape[0]
+        y = torch.empty(M, n_out, dtype=torch.float32, device=device)
+        gathered = torch.empty(world, M, n_out, dtype=torch.float32, device=device) if shard_w else None
+        full = torch.empty(M, world, n_out, dtype=torch.float32, device=device) if shard_w else None
 
+        def step():
+            xa = quantize_x(x, xw, 8, 127)
+            ops.bfp_gemm_aligned(xa, wa, bq, out=y)
+            if shard_w:
+                dist.all_gather_into_tensor(gathered.view(world * M, n_out), y)     # rank-major [P, M, N/P]
+                full.copy_(gathered.permute(1, 0, 2))                               # -> y [M, N] (what the module returns)
+        return step, x, w, b, y
+
+    step, x, w, b, y = build(sharded, 0 if sharded or world == 1 else rank)
+    ops.gemm_timing(False)
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
     ops.gemm_timing(True)       # HIP events around the dominant kernel, recorded by the library on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    dt = timed(torch, dist, world, device, step, args.steps, 0)
     ops.gemm_timing(False)
     n_timed, gemm_avg_ms, gemm_min_ms = ops.gemm_timing_read()
-    flops_step = 2.0 * M * n_out * K
-    total_flops = flops_step * args.steps * world
-    value = total_flops / dt / 1e12
+    n_out = w.shape[0]
+    flops_kernel = 2.0 * M * n_out * K                        # one launch of the dominant kernel on this rank
+    flops_job = 2.0 * M * N * K * (1 if sharded or world == 1 else world)
+    value = flops_job * args.steps / dt / 1e12
+
+    replicas = None
+    if sharded:                                               # the independent-replica number next to it
+        step_r, *_ = build(False, rank)
+        dt_r = timed(torch, dist, world, device, step_r, args.steps, args.warmup)
+        replicas = {"value": round(2.0 * M * N * K * world * args.steps / dt_r / 1e12, 2), "unit": "TFLOP/s", "scaling": "weak",
+                    "ms_per_step": round(dt_r / args.steps * 1e3, 4),
+                    "what": "each rank its own 4096 rows against replicated packed weights, no collective"}
 
     failed = False
     if rank == 0:
-        achieved = flops_step / (gemm_avg_ms * 1e-3) / 1e12
-        traffic = pmc_traffic("mi355q::bfp_gemm_v8<1, 8, false>") if rows_mode and (M, N, K) == (4096, 4096, 4096) else None
+        achieved = flops_kernel / (gemm_avg_ms * 1e-3) / 1e12
+        kname = "mi355q::bfp_gemm_v8<1, 8, 2, false>"
+        traffic, tsrc = committed_traffic(kname) if rows_mode and not sharded else (None, None)
+        ms_step = dt / args.steps * 1e3
         out = {
             "metric": "quantised-GEMM TFLOP/s (4096^2, block=16, W6A6 BFP)",
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak" if args.shard == "tokens" else "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> fused quantise+pack+align (W6, block [1,16]) "
-                                   "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32",
+                                   "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32"
+                                   + (f"; W split by out_features over {world} ranks, x replicated, RCCL all-gather of the fp32 shards "
+                                      "+ layout fix-up" if sharded else ""),
                        "arithmetic": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 row/block scaling, fp32 y",
-                       "M_per_gpu": M, "N": N, "K": K, "shard": args.shard, "align": args.align,
-                       "gemm_variant": ops.set_gemm_variant(args.variant)},
-            "roofline": {"bound": "mfma", "kernel": "bfp_gemm_v8 (row-scale int8 GEMM)" if rows_mode else "bfp_gemm_v6 (int32-chain block GEMM)", "achieved": round(achieved, 2),
-                         "peak": INT8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / INT8_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over "
-                                         "tools/cdriver/step_driver; profiles/r01_pmc_traffic.json)" if traffic else None,
+                       "M_per_gpu": M, "N": N, "N_per_gpu": n_out, "K": K, "shard": args.shard if world > 1 else "none",
+                       "align": args.align, "gemm_variant": ops.set_gemm_variant(args.variant)},
+            "roofline": {"bound": "mfma", "kernel": "bfp_gemm_v8 (row-scale int8 GEMM)" if rows_mode else "bfp_gemm_v6 (int32-chain block GEMM)",
+                         "achieved": round(achieved, 2), "peak": INT8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / INT8_DENSE_PEAK_TFLOPS, 4),
+                         "step_frac": round(value / world / INT8_DENSE_PEAK_TFLOPS, 4),
+                         "step_frac_note": "the whole step (activation quantiser + GEMM + launch gaps) per GPU against the same peak",
+                         "traffic": traffic,
+                         "traffic_source": (f"committed profile profiles/{tsrc}: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per launch, "
+                                            "separate passes over tools/cdriver/step_driver (same step through the C ABI); not "
+                                            "measured by this run") if traffic else None,
                          "avg_launch_ms": round(gemm_avg_ms, 4), "min_launch_ms": round(gemm_min_ms, 4), "launches_timed": n_timed},
         }
+        if replicas:
+            out["replicas"] = replicas
         if not args.no_verify:
             out["verify"] = verify(torch, ops, x, w, b, y)
+            failed = not out["verify"]["ok"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch)
         print(json.dumps(out), flush=True)
-        if not args.no_verify and not out["verify"]["ok"]:
-            failed = True
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
     if failed:
         raise SystemExit("bench.py: the timed step's output does not match the oracle")

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define MI355Q_ABI_VERSION 4
-#define MI355Q_WORKSPACE_BYTES 256
+#define MI355Q_WORKSPACE_BYTES 8192
 
 /* negative error codes (positive values are hipError_t) */
 #define MI355Q_E_BADARG (-1)      /* null pointer, non-positive size, width out of range */

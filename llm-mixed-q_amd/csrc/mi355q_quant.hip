@@ -40,10 +40,10 @@ __device__ __forceinline__ void publish_zero_state(unsigned* ws, bool saw_zero, 
     }
     const bool any_zero = __any(saw_zero);
     if ((threadIdx.x & 63) == 0) {
-        // (read first: after a few waves have reported, hardly any wave still lowers the minimum -- the word sees a
-        //  handful of atomics per launch instead of one per wave)
-        if (inv > __hip_atomic_load(&ws[WS_MINBITS_INV], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            __hip_atomic_fetch_max(&ws[WS_MINBITS_INV], inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned* shard = ws + WS_SHARD0 + WS_SHARD_STRIDE * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (WS_SHARDS - 1));
+        // (read first: after a few waves have reported, hardly any wave still lowers its shard's minimum)
+        if (inv > __hip_atomic_load(shard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(shard, inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (any_zero) __hip_atomic_store(&ws[WS_ZERO_FLAG], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -182,8 +182,8 @@ template <int FMT>
 __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
     __shared__ Lut lut;
     if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) {           // uniform over the grid: nothing to rewrite
-        if (blockIdx.x == 0 && threadIdx.x == 0)          // (nobody reads this word on this path)
-            __hip_atomic_store(&a.ws[WS_MINBITS_INV], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0 && threadIdx.x < WS_SHARDS)   // (nobody reads these words on this path)
+            __hip_atomic_store(&a.ws[WS_SHARD0 + WS_SHARD_STRIDE * threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     load_lut<FMT>(lut);
@@ -191,7 +191,12 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
     const int lane16 = threadIdx.x & 15;
     const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
     const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const unsigned inv_all = ld_agent(&a.ws[WS_MINBITS_INV]);
+    unsigned inv_all = ld_agent(&a.ws[WS_SHARD0 + WS_SHARD_STRIDE * (threadIdx.x & (WS_SHARDS - 1))]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)inv_all, o);
+        inv_all = other > inv_all ? other : inv_all;
+    }
     const float fill = inv_all == 0u ? 1.0f : __uint_as_float(~inv_all);   // all blocks zero -> 1
     unsigned code;
     const BlockParam bp = block_param<FMT>(fill, a, lut, code);
@@ -216,7 +221,8 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(&a.ws[WS_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1u) {
-            __hip_atomic_store(&a.ws[WS_MINBITS_INV], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int sh = 0; sh < WS_SHARDS; ++sh)
+                __hip_atomic_store(&a.ws[WS_SHARD0 + WS_SHARD_STRIDE * sh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.ws[WS_TICKET], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.ws[WS_ZERO_FLAG], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -21,7 +21,10 @@ constexpr float ATOL = 1e-8f;
 
 // workspace words
 constexpr int WS_ZERO_FLAG = 0;   // kernel 1 met an all-zero block
-constexpr int WS_MINBITS_INV = 1; // max over non-zero blocks of ~bits(block max)
+constexpr int WS_MINBITS_INV = 1; // (spare)
+// max over non-zero blocks of ~bits(block max), kept in WS_SHARDS words a cache line apart (a burst of atomics on ONE word
+// serialises: thousands of waves finish together)
+constexpr int WS_SHARDS = 64, WS_SHARD0 = 64, WS_SHARD_STRIDE = 16;
 constexpr int WS_TICKET = 2;      // fix-up kernel exit ticket (the last workgroup out clears the workspace)
 
 struct Lut {

@@ -57,7 +57,7 @@ class BfpOperand(C.Structure):
 
 
 ABI_VERSION = 4
-WORKSPACE_BYTES = 256
+WORKSPACE_BYTES = 8192
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 
 
