@@ -33,7 +33,7 @@ int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gsc
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
                             int* list_to_clear, hipStream_t st, int bcap);
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
-                       long long B, long long M, long long K, long long N, hipStream_t st);
+                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false);
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {

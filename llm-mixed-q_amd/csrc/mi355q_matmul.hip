@@ -194,12 +194,44 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
 constexpr int MM_RESIDENT_STEPS = 3;     // contraction steps (of 64) whose quantised x stays in registers
 
 // (two instantiations: the short-contraction one keeps quantised x in registers, the streaming one stays lean)
-template <bool RESIDENT, int NT>
+// SOFTMAX (streaming instantiations only): x holds attention SCORES; the rows' softmax (fp32: exp(x - max) / sum, the
+// arithmetic of torch.softmax, exponentials to ~1 ulp) is formed on the way in, so the probability tensor [heads, T, T] never exists in memory:
+// two statistics passes over the workgroup's 16 rows (max, then the sum of exponentials; the rows come from L2 the second
+// and third time), then the main pass turns every score into its probability right before the block quantiser.
+// exp(x) for x <= 0 to ~1 ulp in 6 operations: 2^(x log2e) with the product's rounding error carried along
+// (t = fl(x L), r = x L - t exactly by FMA, plus x times the low part of log2e;  2^(t + r) = 2^t (1 + r ln2 + ...)).
+__device__ __forceinline__ float exp_neg(float x) {
+    x = fmaxf(x, -104.0f);               // (masked scores are finfo.min: the scaled argument would overflow; e^-104 = 0 in fp32)
+    constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f, LN2 = 0.693147182464599609375f;
+    const float t = x * L2E_HI;
+    float r = __builtin_fmaf(x, L2E_HI, -t);
+    r = __builtin_fmaf(x, L2E_LO, r);
+    const float p = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(p, r * LN2, p);
+}
+// e / l with the quotient corrected once (q = e inv; q += (e - q l) inv): the correctly rounded quotient except for rare
+// double-rounding cases, in 3 operations instead of the division's ~10
+__device__ __forceinline__ float div_fast(float e, float l, float inv) {
+    const float q = e * inv;
+    return __builtin_fmaf(__builtin_fmaf(-q, l, e), inv, q);
+}
+__device__ __forceinline__ void softmax_xblk(XBlk& s, float m, float l, float inv) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s.v[i].x = div_fast(exp_neg(s.v[i].x - m), l, inv);
+        s.v[i].y = div_fast(exp_neg(s.v[i].y - m), l, inv);
+        s.v[i].z = div_fast(exp_neg(s.v[i].z - m), l, inv);
+        s.v[i].w = div_fast(exp_neg(s.v[i].w - m), l, inv);
+    }
+}
+
+template <bool RESIDENT, int NT, bool SOFTMAX = false>
 __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
                                                           const uint16_t* __restrict__ yt, float* __restrict__ out,
                                                           long long M, long long K, long long Kp, long long N) {
     __shared__ Lut lut;
     __shared__ f32x4 red[4][NT][64];                      // [wave][tile][lane]: split-K partial tiles
+    __shared__ float stat[4][16];
     load_lut<FMT_BFP>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
@@ -250,6 +282,40 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
 #undef MI355Q_MM_CHUNK
         return;
     }
+    float row_max = 0.f, row_sum = 1.f;
+    if (SOFTMAX) {
+        // statistics of this lane's row r = lane % 16: every (wave, lane group g) covers a quarter of a quarter of the
+        // steps' values; combine over g by shuffles, over the waves through LDS.  Values behind K do not count.
+        float mx = -INFINITY;
+        for (long long st = wave; st < nsteps; st += 4) {
+            XBlk s;
+            load_xblk(s, row, st * 64, g, K);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (st * 64 + 16 * i < K) mx = fmaxf(mx, fmaxf(fmaxf(s.v[i].x, s.v[i].y), fmaxf(s.v[i].z, s.v[i].w)));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (g == 0) stat[wave][lane & 15] = mx;
+        __syncthreads();
+        row_max = fmaxf(fmaxf(stat[0][lane & 15], stat[1][lane & 15]), fmaxf(stat[2][lane & 15], stat[3][lane & 15]));
+        __syncthreads();
+        float sm = 0.f;
+        for (long long st = wave; st < nsteps; st += 4) {
+            XBlk s;
+            load_xblk(s, row, st * 64, g, K);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (st * 64 + 16 * i < K)
+                    sm += (exp_neg(s.v[i].x - row_max) + exp_neg(s.v[i].y - row_max)) + (exp_neg(s.v[i].z - row_max) + exp_neg(s.v[i].w - row_max));
+        }
+        sm += __shfl_xor(sm, 16);
+        sm += __shfl_xor(sm, 32);
+        if (g == 0) stat[wave][lane & 15] = sm;
+        __syncthreads();
+        row_sum = (stat[0][lane & 15] + stat[1][lane & 15]) + (stat[2][lane & 15] + stat[3][lane & 15]);
+    }
+    const float row_inv = 1.0f / row_sum;
     // long contraction: wave w streams steps w, w + 4, w + 8, ... of every column chunk (the four waves read adjacent
     // 256-byte pieces of each row: 1 KiB runs per row and DRAM page while they move in step)
     for (long long n0 = 0; n0 < N; n0 += 16 * NT) {                     // (probs x V: one chunk, x streamed once)
@@ -267,6 +333,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
                 __builtin_amdgcn_sched_barrier(0);
                 load_xblk(xb, row, (st + 4) * 64, g, K);   // next step's x in flight under this one's work (behind K: a re-read)
                 __builtin_amdgcn_sched_barrier(0);
+                if (SOFTMAX) softmax_xblk(xa, row_max, row_sum, row_inv);
                 if ((st + 1) * 64 > K) mask_xblk(xa, st * 64, K);          // (uniform: the last, partial step only)
                 quantise_xblk(xa, a, lut, mbits, lane, afr);
                 mma_step<NT>(afr, bf, n0, N, acc);
@@ -278,6 +345,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
                 __builtin_amdgcn_sched_barrier(0);
                 load_xblk(xa, row, (st + 8) * 64, g, K);
                 __builtin_amdgcn_sched_barrier(0);
+                if (SOFTMAX) softmax_xblk(xb, row_max, row_sum, row_inv);
                 if ((st + 5) * 64 > K) mask_xblk(xb, (st + 4) * 64, K);
                 quantise_xblk(xb, a, lut, mbits, lane, afr);
                 mma_step<NT>(afr, bf, n0, N, acc);
@@ -302,7 +370,8 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
 }
 
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
-                       long long B, long long M, long long K, long long N, hipStream_t st) {
+                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax) {
+    if (softmax && (K + 63) / 64 <= 3) return MI355Q_E_UNSUPPORTED;     // (short rows: the caller takes softmax + the plain entry)
     dim3 g1((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)B);
     const long long Kp = (K + 63) / 64;                    // 64-steps: yt is stored in fragment order (kernel 1)
     hipLaunchKernelGGL(bfp_quant_pack_t_kernel, g1, 256, 0, st, ay, y, static_cast<uint16_t*>(yt), K, Kp, N);
@@ -315,6 +384,12 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
         hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 2>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
     else if (Kp == 3)
         hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 3>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    else if (softmax && N <= 64)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    else if (softmax && N <= 128)
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+    else if (softmax)
+        return MI355Q_E_UNSUPPORTED;                       // (one pass over x only: head_dim <= 128)
     else if (N <= 64)
         hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
     else    // (head_dim 128: both halves of the columns in one pass over x)

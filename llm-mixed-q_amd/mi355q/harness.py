@@ -58,8 +58,12 @@ class _Attention(nn.Module):
         w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
         w = w.view(B, self.nh, T, T) + mask
         w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device)).view(B * self.nh, T, T)
-        p = F.softmax(w, dim=-1)
-        o = get_quantized_func("bmm", self.qc["bmm_1"])(p, v, config=self.qc["bmm_1"])
+        c1 = self.qc["bmm_1"]
+        if c1["name"] == "block_fp" and c1.get("mi355q_fused_softmax", False):
+            o = get_quantized_func("softmax_bmm", c1)(w, v, config=c1)      # softmax folded into the product kernel
+        else:
+            p = F.softmax(w, dim=-1)
+            o = get_quantized_func("bmm", c1)(p, v, config=c1)
         o = o.view(B, self.nh, T, self.hd).transpose(1, 2).reshape(B, T, self.h)
         return self.out_proj(o)
 
@@ -192,8 +196,12 @@ class _LlamaAttention(nn.Module):
         w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])
         w = w / math.sqrt(self.hd) + mask
         w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
-        p = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
-        o = get_quantized_func("matmul", self.qc["matmul_1"])(p, v, config=self.qc["matmul_1"])
+        c1 = self.qc["matmul_1"]
+        if c1["name"] == "block_fp" and c1.get("mi355q_fused_softmax", False):
+            o = get_quantized_func("softmax_matmul", c1)(w, v, config=c1)
+        else:
+            p = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+            o = get_quantized_func("matmul", c1)(p, v, config=c1)
         return self.o_proj(o.transpose(1, 2).reshape(B, T, self.h))
 
 

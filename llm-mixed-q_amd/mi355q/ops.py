@@ -601,8 +601,12 @@ def bfp_matmul_supported(x: torch.Tensor, y: torch.Tensor, x_width: int, y_width
             and 2 <= int(y_width) <= 9)
 
 
+def bfp_softmax_matmul_supported(x, y, x_width, y_width) -> bool:
+    return bfp_matmul_supported(x, y, x_width, y_width) and x.shape[2] > 192 and y.shape[2] <= 128
+
+
 def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width: int, x_exponent_bias, y_width: int,
-               y_exponent_width: int, y_exponent_bias) -> torch.Tensor:
+               y_exponent_width: int, y_exponent_bias, *, softmax: bool = False) -> torch.Tensor:
     """out[b] = Qx(x[b]) @ Qy(y[b]) for x [B, M, K], y [B, K, N] fp32: block_fp [1,16] blocks along each operand's last
     dim (reference matmul.py:146-196), x quantised on its way into the MFMAs (one pass over x, no fake-quantised copy)"""
     _require_device(x, "bfp_matmul")
@@ -619,11 +623,11 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
         if len(_MATMUL_WS) > 16:
             _MATMUL_WS.clear()
         ws = _MATMUL_WS[key] = torch.empty(lib.mi355q_bfp_matmul_workspace_bytes(B, K, N), dtype=torch.uint8, device=x.device)
+    fn = lib.mi355q_bfp_softmax_matmul if softmax else lib.mi355q_bfp_matmul
     with torch.cuda.device(x.device):
-        rc = lib.mi355q_bfp_matmul(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), B, M, K, N, int(x_width), int(x_exponent_width),
-                                   _default_bias(x_exponent_bias), int(y_width), int(y_exponent_width),
-                                   _default_bias(y_exponent_bias), sp)
-    _lib.check(rc, "mi355q_bfp_matmul")
+        rc = fn(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), B, M, K, N, int(x_width), int(x_exponent_width),
+                _default_bias(x_exponent_bias), int(y_width), int(y_exponent_width), _default_bias(y_exponent_bias), sp)
+    _lib.check(rc, "mi355q_bfp_softmax_matmul" if softmax else "mi355q_bfp_matmul")
     return out
 
 

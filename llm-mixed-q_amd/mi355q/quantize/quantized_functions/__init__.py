@@ -38,9 +38,10 @@ def _quantise_operand(t, arith, config, prefix):
     return torch.reshape(q(flat, **kw, skip_first_dim=many), t.shape)
 
 
-def _fused_block_fp_matmul(x, y, config, style):
+def _fused_block_fp_matmul(x, y, config, style, softmax=False):
     """one pass over x: quantise inside the product kernel (ops.bfp_matmul) where shapes, block sizes and widths
-    allow; None -> the caller takes the two-quantisers + GEMM route.  Autograd (QAT) stays on that route too."""
+    allow; None -> the caller takes the two-quantisers + GEMM route.  Autograd (QAT) stays on that route too.
+    `softmax`: x holds scores whose row softmax is the quantiser's input (ops.bfp_matmul(..., softmax=True))."""
     from .. import quantizers as _q                                   # noqa: F401  (registry import order)
     from ... import ops
     if not (x.is_cuda and y.is_cuda) or x.dtype != torch.float32 or y.dtype != torch.float32:
@@ -56,10 +57,11 @@ def _fused_block_fp_matmul(x, y, config, style):
         shape = t.shape if many else t.shape[-2:]
         if ops.resolve_blocking(list(shape), config[f"{prefix}_block_size"], many)[3:] != (1, 16):
             return None
-    if not ops.bfp_matmul_supported(x3, y3, config["data_in_width"], config["weight_width"]):
+    supported = ops.bfp_softmax_matmul_supported if softmax else ops.bfp_matmul_supported
+    if not supported(x3, y3, config["data_in_width"], config["weight_width"]):
         return None
     out = ops.bfp_matmul(x3, y3, config["data_in_width"], config["data_in_exponent_width"], config["data_in_exponent_bias"],
-                         config["weight_width"], config["weight_exponent_width"], config["weight_exponent_bias"])
+                         config["weight_width"], config["weight_exponent_width"], config["weight_exponent_bias"], softmax=softmax)
     return out.reshape(*x.shape[:-1], y.shape[-1])
 
 
@@ -79,6 +81,24 @@ def _generic_matmul(x, y, config, arith, style):
     return mm(xq, yq)
 
 
+def _make_softmax(style):
+    """`softmax_{matmul,bmm}_block_fp(scores, y, config)` = `{matmul,bmm}_block_fp(softmax(scores, dim=-1), y, config)`:
+    what the reference's attention computes between its two products (modeling_opt.py:296-312, modeling_llama.py:333-344),
+    as ONE call, so that the probability tensor [heads, T, T] need not exist.  An addition to the registry
+    (keys "softmax_matmul" / "softmax_bmm"); callers that keep the reference's three steps are served as before."""
+    def f(scores, y, config):
+        if not config.get("bypass", False) and config.get("mi355q_fused_matmul", True):
+            for k in _KEYS["block_fp"]:
+                config[f"data_in_{k}"], config[f"weight_{k}"]
+            out = _fused_block_fp_matmul(scores, y, config, style, softmax=True)
+            if out is not None:
+                return out
+        p = torch.nn.functional.softmax(scores, dim=-1, dtype=torch.float32).to(scores.dtype)
+        return _generic_matmul(p, y, config, "block_fp", style)
+    f.__name__ = f"softmax_{style}_block_fp"
+    return f
+
+
 def _make(arith, style):
     def f(x, y, config):
         return _generic_matmul(x, y, config, arith, style)
@@ -91,6 +111,7 @@ matmul_minifloat_denorm, bmm_minifloat_denorm = _make("minifloat_denorm", "matmu
 matmul_minifloat_ieee, bmm_minifloat_ieee = _make("minifloat_ieee", "matmul"), _make("minifloat_ieee", "bmm")
 matmul_log, bmm_log = _make("log", "matmul"), _make("log", "bmm")
 matmul_block_fp, bmm_block_fp = _make("block_fp", "matmul"), _make("block_fp", "bmm")
+softmax_matmul_block_fp, softmax_bmm_block_fp = _make_softmax("matmul"), _make_softmax("bmm")
 matmul_block_minifloat, bmm_block_minifloat = _make("block_minifloat", "matmul"), _make("block_minifloat", "bmm")
 matmul_block_log, bmm_block_log = _make("block_log", "matmul"), _make("block_log", "bmm")
 
@@ -137,6 +158,8 @@ QUANTIZED_FUNC_MAP = {
         "integer": bmm_integer, "log": bmm_block_log, "minifloat_denorm": bmm_minifloat_denorm,
         "minifloat_ieee": bmm_minifloat_ieee,
     },
+    "softmax_matmul": {"block_fp": softmax_matmul_block_fp},
+    "softmax_bmm": {"block_fp": softmax_bmm_block_fp},
     "rotary_positional_encoding": {
         "block_fp": apply_rotary_pos_emb_block_fp, "block_log": apply_rotary_pos_emb_block_log,
         "block_minifloat": apply_rotary_pos_emb_block_minifloat, "integer": apply_rotary_pos_emb_integer,

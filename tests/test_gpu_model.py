@@ -129,3 +129,30 @@ def test_reference_model_fixture(tag):
     if "k128" in tag:
         lin = model.layers[0].fc2 if m["family"] == "opt" else model.layers[0].down_proj
         assert lin._packed is not None, "K % 128 == 0 layer did not take the int8 path"
+
+
+def test_fused_softmax_model_parity():
+    """the harness with softmax folded into the P V product (config["mi355q_fused_softmax"], T long enough for the fused
+    entry point) against the three-step route and the oracle"""
+    import torch
+    from mi355q.harness import TinyOPTConfig, TinyOPTForCausalLM, expand_quant_config
+    d = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+    cfg = TinyOPTConfig(vocab_size=256, hidden_size=128, ffn_dim=256, num_layers=2, num_heads=2, max_positions=256)
+    torch.manual_seed(5)
+    ids = torch.randint(0, cfg.vocab_size, (1, 256))
+    losses = {}
+    for fused in (False, True):
+        torch.manual_seed(6)
+        model = TinyOPTForCausalLM(cfg, expand_quant_config(dict(d, mi355q_fused_softmax=fused), cfg.num_layers))
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.ndim == 2 and "embed" not in n:
+                    p.mul_(4.0)
+        if not fused:
+            ref_loss = _oracle_forward(model, d, ids.numpy())
+        model = model.to("cuda:0")
+        with torch.no_grad():
+            losses[fused] = float(model(ids.to("cuda:0"), labels=ids.to("cuda:0"))[1])
+    assert abs(losses[True] - ref_loss) < 3e-4 and abs(losses[False] - ref_loss) < 3e-4, (losses, ref_loss)

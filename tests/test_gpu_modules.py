@@ -378,3 +378,29 @@ def test_pack_now_and_master_requantize():
     assert torch.equal(y4, fresh4(x)) and torch.equal(lin.weight, fresh4.weight)
     lin.requantize(_lin_cfg(6))                              # and back
     assert torch.equal(lin(x), y6)
+
+
+@pytest.mark.parametrize("B,T,hd", [(6, 320, 64), (4, 2048, 128), (3, 1000, 64)])
+@pytest.mark.parametrize("width", [6, 4])
+def test_softmax_folded_into_the_product(B, T, hd, width):
+    """softmax_bmm_block_fp(scores, v) == bmm_block_fp(softmax(scores), v) (matmul.py:146-196 on the probabilities):
+    causal mask included; against the oracle's float64 evaluation and against the three-step route on the GPU"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = _lin_cfg(width)
+    r = np.random.default_rng(B + T)
+    s = (r.normal(size=(B, T, T)) * 3).astype(np.float32)
+    s += np.triu(np.full((T, T), np.finfo(np.float32).min, np.float32), 1)[None]
+    s = np.maximum(s, np.finfo(np.float32).min)
+    v = r.normal(size=(B, T, hd)).astype(np.float32)
+    st, vt = torch.from_numpy(s).to("cuda:0"), torch.from_numpy(v).to("cuda:0")
+    fused = Q.get_quantized_func("softmax_bmm", cfg)(st, vt, config=cfg)
+    three = Q.get_quantized_func("bmm", cfg)(torch.softmax(st, -1), vt, config=cfg)
+    e = np.exp(s - s.max(-1, keepdims=True))
+    ref = O.matmul_quantized((e / e.sum(-1, keepdims=True)).astype(np.float32), v, cfg)
+    scale = np.abs(ref).max()
+    # (a probability one ulp apart may round to the next mantissa: one 2^-(width-1) step of one of T terms of a row)
+    assert np.abs(fused.cpu().numpy() - ref).max() <= 2e-3 * scale
+    assert (fused - three).abs().max().item() <= 2e-3 * scale
+    assert np.abs(fused.cpu().numpy() - ref).mean() <= 2e-5 * scale
