@@ -48,8 +48,9 @@ int main(int argc, char** argv) {
     std::normal_distribution<float> nd(0.f, 1.f);
     std::vector<float> hx(M * K), hw(N * K), hb(N);
     for (int64_t r = 0; r < M; ++r) { const float s = std::exp(nd(gen)); for (int64_t k = 0; k < K; ++k) hx[r * K + k] = nd(gen) * s; }
-    for (int64_t r = 0; r < N; ++r) { const float s = std::exp(nd(gen)) * 0.02f; for (int64_t k = 0; k < K; ++k) hw[r * K + k] = nd(gen) * s; }
-    for (auto& v : hb) v = nd(gen);
+    // (the distributions of bench.py's make_inputs: rows of x scaled by exp(N(0,1)), weights and bias N(0, 0.02^2))
+    for (auto& v : hw) v = nd(gen) * 0.02f;
+    for (auto& v : hb) v = nd(gen) * 0.02f;
     float *x = dalloc<float>(M * K), *w = dalloc<float>(N * K), *bias = dalloc<float>(N), *y = dalloc<float>(M * N);
     HIP_OK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
