@@ -64,8 +64,30 @@ def _require_device(t: torch.Tensor, what: str) -> None:
                         "configs are fp32 (SURVEY 8a quirk 11)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device) -> int:
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)                 # (no Stream object: this sits on every call's path)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` costs ~5 us even when d is current; most callers never leave device 0"""
+    __slots__ = ("dev", "ctx")
+
+    def __init__(self, dev):
+        self.dev, self.ctx = dev, None
+
+    def __enter__(self):
+        if self.dev.index is not None and self.dev.index != torch.cuda.current_device():
+            self.ctx = torch.cuda.device(self.dev)
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _workspace(device) -> torch.Tensor:
@@ -105,7 +127,7 @@ def block_fp_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent
     exp = (torch.empty(n_blocks(lead, rows, cols, b0, b1), dtype=torch.uint8, device=x.device)
            if want_packed else None)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize(
             _ptr(xc), _ptr(y), _ptr(mant), _ptr(exp), lead, rows, cols, b0, b1, int(width),
             int(exponent_width), _default_bias(exponent_bias),
@@ -128,7 +150,7 @@ def block_fp_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exp
     xc = x.contiguous()
     y = torch.empty(xc.shape, dtype=torch.bfloat16, device=x.device)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_bf16(_ptr(xc), _ptr(y), lead, rows, cols, b0, b1, int(width), int(exponent_width),
                                                _default_bias(exponent_bias), _ptr(_workspace(x.device)), _stream_ptr(x.device))
     _lib.check(rc, "mi355q_block_fp_quantize_bf16")
@@ -158,7 +180,7 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
             yt = _BF16_TILED_BUFFERS[key] = torch.empty(nbytes, dtype=torch.int8, device=x.device)
     else:
         yt = torch.empty(nbytes, dtype=torch.int8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_bf16_tiled(_ptr(x), _ptr(out_fake), _ptr(yt), rows, K, int(width), int(exponent_width),
                                                      _default_bias(exponent_bias), _ptr(_workspace(x.device)),
                                                      _stream_ptr(x.device))
@@ -174,7 +196,7 @@ def bfp_pack_bits(mant: torch.Tensor, width: int) -> torch.Tensor:
     assert mant.is_cuda and mant.dtype == torch.int8 and mant.ndim == 2 and mant.is_contiguous() and mant.shape[1] % 16 == 0
     rows, K = mant.shape
     out = torch.empty(rows, K * int(width) // 8, dtype=torch.uint8, device=mant.device)
-    with torch.cuda.device(mant.device):
+    with _on_device(mant.device):
         rc = _lib.load_library().mi355q_bfp_pack_bits(_ptr(mant), _ptr(out), rows, K, int(width), _stream_ptr(mant.device))
     _lib.check(rc, "mi355q_bfp_pack_bits")
     return out
@@ -215,14 +237,14 @@ class PackedWeights:
         if self.row_scale_flavour:                      # int8 row-scale operand
             tiled = _expand_scratch(dev, lib.mi355q_bfp_tiled_bytes(self.rows, self.K), "i8")
             exp = _expand_scratch(dev, self.rows * (self.K // 16), "exp").view(torch.uint8)
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 rc = lib.mi355q_bfp_expand(_ptr(self.packed), _ptr(self.codes), _ptr(tiled), self.rows, self.K, self.width, 0, off,
                                            _ptr(self.rowexp), _ptr(exp), _stream_ptr(dev))
             _lib.check(rc, "mi355q_bfp_expand")
             return AlignedOperand(self.rows, self.K, None, tiled, exp, self.rowflag, self.rowscale, self.sparse,
                                   self.width - 1, self.exp_bias, row_aligned=True, bucket_cap=0)
         tiled = _expand_scratch(dev, lib.mi355q_bfp_tiled_bytes(self.rows, 2 * self.K), "bf16")
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = lib.mi355q_bfp_expand(_ptr(self.packed), _ptr(self.codes), _ptr(tiled), self.rows, self.K, self.width, 1, off,
                                        0, 0, _stream_ptr(dev))
         _lib.check(rc, "mi355q_bfp_expand")
@@ -261,7 +283,7 @@ def bf16_tile(x: torch.Tensor) -> torch.Tensor:
     rows, K = x.shape
     lib = _lib.load_library()
     yt = torch.empty(lib.mi355q_bfp_tiled_bytes(rows, 2 * K), dtype=torch.int8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_bf16_tile(_ptr(x), _ptr(yt), rows, K, _stream_ptr(x.device))
     _lib.check(rc, "mi355q_bf16_tile")
     return yt
@@ -276,7 +298,7 @@ def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, 
         out = torch.empty(M, N, dtype=torch.float32, device=xt.device)
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
-    with torch.cuda.device(xt.device):
+    with _on_device(xt.device):
         rc = _lib.load_library().mi355q_bf16_gemm_tiled(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy,
                                                        _stream_ptr(xt.device))
     _lib.check(rc, "mi355q_bf16_gemm_tiled")
@@ -292,7 +314,7 @@ def block_minifloat_quantize(x: torch.Tensor, width: int, exponent_width: int, e
     bias = (torch.empty(n_blocks(lead, rows, cols, b0, b1), dtype=torch.uint8, device=x.device)
             if want_bias else None)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_block_minifloat_quantize(
             _ptr(xc), _ptr(y), _ptr(bias), lead, rows, cols, b0, b1, int(width), int(exponent_width),
             int(exponent_bias_width), _lib.ZERO_BLOCK_EXACT, _ptr(_workspace(x.device)),
@@ -310,7 +332,7 @@ def block_log_quantize(x: torch.Tensor, width: int, exponent_bias_width: int, bl
     bias = (torch.empty(n_blocks(lead, rows, cols, b0, b1), dtype=torch.uint8, device=x.device)
             if want_bias else None)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_block_log_quantize(
             _ptr(xc), _ptr(y), _ptr(bias), lead, rows, cols, b0, b1, int(width),
             int(exponent_bias_width), _lib.ZERO_BLOCK_EXACT, _ptr(_workspace(x.device)),
@@ -324,7 +346,7 @@ def integer_quantize(x: torch.Tensor, width: int, frac_width: int, is_signed: bo
     xc = x.contiguous()
     y = torch.empty_like(xc)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_integer_quantize(_ptr(xc), _ptr(y), xc.numel(), int(width), int(frac_width),
                                          int(bool(is_signed)), _stream_ptr(x.device))
     _lib.check(rc, "mi355q_integer_quantize")
@@ -350,7 +372,7 @@ def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Ten
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
     lib = _lib.load_library()
-    with torch.cuda.device(xm.device):
+    with _on_device(xm.device):
         rc = lib.mi355q_bfp_gemm(_ptr(xm), _ptr(xe), _ptr(wm), _ptr(we), _ptr(bias), _ptr(out), M, N, K, ldy,
                                  int(x_mbits), int(x_exp_bias), int(w_mbits), int(w_exp_bias),
                                  _stream_ptr(xm.device))
@@ -384,9 +406,13 @@ class AlignedOperand:
                          else (ROW_BUCKET_CAP if row_aligned else SPARSE_LIST_CAP))
 
     def c_struct(self):
-        return _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
-                               _ptr(self.sparse), self.list_cap, self.mbits, self.exp_bias,
-                               2 if self.unaligned else int(self.row_aligned))
+        cs = getattr(self, "_cs", None)
+        if cs is None:                                   # (operands are immutable once built)
+            cs = self._cs = _lib.BfpOperand(_ptr(self.tiled), _ptr(self.exp), _ptr(self.rowflag), _ptr(self.gscale),
+                                            _ptr(self.sparse), self.list_cap, self.mbits, self.exp_bias,
+                                            2 if self.unaligned else int(self.row_aligned))
+            self._cs_addr = __import__("ctypes").addressof(cs)
+        return cs
 
 
 def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
@@ -406,7 +432,7 @@ def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, 
     flag = torch.empty(rows, groups, dtype=torch.uint8, device=mant.device)
     gscale = torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=mant.device)
     sparse = _new_exception_list(mant.device) if with_list else None
-    with torch.cuda.device(mant.device):
+    with _on_device(mant.device):
         rc = lib.mi355q_bfp_align(_ptr(mant), _ptr(exp), _ptr(mo), _ptr(tiled), _ptr(eo), _ptr(flag), _ptr(gscale),
                                   _ptr(sparse), SPARSE_LIST_CAP, int(exp_bias) + int(mbits), rows, K,
                                   _stream_ptr(mant.device))
@@ -474,7 +500,7 @@ def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: 
     flag = torch.empty(rows, dtype=torch.uint8, device=mant.device)
     rscale = torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=mant.device)
     sparse = _new_row_list(mant.device, rows, bucket_cap) if with_list else None
-    with torch.cuda.device(mant.device):
+    with _on_device(mant.device):
         rc = lib.mi355q_bfp_align_rows(_ptr(mant), _ptr(exp), _ptr(tiled), _ptr(eo), _ptr(flag), _ptr(rscale),
                                        _ptr(sparse), int(exp_bias) + int(mbits), rows, K, int(bucket_cap),
                                        _stream_ptr(mant.device))
@@ -533,7 +559,7 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
     lib = _lib.load_library()
     cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
     buf["calls"] += 1
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_aligned(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
                                                   _ptr(buf["gscale"]), _ptr(cur), SPARSE_LIST_CAP, _ptr(nxt), rows, K,
                                                   int(width), int(exponent_width), bias, _stream_ptr(x.device))
@@ -561,7 +587,7 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     lib = _lib.load_library()
     cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
     buf["calls"] += 1
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_aligned_rows(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
                                                        _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows, K, int(width),
                                                        int(exponent_width), bias, bucket_cap, sp)
@@ -581,11 +607,9 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
     lib = _lib.load_library()
     sp = _stream_ptr(x.tiled.device)
-    xs, ws = x.c_struct(), w.c_struct()
-    import ctypes
-    with torch.cuda.device(x.tiled.device):
-        rc = lib.mi355q_bfp_gemm_aligned(ctypes.addressof(xs), ctypes.addressof(ws), _ptr(bias), _ptr(out), M, N, K,
-                                         ldy, sp)
+    x.c_struct(), w.c_struct()
+    with _on_device(x.tiled.device):
+        rc = lib.mi355q_bfp_gemm_aligned(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(out), M, N, K, ldy, sp)
     _lib.check(rc, "mi355q_bfp_gemm_aligned")
     return out
 
@@ -624,7 +648,7 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
             _MATMUL_WS.clear()
         ws = _MATMUL_WS[key] = torch.empty(lib.mi355q_bfp_matmul_workspace_bytes(B, K, N), dtype=torch.uint8, device=x.device)
     fn = lib.mi355q_bfp_softmax_matmul if softmax else lib.mi355q_bfp_matmul
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = fn(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), B, M, K, N, int(x_width), int(x_exponent_width),
                 _default_bias(x_exponent_bias), int(y_width), int(y_exponent_width), _default_bias(y_exponent_bias), sp)
     _lib.check(rc, "mi355q_bfp_softmax_matmul" if softmax else "mi355q_bfp_matmul")

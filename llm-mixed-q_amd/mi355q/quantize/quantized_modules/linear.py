@@ -90,6 +90,15 @@ class _LinearBase(nn.Linear):
         the MFMA path: block_fp both sides, [1,16] blocks along in_features, widths <= 8."""
         if self.arith != "block_fp" or not x.is_cuda or x.dtype != torch.float32 or x.ndim < 2:
             return None
+        key = (x.ndim, x.shape[-2] if x.ndim == 3 else 0, id(self.config))
+        cached = self.__dict__.get("_plan_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        plan = self._int8_plan_uncached(x)
+        self.__dict__["_plan_cache"] = (key, plan)
+        return plan
+
+    def _int8_plan_uncached(self, x: torch.Tensor):
         c, K = self.config, self.in_features
         if K % 64 or not (2 <= c["data_in_width"] <= 8 and 2 <= c["weight_width"] <= 8):
             return None

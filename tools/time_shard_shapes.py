@@ -1,0 +1,28 @@
+"""The row-sharded layer's per-rank GEMM shapes on one GPU (north_star partition of the 4096^3 benchmark layer and of the
+OPT-1.3B / Llama-7B layers over P ranks): steady-state step (fused quantise + tile GEMM, split-K where the grid is
+under-filled), HIP events."""
+import json, sys; sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
+import torch
+from mi355q import ops
+dev = torch.device('cuda:0')
+def t(fn, n=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return a.elapsed_time(e) / n * 1e3
+for name, M, N, K in (("bench P=8", 4096, 512, 4096), ("bench P=4", 4096, 1024, 4096), ("bench P=2", 4096, 2048, 4096),
+                      ("OPT-1.3B fc1 P=8", 2048, 1024, 2048), ("OPT-1.3B q_proj P=8", 2048, 256, 2048), ("Llama-7B q_proj P=8", 2048, 512, 4096),
+                      ("Llama-7B up P=8", 2048, 1376, 4096)):
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(dev)
+    _, wm, we = ops.block_fp_quantize(w, 6, 8, 127, [1, 16], False, want_fake=False, want_packed=True, fast_zero_blocks=True)
+    wa = ops.bfp_align_rows(wm, we, 5, 127)
+    y = torch.empty(M, N, device=dev)
+    xa = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127)
+    tg = t(lambda: ops.bfp_gemm_aligned(xa, wa, None, out=y))
+    tq = t(lambda: ops.block_fp_quantize_aligned_rows(x, 6, 8, 127))
+    print(json.dumps({"shape": name, "M": M, "N": N, "K": K, "gemm_us": round(tg, 1), "gemm_TOPS": round(2.0 * M * N * K / tg / 1e6), "quantise_us": round(tq, 1)}))
