@@ -279,14 +279,20 @@ int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspac
                       int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
                       int32_t y_exponent_width, int32_t y_exponent_bias, void* stream);
 
-/* The same with the row softmax of the attention scores folded in: out[b] = Qx(softmax(scores[b], dim = -1))
- * @ Qy(y[b]) -- replaces `attn_probs = softmax(attn_weights); bmm_1(attn_probs, value_states)` of the reference's callers
- * (models/opt_quantized/modeling_opt.py:296-312, models/llama_quantized/modeling_llama.py:333-344) without the probability
- * tensor [heads, T, T] ever being written: scores are read (two statistics passes that hit L2, one main pass), softmax is
- * fp32 exp(x - max) / sum like torch's.  K > 192 (shorter rows: softmax + mi355q_bfp_matmul), N <= 128. */
-int mi355q_bfp_softmax_matmul(const float* scores, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
-                              int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
-                              int32_t y_exponent_width, int32_t y_exponent_bias, void* stream);
+/* The same with the attention's softmax stage folded in:
+ *   out[b] = Qx(softmax(max(scores[b] + mask, finfo.min), dim = -1)) @ Qy(y[b])
+ * -- replaces `attn_weights = attn_weights + attention_mask; attn_weights = max(attn_weights, finfo.min);
+ * attn_probs = softmax(attn_weights); bmm_1(attn_probs, value_states)` of the reference's callers
+ * (models/opt_quantized/modeling_opt.py:262-312, models/llama_quantized/modeling_llama.py:318-344) without the masked
+ * scores or the probabilities [heads, T, T] ever being written.  mask: additive fp32 [M, K] shared by all batches, or
+ * NULL; causal != 0: keys behind query i's horizon i + K - M are masked (what a causal mask's finfo.min entries do) and
+ * the steps behind a row block's horizon are skipped altogether (their probabilities are exactly 0).  Scores are read
+ * three times (two statistics passes that hit L2, one main pass); softmax is fp32 exp(x - max) / sum like torch's, the
+ * exponential to ~1 ulp.  K > 192 (shorter rows: softmax + mi355q_bfp_matmul), N <= 128. */
+int mi355q_bfp_softmax_matmul(const float* scores, const float* mask, int32_t causal, const float* y, float* out, void* workspace,
+                              int64_t B, int64_t M, int64_t K, int64_t N, int32_t x_width, int32_t x_exponent_width,
+                              int32_t x_exponent_bias, int32_t y_width, int32_t y_exponent_width, int32_t y_exponent_bias,
+                              void* stream);
 
 /* Kernel timing for benchmarks: when enabled, mi355q_bfp_gemm_aligned brackets its MAIN kernel (the
  * int32-chain GEMM, not the correction / fallback launches) with HIP events on the launch stream.

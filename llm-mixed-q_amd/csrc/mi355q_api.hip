@@ -427,7 +427,7 @@ size_t mi355q_bfp_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N) {
     return (size_t)B * (size_t)((K + 63) / 64 * 64) * (size_t)N * 2 + 64;
 }
 
-static int bfp_matmul_impl(bool softmax, const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
+static int bfp_matmul_impl(bool softmax, const float* mask, long long causal_off, const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
                       int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
                       int32_t y_exponent_width, int32_t y_exponent_bias, void* stream) {
     if (B < 0 || M < 0 || K < 0 || N < 0) return MI355Q_E_BADARG;
@@ -452,21 +452,24 @@ static int bfp_matmul_impl(bool softmax, const float* x, const float* y, float* 
     };
     fill(ax, x_width, x_exponent_width, x_exponent_bias);
     fill(ay, y_width, y_exponent_width, y_exponent_bias);
-    return launch_bfp_qmatmul(ax, ay, x, y, out, workspace, B, M, K, N, static_cast<hipStream_t>(stream), softmax);
+    return launch_bfp_qmatmul(ax, ay, x, y, out, workspace, B, M, K, N, static_cast<hipStream_t>(stream), softmax, mask, causal_off);
 }
 
 int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
                       int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
                       int32_t y_exponent_width, int32_t y_exponent_bias, void* stream) {
-    return bfp_matmul_impl(false, x, y, out, workspace, B, M, K, N, x_width, x_exponent_width, x_exponent_bias, y_width,
+    return bfp_matmul_impl(false, nullptr, -1, x, y, out, workspace, B, M, K, N, x_width, x_exponent_width, x_exponent_bias, y_width,
                            y_exponent_width, y_exponent_bias, stream);
 }
 
-int mi355q_bfp_softmax_matmul(const float* scores, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
-                              int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
-                              int32_t y_exponent_width, int32_t y_exponent_bias, void* stream) {
+int mi355q_bfp_softmax_matmul(const float* scores, const float* mask, int32_t causal, const float* y, float* out, void* workspace,
+                              int64_t B, int64_t M, int64_t K, int64_t N, int32_t x_width, int32_t x_exponent_width,
+                              int32_t x_exponent_bias, int32_t y_width, int32_t y_exponent_width, int32_t y_exponent_bias,
+                              void* stream) {
     if (K > 0 && (K <= 192 || N > 128)) return MI355Q_E_UNSUPPORTED;
-    return bfp_matmul_impl(true, scores, y, out, workspace, B, M, K, N, x_width, x_exponent_width, x_exponent_bias, y_width,
+    if (causal && K < M) return MI355Q_E_BADARG;              // (query i sees keys 0 .. i + K - M)
+    if (mask && reinterpret_cast<uintptr_t>(mask) % 16) return MI355Q_E_ALIGN;
+    return bfp_matmul_impl(true, mask, causal ? (long long)(K - M) : -1, scores, y, out, workspace, B, M, K, N, x_width, x_exponent_width, x_exponent_bias, y_width,
                            y_exponent_width, y_exponent_bias, stream);
 }
 

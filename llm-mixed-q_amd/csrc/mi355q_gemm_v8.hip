@@ -408,16 +408,19 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         // ONE body for every step (two instances: the B fragment sets swap roles): the last step reads its "successor"
         // fragments from the stage it is on (unused values: the hand-counted waits stay the same) and the last two steps
         // request the final step once more (into the free stage of the ring; drained behind the loop, never read).
+        const int dbg = FIXMODE_ == 3 ? a.dbg : 0;            // (diagnostic build: knock parts of the loop out, results invalid)
         auto body = [&](i32x4 (&fb)[TJ], i32x4 (&fbn)[TJ], int t, int sc, int sn, int dslot) {
             V8_WAIT(0);
-            __builtin_amdgcn_s_barrier();
+            if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
             const int ac = va + sc, an = va + sn, bn = vb + sn;
             const long long dstep = (long long)min(t + 2, nsteps - 1) * 1024;
 #define V8_GROUP(i, wait)                                                                                              \
+            if (!(dbg & 4)) {                                                                                          \
             if (i < TI - 2) V8_DSR(fa[(i + 2) & 3], ac, (i + 2) * 1024);                                               \
             else V8_DSR(fa[(i + 2) & 3], an, (i + 2 - TI) * 1024);                                                     \
             if (i >= 2 && i < 2 + TJ) V8_DSR(fbn[(i - 2) & 3], bn, ((i - 2) & 3) * 1024);                              \
-            if (i < LPW)                                                                                               \
+            }                                                                                                          \
+            if (i < LPW && !(dbg & 1))                                                                                 \
                 __builtin_amdgcn_global_load_lds((gptr_t)(src[i & 3] + dstep), (lptr_t)(smem + dslot * STAGE + dst[i & 3]), \
                                                  16, 0, 0);                                                            \
             V8_LGKM(wait);                                                                                             \
@@ -643,59 +646,53 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     //      global memory between the stores (vmcnt counts loads and stores alike: a load's wait would drain them).
     if (FIXMODE_ == 3) rt[2] = __builtin_amdgcn_s_memrealtime();
     const bool look = FIXMODE && (mode == 1 || mode == 2);
-    float val[TI][TJ][4];
+    // One 16-row fragment at a time -- scale, add the vectors of its rows / columns, store -- so that the first stores
+    // leave a few hundred cycles after the K loop: the 64 MiB of y are bound by the HBM write rate chip-wide, and every
+    // microsecond the stores start earlier comes off the kernel.
+    float swv[TJ], bv[TJ];
+    int sc_[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int cl = wn * 64 + j * 16 + l16;
-        const float swv = swt[cl], bv = bst[cl];
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const f32x4 sxv = *reinterpret_cast<const f32x4*>(&sxt[wm * WM + i * 16 + lq * 4]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) val[i][j][r] = BF16 ? (float)acc[i][j][r] + bv : (float)acc[i][j][r] * sxv[r] * swv + bv;
-        }
+        swv[j] = BF16 ? 1.f : swt[cl];
+        bv[j] = bst[cl];
+        sc_[j] = look ? colslot[cl] : -1;
     }
-    if (FIXMODE_ == 3) rt[3] = __builtin_amdgcn_s_memrealtime();
-    if (look) {
-        // one vector per row / column (chains were folded above): one predicated read each
+    if (FIXMODE_ == 3) rt[3] = rt[4] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int sc_ = colslot[wn * 64 + j * 16 + l16];
-            if (__any(sc_ >= 0)) {
-                const float* v = corr + (cx + max(sc_, 0)) * 256 + wm * WM + lq * 4;
+    for (int i = 0; i < TI; ++i) {
+        float val[TJ][4];
+        const f32x4 sxv = BF16 ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(&sxt[wm * WM + i * 16 + lq * 4]);
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(v + i * 16);
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) val[i][j][r] += sc_ >= 0 ? c4[r] : 0.f;
+            for (int r = 0; r < 4; ++r) val[j][r] = BF16 ? (float)acc[i][j][r] + bv[j] : (float)acc[i][j][r] * sxv[r] * swv[j] + bv[j];
+        if (look) {
+            // one vector per row / column (chains were folded above): one predicated read each
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                if (__any(sc_[j] >= 0)) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(corr + (cx + max(sc_[j], 0)) * 256 + wm * WM + i * 16 + lq * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[j][r] += sc_[j] >= 0 ? c4[r] : 0.f;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sr = rowslot[wm * WM + i * 16 + lq * 4 + r];
+                if (__any(sr >= 0)) {
+                    const float* v = corr + max(sr, 0) * 256 + wn * 64 + l16;
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) val[j][r] += sr >= 0 ? v[j * 16] : 0.f;
                 }
             }
         }
-        int sr[TI][4];
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sr[i][r] = rowslot[wm * WM + i * 16 + lq * 4 + r];
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (__any(sr[i][r] >= 0)) {
-                    const float* v = corr + max(sr[i][r], 0) * 256 + wn * 64 + l16;
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) val[i][j][r] += sr[i][r] >= 0 ? v[j * 16] : 0.f;
-                }
-    }
-    if (FIXMODE_ == 3) rt[4] = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long long row = m0 + wm * WM + i * 16 + lq * 4 + r;
             float* yrow = a.y + row * a.ldy + n0 + wn * 64 + l16;
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                if (n0 + wn * 64 + j * 16 + l16 < a.N && row < a.M) yrow[j * 16] = val[i][j][r];
+                if (n0 + wn * 64 + j * 16 + l16 < a.N && row < a.M) yrow[j * 16] = val[j][r];
         }
     }
     if (FIXMODE_ == 3) {

@@ -33,7 +33,8 @@ int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gsc
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
                             int* list_to_clear, hipStream_t st, int bcap);
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
-                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false);
+                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false,
+                       const float* mask = nullptr, long long causal_off = -1);
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {
@@ -53,6 +54,7 @@ struct GemmArgs {
     // split-K of the tile GEMM (under-filled grids): `splits` workgroups share a tile, each over a slice of K; raw
     // accumulator slabs [tile][split] and one arrival ticket per tile in a library-owned workspace (zero when idle)
     int splits;
+    int dbg;          // diagnostic builds only (MI355Q_V8_DBG with MI355Q_V8_STAMPS): 1 no LDS-DMA, 2 no barrier, 4 no fragment reads
     void* slabs;
     int* tickets;
 };

@@ -225,10 +225,31 @@ __device__ __forceinline__ void softmax_xblk(XBlk& s, float m, float l, float in
     }
 }
 
+// scores as the reference's attention hands them to softmax (modeling_opt.py:262-276, modeling_llama.py:318-329):
+// max(x + mask, finfo.min).  `mrow`: the additive mask's row [K] for this lane's query (nullable); causal: keys behind
+// `kvis` are masked (what the causal mask's finfo.min entries do: x + finfo.min clamps to finfo.min for every finite x).
+__device__ __forceinline__ void mask_scores(XBlk& s, const float* __restrict__ mrow, long long k0, int g, long long K, long long kvis) {
+    constexpr float FMIN = -3.4028234663852886e38f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long k = k0 + 16 * i + 4 * g;
+        if (mrow) {
+            const float4 m = *reinterpret_cast<const float4*>(mrow + (k0 + 16 * i < K ? k : 4 * g));
+            s.v[i].x = fmaxf(s.v[i].x + m.x, FMIN); s.v[i].y = fmaxf(s.v[i].y + m.y, FMIN);
+            s.v[i].z = fmaxf(s.v[i].z + m.z, FMIN); s.v[i].w = fmaxf(s.v[i].w + m.w, FMIN);
+        }
+        if (k + 0 > kvis) s.v[i].x = FMIN;
+        if (k + 1 > kvis) s.v[i].y = FMIN;
+        if (k + 2 > kvis) s.v[i].z = FMIN;
+        if (k + 3 > kvis) s.v[i].w = FMIN;
+    }
+}
+
 template <bool RESIDENT, int NT, bool SOFTMAX = false>
 __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
                                                           const uint16_t* __restrict__ yt, float* __restrict__ out,
-                                                          long long M, long long K, long long Kp, long long N) {
+                                                          long long M, long long K, long long Kp, long long N,
+                                                          const float* __restrict__ mask, long long causal_off) {
     __shared__ Lut lut;
     __shared__ f32x4 red[4][NT][64];                      // [wave][tile][lane]: split-K partial tiles
     __shared__ float stat[4][16];
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
     const float* __restrict__ row = x + (b * M + mrow) * K;
     const uint16_t* __restrict__ ytb = yt + b * (N >> 4) * Kp * 1024;   // (Kp = 64-steps per row of tiles)
     float* __restrict__ outb = out + b * M * N;
-    const long long nsteps = (K + 63) / 64;                // (= Kp: yt is stored in fragment order)
+    long long nsteps = (K + 63) / 64;                      // (= Kp: yt is stored in fragment order)
     const int mbits = (int)__builtin_log2f(a.shift);
     bf16x8 afr[2];
     if (RESIDENT) {                      // short contraction (Q K^T): quantise the row block once, waves share the columns
@@ -283,6 +304,17 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
         return;
     }
     float row_max = 0.f, row_sum = 1.f;
+    // (SOFTMAX) causal: this lane's query sees keys 0 .. kvis; the workgroup's 16 rows need no step behind the last
+    // row's horizon (their probabilities are exactly 0 there: all-zero blocks quantise to zeros)
+    const long long kvis = SOFTMAX && causal_off >= 0 ? mrow + causal_off : K;
+    const long long nsteps_all = nsteps;
+    const float* __restrict__ mrowp = SOFTMAX && mask ? mask + mrow * K : nullptr;
+    if (SOFTMAX && causal_off >= 0) {
+        const long long last = min(m0 + 15, M - 1) + causal_off;       // horizon of the workgroup's last row
+        const long long need = last / 64 + 1;
+        if (need < nsteps) nsteps = need < 1 ? 1 : need;
+    }
+    (void)nsteps_all;
     if (SOFTMAX) {
         // statistics of this lane's row r = lane % 16: every (wave, lane group g) covers a quarter of a quarter of the
         // steps' values; combine over g by shuffles, over the waves through LDS.  Values behind K do not count.
@@ -290,6 +322,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
         for (long long st = wave; st < nsteps; st += 4) {
             XBlk s;
             load_xblk(s, row, st * 64, g, K);
+            mask_scores(s, mrowp, st * 64, g, K, kvis);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (st * 64 + 16 * i < K) mx = fmaxf(mx, fmaxf(fmaxf(s.v[i].x, s.v[i].y), fmaxf(s.v[i].z, s.v[i].w)));
@@ -304,6 +337,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
         for (long long st = wave; st < nsteps; st += 4) {
             XBlk s;
             load_xblk(s, row, st * 64, g, K);
+            mask_scores(s, mrowp, st * 64, g, K, kvis);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (st * 64 + 16 * i < K)
@@ -333,7 +367,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
                 __builtin_amdgcn_sched_barrier(0);
                 load_xblk(xb, row, (st + 4) * 64, g, K);   // next step's x in flight under this one's work (behind K: a re-read)
                 __builtin_amdgcn_sched_barrier(0);
-                if (SOFTMAX) softmax_xblk(xa, row_max, row_sum, row_inv);
+                if (SOFTMAX) { mask_scores(xa, mrowp, st * 64, g, K, kvis); softmax_xblk(xa, row_max, row_sum, row_inv); }
                 if ((st + 1) * 64 > K) mask_xblk(xa, st * 64, K);          // (uniform: the last, partial step only)
                 quantise_xblk(xa, a, lut, mbits, lane, afr);
                 mma_step<NT>(afr, bf, n0, N, acc);
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
                 __builtin_amdgcn_sched_barrier(0);
                 load_xblk(xa, row, (st + 8) * 64, g, K);
                 __builtin_amdgcn_sched_barrier(0);
-                if (SOFTMAX) softmax_xblk(xb, row_max, row_sum, row_inv);
+                if (SOFTMAX) { mask_scores(xb, mrowp, (st + 4) * 64, g, K, kvis); softmax_xblk(xb, row_max, row_sum, row_inv); }
                 if ((st + 5) * 64 > K) mask_xblk(xb, (st + 4) * 64, K);
                 quantise_xblk(xb, a, lut, mbits, lane, afr);
                 mma_step<NT>(afr, bf, n0, N, acc);
@@ -370,7 +404,8 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
 }
 
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
-                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax) {
+                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax, const float* mask,
+                       long long causal_off) {
     if (softmax && (K + 63) / 64 <= 3) return MI355Q_E_UNSUPPORTED;     // (short rows: the caller takes softmax + the plain entry)
     dim3 g1((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)B);
     const long long Kp = (K + 63) / 64;                    // 64-steps: yt is stored in fragment order (kernel 1)
@@ -379,21 +414,21 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
     if (e != hipSuccess) return (int)e;
     dim3 g2((unsigned)((M + 15) / 16), (unsigned)B);
     if (Kp == 1)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 1>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 1>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
     else if (Kp == 2)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 2>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 2>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
     else if (Kp == 3)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 3>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 3>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
     else if (softmax && N <= 64)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
     else if (softmax && N <= 128)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
     else if (softmax)
         return MI355Q_E_UNSUPPORTED;                       // (one pass over x only: head_dim <= 128)
     else if (N <= 64)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
     else    // (head_dim 128: both halves of the columns in one pass over x)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N);
+        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
     return (int)hipGetLastError();
 }
 

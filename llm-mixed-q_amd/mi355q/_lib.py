@@ -42,7 +42,7 @@ SIGNATURES = {
     "mi355q_block_fp_quantize_aligned_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,
                                                         _i32, _i32, _vp]),
     "mi355q_bfp_matmul_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
-    "mi355q_bfp_softmax_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_bfp_softmax_matmul": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_gemm_timing_enable": (C.c_int, [C.c_int]),

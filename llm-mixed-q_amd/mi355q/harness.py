@@ -56,12 +56,13 @@ class _Attention(nn.Module):
         q = shape(self.q_proj(x) * self.scaling)
         k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
         w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
-        w = w.view(B, self.nh, T, T) + mask
-        w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device)).view(B * self.nh, T, T)
         c1 = self.qc["bmm_1"]
         if c1["name"] == "block_fp" and c1.get("mi355q_fused_softmax", False):
-            o = get_quantized_func("softmax_bmm", c1)(w, v, config=c1)      # softmax folded into the product kernel
+            # mask add, clamp and softmax folded into the product kernel (the harness' mask is the causal one)
+            o = get_quantized_func("softmax_bmm", c1)(w, v, config=c1, causal=True)
         else:
+            w = w.view(B, self.nh, T, T) + mask
+            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device)).view(B * self.nh, T, T)
             p = F.softmax(w, dim=-1)
             o = get_quantized_func("bmm", c1)(p, v, config=c1)
         o = o.view(B, self.nh, T, self.hd).transpose(1, 2).reshape(B, T, self.h)
@@ -194,12 +195,12 @@ class _LlamaAttention(nn.Module):
         q, k = get_quantized_func("rotary_positional_encoding", rc)(q, k, self.cos[:, :, :T], self.sin[:, :, :T],
                                                                    position_ids, config=rc)
         w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])
-        w = w / math.sqrt(self.hd) + mask
-        w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
         c1 = self.qc["matmul_1"]
         if c1["name"] == "block_fp" and c1.get("mi355q_fused_softmax", False):
-            o = get_quantized_func("softmax_matmul", c1)(w, v, config=c1)
+            o = get_quantized_func("softmax_matmul", c1)(w / math.sqrt(self.hd), v, config=c1, causal=True)
         else:
+            w = w / math.sqrt(self.hd) + mask
+            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
             p = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
             o = get_quantized_func("matmul", c1)(p, v, config=c1)
         return self.o_proj(o.transpose(1, 2).reshape(B, T, self.h))

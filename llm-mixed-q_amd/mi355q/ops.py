@@ -630,7 +630,8 @@ def bfp_softmax_matmul_supported(x, y, x_width, y_width) -> bool:
 
 
 def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width: int, x_exponent_bias, y_width: int,
-               y_exponent_width: int, y_exponent_bias, *, softmax: bool = False) -> torch.Tensor:
+               y_exponent_width: int, y_exponent_bias, *, softmax: bool = False, mask: torch.Tensor = None,
+               causal: bool = False) -> torch.Tensor:
     """out[b] = Qx(x[b]) @ Qy(y[b]) for x [B, M, K], y [B, K, N] fp32: block_fp [1,16] blocks along each operand's last
     dim (reference matmul.py:146-196), x quantised on its way into the MFMAs (one pass over x, no fake-quantised copy)"""
     _require_device(x, "bfp_matmul")
@@ -647,10 +648,15 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
         if len(_MATMUL_WS) > 16:
             _MATMUL_WS.clear()
         ws = _MATMUL_WS[key] = torch.empty(lib.mi355q_bfp_matmul_workspace_bytes(B, K, N), dtype=torch.uint8, device=x.device)
-    fn = lib.mi355q_bfp_softmax_matmul if softmax else lib.mi355q_bfp_matmul
+    args = (B, M, K, N, int(x_width), int(x_exponent_width), _default_bias(x_exponent_bias), int(y_width), int(y_exponent_width),
+            _default_bias(y_exponent_bias), sp)
     with _on_device(x.device):
-        rc = fn(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), B, M, K, N, int(x_width), int(x_exponent_width),
-                _default_bias(x_exponent_bias), int(y_width), int(y_exponent_width), _default_bias(y_exponent_bias), sp)
+        if softmax:
+            if mask is not None:
+                assert mask.shape == (M, K) and mask.dtype == torch.float32 and mask.is_contiguous() and mask.device == x.device
+            rc = lib.mi355q_bfp_softmax_matmul(_ptr(xc), _ptr(mask), int(bool(causal)), _ptr(yc), _ptr(out), _ptr(ws), *args)
+        else:
+            rc = lib.mi355q_bfp_matmul(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), *args)
     _lib.check(rc, "mi355q_bfp_softmax_matmul" if softmax else "mi355q_bfp_matmul")
     return out
 

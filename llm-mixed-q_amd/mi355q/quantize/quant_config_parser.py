@@ -75,4 +75,9 @@ def parse_node_config(config: dict, mase_op: str, strict: bool = True) -> dict:
     for group in optional:
         if optional_entry_exists(config, group):
             cp_multi_values(config, parsed, _keys_of(group, arith), strict=strict)
+    # implementation knobs of this build ("mi355q_align", "mi355q_weight_storage", "mi355q_fused_softmax", ...) ride
+    # along; the reference's configs carry none, so its parsed dicts are reproduced unchanged
+    for k, v in config.items():
+        if k.startswith("mi355q_"):
+            parsed[k] = deepcopy(v)
     return parsed

@@ -38,7 +38,7 @@ def _quantise_operand(t, arith, config, prefix):
     return torch.reshape(q(flat, **kw, skip_first_dim=many), t.shape)
 
 
-def _fused_block_fp_matmul(x, y, config, style, softmax=False):
+def _fused_block_fp_matmul(x, y, config, style, softmax=False, mask=None, causal=False):
     """one pass over x: quantise inside the product kernel (ops.bfp_matmul) where shapes, block sizes and widths
     allow; None -> the caller takes the two-quantisers + GEMM route.  Autograd (QAT) stays on that route too.
     `softmax`: x holds scores whose row softmax is the quantiser's input (ops.bfp_matmul(..., softmax=True))."""
@@ -61,7 +61,8 @@ def _fused_block_fp_matmul(x, y, config, style, softmax=False):
     if not supported(x3, y3, config["data_in_width"], config["weight_width"]):
         return None
     out = ops.bfp_matmul(x3, y3, config["data_in_width"], config["data_in_exponent_width"], config["data_in_exponent_bias"],
-                         config["weight_width"], config["weight_exponent_width"], config["weight_exponent_bias"], softmax=softmax)
+                         config["weight_width"], config["weight_exponent_width"], config["weight_exponent_bias"], softmax=softmax,
+                         mask=mask, causal=causal)
     return out.reshape(*x.shape[:-1], y.shape[-1])
 
 
@@ -82,18 +83,33 @@ def _generic_matmul(x, y, config, arith, style):
 
 
 def _make_softmax(style):
-    """`softmax_{matmul,bmm}_block_fp(scores, y, config)` = `{matmul,bmm}_block_fp(softmax(scores, dim=-1), y, config)`:
-    what the reference's attention computes between its two products (modeling_opt.py:296-312, modeling_llama.py:333-344),
-    as ONE call, so that the probability tensor [heads, T, T] need not exist.  An addition to the registry
-    (keys "softmax_matmul" / "softmax_bmm"); callers that keep the reference's three steps are served as before."""
-    def f(scores, y, config):
-        if not config.get("bypass", False) and config.get("mi355q_fused_matmul", True):
+    """`softmax_{matmul,bmm}_block_fp(scores, y, config, mask=None, causal=False)` =
+    `{matmul,bmm}_block_fp(softmax(max(scores + mask, finfo.min), dim=-1), y, config)`: what the reference's attention
+    computes between its two products (modeling_opt.py:262-312, modeling_llama.py:318-344), as ONE call, so that neither
+    the masked scores nor the probability tensor [heads, T, T] need exist.  `mask`: additive, [T_q, T_k]
+    (or broadcastable to it over the leading dims); `causal=True` stands for the causal mask without reading one.  An
+    addition to the registry (keys "softmax_matmul" / "softmax_bmm"); callers that keep the reference's steps are served
+    as before."""
+    def f(scores, y, config, mask=None, causal=False):
+        m2 = None
+        if mask is not None:
+            m2 = mask.reshape(mask.shape[-2:]) if mask.numel() == mask.shape[-2] * mask.shape[-1] else None
+        if (not config.get("bypass", False) and config.get("mi355q_fused_matmul", True) and (mask is None or m2 is not None)):
             for k in _KEYS["block_fp"]:
                 config[f"data_in_{k}"], config[f"weight_{k}"]
-            out = _fused_block_fp_matmul(scores, y, config, style, softmax=True)
+            out = _fused_block_fp_matmul(scores, y, config, style, softmax=True, mask=None if m2 is None else m2.contiguous(),
+                                         causal=causal)
             if out is not None:
                 return out
-        p = torch.nn.functional.softmax(scores, dim=-1, dtype=torch.float32).to(scores.dtype)
+        w = scores
+        if causal:
+            tq, tk = scores.shape[-2], scores.shape[-1]
+            w = w + torch.full((tq, tk), torch.finfo(w.dtype).min, device=w.device).triu(1 + tk - tq)
+        if mask is not None:
+            w = w + mask
+        if causal or mask is not None:
+            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+        p = torch.nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(scores.dtype)
         return _generic_matmul(p, y, config, "block_fp", style)
     f.__name__ = f"softmax_{style}_block_fp"
     return f

@@ -404,3 +404,33 @@ def test_softmax_folded_into_the_product(B, T, hd, width):
     assert np.abs(fused.cpu().numpy() - ref).max() <= 2e-3 * scale
     assert (fused - three).abs().max().item() <= 2e-3 * scale
     assert np.abs(fused.cpu().numpy() - ref).mean() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("B,T,hd,mode", [(4, 320, 64, "causal"), (2, 2048, 128, "causal"), (3, 520, 64, "mask"), (2, 640, 64, "both"),
+                                         (2, 100, 64, "causal")])
+def test_softmax_product_with_mask_and_causal(B, T, hd, mode):
+    """the reference's attention between its two products -- `w = w + mask; w = max(w, finfo.min); p = softmax(w);
+    bmm_1(p, v)` (modeling_opt.py:262-312) -- as one call: additive mask tensor, the causal rule without a mask tensor,
+    both; rows shorter than the fused kernel takes fall back to the same steps"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = _lin_cfg(6)
+    r = np.random.default_rng(T)
+    fmin = np.finfo(np.float32).min
+    s = (r.normal(size=(B, T, T)) * 3).astype(np.float32)
+    v = r.normal(size=(B, T, hd)).astype(np.float32)
+    causal_mask = np.triu(np.full((T, T), fmin, np.float32), 1)
+    add_mask = (r.normal(size=(T, T)) * 0.5).astype(np.float32)
+    add_mask[:, ::7] = fmin                                    # (a padding-style mask: whole key columns off)
+    add_mask[:, 0] = 0
+    m = {"causal": causal_mask, "mask": add_mask, "both": np.maximum(add_mask + causal_mask, fmin)}[mode]
+    w = np.maximum(s + m[None], fmin)
+    e = np.exp(w - w.max(-1, keepdims=True))
+    ref = O.matmul_quantized((e / e.sum(-1, keepdims=True)).astype(np.float32), v, cfg)
+    st, vt = torch.from_numpy(s).to("cuda:0"), torch.from_numpy(v).to("cuda:0")
+    kw = {"causal": dict(causal=True), "mask": dict(mask=torch.from_numpy(add_mask).to("cuda:0")),
+          "both": dict(mask=torch.from_numpy(add_mask).to("cuda:0")[None], causal=True)}[mode]
+    out = Q.get_quantized_func("softmax_bmm", cfg)(st, vt, cfg, **kw).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(out - ref).max() <= 2e-3 * scale and np.abs(out - ref).mean() <= 2e-5 * scale

@@ -89,9 +89,12 @@ def test_registry_keys_match_reference():
     names = {"block_fp", "block_log", "block_minifloat", "integer", "log", "minifloat_denorm", "minifloat_ieee"}
     assert set(Q.QUANTIZER_MAP) == names
     assert set(Q.QUANTIZED_MODULE_MAP) == {"linear"} and set(Q.QUANTIZED_MODULE_MAP["linear"]) == names
-    assert set(Q.QUANTIZED_FUNC_MAP) == {"matmul", "bmm", "rotary_positional_encoding"}
-    for op in Q.QUANTIZED_FUNC_MAP.values():
-        assert set(op) == names
+    # the reference's three ops, plus this build's two additions (the attention's softmax stage folded into the product)
+    ref_ops = {"matmul", "bmm", "rotary_positional_encoding"}
+    assert set(Q.QUANTIZED_FUNC_MAP) == ref_ops | {"softmax_matmul", "softmax_bmm"}
+    for name in ref_ops:
+        assert set(Q.QUANTIZED_FUNC_MAP[name]) == names
+    assert set(Q.QUANTIZED_FUNC_MAP["softmax_bmm"]) == {"block_fp"}
     # reference quirk: "log" is served by the block_log functions
     assert Q.QUANTIZED_FUNC_MAP["matmul"]["log"] is Q.QUANTIZED_FUNC_MAP["matmul"]["block_log"]
     assert Q.get_quantized_cls("linear", {"name": "block_fp"}).__name__ == "LinearBlockFP"

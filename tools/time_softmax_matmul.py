@@ -14,13 +14,17 @@ def t(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return a.elapsed_time(e) / n * 1e3
 for name, (h, T, hd) in (("OPT-125m", (12, 2048, 64)), ("OPT-1.3B", (32, 2048, 64)), ("Llama-7B", (32, 2048, 128))):
-    s = torch.randn(h, T, T, device=dev) * 3 + torch.full((T, T), torch.finfo(torch.float32).min, device=dev).triu(1)
+    raw = torch.randn(h, T, T, device=dev) * 3                       # what the first product (Q K^T) leaves
+    mask = torch.full((T, T), torch.finfo(torch.float32).min, device=dev).triu(1)
+    fmin = torch.tensor(torch.finfo(torch.float32).min, device=dev)
     v = torch.randn(h, T, hd, device=dev)
     bmm, sbmm = Q.get_quantized_func("bmm", cfg), Q.get_quantized_func("softmax_bmm", cfg)
-    t3 = t(lambda: bmm(torch.softmax(s, -1), v, config=cfg))
-    tsm = t(lambda: torch.softmax(s, -1))
-    t1 = t(lambda: sbmm(s, v, config=cfg))
-    nbytes = s.numel() * 4
-    print(json.dumps({"shape": name, "heads": h, "T": T, "head_dim": hd, "softmax_then_product_us": round(t3, 1), "of_which_softmax_us": round(tsm, 1),
-                      "folded_us": round(t1, 1), "speedup": round(t3 / t1, 2), "probability_tensor_MB_not_written_and_not_reread": round(2 * nbytes / 1e6, 1),
-                      "folded_TBps_of_scores": round(nbytes / t1 / 1e6, 2)}))
+    # the reference's steps (modeling_opt.py:262-312): add the mask, clamp, softmax, product
+    t_ref = t(lambda: bmm(torch.softmax(torch.max(raw + mask, fmin), -1), v, config=cfg))
+    t_glue = t(lambda: torch.softmax(torch.max(raw + mask, fmin), -1))
+    t_causal = t(lambda: sbmm(raw, v, config=cfg, causal=True))
+    t_mask = t(lambda: sbmm(raw, v, config=cfg, mask=mask))
+    nbytes = raw.numel() * 4
+    print(json.dumps({"shape": name, "heads": h, "T": T, "head_dim": hd, "reference_steps_us": round(t_ref, 1), "of_which_mask_clamp_softmax_us": round(t_glue, 1),
+                      "folded_causal_us": round(t_causal, 1), "folded_mask_tensor_us": round(t_mask, 1), "speedup_causal": round(t_ref / t_causal, 2),
+                      "speedup_mask_tensor": round(t_ref / t_mask, 2), "intermediate_tensors_MB_not_written_and_not_reread": round(6 * nbytes / 1e6, 1)}))
