@@ -22,7 +22,8 @@
  *         act    [B,T,C]  -> lead B, rows T, cols C, b0 B0, b1 B1      (skip_first_dim)
  *     with (b0,b1) the reference's right-aligned, clamped block shape (utils.py:42-66).
  *   - `workspace`: MI355Q_WORKSPACE_BYTES bytes of device memory, ZERO-INITIALISED once by
- *     the caller, private to one stream; the library leaves it zeroed after every call.
+ *     the caller, private to one stream; the library leaves its control words zeroed after
+ *     every call (the per-workgroup slots behind them are scratch).
  */
 #ifndef MI355Q_H
 #define MI355Q_H
@@ -34,8 +35,8 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 4
-#define MI355Q_WORKSPACE_BYTES 8192
+#define MI355Q_ABI_VERSION 5
+#define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
 #define MI355Q_E_BADARG (-1)      /* null pointer, non-positive size, width out of range */

@@ -30,21 +30,29 @@
 
 namespace mi355q {
 
-// One wave-reduced atomic max per wave (exact zero-block mode only): the tensor's smallest non-zero block max, kept as
-// max(~bits), and the "met an all-zero block" flag, for the fix-up launch that follows on the same stream.
+// Zero-block state of kernel 1 (exact mode only) for the fix-up launch that follows on the same stream, without a single
+// atomic: each workgroup stores the smallest non-zero block max it met -- as max(~bits) -- in its OWN workspace slot, and
+// a workgroup that met an all-zero block raises the flag word (a plain store of 1: every writer writes the same value).
+// (Thousands of waves finish together in these one-round launches; atomics on shared words serialised at the L2 and
+// cost 6-10 us per call.)
 __device__ __forceinline__ void publish_zero_state(unsigned* ws, bool saw_zero, unsigned inv) {
+    __shared__ unsigned wg_inv[4];
+    __shared__ int wg_zero[4];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const unsigned other = (unsigned)__shfl_xor((int)inv, o);
         inv = other > inv ? other : inv;
     }
     const bool any_zero = __any(saw_zero);
-    if ((threadIdx.x & 63) == 0) {
-        unsigned* shard = ws + WS_SHARD0 + WS_SHARD_STRIDE * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (WS_SHARDS - 1));
-        // (read first: after a few waves have reported, hardly any wave still lowers its shard's minimum)
-        if (inv > __hip_atomic_load(shard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            __hip_atomic_fetch_max(shard, inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (any_zero) __hip_atomic_store(&ws[WS_ZERO_FLAG], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { wg_inv[wave] = inv; wg_zero[wave] = any_zero ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = wg_inv[0];
+        int z = wg_zero[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = wg_inv[w] > m ? wg_inv[w] : m; z |= wg_zero[w]; }
+        ws[WS_SLOT0 + blockIdx.x] = m;
+        if (z) ws[WS_ZERO_FLAG] = 1u;
     }
 }
 
@@ -169,8 +177,8 @@ __global__ __launch_bounds__(256) void quant_generic_kernel(const QuantArgs a) {
 // ---------------------------------------------------------------------------------------
 // kernel 2: all-zero blocks take the tensor-global fill (block_fp.py:54-58).  Kernel 1 has left, in the
 // workspace, whether it met an all-zero block and the smallest non-zero block max of the whole tensor
-// (publish_zero_state); the stream orders the two launches, so there is no in-kernel grid barrier.
-// Returns at once when kernel 1 met no zero block.  The last workgroup out clears the workspace.
+// (publish_zero_state: one slot per workgroup of kernel 1); the stream orders the two launches, so there is no in-kernel
+// grid barrier.  Returns at once when kernel 1 met no zero block.  The last workgroup out lowers the flag.
 // ---------------------------------------------------------------------------------------
 constexpr int FIXUP_GRID = 256;
 
@@ -179,24 +187,28 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
+__global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int n_slots) {
     __shared__ Lut lut;
-    if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) {           // uniform over the grid: nothing to rewrite
-        if (blockIdx.x == 0 && threadIdx.x < WS_SHARDS)   // (nobody reads these words on this path)
-            __hip_atomic_store(&a.ws[WS_SHARD0 + WS_SHARD_STRIDE * threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
+    __shared__ unsigned wg_inv[4];
+    if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) return;     // uniform over the grid: nothing to rewrite
     load_lut<FMT>(lut);
-    __syncthreads();
     const int lane16 = threadIdx.x & 15;
     const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
     const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    unsigned inv_all = ld_agent(&a.ws[WS_SHARD0 + WS_SHARD_STRIDE * (threadIdx.x & (WS_SHARDS - 1))]);
+    // the tensor's smallest non-zero block max: every workgroup reduces kernel 1's slots for itself
+    unsigned inv_all = 0u;
+    for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+        const unsigned v = a.ws[WS_SLOT0 + i];
+        inv_all = v > inv_all ? v : inv_all;
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const unsigned other = (unsigned)__shfl_xor((int)inv_all, o);
         inv_all = other > inv_all ? other : inv_all;
     }
+    if ((threadIdx.x & 63) == 0) wg_inv[threadIdx.x >> 6] = inv_all;
+    __syncthreads();
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) inv_all = wg_inv[w] > inv_all ? wg_inv[w] : inv_all;
     const float fill = inv_all == 0u ? 1.0f : __uint_as_float(~inv_all);   // all blocks zero -> 1
     unsigned code;
     const BlockParam bp = block_param<FMT>(fill, a, lut, code);
@@ -215,14 +227,12 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a) {
         }
         if (a.code && lane16 == 0) a.code[bid] = (uint8_t)code;
     }
-    // exit ticket: the last workgroup out restores the workspace to zero for the next call (every workgroup has read
-    // the two words before it takes its ticket)
+    // exit ticket: the last workgroup out lowers the flag for the next call (every workgroup has read it before it
+    // takes its ticket; the slots need no clearing -- kernel 1 rewrites every slot the next fix-up reads)
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(&a.ws[WS_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1u) {
-            for (int sh = 0; sh < WS_SHARDS; ++sh)
-                __hip_atomic_store(&a.ws[WS_SHARD0 + WS_SHARD_STRIDE * sh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.ws[WS_TICKET], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.ws[WS_ZERO_FLAG], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void integer_kernel(const float* __restrict__ 
 static int grid_for(long long work_items, int per_block) {
     long long g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;     // 256 CUs x 8 blocks, grid-stride beyond (guide: Guideline 11)
+    if (g > WS_SLOTS) g = WS_SLOTS;   // 256 CUs x 8 blocks, grid-stride beyond (guide: Guideline 11); one workspace slot each
     return (int)g;
 }
 
@@ -258,8 +268,9 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
                         (a.ybf == nullptr || reinterpret_cast<uintptr_t>(a.ybf) % 8 == 0) &&
                         (a.mant == nullptr || reinterpret_cast<uintptr_t>(a.mant) % 4 == 0);
     const int lpb = a.b1 / 4;
+    int grid;
     if (vec_ok && (lpb == 1 || lpb == 2 || lpb == 4 || lpb == 8 || lpb == 16 || lpb == 32 || lpb == 64)) {
-        const int grid = grid_for(a.n_elems >> 2, 256);
+        grid = grid_for(a.n_elems >> 2, 256);
         switch (lpb) {
             case 1: hipLaunchKernelGGL((quant_vec_kernel<FMT, 1>), grid, 256, 0, st, a); break;
             case 2: hipLaunchKernelGGL((quant_vec_kernel<FMT, 2>), grid, 256, 0, st, a); break;
@@ -271,13 +282,13 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
         }
     } else {
         if (a.ybf) return MI355Q_E_UNSUPPORTED;            // bf16 output: vector path only
-        const int grid = grid_for(a.n_blocks, 16);
+        grid = grid_for(a.n_blocks, 16);
         hipLaunchKernelGGL((quant_generic_kernel<FMT>), grid, 256, 0, st, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (needs_fixup && (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u) {
-        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), FIXUP_GRID, 256, 0, st, a);
+        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), FIXUP_GRID, 256, 0, st, a, grid);
         e = hipGetLastError();
     }
     return (int)e;

@@ -21,11 +21,10 @@ constexpr float ATOL = 1e-8f;
 
 // workspace words
 constexpr int WS_ZERO_FLAG = 0;   // kernel 1 met an all-zero block
-constexpr int WS_MINBITS_INV = 1; // (spare)
-// max over non-zero blocks of ~bits(block max), kept in WS_SHARDS words a cache line apart (a burst of atomics on ONE word
-// serialises: thousands of waves finish together)
-constexpr int WS_SHARDS = 64, WS_SHARD0 = 64, WS_SHARD_STRIDE = 16;
-constexpr int WS_TICKET = 2;      // fix-up kernel exit ticket (the last workgroup out clears the workspace)
+constexpr int WS_TICKET = 2;      // fix-up kernel exit ticket (the last workgroup out lowers the flag)
+// one word per workgroup of kernel 1: max over its non-zero blocks of ~bits(block max)
+constexpr int WS_SLOT0 = 64, WS_SLOTS = 2048;
+static_assert((WS_SLOT0 + WS_SLOTS) * 4 <= MI355Q_WORKSPACE_BYTES, "workspace too small for the per-workgroup slots");
 
 struct Lut {
     unsigned a[LUT_N];  // bfp: ceil ; bm: floor ; bl: ceil
