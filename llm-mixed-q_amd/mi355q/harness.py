@@ -62,7 +62,7 @@ class _Attention(nn.Module):
             o = get_quantized_func("softmax_bmm", c1)(w, v, config=c1, causal=True)
         else:
             w = w.view(B, self.nh, T, T) + mask
-            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device)).view(B * self.nh, T, T)
+            w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min)).view(B * self.nh, T, T)
             p = F.softmax(w, dim=-1)
             o = get_quantized_func("bmm", c1)(p, v, config=c1)
         o = o.view(B, self.nh, T, self.hd).transpose(1, 2).reshape(B, T, self.h)
@@ -200,7 +200,7 @@ class _LlamaAttention(nn.Module):
             o = get_quantized_func("softmax_matmul", c1)(w / math.sqrt(self.hd), v, config=c1, causal=True)
         else:
             w = w / math.sqrt(self.hd) + mask
-            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+            w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min))
             p = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
             o = get_quantized_func("matmul", c1)(p, v, config=c1)
         return self.o_proj(o.transpose(1, 2).reshape(B, T, self.h))

@@ -509,6 +509,11 @@ def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: 
                           bucket_cap=bucket_cap)
 
 
+def _capturing() -> bool:
+    """the current stream is recording a HIP graph (torch.cuda.graph): no host reads, no state that alternates per call"""
+    return torch.cuda.is_current_stream_capturing()
+
+
 class _ActivationBuffers:
     """Reusable device buffers of the fused activation path, keyed by (device, stream, rows, K).  Two
     exception lists alternate: each quantise call fills one and zeroes the other's count for the next call."""
@@ -557,8 +562,11 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
     buf = _ActivationBuffers.get(x.device, rows, K)
     bias = _default_bias(exponent_bias)
     lib = _lib.load_library()
-    cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
-    buf["calls"] += 1
+    if _capturing():
+        cur, nxt = _new_exception_list(x.device), None     # (see block_fp_quantize_aligned_rows)
+    else:
+        cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
+        buf["calls"] += 1
     with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_aligned(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
                                                   _ptr(buf["gscale"]), _ptr(cur), SPARSE_LIST_CAP, _ptr(nxt), rows, K,
@@ -585,8 +593,14 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True, sp=sp, bucket_cap=bucket_cap)
     bias = _default_bias(exponent_bias)
     lib = _lib.load_library()
-    cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
-    buf["calls"] += 1
+    if _capturing() and bucket_cap >= 0:
+        # HIP-graph capture: a replayed node always sees the pointers it was captured with, so the two alternating lists
+        # (each call fills one and clears the other's counts for the next call) cannot work -- the node gets a list of its
+        # own, zeroed by a fill node in front of it on every replay
+        cur, nxt = _new_row_list(x.device, rows, bucket_cap), None
+    else:
+        cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
+        buf["calls"] += 1
     with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_aligned_rows(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
                                                        _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows, K, int(width),

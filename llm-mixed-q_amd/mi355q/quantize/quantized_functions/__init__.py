@@ -108,7 +108,7 @@ def _make_softmax(style):
         if mask is not None:
             w = w + mask
         if causal or mask is not None:
-            w = torch.max(w, torch.tensor(torch.finfo(w.dtype).min, device=w.device))
+            w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min))
         p = torch.nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(scores.dtype)
         return _generic_matmul(p, y, config, "block_fp", style)
     f.__name__ = f"softmax_{style}_block_fp"

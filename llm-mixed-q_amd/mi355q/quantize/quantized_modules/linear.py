@@ -343,8 +343,9 @@ class _LinearBase(nn.Linear):
         if self._align_mode == "rows" and self.align == "auto" and self._x_cap != ops.ROW_NO_ALIGN:
             # results never depend on the mode (an overflowing exception bucket only sends the GEMM to its slow
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats
-            self._calls += 1
-            if self._calls & (self._calls - 1) == 0 and int(xa.sparse[0]) != 0:
+            # (not while a HIP graph is being recorded: the read is a host synchronisation)
+            self._calls += 0 if ops._capturing() else 1
+            if not ops._capturing() and self._calls & (self._calls - 1) == 0 and int(xa.sparse[0]) != 0:
                 self._row_overflows += 1
                 if self._row_overflows >= 2:
                     self._x_cap = ops.ROW_NO_ALIGN                # activations stopped fitting: no alignment from now on

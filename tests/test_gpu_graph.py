@@ -1,0 +1,75 @@
+"""HIP-graph replay of the quantised forward == eager forward, bit for bit (mi355q/graphs.py)."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "llm-mixed-q_amd"))
+
+pytestmark = pytest.mark.gpu
+
+W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+            data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+            weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+
+
+def _model(family, fused):
+    from mi355q.harness import (TinyLlamaConfig, TinyLlamaForCausalLM, TinyOPTConfig, TinyOPTForCausalLM,
+                                expand_llama_quant_config, expand_quant_config)
+    torch.manual_seed(3)
+    qc = dict(W6A6, mi355q_fused_softmax=fused)
+    if family == "opt":
+        cfg = TinyOPTConfig(vocab_size=512, hidden_size=256, ffn_dim=1024, num_layers=2, num_heads=4, max_positions=512)
+        m = TinyOPTForCausalLM(cfg, expand_quant_config(qc, cfg.num_layers))
+    else:
+        cfg = TinyLlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=512)
+        m = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(qc, cfg.num_layers))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.ndim == 2 and "embed" not in n:
+                p.mul_(3.0)
+    return m.to("cuda:0").eval(), cfg
+
+
+@pytest.mark.parametrize("family,fused", [("opt", True), ("opt", False), ("llama", True)])
+def test_graph_replay_equals_eager(family, fused):
+    from mi355q.graphs import GraphedForward
+    model, cfg = _model(family, fused)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    ids = [torch.randint(0, cfg.vocab_size, (1, 384), generator=g).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        eager = [model(i)[0].clone() for i in ids]
+    fwd = GraphedForward(lambda t: model(t)[0], (ids[0],))
+    for rep in range(2):                                  # the second round replays nodes whose lists were used before
+        for i, e in zip(ids, eager):
+            out = fwd(i)
+            assert torch.equal(out, e), (family, fused, rep, float((out - e).abs().max()))
+    with torch.no_grad():                                 # eager calls after replays still see clean state
+        for i, e in zip(ids, eager):
+            assert torch.equal(model(i)[0], e)
+
+
+def test_graph_linear_with_exceptions():
+    """a row-scale Linear whose activations carry exception blocks: the captured node's own list is cleared on every replay"""
+    from mi355q.graphs import GraphedForward
+    from mi355q.quantize import get_quantized_cls
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    lin = get_quantized_cls("linear", W6A6)(512, 256, bias=True, config=dict(W6A6, mi355q_align="rows")).to(dev)
+    xs = []
+    for s in range(3):
+        x = torch.randn(300, 512, generator=torch.Generator().manual_seed(s))
+        x[::7, 32:48] *= 2.0 ** -9                        # blocks far below their row's window: exceptions
+        x[5::11, 64:80] *= 2.0 ** 7
+        xs.append(x.to(dev))
+    with torch.no_grad():
+        eager = [lin(x).clone() for x in xs]
+    fwd = GraphedForward(lambda t: lin(t), (xs[0],))
+    for rep in range(3):
+        for x, e in zip(xs, eager):
+            assert torch.equal(fwd(x), e), rep
+    with torch.no_grad():
+        for x, e in zip(xs, eager):
+            assert torch.equal(lin(x), e)
