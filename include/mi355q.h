@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 5
+#define MI355Q_ABI_VERSION 6
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -294,6 +294,24 @@ int mi355q_bfp_softmax_matmul(const float* scores, const float* mask, int32_t ca
                               int64_t B, int64_t M, int64_t K, int64_t N, int32_t x_width, int32_t x_exponent_width,
                               int32_t x_exponent_bias, int32_t y_width, int32_t y_exponent_width, int32_t y_exponent_bias,
                               void* stream);
+
+/* ---- the quantised attention core in one pass ------------------------------------------------------------------
+ * replaces, in the reference's attention modules (models/opt_quantized/modeling_opt.py:246-312,
+ * models/llama_quantized/modeling_llama.py:309-344), the sequence
+ *     w = bmm_0(q, k^T)  [ / scale_div ]   w = max(w + mask, finfo.min)   p = softmax(w, -1)   out = bmm_1(p, v)
+ * with the four block_fp quantisers of the two products (matmul.py:146-196: [1,16] blocks along each operand's last dim,
+ * data_in_* parameters for q and p, weight_* parameters for k^T and v) applied exactly where the reference applies them.
+ * q fp32 [B, M, D], k and v fp32 [B, T, D] (k UNtransposed), out fp32 [B, M, D]; mask additive fp32 [M, T] or NULL;
+ * causal != 0: query i sees keys 0 .. i + T - M; scale_div: 0 = none (OPT scales q beforehand), else scores / scale_div
+ * (Llama: sqrt(head_dim)).  qk_params / pv_params: {x width, exponent width, exponent bias, y width, exponent width,
+ * exponent bias} of bmm_0 / bmm_1.  Neither scores nor probabilities are written anywhere: a workgroup keeps the score
+ * strip of its 16 queries in MFMA accumulators.  T <= 2048, T % 16 == 0, D % 32 == 0, D <= 128, widths <= 9, else
+ * MI355Q_E_UNSUPPORTED (callers then chain mi355q_bfp_matmul and mi355q_bfp_softmax_matmul).  Key tiles behind the
+ * horizon of a workgroup's last query are skipped (probabilities exactly 0 there). */
+size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D);
+int mi355q_bfp_attention(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                         float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
+                         const int32_t* pv_params, void* stream);
 
 /* Kernel timing for benchmarks: when enabled, mi355q_bfp_gemm_aligned brackets its MAIN kernel (the
  * int32-chain GEMM, not the correction / fallback launches) with HIP events on the launch stream.

@@ -455,6 +455,41 @@ static int bfp_matmul_impl(bool softmax, const float* mask, long long causal_off
     return launch_bfp_qmatmul(ax, ay, x, y, out, workspace, B, M, K, N, static_cast<hipStream_t>(stream), softmax, mask, causal_off);
 }
 
+size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D) {
+    if (B <= 0 || T <= 0 || D <= 0) return 0;
+    return attention_workspace_bytes(B, T, D);
+}
+
+int mi355q_bfp_attention(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                         float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
+                         const int32_t* pv_params, void* stream) {
+    if (B < 0 || M < 0 || T < 0 || D < 0) return MI355Q_E_BADARG;
+    if (B == 0 || M == 0 || D == 0) return 0;
+    if (!q || !k || !v || !out || !workspace || !qk_params || !pv_params || T == 0 || B > 65535) return MI355Q_E_BADARG;
+    if (causal && T < M) return MI355Q_E_BADARG;              // (query i sees keys 0 .. i + T - M)
+    for (int i = 0; i < 2; ++i) {
+        const int32_t* pr = i ? pv_params : qk_params;
+        if (pr[0] < 2 || pr[3] < 2 || pr[1] < 1 || pr[1] > 8 || pr[4] < 1 || pr[4] > 8) return MI355Q_E_BADARG;
+        if (pr[0] > 9 || pr[3] > 9) return MI355Q_E_UNSUPPORTED;      // a quantised value must fit bf16's 8 significant bits
+    }
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(mask)) % 16)
+        return MI355Q_E_ALIGN;
+    QuantArgs a[4] = {};
+    for (int i = 0; i < 4; ++i) {
+        const int32_t* pr = (i < 2 ? qk_params : pv_params) + 3 * (i & 1);
+        int bias = pr[2];
+        if (bias == MI355Q_BIAS_DEFAULT) bias = (1 << (pr[1] - 1)) - 1;
+        a[i].b0 = 1; a[i].b1 = 16;
+        a[i].code_bias = bias;
+        a[i].e_min = -bias;
+        a[i].e_max = (1 << pr[1]) - 1 - bias;
+        set_mantissa(a[i], pr[0] - 1);
+    }
+    return launch_bfp_attention(a[0], a[1], a[2], a[3], q, k, v, mask, out, workspace, B, M, T, D, causal ? T - M : -1,
+                                scale_div, static_cast<hipStream_t>(stream));
+}
+
 int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
                       int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
                       int32_t y_exponent_width, int32_t y_exponent_bias, void* stream) {

@@ -1,0 +1,418 @@
+// mi355q_attention.hip -- the reference's quantised attention core as ONE pass per 16 queries:
+//
+//     scores = bmm_0(Qa(q), Qb(k^T))            quantized_functions/matmul.py:146-196 (block_fp), callers
+//     scores = scores / scale                   modeling_llama.py:318-322 (OPT scales q before the product instead)
+//     scores = max(scores + mask, finfo.min)    modeling_opt.py:262-276, modeling_llama.py:323-329
+//     probs  = softmax(scores, -1)              fp32
+//     out    = bmm_1(Qc(probs), Qd(v))          modeling_opt.py:312, modeling_llama.py:341
+//
+// Neither the scores nor the probabilities [heads, T, T] exist in memory: a workgroup keeps the score strip of its 16
+// queries (16 x T fp32, T <= 2048) in MFMA accumulators -- 128 VGPRs per lane at T = 2048 -- from the first product to
+// the second.  Block structure of the four quantisers ([1,16] blocks along each operand's LAST dim, like the reference):
+//   q [.., M, D]  blocks of 16 along D  (the contraction of the first product): quantised in registers here
+//   k^T [.., D, T] blocks of 16 consecutive KEYS at a fixed d: attn_pack_k_kernel (k is taken untransposed)
+//   probs          blocks of 16 consecutive keys of a query = one 16 x 16 score tile's row: quantised in registers
+//   v [.., T, D]  blocks of 16 along D at a fixed key: attn_pack_v_kernel
+// MFMA operand roles (v_mfma_f32_16x16x32_bf16; A rows x k, B k x columns, lane (c = lane % 16, g = lane / 16) holds k
+// slots 8 g .. 8 g + 7 of row / column c and gets rows 4 g .. 4 g + 3 of column c of the result):
+//   scores tile t (16 keys):  A = K fragment (rows = keys 16 t + c, slots = d),  B = Q fragment (columns = queries)
+//        -> lane holds scores[query c][keys 16 t + 4 g + 0..3]
+//   output:  A = V fragment (rows = d, slots = keys),  B = P fragment (columns = queries, slots = keys)
+//        -> lane holds out[query c][d = 16 dt + 4 g + 0..3]: 16-byte stores.
+//   The P fragment of a lane is made of its own values of TWO score tiles a, b: slot j <-> key 16 (j < 4 ? a : b) + 4 g +
+//   (j & 3); attn_pack_v_kernel stores V with the same slot order, so no value ever changes lanes between the products.
+// Wave w owns the key tiles t = w, w + 4, w + 8, ... (interleaved: under a causal mask every wave loses the same share);
+// tiles behind the horizon of the workgroup's last query are skipped altogether (probabilities exactly 0).  A workgroup is
+// two such 4-wave groups (32 queries) that walk the same fragments in step, so that every other fragment request is an L1 hit.
+// Row statistics (max, sum of exponentials) are combined over the 4 lane groups by shuffles and over the 4 waves through
+// LDS; the partial outputs of the waves are summed through LDS in wave order (reproducible).
+// Arithmetic: products of two block_fp values (width <= 9) are exact in fp32, accumulation is fp32 like the reference's
+// GEMMs (order differs: the tolerance of the matmul tests); exp to ~1 ulp, quotient corrected once (mi355q_matmul.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi355q.h"
+#include "mi355q_internal.h"
+#include "mi355q_quant_dev.h"
+
+namespace mi355q {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int AT_MAX_T = 2048, AT_MAX_D = 128;
+
+// element of a block with shared exponent p (mi355q_matmul.hip: quant_elem_fused)
+__device__ __forceinline__ float at_quant(float x, int up, int down, float mant_max) {
+    const float m = fminf(__builtin_rintf(__builtin_ldexpf(fabsf(x) + EPS9, up)), mant_max);
+    const float q = __builtin_copysignf(__builtin_ldexpf(m, down), x);
+    return fabsf(x) <= ATOL ? x : q;
+}
+__device__ __forceinline__ float at_exp_neg(float x) {
+    x = fmaxf(x, -104.0f);
+    constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f, LN2 = 0.693147182464599609375f;
+    const float t = x * L2E_HI;
+    float r = __builtin_fmaf(x, L2E_HI, -t);
+    r = __builtin_fmaf(x, L2E_LO, r);
+    const float p = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(p, r * LN2, p);
+}
+__device__ __forceinline__ float at_div(float e, float l, float inv) {
+    const float q = e * inv;
+    return __builtin_fmaf(__builtin_fmaf(-q, l, e), inv, q);
+}
+
+// shared exponent of a block whose largest magnitude is bmax >= 0 (block_fp.py:72-73): ceil(log2(bmax)) is the fp32
+// exponent field, plus one unless bmax is a power of two -- except within 45 ulps above one (fp32 log2 rounds back onto the
+// integer there: log2_tables.inc) and for subnormals, where some lane of the wave sends everybody to the table walk.
+__device__ __forceinline__ int at_block_exponent(float bmax, const QuantArgs& a, const Lut& lut) {
+    const unsigned bits = __float_as_uint(bmax), E = bits >> 23, f = bits & 0x7FFFFFu;
+    if (__any((E == 0u && bits != 0u) || (f != 0u && f < MI355Q_LOG2_CEIL_THR_MAX))) {
+        unsigned code;
+        return block_param<FMT_BFP>(bmax != 0.f ? bmax : 1.0f, a, lut, code).p;
+    }
+    return clampi((int)E - 127 + (f != 0u ? 1 : 0), a.e_min, a.e_max);
+}
+// block_fp element for x >= 0 (probabilities) given the block's scales 2^up, 2^-up (block_fp.py:69-94 with sign = +1)
+__device__ __forceinline__ float at_quant_pos(float x, float sc_up, float sc_dn, float mant_max) {
+    const float m = fminf(__builtin_rintf((x + EPS9) * sc_up), mant_max);
+    return x <= ATOL ? x : m * sc_dn;
+}
+
+// ---- k [B, T, D] -> fragments of Qb(k^T): blocks of 16 consecutive keys at a fixed d --------------------------------
+// piece (b, t, c) = 1 KiB: lane (key = lane % 16, g = lane / 16) holds d = 32 c + 8 g .. + 7 of key 16 t + (lane % 16).
+// One workgroup = 256 / D key tiles; thread (tile, d) walks the 16 keys of its block (coalesced over d).
+__device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, uint16_t* __restrict__ tile,
+                                            const float* __restrict__ k, uint16_t* __restrict__ kf, long long T, int D,
+                                            long long NT, long long bx) {
+    // tile: [sub-tile][c][lane][8] = D * 16 values per sub-tile
+    const int tid = threadIdx.x, per = 256 / D, sub = tid / D, d = tid % D;
+    const long long b = blockIdx.y, t = bx * per + sub;
+    const int mbits = (int)__builtin_log2f(a.shift);
+    if (sub < per && t < NT) {
+        float v[16];
+        float bmax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long long key = t * 16 + e;
+            v[e] = key < T ? k[(b * T + key) * D + d] : 0.f;
+            bmax = fmaxf(bmax, fabsf(v[e]));
+        }
+        unsigned code;
+        const int p = bmax != 0.f ? block_param<FMT_BFP>(bmax, a, lut, code).p : 0;
+        const int c = d >> 5, g = (d >> 3) & 3, j = d & 7;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float q = bmax != 0.f ? at_quant(v[e], mbits - p, p - mbits, a.mant_max) : 0.f;
+            tile[sub * D * 16 + (c * 64 + e + 16 * g) * 8 + j] = (uint16_t)(pack_bf16(q, 0.f) & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+    // D * 16 * 2 bytes per sub-tile = D * 2 sixteen-byte chunks; 256 threads write 16 bytes each, twice
+    const int chunks = per * D * 2;
+    for (int ch = tid; ch < chunks; ch += 256) {
+        const int s2 = ch / (D * 2), in = ch % (D * 2);
+        const long long t2 = bx * per + s2;
+        if (t2 < NT)
+            *reinterpret_cast<uint4*>(kf + ((b * NT + t2) * (D >> 5)) * 512 + in * 8) =
+                *reinterpret_cast<const uint4*>(&tile[s2 * D * 16 + in * 8]);
+    }
+}
+
+// ---- v [B, T, D] -> fragments of Qd(v): blocks of 16 along D at a fixed key ------------------------------------------
+// piece (b, dt, pair) = 1 KiB, pair = 4 s + w <-> key tiles a = 8 s + w, b = 8 s + 4 + w (wave w's s-th pair):
+// lane (d = 16 dt + lane % 16, g = lane / 16) holds slot j <-> key 16 (j < 4 ? a : b) + 4 g + (j & 3).  Keys behind T: 0.
+// One workgroup = 128 keys (8 tiles = 4 pairs) x D; thread (key, 16-d block) quantises one block.
+__device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, uint16_t* __restrict__ stage,
+                                            const float* __restrict__ v, uint16_t* __restrict__ vf, long long T, int D,
+                                            long long NPAIR, long long bx) {
+    // stage: [dt][pair in group (w)][lane][8]
+    const int tid = threadIdx.x, DT = D >> 4;
+    const long long b = blockIdx.y, key0 = bx * 128;
+    const int mbits = (int)__builtin_log2f(a.shift);
+    for (int item = tid; item < 128 * DT; item += 256) {
+        const int kl = item / DT, dt = item % DT;         // key inside the group, 16-d block
+        const long long key = key0 + kl;
+        float x[16];
+        float bmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (key < T) f = *reinterpret_cast<const float4*>(v + (b * T + key) * D + dt * 16 + 4 * i);
+            x[4 * i] = f.x; x[4 * i + 1] = f.y; x[4 * i + 2] = f.z; x[4 * i + 3] = f.w;
+            bmax = fmaxf(bmax, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
+        }
+        unsigned code;
+        const int p = bmax != 0.f ? block_param<FMT_BFP>(bmax, a, lut, code).p : 0;
+        // key inside the 128-group: tile tl = kl / 16 (0..7) -> pair w = tl & 3, half h = tl >> 2; g = (kl & 15) / 4
+        const int tl = kl >> 4, w = tl & 3, h = tl >> 2, g = (kl & 15) >> 2, j = 4 * h + (kl & 3);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float q = bmax != 0.f ? at_quant(x[c], mbits - p, p - mbits, a.mant_max) : 0.f;
+            stage[((dt * 4 + w) * 64 + c + 16 * g) * 8 + j] = (uint16_t)(pack_bf16(q, 0.f) & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+    const long long s = bx;                                // pair group: pairs 4 s .. 4 s + 3
+    for (int ch = tid; ch < DT * 4 * 64; ch += 256) {
+        const int dt = ch / 256, w = (ch >> 6) & 3, ln = ch & 63;
+        *reinterpret_cast<uint4*>(vf + (((b * DT + dt) * NPAIR + 4 * s + w) * 64 + ln) * 8) =
+            *reinterpret_cast<const uint4*>(&stage[((dt * 4 + w) * 64 + ln) * 8]);
+    }
+}
+
+// both small operands in one launch: workgroups [0, kblocks) pack k, the rest v
+__global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, const QuantArgs av, const float* __restrict__ k,
+                                                           const float* __restrict__ v, uint16_t* __restrict__ kf,
+                                                           uint16_t* __restrict__ vf, long long T, int D, long long NT,
+                                                           long long NPAIR, int kblocks) {
+    __shared__ Lut lut;
+    __shared__ __attribute__((aligned(16))) uint16_t buf[AT_MAX_D / 16 * 4 * 512];
+    load_lut<FMT_BFP>(lut);
+    if ((int)blockIdx.x < kblocks) attn_pack_k(ak, lut, buf, k, kf, T, D, NT, blockIdx.x);
+    else attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks);
+}
+
+// ---- the attention pass ------------------------------------------------------------------------------------------------
+// NTW = score tiles per wave (8, 16, 32 <-> T <= 512, 1024, 2048), DC = D / 32.
+struct AttnArgs {
+    const float* q;
+    const uint16_t* kf;
+    const uint16_t* vf;
+    const float* mask;        // additive [M, T] or null
+    float* out;
+    long long M, T, NT, NPAIR;
+    long long causal_off;     // >= 0: query i sees keys 0 .. i + causal_off; < 0: no causal rule
+    float scale_div;          // 0: none
+    int D;
+};
+
+// QG = 16-query groups per workgroup (4 waves each).  Two groups walk the same key tiles in step: the second request for
+// a K / V fragment is served by the compute unit's L1 instead of the L2 (the kernel is L2-bandwidth bound at long T: every
+// 16 queries stream their head's whole K and V fragments).
+template <int NTW, int DC, int QG>
+__global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
+    constexpr int DT = DC * 2;
+    constexpr float FMIN = -3.4028234663852886e38f;
+    __shared__ Lut lut;
+    __shared__ float stat_[QG][4][16];
+    __shared__ f32x4 red_[QG][4][DT][64];
+    load_lut<FMT_BFP>(lut);
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, grp = wave_all >> 2;
+    float (&stat)[4][16] = stat_[grp];
+    f32x4 (&red)[4][DT][64] = red_[grp];
+    const int c16 = lane & 15, lg = lane >> 4;
+    const long long b = blockIdx.y, m0 = ((long long)blockIdx.x * QG + grp) * 16;
+    const long long qrow = min(m0 + c16, g.M - 1);
+    const int D = DC * 32;
+
+    // Q fragments: lane (query c16, g) holds d = 32 c + 8 g .. + 7; a [1,16] block = the lanes g, g ^ 1 of a chunk
+    bf16x8 qf[DC];
+    {
+        const int mb = (int)__builtin_log2f(aq.shift);
+        const float* __restrict__ qp = g.q + (b * g.M + qrow) * D;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            const float4 lo = *reinterpret_cast<const float4*>(qp + 32 * c + 8 * lg);
+            const float4 hi = *reinterpret_cast<const float4*>(qp + 32 * c + 8 * lg + 4);
+            float bmax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(lo.w))),
+                               fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fmaxf(fabsf(hi.z), fabsf(hi.w))));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
+            unsigned code;
+            const int p = block_param<FMT_BFP>(bmax != 0.f ? bmax : 1.0f, aq, lut, code).p;
+            const int up = mb - p, dn = p - mb;
+            uint4 pk;
+            pk.x = pack_bf16(at_quant(lo.x, up, dn, aq.mant_max), at_quant(lo.y, up, dn, aq.mant_max));
+            pk.y = pack_bf16(at_quant(lo.z, up, dn, aq.mant_max), at_quant(lo.w, up, dn, aq.mant_max));
+            pk.z = pack_bf16(at_quant(hi.x, up, dn, aq.mant_max), at_quant(hi.y, up, dn, aq.mant_max));
+            pk.w = pack_bf16(at_quant(hi.z, up, dn, aq.mant_max), at_quant(hi.w, up, dn, aq.mant_max));
+            qf[c] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    // tiles this workgroup needs: up to the horizon of its last query
+    const long long kvis = g.causal_off >= 0 ? qrow + g.causal_off : g.T - 1;           // this lane's query
+    long long need = g.NT;
+    if (g.causal_off >= 0) need = min(g.NT, (min(m0 + 15, g.M - 1) + g.causal_off) / 16 + 1);
+    const uint16_t* __restrict__ kfb = g.kf + b * g.NT * DC * 512;
+    const float* __restrict__ mrow = g.mask ? g.mask + qrow * g.T : nullptr;
+
+    // ---- scores of this wave's tiles, masked; row maximum.  K fragments arrive in groups of G tiles, the next group
+    //      requested before this one is used, and UNCONDITIONALLY (a tile behind the horizon re-reads the last needed one:
+    //      an L1 hit): a load inside a branch makes the compiler drain everything in flight at every tile -- one L2 round
+    //      trip per tile was 57 % of the kernel.
+    constexpr int G = DC == 1 ? 8 : (DC == 2 ? 4 : 2), NG = NTW / G;
+    f32x4 acc[NTW];
+    float mx = -INFINITY;
+    const long long tlast = need - 1;
+    uint4 kb[2][G][DC];
+    auto load_group = [&](int gi, uint4 (&dst)[G][DC]) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const long long t = min((long long)(4 * (gi * G + j) + wave), tlast);
+#pragma unroll
+            for (int c = 0; c < DC; ++c) dst[j][c] = *reinterpret_cast<const uint4*>(kfb + ((t * DC + c) * 64 + lane) * 8);
+        }
+    };
+    load_group(0, kb[0]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) load_group(gi + 1, kb[(gi + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int i = gi * G + j;
+            const long long t = 4 * i + wave;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < DC; ++c)
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[gi & 1][j][c]), qf[c], s, 0, 0, 0);
+            if (t < need) {                                // (uniform over the wave)
+                const long long key0 = t * 16 + 4 * lg;
+                if (g.scale_div != 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = s[e] / g.scale_div;
+                }
+                if (mrow) {
+                    const float4 mk = *reinterpret_cast<const float4*>(mrow + key0);
+                    s[0] = fmaxf(s[0] + mk.x, FMIN); s[1] = fmaxf(s[1] + mk.y, FMIN);
+                    s[2] = fmaxf(s[2] + mk.z, FMIN); s[3] = fmaxf(s[3] + mk.w, FMIN);
+                }
+                if (t * 16 + 15 > m0 + g.causal_off && g.causal_off >= 0) {      // (uniform: a tile on the diagonal)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key0 + e > kvis) s[e] = FMIN;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+            }
+            acc[i] = s;
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (lg == 0) stat[wave][c16] = mx;
+    __syncthreads();
+    const float row_max = fmaxf(fmaxf(stat[0][c16], stat[1][c16]), fmaxf(stat[2][c16], stat[3][c16]));
+    __syncthreads();
+    // ---- exponentials in place, row sum
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        if (4 * i + wave < need) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ex = at_exp_neg(acc[i][e] - row_max);
+                acc[i][e] = ex;
+                sm += ex;
+            }
+        }
+    }
+    sm += __shfl_xor(sm, 16);
+    sm += __shfl_xor(sm, 32);
+    if (lg == 0) stat[wave][c16] = sm;
+    __syncthreads();
+    const float row_sum = (stat[0][c16] + stat[1][c16]) + (stat[2][c16] + stat[3][c16]);
+    const float row_inv = 1.0f / row_sum;
+
+    // ---- probabilities, quantised per tile row (one [1,16] block = the 4 lanes c16 + 16 g'), times V
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int mbp = (int)__builtin_log2f(ap.shift);
+    const uint16_t* __restrict__ vfb = g.vf + b * DT * g.NPAIR * 512;
+    // (V fragments one pair ahead and unconditional, like the K fragments; a pair behind the horizon re-reads the last one)
+    const long long slast = max((tlast - wave) / 8, 0ll);
+    uint4 vb[2][DT];
+    auto load_pair = [&](int sp, uint4 (&dst)[DT]) {
+        const long long sc = min((long long)sp, slast);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            dst[dt] = *reinterpret_cast<const uint4*>(vfb + ((dt * g.NPAIR + 4 * sc + wave) * 64 + lane) * 8);
+    };
+    load_pair(0, vb[0]);
+#pragma unroll
+    for (int s = 0; s < NTW / 2; ++s) {
+        if (s + 1 < NTW / 2) load_pair(s + 1, vb[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (4 * (2 * s) + wave < need) {                   // (uniform; tiles are needed in order)
+            float pq[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * s + h;
+                float pr[4];
+                float bmax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pr[e] = 4 * i + wave < need ? at_div(acc[i][e], row_sum, row_inv) : 0.f;
+                    bmax = fmaxf(bmax, pr[e]);
+                }
+                bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
+                bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
+                const int p = at_block_exponent(bmax, ap, lut);
+                const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pq[4 * h + e] = at_quant_pos(pr[e], sc_up, sc_dn, ap.mant_max);
+            }
+            uint4 pk;
+            pk.x = pack_bf16(pq[0], pq[1]); pk.y = pack_bf16(pq[2], pq[3]);
+            pk.z = pack_bf16(pq[4], pq[5]); pk.w = pack_bf16(pq[6], pq[7]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vb[s & 1][dt]), pf, o[dt], 0, 0, 0);
+        }
+    }
+    // ---- sum the four waves' partial outputs in wave order, store
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) red[wave][dt][lane] = o[dt];
+    __syncthreads();
+    const long long m = m0 + c16;
+    for (int dt = wave; dt < DT; dt += 4) {
+        f32x4 sum = red[0][dt][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum += red[w][dt][lane];
+        if (m < g.M)
+            *reinterpret_cast<float4*>(g.out + (b * g.M + m) * D + 16 * dt + 4 * lg) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    }
+}
+
+size_t attention_workspace_bytes(long long B, long long T, long long D) {
+    const long long NT = (T + 15) / 16, NPAIR = ((T + 127) / 128) * 4;
+    return (size_t)B * (size_t)(NT * (D / 32) * 1024 + (D / 16) * NPAIR * 1024) + 256;
+}
+
+int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
+                         const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
+                         long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st) {
+    if (T > AT_MAX_T || D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
+    const long long NT = T / 16, NPAIR = ((T + 127) / 128) * 4;
+    uint16_t* kf = static_cast<uint16_t*>(workspace);
+    uint16_t* vf = kf + (size_t)B * NT * (D / 32) * 512;
+    const int per = 256 / (int)D;
+    const int kblocks = (int)((NT + per - 1) / per);
+    hipLaunchKernelGGL(attn_pack_kv_kernel, dim3((unsigned)(kblocks + NPAIR / 4), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf, T,
+                       (int)D, NT, NPAIR, kblocks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D};
+    // two 16-query groups per workgroup (measured at T = 2048: 70 vs 101 us at 12 heads x 64, 235 vs 342 us at 32 x 128)
+    const int qg = 2;
+    const dim3 grid((unsigned)(((M + 15) / 16 + qg - 1) / qg), (unsigned)B);
+    const int ntw = T <= 512 ? 8 : (T <= 1024 ? 16 : 32);
+#define MI355Q_ATTN(NTW_, DC_) hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 2>), grid, 512, 0, st, aq, ap, g)
+#define MI355Q_ATTN_D(NTW_)                                     \
+    switch (D / 32) {                                          \
+        case 1: MI355Q_ATTN(NTW_, 1); break;                   \
+        case 2: MI355Q_ATTN(NTW_, 2); break;                   \
+        case 3: MI355Q_ATTN(NTW_, 3); break;                   \
+        default: MI355Q_ATTN(NTW_, 4); break;                  \
+    }
+    if (ntw == 8) { MI355Q_ATTN_D(8) }
+    else if (ntw == 16) { MI355Q_ATTN_D(16) }
+    else { MI355Q_ATTN_D(32) }
+#undef MI355Q_ATTN_D
+#undef MI355Q_ATTN
+    return (int)hipGetLastError();
+}
+
+}  // namespace mi355q

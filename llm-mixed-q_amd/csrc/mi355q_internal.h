@@ -35,6 +35,10 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
                        long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false,
                        const float* mask = nullptr, long long causal_off = -1);
+size_t attention_workspace_bytes(long long B, long long T, long long D);
+int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
+                         const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
+                         long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st);
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {

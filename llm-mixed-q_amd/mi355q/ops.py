@@ -675,6 +675,51 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
     return out
 
 
+_ATTN_WS: dict = {}
+ATTENTION_MAX_KEYS, ATTENTION_MAX_HEAD_DIM = 2048, 128
+
+
+def bfp_attention_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, widths) -> bool:
+    """shapes / widths the one-pass attention kernel takes (include/mi355q.h, mi355q_bfp_attention)"""
+    return (q.is_cuda and k.is_cuda and v.is_cuda and q.dtype == k.dtype == v.dtype == torch.float32 and q.ndim == 3
+            and k.ndim == 3 and v.shape == k.shape and q.shape[0] == k.shape[0] and q.shape[2] == k.shape[2]
+            and 0 < q.shape[0] <= 65535 and 0 < k.shape[1] <= ATTENTION_MAX_KEYS and k.shape[1] % 16 == 0 and q.shape[1] > 0
+            and q.shape[2] % 32 == 0 and 0 < q.shape[2] <= ATTENTION_MAX_HEAD_DIM and all(2 <= int(w) <= 9 for w in widths))
+
+
+def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, pv_params, *, mask: torch.Tensor = None,
+                  causal: bool = False, scale_div: float = None) -> torch.Tensor:
+    """out[b] = Qc(softmax(max(Qa(q[b]) @ Qb(k[b]^T) [/ scale_div] + mask, finfo.min))) @ Qd(v[b]) for q [B, M, D], k and v
+    [B, T, D] fp32 (k untransposed), block_fp [1,16] blocks along each operand's last dim as the reference's two products
+    apply them (matmul.py:146-196); neither scores nor probabilities are written.  qk_params / pv_params:
+    (x width, x exponent width, x exponent bias, y width, y exponent width, y exponent bias) of bmm_0 / bmm_1."""
+    import ctypes
+    _require_device(q, "bfp_attention")
+    assert bfp_attention_supported(q, k, v, (qk_params[0], qk_params[3], pv_params[0], pv_params[3]))
+    B, M, D = q.shape
+    T = k.shape[1]
+    qc, kc, vc = q.contiguous(), k.contiguous(), v.contiguous()
+    out = torch.empty(B, M, D, dtype=torch.float32, device=q.device)
+    lib = _lib.load_library()
+    sp = _stream_ptr(q.device)
+    key = (q.device.index, sp, B, T, D)
+    ws = _ATTN_WS.get(key)
+    if ws is None:
+        if len(_ATTN_WS) > 16:
+            _ATTN_WS.clear()
+        ws = _ATTN_WS[key] = torch.empty(lib.mi355q_bfp_attention_workspace_bytes(B, T, D), dtype=torch.uint8, device=q.device)
+    if mask is not None:
+        assert mask.shape == (M, T) and mask.dtype == torch.float32 and mask.is_contiguous() and mask.device == q.device
+    pa = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(qk_params)])
+    pb = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(pv_params)])
+    with _on_device(q.device):
+        rc = lib.mi355q_bfp_attention(_ptr(qc), _ptr(kc), _ptr(vc), _ptr(mask), int(bool(causal)),
+                                      float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(ws), B, M, T, D,
+                                      ctypes.addressof(pa), ctypes.addressof(pb), sp)
+    _lib.check(rc, "mi355q_bfp_attention")
+    return out
+
+
 def set_gemm_variant(variant: int) -> int:
     return _lib.load_library().mi355q_bfp_gemm_set_variant(int(variant))
 

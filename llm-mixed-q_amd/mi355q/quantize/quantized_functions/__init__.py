@@ -115,6 +115,59 @@ def _make_softmax(style):
     return f
 
 
+def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, scale_div=None):
+    """The reference's quantised attention core as one call (modeling_opt.py:246-312, modeling_llama.py:309-344):
+
+        w = bmm_0(q, k^T)  [w = w / scale_div]  w = max(w + mask, finfo.min)  p = softmax(w, -1)  out = bmm_1(p, v)
+
+    `q` [..., T_q, hd], `k`, `v` [..., T_k, hd] (k NOT transposed); `config_qk` / `config_pv` are the configs of the two
+    products (OPT: bmm_0 / bmm_1, Llama: matmul_0 / matmul_1); `mask` additive [T_q, T_k] (or broadcastable to it over the
+    leading dims), `causal=True` stands for the causal mask without reading one; `scale_div`: Llama's sqrt(head_dim).  On
+    the HIP path neither scores nor probabilities are ever written (ops.bfp_attention); shapes it does not take, other
+    arithmetics and autograd fall back to the same steps through the registry's own functions.  An addition to the
+    registry (key "attention")."""
+    from ... import ops
+    m2 = None
+    if mask is not None:
+        m2 = mask.reshape(mask.shape[-2:]) if mask.numel() == mask.shape[-2] * mask.shape[-1] else None
+    both_fp = config_qk.get("name") == "block_fp" and config_pv.get("name") == "block_fp"
+    fused_ok = (both_fp and not config_qk.get("bypass", False) and not config_pv.get("bypass", False)
+                and config_qk.get("mi355q_fused_matmul", True) and config_pv.get("mi355q_fused_matmul", True)
+                and (mask is None or m2 is not None) and q.ndim == k.ndim == v.ndim and q.ndim >= 3
+                and q.shape[:-2] == k.shape[:-2] == v.shape[:-2]
+                and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)))
+    if fused_ok:
+        for c in (config_qk, config_pv):
+            for key in _KEYS["block_fp"]:
+                c[f"data_in_{key}"], c[f"weight_{key}"]
+        q3, k3, v3 = (t.reshape(-1, *t.shape[-2:]) for t in (q, k, v))
+        blocks_ok = all(ops.resolve_blocking(list(shape), bs, True)[3:] == (1, 16) for shape, bs in (
+            (q3.shape, config_qk["data_in_block_size"]), ((k3.shape[0], k3.shape[2], k3.shape[1]), config_qk["weight_block_size"]),
+            ((q3.shape[0], q3.shape[1], k3.shape[1]), config_pv["data_in_block_size"]), (v3.shape, config_pv["weight_block_size"])))
+        widths = (config_qk["data_in_width"], config_qk["weight_width"], config_pv["data_in_width"], config_pv["weight_width"])
+        if blocks_ok and ops.bfp_attention_supported(q3, k3, v3, widths) and (not causal or k3.shape[1] >= q3.shape[1]):
+            par = lambda c: (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"], c["weight_width"],
+                             c["weight_exponent_width"], c["weight_exponent_bias"])
+            out = ops.bfp_attention(q3, k3, v3, par(config_qk), par(config_pv), mask=None if m2 is None else m2.contiguous(),
+                                    causal=causal, scale_div=scale_div)
+            return out.reshape(*q.shape)
+    style = "bmm" if q.ndim == 3 else "matmul"
+    w = QUANTIZED_FUNC_MAP[style][config_qk["name"]](q, k.transpose(-1, -2), config=config_qk)
+    if scale_div:
+        w = w / scale_div
+    if config_pv["name"] == "block_fp":
+        return QUANTIZED_FUNC_MAP["softmax_" + style]["block_fp"](w, v, config_pv, mask=mask, causal=causal)
+    if causal:
+        tq, tk = w.shape[-2], w.shape[-1]
+        w = w + torch.full((tq, tk), torch.finfo(w.dtype).min, device=w.device).triu(1 + tk - tq)
+    if mask is not None:
+        w = w + mask
+    if causal or mask is not None:
+        w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min))
+    p = torch.nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    return QUANTIZED_FUNC_MAP[style][config_pv["name"]](p, v, config=config_pv)
+
+
 def _make(arith, style):
     def f(x, y, config):
         return _generic_matmul(x, y, config, arith, style)
@@ -176,6 +229,7 @@ QUANTIZED_FUNC_MAP = {
     },
     "softmax_matmul": {"block_fp": softmax_matmul_block_fp},
     "softmax_bmm": {"block_fp": softmax_bmm_block_fp},
+    "attention": {"block_fp": attention_block_fp},
     "rotary_positional_encoding": {
         "block_fp": apply_rotary_pos_emb_block_fp, "block_log": apply_rotary_pos_emb_block_log,
         "block_minifloat": apply_rotary_pos_emb_block_minifloat, "integer": apply_rotary_pos_emb_integer,

@@ -1,0 +1,143 @@
+"""The one-pass attention kernel (mi355q_bfp_attention behind the registry's "attention" function) against the oracle's
+restatement of the reference's steps -- bmm_0 (matmul.py:146-196), scale, mask + clamp, softmax, bmm_1
+(modeling_opt.py:246-312, modeling_llama.py:309-344) -- and against the step-by-step route on the GPU."""
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "llm-mixed-q_amd"))
+sys.path.insert(0, str(ROOT))
+
+pytestmark = pytest.mark.gpu
+FMIN = np.finfo(np.float32).min
+
+
+def _cfg(width, **extra):
+    return dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=width, data_in_exponent_width=8,
+                data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=width, weight_exponent_width=8,
+                weight_exponent_bias=127, weight_block_size=[1, 16], **extra)
+
+
+def _oracle(q, k, v, c0, c1, mask=None, causal=False, scale_div=None):
+    from oracle import np_oracle as O
+    w = O.matmul_quantized(q, np.swapaxes(k, -1, -2), c0)
+    if scale_div:
+        w = (w / np.float32(scale_div)).astype(np.float32)
+    tq, tk = w.shape[-2:]
+    m = np.zeros((tq, tk), np.float32)
+    if causal:
+        m = np.triu(np.full((tq, tk), FMIN, np.float32), 1 + tk - tq)
+    if mask is not None:
+        with np.errstate(over="ignore"):
+            m = np.maximum(m + mask, FMIN)
+    if causal or mask is not None:
+        with np.errstate(over="ignore"):
+            w = np.maximum(w + m, FMIN)
+    e = np.exp((w - w.max(-1, keepdims=True)).astype(np.float64))
+    p = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    return O.matmul_quantized(p, v, c1)
+
+
+def _inputs(B, M, T, hd, seed):
+    r = np.random.default_rng(seed)
+    q = (r.normal(size=(B, M, hd)) * np.exp(r.normal(size=(B, M, 1)) * 0.5) * 0.7).astype(np.float32)
+    k = (r.normal(size=(B, T, hd)) * np.exp(r.normal(size=(B, 1, hd)) * 0.5)).astype(np.float32)
+    v = r.normal(size=(B, T, hd)).astype(np.float32)
+    return q, k, v
+
+
+def _check(out, ref):
+    scale = np.abs(ref).max()
+    # (a score or probability one ulp apart may round to the next mantissa step of one of T terms of a row)
+    assert np.abs(out - ref).max() <= 3e-3 * scale, (np.abs(out - ref).max(), scale)
+    assert np.abs(out - ref).mean() <= 3e-5 * scale, (np.abs(out - ref).mean(), scale)
+
+
+@pytest.mark.parametrize("B,T,hd,width,mode", [
+    (6, 320, 64, 6, "causal"), (3, 2048, 128, 6, "causal_scaled"), (4, 1008, 64, 6, "mask"), (2, 640, 64, 4, "both"),
+    (3, 512, 32, 6, "plain"), (2, 1024, 96, 5, "causal"), (5, 16, 64, 6, "causal"), (2, 2048, 64, 6, "plain")])
+def test_attention_one_pass_vs_oracle(B, T, hd, width, mode):
+    import torch
+    import mi355q.quantize as Q
+    c0, c1 = _cfg(width), _cfg(width)
+    q, k, v = _inputs(B, T, T, hd, seed=T + hd)
+    r = np.random.default_rng(T)
+    add_mask = (r.normal(size=(T, T)) * 0.5).astype(np.float32)
+    add_mask[:, ::7] = FMIN
+    add_mask[:, 0] = 0
+    kw_np = {"causal": dict(causal=True), "causal_scaled": dict(causal=True, scale_div=math.sqrt(hd)), "mask": dict(mask=add_mask),
+             "both": dict(mask=add_mask, causal=True), "plain": {}}[mode]
+    ref = _oracle(q, k, v, c0, c1, **kw_np)
+    dev = "cuda:0"
+    kw = dict(kw_np)
+    if "mask" in kw:
+        kw["mask"] = torch.from_numpy(add_mask).to(dev)
+    qt, kt, vt = (torch.from_numpy(t).to(dev) for t in (q, k, v))
+    out = Q.get_quantized_func("attention", c1)(qt, kt, vt, c0, c1, **kw)
+    _check(out.cpu().numpy(), ref)
+    # the step-by-step route through the registry's own functions
+    steps = Q.get_quantized_func("attention", c1)(qt, kt, vt, dict(c0, mi355q_fused_matmul=False), dict(c1, mi355q_fused_matmul=False), **kw)
+    _check(steps.cpu().numpy(), ref)
+    assert (out - steps).abs().max().item() <= 3e-3 * np.abs(ref).max()
+
+
+def test_attention_mixed_widths_4d_and_fewer_queries():
+    """Llama-style 4-D operands, W4 first product / W6 second, fewer queries than keys under the causal rule (query i sees
+    keys 0 .. i + T_k - T_q)"""
+    import torch
+    import mi355q.quantize as Q
+    c0, c1 = _cfg(4), _cfg(6)
+    B, H, M, T, hd = 2, 3, 96, 384, 64
+    q, k, v = _inputs(B * H, M, T, hd, seed=9)
+    ref = _oracle(q, k, v, c0, c1, causal=True, scale_div=8.0).reshape(B, H, M, hd)
+    t4 = lambda a, n: torch.from_numpy(a).to("cuda:0").reshape(B, H, n, hd)
+    out = Q.get_quantized_func("attention", c1)(t4(q, M), t4(k, T), t4(v, T), c0, c1, causal=True, scale_div=8.0)
+    assert out.shape == (B, H, M, hd)
+    _check(out.cpu().numpy(), ref)
+
+
+def test_attention_falls_back_outside_the_kernel_shapes():
+    """T % 16 != 0 and T > 2048: the same steps through bmm / softmax_bmm, same answer"""
+    import torch
+    import mi355q.quantize as Q
+    c0, c1 = _cfg(6), _cfg(6)
+    for B, T, hd in ((3, 100, 64), (1, 2304, 64)):
+        q, k, v = _inputs(B, T, T, hd, seed=T)
+        ref = _oracle(q, k, v, c0, c1, causal=True)
+        qt, kt, vt = (torch.from_numpy(t).to("cuda:0") for t in (q, k, v))
+        out = Q.get_quantized_func("attention", c1)(qt, kt, vt, c0, c1, causal=True)
+        _check(out.cpu().numpy(), ref)
+
+
+def test_attention_model_parity():
+    """tiny OPT / Llama through the harness with config["mi355q_fused_attention"]: logits against the step-by-step model"""
+    import torch
+    from mi355q.harness import (TinyLlamaConfig, TinyLlamaForCausalLM, TinyOPTConfig, TinyOPTForCausalLM,
+                                expand_llama_quant_config, expand_quant_config)
+    base = dict(_cfg(6), bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+    for family in ("opt", "llama"):
+        outs = []
+        for fused in (False, True):
+            torch.manual_seed(1)
+            qc = dict(base, mi355q_fused_attention=fused)
+            if family == "opt":
+                cfg = TinyOPTConfig(vocab_size=512, hidden_size=256, ffn_dim=1024, num_layers=2, num_heads=4, max_positions=512)
+                m = TinyOPTForCausalLM(cfg, expand_quant_config(qc, cfg.num_layers))
+            else:
+                cfg = TinyLlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=512)
+                m = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(qc, cfg.num_layers))
+            with torch.no_grad():
+                for n, p in m.named_parameters():
+                    if p.ndim == 2 and "embed" not in n:
+                        p.mul_(3.0)
+            m = m.to("cuda:0").eval()
+            ids = torch.randint(0, cfg.vocab_size, (1, 384), generator=torch.Generator().manual_seed(2)).to("cuda:0")
+            with torch.no_grad():
+                outs.append(m(ids, labels=ids))
+        (l0, s0), (l1, s1) = outs
+        assert abs(float(s0) - float(s1)) <= 2e-3, (family, float(s0), float(s1))
+        assert (l0 - l1).abs().max().item() <= 2e-2 * l0.abs().max().item()

@@ -91,7 +91,7 @@ def test_registry_keys_match_reference():
     assert set(Q.QUANTIZED_MODULE_MAP) == {"linear"} and set(Q.QUANTIZED_MODULE_MAP["linear"]) == names
     # the reference's three ops, plus this build's two additions (the attention's softmax stage folded into the product)
     ref_ops = {"matmul", "bmm", "rotary_positional_encoding"}
-    assert set(Q.QUANTIZED_FUNC_MAP) == ref_ops | {"softmax_matmul", "softmax_bmm"}
+    assert set(Q.QUANTIZED_FUNC_MAP) == ref_ops | {"softmax_matmul", "softmax_bmm", "attention"}
     for name in ref_ops:
         assert set(Q.QUANTIZED_FUNC_MAP[name]) == names
     assert set(Q.QUANTIZED_FUNC_MAP["softmax_bmm"]) == {"block_fp"}

@@ -43,6 +43,28 @@ int main(int argc, char** argv) {
         std::printf("step_driver matmul: %d calls, out[0..3] = %g %g %g %g\n", steps, h[0], h[1], h[2], h[3]);
         return 0;
     }
+    if (argc > 2 && std::string(argv[2]) == "attention") {   // the one-pass attention core: [heads] [head_dim], T = 2048, causal
+        const int64_t B = argc > 3 ? std::atoi(argv[3]) : 12, T = 2048, D = argc > 4 ? std::atoi(argv[4]) : 64;
+        std::mt19937 gen(1);
+        std::normal_distribution<float> nd(0.f, 1.f);
+        std::vector<float> hq(B * T * D), hk(B * T * D), hv(B * T * D);
+        for (auto& v : hq) v = nd(gen);
+        for (auto& v : hk) v = nd(gen);
+        for (auto& v : hv) v = nd(gen);
+        float *q = dalloc<float>(hq.size()), *k = dalloc<float>(hk.size()), *v = dalloc<float>(hv.size()), *out = dalloc<float>(hq.size());
+        void* ws = dalloc<unsigned char>(mi355q_bfp_attention_workspace_bytes(B, T, D));
+        HIP_OK(hipMemcpy(q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(k, hk.data(), hk.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(v, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+        const int32_t par[6] = {6, 8, 127, 6, 8, 127};
+        for (int s = 0; s < steps; ++s)
+            Q_OK(mi355q_bfp_attention(q, k, v, nullptr, 1, D == 128 ? std::sqrt(128.f) : 0.f, out, ws, B, T, T, D, par, par, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        float h[4];
+        HIP_OK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost));
+        std::printf("step_driver attention [%lld, %lld, %lld]: %d calls, out[0..3] = %g %g %g %g\n", (long long)B, (long long)T, (long long)D, steps, h[0], h[1], h[2], h[3]);
+        return 0;
+    }
     const int64_t M = 4096, N = 4096, K = 4096;
     std::mt19937 gen(0);
     std::normal_distribution<float> nd(0.f, 1.f);

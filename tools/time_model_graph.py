@@ -8,7 +8,7 @@ from mi355q.harness import (TinyOPTConfig, TinyOPTForCausalLM, TinyLlamaConfig, 
 W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16],
-            mi355q_fused_softmax=True)
+            mi355q_fused_softmax=True, mi355q_fused_attention=(len(sys.argv) > 1 and sys.argv[1] == "one_pass"))
 dev = torch.device("cuda:0")
 for family in ("opt", "llama"):
     torch.manual_seed(0)
@@ -37,5 +37,5 @@ for family in ("opt", "llama"):
     fwd = GraphedForward(lambda t: model(t)[0], (ids,))
     same = bool(torch.equal(fwd(ids), ref))
     t_graph = timed(lambda: fwd(ids))
-    print(json.dumps({"model": f"{'OPT-125m' if family == 'opt' else 'Llama-160m'} width, 12 layers, T=2048, W6A6, softmax folded",
+    print(json.dumps({"model": f"{'OPT-125m' if family == 'opt' else 'Llama-160m'} width, 12 layers, T=2048, W6A6, " + ("one-pass attention" if W6A6["mi355q_fused_attention"] else "softmax folded into P V"),
                       "eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3), "graph_equals_eager": same}), flush=True)
