@@ -17,10 +17,13 @@ layers = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 family = sys.argv[3] if len(sys.argv) > 3 else "opt"
 fused = len(sys.argv) > 4 and sys.argv[4] == "fused"        # softmax stage folded into the P V product (causal)
+one_pass = len(sys.argv) > 4 and sys.argv[4] == "one_pass"  # both products, mask and softmax in one kernel
 W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
-if fused:
+if one_pass:
+    W6A6_model = dict(W6A6, mi355q_fused_attention=True)
+elif fused:
     W6A6_model = dict(W6A6, mi355q_fused_softmax=True)
 else:
     W6A6_model = W6A6
@@ -46,7 +49,7 @@ with torch.no_grad():
     loss = float(model(ids.to(dev), labels=ids.to(dev))[1])
 modes = sorted({m._align_mode + ({120: "", -1: "+blockwise"}.get(getattr(m, "_x_cap", 120), "+post-pass") if m._align_mode == "rows" else "")
                 for m in model.modules() if hasattr(m, "_align_mode") and m._align_mode})
-out = {"shape": f"{'Llama-160m' if family == 'llama' else 'OPT-125m'} width, {layers} layers, T={T}" + (", softmax stage folded" if fused else ""), "gpu_loss": loss, "oracle_loss": ref, "abs_diff": abs(loss - ref),
+out = {"shape": f"{'Llama-160m' if family == 'llama' else 'OPT-125m'} width, {layers} layers, T={T}" + (", softmax stage folded" if fused else ", one-pass attention" if one_pass else ""), "gpu_loss": loss, "oracle_loss": ref, "abs_diff": abs(loss - ref),
        "ppl_gpu": round(math.exp(loss), 3), "ppl_oracle": round(math.exp(ref), 3), "oracle_seconds": round(t_cpu, 1),
        "linear_align_modes": modes}
 # GPU timing at the perplexity-run shape (B=1, T=2048)
