@@ -300,8 +300,10 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
         const int n = cx + cw;
-        // (split-K: only the tile's last arriver adds exceptions, so their vectors are formed behind the K loop)
-        mode = n == 0 ? 0 : (n <= V8_FAST_MAX && S == 1 ? 1 : (n <= V8_SLOW_MAX ? 2 : 3));
+        // (split-K: only the tile's last arriver adds the exceptions, but which slice that will be is not known here:
+        // every slice forms the vectors in its prologue, where the gathers hide behind the first stages -- forming them
+        // behind the K loop instead cost the reducer 5-8 us of exposed round trips)
+        mode = n == 0 ? 0 : (n <= V8_FAST_MAX ? 1 : (n <= V8_SLOW_MAX ? 2 : 3));
         if (mode) {
             rowslot[tid & 255] = -1;                        // tid < 256: rowslot, else colslot (contiguous)
             if (tid >= 256) colslot[tid & 255] = -1;
@@ -745,13 +747,18 @@ static SplitWorkspace* split_workspace(hipStream_t st, size_t slab_bytes, int nt
 }
 // slices per tile for an under-filled grid: the largest S with tiles * S <= 256 (one workgroup per compute unit), whole
 // and, where the schedule needs it, even numbers of K-steps per slice, at least 8 of them
-static int choose_splits(long long tiles, int nsteps_all, bool need_even) {
+// `min_steps`: K-steps a slice must keep.  Splitting costs the slabs' round trip through memory (S x the output, written
+// and read), the agent-scope release / acquire and, in the flavour that carries exception lists, every slice's own
+// bookkeeping prologue: measured 16-22 us at 128 tiles x 2 slices, so a row-scale int8 product is split only while a
+// slice keeps 32 steps (2048^3: 27.7 us unsplit, 38.3 split in two; 4096 x 4096 x 512: 46.7 unsplit, 40.2 in two)
+static int choose_splits(long long tiles, int nsteps_all, bool need_even, int min_steps = 8) {
     static const int forced = getenv("MI355Q_V8_SPLITS") ? atoi(getenv("MI355Q_V8_SPLITS")) : 0;
+    if (forced) min_steps = 8;
     int best = 1;
     for (int S = 2; S <= 16; ++S) {
         if (nsteps_all % S) continue;
         const int steps = nsteps_all / S;
-        if (steps < 8) break;
+        if (steps < min_steps) break;
         if (need_even && (steps & 1)) continue;
         if (forced ? S > forced : tiles * S > 256) break;
         best = S;
@@ -774,7 +781,7 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     unsigned tiles = (unsigned)(small ? t128 : t256);
     {   // under-filled grid: split K (the 128-row tile's schedule takes any slice length, the 256-row one even ones)
         static const int sched_ = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
-        const int S = choose_splits(tiles, (int)(a.K >> 6), !small && sched_ == 2);
+        const int S = choose_splits(tiles, (int)(a.K >> 6), !small && sched_ == 2, xlist && wlist ? 32 : 8);
         a.splits = 1;
         if (S > 1) {
             SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * (small ? 128 : 256) * 256 * 4, (int)tiles);
