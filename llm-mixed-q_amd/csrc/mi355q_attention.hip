@@ -62,6 +62,26 @@ __device__ __forceinline__ float at_div(float e, float l, float inv) {
     return __builtin_fmaf(__builtin_fmaf(-q, l, e), inv, q);
 }
 
+// max / sum over the four lanes c16, c16 + 16, c16 + 32, c16 + 48 (one query's values of a score tile), on the VALU:
+// v_permlane32_swap / v_permlane16_swap of a register with itself leave {own, partner} in the result pair for every lane
+// (gfx950; no LDS crossbar round trip as with ds_bpermute, whose latency two waves per SIMD cannot hide)
+__device__ __forceinline__ float at_max4(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float at_sum4(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float at_max2_16(float x) {       // lanes l, l ^ 16
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // shared exponent of a block whose largest magnitude is bmax >= 0 (block_fp.py:72-73): ceil(log2(bmax)) is the fp32
 // exponent field, plus one unless bmax is a power of two -- except within 45 ulps above one (fp32 log2 rounds back onto the
 // integer there: log2_tables.inc) and for subnormals, where some lane of the wave sends everybody to the table walk.
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
             const float4 hi = *reinterpret_cast<const float4*>(qp + 32 * c + 8 * lg + 4);
             float bmax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(lo.w))),
                                fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fmaxf(fabsf(hi.z), fabsf(hi.w))));
-            bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
+            bmax = at_max2_16(bmax);
             unsigned code;
             const int p = block_param<FMT_BFP>(bmax != 0.f ? bmax : 1.0f, aq, lut, code).p;
             const int up = mb - p, dn = p - mb;
@@ -288,8 +308,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
             acc[i] = s;
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = at_max4(mx);
     if (lg == 0) stat[wave][c16] = mx;
     __syncthreads();
     const float row_max = fmaxf(fmaxf(stat[0][c16], stat[1][c16]), fmaxf(stat[2][c16], stat[3][c16]));
@@ -307,8 +326,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
             }
         }
     }
-    sm += __shfl_xor(sm, 16);
-    sm += __shfl_xor(sm, 32);
+    sm = at_sum4(sm);
     if (lg == 0) stat[wave][c16] = sm;
     __syncthreads();
     const float row_sum = (stat[0][c16] + stat[1][c16]) + (stat[2][c16] + stat[3][c16]);
@@ -346,8 +364,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
                     pr[e] = 4 * i + wave < need ? at_div(acc[i][e], row_sum, row_inv) : 0.f;
                     bmax = fmaxf(bmax, pr[e]);
                 }
-                bmax = fmaxf(bmax, __shfl_xor(bmax, 16));
-                bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
+                bmax = at_max4(bmax);
                 const int p = at_block_exponent(bmax, ap, lut);
                 const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp);
 #pragma unroll
