@@ -197,6 +197,12 @@ def main():
                     help="exponent alignment of the packed operands: whole rows (row-scale int8 GEMM) or 256-value groups")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: whatever native libraries print there (RCCL's "Librccl path" banner
+    # arrives at process exit, behind the JSON line) goes to stderr instead
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from mi355q import ops
@@ -221,7 +227,8 @@ def main():
     if args.workload == "quantizers":
         out = quantizer_workload(torch, ops, args, device)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            result_out.write(json.dumps(out) + "\n")
+            result_out.flush()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -314,7 +321,8 @@ def main():
             failed = not out["verify"]["ok"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch)
-        print(json.dumps(out), flush=True)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if world > 1 or force_dist:
         dist.destroy_process_group()
     if failed:

@@ -395,9 +395,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, 0, 0, st);
         if (variant == 8) return launch_bfp_gemm_v8(a, x->gscale, w->gscale, nullptr, nullptr, 0, st);
         // ONE launch: the row-scale GEMM forms the correction vectors of its tile's exception blocks itself and adds them
-        // in its epilogue; if an exception bucket overflowed anywhere its tiles leave at once and the fallback workgroups
-        // that ride behind them -- which leave at once otherwise -- form the whole product blockwise-exact (decided on
-        // the device)
+        // in its epilogue; if an exception bucket overflowed anywhere its workgroups form the whole product
+        // blockwise-exact between them instead (decided on the device)
         hipEvent_t te = g_timing.begin(st);
         int rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st, x->rowflag, w->rowflag);
         g_timing.end(te, st);

@@ -49,7 +49,7 @@ constexpr int V8_SXT = V8_MAP + 2 * 256 * 4, V8_SWT = V8_SXT + 1024, V8_BIAS = V
 constexpr int V8_FLAGS = V8_BIAS + 1024;             // a few flag words
 constexpr int V8_OVF = V8_FLAGS + 256;                // LDS copies of the two lists' header words (word 0 = overflow)
 constexpr int V8_CORR = V8_OVF + 512;
-constexpr int V8_LDS = 159 * 1024;            // (the blockwise body of the fallback workgroups keeps a few words of its own)
+constexpr int V8_LDS = 159 * 1024;            // (the blockwise fallback body keeps a few words of its own)
 constexpr int V8_FAST_MAX = (V8_LDS - V8_CORR) / 1024;      // entries (x + w) whose vectors fit beside the stages
 constexpr int V8_SLOW_MAX = V8_S * V8_STAGE / 1024;         // ... that fit the stage area after the K loop
 static_assert(ROW_BUCKET_WORDS * 4 <= V8_BUCKET, "bucket copy");
@@ -90,11 +90,11 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
     }
 }
 
-// Workgroups behind the tiles (blockIdx >= number of tiles) are the FALLBACK of the launch: they leave at once unless an
-// exception bucket overflowed somewhere (a row that could not store its exception blocks keeps its own exponents,
-// rowflag 0); then the tile workgroups have left without writing and these form the whole product with the
-// blockwise-exact body (128 x 128 tiles, one 256-thread team per workgroup) and add each tile's exception blocks right
-// after its stores.  One launch either way: no second kernel on the stream for a case that hardly ever happens.
+// The FALLBACK of the launch: when an exception bucket overflowed somewhere (a row that could not store its exception
+// blocks keeps its own exponents, rowflag 0) the row-scale product does not apply; the launch's workgroups then share the
+// whole product with the blockwise-exact body (128 x 128 tiles, one 256-thread team per workgroup) and add each tile's
+// exception blocks right after its stores.  One launch either way, and no extra workgroups in the common case (256 of
+// them used to ride behind the tiles and leave at once: their dispatch alone cost the launch 1-2 us).
 __device__ __forceinline__ void v8_fallback(const GemmArgs& a, const uint8_t* __restrict__ xf, const uint8_t* __restrict__ wf,
                                          const int* __restrict__ xlist, const int* __restrict__ wlist, unsigned char* smem,
                                          int wg, int nwg) {
@@ -112,7 +112,6 @@ __device__ __forceinline__ void v8_fallback(const GemmArgs& a, const uint8_t* __
         __syncthreads();
     }
 }
-constexpr int V8_FALLBACK_WGS = 256;
 
 // the two arithmetics of the tile kernel: int8 mantissas -> int32 (row-scale block-fp GEMM), or bf16 values -> fp32
 // (operands that keep every block's own exponent: a block_fp value of width <= 9 is exact in bf16 and a product of two
@@ -147,10 +146,6 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
     const int S = a.splits > 1 ? a.splits : 1;                 // workgroups per tile (split-K)
     const int nwg = tiles_m * tiles_n * S;
-    if (FIXMODE && (int)blockIdx.x >= nwg) {
-        v8_fallback(a, xf, wf, xlist, wlist, smem, (int)blockIdx.x - nwg, (int)gridDim.x - nwg);
-        return;
-    }
     int pid;
     {
         const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
@@ -290,11 +285,14 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         if (TI == 4 && nsteps > 2) V8_WAIT(3 * LPW); else if (nsteps > 1 && !LATE_STAGE1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
         if (FIXMODE_ == 3) pst[1] = __builtin_amdgcn_s_memrealtime();
-        // a bucket overflowed somewhere: the launch in front of this one formed the product, this one must not write
-        // (uniform over the grid).  The operand loads in flight land in LDS only; nothing else is pending.
+        // a bucket overflowed somewhere (uniform over the grid): the row-scale product does not apply; the workgroups of
+        // this launch share the blockwise-exact product instead (v8_fallback).  The operand loads in flight land in LDS
+        // only; nothing else is pending.
         const int* ovf = reinterpret_cast<const int*>(smem + V8_OVF);
         if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
             V8_WAIT(0);
+            __syncthreads();
+            v8_fallback(a, xf, wf, xlist, wlist, smem, (int)blockIdx.x, nwg);
             return;
         }
         cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
@@ -800,7 +798,7 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     // K-loop schedule of the 256 x 256 tile: 2 = pipelined (one barrier per K-step, default: 71.0 vs 72.8 us at 4096^3),
     // 0 = two staggered wave groups, four barriers per K-step (kept for A/B runs: MI355Q_V8_SCHED=0)
     static const int sched = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
-    const unsigned grid = tiles + (fix ? V8_FALLBACK_WGS : 0);          // the fallback workgroups ride behind the tiles
+    const unsigned grid = tiles;            // (on a bucket overflow the tile workgroups themselves form the product blockwise)
     if (small) {
         if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
         else hipLaunchKernelGGL((bfp_gemm_v8<0, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
