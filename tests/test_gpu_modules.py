@@ -434,3 +434,53 @@ def test_softmax_product_with_mask_and_causal(B, T, hd, mode):
     out = Q.get_quantized_func("softmax_bmm", cfg)(st, vt, cfg, **kw).cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(out - ref).max() <= 2e-3 * scale and np.abs(out - ref).mean() <= 2e-5 * scale
+
+
+def test_shared_activation_is_quantised_once():
+    """q / k / v style: layers called on the same activation reuse the quantised operand (one quantiser launch); an in-place
+    write or another tensor at the same address quantises again; results equal layers that never share"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import _lib, ops
+    cfg = _lin_cfg(6, mi355q_align="rows")
+    dev = "cuda:0"
+    torch.manual_seed(4)
+    layers = [Q.get_quantized_cls("linear", cfg)(256, 128, bias=True, config=dict(cfg)).to(dev) for _ in range(3)]
+    x = torch.randn(2, 96, 256, device=dev)
+    lib = _lib.load_library()
+    real = lib.mi355q_block_fp_quantize_aligned_rows
+    calls = []
+
+    def counting(*a):
+        calls.append(1)
+        return real(*a)
+
+    with torch.no_grad():
+        for l in layers:                                     # first forwards: weight packing + route decision
+            l(x.clone())
+        ops.REUSE_QUANTISED_INPUT = False
+        ref = [l(x).clone() for l in layers]
+        ops.REUSE_QUANTISED_INPUT = True
+        layers[0](x.clone())                                 # (another tensor of the shape: the record no longer names x)
+        lib.mi355q_block_fp_quantize_aligned_rows = counting
+        try:
+            out = [l(x).clone() for l in layers]
+            assert len(calls) == 1, len(calls)
+            assert all(torch.equal(a, b) for a, b in zip(out, ref))
+            x.mul_(1.5)                                      # in-place write: version counter moves
+            out2 = layers[1](x).clone()
+            assert len(calls) == 2
+            ops.REUSE_QUANTISED_INPUT = False
+            assert torch.equal(out2, layers[1](x))
+            ops.REUSE_QUANTISED_INPUT = True
+            n0 = len(calls)
+            y = layers[0](x)                                 # (a hit: the record names x since the call above)
+            del x
+            z = torch.randn(2, 96, 256, device=dev)          # may land on the freed address: the record keeps x alive, so it cannot
+            got = layers[2](z).clone()
+            assert len(calls) == n0 + 1
+            ops.REUSE_QUANTISED_INPUT = False
+            assert torch.equal(got, layers[2](z))
+        finally:
+            lib.mi355q_block_fp_quantize_aligned_rows = real
+            ops.REUSE_QUANTISED_INPUT = True
