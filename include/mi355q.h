@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 6
+#define MI355Q_ABI_VERSION 7
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -312,6 +312,19 @@ size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D);
 int mi355q_bfp_attention(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                          float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                          const int32_t* pv_params, void* stream);
+
+/* ---- rotary position embedding -------------------------------------------------------------------------------------
+ * replaces: quantized_functions/rotary_positional_encoding.py:59-248 (apply_rotary_pos_emb_<arithmetic>; callers
+ *           models/llama_quantized/modeling_llama.py:289-299) AFTER the caller has quantised the cos / sin tables with the
+ *           arithmetic's own quantiser (two small tensors [table_rows, D]):
+ *     q_out = q * cos_q[pos] + rotate_half(q) * sin_q[pos],   rotate_half(x) = cat(-x[D/2:], x[:D/2]),   the same for k
+ * in one launch for both (position lookup included; the reference runs ten elementwise kernels and two gathers).  fp32,
+ * products and sum rounded one by one like the reference's ops.  q [B, Hq, T, D] and k [B, Hk, T, D] by element strides
+ * {batch, head, position} (innermost stride 1; multiples of 4), outputs contiguous [B, H, T, D]; position_ids int64 [B, T]
+ * (clamped to the table).  D % 8 == 0. */
+int mi355q_rope_apply(const float* q, const float* k, const float* cos_q, const float* sin_q, const int64_t* position_ids,
+                      float* q_out, float* k_out, int64_t B, int64_t Hq, int64_t Hk, int64_t T, int64_t D, int64_t table_rows,
+                      const int64_t* q_strides, const int64_t* k_strides, void* stream);
 
 /* Kernel timing for benchmarks: when enabled, mi355q_bfp_gemm_aligned brackets its MAIN kernel (the
  * int32-chain GEMM, not the correction / fallback launches) with HIP events on the launch stream.

@@ -454,6 +454,30 @@ static int bfp_matmul_impl(bool softmax, const float* mask, long long causal_off
     return launch_bfp_qmatmul(ax, ay, x, y, out, workspace, B, M, K, N, static_cast<hipStream_t>(stream), softmax, mask, causal_off);
 }
 
+int mi355q_rope_apply(const float* q, const float* k, const float* cos_q, const float* sin_q, const int64_t* position_ids,
+                      float* q_out, float* k_out, int64_t B, int64_t Hq, int64_t Hk, int64_t T, int64_t D, int64_t table_rows,
+                      const int64_t* q_strides, const int64_t* k_strides, void* stream) {
+    if (B < 0 || Hq < 0 || Hk < 0 || T < 0 || D < 0) return MI355Q_E_BADARG;
+    if (B == 0 || T == 0 || D == 0 || (Hq == 0 && Hk == 0)) return 0;
+    if (!q || !k || !cos_q || !sin_q || !position_ids || !q_out || !k_out || !q_strides || !k_strides || table_rows <= 0)
+        return MI355Q_E_BADARG;
+    if (D % 8 != 0) return MI355Q_E_UNSUPPORTED;              // float4 halves
+    for (int i = 0; i < 3; ++i)
+        if (q_strides[i] % 4 || k_strides[i] % 4) return MI355Q_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(cos_q) |
+         reinterpret_cast<uintptr_t>(sin_q) | reinterpret_cast<uintptr_t>(q_out) | reinterpret_cast<uintptr_t>(k_out)) % 16)
+        return MI355Q_E_ALIGN;
+    RopeArgs a{};
+    a.x[0] = q; a.x[1] = k; a.y[0] = q_out; a.y[1] = k_out;
+    a.sb[0] = q_strides[0]; a.sh[0] = q_strides[1]; a.st[0] = q_strides[2];
+    a.sb[1] = k_strides[0]; a.sh[1] = k_strides[1]; a.st[1] = k_strides[2];
+    a.heads[0] = Hq; a.heads[1] = Hk;
+    a.cos = cos_q; a.sin = sin_q;
+    a.pos = reinterpret_cast<const long long*>(position_ids);
+    a.B = B; a.T = T; a.D = D; a.table_rows = table_rows;
+    return launch_rope(a, static_cast<hipStream_t>(stream));
+}
+
 size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D) {
     if (B <= 0 || T <= 0 || D <= 0) return 0;
     return attention_workspace_bytes(B, T, D);

@@ -39,6 +39,17 @@ size_t attention_workspace_bytes(long long B, long long T, long long D);
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st);
+struct RopeArgs {
+    const float* x[2];          // q, k
+    float* y[2];
+    long long sb[2], sh[2], st[2];      // element strides of batch, head, position (innermost stride 1)
+    long long heads[2];
+    const float* cos;           // [table_rows, D], already quantised
+    const float* sin;
+    const long long* pos;       // [B, T]
+    long long B, T, D, table_rows;
+};
+int launch_rope(const RopeArgs& a, hipStream_t st);
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {

@@ -755,6 +755,29 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
     return out
 
 
+def rope_apply(q: torch.Tensor, k: torch.Tensor, cos_q: torch.Tensor, sin_q: torch.Tensor, position_ids: torch.Tensor):
+    """(q * cos[pos] + rotate_half(q) * sin[pos], the same for k) for q [B, Hq, T, D], k [B, Hk, T, D] fp32 (any strides
+    with a unit innermost one), cos_q / sin_q [rows, D] already quantised, position_ids int64 [B, T]: one launch
+    (include/mi355q.h, mi355q_rope_apply).  Outputs are contiguous."""
+    import ctypes
+    _require_device(q, "rope_apply")
+    B, Hq, T, D = q.shape
+    Hk = k.shape[1]
+    assert k.shape == (B, Hk, T, D) and q.stride(3) == 1 and k.stride(3) == 1 and D % 8 == 0
+    assert cos_q.shape == sin_q.shape and cos_q.shape[1] == D and cos_q.is_contiguous() and sin_q.is_contiguous()
+    assert position_ids.dtype == torch.int64 and position_ids.shape == (B, T) and position_ids.is_contiguous()
+    qo = torch.empty(B, Hq, T, D, dtype=torch.float32, device=q.device)
+    ko = torch.empty(B, Hk, T, D, dtype=torch.float32, device=q.device)
+    qs = (ctypes.c_int64 * 3)(q.stride(0), q.stride(1), q.stride(2))
+    ks = (ctypes.c_int64 * 3)(k.stride(0), k.stride(1), k.stride(2))
+    with _on_device(q.device):
+        rc = _lib.load_library().mi355q_rope_apply(_ptr(q), _ptr(k), _ptr(cos_q), _ptr(sin_q), _ptr(position_ids), _ptr(qo), _ptr(ko),
+                                                   B, Hq, Hk, T, D, cos_q.shape[0], ctypes.addressof(qs), ctypes.addressof(ks),
+                                                   _stream_ptr(q.device))
+    _lib.check(rc, "mi355q_rope_apply")
+    return qo, ko
+
+
 def set_gemm_variant(variant: int) -> int:
     return _lib.load_library().mi355q_bfp_gemm_set_variant(int(variant))
 

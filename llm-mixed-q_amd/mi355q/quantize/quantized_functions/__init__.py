@@ -190,6 +190,15 @@ def _rotate_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
+def _rope_kernel_applies(q, k, cos_q, sin_q, position_ids) -> bool:
+    return (q.is_cuda and k.is_cuda and q.dtype == k.dtype == cos_q.dtype == torch.float32 and q.ndim == 4 and k.ndim == 4
+            and q.shape[0] == k.shape[0] and q.shape[2:] == k.shape[2:] and q.shape[3] % 8 == 0 and q.stride(3) == 1
+            and k.stride(3) == 1 and all(s % 4 == 0 for s in q.stride()[:3] + k.stride()[:3])
+            and cos_q.ndim == 2 and cos_q.shape == sin_q.shape and cos_q.shape[1] == q.shape[3]
+            and position_ids.dtype == torch.int64 and position_ids.shape == (q.shape[0], q.shape[2])
+            and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
+
+
 def _make_rope(arith, honours_bypass=True):
     def f(q, k, cos, sin, position_ids, config):
         if honours_bypass and config.get("bypass", False):
@@ -201,8 +210,13 @@ def _make_rope(arith, honours_bypass=True):
             elif arith == "integer":
                 kw["is_signed"] = True
             quant = lambda t: QUANTIZER_MAP[arith](t, **kw)
-        cos = quant(cos.squeeze(1).squeeze(0))[position_ids].unsqueeze(1)   # [bs, 1, seq, dim]
-        sin = quant(sin.squeeze(1).squeeze(0))[position_ids].unsqueeze(1)
+        cos_q, sin_q = quant(cos.squeeze(1).squeeze(0)), quant(sin.squeeze(1).squeeze(0))
+        if _rope_kernel_applies(q, k, cos_q, sin_q, position_ids):
+            # one launch for q and k, position lookup included (ops.rope_apply), instead of ten elementwise kernels
+            from ... import ops
+            return ops.rope_apply(q, k, cos_q.contiguous(), sin_q.contiguous(), position_ids.contiguous())
+        cos = cos_q[position_ids].unsqueeze(1)   # [bs, 1, seq, dim]
+        sin = sin_q[position_ids].unsqueeze(1)
         return (q * cos) + (_rotate_half(q) * sin), (k * cos) + (_rotate_half(k) * sin)
     f.__name__ = f"apply_rotary_pos_emb_{arith}"
     return f

@@ -484,3 +484,40 @@ def test_shared_activation_is_quantised_once():
         finally:
             lib.mi355q_block_fp_quantize_aligned_rows = real
             ops.REUSE_QUANTISED_INPUT = True
+
+
+@pytest.mark.parametrize("B,H,T,hd,strided", [(1, 12, 2048, 64, True), (2, 3, 40, 128, False), (1, 4, 100, 32, True)])
+def test_rope_one_launch_bit_exact(B, H, T, hd, strided):
+    """apply_rotary_pos_emb_block_fp through the one-launch kernel (mi355q_rope_apply) == the reference's op sequence
+    `(q * cos) + (rotate_half(q) * sin)` evaluated op by op in fp32 (rotary_positional_encoding.py:59-82), bit for bit;
+    q / k as the transposed views the Llama attention hands over, shuffled position ids"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = _lin_cfg(6)
+    f = Q.get_quantized_func("rotary_positional_encoding", cfg)
+    g = torch.Generator().manual_seed(T + hd)
+    pos = torch.arange(T)[:, None] * (1.0 / 10000 ** (torch.arange(0, hd, 2) / hd))[None, :]
+    emb = torch.cat((pos, pos), -1)
+    cos, sin = emb.cos()[None, None], emb.sin()[None, None]
+    if strided:
+        q = torch.randn(B, T, H, hd, generator=g).transpose(1, 2)
+        k = torch.randn(B, T, H, hd, generator=g).transpose(1, 2)
+    else:
+        q, k = torch.randn(B, H, T, hd, generator=g), torch.randn(B, H, T, hd, generator=g)
+    ids = torch.stack([torch.randperm(T, generator=g) for _ in range(B)])
+    dev = "cuda:0"
+    qd, kd = q.to(dev), k.to(dev)
+    if strided:
+        qd, kd = qd.transpose(1, 2).contiguous().transpose(1, 2), kd.transpose(1, 2).contiguous().transpose(1, 2)
+        assert not qd.is_contiguous()
+    qe, ke = f(qd, kd, cos.to(dev), sin.to(dev), ids.to(dev), cfg)
+    cq = O.block_fp_quantize(cos.numpy()[0, 0], 6, 8, 127, [1, 16], False)
+    sq = O.block_fp_quantize(sin.numpy()[0, 0], 6, 8, 127, [1, 16], False)
+    for got, x in ((qe, q), (ke, k)):
+        xn = x.numpy()
+        c, s = cq[ids.numpy()][:, None], sq[ids.numpy()][:, None]
+        rot = np.concatenate((-xn[..., hd // 2:], xn[..., : hd // 2]), -1)
+        ref = (xn * c).astype(np.float32) + (rot * s).astype(np.float32)
+        assert got.shape == x.shape and got.is_contiguous()
+        assert np.array_equal(got.cpu().numpy(), ref.astype(np.float32))

@@ -9,10 +9,10 @@ W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
 torch.manual_seed(0)
 cfg = TinyLlamaConfig(vocab_size=2048, hidden_size=768, intermediate_size=2048, num_layers=12, num_heads=12, max_positions=2048)
-model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(W6A6, cfg.num_layers))
+model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(dict(W6A6, mi355q_fused_attention=True), cfg.num_layers))
 with torch.no_grad():
     for n, p in model.named_parameters():
-        if p.ndim == 2 and "embed" not in n: p.mul_(2.0)
+        if p.ndim == 2 and "embed" not in n: p.mul_(1.0)
 model = model.to("cuda:0")
 ids = torch.randint(0, cfg.vocab_size, (1, 2048)).to("cuda:0")
 with torch.no_grad():
