@@ -313,6 +313,11 @@ int mi355q_bfp_attention(const float* q, const float* k, const float* v, const f
                          float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                          const int32_t* pv_params, void* stream);
 
+/* The capture sequence `stream` is recording into a HIP graph (non-zero, unique per capture), or 0 when it is not
+ * capturing.  Host-side caches that skip a launch (the Python layer's reuse of an already quantised activation) are
+ * only valid inside the capture -- or the eager stretch -- they were made in. */
+unsigned long long mi355q_stream_capture_id(void* stream);
+
 /* ---- rotary position embedding -------------------------------------------------------------------------------------
  * replaces: quantized_functions/rotary_positional_encoding.py:59-248 (apply_rotary_pos_emb_<arithmetic>; callers
  *           models/llama_quantized/modeling_llama.py:289-299) AFTER the caller has quantised the cos / sin tables with the

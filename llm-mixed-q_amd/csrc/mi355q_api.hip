@@ -454,6 +454,13 @@ static int bfp_matmul_impl(bool softmax, const float* mask, long long causal_off
     return launch_bfp_qmatmul(ax, ay, x, y, out, workspace, B, M, K, N, static_cast<hipStream_t>(stream), softmax, mask, causal_off);
 }
 
+unsigned long long mi355q_stream_capture_id(void* stream) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(static_cast<hipStream_t>(stream), &status, &id) != hipSuccess) return 0;
+    return status == hipStreamCaptureStatusActive ? (id ? id : ~0ull) : 0;
+}
+
 int mi355q_rope_apply(const float* q, const float* k, const float* cos_q, const float* sin_q, const int64_t* position_ids,
                       float* q_out, float* k_out, int64_t B, int64_t Hq, int64_t Hk, int64_t T, int64_t D, int64_t table_rows,
                       const int64_t* q_strides, const int64_t* k_strides, void* stream) {

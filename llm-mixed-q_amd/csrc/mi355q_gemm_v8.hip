@@ -819,11 +819,30 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     const long long tn = (a.N + V8_BN - 1) / V8_BN;
     const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
-    const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost128 = (double)((t128 + 255) / 256) * 0.82;
-    const bool small = cost128 < cost256;
+    // Tile height and split together, by a small cost model fitted to tools/sweep_bf16_tile_split.py (us): rounds x steps
+    // per slice x 0.70 (256 rows) or 0.56 (128 rows) per K-step, plus, when split, 12 + 0.7 per MiB of slab traffic (S x
+    // the fp32 output through memory twice).  It ranks the measured settings of the post-activation layer shapes
+    // correctly: 2048 x 11008 x 4096 -> 256 rows in two slices (177 vs 192 us), 2048 x 8192 x 2048 -> 256 rows in four.
+    const char* force = getenv("MI355Q_V8_TILE_ROWS");          // (sweeps pin either flavour)
+    const int nsteps_all = (int)(a.K >> 6);
+    const double out_mib = (double)a.M * (double)a.N * 4.0 / 1048576.0;
+    bool small = false;
+    int S = 1;
+    double best_t = 1e30;
+    for (int kind = 0; kind < 2; ++kind) {                      // 0: 256 rows, 1: 128 rows
+        if (force && atoi(force) && (atoi(force) == 128) != (kind == 1)) continue;
+        const long long t = kind ? t128 : t256;
+        const int smax = choose_splits(t, nsteps_all, kind == 0 && a.K % 128 == 0);
+        for (int sp = 1; sp <= smax; ++sp) {
+            if (getenv("MI355Q_V8_SPLITS") && sp != smax) continue;                      // (sweeps pin the split too)
+            if (nsteps_all % sp || (kind == 0 && a.K % 128 == 0 && ((nsteps_all / sp) & 1))) continue;
+            const double rounds = (double)((t * sp + 255) / 256);
+            const double est = rounds * (nsteps_all / sp) * (kind ? 0.56 : 0.70) + (sp > 1 ? 12.0 + 0.7 * out_mib * sp : 0.0);
+            if (est < best_t) { best_t = est; small = kind == 1; S = sp; }
+        }
+    }
     unsigned tiles = (unsigned)(small ? t128 : t256);
     {
-        const int S = choose_splits(tiles, (int)(a.K >> 6), !small && a.K % 128 == 0);
         a.splits = 1;
         if (S > 1) {
             SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * (small ? 128 : 256) * 256 * 4, (int)tiles);

@@ -620,7 +620,9 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     sp = _stream_ptr(x.device)
     buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True, sp=sp, bucket_cap=bucket_cap)
     bias = _default_bias(exponent_bias)
-    sig = (int(width), int(exponent_width), bias, bucket_cap)
+    # (the record is only good inside the capture sequence -- or the eager stretch -- it was made in: a hit while a graph
+    #  is being recorded on a record from the warm-up would leave the quantiser out of the graph)
+    sig = (int(width), int(exponent_width), bias, bucket_cap, _lib.load_library().mi355q_stream_capture_id(sp))
     again = _recorded_operand(buf, x, sig)
     if again is not None:
         return again

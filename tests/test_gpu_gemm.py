@@ -454,7 +454,7 @@ def test_row_aligned_gemm_bucket_overflow_takes_the_fallback():
 @pytest.mark.parametrize("style,rows", [("rowscale", 300), ("outlier", 40), ("sparse", 24)])
 @pytest.mark.parametrize("width", [6, 4])
 @pytest.mark.parametrize("K", [1024, 4096, 320, 5120])
-def test_fused_quantize_align_rows_equals_two_step(style, rows, width, K):
+def test_fused_quantize_align_rows_equals_two_step(style, rows, width, K, monkeypatch):
     import torch
     from mi355q import ops
     dev = torch.device("cuda:0")
@@ -480,6 +480,8 @@ def test_fused_quantize_align_rows_equals_two_step(style, rows, width, K):
     assert torch.equal(got.exp, ref.exp.reshape(-1)) and torch.equal(got.rowflag, ref.rowflag)
     assert torch.equal(got.gscale[:rows], ref.gscale[:rows])
     # alternating lists: the second call fills the other list, the third one the first again (emptied in between)
+    # (with the shared-activation reuse off: the same tensor again would hand back the operand already in the buffers)
+    monkeypatch.setattr(ops, "REUSE_QUANTISED_INPUT", False)
     again = ops.block_fp_quantize_aligned_rows(xt, width, 8, 127)
     third = ops.block_fp_quantize_aligned_rows(xt, width, 8, 127)
     torch.cuda.synchronize()

@@ -8,11 +8,18 @@ from mi355q.harness import (TinyOPTConfig, TinyOPTForCausalLM, TinyLlamaConfig, 
 W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16],
-            mi355q_fused_softmax=True, mi355q_fused_attention=(len(sys.argv) > 1 and sys.argv[1] == "one_pass"))
+            mi355q_fused_attention="one_pass" in sys.argv, mi355q_fused_softmax="steps" not in sys.argv)
 dev = torch.device("cuda:0")
-for family in ("opt", "llama"):
+families = ("opt1.3b", "llama7b") if "real_widths" in sys.argv else ("opt", "llama")
+for family in families:
     torch.manual_seed(0)
-    if family == "opt":
+    if family == "opt1.3b":      # BASELINE config 4's width, 2 layers (per-layer time = difference to the head + embedding)
+        cfg = TinyOPTConfig(vocab_size=2048, hidden_size=2048, ffn_dim=8192, num_layers=2, num_heads=32, max_positions=2048)
+        model = TinyOPTForCausalLM(cfg, expand_quant_config(W6A6, cfg.num_layers))
+    elif family == "llama7b":    # BASELINE config 3's width
+        cfg = TinyLlamaConfig(vocab_size=2048, hidden_size=4096, intermediate_size=11008, num_layers=2, num_heads=32, max_positions=2048)
+        model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(W6A6, cfg.num_layers))
+    elif family == "opt":
         cfg = TinyOPTConfig(vocab_size=2048, hidden_size=768, ffn_dim=3072, num_layers=12, num_heads=12, max_positions=2048)
         model = TinyOPTForCausalLM(cfg, expand_quant_config(W6A6, cfg.num_layers))
     else:
@@ -37,5 +44,7 @@ for family in ("opt", "llama"):
     fwd = GraphedForward(lambda t: model(t)[0], (ids,))
     same = bool(torch.equal(fwd(ids), ref))
     t_graph = timed(lambda: fwd(ids))
-    print(json.dumps({"model": f"{'OPT-125m' if family == 'opt' else 'Llama-160m'} width, 12 layers, T=2048, W6A6, " + ("one-pass attention" if W6A6["mi355q_fused_attention"] else "softmax folded into P V"),
+    label = {"opt": "OPT-125m width, 12 layers", "llama": "Llama-160m width, 12 layers", "opt1.3b": "OPT-1.3B width, 2 layers",
+             "llama7b": "Llama-7B width, 2 layers"}[family]
+    print(json.dumps({"model": f"{label}, T=2048, W6A6, " + ("one-pass attention" if W6A6["mi355q_fused_attention"] else "softmax folded into P V" if W6A6["mi355q_fused_softmax"] else "attention as the reference steps it"),
                       "eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3), "graph_equals_eager": same}), flush=True)
