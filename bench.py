@@ -206,6 +206,9 @@ def main():
     import torch
     import torch.distributed as dist
     from mi355q import ops
+    # every timed step quantises its activation: the loop below feeds ONE tensor as a stand-in for a fresh activation per
+    # step, which the module layer's shared-activation reuse (ops.REUSE_QUANTISED_INPUT) would recognise and skip
+    ops.REUSE_QUANTISED_INPUT = False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

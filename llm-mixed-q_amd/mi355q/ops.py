@@ -3,6 +3,7 @@ to the library, current HIP stream.  torch is plumbing here (device memory, stre
 from __future__ import annotations
 
 import math
+import os
 from typing import Sequence
 
 import torch
@@ -583,7 +584,7 @@ def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, 
 # views too) and the same quantiser parameters.  The record keeps the tensor alive, so its address cannot have been handed
 # to another allocation in between; every quantise call of that shape overwrites the record, so what the record names is
 # always what the buffers hold.  Cost: one activation per shape stays allocated until the next call of that shape.
-REUSE_QUANTISED_INPUT = True
+REUSE_QUANTISED_INPUT = os.environ.get("MI355Q_REUSE_INPUT", "1") != "0"    # (timing loops over ONE tensor switch it off)
 
 
 def _recorded_operand(buf, x, sig):

@@ -6,6 +6,7 @@ import torch
 from mi355q import ops
 from mi355q.harness import TinyOPTConfig, TinyOPTForCausalLM, expand_quant_config
 from mi355q.quantize.quantized_modules.linear import LinearBlockFP
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])

@@ -4,6 +4,7 @@ sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch
 from mi355q import ops
 import bench
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device('cuda:0')
 x, w, b = bench.make_inputs(torch, dev, 0)

@@ -4,6 +4,7 @@ import sys
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import numpy as np, torch
 from mi355q import ops
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev = torch.device("cuda:0")
 r = np.random.default_rng(11)
 for (M, N, K) in ((2048, 768, 3072), (600, 200, 1024), (4096, 1024, 4096)):

@@ -4,6 +4,7 @@ import sys, os
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch
 from mi355q import ops
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev = torch.device('cuda:0')
 for (M, N, K, reps) in [(4096, 4096, 4096, 300), (2048, 4096, 4096, 300), (2048, 11008, 4096, 100), (2048, 4096, 11008, 100),
                         (300, 520, 1024, 300), (4096, 4096, 128, 300), (777, 1300, 2048, 200)]:

@@ -3,6 +3,7 @@ import json, os, sys
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch
 from mi355q import ops
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev = torch.device("cuda:0")
 M, K, N = (int(v) for v in sys.argv[1:4])
 g = torch.Generator().manual_seed(M + K + N)

@@ -4,6 +4,7 @@ import json, sys
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch
 from mi355q import ops
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev = torch.device("cuda:0")
 shapes = [("OPT-125m q/k/v/out", 2048, 768, 768), ("OPT-125m fc1", 2048, 768, 3072), ("OPT-1.3B q/k/v/out", 2048, 2048, 2048),
           ("OPT-1.3B fc1", 2048, 2048, 8192), ("Llama-7B q/k/v/o", 2048, 4096, 4096), ("Llama-7B gate/up", 2048, 4096, 11008),

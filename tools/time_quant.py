@@ -3,6 +3,7 @@ import sys
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch
 from mi355q import ops
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
 x = (torch.randn(4096, 4096, generator=g) * torch.exp(torch.randn(4096, 1, generator=g))).to(dev)

@@ -4,6 +4,7 @@ under-filled), HIP events."""
 import json, sys; sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch
 from mi355q import ops
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev = torch.device('cuda:0')
 def t(fn, n=50):
     for _ in range(5): fn()

@@ -6,6 +6,7 @@ import torch
 import bench
 from mi355q.graphs import GraphedForward
 from mi355q.quantize import get_quantized_cls
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 
 dev = torch.device("cuda:0")
 x, w, b = bench.make_inputs(torch, dev, 0)

@@ -3,6 +3,7 @@ operands of decreasing switching activity: benchmark data, constant small mantis
 import sys; sys.path.insert(0,'llm-mixed-q_amd'); sys.path.insert(0,'.')
 import torch, bench
 from mi355q import ops
+import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev=torch.device('cuda:0')
 x,w,b=bench.make_inputs(torch,dev,0)
 for name,(xx,ww) in {"benchmark data":(x,w), "constant 1.0 / 0.02":(torch.ones_like(x), torch.full_like(w,0.02)), "zeros":(torch.zeros_like(x),torch.zeros_like(w))}.items():
