@@ -186,6 +186,8 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
                                                      _default_bias(exponent_bias), _ptr(_workspace(x.device)),
                                                      _stream_ptr(x.device))
     _lib.check(rc, "mi355q_block_fp_quantize_bf16_tiled")
+    if out_fake is not None:
+        _wrote_into(out_fake)
     return yt
 
 
@@ -295,6 +297,7 @@ def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, 
     the tile GEMM's bf16 arithmetic -- operands whose blocks keep their own exponents."""
     if not (xt.is_cuda and wt.is_cuda):
         raise RuntimeError("mi355q.bf16_gemm_tiled: operands must be on a HIP device; there is no CPU fallback")
+    given = out is not None
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=xt.device)
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
@@ -303,6 +306,8 @@ def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, 
         rc = _lib.load_library().mi355q_bf16_gemm_tiled(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy,
                                                        _stream_ptr(xt.device))
     _lib.check(rc, "mi355q_bf16_gemm_tiled")
+    if given:
+        _wrote_into(out)
     return out
 
 
@@ -368,6 +373,7 @@ def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Ten
     assert wm.shape[1] == K and xm.dtype == torch.int8 and wm.dtype == torch.int8
     assert xe.numel() == M * (K // 16) and we.numel() == N * (K // 16)
     assert xm.is_contiguous() and wm.is_contiguous() and xe.is_contiguous() and we.is_contiguous()
+    given = out is not None
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=xm.device)
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
@@ -378,6 +384,8 @@ def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Ten
                                  int(x_mbits), int(x_exp_bias), int(w_mbits), int(w_exp_bias),
                                  _stream_ptr(xm.device))
     _lib.check(rc, "mi355q_bfp_gemm")
+    if given:
+        _wrote_into(out)
     return out
 
 
@@ -508,6 +516,13 @@ def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: 
     _lib.check(rc, "mi355q_bfp_align_rows")
     return AlignedOperand(rows, K, None, tiled, eo, flag, rscale, sparse, mbits, exp_bias, row_aligned=True,
                           bucket_cap=bucket_cap)
+
+
+def _wrote_into(t: torch.Tensor) -> None:
+    """a kernel of this library has just written into a caller-provided tensor through its raw pointer: move its version
+    counter like an in-place torch op would (version-keyed caches -- the quantised-activation reuse below, autograd's
+    saved-tensor checks -- must see the write)"""
+    torch.autograd.graph.increment_version(t)
 
 
 def _capturing() -> bool:
@@ -653,6 +668,7 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     """bfp_gemm on operands rewritten by bfp_align."""
     M, K, N = x.rows, x.K, w.rows
     assert w.K == K
+    given = out is not None
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.tiled.device)
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
@@ -663,6 +679,8 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     with _on_device(x.tiled.device):
         rc = lib.mi355q_bfp_gemm_aligned(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(out), M, N, K, ldy, sp)
     _lib.check(rc, "mi355q_bfp_gemm_aligned")
+    if given:
+        _wrote_into(out)
     return out
 
 

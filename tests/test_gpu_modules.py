@@ -521,3 +521,34 @@ def test_rope_one_launch_bit_exact(B, H, T, hd, strided):
         ref = (xn * c).astype(np.float32) + (rot * s).astype(np.float32)
         assert got.shape == x.shape and got.is_contiguous()
         assert np.array_equal(got.cpu().numpy(), ref.astype(np.float32))
+
+
+def test_out_buffers_move_their_version_counter():
+    """a GEMM that writes into a caller's `out` tensor through its raw pointer bumps the tensor's version like an in-place
+    torch op: the shared-activation reuse (keyed by the version) never serves a stale operand for a re-filled buffer"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    dev = "cuda:0"
+    cfg = _lin_cfg(6, mi355q_align="rows")
+    torch.manual_seed(8)
+    a, b = (torch.randn(64, 256, device=dev) for _ in range(2))
+    w = torch.randn(256, 256, device=dev) * 0.05
+    _, wm, we = ops.block_fp_quantize(w, 6, 8, 127, [1, 16], False, want_fake=False, want_packed=True)
+    wa = ops.bfp_align_rows(wm, we, 5, 127)
+    lin = Q.get_quantized_cls("linear", cfg)(256, 128, bias=False, config=dict(cfg)).to(dev)
+    buf = torch.empty(64, 256, device=dev)
+    with torch.no_grad():
+        outs = []
+        for src in (a, b):
+            v0 = buf._version
+            ops.bfp_gemm_aligned(ops.block_fp_quantize_aligned_rows(src, 6, 8, 127), wa, None, out=buf)
+            assert buf._version > v0
+            outs.append(lin(buf).clone())
+        ops.REUSE_QUANTISED_INPUT = False
+        try:
+            ops.bfp_gemm_aligned(ops.block_fp_quantize_aligned_rows(b, 6, 8, 127), wa, None, out=buf)
+            assert torch.equal(outs[1], lin(buf))
+        finally:
+            ops.REUSE_QUANTISED_INPUT = True
+    assert not torch.equal(outs[0], outs[1])
