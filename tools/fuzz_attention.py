@@ -1,0 +1,75 @@
+"""Random shapes / widths / masks: the one-pass attention kernel against the step-by-step route through the registry's own
+functions (fused kernels off), and the one-launch rotary embedding against the reference's op sequence in torch."""
+import json, math, sys
+sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
+import numpy as np
+import torch
+import mi355q.quantize as Q
+from mi355q.quantize.quantized_functions import _rotate_half
+
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+
+
+def cfg(w0, w1):
+    return dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=w0, data_in_exponent_width=8, data_in_exponent_bias=127,
+                data_in_block_size=[1, 16], weight_width=w1, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16])
+
+
+worst = 0.0
+for it in range(N):
+    B = int(rng.integers(1, 9)); hd = int(rng.choice([32, 64, 96, 128])); T = 16 * int(rng.integers(1, 129))
+    M = T if rng.random() < 0.7 else 16 * int(rng.integers(1, T // 16 + 1))
+    c0, c1 = cfg(int(rng.integers(3, 9)), int(rng.integers(3, 9))), cfg(int(rng.integers(3, 9)), int(rng.integers(3, 9)))
+    mode = rng.choice(["causal", "mask", "both", "plain"])
+    scale = float(rng.choice([0.0, math.sqrt(hd)]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    q = (torch.randn(B, M, hd, generator=g) * float(rng.choice([0.3, 1.0, 3.0]))).to(dev)
+    k = (torch.randn(B, T, hd, generator=g) * torch.exp(torch.randn(B, 1, hd, generator=g) * 0.5)).to(dev)
+    v = torch.randn(B, T, hd, generator=g).to(dev)
+    kw = {}
+    if mode in ("mask", "both"):
+        m = torch.randn(M, T, generator=g) * 0.5
+        m[:, ::5] = torch.finfo(torch.float32).min
+        m[:, 0] = 0
+        kw["mask"] = m.to(dev)
+    if mode in ("causal", "both"):
+        kw["causal"] = True
+    if scale:
+        kw["scale_div"] = scale
+    f = Q.get_quantized_func("attention", c1)
+    one = f(q, k, v, c0, c1, **kw)
+    steps = f(q, k, v, dict(c0, mi355q_fused_matmul=False), dict(c1, mi355q_fused_matmul=False), **kw)
+    err = float((one - steps).abs().max() / steps.abs().max().clamp_min(1e-30))
+    worst = max(worst, err)
+    if not torch.isfinite(one).all() or err > 6e-2:      # (a score one ulp apart -- the steps route multiplies by 1 / scale -- may flip one probability by a mantissa step)
+        print(json.dumps({"FAIL": it, "B": B, "M": M, "T": T, "hd": hd, "mode": str(mode), "scale": scale, "widths": [c0["data_in_width"], c0["weight_width"], c1["data_in_width"], c1["weight_width"]], "rel_err": err}))
+        sys.exit(1)
+print(json.dumps({"attention_cases": N, "worst_max_rel_err_vs_steps": worst}))
+
+# rotary embedding
+bad = 0
+for it in range(40):
+    B = int(rng.integers(1, 4)); H = int(rng.integers(1, 9)); T = int(rng.integers(1, 300)); hd = int(rng.choice([16, 32, 64, 128]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    strided = rng.random() < 0.5
+    q = (torch.randn(B, T, H, hd, generator=g).to(dev).transpose(1, 2) if strided else torch.randn(B, H, T, hd, generator=g).to(dev))
+    k = (torch.randn(B, T, H, hd, generator=g).to(dev).transpose(1, 2) if strided else torch.randn(B, H, T, hd, generator=g).to(dev))
+    rows = T + int(rng.integers(0, 10))
+    pos = torch.arange(rows)[:, None] * (1.0 / 10000 ** (torch.arange(0, hd, 2) / hd))[None, :]
+    emb = torch.cat((pos, pos), -1)
+    cos, sin = emb.cos()[None, None].to(dev), emb.sin()[None, None].to(dev)
+    ids = torch.stack([torch.randperm(rows, generator=g)[:T] for _ in range(B)]).to(dev)
+    c = cfg(6, 6)
+    qe, ke = Q.get_quantized_func("rotary_positional_encoding", c)(q, k, cos, sin, ids, c)
+    from mi355q.quantize.quantizers import QUANTIZER_MAP
+    kwq = dict(width=6, exponent_width=8, exponent_bias=127, block_size=[1, 16], skip_first_dim=False)
+    cq = QUANTIZER_MAP["block_fp"](cos[0, 0], **kwq)[ids].unsqueeze(1)
+    sq = QUANTIZER_MAP["block_fp"](sin[0, 0], **kwq)[ids].unsqueeze(1)
+    rq, rk = (q * cq) + (_rotate_half(q) * sq), (k * cq) + (_rotate_half(k) * sq)
+    if not (torch.equal(qe, rq) and torch.equal(ke, rk)):
+        bad += 1
+        print(json.dumps({"ROPE_FAIL": it, "B": B, "H": H, "T": T, "hd": hd, "strided": bool(strided)}))
+print(json.dumps({"rope_cases": 40, "mismatches": bad}))
+sys.exit(1 if bad else 0)
