@@ -210,7 +210,7 @@ struct AttnArgs {
 // QG = 16-query groups per workgroup (4 waves each).  Two groups walk the same key tiles in step: the second request for
 // a K / V fragment is served by the compute unit's L1 instead of the L2 (the kernel is L2-bandwidth bound at long T: every
 // 16 queries stream their head's whole K and V fragments).
-template <int NTW, int DC, int QG>
+template <int NTW, int DC, int QG, bool HASMASK>
 __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
     constexpr int DT = DC * 2;
     constexpr float FMIN = -3.4028234663852886e38f;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     long long need = g.NT;
     if (g.causal_off >= 0) need = min(g.NT, (min(m0 + 15, g.M - 1) + g.causal_off) / 16 + 1);
     const uint16_t* __restrict__ kfb = g.kf + b * g.NT * DC * 512;
-    const float* __restrict__ mrow = g.mask ? g.mask + qrow * g.T : nullptr;
+    const float* __restrict__ mrow = HASMASK ? g.mask + qrow * g.T : nullptr;
 
     // ---- scores of this wave's tiles, masked; row maximum.  K fragments arrive in groups of G tiles, the next group
     //      requested before this one is used, and UNCONDITIONALLY (a tile behind the horizon re-reads the last needed one:
@@ -266,18 +266,20 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     float mx = -INFINITY;
     const long long tlast = need - 1;
     uint4 kb[2][G][DC];
-    auto load_group = [&](int gi, uint4 (&dst)[G][DC]) {
+    float4 mb[2][HASMASK ? G : 1];                         // (the additive mask's values ride with the K fragments)
+    auto load_group = [&](int gi, uint4 (&dst)[G][DC], float4 (&mdst)[HASMASK ? G : 1]) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const long long t = min((long long)(4 * (gi * G + j) + wave), tlast);
 #pragma unroll
             for (int c = 0; c < DC; ++c) dst[j][c] = *reinterpret_cast<const uint4*>(kfb + ((t * DC + c) * 64 + lane) * 8);
+            if (HASMASK) mdst[j] = *reinterpret_cast<const float4*>(mrow + t * 16 + 4 * lg);
         }
     };
-    load_group(0, kb[0]);
+    load_group(0, kb[0], mb[0]);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-        if (gi + 1 < NG) load_group(gi + 1, kb[(gi + 1) & 1]);
+        if (gi + 1 < NG) load_group(gi + 1, kb[(gi + 1) & 1], mb[(gi + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -293,8 +295,8 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
 #pragma unroll
                     for (int e = 0; e < 4; ++e) s[e] = s[e] / g.scale_div;
                 }
-                if (mrow) {
-                    const float4 mk = *reinterpret_cast<const float4*>(mrow + key0);
+                if (HASMASK) {
+                    const float4 mk = mb[gi & 1][j];
                     s[0] = fmaxf(s[0] + mk.x, FMIN); s[1] = fmaxf(s[1] + mk.y, FMIN);
                     s[2] = fmaxf(s[2] + mk.z, FMIN); s[3] = fmaxf(s[3] + mk.w, FMIN);
                 }
@@ -416,7 +418,9 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     const int qg = 2;
     const dim3 grid((unsigned)(((M + 15) / 16 + qg - 1) / qg), (unsigned)B);
     const int ntw = T <= 512 ? 8 : (T <= 1024 ? 16 : 32);
-#define MI355Q_ATTN(NTW_, DC_) hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 2>), grid, 512, 0, st, aq, ap, g)
+#define MI355Q_ATTN(NTW_, DC_)                                                                                \
+    if (mask) hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 2, true>), grid, 512, 0, st, aq, ap, g);    \
+    else hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 2, false>), grid, 512, 0, st, aq, ap, g)
 #define MI355Q_ATTN_D(NTW_)                                     \
     switch (D / 32) {                                          \
         case 1: MI355Q_ATTN(NTW_, 1); break;                   \
