@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 7
+#define MI355Q_ABI_VERSION 8
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -312,6 +312,12 @@ size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D);
 int mi355q_bfp_attention(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                          float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                          const int32_t* pv_params, void* stream);
+/* The same on strided operands -- the [heads, T, D] views of [T, heads, D] projections that the models hand over, without
+ * a contiguous copy first: strides = {q batch, q row, k batch, k row, v batch, v row} in elements (innermost stride 1,
+ * multiples of 4), NULL = contiguous.  out is contiguous [B, M, D]. */
+int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                                 float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D,
+                                 const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides, void* stream);
 
 /* The capture sequence `stream` is recording into a HIP graph (non-zero, unique per capture), or 0 when it is not
  * capturing.  Host-side caches that skip a launch (the Python layer's reuse of an already quantised activation) are

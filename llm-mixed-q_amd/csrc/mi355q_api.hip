@@ -493,6 +493,13 @@ size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D) {
 int mi355q_bfp_attention(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                          float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                          const int32_t* pv_params, void* stream) {
+    return mi355q_bfp_attention_strided(q, k, v, mask, causal, scale_div, out, workspace, B, M, T, D, qk_params, pv_params,
+                                        nullptr, stream);
+}
+
+int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                                 float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D,
+                                 const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides, void* stream) {
     if (B < 0 || M < 0 || T < 0 || D < 0) return MI355Q_E_BADARG;
     if (B == 0 || M == 0 || D == 0) return 0;
     if (!q || !k || !v || !out || !workspace || !qk_params || !pv_params || T == 0 || B > 65535) return MI355Q_E_BADARG;
@@ -516,8 +523,14 @@ int mi355q_bfp_attention(const float* q, const float* k, const float* v, const f
         a[i].e_max = (1 << pr[1]) - 1 - bias;
         set_mantissa(a[i], pr[0] - 1);
     }
+    long long st6[6];
+    if (strides)
+        for (int i = 0; i < 6; ++i) {
+            if (strides[i] % 4) return MI355Q_E_ALIGN;            // (16-byte loads of every row)
+            st6[i] = strides[i];
+        }
     return launch_bfp_attention(a[0], a[1], a[2], a[3], q, k, v, mask, out, workspace, B, M, T, D, causal ? T - M : -1,
-                                scale_div, static_cast<hipStream_t>(stream));
+                                scale_div, static_cast<hipStream_t>(stream), strides ? st6 : nullptr);
 }
 
 int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,

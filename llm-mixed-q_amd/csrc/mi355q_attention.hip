@@ -104,7 +104,7 @@ __device__ __forceinline__ float at_quant_pos(float x, float sc_up, float sc_dn,
 // One workgroup = 256 / D key tiles; thread (tile, d) walks the 16 keys of its block (coalesced over d).
 __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, uint16_t* __restrict__ tile,
                                             const float* __restrict__ k, uint16_t* __restrict__ kf, long long T, int D,
-                                            long long NT, long long bx) {
+                                            long long NT, long long bx, long long sb, long long st) {
     // tile: [sub-tile][c][lane][8] = D * 16 values per sub-tile
     const int tid = threadIdx.x, per = 256 / D, sub = tid / D, d = tid % D;
     const long long b = blockIdx.y, t = bx * per + sub;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long long key = t * 16 + e;
-            v[e] = key < T ? k[(b * T + key) * D + d] : 0.f;
+            v[e] = key < T ? k[b * sb + key * st + d] : 0.f;
             bmax = fmaxf(bmax, fabsf(v[e]));
         }
         unsigned code;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, 
 // One workgroup = 128 keys (8 tiles = 4 pairs) x D; thread (key, 16-d block) quantises one block.
 __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, uint16_t* __restrict__ stage,
                                             const float* __restrict__ v, uint16_t* __restrict__ vf, long long T, int D,
-                                            long long NPAIR, long long bx) {
+                                            long long NPAIR, long long bx, long long sb, long long st) {
     // stage: [dt][pair in group (w)][lane][8]
     const int tid = threadIdx.x, DT = D >> 4;
     const long long b = blockIdx.y, key0 = bx * 128;
@@ -158,7 +158,7 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (key < T) f = *reinterpret_cast<const float4*>(v + (b * T + key) * D + dt * 16 + 4 * i);
+            if (key < T) f = *reinterpret_cast<const float4*>(v + b * sb + key * st + dt * 16 + 4 * i);
             x[4 * i] = f.x; x[4 * i + 1] = f.y; x[4 * i + 2] = f.z; x[4 * i + 3] = f.w;
             bmax = fmaxf(bmax, fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w))));
         }
@@ -185,12 +185,13 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
 __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, const QuantArgs av, const float* __restrict__ k,
                                                            const float* __restrict__ v, uint16_t* __restrict__ kf,
                                                            uint16_t* __restrict__ vf, long long T, int D, long long NT,
-                                                           long long NPAIR, int kblocks) {
+                                                           long long NPAIR, int kblocks, long long ksb, long long kst,
+                                                           long long vsb, long long vst) {
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) uint16_t buf[AT_MAX_D / 16 * 4 * 512];
     load_lut<FMT_BFP>(lut);
-    if ((int)blockIdx.x < kblocks) attn_pack_k(ak, lut, buf, k, kf, T, D, NT, blockIdx.x);
-    else attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks);
+    if ((int)blockIdx.x < kblocks) attn_pack_k(ak, lut, buf, k, kf, T, D, NT, blockIdx.x, ksb, kst);
+    else attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst);
 }
 
 // ---- the attention pass ------------------------------------------------------------------------------------------------
@@ -205,6 +206,7 @@ struct AttnArgs {
     long long causal_off;     // >= 0: query i sees keys 0 .. i + causal_off; < 0: no causal rule
     float scale_div;          // 0: none
     int D;
+    long long qsb, qsm;       // element strides of q's batch (head) and row
 };
 
 // QG = 16-query groups per workgroup (4 waves each).  Two groups walk the same key tiles in step: the second request for
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     bf16x8 qf[DC];
     {
         const int mb = (int)__builtin_log2f(aq.shift);
-        const float* __restrict__ qp = g.q + (b * g.M + qrow) * D;
+        const float* __restrict__ qp = g.q + b * g.qsb + qrow * g.qsm;
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
             const float4 lo = *reinterpret_cast<const float4*>(qp + 32 * c + 8 * lg);
@@ -402,18 +404,23 @@ size_t attention_workspace_bytes(long long B, long long T, long long D) {
 
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
-                         long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st) {
+                         long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
+                         const long long* strides) {
     if (T > AT_MAX_T || D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
     const long long NT = T / 16, NPAIR = ((T + 127) / 128) * 4;
     uint16_t* kf = static_cast<uint16_t*>(workspace);
     uint16_t* vf = kf + (size_t)B * NT * (D / 32) * 512;
     const int per = 256 / (int)D;
     const int kblocks = (int)((NT + per - 1) / per);
+    // strides: {q batch, q row, k batch, k row, v batch, v row} in elements (innermost stride 1); null = contiguous
+    const long long qsb = strides ? strides[0] : M * D, qsm = strides ? strides[1] : D;
+    const long long ksb = strides ? strides[2] : T * D, kst = strides ? strides[3] : D;
+    const long long vsb = strides ? strides[4] : T * D, vst = strides ? strides[5] : D;
     hipLaunchKernelGGL(attn_pack_kv_kernel, dim3((unsigned)(kblocks + NPAIR / 4), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf, T,
-                       (int)D, NT, NPAIR, kblocks);
+                       (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D};
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm};
     // two 16-query groups per workgroup (measured at T = 2048: 70 vs 101 us at 12 heads x 64, 235 vs 342 us at 32 x 128)
     const int qg = 2;
     const dim3 grid((unsigned)(((M + 15) / 16 + qg - 1) / qg), (unsigned)B);

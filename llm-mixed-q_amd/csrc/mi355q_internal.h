@@ -38,7 +38,8 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
 size_t attention_workspace_bytes(long long B, long long T, long long D);
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
-                         long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st);
+                         long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
+                         const long long* strides = nullptr);
 struct RopeArgs {
     const float* x[2];          // q, k
     float* y[2];

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mi355q_bfp_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_attention_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
     "mi355q_bfp_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "mi355q_bfp_attention_strided": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mi355q_stream_capture_id": (C.c_uint64, [_vp]),
     "mi355q_rope_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -61,7 +62,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

@@ -53,13 +53,16 @@ class _Attention(nn.Module):
     def forward(self, x, mask):
         B, T, _ = x.shape
         shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2).contiguous().view(B * self.nh, T, self.hd)
-        q = shape(self.q_proj(x) * self.scaling)
-        k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
         c1 = self.qc["bmm_1"]
         if c1["name"] == "block_fp" and c1.get("mi355q_fused_attention", False):
-            # both products, the mask and the softmax in one pass per 16 queries (the harness' mask is the causal one)
-            o = get_quantized_func("attention", c1)(q, k, v, self.qc["bmm_0"], c1, causal=True)
-            return self.out_proj(o.view(B, self.nh, T, self.hd).transpose(1, 2).reshape(B, T, self.h))
+            # both products, the mask and the softmax in one pass per 16 queries (the harness' mask is the causal one); the
+            # kernel reads the [heads, T, hd] views of the projections in place: no `_shape(...).contiguous()` copies
+            heads = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
+            o = get_quantized_func("attention", c1)(heads(self.q_proj(x) * self.scaling), heads(self.k_proj(x)),
+                                                    heads(self.v_proj(x)), self.qc["bmm_0"], c1, causal=True)
+            return self.out_proj(o.transpose(1, 2).reshape(B, T, self.h))
+        q = shape(self.q_proj(x) * self.scaling)
+        k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
         w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
         if c1["name"] == "block_fp" and c1.get("mi355q_fused_softmax", False):
             # mask add, clamp and softmax folded into the product kernel (the harness' mask is the causal one)

@@ -735,27 +735,53 @@ _ATTN_WS: dict = {}
 ATTENTION_MAX_KEYS, ATTENTION_MAX_HEAD_DIM = 2048, 128
 
 
+def _as_heads_view(t: torch.Tensor):
+    """[..., T, D] -> (tensor3 [B, T, D], batch stride, row stride) without copying when the leading dims fold into one
+    stride (always for one leading dim; for [B, H, T, D] views of [B, T, H, D] projections whenever B == 1) and the
+    innermost stride is 1 with 16-byte aligned rows; a contiguous copy otherwise"""
+    lead = t.shape[:-2]
+    T, D = t.shape[-2:]
+    if t.stride(-1) == 1 and t.stride(-2) % 4 == 0 and t.data_ptr() % 16 == 0:
+        dims = [(n, st) for n, st in zip(lead, t.stride()[:-2]) if n != 1]
+        ok, bstride = True, (dims[-1][1] if dims else T * D)
+        for (n0, s0), (n1, s1) in zip(dims[:-1], dims[1:]):
+            ok = ok and s0 == n1 * s1
+        if ok and bstride % 4 == 0:
+            nb = 1
+            for n in lead:
+                nb *= n
+            return t.as_strided((nb, T, D), (bstride, t.stride(-2), 1)), bstride, t.stride(-2)
+    c = t.reshape(-1, T, D).contiguous()
+    return c, T * D, D
+
+
 def bfp_attention_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, widths) -> bool:
-    """shapes / widths the one-pass attention kernel takes (include/mi355q.h, mi355q_bfp_attention)"""
-    return (q.is_cuda and k.is_cuda and v.is_cuda and q.dtype == k.dtype == v.dtype == torch.float32 and q.ndim == 3
-            and k.ndim == 3 and v.shape == k.shape and q.shape[0] == k.shape[0] and q.shape[2] == k.shape[2]
-            and 0 < q.shape[0] <= 65535 and 0 < k.shape[1] <= ATTENTION_MAX_KEYS and k.shape[1] % 16 == 0 and q.shape[1] > 0
-            and q.shape[2] % 32 == 0 and 0 < q.shape[2] <= ATTENTION_MAX_HEAD_DIM and all(2 <= int(w) <= 9 for w in widths))
+    """shapes / widths the one-pass attention kernel takes (include/mi355q.h, mi355q_bfp_attention): q [..., M, D],
+    k / v [..., T, D] with equal leading dims"""
+    return (q.is_cuda and k.is_cuda and v.is_cuda and q.dtype == k.dtype == v.dtype == torch.float32 and q.ndim >= 3
+            and k.ndim == q.ndim and v.shape == k.shape and q.shape[:-2] == k.shape[:-2] and q.shape[-1] == k.shape[-1]
+            and 0 < q.shape[:-2].numel() <= 65535 and 0 < k.shape[-2] <= ATTENTION_MAX_KEYS and k.shape[-2] % 16 == 0
+            and q.shape[-2] > 0 and q.shape[-1] % 32 == 0 and 0 < q.shape[-1] <= ATTENTION_MAX_HEAD_DIM
+            and all(2 <= int(w) <= 9 for w in widths))
 
 
 def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, pv_params, *, mask: torch.Tensor = None,
                   causal: bool = False, scale_div: float = None) -> torch.Tensor:
-    """out[b] = Qc(softmax(max(Qa(q[b]) @ Qb(k[b]^T) [/ scale_div] + mask, finfo.min))) @ Qd(v[b]) for q [B, M, D], k and v
-    [B, T, D] fp32 (k untransposed), block_fp [1,16] blocks along each operand's last dim as the reference's two products
-    apply them (matmul.py:146-196); neither scores nor probabilities are written.  qk_params / pv_params:
-    (x width, x exponent width, x exponent bias, y width, y exponent width, y exponent bias) of bmm_0 / bmm_1."""
+    """out[b] = Qc(softmax(max(Qa(q[b]) @ Qb(k[b]^T) [/ scale_div] + mask, finfo.min))) @ Qd(v[b]) for q [..., M, D], k and v
+    [..., T, D] fp32 (k untransposed; strided head views are read in place), block_fp [1,16] blocks along each operand's
+    last dim as the reference's two products apply them (matmul.py:146-196); neither scores nor probabilities are
+    written.  qk_params / pv_params: (x width, x exponent width, x exponent bias, y width, y exponent width, y exponent
+    bias) of bmm_0 / bmm_1.  Returns a contiguous tensor of q's shape."""
     import ctypes
     _require_device(q, "bfp_attention")
     assert bfp_attention_supported(q, k, v, (qk_params[0], qk_params[3], pv_params[0], pv_params[3]))
-    B, M, D = q.shape
-    T = k.shape[1]
-    qc, kc, vc = q.contiguous(), k.contiguous(), v.contiguous()
-    out = torch.empty(B, M, D, dtype=torch.float32, device=q.device)
+    M, D = q.shape[-2:]
+    T = k.shape[-2]
+    q3, qsb, qsm = _as_heads_view(q)
+    k3, ksb, kst = _as_heads_view(k)
+    v3, vsb, vst = _as_heads_view(v)
+    B = q3.shape[0]
+    out = torch.empty(*q.shape, dtype=torch.float32, device=q.device)
     lib = _lib.load_library()
     sp = _stream_ptr(q.device)
     key = (q.device.index, sp, B, T, D)
@@ -768,11 +794,12 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
         assert mask.shape == (M, T) and mask.dtype == torch.float32 and mask.is_contiguous() and mask.device == q.device
     pa = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(qk_params)])
     pb = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(pv_params)])
+    strides = (ctypes.c_int64 * 6)(qsb, qsm, ksb, kst, vsb, vst)
     with _on_device(q.device):
-        rc = lib.mi355q_bfp_attention(_ptr(qc), _ptr(kc), _ptr(vc), _ptr(mask), int(bool(causal)),
-                                      float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(ws), B, M, T, D,
-                                      ctypes.addressof(pa), ctypes.addressof(pb), sp)
-    _lib.check(rc, "mi355q_bfp_attention")
+        rc = lib.mi355q_bfp_attention_strided(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)),
+                                              float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(ws), B, M, T, D,
+                                              ctypes.addressof(pa), ctypes.addressof(pb), ctypes.addressof(strides), sp)
+    _lib.check(rc, "mi355q_bfp_attention_strided")
     return out
 
 

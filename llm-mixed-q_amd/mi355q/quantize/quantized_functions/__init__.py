@@ -140,17 +140,16 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
         for c in (config_qk, config_pv):
             for key in _KEYS["block_fp"]:
                 c[f"data_in_{key}"], c[f"weight_{key}"]
-        q3, k3, v3 = (t.reshape(-1, *t.shape[-2:]) for t in (q, k, v))
+        nb, (tq, hd), tk = q.shape[:-2].numel(), q.shape[-2:], k.shape[-2]
         blocks_ok = all(ops.resolve_blocking(list(shape), bs, True)[3:] == (1, 16) for shape, bs in (
-            (q3.shape, config_qk["data_in_block_size"]), ((k3.shape[0], k3.shape[2], k3.shape[1]), config_qk["weight_block_size"]),
-            ((q3.shape[0], q3.shape[1], k3.shape[1]), config_pv["data_in_block_size"]), (v3.shape, config_pv["weight_block_size"])))
+            ((nb, tq, hd), config_qk["data_in_block_size"]), ((nb, hd, tk), config_qk["weight_block_size"]),
+            ((nb, tq, tk), config_pv["data_in_block_size"]), ((nb, tk, hd), config_pv["weight_block_size"])))
         widths = (config_qk["data_in_width"], config_qk["weight_width"], config_pv["data_in_width"], config_pv["weight_width"])
-        if blocks_ok and ops.bfp_attention_supported(q3, k3, v3, widths) and (not causal or k3.shape[1] >= q3.shape[1]):
+        if blocks_ok and ops.bfp_attention_supported(q, k, v, widths) and (not causal or tk >= tq):
             par = lambda c: (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"], c["weight_width"],
                              c["weight_exponent_width"], c["weight_exponent_bias"])
-            out = ops.bfp_attention(q3, k3, v3, par(config_qk), par(config_pv), mask=None if m2 is None else m2.contiguous(),
-                                    causal=causal, scale_div=scale_div)
-            return out.reshape(*q.shape)
+            return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=None if m2 is None else m2.contiguous(),
+                                     causal=causal, scale_div=scale_div)
     style = "bmm" if q.ndim == 3 else "matmul"
     w = QUANTIZED_FUNC_MAP[style][config_qk["name"]](q, k.transpose(-1, -2), config=config_qk)
     if scale_div:

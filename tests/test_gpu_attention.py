@@ -141,3 +141,20 @@ def test_attention_model_parity():
         (l0, s0), (l1, s1) = outs
         assert abs(float(s0) - float(s1)) <= 2e-3, (family, float(s0), float(s1))
         assert (l0 - l1).abs().max().item() <= 2e-2 * l0.abs().max().item()
+
+
+def test_attention_reads_strided_head_views_in_place():
+    """[B, heads, T, hd] views of [B, T, heads, hd] projections (what the models hand over): same result as contiguous copies,
+    for B == 1 (strides fold, no copy) and B == 2 (a copy inside)"""
+    import torch
+    import mi355q.quantize as Q
+    c0, c1 = _cfg(6), _cfg(6)
+    f = Q.get_quantized_func("attention", c1)
+    for B in (1, 2):
+        g = torch.Generator().manual_seed(B)
+        base = [torch.randn(B, 160, 6, 64, generator=g).to("cuda:0") for _ in range(3)]
+        views = [t.transpose(1, 2) for t in base]
+        assert not views[0].is_contiguous()
+        got = f(*views, c0, c1, causal=True)
+        want = f(*(t.contiguous() for t in views), c0, c1, causal=True)
+        assert got.shape == (B, 6, 160, 64) and got.is_contiguous() and torch.equal(got, want)
