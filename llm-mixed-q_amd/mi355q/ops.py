@@ -468,6 +468,15 @@ def _new_row_list(device, rows, bucket_cap=0):
 
 
 ROW_TILE_ENTRIES_FAST = 48      # entries of one tile (x bucket + w bucket) the row-scale GEMM adds back from spare LDS
+ROW_TILE_ENTRIES_SLOW = 96      # ... from the stage area behind the K loop (gathers exposed: +10-30 us per launch)
+
+
+def gemm_tile_rows(M: int, N: int) -> int:
+    """rows of the tile the row-scale GEMM takes for an M x N output (the launch rule of mi355q_gemm_v8.hip: 256 x 256
+    unless 128 x 256 fills the 256 compute units better).  A 128-row tile sees about half of a 256-row bucket's entries."""
+    tn = -(-N // 256)
+    t256, t128 = -(-M // 256) * tn, -(-M // 128) * tn
+    return 128 if -(-t128 // 256) * 0.82 < -(-t256 // 256) * 1.0 else 256
 
 
 def row_list_fill(lst, rows, bucket_cap=None):

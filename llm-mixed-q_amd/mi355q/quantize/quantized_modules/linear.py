@@ -180,7 +180,16 @@ class _LinearBase(nn.Linear):
                                                     c["data_in_exponent_width"], c["data_in_exponent_bias"],
                                                     bucket_cap=ops.ROW_BUCKET_CAP_MAX)
             x_over, x_max = ops.row_list_fill(xa.sparse, xa.rows, xa.list_cap)
-            fits = x_over == 0 and w_max + x_max <= ops.ROW_TILE_ENTRIES_FAST
+            # (a 128-row tile carries about half of its 256-row bucket's activation entries; 15 % margin for the busier
+            # half.  Measured at 2048 x 4096 -> 4096, tools/time_exception_density.py: the row-scale route wins up to a
+            # fullest activation bucket of ~60 there, the per-block route beyond ~85)
+            # Between 48 and 96 entries a tile forms its vectors behind the K loop: still ahead of the per-block route where
+            # that one runs 256-row tiles (2048 x 4096 -> 11008: 163 vs 208 us at a fullest bucket of 87), behind it on
+            # 128-row tiles (2048 x 4096 -> 4096: 100 vs 91 us).
+            tile_rows = ops.gemm_tile_rows(xa.rows, self.out_features)
+            n_tile = w_max + int(x_max * (0.5 * 1.15 if tile_rows == 128 else 1.0) + 0.999)
+            fits = x_over == 0 and (n_tile <= ops.ROW_TILE_ENTRIES_FAST or
+                                    (tile_rows == 256 and n_tile <= ops.ROW_TILE_ENTRIES_SLOW - 8))
             self._x_cap = ops.ROW_BUCKET_CAP if fits else ops.ROW_NO_ALIGN
         return "rows"
 
