@@ -795,6 +795,8 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     static const bool want_clock = getenv("MI355Q_V8_CLOCK") != nullptr, want_stamps = getenv("MI355Q_V8_STAMPS") != nullptr;
     const bool fix = xlist && wlist;
     if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
+    static const int dbg = getenv("MI355Q_V8_DBG") ? atoi(getenv("MI355Q_V8_DBG")) : 0;    // (stamps build only: see a.dbg)
+    a.dbg = dbg;
     // K-loop schedule of the 256 x 256 tile: 2 = pipelined (one barrier per K-step, default: 71.0 vs 72.8 us at 4096^3),
     // 0 = two staggered wave groups, four barriers per K-step (kept for A/B runs: MI355Q_V8_SCHED=0)
     static const int sched = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
