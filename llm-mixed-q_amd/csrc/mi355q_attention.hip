@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     long long need = g.NT;
     if (g.causal_off >= 0) need = min(g.NT, (min(m0 + 15, g.M - 1) + g.causal_off) / 16 + 1);
     const uint16_t* __restrict__ kfb = g.kf + b * g.NT * DC * 512;
+    const float scale_inv = g.scale_div != 0.f ? 1.0f / g.scale_div : 0.f;
     const float* __restrict__ mrow = HASMASK ? g.mask + qrow * g.T : nullptr;
 
     // ---- scores of this wave's tiles, masked; row maximum.  K fragments arrive in groups of G tiles, the next group
@@ -293,9 +294,9 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[gi & 1][j][c]), qf[c], s, 0, 0, 0);
             if (t < need) {                                // (uniform over the wave)
                 const long long key0 = t * 16 + 4 * lg;
-                if (g.scale_div != 0.f) {
+                if (g.scale_div != 0.f) {                  // (the corrected quotient of at_div: 3 operations instead of ~10)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s[e] = s[e] / g.scale_div;
+                    for (int e = 0; e < 4; ++e) s[e] = at_div(s[e], g.scale_div, scale_inv);
                 }
                 if (HASMASK) {
                     const float4 mk = mb[gi & 1][j];
