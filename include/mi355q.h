@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 8
+#define MI355Q_ABI_VERSION 9
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -318,6 +318,18 @@ int mi355q_bfp_attention(const float* q, const float* k, const float* v, const f
 int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                                  float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D,
                                  const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides, void* stream);
+
+/* ---- the un-blocked quantisers -------------------------------------------------------------------------------------
+ * replaces: quantizers/minifloat.py:134-196 (minifloat_ieee_quantizer: implicit leading one, subnormals at the lowest
+ *           exponent), :21-86 (minifloat_denorm_quantizer: no implicit one, exponent ceil(log2(|x| + 1e-9)) per element)
+ *           and quantizers/log.py:22-56 (log_quantizer: sign * 2^clamp(rint(log2(|x| + 0.1 * 2^-bias)))) behind
+ *           QUANTIZER_MAP["minifloat_ieee" | "minifloat_denorm" | "log"] (quantizers/__init__.py:8-16).
+ * Element-wise over n fp32 values, one fixed exponent_bias (MI355Q_BIAS_DEFAULT: 2^(exponent bits - 1) - 1), bit-exact
+ * with the reference (threshold tables instead of logarithms, like the block formats).  minifloats: |x| <= 1e-8 passes
+ * through; log cannot represent 0.  Bound: HBM, 8 B per element. */
+int mi355q_minifloat_quantize(const float* x, float* y, int64_t n, int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                              int32_t denorm, void* stream);
+int mi355q_log_quantize(const float* x, float* y, int64_t n, int32_t width, int32_t exponent_bias, void* stream);
 
 /* The capture sequence `stream` is recording into a HIP graph (non-zero, unique per capture), or 0 when it is not
  * capturing.  Host-side caches that skip a launch (the Python layer's reuse of an already quantised activation) are

@@ -229,6 +229,37 @@ int mi355q_block_log_quantize(const float* x, float* y, uint8_t* bias, int64_t l
     return launch_quant(a, 2, /*needs_fixup=*/true, static_cast<hipStream_t>(stream));
 }
 
+int mi355q_minifloat_quantize(const float* x, float* y, int64_t n, int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                              int32_t denorm, void* stream) {
+    if (n < 0) return MI355Q_E_BADARG;
+    if (n == 0) return 0;
+    if (!x || !y) return MI355Q_E_BADARG;
+    const int mbits = width - exponent_width - 1;
+    if (exponent_width < 1 || exponent_width > 8 || mbits < 0 || mbits > 23) return MI355Q_E_BADARG;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias < -100 || exponent_bias > 140) return MI355Q_E_UNSUPPORTED;      // (exponents must stay inside fp32's)
+    QuantArgs a{};
+    a.x = x; a.y = y; a.n_elems = n;
+    a.span = (1 << exponent_width) - 1;                       // ieee: e in [-bias, span - bias]
+    a.e_min = -exponent_bias;                                 // denorm: the same range
+    a.e_max = a.span - exponent_bias;
+    set_mantissa(a, mbits);
+    return launch_quant_flat(a, denorm ? 3 : 1, exponent_bias, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_log_quantize(const float* x, float* y, int64_t n, int32_t width, int32_t exponent_bias, void* stream) {
+    if (n < 0 || width < 2 || width > 9) return MI355Q_E_BADARG;      // exponent code of width - 1 <= 8 bits
+    if (n == 0) return 0;
+    if (!x || !y) return MI355Q_E_BADARG;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (width - 2)) - 1;
+    if (exponent_bias < -100 || exponent_bias > 140) return MI355Q_E_UNSUPPORTED;
+    QuantArgs a{};
+    a.x = x; a.y = y; a.n_elems = n;
+    a.span = (1 << (width - 1)) - 1;
+    set_mantissa(a, 0);
+    return launch_quant_flat(a, 2, exponent_bias, static_cast<hipStream_t>(stream));
+}
+
 int mi355q_integer_quantize(const float* x, float* y, int64_t n, int32_t width, int32_t frac_width,
                             int32_t is_signed, void* stream) {
     if (n < 0 || width < 1 || width > 24) return MI355Q_E_BADARG;

@@ -51,6 +51,7 @@ struct RopeArgs {
     long long B, T, D, table_rows;
 };
 int launch_rope(const RopeArgs& a, hipStream_t st);
+int launch_quant_flat(const QuantArgs& a, int fmt, int bias, hipStream_t st);     // fmt 1 minifloat_ieee, 2 log, 3 minifloat_denorm
 int launch_integer(const float* x, float* y, long long n, float scale, float lo, float hi, hipStream_t st);
 
 struct GemmArgs {

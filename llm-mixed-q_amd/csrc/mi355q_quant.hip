@@ -239,6 +239,69 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The un-blocked siblings (minifloat.py:21-196, log.py:22-56): every element by itself with ONE fixed bias -- the
+// element functions of block_minifloat / block_log with the bias a parameter, plus the denormal minifloat (no implicit
+// leading one: exponent ceil(log2(|x| + 1e-9)) per element, mantissa |x| / 2^e without the 1e-9).  Flat float4 stream.
+// ---------------------------------------------------------------------------------------
+constexpr int FMT_DN = 3;
+__device__ __forceinline__ float quant_denorm(float x, const QuantArgs& a, const Lut& lut) {
+    const float ax = fabsf(x);
+    const float s = sgn(x + EPS9);
+    const int e = clampi(ceil_log2(ax + EPS9, lut), a.e_min, a.e_max);
+    const float m = clampf(__builtin_rintf(__builtin_ldexpf(ax, -e) * a.shift), 0.f, a.mant_max);
+    const float q = __builtin_ldexpf(s, e) * (m * a.inv_shift);
+    return ax <= ATOL ? x + 0.0f : q;       // (+ 0: the reference's mask arithmetic turns -0.0 into +0.0)
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void quant_flat_kernel(const QuantArgs a, int bias) {
+    __shared__ Lut lut;
+    load_lut<FMT == FMT_DN ? FMT_BFP : FMT>(lut);
+    BlockParam bp;
+    bp.p = bias;
+    bp.eps = FMT == FMT_BL ? (float)(__builtin_ldexp(1.0, -bias) * 0.1) : 0.f;     // (python float arithmetic: log.py:45-48)
+    const long long n4 = a.n_elems >> 2, stride = (long long)gridDim.x * blockDim.x;
+    auto one = [&](float v) {
+        int mant;
+        return FMT == FMT_DN ? quant_denorm(v, a, lut) : quant_elem<FMT>(v, bp, a, lut, mant);
+    };
+    if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y)) % 16 == 0) {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
+        float4* __restrict__ y4 = reinterpret_cast<float4*>(a.y);
+        // (the rare-lookup shortcuts of floor_log2 / rint_log2 vote over the wave: every lane takes every trip)
+        const long long n4_pad = (n4 + 63) & ~63ll;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4_pad; i += stride) {
+            float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (i < n4) v = x4[i];
+            const float4 o = make_float4(one(v.x), one(v.y), one(v.z), one(v.w));
+            if (i < n4) y4[i] = o;
+        }
+        const long long tail0 = n4 << 2, ntail = a.n_elems - tail0;
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            const float v = (long long)threadIdx.x < ntail ? a.x[tail0 + threadIdx.x] : 1.f;
+            const float o = one(v);
+            if ((long long)threadIdx.x < ntail) a.y[tail0 + threadIdx.x] = o;
+        }
+    } else {
+        const long long n_pad = (a.n_elems + 63) & ~63ll;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {
+            const float v = i < a.n_elems ? a.x[i] : 1.f;
+            const float o = one(v);
+            if (i < a.n_elems) a.y[i] = o;
+        }
+    }
+}
+
+static int grid_for(long long work_items, int per_block);
+int launch_quant_flat(const QuantArgs& a, int fmt, int bias, hipStream_t st) {
+    const int grid = grid_for((a.n_elems >> 2) + 64, 256);
+    if (fmt == FMT_BM) hipLaunchKernelGGL((quant_flat_kernel<FMT_BM>), grid, 256, 0, st, a, bias);
+    else if (fmt == FMT_BL) hipLaunchKernelGGL((quant_flat_kernel<FMT_BL>), grid, 256, 0, st, a, bias);
+    else hipLaunchKernelGGL((quant_flat_kernel<FMT_DN>), grid, 256, 0, st, a, bias);
+    return (int)hipGetLastError();
+}
+
 // integer fixed point (integer.py:49-52): clamp(rint(x * 2^f), lo, hi) / 2^f
 __global__ __launch_bounds__(256) void integer_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       long long n, float scale, float lo, float hi) {

@@ -126,7 +126,7 @@ __device__ __forceinline__ float quant_elem(float x, const BlockParam& bp, const
         const float m = clampf(__builtin_rintf(r), 0.f, a.mant_max);
         mant = (int)(s * m);
         const float q = __builtin_ldexpf(s, bp.p) * (m * a.inv_shift);
-        return ax <= ATOL ? x : q;
+        return ax <= ATOL ? x + 0.0f : q;      // (+ 0: the reference's mask arithmetic turns -0.0 into +0.0)
     } else if (FMT == FMT_BM) {     // minifloat.py:165-194 with exponent_bias = bp.p
         const float s = sgn(x + EPS9);
         const int e_min = -bp.p, e_max = a.span - bp.p;
@@ -138,7 +138,7 @@ __device__ __forceinline__ float quant_elem(float x, const BlockParam& bp, const
         const float frac = normal ? (1.0f + sm * a.inv_shift) : (sm * a.inv_shift * 2.0f);
         const float q = __builtin_ldexpf(s, e) * frac;
         mant = 0;
-        return ax <= ATOL ? x : q;
+        return ax <= ATOL ? x + 0.0f : q;      // (+ 0: the reference's mask arithmetic turns -0.0 into +0.0)
     } else {                        // log.py:47-56 with exponent_bias = bp.p
         const float s = sgn(x + bp.eps);
         const float v = ax + bp.eps;

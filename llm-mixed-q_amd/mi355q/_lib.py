@@ -27,6 +27,8 @@ SIGNATURES = {
                                                   _i32, _i32, _i32, _u32, _vp, _vp]),
     "mi355q_block_log_quantize": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                             _i32, _i32, _u32, _vp, _vp]),
+    "mi355q_minifloat_quantize": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_log_quantize": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "mi355q_integer_quantize": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                   _i32, _i32, _i32, _i32, _vp]),
@@ -62,7 +64,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

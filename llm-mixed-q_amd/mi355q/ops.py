@@ -347,6 +347,30 @@ def block_log_quantize(x: torch.Tensor, width: int, exponent_bias_width: int, bl
     return (y, bias) if want_bias else y
 
 
+def minifloat_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent_bias=None, *, denorm: bool = False) -> torch.Tensor:
+    """minifloat_ieee_quantizer / minifloat_denorm_quantizer of the reference (minifloat.py:134-196 / 21-86), element-wise"""
+    _require_device(x, "minifloat_quantize")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    with _on_device(x.device):
+        rc = _lib.load_library().mi355q_minifloat_quantize(_ptr(xc), _ptr(y), xc.numel(), int(width), int(exponent_width),
+                                                           _default_bias(exponent_bias), int(bool(denorm)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_minifloat_quantize")
+    return y
+
+
+def log_quantize(x: torch.Tensor, width: int, exponent_bias=None) -> torch.Tensor:
+    """log_quantizer of the reference (log.py:22-56), element-wise"""
+    _require_device(x, "log_quantize")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    with _on_device(x.device):
+        rc = _lib.load_library().mi355q_log_quantize(_ptr(xc), _ptr(y), xc.numel(), int(width), _default_bias(exponent_bias),
+                                                     _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_log_quantize")
+    return y
+
+
 def integer_quantize(x: torch.Tensor, width: int, frac_width: int, is_signed: bool = True) -> torch.Tensor:
     _require_device(x, "integer_quantize")
     xc = x.contiguous()

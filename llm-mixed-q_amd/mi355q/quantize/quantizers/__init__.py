@@ -1,6 +1,6 @@
 """Quantiser registry -- same keys and call signatures as the reference's
-`models/quantize/quantizers/__init__.py:8-16`; the three block formats and `integer` run as HIP
-kernels (mi355q.ops), backward is the reference's straight-through estimator."""
+`models/quantize/quantizers/__init__.py:8-16`; all seven run as HIP kernels (mi355q.ops), backward is
+the reference's straight-through estimator."""
 from __future__ import annotations
 
 import torch
@@ -26,6 +26,9 @@ _FORWARD = {
     "block_minifloat": lambda x, w, ew, ebw, bs, skip: ops.block_minifloat_quantize(x, w, ew, ebw, bs, skip),
     "block_log": lambda x, w, ebw, bs, skip: ops.block_log_quantize(x, w, ebw, bs, skip),
     "integer": lambda x, w, fw, signed: ops.integer_quantize(x, w, fw, signed),
+    "minifloat_ieee": lambda x, w, ew, eb: ops.minifloat_quantize(x, w, ew, eb),
+    "minifloat_denorm": lambda x, w, ew, eb: ops.minifloat_quantize(x, w, ew, eb, denorm=True),
+    "log": lambda x, w, eb: ops.log_quantize(x, w, eb),
 }
 
 
@@ -54,18 +57,20 @@ def integer_quantizer(x, width: int, frac_width: int, is_signed: bool = True):
     return _STE.apply(x, "integer", (width, frac_width, is_signed))
 
 
-def _off_path(name):
-    def f(*args, **kwargs):
-        raise NotImplementedError(
-            f"quantizer '{name}' is not on the MI355X block-quantised hot path (SURVEY.md 8a); "
-            "only block_fp, block_minifloat, block_log and integer are built as HIP kernels")
-    f.__name__ = f"{name}_quantizer"
-    return f
+def minifloat_ieee_quantizer(x, width: int, exponent_width: int, exponent_bias: int = None):
+    """reference minifloat.py:216-240"""
+    return _STE.apply(x, "minifloat_ieee", (width, exponent_width, exponent_bias))
 
 
-log_quantizer = _off_path("log")
-minifloat_denorm_quantizer = _off_path("minifloat_denorm")
-minifloat_ieee_quantizer = _off_path("minifloat_ieee")
+def minifloat_denorm_quantizer(x, width: int, exponent_width: int, exponent_bias: int = None):
+    """reference minifloat.py:106-131"""
+    return _STE.apply(x, "minifloat_denorm", (width, exponent_width, exponent_bias))
+
+
+def log_quantizer(x, width: int, exponent_bias: int = None):
+    """reference log.py:59-87 (backward: identity on x, log.py:66-69)"""
+    return _STE.apply(x, "log", (width, exponent_bias))
+
 
 QUANTIZER_MAP = {
     "block_fp": block_fp_quantizer,

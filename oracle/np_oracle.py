@@ -321,6 +321,66 @@ def block_log_quantize(x, width: int, exponent_bias_width: int = None, block_siz
 
 
 # ----------------------------------------------------------------------------------
+# element-wise minifloats and log (minifloat.py:21-86, 134-196; log.py:22-56): the un-blocked siblings, one fixed bias
+# ----------------------------------------------------------------------------------
+def _default_bias(exponent_bias, exponent_bits: int) -> int:
+    return 2 ** (int(exponent_bits) - 1) - 1 if exponent_bias in (None, "none", "None") else int(exponent_bias)
+
+
+def minifloat_ieee_quantize(x, width: int, exponent_width: int, exponent_bias=None) -> np.ndarray:
+    """== reference ``minifloat_ieee_quantizer`` (minifloat.py:134-196): implicit leading one, subnormals at the lowest
+    exponent, saturating, |x| <= 1e-8 passed through."""
+    x = np.asarray(x, dtype=F32)
+    mbits = int(width) - int(exponent_width) - 1
+    bias = _default_bias(exponent_bias, exponent_width)
+    e_max, e_min = F32(2 ** int(exponent_width) - 1 - bias), F32(-bias)
+    sign = np.sign(x + _EPS9)
+    value = np.abs(x)
+    e = np.clip(np.floor(log2_f32(value + _EPS9)), e_min, e_max).astype(F32)
+    shift = F32(2 ** mbits)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        mant = value / pow2_f32(e)
+        normal = e != e_min
+        sm = np.where(normal, np.clip(np.rint(mant * shift - shift), 0, 2 ** mbits - 1),
+                      np.clip(np.rint(mant * shift / F32(2.0)), 0, 2 ** mbits - 1)).astype(F32)
+        frac = np.where(normal, F32(1.0) + sm / shift, (sm / shift) * F32(2.0)).astype(F32)
+        q = (sign * pow2_f32(e)) * frac
+    return _passthrough_mix(value <= _ATOL, q.astype(F32), x)
+
+
+def minifloat_denorm_quantize(x, width: int, exponent_width: int, exponent_bias=None) -> np.ndarray:
+    """== reference ``minifloat_denorm_quantizer`` (minifloat.py:21-86): no implicit leading one, per-element exponent
+    ceil(log2(|x| + 1e-9)), mantissa |x| / 2^e (WITHOUT the 1e-9) rounded to mantissa_bits."""
+    x = np.asarray(x, dtype=F32)
+    mbits = int(width) - int(exponent_width) - 1
+    bias = _default_bias(exponent_bias, exponent_width)
+    e_max, e_min = F32(2 ** int(exponent_width) - 1 - bias), F32(-bias)
+    sign = np.sign(x + _EPS9)
+    value = np.abs(x)
+    e = np.clip(np.ceil(log2_f32(value + _EPS9)), e_min, e_max).astype(F32)
+    shift = F32(2 ** mbits)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        sm = np.clip(np.rint((value / pow2_f32(e)) * shift), 0, 2 ** mbits - 1).astype(F32)
+        q = (sign * pow2_f32(e)) * (sm / shift)
+    return _passthrough_mix(value <= _ATOL, q.astype(F32), x)
+
+
+def log_quantize(x, width: int, exponent_bias=None) -> np.ndarray:
+    """== reference ``log_quantizer`` (log.py:22-56): sign * 2^clamp(rint(log2(|x| + 0.1 * 2^-bias))); cannot
+    represent 0, no pass-through."""
+    x = np.asarray(x, dtype=F32)
+    ebits = int(width) - 1
+    bias = _default_bias(exponent_bias, ebits)
+    e_max, e_min = F32(2 ** ebits - 1 - bias), F32(-bias)
+    eps = F32(np.float64(2.0) ** (-bias) * 0.1)       # (python float arithmetic, then the tensor's dtype: log.py:45-48)
+    sign = np.sign(x + eps)
+    value = np.abs(x) + eps
+    e = np.clip(np.rint(log2_f32(value)), e_min, e_max)
+    with np.errstate(over="ignore"):
+        return (sign * pow2_f32(e)).astype(F32)
+
+
+# ----------------------------------------------------------------------------------
 # integer fixed point (RoPE tables in every shipped TOML; integer.py:25-58)
 # ----------------------------------------------------------------------------------
 def integer_quantize(x, width: int, frac_width: int, is_signed: bool = True) -> np.ndarray:

@@ -552,3 +552,33 @@ def test_out_buffers_move_their_version_counter():
         finally:
             ops.REUSE_QUANTISED_INPUT = True
     assert not torch.equal(outs[0], outs[1])
+
+
+def test_linear_and_matmul_in_the_unblocked_arithmetics():
+    """LinearMinifloatIEEE / LinearMinifloatDenorm and the matmul functions of the un-blocked arithmetics run on the HIP
+    quantisers (reference linear.py:206-259, matmul.py:36-143); LinearLog fails at its first forward like the reference's
+    (it hands `exponent_width` to log_quantizer: SURVEY 8a quirk 3)"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    dev = "cuda:0"
+    torch.manual_seed(2)
+    x = torch.randn(3, 40, 96, device=dev)
+    for name, f in (("minifloat_ieee", O.minifloat_ieee_quantize), ("minifloat_denorm", O.minifloat_denorm_quantize)):
+        cfg = dict(name=name, is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4, data_in_exponent_bias=None,
+                   weight_width=8, weight_exponent_width=4, weight_exponent_bias=9, bias_width=8, bias_exponent_width=4,
+                   bias_exponent_bias=None)
+        lin = Q.get_quantized_cls("linear", cfg)(96, 64, bias=True, config=cfg).to(dev)
+        w0, b0 = lin.weight.detach().cpu().numpy().copy(), lin.bias.detach().cpu().numpy().copy()
+        y = lin(x).detach().cpu().numpy()
+        xq = f(x.cpu().numpy(), 8, 4, None)
+        wq, bq = f(w0, 8, 4, 9), f(b0, 8, 4, None)
+        assert np.array_equal(lin.weight.detach().cpu().numpy(), wq)
+        np.testing.assert_allclose(y, xq @ wq.T + bq, rtol=1e-4, atol=1e-5)
+        mm = Q.get_quantized_func("matmul", cfg)(x, x.transpose(1, 2).contiguous(), cfg).cpu().numpy()
+        np.testing.assert_allclose(mm, xq @ np.swapaxes(f(np.swapaxes(x.cpu().numpy(), 1, 2).copy(), 8, 4, 9), 0, 0), rtol=1e-4, atol=1e-4)
+    cfg = dict(name="log", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4, data_in_exponent_bias=None,
+               weight_width=8, weight_exponent_width=4, weight_exponent_bias=None, bias_width=8, bias_exponent_width=4,
+               bias_exponent_bias=None)
+    with pytest.raises(TypeError):
+        Q.get_quantized_cls("linear", cfg)(96, 64, bias=True, config=cfg).to(dev)(x)

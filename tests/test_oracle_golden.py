@@ -105,3 +105,25 @@ def test_matmul_matches_reference(tag, op, golden_modules):
     out = O.matmul_quantized(data[f"{tag}/{op}/x"], data[f"{tag}/{op}/y"], cfg)
     ref = data[f"{tag}/{op}/out"]
     np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+def test_elementwise_quantizers_match_reference_fixtures():
+    """minifloat_ieee / minifloat_denorm / log (minifloat.py:21-196, log.py:22-56): the oracle on the fixtures that
+    tools/gen_golden.py:gen_elementwise generated by running the reference, bit for bit; plus the two known-answer values of
+    the reference's docstrings"""
+    import json
+    from pathlib import Path
+    import numpy as np
+    from oracle import np_oracle as O
+    g = Path(__file__).parent / "golden"
+    z, cases = np.load(g / "elementwise.npz"), json.loads((g / "elementwise.json").read_text())
+    fns = {"minifloat_ieee": O.minifloat_ieee_quantize, "minifloat_denorm": O.minifloat_denorm_quantize, "log": O.log_quantize}
+    assert len(cases) == 70
+    for tag, c in cases.items():
+        got = fns[c["quantizer"]](z[f"x/{c['input']}"], **c["params"])
+        assert np.array_equal(got.view(np.uint32), z[f"y/{tag}"].view(np.uint32)), tag
+    kat = json.loads((g / "kat.json").read_text())
+    # 1 0111 011 with bias 15: (-1) * 2^(7-15) * (1 + 3/8) resp. * (3/8); both are fixed points of their quantiser
+    for name, f in (("minifloat_ieee_8_4_bias15", O.minifloat_ieee_quantize), ("minifloat_denorm_8_4_bias15", O.minifloat_denorm_quantize)):
+        v = np.float32(kat[name]["value"])
+        assert f(np.array([v]), 8, 4, 15)[0] == v

@@ -366,6 +366,38 @@ def gen_config_and_profile(refq):
     print(f"config/profile: {len(out['parse_node_config'])} parse cases")
 
 
+def gen_elementwise(refq):
+    """The un-blocked quantisers (minifloat.py:21-196, log.py:22-56): reference outputs on the edge sets and random
+    tensors, several (width, exponent width, bias) settings each -> tests/golden/elementwise.{npz,json}"""
+    r = np.random.default_rng(11)
+    inputs = {"edge": edge_values().reshape(-1), "randn": r.normal(size=(37, 53)).astype(np.float32),
+              "scaled": (r.normal(size=(16, 64)) * np.exp(r.normal(size=(16, 1)) * 4)).astype(np.float32),
+              "tiny": (r.normal(size=(8, 48)) * 1e-6).astype(np.float32), "zeros": np.zeros((3, 17), np.float32)}
+    settings = {
+        "minifloat_ieee": [dict(width=8, exponent_width=4, exponent_bias=None), dict(width=8, exponent_width=4, exponent_bias=15),
+                           dict(width=6, exponent_width=3, exponent_bias=2), dict(width=12, exponent_width=5, exponent_bias=None),
+                           dict(width=5, exponent_width=4, exponent_bias=-3)],
+        "minifloat_denorm": [dict(width=8, exponent_width=4, exponent_bias=None), dict(width=8, exponent_width=4, exponent_bias=15),
+                             dict(width=6, exponent_width=3, exponent_bias=2), dict(width=12, exponent_width=5, exponent_bias=None),
+                             dict(width=5, exponent_width=4, exponent_bias=-3)],
+        "log": [dict(width=8, exponent_bias=None), dict(width=8, exponent_bias=100), dict(width=4, exponent_bias=3),
+                dict(width=6, exponent_bias=-2)],
+    }
+    arrays, cases = {}, {}
+    for iname, x in inputs.items():
+        arrays[f"x/{iname}"] = x
+    for qname, plist in settings.items():
+        fn = refq.quantizers.QUANTIZER_MAP[qname]
+        for pi, params in enumerate(plist):
+            for iname, x in inputs.items():
+                tag = f"{qname}/{pi}/{iname}"
+                arrays[f"y/{tag}"] = fn(torch.from_numpy(x.copy()), **params).numpy()
+                cases[tag] = {"quantizer": qname, "params": params, "input": iname}
+    np.savez_compressed(OUT / "elementwise.npz", **arrays)
+    (OUT / "elementwise.json").write_text(json.dumps(cases, indent=1))
+    print(f"elementwise: {len(cases)} cases")
+
+
 def gen_kat():
     """The two scalar known-answer values the reference's docstrings hold (minifloat.py:41-43,150-153)."""
     (OUT / "kat.json").write_text(json.dumps({
@@ -380,6 +412,7 @@ def main():
     gen_quantizers(refq)
     gen_modules(refq)
     gen_config_and_profile(refq)
+    gen_elementwise(refq)
     gen_kat()
 
 
