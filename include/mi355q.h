@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 9
+#define MI355Q_ABI_VERSION 10
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -305,10 +305,14 @@ int mi355q_bfp_softmax_matmul(const float* scores, const float* mask, int32_t ca
  * causal != 0: query i sees keys 0 .. i + T - M; scale_div: 0 = none (OPT scales q beforehand), else scores / scale_div
  * (Llama: sqrt(head_dim)).  qk_params / pv_params: {x width, exponent width, exponent bias, y width, exponent width,
  * exponent bias} of bmm_0 / bmm_1.  Neither scores nor probabilities are written anywhere: a workgroup keeps the score
- * strip of its 16 queries in MFMA accumulators.  T <= 2048, T % 16 == 0, D % 32 == 0, D <= 128, widths <= 9, else
- * MI355Q_E_UNSUPPORTED (callers then chain mi355q_bfp_matmul and mi355q_bfp_softmax_matmul).  Key tiles behind the
- * horizon of a workgroup's last query are skipped (probabilities exactly 0 there). */
+ * strip of its 16 queries in MFMA accumulators (T <= 2048), or forms the scores twice -- statistics, then probabilities --
+ * with the K / V fragments staged through LDS for 64 queries at a time (any T).  T % 16 == 0, D % 32 == 0, D <= 128,
+ * widths <= 9, else MI355Q_E_UNSUPPORTED (callers then chain mi355q_bfp_matmul and mi355q_bfp_softmax_matmul).  Key tiles
+ * behind the horizon of a workgroup's last query are skipped (probabilities exactly 0 there). */
 size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D);
+/* Which of the two kernels serves mi355q_bfp_attention: 0 = by size (default), 1 = scores resident in registers
+ * (T <= 2048), 2 = streaming (scores formed twice, any T).  Returns the previous setting.  For A/B runs and tests. */
+int mi355q_bfp_attention_set_kernel(int which);
 int mi355q_bfp_attention(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                          float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                          const int32_t* pv_params, void* stream);

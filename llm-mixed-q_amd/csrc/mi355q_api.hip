@@ -516,6 +516,8 @@ int mi355q_rope_apply(const float* q, const float* k, const float* cos_q, const 
     return launch_rope(a, static_cast<hipStream_t>(stream));
 }
 
+int mi355q_bfp_attention_set_kernel(int which) { return attention_set_kernel(which); }
+
 size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D) {
     if (B <= 0 || T <= 0 || D <= 0) return 0;
     return attention_workspace_bytes(B, T, D);

@@ -140,12 +140,12 @@ __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, 
 }
 
 // ---- v [B, T, D] -> fragments of Qd(v): blocks of 16 along D at a fixed key ------------------------------------------
-// piece (b, dt, pair) = 1 KiB, pair = 4 s + w <-> key tiles a = 8 s + w, b = 8 s + 4 + w (wave w's s-th pair):
+// piece (b, pair, dt) = 1 KiB, pair = 4 s + w <-> key tiles a = 8 s + w, b = 8 s + 4 + w (wave w's s-th pair; kw = 4):
 // lane (d = 16 dt + lane % 16, g = lane / 16) holds slot j <-> key 16 (j < 4 ? a : b) + 4 g + (j & 3).  Keys behind T: 0.
 // One workgroup = 128 keys (8 tiles = 4 pairs) x D; thread (key, 16-d block) quantises one block.
 __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, uint16_t* __restrict__ stage,
                                             const float* __restrict__ v, uint16_t* __restrict__ vf, long long T, int D,
-                                            long long NPAIR, long long bx, long long sb, long long st) {
+                                            long long NPAIR, long long bx, long long sb, long long st, int kw) {
     // stage: [dt][pair in group (w)][lane][8]
     const int tid = threadIdx.x, DT = D >> 4;
     const long long b = blockIdx.y, key0 = bx * 128;
@@ -164,8 +164,11 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
         }
         unsigned code;
         const int p = bmax != 0.f ? block_param<FMT_BFP>(bmax, a, lut, code).p : 0;
-        // key inside the 128-group: tile tl = kl / 16 (0..7) -> pair w = tl & 3, half h = tl >> 2; g = (kl & 15) / 4
-        const int tl = kl >> 4, w = tl & 3, h = tl >> 2, g = (kl & 15) >> 2, j = 4 * h + (kl & 3);
+        // key inside the 128-group: tile tl = kl / 16 (0..7) -> pair w of the group and half h of the pair -- tiles
+        // (w, w + 4) for the resident kernel's four key-waves (kw = 4), consecutive tiles (2 w, 2 w + 1) for the streaming
+        // kernel (kw = 1); g = (kl & 15) / 4
+        const int tl = kl >> 4, w = kw == 4 ? tl & 3 : tl >> 1, h = kw == 4 ? tl >> 2 : tl & 1, g = (kl & 15) >> 2,
+                  j = 4 * h + (kl & 3);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const float q = bmax != 0.f ? at_quant(x[c], mbits - p, p - mbits, a.mant_max) : 0.f;
@@ -176,7 +179,7 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
     const long long s = bx;                                // pair group: pairs 4 s .. 4 s + 3
     for (int ch = tid; ch < DT * 4 * 64; ch += 256) {
         const int dt = ch / 256, w = (ch >> 6) & 3, ln = ch & 63;
-        *reinterpret_cast<uint4*>(vf + (((b * DT + dt) * NPAIR + 4 * s + w) * 64 + ln) * 8) =
+        *reinterpret_cast<uint4*>(vf + (((b * NPAIR + 4 * s + w) * DT + dt) * 64 + ln) * 8) =
             *reinterpret_cast<const uint4*>(&stage[((dt * 4 + w) * 64 + ln) * 8]);
     }
 }
@@ -186,12 +189,12 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, c
                                                            const float* __restrict__ v, uint16_t* __restrict__ kf,
                                                            uint16_t* __restrict__ vf, long long T, int D, long long NT,
                                                            long long NPAIR, int kblocks, long long ksb, long long kst,
-                                                           long long vsb, long long vst) {
+                                                           long long vsb, long long vst, int kw) {
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) uint16_t buf[AT_MAX_D / 16 * 4 * 512];
     load_lut<FMT_BFP>(lut);
     if ((int)blockIdx.x < kblocks) attn_pack_k(ak, lut, buf, k, kf, T, D, NT, blockIdx.x, ksb, kst);
-    else attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst);
+    else attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst, kw);
 }
 
 // ---- the attention pass ------------------------------------------------------------------------------------------------
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
         const long long sc = min((long long)sp, slast);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            dst[dt] = *reinterpret_cast<const uint4*>(vfb + ((dt * g.NPAIR + 4 * sc + wave) * 64 + lane) * 8);
+            dst[dt] = *reinterpret_cast<const uint4*>(vfb + (((4 * sc + wave) * DT + dt) * 64 + lane) * 8);
     };
     load_pair(0, vb[0]);
 #pragma unroll
@@ -398,6 +401,193 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     }
 }
 
+// ---- the same pass for any number of keys: scores are not kept but formed twice ----------------------------------------
+// A workgroup is 64 queries (4 waves x 16) that walk the key tiles together, 32 keys a step; the step's K (and, second
+// time round, V) fragments come into LDS by LDS-DMA one step ahead, ONE barrier a step, and all four waves read them from
+// there: each fragment leaves the L2 once per 64 queries (the resident kernel above: once per 32).  Pass 1 keeps, per
+// lane, a running maximum and sum of exponentials of its scores (re-based when the maximum moves: rare after the first
+// tiles) -- combined over the four lanes of a query at the end; pass 2 forms the scores again (the same MFMAs on the same
+// operands: the same bits), turns them into probabilities with the final statistics, quantises, multiplies with V.  No
+// cross-wave exchange at all, ~90 VGPRs (4-5 waves per SIMD against 2), any T.  The sum of exponentials is accumulated
+// in a different order than in the resident kernel (and than torch's): 1e-7 relative, inside the functions' tolerance.
+template <int DC, bool HASMASK>
+__global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
+    constexpr int DT = DC * 2, KSTEP = 2 * DC * 1024, VSTEP = DT * 1024, STEP = KSTEP + VSTEP;      // bytes per 32 keys
+    constexpr float FMIN = -3.4028234663852886e38f;
+    using gptr_t = const __attribute__((address_space(1))) void*;
+    using lptr_t = __attribute__((address_space(3))) void*;
+    __shared__ Lut lut;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[2][STEP];
+    load_lut<FMT_BFP>(lut);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, lg = lane >> 4;
+    const long long b = blockIdx.y;
+    const long long wg0 = (long long)(g.causal_off >= 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 64;   // heavy blocks first
+    const long long m0 = wg0 + 16 * wave;
+    const long long qrow = min(m0 + c16, g.M - 1);
+    const int D = DC * 32;
+    bf16x8 qf[DC];
+    {
+        const int mb = (int)__builtin_log2f(aq.shift);
+        const float* __restrict__ qp = g.q + b * g.qsb + qrow * g.qsm;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            const float4 lo = *reinterpret_cast<const float4*>(qp + 32 * c + 8 * lg);
+            const float4 hi = *reinterpret_cast<const float4*>(qp + 32 * c + 8 * lg + 4);
+            float bmax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(lo.w))),
+                               fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fmaxf(fabsf(hi.z), fabsf(hi.w))));
+            bmax = at_max2_16(bmax);
+            unsigned code;
+            const int p = block_param<FMT_BFP>(bmax != 0.f ? bmax : 1.0f, aq, lut, code).p;
+            const int up = mb - p, dn = p - mb;
+            uint4 pk;
+            pk.x = pack_bf16(at_quant(lo.x, up, dn, aq.mant_max), at_quant(lo.y, up, dn, aq.mant_max));
+            pk.y = pack_bf16(at_quant(lo.z, up, dn, aq.mant_max), at_quant(lo.w, up, dn, aq.mant_max));
+            pk.z = pack_bf16(at_quant(hi.x, up, dn, aq.mant_max), at_quant(hi.y, up, dn, aq.mant_max));
+            pk.w = pack_bf16(at_quant(hi.z, up, dn, aq.mant_max), at_quant(hi.w, up, dn, aq.mant_max));
+            qf[c] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    const long long kvis = g.causal_off >= 0 ? qrow + g.causal_off : g.T - 1;
+    long long need = g.NT;                                  // tiles the WORKGROUP walks: up to its last query's horizon
+    if (g.causal_off >= 0) need = min(g.NT, (min(wg0 + 63, g.M - 1) + g.causal_off) / 16 + 1);
+    const int nsteps = (int)((need + 1) / 2);
+    const unsigned char* __restrict__ kfb = reinterpret_cast<const unsigned char*>(g.kf) + b * g.NT * DC * 1024;
+    const unsigned char* __restrict__ vfb = reinterpret_cast<const unsigned char*>(g.vf) + b * g.NPAIR * DT * 1024;
+    const float* __restrict__ mrow = HASMASK ? g.mask + qrow * g.T : nullptr;
+    const float scale_inv = g.scale_div != 0.f ? 1.0f / g.scale_div : 0.f;
+
+    // LDS-DMA of one step: K pieces (2 DC KiB, contiguous) and, when with_v, V pieces (DT KiB, contiguous); piece p by wave p % 4
+    // (an odd tile count: the last step's second tile reads DC KiB past this batch's K fragments -- the next batch's, or the
+    //  V fragments that follow in the workspace; its scores are never used)
+    auto dma = [&](int st, int buf, bool with_v) {
+#pragma unroll
+        for (int p = 0; p < 2 * DC; ++p)
+            if ((p & 3) == wave)
+                __builtin_amdgcn_global_load_lds((gptr_t)(kfb + (long long)st * KSTEP + p * 1024 + lane * 16),
+                                                 (lptr_t)(&stage[buf][p * 1024]), 16, 0, 0);
+        if (with_v) {
+#pragma unroll
+            for (int p = 0; p < DT; ++p)
+                if ((p & 3) == wave)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(vfb + (long long)st * VSTEP + p * 1024 + lane * 16),
+                                                     (lptr_t)(&stage[buf][KSTEP + p * 1024]), 16, 0, 0);
+        }
+    };
+    // scores of the step's two tiles for this lane's query: s[h][e] <-> key 32 st + 16 h + 4 lg + e, masked
+    auto scores = [&](int st, int buf, f32x4 (&sv)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const uint4 kv = *reinterpret_cast<const uint4*>(&stage[buf][(h * DC + c) * 1024 + lane * 16]);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kv), qf[c], s, 0, 0, 0);
+            }
+            const long long t = 2ll * st + h, key0 = t * 16 + 4 * lg;
+            if (t < need) {
+                if (g.scale_div != 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] = at_div(s[e], g.scale_div, scale_inv);
+                }
+                if (HASMASK) {
+                    const float4 mk = *reinterpret_cast<const float4*>(mrow + key0);
+                    s[0] = fmaxf(s[0] + mk.x, FMIN); s[1] = fmaxf(s[1] + mk.y, FMIN);
+                    s[2] = fmaxf(s[2] + mk.z, FMIN); s[3] = fmaxf(s[3] + mk.w, FMIN);
+                }
+                if (g.causal_off >= 0 && t * 16 + 15 > m0 + g.causal_off) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key0 + e > kvis) s[e] = FMIN;
+                }
+            } else {
+                s = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};       // (not a tile of this product)
+            }
+            sv[h] = s;
+        }
+    };
+
+    // ---- pass 1: running maximum and sum of exponentials per lane
+    float m_run = -INFINITY, l_run = 0.f;
+    dma(0, 0, false);
+    for (int st = 0; st < nsteps; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < nsteps) dma(st + 1, (st + 1) & 1, false);
+        f32x4 sv[2];
+        scores(st, st & 1, sv);
+        const float tmax = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
+                                 fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
+        if (__any(tmax > m_run)) {                          // re-base (exp(-inf) = 0 takes care of the first tile)
+            const float m_new = fmaxf(m_run, tmax);
+            l_run = m_new == -INFINITY ? 0.f : l_run * at_exp_neg(m_run - m_new);
+            m_run = m_new;
+        }
+        float add = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) add += sv[h][e] == -INFINITY ? 0.f : at_exp_neg(sv[h][e] - m_run);
+        l_run += add;
+    }
+    const float row_max = at_max4(m_run);
+    const float row_sum = at_sum4(m_run == -INFINITY ? 0.f : l_run * at_exp_neg(m_run - row_max));
+    const float row_inv = 1.0f / row_sum;
+    __syncthreads();                                        // (every wave is out of the last step's buffer)
+
+    // ---- pass 2: the scores again, probabilities, quantised, times V
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int mbp = (int)__builtin_log2f(ap.shift);
+    dma(0, 0, true);
+    for (int st = 0; st < nsteps; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < nsteps) dma(st + 1, (st + 1) & 1, true);
+        f32x4 sv[2];
+        scores(st, st & 1, sv);
+        float pq[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float pr[4];
+            float bmax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pr[e] = sv[h][e] == -INFINITY ? 0.f : at_div(at_exp_neg(sv[h][e] - row_max), row_sum, row_inv);
+                bmax = fmaxf(bmax, pr[e]);
+            }
+            bmax = at_max4(bmax);
+            const int p = at_block_exponent(bmax, ap, lut);
+            const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pq[4 * h + e] = at_quant_pos(pr[e], sc_up, sc_dn, ap.mant_max);
+        }
+        uint4 pk;
+        pk.x = pack_bf16(pq[0], pq[1]); pk.y = pack_bf16(pq[2], pq[3]);
+        pk.z = pack_bf16(pq[4], pq[5]); pk.w = pack_bf16(pq[6], pq[7]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const uint4 vv = *reinterpret_cast<const uint4*>(&stage[st & 1][KSTEP + dt * 1024 + lane * 16]);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[dt], 0, 0, 0);
+        }
+    }
+    const long long m = m0 + c16;
+    if (m < g.M) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<float4*>(g.out + (b * g.M + m) * D + 16 * dt + 4 * lg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+    }
+}
+
+static int g_attention_kernel = 0;          // 0: by size, 1: resident scores (T <= 2048), 2: streaming (A/B runs, tests)
+int attention_set_kernel(int which) {
+    const int prev = g_attention_kernel;
+    if (which >= 0 && which <= 2) g_attention_kernel = which;
+    return prev;
+}
+
 size_t attention_workspace_bytes(long long B, long long T, long long D) {
     const long long NT = (T + 15) / 16, NPAIR = ((T + 127) / 128) * 4;
     return (size_t)B * (size_t)(NT * (D / 32) * 1024 + (D / 16) * NPAIR * 1024) + 256;
@@ -407,7 +597,9 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
                          const long long* strides) {
-    if (T > AT_MAX_T || D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
+    if (D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
+    const bool stream = g_attention_kernel == 2 || (g_attention_kernel != 1 && T > AT_MAX_T);
+    if (!stream && T > AT_MAX_T) return MI355Q_E_UNSUPPORTED;
     const long long NT = T / 16, NPAIR = ((T + 127) / 128) * 4;
     uint16_t* kf = static_cast<uint16_t*>(workspace);
     uint16_t* vf = kf + (size_t)B * NT * (D / 32) * 512;
@@ -418,10 +610,24 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     const long long ksb = strides ? strides[2] : T * D, kst = strides ? strides[3] : D;
     const long long vsb = strides ? strides[4] : T * D, vst = strides ? strides[5] : D;
     hipLaunchKernelGGL(attn_pack_kv_kernel, dim3((unsigned)(kblocks + NPAIR / 4), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf, T,
-                       (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst);
+                       (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, stream ? 1 : 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm};
+    if (stream) {
+        const dim3 sgrid((unsigned)((M + 63) / 64), (unsigned)B);
+#define MI355Q_ATTN_S(DC_)                                                                                          \
+    if (mask) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, true>), sgrid, 256, 0, st, aq, ap, g);           \
+    else hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, false>), sgrid, 256, 0, st, aq, ap, g)
+        switch (D / 32) {
+            case 1: MI355Q_ATTN_S(1); break;
+            case 2: MI355Q_ATTN_S(2); break;
+            case 3: MI355Q_ATTN_S(3); break;
+            default: MI355Q_ATTN_S(4); break;
+        }
+#undef MI355Q_ATTN_S
+        return (int)hipGetLastError();
+    }
     // two 16-query groups per workgroup (measured at T = 2048: 70 vs 101 us at 12 heads x 64, 235 vs 342 us at 32 x 128)
     const int qg = 2;
     const dim3 grid((unsigned)(((M + 15) / 16 + qg - 1) / qg), (unsigned)B);

@@ -36,6 +36,7 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
                        long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false,
                        const float* mask = nullptr, long long causal_off = -1);
 size_t attention_workspace_bytes(long long B, long long T, long long D);
+int attention_set_kernel(int which);
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,

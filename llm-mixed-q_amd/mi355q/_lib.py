@@ -46,6 +46,7 @@ SIGNATURES = {
     "mi355q_bfp_matmul_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
     "mi355q_bfp_softmax_matmul": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_bfp_attention_set_kernel": (C.c_int, [C.c_int]),
     "mi355q_bfp_attention_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
     "mi355q_bfp_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi355q_bfp_attention_strided": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
@@ -64,7 +65,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

@@ -765,7 +765,7 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
 
 
 _ATTN_WS: dict = {}
-ATTENTION_MAX_KEYS, ATTENTION_MAX_HEAD_DIM = 2048, 128
+ATTENTION_MAX_KEYS, ATTENTION_MAX_HEAD_DIM = 1 << 20, 128      # (beyond 2048 keys: the streaming kernel, scores formed twice)
 
 
 def _as_heads_view(t: torch.Tensor):
@@ -834,6 +834,11 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
                                               ctypes.addressof(pa), ctypes.addressof(pb), ctypes.addressof(strides), sp)
     _lib.check(rc, "mi355q_bfp_attention_strided")
     return out
+
+
+def attention_set_kernel(which: int) -> int:
+    """0: the library picks by size, 1: resident-score kernel, 2: streaming kernel; returns the previous setting"""
+    return _lib.load_library().mi355q_bfp_attention_set_kernel(int(which))
 
 
 def rope_apply(q: torch.Tensor, k: torch.Tensor, cos_q: torch.Tensor, sin_q: torch.Tensor, position_ids: torch.Tensor):

@@ -60,7 +60,19 @@ def _check(out, ref):
 @pytest.mark.parametrize("B,T,hd,width,mode", [
     (6, 320, 64, 6, "causal"), (3, 2048, 128, 6, "causal_scaled"), (4, 1008, 64, 6, "mask"), (2, 640, 64, 4, "both"),
     (3, 512, 32, 6, "plain"), (2, 1024, 96, 5, "causal"), (5, 16, 64, 6, "causal"), (2, 2048, 64, 6, "plain")])
-def test_attention_one_pass_vs_oracle(B, T, hd, width, mode):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_attention_one_pass_vs_oracle(B, T, hd, width, mode, kernel):
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    prev = ops.attention_set_kernel(kernel)        # 1: scores resident in registers, 2: streaming (scores formed twice)
+    try:
+        _attention_vs_oracle(B, T, hd, width, mode)
+    finally:
+        ops.attention_set_kernel(prev)
+
+
+def _attention_vs_oracle(B, T, hd, width, mode):
     import torch
     import mi355q.quantize as Q
     c0, c1 = _cfg(width), _cfg(width)
@@ -101,7 +113,7 @@ def test_attention_mixed_widths_4d_and_fewer_queries():
 
 
 def test_attention_falls_back_outside_the_kernel_shapes():
-    """T % 16 != 0 and T > 2048: the same steps through bmm / softmax_bmm, same answer"""
+    """T % 16 != 0: the same steps through bmm / softmax_bmm, same answer; T > 2048: the streaming kernel"""
     import torch
     import mi355q.quantize as Q
     c0, c1 = _cfg(6), _cfg(6)

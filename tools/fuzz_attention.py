@@ -10,6 +10,9 @@ from mi355q.quantize.quantized_functions import _rotate_half
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+if len(sys.argv) > 3:                      # 1: resident-score kernel, 2: streaming kernel (default: the library picks by size)
+    from mi355q import ops
+    ops.attention_set_kernel(int(sys.argv[3]))
 
 
 def cfg(w0, w1):
@@ -19,7 +22,7 @@ def cfg(w0, w1):
 
 worst = 0.0
 for it in range(N):
-    B = int(rng.integers(1, 9)); hd = int(rng.choice([32, 64, 96, 128])); T = 16 * int(rng.integers(1, 129))
+    B = int(rng.integers(1, 9)); hd = int(rng.choice([32, 64, 96, 128])); T = 16 * int(rng.integers(1, 129 if len(sys.argv) <= 3 or sys.argv[3] != '2' else 200))
     M = T if rng.random() < 0.7 else 16 * int(rng.integers(1, T // 16 + 1))
     c0, c1 = cfg(int(rng.integers(3, 9)), int(rng.integers(3, 9))), cfg(int(rng.integers(3, 9)), int(rng.integers(3, 9)))
     mode = rng.choice(["causal", "mask", "both", "plain"])

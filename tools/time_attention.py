@@ -28,7 +28,8 @@ def timed(fn, n=20):
 
 
 for name, H, T, hd, scale in (("OPT-125m", 12, 2048, 64, None), ("OPT-1.3B", 32, 2048, 64, None), ("Llama-7B", 32, 2048, 128, math.sqrt(128)),
-                              ("OPT-125m T=1024", 12, 1024, 64, None), ("OPT-125m T=512", 12, 512, 64, None)):
+                              ("OPT-125m T=1024", 12, 1024, 64, None), ("OPT-125m T=512", 12, 512, 64, None),
+                              ("Llama-2-7B T=4096", 32, 4096, 128, math.sqrt(128))):
     g = torch.Generator().manual_seed(0)
     q, k, v = (torch.randn(H, T, hd, generator=g).to(dev) for _ in range(3))
     mask = torch.full((T, T), torch.finfo(torch.float32).min, device=dev).triu(1)
@@ -53,8 +54,18 @@ for name, H, T, hd, scale in (("OPT-125m", 12, 2048, 64, None), ("OPT-1.3B", 32,
     ref = steps()
     err = float((one_pass() - ref).abs().max() / ref.abs().max())
     flops = 2 * 2 * H * T * T * hd          # both products, full (unmasked) count
-    r = {"shape": f"{name}: q, k, v [{H}, {T}, {hd}], causal", "steps_us": round(timed(steps), 1), "folded_us": round(timed(folded), 1),
-         "one_pass_us": round(timed(one_pass), 1), "one_pass_vs_steps_max_rel": round(err, 6)}
+    from mi355q import ops
+    r = {"shape": f"{name}: q, k, v [{H}, {T}, {hd}], causal", "steps_us": round(timed(steps), 1), "folded_us": round(timed(folded), 1)}
+    for label, which in (("one_pass_resident_us", 1), ("one_pass_stream_us", 2)):
+        if which == 1 and T > 2048:
+            continue
+        prev = ops.attention_set_kernel(which)
+        try:
+            r[label] = round(timed(one_pass), 1)
+        finally:
+            ops.attention_set_kernel(prev)
+    r["one_pass_us"] = round(timed(one_pass), 1)
+    r["one_pass_vs_steps_max_rel"] = round(err, 6)
     r["speedup_vs_steps"] = round(r["steps_us"] / r["one_pass_us"], 2)
     r["one_pass_TFLOPs_full_count"] = round(flops / r["one_pass_us"] / 1e6, 1)
     print(json.dumps(r), flush=True)
