@@ -193,6 +193,7 @@ def _rope_kernel_applies(q, k, cos_q, sin_q, position_ids) -> bool:
     return (q.is_cuda and k.is_cuda and q.dtype == k.dtype == cos_q.dtype == torch.float32 and q.ndim == 4 and k.ndim == 4
             and q.shape[0] == k.shape[0] and q.shape[2:] == k.shape[2:] and q.shape[3] % 8 == 0 and q.stride(3) == 1
             and k.stride(3) == 1 and all(s % 4 == 0 for s in q.stride()[:3] + k.stride()[:3])
+            and q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0
             and cos_q.ndim == 2 and cos_q.shape == sin_q.shape and cos_q.shape[1] == q.shape[3]
             and position_ids.dtype == torch.int64 and position_ids.shape == (q.shape[0], q.shape[2])
             and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
