@@ -310,8 +310,9 @@ int mi355q_bfp_softmax_matmul(const float* scores, const float* mask, int32_t ca
  * widths <= 9, else MI355Q_E_UNSUPPORTED (callers then chain mi355q_bfp_matmul and mi355q_bfp_softmax_matmul).  Key tiles
  * behind the horizon of a workgroup's last query are skipped (probabilities exactly 0 there). */
 size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D);
-/* Which of the two kernels serves mi355q_bfp_attention: 0 = by size (default), 1 = scores resident in registers
- * (T <= 2048), 2 = streaming (scores formed twice, any T).  Returns the previous setting.  For A/B runs and tests. */
+/* Which kernel serves mi355q_bfp_attention: 0 = by size (default), 1 = scores resident in registers, four waves share a
+ * query group's keys (T <= 2048), 2 = streaming (scores formed twice, any T), 3 = resident with eight key-waves (head_dim
+ * <= 64; otherwise as 1).  Returns the previous setting.  For A/B runs and tests. */
 int mi355q_bfp_attention_set_kernel(int which);
 int mi355q_bfp_attention(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                          float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,

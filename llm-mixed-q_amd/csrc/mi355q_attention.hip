@@ -140,17 +140,17 @@ __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, 
 }
 
 // ---- v [B, T, D] -> fragments of Qd(v): blocks of 16 along D at a fixed key ------------------------------------------
-// piece (b, pair, dt) = 1 KiB, pair = 4 s + w <-> key tiles a = 8 s + w, b = 8 s + 4 + w (wave w's s-th pair; kw = 4):
+// piece (b, pair, dt) = 1 KiB, pair = 4 s + w <-> key tiles a = 8 s + w, b = 8 s + 4 + w (wave w's s-th pair; kw = 4; kw = 8: 16 s + w, 16 s + 8 + w):
 // lane (d = 16 dt + lane % 16, g = lane / 16) holds slot j <-> key 16 (j < 4 ? a : b) + 4 g + (j & 3).  Keys behind T: 0.
 // One workgroup = 128 keys (8 tiles = 4 pairs) x D; thread (key, 16-d block) quantises one block.
 __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, uint16_t* __restrict__ stage,
                                             const float* __restrict__ v, uint16_t* __restrict__ vf, long long T, int D,
                                             long long NPAIR, long long bx, long long sb, long long st, int kw) {
     // stage: [dt][pair in group (w)][lane][8]
-    const int tid = threadIdx.x, DT = D >> 4;
-    const long long b = blockIdx.y, key0 = bx * 128;
+    const int tid = threadIdx.x, DT = D >> 4, PG = kw == 8 ? 8 : 4;         // pairs per workgroup: 32 PG keys
+    const long long b = blockIdx.y, key0 = bx * 32 * PG;
     const int mbits = (int)__builtin_log2f(a.shift);
-    for (int item = tid; item < 128 * DT; item += 256) {
+    for (int item = tid; item < 32 * PG * DT; item += 256) {
         const int kl = item / DT, dt = item % DT;         // key inside the group, 16-d block
         const long long key = key0 + kl;
         float x[16];
@@ -167,20 +167,20 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
         // key inside the 128-group: tile tl = kl / 16 (0..7) -> pair w of the group and half h of the pair -- tiles
         // (w, w + 4) for the resident kernel's four key-waves (kw = 4), consecutive tiles (2 w, 2 w + 1) for the streaming
         // kernel (kw = 1); g = (kl & 15) / 4
-        const int tl = kl >> 4, w = kw == 4 ? tl & 3 : tl >> 1, h = kw == 4 ? tl >> 2 : tl & 1, g = (kl & 15) >> 2,
+        const int tl = kl >> 4, w = kw == 1 ? tl >> 1 : tl & (kw - 1), h = kw == 1 ? tl & 1 : tl / kw, g = (kl & 15) >> 2,
                   j = 4 * h + (kl & 3);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const float q = bmax != 0.f ? at_quant(x[c], mbits - p, p - mbits, a.mant_max) : 0.f;
-            stage[((dt * 4 + w) * 64 + c + 16 * g) * 8 + j] = (uint16_t)(pack_bf16(q, 0.f) & 0xFFFFu);
+            stage[((dt * PG + w) * 64 + c + 16 * g) * 8 + j] = (uint16_t)(pack_bf16(q, 0.f) & 0xFFFFu);
         }
     }
     __syncthreads();
-    const long long s = bx;                                // pair group: pairs 4 s .. 4 s + 3
-    for (int ch = tid; ch < DT * 4 * 64; ch += 256) {
-        const int dt = ch / 256, w = (ch >> 6) & 3, ln = ch & 63;
-        *reinterpret_cast<uint4*>(vf + (((b * NPAIR + 4 * s + w) * DT + dt) * 64 + ln) * 8) =
-            *reinterpret_cast<const uint4*>(&stage[((dt * 4 + w) * 64 + ln) * 8]);
+    const long long s = bx;                                // pair group: pairs PG s .. PG s + PG - 1
+    for (int ch = tid; ch < DT * PG * 64; ch += 256) {
+        const int dt = ch / (PG * 64), w = (ch >> 6) % PG, ln = ch & 63;
+        *reinterpret_cast<uint4*>(vf + (((b * NPAIR + PG * s + w) * DT + dt) * 64 + ln) * 8) =
+            *reinterpret_cast<const uint4*>(&stage[((dt * PG + w) * 64 + ln) * 8]);
     }
 }
 
@@ -215,18 +215,20 @@ struct AttnArgs {
 // QG = 16-query groups per workgroup (4 waves each).  Two groups walk the same key tiles in step: the second request for
 // a K / V fragment is served by the compute unit's L1 instead of the L2 (the kernel is L2-bandwidth bound at long T: every
 // 16 queries stream their head's whole K and V fragments).
-template <int NTW, int DC, int QG, bool HASMASK>
-__global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
+// KW = waves that share the keys of a query group (4, or 8 with half the strip per wave: 64 accumulator VGPRs, twice the
+// waves per SIMD).
+template <int NTW, int DC, int QG, bool HASMASK, int KW = 4>
+__global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
     constexpr int DT = DC * 2;
     constexpr float FMIN = -3.4028234663852886e38f;
     __shared__ Lut lut;
-    __shared__ float stat_[QG][4][16];
-    __shared__ f32x4 red_[QG][4][DT][64];
+    __shared__ float stat_[QG][KW][16];
+    __shared__ f32x4 red_[QG][KW][DT][64];
     load_lut<FMT_BFP>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_all & 3, grp = wave_all >> 2;
-    float (&stat)[4][16] = stat_[grp];
-    f32x4 (&red)[4][DT][64] = red_[grp];
+    const int wave = wave_all % KW, grp = wave_all / KW;
+    float (&stat)[KW][16] = stat_[grp];
+    f32x4 (&red)[KW][DT][64] = red_[grp];
     const int c16 = lane & 15, lg = lane >> 4;
     const long long b = blockIdx.y, m0 = ((long long)blockIdx.x * QG + grp) * 16;
     const long long qrow = min(m0 + c16, g.M - 1);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     auto load_group = [&](int gi, uint4 (&dst)[G][DC], float4 (&mdst)[HASMASK ? G : 1]) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            const long long t = min((long long)(4 * (gi * G + j) + wave), tlast);
+            const long long t = min((long long)(KW * (gi * G + j) + wave), tlast);
 #pragma unroll
             for (int c = 0; c < DC; ++c) dst[j][c] = *reinterpret_cast<const uint4*>(kfb + ((t * DC + c) * 64 + lane) * 8);
             if (HASMASK) mdst[j] = *reinterpret_cast<const float4*>(mrow + t * 16 + 4 * lg);
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int i = gi * G + j;
-            const long long t = 4 * i + wave;
+            const long long t = KW * i + wave;
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < DC; ++c)
@@ -319,13 +321,15 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     mx = at_max4(mx);
     if (lg == 0) stat[wave][c16] = mx;
     __syncthreads();
-    const float row_max = fmaxf(fmaxf(stat[0][c16], stat[1][c16]), fmaxf(stat[2][c16], stat[3][c16]));
+    float row_max = stat[0][c16];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) row_max = fmaxf(row_max, stat[w][c16]);
     __syncthreads();
     // ---- exponentials in place, row sum
     float sm = 0.f;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        if (4 * i + wave < need) {
+        if (KW * i + wave < need) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float ex = at_exp_neg(acc[i][e] - row_max);
@@ -337,7 +341,8 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     sm = at_sum4(sm);
     if (lg == 0) stat[wave][c16] = sm;
     __syncthreads();
-    const float row_sum = (stat[0][c16] + stat[1][c16]) + (stat[2][c16] + stat[3][c16]);
+    float row_sum = (stat[0][c16] + stat[1][c16]) + (stat[2][c16] + stat[3][c16]);
+    if (KW == 8) row_sum += (stat[4][c16] + stat[5][c16]) + (stat[6][c16] + stat[7][c16]);
     const float row_inv = 1.0f / row_sum;
 
     // ---- probabilities, quantised per tile row (one [1,16] block = the 4 lanes c16 + 16 g'), times V
@@ -347,20 +352,20 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     const int mbp = (int)__builtin_log2f(ap.shift);
     const uint16_t* __restrict__ vfb = g.vf + b * DT * g.NPAIR * 512;
     // (V fragments one pair ahead and unconditional, like the K fragments; a pair behind the horizon re-reads the last one)
-    const long long slast = max((tlast - wave) / 8, 0ll);
+    const long long slast = max((tlast - wave) / (2 * KW), 0ll);
     uint4 vb[2][DT];
     auto load_pair = [&](int sp, uint4 (&dst)[DT]) {
         const long long sc = min((long long)sp, slast);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            dst[dt] = *reinterpret_cast<const uint4*>(vfb + (((4 * sc + wave) * DT + dt) * 64 + lane) * 8);
+            dst[dt] = *reinterpret_cast<const uint4*>(vfb + (((KW * sc + wave) * DT + dt) * 64 + lane) * 8);
     };
     load_pair(0, vb[0]);
 #pragma unroll
     for (int s = 0; s < NTW / 2; ++s) {
         if (s + 1 < NTW / 2) load_pair(s + 1, vb[(s + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (4 * (2 * s) + wave < need) {                   // (uniform; tiles are needed in order)
+        if (KW * (2 * s) + wave < need) {                  // (uniform; tiles are needed in order)
             float pq[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
                 float bmax = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pr[e] = 4 * i + wave < need ? at_div(acc[i][e], row_sum, row_inv) : 0.f;
+                    pr[e] = KW * i + wave < need ? at_div(acc[i][e], row_sum, row_inv) : 0.f;
                     bmax = fmaxf(bmax, pr[e]);
                 }
                 bmax = at_max4(bmax);
@@ -392,10 +397,10 @@ __global__ __launch_bounds__(256 * QG) void bfp_attention_kernel(const QuantArgs
     for (int dt = 0; dt < DT; ++dt) red[wave][dt][lane] = o[dt];
     __syncthreads();
     const long long m = m0 + c16;
-    for (int dt = wave; dt < DT; dt += 4) {
+    for (int dt = wave; dt < DT; dt += KW) {
         f32x4 sum = red[0][dt][lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) sum += red[w][dt][lane];
+        for (int w = 1; w < KW; ++w) sum += red[w][dt][lane];
         if (m < g.M)
             *reinterpret_cast<float4*>(g.out + (b * g.M + m) * D + 16 * dt + 4 * lg) = make_float4(sum[0], sum[1], sum[2], sum[3]);
     }
@@ -581,15 +586,16 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
     }
 }
 
-static int g_attention_kernel = 0;          // 0: by size, 1: resident scores (T <= 2048), 2: streaming (A/B runs, tests)
+static int g_attention_kernel = 0;          // 0: by size, 1: resident scores with 4 key-waves (T <= 2048), 2: streaming,
+                                            // 3: resident scores with 8 key-waves (head_dim <= 64)   (A/B runs, tests)
 int attention_set_kernel(int which) {
     const int prev = g_attention_kernel;
-    if (which >= 0 && which <= 2) g_attention_kernel = which;
+    if (which >= 0 && which <= 3) g_attention_kernel = which;
     return prev;
 }
 
 size_t attention_workspace_bytes(long long B, long long T, long long D) {
-    const long long NT = (T + 15) / 16, NPAIR = ((T + 127) / 128) * 4;
+    const long long NT = (T + 15) / 16, NPAIR = ((T + 255) / 256) * 8;            // (the widest pair grouping)
     return (size_t)B * (size_t)(NT * (D / 32) * 1024 + (D / 16) * NPAIR * 1024) + 256;
 }
 
@@ -598,9 +604,13 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
                          const long long* strides) {
     if (D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
-    const bool stream = g_attention_kernel == 2 || (g_attention_kernel != 1 && T > AT_MAX_T);
+    const bool stream = g_attention_kernel == 2 || ((g_attention_kernel == 0 || g_attention_kernel > 3) && T > AT_MAX_T);
     if (!stream && T > AT_MAX_T) return MI355Q_E_UNSUPPORTED;
-    const long long NT = T / 16, NPAIR = ((T + 127) / 128) * 4;
+    // eight key-waves per query group (half the score strip per wave: 127 VGPRs, twice the waves per SIMD) for head_dim <=
+    // 64 and long rows: 65 vs 78 us at 12 x 2048 x 64, 135 vs 167 us at 32 x 2048 x 64; no difference at 1024 keys
+    const bool kw8 = !stream && D <= 64 && (g_attention_kernel == 3 || (g_attention_kernel == 0 && T > 1024));
+    const int kw = stream ? 1 : (kw8 ? 8 : 4), pg = kw == 8 ? 8 : 4;
+    const long long NT = T / 16, NPAIR = ((T + 32 * pg - 1) / (32 * pg)) * pg;
     uint16_t* kf = static_cast<uint16_t*>(workspace);
     uint16_t* vf = kf + (size_t)B * NT * (D / 32) * 512;
     const int per = 256 / (int)D;
@@ -609,8 +619,8 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     const long long qsb = strides ? strides[0] : M * D, qsm = strides ? strides[1] : D;
     const long long ksb = strides ? strides[2] : T * D, kst = strides ? strides[3] : D;
     const long long vsb = strides ? strides[4] : T * D, vst = strides ? strides[5] : D;
-    hipLaunchKernelGGL(attn_pack_kv_kernel, dim3((unsigned)(kblocks + NPAIR / 4), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf, T,
-                       (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, stream ? 1 : 4);
+    hipLaunchKernelGGL(attn_pack_kv_kernel, dim3((unsigned)(kblocks + NPAIR / pg), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf, T,
+                       (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm};
@@ -626,6 +636,17 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
             default: MI355Q_ATTN_S(4); break;
         }
 #undef MI355Q_ATTN_S
+        return (int)hipGetLastError();
+    }
+    if (kw8) {
+        const dim3 grid8((unsigned)((M + 15) / 16), (unsigned)B);
+        const int ntw8 = T <= 1024 ? 8 : 16;
+#define MI355Q_ATTN8(NTW_, DC_)                                                                                  \
+    if (mask) hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 1, true, 8>), grid8, 512, 0, st, aq, ap, g);   \
+    else hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 1, false, 8>), grid8, 512, 0, st, aq, ap, g)
+        if (ntw8 == 8) { if (D == 32) { MI355Q_ATTN8(8, 1); } else { MI355Q_ATTN8(8, 2); } }
+        else { if (D == 32) { MI355Q_ATTN8(16, 1); } else { MI355Q_ATTN8(16, 2); } }
+#undef MI355Q_ATTN8
         return (int)hipGetLastError();
     }
     // two 16-query groups per workgroup (measured at T = 2048: 70 vs 101 us at 12 heads x 64, 235 vs 342 us at 32 x 128)

@@ -60,12 +60,12 @@ def _check(out, ref):
 @pytest.mark.parametrize("B,T,hd,width,mode", [
     (6, 320, 64, 6, "causal"), (3, 2048, 128, 6, "causal_scaled"), (4, 1008, 64, 6, "mask"), (2, 640, 64, 4, "both"),
     (3, 512, 32, 6, "plain"), (2, 1024, 96, 5, "causal"), (5, 16, 64, 6, "causal"), (2, 2048, 64, 6, "plain")])
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_attention_one_pass_vs_oracle(B, T, hd, width, mode, kernel):
     import torch
     import mi355q.quantize as Q
     from mi355q import ops
-    prev = ops.attention_set_kernel(kernel)        # 1: scores resident in registers, 2: streaming (scores formed twice)
+    prev = ops.attention_set_kernel(kernel)        # 1: scores resident in registers, 2: streaming (scores formed twice), 3: resident, 8 key-waves (head_dim <= 64; else as 1)
     try:
         _attention_vs_oracle(B, T, hd, width, mode)
     finally:

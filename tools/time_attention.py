@@ -56,8 +56,8 @@ for name, H, T, hd, scale in (("OPT-125m", 12, 2048, 64, None), ("OPT-1.3B", 32,
     flops = 2 * 2 * H * T * T * hd          # both products, full (unmasked) count
     from mi355q import ops
     r = {"shape": f"{name}: q, k, v [{H}, {T}, {hd}], causal", "steps_us": round(timed(steps), 1), "folded_us": round(timed(folded), 1)}
-    for label, which in (("one_pass_resident_us", 1), ("one_pass_stream_us", 2)):
-        if which == 1 and T > 2048:
+    for label, which in (("one_pass_resident_us", 1), ("one_pass_resident_8_key_waves_us", 3), ("one_pass_stream_us", 2)):
+        if which in (1, 3) and (T > 2048 or (which == 3 and hd > 64)):
             continue
         prev = ops.attention_set_kernel(which)
         try:
