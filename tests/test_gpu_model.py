@@ -98,8 +98,39 @@ from tests.conftest import GOLDEN as _GOLDEN
 _G5 = _json.loads((_GOLDEN / "models.json").read_text())
 
 
+def _with_knob(qc, **knobs):
+    """the implementation knobs (mi355q_*) into every node config of a TOML-level quant config (parse_node_config hands
+    them through to the modules / functions)"""
+    if isinstance(qc, dict):
+        out = {k: _with_knob(v, **knobs) for k, v in qc.items()}
+        if "name" in qc:
+            out.update(knobs)
+        return out
+    return qc
+
+
+@pytest.mark.parametrize("attention", ["steps", "folded", "one_pass"])
+@pytest.mark.parametrize("tag", sorted(t for t in _G5 if t.endswith("_t48")))
+def test_reference_model_fixture_fused_attention(tag, attention):
+    """the reference's own logits (48 tokens, head_dim 64, uniform and mixed per-layer widths) against the harness with the
+    attention core as the reference steps it, with the softmax folded into P V, and as the one-pass kernel"""
+    from mi355q import ops
+    knobs = {"steps": {}, "folded": {"mi355q_fused_softmax": True}, "one_pass": {"mi355q_fused_attention": True}}[attention]
+    calls, real = [], ops.bfp_attention
+    ops.bfp_attention = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        _check_fixture(tag, knobs)
+    finally:
+        ops.bfp_attention = real
+    assert (len(calls) == 2) == (attention == "one_pass"), len(calls)      # (the kernel really ran: once per layer)
+
+
 @pytest.mark.parametrize("tag", sorted(_G5))
 def test_reference_model_fixture(tag):
+    _check_fixture(tag, {})
+
+
+def _check_fixture(tag, knobs):
     """weights + token ids + logits + loss of the reference's OPTQuantizedForCausalLM / LlamaQuantizedForCausalLM
     (2 layers; W6A6, W4A4, mixed per-layer widths, K % 128 == 0 variants that take the int8 GEMM): the harness on the
     GPU, driven through the registry API with the reference's per-layer config, must reproduce them."""
@@ -111,12 +142,12 @@ def test_reference_model_fixture(tag):
     if m["family"] == "opt":
         cfg = H.TinyOPTConfig(vocab_size=m["vocab_size"], hidden_size=m["hidden_size"], ffn_dim=m["ffn_dim"],
                               num_layers=m["num_layers"], num_heads=m["num_heads"], max_positions=m["max_positions"])
-        model = H.TinyOPTForCausalLM(cfg, H.expand_quant_config(m["quant_config"], cfg.num_layers))
+        model = H.TinyOPTForCausalLM(cfg, H.expand_quant_config(_with_knob(m["quant_config"], **knobs), cfg.num_layers))
     else:
         cfg = H.TinyLlamaConfig(vocab_size=m["vocab_size"], hidden_size=m["hidden_size"],
                                 intermediate_size=m["intermediate_size"], num_layers=m["num_layers"],
                                 num_heads=m["num_heads"], max_positions=m["max_positions"], rms_eps=m["rms_eps"])
-        model = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(m["quant_config"], cfg.num_layers))
+        model = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(_with_knob(m["quant_config"], **knobs), cfg.num_layers))
     model.load_reference_state_dict(sd).to("cuda:0").eval()
     t = torch.from_numpy(ids).to("cuda:0")
     with torch.no_grad():

@@ -42,4 +42,7 @@ def test_oracle_model_forward_matches_reference(tag, data):
         logits, loss = NM.llama_forward(sd, qc, ids, m["num_heads"], m["rms_eps"])
     assert np.abs(logits - ref_logits).max() < 1e-5
     assert abs(loss - ref_loss) < 2e-6
-    assert round(float(np.exp(loss)), 3) == round(float(np.exp(ref_loss)), 3)
+    # perplexity to 3 d.p. (north_star): equal after rounding, or within half a unit of the third place where the reference's
+    # own fp32 loss (spacing 5e-7 here, i.e. 8e-5 in ppl) puts the two on either side of a rounding boundary
+    ppl, ref_ppl = float(np.exp(loss)), float(np.exp(ref_loss))
+    assert round(ppl, 3) == round(ref_ppl, 3) or abs(ppl - ref_ppl) < 1e-4, (ppl, ref_ppl)

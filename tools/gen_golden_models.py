@@ -183,6 +183,12 @@ def main():
     run_llama(llama, llamac, "llama_w4a4", {"default": bfp_default(4, 4)}, arrays, meta, seed=50)
     run_llama(llama, llamac, "llama_mixed", mixed_llama_config(), arrays, meta, seed=60)
     run_llama(llama, llamac, "llama_w6a6_k128", {"default": bfp_default(6, 6)}, arrays, meta, hidden=128, inter=256, heads=2, seed=70)
+    # 48 tokens, head_dim 64: shapes the one-pass attention kernel takes (T % 16 == 0, head_dim % 32 == 0), so that the
+    # reference's own logits pin that route too (uniform and mixed per-layer widths)
+    run_opt(opt, optc, "opt_w6a6_t48", {"default": bfp_default(6, 6)}, arrays, meta, hidden=128, ffn=256, heads=2, T=48, seed=80)
+    run_opt(opt, optc, "opt_mixed_t48", mixed_opt_config(), arrays, meta, hidden=128, ffn=256, heads=2, T=48, seed=90)
+    run_llama(llama, llamac, "llama_w6a6_t48", {"default": bfp_default(6, 6)}, arrays, meta, hidden=128, inter=256, heads=2, T=48, seed=100)
+    run_llama(llama, llamac, "llama_mixed_t48", mixed_llama_config(), arrays, meta, hidden=128, inter=256, heads=2, T=48, seed=110)
     OUT.mkdir(parents=True, exist_ok=True)
     np.savez_compressed(OUT / "models.npz", **arrays)
     (OUT / "models.json").write_text(json.dumps(meta, indent=1))
