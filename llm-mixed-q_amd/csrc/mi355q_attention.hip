@@ -1,4 +1,5 @@
-// mi355q_attention.hip -- the reference's quantised attention core as ONE pass per 16 queries:
+// mi355q_attention.hip -- the reference's quantised attention core as ONE pass (bfp_attention_kernel: per 16 queries, the
+// score strip resident in registers; bfp_attention_stream_kernel further down: any number of keys, scores formed twice):
 //
 //     scores = bmm_0(Qa(q), Qb(k^T))            quantized_functions/matmul.py:146-196 (block_fp), callers
 //     scores = scores / scale                   modeling_llama.py:318-322 (OPT scales q before the product instead)
@@ -10,9 +11,9 @@
 // queries (16 x T fp32, T <= 2048) in MFMA accumulators -- 128 VGPRs per lane at T = 2048 -- from the first product to
 // the second.  Block structure of the four quantisers ([1,16] blocks along each operand's LAST dim, like the reference):
 //   q [.., M, D]  blocks of 16 along D  (the contraction of the first product): quantised in registers here
-//   k^T [.., D, T] blocks of 16 consecutive KEYS at a fixed d: attn_pack_k_kernel (k is taken untransposed)
+//   k^T [.., D, T] blocks of 16 consecutive KEYS at a fixed d: attn_pack_kv_kernel / attn_pack_k (k is taken untransposed)
 //   probs          blocks of 16 consecutive keys of a query = one 16 x 16 score tile's row: quantised in registers
-//   v [.., T, D]  blocks of 16 along D at a fixed key: attn_pack_v_kernel
+//   v [.., T, D]  blocks of 16 along D at a fixed key: attn_pack_kv_kernel / attn_pack_v
 // MFMA operand roles (v_mfma_f32_16x16x32_bf16; A rows x k, B k x columns, lane (c = lane % 16, g = lane / 16) holds k
 // slots 8 g .. 8 g + 7 of row / column c and gets rows 4 g .. 4 g + 3 of column c of the result):
 //   scores tile t (16 keys):  A = K fragment (rows = keys 16 t + c, slots = d),  B = Q fragment (columns = queries)
@@ -20,11 +21,12 @@
 //   output:  A = V fragment (rows = d, slots = keys),  B = P fragment (columns = queries, slots = keys)
 //        -> lane holds out[query c][d = 16 dt + 4 g + 0..3]: 16-byte stores.
 //   The P fragment of a lane is made of its own values of TWO score tiles a, b: slot j <-> key 16 (j < 4 ? a : b) + 4 g +
-//   (j & 3); attn_pack_v_kernel stores V with the same slot order, so no value ever changes lanes between the products.
-// Wave w owns the key tiles t = w, w + 4, w + 8, ... (interleaved: under a causal mask every wave loses the same share);
-// tiles behind the horizon of the workgroup's last query are skipped altogether (probabilities exactly 0).  A workgroup is
-// two such 4-wave groups (32 queries) that walk the same fragments in step, so that every other fragment request is an L1 hit.
-// Row statistics (max, sum of exponentials) are combined over the 4 lane groups by shuffles and over the 4 waves through
+//   (j & 3); attn_pack_v stores V with the same slot order, so no value ever changes lanes between the products.
+// Wave w owns the key tiles t = w, w + KW, w + 2 KW, ... (KW = 4 or 8 key-waves; interleaved: under a causal mask every wave
+// loses the same share);
+// tiles behind the horizon of the workgroup's last query are skipped altogether (probabilities exactly 0).  With KW = 4 a
+// workgroup is two such groups (32 queries) that walk the same fragments in step: every other fragment request is an L1 hit.
+// Row statistics (max, sum of exponentials) are combined over the 4 lane groups by lane swaps and over the KW waves through
 // LDS; the partial outputs of the waves are summed through LDS in wave order (reproducible).
 // Arithmetic: products of two block_fp values (width <= 9) are exact in fp32, accumulation is fp32 like the reference's
 // GEMMs (order differs: the tolerance of the matmul tests); exp to ~1 ulp, quotient corrected once (mi355q_matmul.hip).
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, c
 }
 
 // ---- the attention pass ------------------------------------------------------------------------------------------------
-// NTW = score tiles per wave (8, 16, 32 <-> T <= 512, 1024, 2048), DC = D / 32.
+// NTW = score tiles per wave (KW = 4: 8, 16, 32 <-> T <= 512, 1024, 2048; KW = 8: half of that), DC = D / 32.
 struct AttnArgs {
     const float* q;
     const uint16_t* kf;
