@@ -8,20 +8,22 @@
 //
 // Workgroup = 256 x 256 outputs, 8 waves as 2 x 4 (two per SIMD), v_mfma_i32_16x16x64_i8.  K-step 64: one stage =
 // A 16 KiB + B 16 KiB of 1-KiB pieces (block-major inside, mi355q_gemm_v2.h), three stages filled by global_load_lds,
-// counted s_waitcnt vmcnt, raw s_barriers.  The two waves of every SIMD run one barrier apart: while one issues 16
-// MFMAs the other reads its fragments and issues its LDS-DMA loads (two such phases per K-step).  The scale / bias
+// counted s_waitcnt vmcnt, raw s_barriers.  Default schedule (SCHED 2): ONE barrier per K-step, both waves of a SIMD run
+// the same stream -- 32 MFMAs a step from registers while fragment i + 2 is read (inline-asm ds_read_b128, hand-counted
+// lgkmcnt) and the step's four LDS-DMA pieces for step t + 2 go out one per MFMA group.  (SCHED 0: the two waves of a
+// SIMD one barrier apart, two phases per K-step; SCHED 1: the one-phase schedule of the 128 x 256 tile.)  The scale / bias
 // slices of the tile, its two exception buckets and the lists' overflow words ride in front of the operand stream.
 //
-// Exceptions (blocks outside their row's exponent window; a few dozen per tile at most in the usual case) are
-// added back without floating-point atomics.  The short launch in front of this kernel (bfp_gemm_tail,
-// mi355q_gemm_v6.hip) has multiplied every exception block with the other operand: one vector of 256 products per
-// (entry, 256 rows of the other operand).  A tile fetches the vectors of its two buckets by ONE contiguous 1-KiB
-// LDS-DMA each, behind its buckets and in front of the operand stream, into spare LDS; links the entries of each
-// tile row / column into chains; after the K loop adds the exception x exception terms (same K position in both
-// lists), folds chains into their heads, and the store epilogue adds one vector per affected row / column.  Tiles
-// with more entries than the spare area holds fetch the vectors into the stage area after the K loop; beyond
-// that the products are added with atomics after the stores.  If a bucket overflowed anywhere the kernel leaves
-// at once (the launch in front formed the whole product blockwise-exact).
+// Exceptions (blocks outside their row's exponent window; a few dozen per tile at most in the usual case) are added back
+// without floating-point atomics and without a launch of their own: the tile reads its two buckets, gathers -- ONE round
+// trip for all entries -- the other operand's blocks at each entry's K position (256 rows x 16 bytes = 4 KiB contiguous
+// in the block-major pieces), multiplies, and keeps one vector of 256 products per entry in spare LDS; links the entries
+// of each tile row / column into chains while the gathers fly; after the K loop adds the exception x exception terms (same
+// K position in both lists), folds chains into their heads, and the store epilogue adds one vector per affected row /
+// column.  Tiles with more entries than the spare area holds form the vectors in the stage area after the K loop; beyond
+// that the products are added with atomics after the stores.  If a bucket overflowed anywhere (uniform over the grid) the
+// launch's workgroups share the blockwise-exact product instead (v8_fallback).  Under-filled grids split K over several
+// workgroups per tile (slabs + tickets, choose_splits).
 // Roofline: int8 MFMA, 2*M*N*K ops; y leaves as full fp32 (64 MiB at 4096^2: ~10 us of HBM write time).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
