@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 10
+#define MI355Q_ABI_VERSION 11
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -265,6 +265,16 @@ typedef struct mi355q_bfp_operand {
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);
+
+/* Several weight operands of the SAME shape against ONE activation operand in one launch (the q / k / v projections of an
+ * attention block, gate / up of a gated MLP: reference modules called one after the other on the same input,
+ * modeling_opt.py:231-245, modeling_llama.py:216,283-287): y[i] = x . w[i]^T + bias[i].  The column tiles of all of them
+ * form one grid, which fills the 256 compute units where the single products leave them idle (2048 x 2048 -> 2048: 128
+ * tiles each) or waste most of a second round (2048 x 4096 -> 11008: 344 tiles each).  count <= 3; row-aligned operands with
+ * 120-entry buckets, K % 128 == 0, else MI355Q_E_UNSUPPORTED (callers launch mi355q_bfp_gemm_aligned per weight).
+ * Results equal the separate launches' bit for bit. */
+int mi355q_bfp_gemm_aligned_multi(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const float* const* bias,
+                                  float* const* y, int32_t count, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream);
 
 /* ---- block_fp quantised batched matmul ------------------------------------------------------------
  * replaces: quantized_functions/matmul.py:146-196 (generic_matmul_block_fp behind matmul_block_fp / bmm_block_fp,

@@ -452,6 +452,38 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
     return launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
 }
 
+int mi355q_bfp_gemm_aligned_multi(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const float* const* bias,
+                                  float* const* y, int32_t count, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
+    if (!x || !w || !y || count < 1 || count > 3 || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
+    if (M == 0 || N == 0) return 0;
+    for (int i = 0; i < count; ++i) {
+        if (!w[i] || !y[i] || !w[i]->mant || !w[i]->exp || !w[i]->rowflag || !w[i]->gscale || !w[i]->list) return MI355Q_E_BADARG;
+        // one grid over all of them: the same flavour, scales and bucket size everywhere
+        if (w[i]->row_aligned != 1 || w[i]->mbits != w[0]->mbits || w[i]->exp_bias != w[0]->exp_bias ||
+            bucket_cap_of(w[i]->list_cap) != ROW_BCAP)
+            return MI355Q_E_UNSUPPORTED;
+        if (reinterpret_cast<uintptr_t>(w[i]->mant) % 16) return MI355Q_E_ALIGN;
+    }
+    if (!x->mant || !x->exp || !x->rowflag || !x->gscale || !x->list) return MI355Q_E_BADARG;
+    if (x->row_aligned != 1 || bucket_cap_of(x->list_cap) != ROW_BCAP || K % 128 != 0 || K > MI355Q_ROW_ALIGN_MAX_K ||
+        g_gemm_variant.load() != 0)
+        return MI355Q_E_UNSUPPORTED;                  // (callers then launch mi355q_bfp_gemm_aligned per weight)
+    if (x->mbits < 1 || x->mbits > 7 || w[0]->mbits < 1 || w[0]->mbits > 7) return MI355Q_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(x->mant) % 16) return MI355Q_E_ALIGN;
+    if (count == 1) return mi355q_bfp_gemm_aligned(x, w[0], bias ? bias[0] : nullptr, y[0], M, N, K, ldy, stream);
+    GemmArgs a{x->mant, x->exp, w[0]->mant, w[0]->exp, bias ? bias[0] : nullptr, y[0], M, N, K, ldy,
+               x->exp_bias + x->mbits + w[0]->exp_bias + w[0]->mbits, 1,
+               x->exp_bias + x->mbits, w[0]->exp_bias + w[0]->mbits,
+               ROW_BCAP, ROW_BCAP, 0};
+    a.ngroup = count;
+    for (int i = 0; i < count; ++i) {
+        a.g_wm[i] = w[i]->mant; a.g_we[i] = w[i]->exp; a.g_sw[i] = w[i]->gscale; a.g_wlist[i] = w[i]->list;
+        a.g_wf[i] = w[i]->rowflag; a.g_bias[i] = bias ? bias[i] : nullptr; a.g_y[i] = y[i];
+    }
+    return launch_bfp_gemm_v8(a, x->gscale, w[0]->gscale, x->list, w[0]->list, 0, static_cast<hipStream_t>(stream), x->rowflag,
+                              w[0]->rowflag);
+}
+
 size_t mi355q_bfp_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N) {
     if (B <= 0 || K <= 0 || N <= 0) return 0;
     return (size_t)B * (size_t)((K + 63) / 64 * 64) * (size_t)N * 2 + 64;

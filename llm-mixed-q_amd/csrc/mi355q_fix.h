@@ -32,8 +32,12 @@ __device__ __forceinline__ const int* row_bucket(const int* __restrict__ list, l
 __device__ __forceinline__ void fix_entry_sweep(const GemmArgs& a, bool is_x, int row, int kb, int code, const int4& pv,
                                                 long long q0, long long q1, int lane_id, int nlanes) {
     const long long nkb = a.K >> 4;
-    const int8_t* qm = is_x ? a.wm : a.xm;
-    const uint8_t* qe = is_x ? a.we : a.xe;
+    // (both fields read first: a conditional over `a.we` / `a.xe` themselves becomes a select of addresses inside `a`,
+    //  which keeps a caller's by-value copy of the argument block in scratch memory)
+    const int8_t *w_m = a.wm, *x_m = a.xm;
+    const uint8_t *w_e = a.we, *x_e = a.xe;
+    const int8_t* qm = is_x ? w_m : x_m;
+    const uint8_t* qe = is_x ? w_e : x_e;
     for (long long q = q0 + lane_id; q < q1; q += nlanes) {
         const int4 qv = *reinterpret_cast<const int4*>(qm + tiled_offset(q, (long long)kb * 16, a.K));
         const int ecode = (int)qe[q * nkb + kb];

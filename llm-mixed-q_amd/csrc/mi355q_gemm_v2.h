@@ -113,7 +113,8 @@ __device__ __forceinline__ void bfp_gemm_v2_tile(const GemmArgs& a, const uint8_
     const int sr = tid & 127;
     const long long srow = is_a ? min(m0 + sr, a.M - 1) : min(n0 + sr, a.N - 1);
     const uint8_t* __restrict__ fl = is_a ? xf : wf;
-    const uint8_t* __restrict__ ex = is_a ? a.xe : a.we;
+    const uint8_t *x_e = a.xe, *w_e = a.we;     // (read both, then select: a conditional over the fields is a select of addresses in `a`)
+    const uint8_t* __restrict__ ex = is_a ? x_e : w_e;
     const int sh = is_a ? half_a : half_b;
 
     for (int g = 0; g < ngroups; ++g) {

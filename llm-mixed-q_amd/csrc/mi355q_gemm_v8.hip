@@ -76,12 +76,12 @@ __device__ __forceinline__ void v8_fix_atomic(const GemmArgs& a, int* xb, int* w
         const int* e = v8_entry(xb, wb, cx, j >> 2);
         const int rl = (j & 3) * 64 + lane;
         const long long q = (is_x ? n0 : m0) + rl, r = e[0];
-        if (e[3] == -2 || q >= (is_x ? a.N : a.M) || (!is_x && rl >= bm)) continue;
-        const int4 qv = *reinterpret_cast<const int4*>((is_x ? a.wm : a.xm) + tiled_offset(q, (long long)e[1] * 16, a.K));
+        if (e[3] == -2 || q >= (is_x ? +a.N : +a.M) || (!is_x && rl >= bm)) continue;
+        const int4 qv = *reinterpret_cast<const int4*>((is_x ? +a.wm : +a.xm) + tiled_offset(q, (long long)e[1] * 16, a.K));
         const int d = dot16(*reinterpret_cast<const int4*>(e + 4), qv);
         if (d != 0)
             atomicAdd(&a.y[(is_x ? r : q) * a.ldy + (is_x ? q : r)],
-                      __builtin_ldexpf((float)d, e[2] - (is_x ? a.x_off : a.w_off)) * (is_x ? swt : sxt)[rl]);
+                      __builtin_ldexpf((float)d, e[2] - (is_x ? +a.x_off : +a.w_off)) * (is_x ? swt : sxt)[rl]);
     }
     for (int idx = tid; idx < cx * cw; idx += V8_NT) {
         const int* e = xb + EXC_HEADER + EXC_ENTRY * (idx / cw);
@@ -128,10 +128,10 @@ __device__ __forceinline__ f32x4 v8_mma(const i32x4& fa, const i32x4& fb, const 
 
 template <int FIXMODE_, int TI, int SCHED = (TI == 4 ? 1 : 0), bool BF16 = false>     // 0: the product of the rewritten operands only (benchmarks), 1: with the exception add-back,
                             // 2: as 0, and workgroup 0 prints the clock it held over the K loop (diagnostic build)
-__global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const float* __restrict__ sx,
-                                                        const float* __restrict__ sw, const int* __restrict__ xlist,
-                                                        const int* __restrict__ wlist, const uint8_t* __restrict__ xf,
-                                                        const uint8_t* __restrict__ wf) {
+__global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, const float* __restrict__ sx,
+                                                        const float* __restrict__ sw_in, const int* __restrict__ xlist,
+                                                        const int* __restrict__ wlist_in, const uint8_t* __restrict__ xf,
+                                                        const uint8_t* __restrict__ wf_in) {
     constexpr int FIXMODE = (FIXMODE_ == 1 || FIXMODE_ == 3) ? 1 : 0;      // 3: as 1, with phase timing printed by workgroup 0
     // TI = 16-row MFMA tiles per wave along M.  8: 256 x 256 workgroup tile, two MFMA phases per K-step, three 32-KiB
     // stages.  4: 128 x 256 tile (for shapes whose 256 x 256 tiles would leave compute units idle), one phase per K-step,
@@ -145,7 +145,13 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
 
     const unsigned long long kernel_t0 = FIXMODE_ == 3 ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (int)((a.N + V8_BN - 1) / V8_BN);
+    GemmArgs a = a_in;
+    const float* __restrict__ sw = sw_in;
+    const int* __restrict__ wlist = wlist_in;
+    const uint8_t* __restrict__ wf = wf_in;
+    // grouped launch: the column tiles of `ngroup` equally shaped weight operands side by side (one x, one grid)
+    const int ngroup = a.ngroup > 1 ? a.ngroup : 1;
+    const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n1 = (int)((a.N + V8_BN - 1) / V8_BN), tiles_n = tiles_n1 * ngroup;
     const int S = a.splits > 1 ? a.splits : 1;                 // workgroups per tile (split-K)
     const int nwg = tiles_m * tiles_n * S;
     int pid;
@@ -156,7 +162,17 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
     const int split = pid % S, tile_id = pid / S;               // (a tile's slices are neighbours: same XCD, speed only)
     const int GM = 4, in_group = GM * tiles_n, group_id = tile_id / in_group, first_m = group_id * GM;
     const int gsz = min(tiles_m - first_m, GM);
-    const int tm = first_m + (tile_id % in_group) % gsz, tn = (tile_id % in_group) / gsz;
+    const int tm = first_m + (tile_id % in_group) % gsz;
+    int tn = (tile_id % in_group) / gsz;
+    if (ngroup > 1) {
+        const int which = tn / tiles_n1;                        // (wave-uniform: scalar loads from the argument block)
+        tn -= which * tiles_n1;
+        // (selects over constant indices: a runtime index would put the argument block in scratch memory)
+#define V8_PICK(f) (which == 0 ? a_in.f[0] : which == 1 ? a_in.f[1] : a_in.f[2])
+        a.wm = V8_PICK(g_wm); a.we = V8_PICK(g_we); a.bias = V8_PICK(g_bias); a.y = V8_PICK(g_y);
+        sw = V8_PICK(g_sw); wlist = V8_PICK(g_wlist); wf = V8_PICK(g_wf);
+#undef V8_PICK
+    }
     const long long m0 = (long long)tm * BM, n0 = (long long)tn * V8_BN;
     const int nsteps_all = (int)(a.K >> 6);
     const int kstep0 = (int)((long long)nsteps_all * split / S);          // this workgroup's slice of the K-steps
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
             const bool is_x = i < cx;
             const int* e = v8_entry(xb, wb, cx, i);
             const long long kcol = (long long)e[1] * 16;
-            const int8_t* qm = is_x ? a.wm : a.xm;
+            const int8_t* qm = is_x ? +a.wm : +a.xm;           // (unary +: values, not a select of addresses in the argument block)
             const long long q0 = is_x ? n0 : m0, qmax = (is_x ? Ncols : Mrows) - 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
                 const bool is_x = i < cx;
                 const int* e = v8_entry(xb, wb, cx, i);
                 const int4 pv = *reinterpret_cast<const int4*>(e + 4);
-                const int sh = e[2] - (is_x ? a.x_off : a.w_off);
+                const int sh = e[2] - (is_x ? +a.x_off : +a.w_off);
                 const float* sc = is_x ? swt : sxt;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -294,7 +310,9 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a, const 
         if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
             V8_WAIT(0);
             __syncthreads();
-            v8_fallback(a, xf, wf, xlist, wlist, smem, (int)blockIdx.x, nwg);
+            // (grouped launch: the workgroups of one weight operand share that operand's product)
+            v8_fallback(a, xf, wf, xlist, wlist, smem, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
+                        ngroup > 1 ? tiles_m * tiles_n1 * S : nwg);
             return;
         }
         cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
@@ -770,10 +788,11 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
                        int list_cap, hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
     (void)list_cap;
     GemmArgs a = a_in;
+    const int ngroup = a.ngroup > 1 ? a.ngroup : 1;            // grouped launch: that many weight operands' column tiles
     // 256 x 256 tiles unless they would leave too many of the 256 compute units idle: a 128 x 256 tile does half the
     // work in 0.8 of the time (measured: 48 vs 58 us at 2048 x 4096 x 4096; the fragment reads and LDS-DMA issue of a
     // K-step are shared by half as many MFMAs)
-    const long long tn = (a.N + V8_BN - 1) / V8_BN;
+    const long long tn = (a.N + V8_BN - 1) / V8_BN * ngroup;
     const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
     const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost128 = (double)((t128 + 255) / 256) * 0.82;
     const char* force = getenv("MI355Q_V8_TILE_ROWS");          // (tests pin either flavour)

@@ -75,6 +75,16 @@ struct GemmArgs {
     int dbg;          // diagnostic builds only (MI355Q_V8_DBG with MI355Q_V8_STAMPS): 1 no LDS-DMA, 2 no barrier, 4 no fragment reads
     void* slabs;
     int* tickets;
+    // grouped launch of the tile GEMM (mi355q_bfp_gemm_aligned_multi): `ngroup` weight operands of the same shape against
+    // ONE x; the column tiles of all of them form one grid (column tile tn belongs to weight tn / tiles_n).  0: off.
+    int ngroup;
+    const int8_t* g_wm[3];
+    const uint8_t* g_we[3];
+    const float* g_sw[3];
+    const int* g_wlist[3];
+    const uint8_t* g_wf[3];
+    const float* g_bias[3];
+    float* g_y[3];
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,

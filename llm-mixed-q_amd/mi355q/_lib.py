@@ -53,6 +53,7 @@ SIGNATURES = {
     "mi355q_stream_capture_id": (C.c_uint64, [_vp]),
     "mi355q_rope_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "mi355q_bfp_gemm_aligned_multi": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_gemm_timing_enable": (C.c_int, [C.c_int]),
     "mi355q_gemm_timing_read": (C.c_int, [_vp, _vp, _vp]),
     "mi355q_bfp_gemm_set_variant": (C.c_int, [C.c_int]),
@@ -65,7 +66,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 
@@ -97,6 +98,9 @@ def load_library() -> C.CDLL:
         raise RuntimeError(f"mi355q: ABI version mismatch (library {got}, binding {ABI_VERSION})")
     _LIB = lib
     return lib
+
+
+E_BADARG, E_UNSUPPORTED, E_ALIGN = -1, -2, -3          # include/mi355q.h
 
 
 def check(code: int, what: str) -> None:

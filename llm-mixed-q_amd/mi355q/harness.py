@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .quantize import get_quantized_cls, get_quantized_func
+from .quantize import get_quantized_cls, get_quantized_func, grouped_linear
 from .quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
 
 
@@ -58,8 +58,12 @@ class _Attention(nn.Module):
             # both products, the mask and the softmax in one pass per 16 queries (the harness' mask is the causal one); the
             # kernel reads the [heads, T, hd] views of the projections in place: no `_shape(...).contiguous()` copies
             heads = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
-            o = get_quantized_func("attention", c1)(heads(self.q_proj(x) * self.scaling), heads(self.k_proj(x)),
-                                                    heads(self.v_proj(x)), self.qc["bmm_0"], c1, causal=True)
+            if c1.get("mi355q_grouped_linear", False):       # q / k / v projections: one quantisation, one GEMM launch
+                qp, kp, vp = grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj))
+            else:
+                qp, kp, vp = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+            o = get_quantized_func("attention", c1)(heads(qp * self.scaling), heads(kp), heads(vp), self.qc["bmm_0"], c1,
+                                                    causal=True)
             return self.out_proj(o.transpose(1, 2).reshape(B, T, self.h))
         q = shape(self.q_proj(x) * self.scaling)
         k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
@@ -197,7 +201,10 @@ class _LlamaAttention(nn.Module):
     def forward(self, x, mask, position_ids):
         B, T, _ = x.shape
         shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
-        q, k, v = shape(self.q_proj(x)), shape(self.k_proj(x)), shape(self.v_proj(x))
+        if self.qc["matmul_1"].get("mi355q_grouped_linear", False):
+            q, k, v = (shape(t) for t in grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj)))
+        else:
+            q, k, v = shape(self.q_proj(x)), shape(self.k_proj(x)), shape(self.v_proj(x))
         rc = self.qc["rotary_positional_encoding"]
         q, k = get_quantized_func("rotary_positional_encoding", rc)(q, k, self.cos[:, :, :T], self.sin[:, :, :T],
                                                                    position_ids, config=rc)
@@ -230,6 +237,9 @@ class _LlamaLayer(nn.Module):
     def forward(self, x, mask, position_ids):
         x = x + self.self_attn(self.input_layernorm(x), mask, position_ids)
         h = self.post_attention_layernorm(x)
+        if self.gate_proj.config.get("mi355q_grouped_linear", False):
+            gate, up = grouped_linear(h, (self.gate_proj, self.up_proj))
+            return x + self.down_proj(F.silu(gate) * up)
         return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))     # (modeling_llama.py:208-240)
 
 

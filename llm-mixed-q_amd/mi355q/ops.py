@@ -717,6 +717,30 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     return out
 
 
+def bfp_gemm_aligned_multi(x: AlignedOperand, ws, biases=None):
+    """[x . w^T + bias for w in ws] in ONE launch of the tile GEMM (equally shaped row-aligned weight operands: q / k / v,
+    gate / up); returns None when the library does not take the group (callers then use bfp_gemm_aligned per weight)."""
+    import ctypes
+    M, K, N = x.rows, x.K, ws[0].rows
+    n = len(ws)
+    if not (1 <= n <= 3) or any(w.K != K or w.rows != N for w in ws):
+        return None
+    outs = [torch.empty(M, N, dtype=torch.float32, device=x.tiled.device) for _ in range(n)]
+    x.c_struct()
+    for w in ws:
+        w.c_struct()
+    wp = (ctypes.c_void_p * n)(*[w._cs_addr for w in ws])
+    bp = (ctypes.c_void_p * n)(*[(_ptr(b) if b is not None else None) for b in (biases or [None] * n)])
+    yp = (ctypes.c_void_p * n)(*[_ptr(o) for o in outs])
+    with _on_device(x.tiled.device):
+        rc = _lib.load_library().mi355q_bfp_gemm_aligned_multi(x._cs_addr, ctypes.addressof(wp), ctypes.addressof(bp), ctypes.addressof(yp),
+                                                              n, M, N, K, N, _stream_ptr(x.tiled.device))
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "mi355q_bfp_gemm_aligned_multi")
+    return outs
+
+
 _MATMUL_WS: dict = {}
 
 

@@ -4,7 +4,7 @@ from .quant_config_parser import parse_node_config
 from .quantized_functions import QUANTIZED_FUNC_MAP
 from .quantized_layer_profiler import (profile_linear_layer, profile_matmul_layer, register_a_stat_hook,
                                        update_profile)
-from .quantized_modules import QUANTIZED_MODULE_MAP
+from .quantized_modules import QUANTIZED_MODULE_MAP, grouped_linear      # grouped_linear: an addition (q / k / v in one launch)
 from .quantizers import QUANTIZER_MAP
 
 

@@ -377,6 +377,39 @@ class _LinearBase(nn.Linear):
             self.config.get("bias_width", "NA"))
 
 
+def grouped_linear(x, layers):
+    """[layer(x) for layer in layers] for block_fp PTQ Linear layers that take the SAME input and have the same shape and
+    widths -- the q / k / v projections of an attention block, gate / up of a gated MLP, which the reference's modules
+    call one after the other (modeling_opt.py:231-245, modeling_llama.py:216, 283-287) -- as ONE activation quantisation
+    and ONE launch of the tile GEMM over all their column tiles (ops.bfp_gemm_aligned_multi): the separate products
+    leave compute units idle (2048 -> 2048: 128 tiles each) or waste most of a second round (4096 -> 11008: 344 tiles).
+    Bit-identical to the separate calls; falls back to them whenever the group does not qualify (first PTQ forward,
+    other arithmetics, the per-block bf16 route, differing shapes ...)."""
+    layers = list(layers)
+    first = layers[0]
+    ok = (len(layers) in (2, 3) and all(isinstance(l, _LinearBase) and l.arith == "block_fp" and l.is_ptq and not l.bypass
+                                         and not l.weight_requires_quantisation for l in layers)
+          and not (torch.is_grad_enabled() and x.requires_grad))
+    if ok:
+        plan = first._int8_plan(x)
+        ok = plan is not None and all(
+            l._packed_is_current() and l._align_mode == "rows" and not l._uses_bf16_route() and l._w_packed is None
+            and l.in_features == first.in_features and l.out_features == first.out_features and l._x_cap == first._x_cap
+            and l._x_cap == ops.ROW_BUCKET_CAP and l._int8_plan(x) == plan
+            and all(l.config[k] == first.config[k] for k in ("data_in_width", "data_in_exponent_width", "data_in_exponent_bias"))
+            for l in layers)
+    if ok:
+        c = first.config
+        x2 = x.reshape(-1, first.in_features)
+        with torch.no_grad():
+            xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                                    bucket_cap=first._x_cap)
+            outs = ops.bfp_gemm_aligned_multi(xa, [l._packed[0] for l in layers], [l.bias for l in layers])
+        if outs is not None:
+            return [y.reshape(*x.shape[:-1], first.out_features) for y in outs]
+    return [l(x) for l in layers]
+
+
 def _linear_class(name: str, arith: str):
     return type(name, (_LinearBase,), {"arith": arith, "__module__": __name__,
                                        "__doc__": f"nn.Linear with {arith} input / weight / bias quantisers"})

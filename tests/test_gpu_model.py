@@ -187,3 +187,37 @@ def test_fused_softmax_model_parity():
         with torch.no_grad():
             losses[fused] = float(model(ids.to("cuda:0"), labels=ids.to("cuda:0"))[1])
     assert abs(losses[True] - ref_loss) < 3e-4 and abs(losses[False] - ref_loss) < 3e-4, (losses, ref_loss)
+
+
+@pytest.mark.parametrize("family", ["opt", "llama"])
+def test_grouped_projections_model_bit_identical(family):
+    """config["mi355q_grouped_linear"]: q / k / v (and Llama's gate / up) through ONE quantisation + ONE tile-GEMM launch:
+    logits bit-identical to the layers called one by one (second forward: the first one packs the weights)"""
+    import torch
+    from mi355q import harness as H, ops
+    base = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+                data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+                weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16],
+                mi355q_fused_attention=True, mi355q_align="rows")
+    outs, multi_calls = [], []
+    for grouped in (False, True):
+        torch.manual_seed(7)
+        qc = dict(base, mi355q_grouped_linear=grouped)
+        if family == "opt":
+            cfg = H.TinyOPTConfig(vocab_size=512, hidden_size=256, ffn_dim=512, num_layers=2, num_heads=4, max_positions=512)
+            m = H.TinyOPTForCausalLM(cfg, H.expand_quant_config(qc, cfg.num_layers))
+        else:
+            cfg = H.TinyLlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=512)
+            m = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(qc, cfg.num_layers))
+        m = m.to("cuda:0").eval()
+        ids = torch.randint(0, cfg.vocab_size, (1, 320), generator=torch.Generator().manual_seed(1)).to("cuda:0")
+        real = ops.bfp_gemm_aligned_multi
+        ops.bfp_gemm_aligned_multi = lambda *a, **k: (multi_calls.append(grouped), real(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                m(ids)
+                outs.append(m(ids)[0].clone())
+        finally:
+            ops.bfp_gemm_aligned_multi = real
+    assert torch.equal(outs[0], outs[1])
+    assert multi_calls and all(multi_calls), multi_calls          # (the grouped launch really ran, and only with the knob)

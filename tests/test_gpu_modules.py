@@ -582,3 +582,39 @@ def test_linear_and_matmul_in_the_unblocked_arithmetics():
                bias_exponent_bias=None)
     with pytest.raises(TypeError):
         Q.get_quantized_cls("linear", cfg)(96, 64, bias=True, config=cfg).to(dev)(x)
+
+
+@pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 2048, 2048, 3), (1000, 1024, 2816, 2)])
+def test_grouped_linear_equals_separate_calls(M, K, N, n):
+    """grouped_linear(x, [q, k, v]) -- one quantisation, ONE launch of the tile GEMM over all column tiles -- == the layers
+    called one by one, bit for bit (exceptions of x and of every w included); groups that do not qualify fall back"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    dev = "cuda:0"
+    cfg = _lin_cfg(6, mi355q_align="rows")
+    torch.manual_seed(M + N)
+    layers = [Q.get_quantized_cls("linear", cfg)(K, N, bias=True, config=dict(cfg)).to(dev) for _ in range(n)]
+    with torch.no_grad():
+        for i, l in enumerate(layers):
+            l.weight[i::7, 48:64] *= 2.0 ** 6                 # exception blocks in every weight, different rows
+    x = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev))
+    x[::9, 32:48] *= 2.0 ** -9
+    with torch.no_grad():
+        first = Q.grouped_linear(x, layers)                   # first PTQ forward: not packed yet -> separate calls
+        ref = [l(x).clone() for l in layers]
+        calls, real = [], ops.bfp_gemm_aligned_multi
+        ops.bfp_gemm_aligned_multi = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            got = Q.grouped_linear(x, layers)
+        finally:
+            ops.bfp_gemm_aligned_multi = real
+    assert len(calls) == 1
+    for a, b, c in zip(first, ref, got):
+        assert torch.equal(a, b) and torch.equal(b, c)
+    # a group with different widths does not qualify: same results through the separate calls
+    other = Q.get_quantized_cls("linear", _lin_cfg(4))(K, N, bias=True, config=_lin_cfg(4, mi355q_align="rows")).to(dev)
+    with torch.no_grad():
+        o1 = other(x).clone()
+        mixed = Q.grouped_linear(x, [layers[0], other])
+    assert torch.equal(mixed[0], ref[0]) and torch.equal(mixed[1], o1)

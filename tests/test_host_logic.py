@@ -183,3 +183,48 @@ def test_linear_contract_on_cpu():
     assert torch.equal(byp(x), torch.nn.functional.linear(x, byp.weight, byp.bias))
     with pytest.raises(KeyError):
         cls(32, 16, config={"name": "block_fp", "is_ptq": True})
+
+
+def test_no_kernel_uses_scratch_memory(tmp_path):
+    """Every gfx950 kernel in libmi355q.so keeps its state in registers / LDS: private_segment_fixed_size == 0.
+
+    A kernel that touches scratch memory pays for it on every launch (a by-value copy of the argument block indexed at
+    run time once put the tile GEMM there: +13 us per launch, 94 -> 114 us on the headline step), and the compiler
+    does that silently, so the built code objects are checked here.
+    """
+    import shutil
+    import subprocess
+
+    from mi355q import _lib
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    tools = [llvm / "llvm-objcopy", llvm / "clang-offload-bundler", llvm / "llvm-readelf"]
+    if not all(t.exists() for t in tools) or not Path(_lib.library_path()).exists():
+        pytest.skip("ROCm llvm tools or the built library are not here")
+    fat = tmp_path / "fat.bin"
+    subprocess.run([str(tools[0]), "-O", "binary", "--only-section=.hip_fatbin", str(_lib.library_path()), str(fat)], check=True)
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundles in .hip_fatbin"
+    kernels, offenders = 0, []
+    for i, s in enumerate(starts):
+        part = tmp_path / f"bundle{i}.bin"
+        part.write_bytes(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"co{i}.o"
+        subprocess.run([str(tools[1]), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={part}", f"--output={co}"], check=True)
+        notes = subprocess.run([str(tools[2]), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+            elif line.startswith(".private_segment_fixed_size:"):
+                kernels += 1
+                size = int(line.split(":", 1)[1])
+                if size:
+                    offenders.append((name, size))
+    shutil.rmtree(tmp_path, ignore_errors=True)
+    assert kernels >= 100, kernels
+    assert not offenders, offenders
