@@ -584,7 +584,8 @@ def test_linear_and_matmul_in_the_unblocked_arithmetics():
         Q.get_quantized_cls("linear", cfg)(96, 64, bias=True, config=cfg).to(dev)(x)
 
 
-@pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 2048, 2048, 3), (1000, 1024, 2816, 2)])
+@pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 2048, 2048, 3), (1000, 1024, 2816, 2),
+                                     (256, 8192, 256, 3), (130, 4096, 512, 2)])       # (the last two: split-K slices)
 def test_grouped_linear_equals_separate_calls(M, K, N, n):
     """grouped_linear(x, [q, k, v]) -- one quantisation, ONE launch of the tile GEMM over all column tiles -- == the layers
     called one by one, bit for bit (exceptions of x and of every w included); groups that do not qualify fall back"""
@@ -598,7 +599,13 @@ def test_grouped_linear_equals_separate_calls(M, K, N, n):
     with torch.no_grad():
         for i, l in enumerate(layers):
             l.weight[i::7, 48:64] *= 2.0 ** 6                 # exception blocks in every weight, different rows
-    x = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev))
+    if K <= 2048:
+        x = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev))
+    else:
+        # (rows this long spread their block maxima over more exponents than a row window holds: the buckets would
+        #  overflow and the launch take its blockwise product, whose atomic add-back is not reproducible to the bit.
+        #  Magnitudes within a factor of two keep the exception blocks to the ones placed below.)
+        x = (torch.rand(M, K, device=dev) * 0.9 + 0.6) * torch.sign(torch.randn(M, K, device=dev)) * torch.exp(torch.randn(M, 1, device=dev))
     x[::9, 32:48] *= 2.0 ** -9
     with torch.no_grad():
         first = Q.grouped_linear(x, layers)                   # first PTQ forward: not packed yet -> separate calls
@@ -618,3 +625,41 @@ def test_grouped_linear_equals_separate_calls(M, K, N, n):
         o1 = other(x).clone()
         mixed = Q.grouped_linear(x, [layers[0], other])
     assert torch.equal(mixed[0], ref[0]) and torch.equal(mixed[1], o1)
+
+
+@pytest.mark.parametrize("which", ["x", "w"])
+def test_grouped_linear_bucket_overflow_takes_the_blockwise_product(which):
+    """an exception bucket that overflows (x rows or one weight's rows with more out-of-window blocks than a bucket
+    holds) sends the WHOLE grouped launch to the blockwise-exact product its workgroups carry, each weight's share
+    computed by that weight's workgroups: still == the layers called one by one"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    dev = "cuda:0"
+    M, K, N, n = 512, 2048, 512, 3
+    cfg = _lin_cfg(6, mi355q_align="rows")
+    torch.manual_seed(11)
+    layers = [Q.get_quantized_cls("linear", cfg)(K, N, bias=True, config=dict(cfg)).to(dev) for _ in range(n)]
+    x = torch.randn(M, K, device=dev)
+    with torch.no_grad():
+        if which == "w":
+            layers[1].weight[:64].view(64, K // 16, 16)[:, ::2] *= 2.0 ** -8      # every other block of 64 rows: > 120 per bucket
+        else:
+            x[:64].view(64, K // 16, 16)[:, ::2] *= 2.0 ** -8
+        first = Q.grouped_linear(x, layers)
+        ref = [l(x).clone() for l in layers]
+        calls, real = [], ops.bfp_gemm_aligned_multi
+        ops.bfp_gemm_aligned_multi = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            got = Q.grouped_linear(x, layers)
+        finally:
+            ops.bfp_gemm_aligned_multi = real
+    assert len(calls) == 1
+    for a, b, c in zip(first, ref, got):                      # (the blockwise product adds its exception blocks with fp32
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)    #  atomics: the order of a row's additions is not fixed)
+        torch.testing.assert_close(b, c, rtol=1e-5, atol=1e-5)
+    from oracle import np_oracle as O
+    xq = O.block_fp_quantize(x.cpu().numpy(), 6, 8, 127, [1, 16], skip_first_dim=False)
+    for l, y in zip(layers, got):
+        want = xq.astype(np.float64) @ l.weight.detach().cpu().numpy().astype(np.float64).T + l.bias.detach().cpu().numpy()
+        np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
