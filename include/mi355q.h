@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 11
+#define MI355Q_ABI_VERSION 12
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -92,6 +92,26 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
  *   row-scale int8 GEMM with v_mfma_f32_16x16x32_bf16. */
 int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
                                         int32_t exponent_width, int32_t exponent_bias, void* workspace, void* stream);
+
+/* ---- the elementwise step in front of fc2 / down_proj folded into the operand quantisers ---------------
+ * replaces: models/opt_quantized/modeling_opt.py:412-420 (`fc2(relu(fc1(x)))`: the activation_fn between the two quantised
+ * Linears) and models/llama_quantized/modeling_llama.py:216 (`down_proj(act_fn(gate_proj(x)) * up_proj(x))`) -- there two /
+ * three torch kernels whose result the Linear's x quantiser reads back; here the quantiser reads fc1's / gate's and up's
+ * outputs itself.  pre_op: MI355Q_PRE_NONE x, MI355Q_PRE_RELU max(x, 0), MI355Q_PRE_SILU_MUL (x / (1 + exp(-x))) * x2 with
+ * every operation rounded to fp32 as the separate kernels round it (x2: same shape as x, 16-byte aligned; NULL otherwise).
+ * Everything else as mi355q_block_fp_quantize_bf16_tiled / mi355q_block_fp_quantize_aligned_rows (which are these with
+ * MI355Q_PRE_NONE). */
+#define MI355Q_PRE_NONE 0
+#define MI355Q_PRE_RELU 1
+#define MI355Q_PRE_SILU_MUL 2
+int mi355q_block_fp_quantize_bf16_tiled_pre(const float* x, const float* x2, int32_t pre_op, float* y, uint16_t* y_tiled,
+                                            int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                            int32_t exponent_bias, void* workspace, void* stream);
+int mi355q_block_fp_quantize_aligned_rows_pre(const float* x, const float* x2, int32_t pre_op, int8_t* mant_tiled,
+                                              uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list,
+                                              int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
+                                              int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
+                                              void* stream);
 /* ---- true width-bit weight storage ---------------------------------------------------
  * replaces: nothing the reference executes -- it realises the storage its profiler accounts for
  * (quantized_layer_profiler.py:18-27: width bits per value + exponent_width bits per block; README.md:11, 5x memory

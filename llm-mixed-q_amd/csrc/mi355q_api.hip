@@ -119,12 +119,27 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
     return launch_quant(a, 0, /*needs_fixup=*/false, static_cast<hipStream_t>(stream));
 }
 
+static bool pre_op_ok(int32_t pre_op, const float* x2) {
+    if (pre_op != MI355Q_PRE_NONE && pre_op != MI355Q_PRE_RELU && pre_op != MI355Q_PRE_SILU_MUL) return false;
+    return pre_op != MI355Q_PRE_SILU_MUL || (x2 != nullptr && reinterpret_cast<uintptr_t>(x2) % 16 == 0);
+}
+
 int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
                                         int32_t exponent_width, int32_t exponent_bias, void* workspace, void* stream) {
+    return mi355q_block_fp_quantize_bf16_tiled_pre(x, nullptr, MI355Q_PRE_NONE, y, y_tiled, rows, K, width, exponent_width,
+                                                   exponent_bias, workspace, stream);
+}
+
+int mi355q_block_fp_quantize_bf16_tiled_pre(const float* x, const float* x2, int32_t pre_op, float* y, uint16_t* y_tiled,
+                                            int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                            int32_t exponent_bias, void* workspace, void* stream) {
+    if (!pre_op_ok(pre_op, x2)) return MI355Q_E_BADARG;
     QuantArgs a;
     const int rc = fill_common(a, x, y, workspace, 1, rows, K, 1, 16, MI355Q_ZERO_BLOCK_FAST);
     if (rc == (1 << 30)) return 0;
     if (rc) return rc;
+    a.x2 = x2;
+    a.pre_op = pre_op;
     if (y_tiled == nullptr) return MI355Q_E_BADARG;
     if (exponent_width < 1 || exponent_width > 8 || width < 2) return MI355Q_E_BADARG;
     if (width > 9 || K % 32 != 0) return MI355Q_E_UNSUPPORTED;   // bf16's 8 significant bits; whole 64-byte K-steps
@@ -365,6 +380,17 @@ int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, ui
                                           float* rowscale, int32_t* list, int32_t* list_to_clear, int64_t rows,
                                           int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias,
                                           int32_t bucket_cap, void* stream) {
+    return mi355q_block_fp_quantize_aligned_rows_pre(x, nullptr, MI355Q_PRE_NONE, mant_tiled, exp_out, rowflag, rowscale, list,
+                                                     list_to_clear, rows, K, width, exponent_width, exponent_bias, bucket_cap,
+                                                     stream);
+}
+
+int mi355q_block_fp_quantize_aligned_rows_pre(const float* x, const float* x2, int32_t pre_op, int8_t* mant_tiled,
+                                              uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list,
+                                              int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
+                                              int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
+                                              void* stream) {
+    if (!pre_op_ok(pre_op, x2)) return MI355Q_E_BADARG;
     if (rows < 0 || K < 0 || bucket_cap < MI355Q_ROW_NO_ALIGN || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
     if (rows == 0 || K == 0) return 0;
     if (!x || !mant_tiled || !exp_out || !rowflag || !rowscale || (!list && bucket_cap >= 0) || (list && list_to_clear == list))
@@ -376,6 +402,8 @@ int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, ui
     if (exponent_bias < 0) return MI355Q_E_UNSUPPORTED;          // biased uint8 exponent codes: non-negative biases only
     QuantArgs a{};
     a.x = x;
+    a.x2 = x2;
+    a.pre_op = pre_op;
     a.code = exp_out;
     a.lead = 1; a.rows = rows; a.cols = K;
     a.b0 = 1; a.b1 = 16;

@@ -24,6 +24,10 @@ struct QuantArgs {
     int bias_max;         // bm / bl: 2^exponent_bias_width - 1
     float shift, inv_shift, mant_max;   // 2^mbits, 2^-mbits, 2^mbits - 1
     unsigned flags;
+    // what the two GEMM-operand quantisers (aligned rows, bf16 tiled) read: 0 x itself, MI355Q_PRE_RELU max(x, 0),
+    // MI355Q_PRE_SILU_MUL silu(x) * x2 -- the elementwise step the reference's MLPs put in front of fc2 / down_proj
+    const float* x2;
+    int pre_op;
 };
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);

@@ -497,10 +497,18 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     };
     auto load_row = [&](float4 (&v)[MAXIT], long long row) {
         const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
+        const float4* __restrict__ u4 = reinterpret_cast<const float4*>(a.x2 + row * K);      // (read under pre_op only)
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int kb = it * 64 + wave * 16 + (lane >> 2);
             v[it] = (FULL || (it < nit && kb < nkb)) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (a.pre_op) {                                                                         // (uniform)
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int kb = it * 64 + wave * 16 + (lane >> 2);
+                if (FULL || (it < nit && kb < nkb)) v[it] = apply_pre(a, v[it], u4, it * 256 + tid);
+            }
         }
     };
     // the first row is requested before anything else: the threshold table's own round trip (global -> LDS) and the
@@ -654,6 +662,11 @@ __global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantAr
             const bool valid = j < nhalf;
             float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
             if (valid) { v0 = x4[2 * j]; v1 = x4[2 * j + 1]; }
+            if (valid && a.pre_op) {
+                const float4* __restrict__ u4 = reinterpret_cast<const float4*>(a.x2 + row * K);
+                v0 = apply_pre(a, v0, u4, 2 * j);
+                v1 = apply_pre(a, v1, u4, 2 * j + 1);
+            }
             float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             if (!cast_only) {
                 unsigned m = 0u;

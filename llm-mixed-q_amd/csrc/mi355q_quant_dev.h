@@ -166,6 +166,25 @@ __device__ __forceinline__ float group_max(float v) {
 // two floats -> one dword of bf16 (v_cvt_pk_bf16_f32, round to nearest even).  Quantised values are exact in bf16; the
 // only inexact inputs are elements |x| <= 1e-8, which the reference passes through unquantised (block_fp.py:93-94): they
 // enter the product with a relative error of 2^-9 of themselves, at most 2e-11 absolute each.
+// The elementwise step in front of a GEMM-operand quantiser (QuantArgs::pre_op), with the arithmetic of the torch kernels
+// the reference's MLPs run there: relu = max(x, 0) (NaN kept), silu(x) * u = (x / (1 + exp(-x))) * u, each operation rounded
+// to fp32 (no contraction: the product of the reference is a separate kernel).
+__device__ __forceinline__ float pre_relu(float x) { return x > 0.f || x != x ? x : 0.f; }
+__device__ __forceinline__ float pre_silu_mul(float x, float u) {
+    float s = x / (1.0f + expf(-x));
+    asm volatile("" : "+v"(s));                  // (keeps the product from being fused into the division's last step)
+    return s * u;
+}
+__device__ __forceinline__ float4 apply_pre(const QuantArgs& a, float4 v, const float4* __restrict__ x2_4, long long idx) {
+    if (a.pre_op == MI355Q_PRE_RELU) {
+        v = make_float4(pre_relu(v.x), pre_relu(v.y), pre_relu(v.z), pre_relu(v.w));
+    } else if (a.pre_op == MI355Q_PRE_SILU_MUL) {
+        const float4 u = x2_4[idx];
+        v = make_float4(pre_silu_mul(v.x, u.x), pre_silu_mul(v.y, u.y), pre_silu_mul(v.z, u.z), pre_silu_mul(v.w, u.w));
+    }
+    return v;
+}
+
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};

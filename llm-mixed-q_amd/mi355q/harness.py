@@ -93,7 +93,10 @@ class _DecoderLayer(nn.Module):
         x = x + self.self_attn(self.self_attn_layer_norm(x), mask)
         shape = x.shape
         h = x.reshape(-1, shape[-1])                       # the MLP sees a 2-D activation (modeling_opt.py:412)
-        h = h + self.fc2(F.relu(self.fc1(self.final_layer_norm(h))))
+        if self.fc2.config.get("mi355q_fused_activation", False):    # relu read by fc2's x quantiser (Linear.forward_after)
+            h = h + self.fc2.forward_after(self.fc1(self.final_layer_norm(h)), "relu")
+        else:
+            h = h + self.fc2(F.relu(self.fc1(self.final_layer_norm(h))))
         return h.view(shape)
 
 
@@ -239,8 +242,11 @@ class _LlamaLayer(nn.Module):
         h = self.post_attention_layernorm(x)
         if self.gate_proj.config.get("mi355q_grouped_linear", False):
             gate, up = grouped_linear(h, (self.gate_proj, self.up_proj))
-            return x + self.down_proj(F.silu(gate) * up)
-        return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))     # (modeling_llama.py:208-240)
+        else:
+            gate, up = self.gate_proj(h), self.up_proj(h)
+        if self.down_proj.config.get("mi355q_fused_activation", False):    # silu(gate) * up read by down_proj's x quantiser
+            return x + self.down_proj.forward_after(gate, "silu_mul", up)
+        return x + self.down_proj(F.silu(gate) * up)                      # (modeling_llama.py:208-240)
 
 
 class TinyLlamaForCausalLM(nn.Module):

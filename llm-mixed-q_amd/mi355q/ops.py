@@ -161,8 +161,26 @@ def block_fp_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exp
 _BF16_TILED_BUFFERS: dict = {}
 
 
+PRE_NONE, PRE_RELU, PRE_SILU_MUL = 0, 1, 2        # include/mi355q.h: the elementwise step folded into an operand quantiser
+PRE_OPS = {None: PRE_NONE, "relu": PRE_RELU, "silu_mul": PRE_SILU_MUL}
+
+
+def _pre_args(x, pre):
+    """(op code, second input) of a `pre` = None | ("relu", None) | ("silu_mul", other) request on x [rows, K]"""
+    if pre is None:
+        return PRE_NONE, None
+    op, other = pre
+    code = PRE_OPS[op]
+    if code == PRE_SILU_MUL:
+        assert other is not None and other.shape == x.shape and other.dtype == torch.float32 and other.device == x.device
+        other = other.contiguous()
+    else:
+        other = None
+    return code, other
+
+
 def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, *, out_fake: torch.Tensor = None,
-                                 reuse: bool = True) -> torch.Tensor:
+                                 reuse: bool = True, pre=None) -> torch.Tensor:
     """x [rows, K] fp32 ([1,16] blocks along K) -> bf16 in the tile order of `bf16_gemm_tiled` (a flat int8 buffer of
     mi355q_bfp_tiled_bytes(rows, 2 K) bytes).  `out_fake`: also write the fp32 fake-quantised values there (may be x
     itself).  `reuse`: the buffer is shared by calls with the same shape on the same stream (activations; consume it
@@ -181,11 +199,12 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
             yt = _BF16_TILED_BUFFERS[key] = torch.empty(nbytes, dtype=torch.int8, device=x.device)
     else:
         yt = torch.empty(nbytes, dtype=torch.int8, device=x.device)
+    pre_op, other = _pre_args(x, pre)              # (`pre`: quantise relu(x) / silu(x) * other instead of x, one pass)
     with _on_device(x.device):
-        rc = lib.mi355q_block_fp_quantize_bf16_tiled(_ptr(x), _ptr(out_fake), _ptr(yt), rows, K, int(width), int(exponent_width),
-                                                     _default_bias(exponent_bias), _ptr(_workspace(x.device)),
-                                                     _stream_ptr(x.device))
-    _lib.check(rc, "mi355q_block_fp_quantize_bf16_tiled")
+        rc = lib.mi355q_block_fp_quantize_bf16_tiled_pre(_ptr(x), _ptr(other), pre_op, _ptr(out_fake), _ptr(yt), rows, K,
+                                                         int(width), int(exponent_width), _default_bias(exponent_bias),
+                                                         _ptr(_workspace(x.device)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_fp_quantize_bf16_tiled_pre")
     if out_fake is not None:
         _wrote_into(out_fake)
     return yt
@@ -656,7 +675,7 @@ def _record_operand(buf, x, sig, operand):
 
 
 def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: int, exponent_bias,
-                                   bucket_cap: int = None) -> AlignedOperand:
+                                   bucket_cap: int = None, pre=None) -> AlignedOperand:
     """Fused activation path, ROW-aligned flavour: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack +
     row-align + tile in one kernel (K % 64 == 0, K <= ROW_ALIGN_MAX_K).  Buffers are reused per shape and
     stream like block_fp_quantize_aligned's.  `bucket_cap`: exception entries per 256 rows (default
@@ -672,10 +691,11 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     # (the record is only good inside the capture sequence -- or the eager stretch -- it was made in: a hit while a graph
     #  is being recorded on a record from the warm-up would leave the quantiser out of the graph)
     sig = (int(width), int(exponent_width), bias, bucket_cap, _lib.load_library().mi355q_stream_capture_id(sp))
-    again = _recorded_operand(buf, x, sig)
+    again = _recorded_operand(buf, x, sig) if pre is None else None
     if again is not None:
         return again
     xc = x.contiguous()
+    pre_op, other = _pre_args(xc, pre)             # (`pre`: quantise relu(x) / silu(x) * other instead of x, one pass)
     lib = _lib.load_library()
     if _capturing() and bucket_cap >= 0:
         # HIP-graph capture: a replayed node always sees the pointers it was captured with, so the two alternating lists
@@ -686,14 +706,17 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
         cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
         buf["calls"] += 1
     with _on_device(x.device):
-        rc = lib.mi355q_block_fp_quantize_aligned_rows(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
-                                                       _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows, K, int(width),
-                                                       int(exponent_width), bias, bucket_cap, sp)
-    _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows")
+        rc = lib.mi355q_block_fp_quantize_aligned_rows_pre(_ptr(xc), _ptr(other), pre_op, _ptr(buf["tiled"]), _ptr(buf["exp"]),
+                                                           _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), rows,
+                                                           K, int(width), int(exponent_width), bias, bucket_cap, sp)
+    _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows_pre")
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
     operand = AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
                              int(width) - 1, eb, row_aligned=True, bucket_cap=bucket_cap)
-    _record_operand(buf, x, sig, operand)
+    if pre is None:
+        _record_operand(buf, x, sig, operand)
+    else:
+        buf["last"] = None                         # (the buffers hold another tensor's operand now)
     return operand
 
 

@@ -313,7 +313,30 @@ class _LinearBase(nn.Linear):
         bias = self.b_quantizer(self.bias) if self.bias is not None else None
         return F.linear(x, w, bias)
 
-    def _forward_int8(self, x, plan):
+    def forward_after(self, x, op, other=None):
+        """self(relu(x)) (op = "relu": OPT's fc2 behind its activation_fn, modeling_opt.py:412-420) or
+        self(silu(x) * other) (op = "silu_mul": Llama's down_proj, modeling_llama.py:216) with the elementwise step read by
+        the layer's x quantiser itself -- the reference runs it as torch kernels whose result the quantiser reads back
+        (three passes over the [tokens, ffn] tensor instead of one).  Same arithmetic, rounded to fp32 operation by
+        operation; whenever the fused quantisers do not apply (first PTQ forward, QAT, bypass, other arithmetics, the
+        group flavour) the step runs as torch ops in front of forward()."""
+        if op not in ("relu", "silu_mul") or (op == "silu_mul") != (other is not None):
+            raise ValueError("forward_after: op is 'relu' (no other) or 'silu_mul' (with other)")
+        fused = (self.arith == "block_fp" and self.is_ptq and not self.bypass and not self.weight_requires_quantisation
+                 and x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and (x.requires_grad or (
+                     other is not None and other.requires_grad)))
+                 and (other is None or (other.shape == x.shape and other.dtype == x.dtype and other.device == x.device)))
+        if fused:
+            plan = self._int8_plan(x)
+            fused = (plan is not None and self._packed_is_current()
+                     and (self._uses_bf16_route() or self._align_mode == "rows"))
+        if fused:
+            with torch.no_grad():
+                o2 = None if other is None else other.reshape(-1, self.in_features)
+                return self._forward_int8(x, plan, pre=(op, o2))
+        return self(F.relu(x) if op == "relu" else F.silu(x) * other)
+
+    def _forward_int8(self, x, plan, pre=None):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
         x2 = x.reshape(-1, self.in_features)
@@ -333,12 +356,12 @@ class _LinearBase(nn.Linear):
                     self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
                 wt = self._w_bf16[0]
             xt = ops.block_fp_quantize_bf16_tiled(x2.contiguous(), c["data_in_width"], c["data_in_exponent_width"],
-                                                  c["data_in_exponent_bias"])
+                                                  c["data_in_exponent_bias"], pre=pre)
             y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias)
             return y.reshape(*x.shape[:-1], self.out_features)
         if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
-                                                    c["data_in_exponent_bias"], bucket_cap=self._x_cap)
+                                                    c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre)
         elif self.in_features % 256 == 0:    # the same per 256-value group
             xa = ops.block_fp_quantize_aligned(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                c["data_in_exponent_bias"])

@@ -221,3 +221,39 @@ def test_grouped_projections_model_bit_identical(family):
             ops.bfp_gemm_aligned_multi = real
     assert torch.equal(outs[0], outs[1])
     assert multi_calls and all(multi_calls), multi_calls          # (the grouped launch really ran, and only with the knob)
+
+
+@pytest.mark.parametrize("family,align", [("opt", "auto"), ("opt", "rows"), ("llama", "auto"), ("llama", "rows")])
+def test_fused_activation_model_bit_identical(family, align):
+    """config["mi355q_fused_activation"]: relu (OPT fc2) / silu(gate) * up (Llama down_proj) read by the layer's own x
+    quantiser (Linear.forward_after) instead of torch kernels in front of it: logits bit-identical (second forward:
+    the first one packs the weights and runs the torch ops)"""
+    import torch
+    from mi355q import harness as H, ops
+    base = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+                data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+                weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16],
+                mi355q_fused_attention=True, mi355q_align=align)
+    outs, pre_calls = [], []
+    for fused in (False, True):
+        torch.manual_seed(7)
+        qc = dict(base, mi355q_fused_activation=fused)
+        if family == "opt":
+            cfg = H.TinyOPTConfig(vocab_size=512, hidden_size=256, ffn_dim=512, num_layers=2, num_heads=4, max_positions=512)
+            m = H.TinyOPTForCausalLM(cfg, H.expand_quant_config(qc, cfg.num_layers))
+        else:
+            cfg = H.TinyLlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=512)
+            m = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(qc, cfg.num_layers))
+        m = m.to("cuda:0").eval()
+        ids = torch.randint(0, cfg.vocab_size, (1, 320), generator=torch.Generator().manual_seed(1)).to("cuda:0")
+        real_t, real_r = ops.block_fp_quantize_bf16_tiled, ops.block_fp_quantize_aligned_rows
+        ops.block_fp_quantize_bf16_tiled = lambda *a, **k: (pre_calls.append((fused, k.get("pre") is not None)), real_t(*a, **k))[1]
+        ops.block_fp_quantize_aligned_rows = lambda *a, **k: (pre_calls.append((fused, k.get("pre") is not None)), real_r(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                m(ids)
+                outs.append(m(ids)[0].clone())
+        finally:
+            ops.block_fp_quantize_bf16_tiled, ops.block_fp_quantize_aligned_rows = real_t, real_r
+    assert torch.equal(outs[0], outs[1])
+    assert any(f and p for f, p in pre_calls) and not any(p and not f for f, p in pre_calls), pre_calls

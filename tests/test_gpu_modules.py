@@ -663,3 +663,72 @@ def test_grouped_linear_bucket_overflow_takes_the_blockwise_product(which):
     for l, y in zip(layers, got):
         want = xq.astype(np.float64) @ l.weight.detach().cpu().numpy().astype(np.float64).T + l.bias.detach().cpu().numpy()
         np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("op", ["relu", "silu_mul"])
+@pytest.mark.parametrize("route", ["bf16", "rows"])
+def test_forward_after_equals_torch_ops_then_forward(op, route):
+    """Linear.forward_after(x, op[, other]) -- relu / silu(x) * other read by the layer's x quantiser itself -- == the
+    layer called on the torch result (fc2(relu(.)), modeling_opt.py:412-420; down_proj(act(gate) * up),
+    modeling_llama.py:216), bit for bit: the fused arithmetic rounds operation by operation like the separate kernels"""
+    import torch
+    import torch.nn.functional as F
+    import mi355q.quantize as Q
+    from mi355q import ops
+    dev = "cuda:0"
+    M, K, N = 777, 2048, 512
+    cfg = _lin_cfg(6, mi355q_align="rows")
+    torch.manual_seed(5)
+    lin = Q.get_quantized_cls("linear", cfg)(K, N, bias=True, config=cfg).to(dev)
+    x = torch.randn(M, K, device=dev) * 3
+    other = torch.randn(M, K, device=dev) if op == "silu_mul" else None
+    x[3, :40] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1e-9, -1e-9, 12.0, -12.0, 20.0, -20.0] * 4, device=dev)[:40]
+    x[5, :16] = 0
+    with torch.no_grad():
+        plain = F.relu(x) if op == "relu" else F.silu(x) * other
+        first = lin.forward_after(x, op, other)                # first PTQ forward: packs the weight, torch ops in front
+        assert torch.equal(first, lin(plain))
+        lin._x_cap = ops.ROW_NO_ALIGN if route == "bf16" else ops.ROW_BUCKET_CAP_MAX
+        assert lin._uses_bf16_route() == (route == "bf16")
+        want = lin(plain).clone()
+        calls = []
+        real_t, real_r = ops.block_fp_quantize_bf16_tiled, ops.block_fp_quantize_aligned_rows
+        ops.block_fp_quantize_bf16_tiled = lambda *a, **k: (calls.append(k.get("pre")), real_t(*a, **k))[1]
+        ops.block_fp_quantize_aligned_rows = lambda *a, **k: (calls.append(k.get("pre")), real_r(*a, **k))[1]
+        try:
+            got = lin.forward_after(x, op, other)
+            got3 = lin.forward_after(x.view(1, M, K), op, None if other is None else other.view(1, M, K))
+        finally:
+            ops.block_fp_quantize_bf16_tiled, ops.block_fp_quantize_aligned_rows = real_t, real_r
+    assert len(calls) == 2 and all(c is not None and c[0] == op for c in calls)
+    assert torch.equal(got, want) and torch.equal(got3.view(M, N), want)
+    # what does not qualify runs the torch ops in front of forward(): same values
+    byp = Q.get_quantized_cls("linear", dict(cfg, bypass=True))(K, N, bias=True, config=dict(cfg, bypass=True)).to(dev)
+    with torch.no_grad():
+        torch.testing.assert_close(byp.forward_after(x, op, other), byp(plain), rtol=1e-5, atol=1e-4)     # (library fp32 GEMM)
+    with pytest.raises(ValueError):
+        lin.forward_after(x, "gelu")
+
+
+def test_silu_matches_torch_bit_for_bit_over_the_float_range():
+    """the fused quantiser's silu(x) * u against torch's two kernels on 2^24 values spread over every exponent: the bf16
+    operand (exact image of the fake-quantised values) is identical"""
+    import torch
+    import torch.nn.functional as F
+    from mi355q import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(1)
+    bits = torch.randint(0, 2 ** 31 - 1, (4096, 4096), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+    x = bits.view(torch.float32).clone()
+    x = torch.where(torch.isfinite(x) & (x.abs() < 1e30), x, torch.randn_like(x))
+    x = torch.where(torch.rand(x.shape, device=dev, generator=g) < 0.5, x, torch.randn(x.shape, device=dev, generator=g) * 4)
+    u = torch.randn(x.shape, device=dev, generator=g)
+    want = F.silu(x) * u
+    want = torch.where(torch.isfinite(want), want, torch.zeros_like(want))
+    x = torch.where(torch.isfinite(F.silu(x) * u), x, torch.zeros_like(x))
+    a = ops.block_fp_quantize_bf16_tiled(want.contiguous(), 8, 8, None, reuse=False)
+    b = ops.block_fp_quantize_bf16_tiled(x.contiguous(), 8, 8, None, reuse=False, pre=("silu_mul", u))
+    assert torch.equal(a, b)
+    r1 = ops.block_fp_quantize_bf16_tiled(F.relu(x).contiguous(), 8, 8, None, reuse=False)
+    r2 = ops.block_fp_quantize_bf16_tiled(x.contiguous(), 8, 8, None, reuse=False, pre=("relu", None))
+    assert torch.equal(r1, r2)
