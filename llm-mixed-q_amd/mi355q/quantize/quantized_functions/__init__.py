@@ -199,6 +199,29 @@ def _rope_kernel_applies(q, k, cos_q, sin_q, position_ids) -> bool:
             and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)))
 
 
+# cos / sin tables are constants of the model: their quantised images are kept (the reference re-quantises both on every
+# call, rotary_positional_encoding.py:59-82 -- same values).  Keyed by storage, shape, strides, version counter and
+# quantiser parameters; the record holds the source tensor, so its address cannot have been re-used.  Not consulted while
+# a HIP graph is being recorded (a replay must not depend on a buffer the cache may drop).
+_ROPE_TABLES = {}
+
+
+def _quantised_table(t, quant, sig):
+    from ... import ops
+    if not t.is_cuda or t.requires_grad or ops._capturing():
+        return quant(t)
+    try:
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, sig)
+    except RuntimeError:                      # (inference-mode tensors have no version counter)
+        return quant(t)
+    hit = _ROPE_TABLES.get(key)
+    if hit is None:
+        if len(_ROPE_TABLES) >= 32:
+            _ROPE_TABLES.clear()
+        hit = _ROPE_TABLES[key] = (t.detach(), quant(t).contiguous())
+    return hit[1]
+
+
 def _make_rope(arith, honours_bypass=True):
     def f(q, k, cos, sin, position_ids, config):
         if honours_bypass and config.get("bypass", False):
@@ -209,7 +232,10 @@ def _make_rope(arith, honours_bypass=True):
                 kw["skip_first_dim"] = False
             elif arith == "integer":
                 kw["is_signed"] = True
-            quant = lambda t: QUANTIZER_MAP[arith](t, **kw)
+            raw = lambda t: QUANTIZER_MAP[arith](t, **kw)
+            sig = (arith,) + tuple((key, str(val)) for key, val in sorted(kw.items()))
+            wants_grad = torch.is_grad_enabled() and (cos.requires_grad or sin.requires_grad)
+            quant = raw if wants_grad else (lambda t: _quantised_table(t, raw, sig))
         cos_q, sin_q = quant(cos.squeeze(1).squeeze(0)), quant(sin.squeeze(1).squeeze(0))
         if _rope_kernel_applies(q, k, cos_q, sin_q, position_ids):
             # one launch for q and k, position lookup included (ops.rope_apply), instead of ten elementwise kernels

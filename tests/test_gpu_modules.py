@@ -448,7 +448,7 @@ def test_shared_activation_is_quantised_once():
     layers = [Q.get_quantized_cls("linear", cfg)(256, 128, bias=True, config=dict(cfg)).to(dev) for _ in range(3)]
     x = torch.randn(2, 96, 256, device=dev)
     lib = _lib.load_library()
-    real = lib.mi355q_block_fp_quantize_aligned_rows
+    real = lib.mi355q_block_fp_quantize_aligned_rows_pre
     calls = []
 
     def counting(*a):
@@ -462,7 +462,7 @@ def test_shared_activation_is_quantised_once():
         ref = [l(x).clone() for l in layers]
         ops.REUSE_QUANTISED_INPUT = True
         layers[0](x.clone())                                 # (another tensor of the shape: the record no longer names x)
-        lib.mi355q_block_fp_quantize_aligned_rows = counting
+        lib.mi355q_block_fp_quantize_aligned_rows_pre = counting
         try:
             out = [l(x).clone() for l in layers]
             assert len(calls) == 1, len(calls)
@@ -482,7 +482,7 @@ def test_shared_activation_is_quantised_once():
             ops.REUSE_QUANTISED_INPUT = False
             assert torch.equal(got, layers[2](z))
         finally:
-            lib.mi355q_block_fp_quantize_aligned_rows = real
+            lib.mi355q_block_fp_quantize_aligned_rows_pre = real
             ops.REUSE_QUANTISED_INPUT = True
 
 
@@ -732,3 +732,40 @@ def test_silu_matches_torch_bit_for_bit_over_the_float_range():
     r1 = ops.block_fp_quantize_bf16_tiled(F.relu(x).contiguous(), 8, 8, None, reuse=False)
     r2 = ops.block_fp_quantize_bf16_tiled(x.contiguous(), 8, 8, None, reuse=False, pre=("relu", None))
     assert torch.equal(r1, r2)
+
+
+def test_rope_tables_are_quantised_once():
+    """the cos / sin tables are model constants: their quantised images are kept between calls (same storage, version and
+    quantiser parameters), re-made after an in-place change or under another config; outputs identical either way"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q.quantize import quantized_functions as QF
+    cfg = _lin_cfg(6)
+    f = Q.get_quantized_func("rotary_positional_encoding", cfg)
+    dev = "cuda:0"
+    T, hd = 96, 64
+    pos = torch.arange(T)[:, None] * (1.0 / 10000 ** (torch.arange(0, hd, 2) / hd))[None, :]
+    emb = torch.cat((pos, pos), -1)
+    cos, sin = emb.cos()[None, None].to(dev), emb.sin()[None, None].to(dev)
+    q, k = torch.randn(2, 4, T, hd, device=dev), torch.randn(2, 4, T, hd, device=dev)
+    ids = torch.arange(T, device=dev)[None].expand(2, T).contiguous()
+    calls, real = [], QF.QUANTIZER_MAP["block_fp"]
+    QF._ROPE_TABLES.clear()
+    QF.QUANTIZER_MAP["block_fp"] = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    try:
+        a = f(q, k, cos, sin, ids, cfg)
+        assert len(calls) == 2
+        b = f(q, k, cos[:, :, :T], sin[:, :, :T], ids, cfg)          # (new view objects of the same storage: the model's slices)
+        assert len(calls) == 2
+        cfg4 = _lin_cfg(4)
+        f(q, k, cos, sin, ids, cfg4)
+        assert len(calls) == 4
+        cos.mul_(0.5)
+        c = f(q, k, cos, sin, ids, cfg)
+        assert len(calls) == 5                                        # (cos changed in place, sin did not)
+    finally:
+        QF.QUANTIZER_MAP["block_fp"] = real
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not torch.equal(a[0], c[0])
+    QF._ROPE_TABLES.clear()
+    d = f(q, k, cos, sin, ids, cfg)
+    assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])

@@ -228,3 +228,17 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
     shutil.rmtree(tmp_path, ignore_errors=True)
     assert kernels >= 100, kernels
     assert not offenders, offenders
+
+
+def test_pre_op_entry_points_validate_without_a_gpu():
+    """the quantisers with a folded elementwise step reject unknown ops and a missing / misaligned second input"""
+    from mi355q import _lib
+    lib = _lib.load_library()
+    E_BADARG = _lib.E_BADARG
+    p = 1 << 20
+    assert lib.mi355q_block_fp_quantize_aligned_rows_pre(p, None, 3, p, p, p, p, p, None, 4, 64, 6, 8, 127, 0, None) == E_BADARG
+    assert lib.mi355q_block_fp_quantize_aligned_rows_pre(p, None, 2, p, p, p, p, p, None, 4, 64, 6, 8, 127, 0, None) == E_BADARG
+    assert lib.mi355q_block_fp_quantize_aligned_rows_pre(p, p + 4, 2, p, p, p, p, p, None, 4, 64, 6, 8, 127, 0, None) == E_BADARG
+    assert lib.mi355q_block_fp_quantize_bf16_tiled_pre(p, None, 2, None, p, 4, 64, 6, 8, 127, p, None) == E_BADARG
+    assert lib.mi355q_block_fp_quantize_bf16_tiled_pre(p, None, -1, None, p, 4, 64, 6, 8, 127, p, None) == E_BADARG
+    assert lib.mi355q_block_fp_quantize_bf16_tiled_pre(p, None, 1, None, p, 0, 64, 6, 8, 127, p, None) == 0       # nothing to do
