@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 12
+#define MI355Q_ABI_VERSION 13
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -348,8 +348,9 @@ int mi355q_bfp_attention(const float* q, const float* k, const float* v, const f
                          float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                          const int32_t* pv_params, void* stream);
 /* The same on strided operands -- the [heads, T, D] views of [T, heads, D] projections that the models hand over, without
- * a contiguous copy first: strides = {q batch, q row, k batch, k row, v batch, v row} in elements (innermost stride 1,
- * multiples of 4), NULL = contiguous.  out is contiguous [B, M, D]. */
+ * a contiguous copy first -- and out written where the out-projection reads it ([T, heads, D], i.e. out batch stride D,
+ * row stride heads * D: no transpose copy behind the kernel either): strides = {q batch, q row, k batch, k row, v batch,
+ * v row, out batch, out row} in elements (innermost stride 1, multiples of 4), NULL = all contiguous [B, rows, D]. */
 int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                                  float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D,
                                  const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides, void* stream);

@@ -616,10 +616,10 @@ int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v,
         a[i].e_max = (1 << pr[1]) - 1 - bias;
         set_mantissa(a[i], pr[0] - 1);
     }
-    long long st6[6];
+    long long st6[8];
     if (strides)
-        for (int i = 0; i < 6; ++i) {
-            if (strides[i] % 4) return MI355Q_E_ALIGN;            // (16-byte loads of every row)
+        for (int i = 0; i < 8; ++i) {
+            if (strides[i] % 4) return MI355Q_E_ALIGN;            // (16-byte loads / stores of every row)
             st6[i] = strides[i];
         }
     return launch_bfp_attention(a[0], a[1], a[2], a[3], q, k, v, mask, out, workspace, B, M, T, D, causal ? T - M : -1,

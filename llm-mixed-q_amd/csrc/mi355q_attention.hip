@@ -212,6 +212,7 @@ struct AttnArgs {
     float scale_div;          // 0: none
     int D;
     long long qsb, qsm;       // element strides of q's batch (head) and row
+    long long osb, osm;       // ... of out's
 };
 
 // QG = 16-query groups per workgroup (4 waves each).  Two groups walk the same key tiles in step: the second request for
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
 #pragma unroll
         for (int w = 1; w < KW; ++w) sum += red[w][dt][lane];
         if (m < g.M)
-            *reinterpret_cast<float4*>(g.out + (b * g.M + m) * D + 16 * dt + 4 * lg) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            *reinterpret_cast<float4*>(g.out + b * g.osb + m * g.osm + 16 * dt + 4 * lg) = make_float4(sum[0], sum[1], sum[2], sum[3]);
     }
 }
 
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
     if (m < g.M) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<float4*>(g.out + (b * g.M + m) * D + 16 * dt + 4 * lg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+            *reinterpret_cast<float4*>(g.out + b * g.osb + m * g.osm + 16 * dt + 4 * lg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
     }
 }
 
@@ -617,15 +618,17 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     uint16_t* vf = kf + (size_t)B * NT * (D / 32) * 512;
     const int per = 256 / (int)D;
     const int kblocks = (int)((NT + per - 1) / per);
-    // strides: {q batch, q row, k batch, k row, v batch, v row} in elements (innermost stride 1); null = contiguous
+    // strides: {q batch, q row, k batch, k row, v batch, v row, out batch, out row} in elements (innermost stride 1);
+    // null = contiguous
     const long long qsb = strides ? strides[0] : M * D, qsm = strides ? strides[1] : D;
     const long long ksb = strides ? strides[2] : T * D, kst = strides ? strides[3] : D;
     const long long vsb = strides ? strides[4] : T * D, vst = strides ? strides[5] : D;
+    const long long osb = strides ? strides[6] : M * D, osm = strides ? strides[7] : D;
     hipLaunchKernelGGL(attn_pack_kv_kernel, dim3((unsigned)(kblocks + NPAIR / pg), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf, T,
                        (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm};
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm};
     if (stream) {
         const dim3 sgrid((unsigned)((M + 63) / 64), (unsigned)B);
 #define MI355Q_ATTN_S(DC_)                                                                                          \

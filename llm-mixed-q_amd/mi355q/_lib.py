@@ -69,7 +69,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

@@ -846,12 +846,14 @@ def bfp_attention_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, w
 
 
 def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, pv_params, *, mask: torch.Tensor = None,
-                  causal: bool = False, scale_div: float = None) -> torch.Tensor:
+                  causal: bool = False, scale_div: float = None, token_major: bool = False) -> torch.Tensor:
     """out[b] = Qc(softmax(max(Qa(q[b]) @ Qb(k[b]^T) [/ scale_div] + mask, finfo.min))) @ Qd(v[b]) for q [..., M, D], k and v
     [..., T, D] fp32 (k untransposed; strided head views are read in place), block_fp [1,16] blocks along each operand's
     last dim as the reference's two products apply them (matmul.py:146-196); neither scores nor probabilities are
     written.  qk_params / pv_params: (x width, x exponent width, x exponent bias, y width, y exponent width, y exponent
-    bias) of bmm_0 / bmm_1.  Returns a contiguous tensor of q's shape."""
+    bias) of bmm_0 / bmm_1.  Returns a contiguous tensor of q's shape -- or, with `token_major` and q [1, H, M, D], the
+    [1, H, M, D] view of a contiguous [1, M, H, D] buffer: what the models' `attn_output.transpose(1, 2).reshape(B, T, H * D)`
+    (modeling_opt.py:318-322, modeling_llama.py:349-350) then takes without a copy."""
     import ctypes
     _require_device(q, "bfp_attention")
     assert bfp_attention_supported(q, k, v, (qk_params[0], qk_params[3], pv_params[0], pv_params[3]))
@@ -861,7 +863,13 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
     k3, ksb, kst = _as_heads_view(k)
     v3, vsb, vst = _as_heads_view(v)
     B = q3.shape[0]
-    out = torch.empty(*q.shape, dtype=torch.float32, device=q.device)
+    if token_major and q.ndim == 4 and q.shape[0] == 1:
+        H = q.shape[1]
+        out = torch.empty(1, M, H, D, dtype=torch.float32, device=q.device).permute(0, 2, 1, 3)
+        osb, osm = D, H * D
+    else:
+        out = torch.empty(*q.shape, dtype=torch.float32, device=q.device)
+        osb, osm = M * D, D
     lib = _lib.load_library()
     sp = _stream_ptr(q.device)
     key = (q.device.index, sp, B, T, D)
@@ -874,7 +882,7 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
         assert mask.shape == (M, T) and mask.dtype == torch.float32 and mask.is_contiguous() and mask.device == q.device
     pa = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(qk_params)])
     pb = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(pv_params)])
-    strides = (ctypes.c_int64 * 6)(qsb, qsm, ksb, kst, vsb, vst)
+    strides = (ctypes.c_int64 * 8)(qsb, qsm, ksb, kst, vsb, vst, osb, osm)
     with _on_device(q.device):
         rc = lib.mi355q_bfp_attention_strided(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)),
                                               float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(ws), B, M, T, D,

@@ -124,8 +124,10 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
     products (OPT: bmm_0 / bmm_1, Llama: matmul_0 / matmul_1); `mask` additive [T_q, T_k] (or broadcastable to it over the
     leading dims), `causal=True` stands for the causal mask without reading one; `scale_div`: Llama's sqrt(head_dim).  On
     the HIP path neither scores nor probabilities are ever written (ops.bfp_attention); shapes it does not take, other
-    arithmetics and autograd fall back to the same steps through the registry's own functions.  An addition to the
-    registry (key "attention")."""
+    arithmetics and autograd fall back to the same steps through the registry's own functions.  With
+    `config_pv["mi355q_token_major_output"]` and q [1, heads, T, hd] the result is the [1, heads, T, hd] view of a
+    contiguous [1, T, heads, hd] buffer (same values): the `transpose(1, 2).reshape(B, T, hidden)` that follows in both
+    models is then free.  An addition to the registry (key "attention")."""
     from ... import ops
     m2 = None
     if mask is not None:
@@ -149,7 +151,8 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
             par = lambda c: (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"], c["weight_width"],
                              c["weight_exponent_width"], c["weight_exponent_bias"])
             return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=None if m2 is None else m2.contiguous(),
-                                     causal=causal, scale_div=scale_div)
+                                     causal=causal, scale_div=scale_div,
+                                     token_major=bool(config_pv.get("mi355q_token_major_output", False)))
     style = "bmm" if q.ndim == 3 else "matmul"
     w = QUANTIZED_FUNC_MAP[style][config_qk["name"]](q, k.transpose(-1, -2), config=config_qk)
     if scale_div:

@@ -170,3 +170,34 @@ def test_attention_reads_strided_head_views_in_place():
         got = f(*views, c0, c1, causal=True)
         want = f(*(t.contiguous() for t in views), c0, c1, causal=True)
         assert got.shape == (B, 6, 160, 64) and got.is_contiguous() and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("H,T,D,kernel", [(12, 512, 64, 0), (4, 1536, 64, 3), (3, 640, 128, 1), (2, 2304, 64, 2)])
+def test_token_major_output_is_the_same_tensor_without_the_transpose_copy(H, T, D, kernel):
+    """config_pv["mi355q_token_major_output"]: the kernel stores out where the out-projection reads it ([1, T, H, D]); the
+    [1, H, T, D] view it returns holds the same bits as the contiguous result, and `transpose(1, 2).reshape(1, T, H * D)` is a
+    view of it (no copy)"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    dev = "cuda:0"
+    torch.manual_seed(H + T)
+    proj = [torch.randn(1, T, H * D, device=dev) for _ in range(3)]
+    q, k, v = (p.view(1, T, H, D).transpose(1, 2) for p in proj)
+    cfg = dict(name="block_fp", bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=None,
+               data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=None,
+               weight_block_size=[1, 16])
+    f = Q.get_quantized_func("attention", cfg)
+    prev = ops.attention_set_kernel(kernel)
+    try:
+        want = f(q, k, v, cfg, dict(cfg), causal=True, scale_div=float(D) ** 0.5)
+        got = f(q, k, v, cfg, dict(cfg, mi355q_token_major_output=True), causal=True, scale_div=float(D) ** 0.5)
+    finally:
+        ops.attention_set_kernel(prev)
+    assert want.is_contiguous() and got.shape == want.shape and torch.equal(got, want)
+    flat = got.transpose(1, 2).reshape(1, T, H * D)
+    assert flat.data_ptr() == got.data_ptr() and flat.is_contiguous()
+    # batches of several sequences keep the contiguous layout (one stride cannot span batch and head)
+    q2, k2, v2 = (torch.randn(2, H, 64, D, device=dev) for _ in range(3))
+    got2 = f(q2, k2, v2, cfg, dict(cfg, mi355q_token_major_output=True), causal=True)
+    assert got2.is_contiguous() and torch.equal(got2, f(q2, k2, v2, cfg, dict(cfg), causal=True))

@@ -257,3 +257,35 @@ def test_fused_activation_model_bit_identical(family, align):
             ops.block_fp_quantize_bf16_tiled, ops.block_fp_quantize_aligned_rows = real_t, real_r
     assert torch.equal(outs[0], outs[1])
     assert any(f and p for f, p in pre_calls) and not any(p and not f for f, p in pre_calls), pre_calls
+
+
+@pytest.mark.parametrize("family", ["opt", "llama"])
+def test_all_knobs_together_model_bit_identical(family):
+    """one-pass attention with token-major output + grouped projections + activation inside the x quantiser, all at once,
+    against one-pass attention alone: bit-identical logits, eager and replayed as a HIP graph"""
+    import torch
+    from mi355q import harness as H
+    from mi355q.graphs import GraphedForward
+    base = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+                data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+                weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16],
+                mi355q_fused_attention=True)
+    outs = []
+    for on in (False, True):
+        torch.manual_seed(7)
+        qc = dict(base, mi355q_grouped_linear=on, mi355q_fused_activation=on, mi355q_token_major_output=on)
+        if family == "opt":
+            cfg = H.TinyOPTConfig(vocab_size=512, hidden_size=256, ffn_dim=512, num_layers=2, num_heads=4, max_positions=512)
+            m = H.TinyOPTForCausalLM(cfg, H.expand_quant_config(qc, cfg.num_layers))
+        else:
+            cfg = H.TinyLlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=512)
+            m = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(qc, cfg.num_layers))
+        m = m.to("cuda:0").eval()
+        ids = torch.randint(0, cfg.vocab_size, (1, 320), generator=torch.Generator().manual_seed(1)).to("cuda:0")
+        with torch.no_grad():
+            m(ids)
+            outs.append(m(ids)[0].clone())
+            if on:
+                g = GraphedForward(lambda t: m(t)[0], (ids,))
+                outs.append(g(ids).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
