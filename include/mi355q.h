@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 13
+#define MI355Q_ABI_VERSION 14
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -104,6 +104,7 @@ int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_ti
 #define MI355Q_PRE_NONE 0
 #define MI355Q_PRE_RELU 1
 #define MI355Q_PRE_SILU_MUL 2
+#define MI355Q_PRE_RMSNORM 3        /* mi355q_block_fp_quantize_aligned_rows_norm only */
 int mi355q_block_fp_quantize_bf16_tiled_pre(const float* x, const float* x2, int32_t pre_op, float* y, uint16_t* y_tiled,
                                             int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
                                             int32_t exponent_bias, void* workspace, void* stream);
@@ -112,6 +113,17 @@ int mi355q_block_fp_quantize_aligned_rows_pre(const float* x, const float* x2, i
                                               int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
                                               int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
                                               void* stream);
+/* The same with LlamaRMSNorm in front (models/llama_quantized/modeling_llama.py:81-92: `weight * (x * rsqrt(mean(x^2, -1) +
+ * eps))`, the input of q / k / v and of gate / up, which nothing else reads): pre_op = MI355Q_PRE_RMSNORM, x2 = the norm's
+ * weight [K] (16-byte aligned), eps its epsilon; the row kernel already holds the whole row, so the normalised tensor is
+ * never written.  The products round to fp32 one by one as the reference's ops do; the mean is summed in a fixed order of
+ * this kernel's own (reproducible; within an ulp or two of any other fp32 summation order, torch's reduction kernels
+ * included).  Other pre_op values behave as in mi355q_block_fp_quantize_aligned_rows_pre (eps ignored). */
+int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, int32_t pre_op, float eps, int8_t* mant_tiled,
+                                               uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list,
+                                               int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
+                                               int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
+                                               void* stream);
 /* ---- true width-bit weight storage ---------------------------------------------------
  * replaces: nothing the reference executes -- it realises the storage its profiler accounts for
  * (quantized_layer_profiler.py:18-27: width bits per value + exponent_width bits per block; README.md:11, 5x memory

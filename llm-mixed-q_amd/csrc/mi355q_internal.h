@@ -25,9 +25,11 @@ struct QuantArgs {
     float shift, inv_shift, mant_max;   // 2^mbits, 2^-mbits, 2^mbits - 1
     unsigned flags;
     // what the two GEMM-operand quantisers (aligned rows, bf16 tiled) read: 0 x itself, MI355Q_PRE_RELU max(x, 0),
-    // MI355Q_PRE_SILU_MUL silu(x) * x2 -- the elementwise step the reference's MLPs put in front of fc2 / down_proj
+    // MI355Q_PRE_SILU_MUL silu(x) * x2 -- the elementwise step the reference's MLPs put in front of fc2 / down_proj;
+    // MI355Q_PRE_RMSNORM (x * rsqrt(mean(x^2) + eps)) * weight -- LlamaRMSNorm in front of q / k / v and gate / up
     const float* x2;
     int pre_op;
+    float pre_eps;        // MI355Q_PRE_RMSNORM (aligned-rows quantiser only): x2 = the norm's weight [cols], pre_eps its epsilon
 };
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);

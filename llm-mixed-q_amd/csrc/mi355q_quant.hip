@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
                                                                    int* __restrict__ list_to_clear, int bcap) {
     __shared__ Lut lut;
     __shared__ RowAlignSmem rsm;
+    __shared__ float norm_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long K = a.cols;
     const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
@@ -503,7 +504,33 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             const int kb = it * 64 + wave * 16 + (lane >> 2);
             v[it] = (FULL || (it < nit && kb < nkb)) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (a.pre_op) {                                                                         // (uniform)
+        if (a.pre_op == MI355Q_PRE_RMSNORM) {                                                  // (uniform)
+            // LlamaRMSNorm (modeling_llama.py:88-92): x * rsqrt(mean(x^2) + eps), then weight * that, each product rounded
+            // to fp32 like the reference's separate ops.  The mean is summed in a fixed order (lane partials over the
+            // row's chunks, xor tree over the wave, the four waves in turn): the same bits run after run, not the bits of
+            // torch's reduction kernel (no two of its back ends agree on those either).
+            float ss = 0.f;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) ss += (v[it].x * v[it].x + v[it].y * v[it].y) + (v[it].z * v[it].z + v[it].w * v[it].w);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+            __syncthreads();                                   // (the previous row's readers are done with norm_part)
+            if (lane == 0) norm_part[wave] = ss;
+            __syncthreads();
+            const float var = (((norm_part[0] + norm_part[1]) + norm_part[2]) + norm_part[3]) * (1.0f / (float)K);
+            const float rs = rsqrtf(var + a.pre_eps);
+            const float4* __restrict__ w4 = reinterpret_cast<const float4*>(a.x2);
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int kb = it * 64 + wave * 16 + (lane >> 2);
+                if (FULL || (it < nit && kb < nkb)) {
+                    const float4 w = w4[it * 256 + tid];
+                    float4 h = make_float4(v[it].x * rs, v[it].y * rs, v[it].z * rs, v[it].w * rs);
+                    asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w));       // (two roundings, as two ops)
+                    v[it] = make_float4(w.x * h.x, w.y * h.y, w.z * h.z, w.w * h.w);
+                }
+            }
+        } else if (a.pre_op) {                                                                  // (uniform)
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
                 const int kb = it * 64 + wave * 16 + (lane >> 2);

@@ -201,11 +201,11 @@ class _LlamaAttention(nn.Module):
         self.register_buffer("cos", emb.cos()[None, None], persistent=False)       # [1, 1, pos, hd]
         self.register_buffer("sin", emb.sin()[None, None], persistent=False)
 
-    def forward(self, x, mask, position_ids):
+    def forward(self, x, mask, position_ids, norm=None):
         B, T, _ = x.shape
         shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
         if self.qc["matmul_1"].get("mi355q_grouped_linear", False):
-            q, k, v = (shape(t) for t in grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj)))
+            q, k, v = (shape(t) for t in grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj), norm=norm))
         else:
             q, k, v = shape(self.q_proj(x)), shape(self.k_proj(x)), shape(self.v_proj(x))
         rc = self.qc["rotary_positional_encoding"]
@@ -238,6 +238,15 @@ class _LlamaLayer(nn.Module):
         self.down_proj = lin("down_proj", cfg.intermediate_size, cfg.hidden_size)
 
     def forward(self, x, mask, position_ids):
+        gc = self.gate_proj.config
+        fused_norm = gc.get("mi355q_grouped_linear", False) and gc.get("mi355q_fused_norm", False)
+        if fused_norm:      # the norms are applied by the quantiser of the projections they feed (grouped_linear(norm=...))
+            n1, n2 = self.input_layernorm, self.post_attention_layernorm
+            x = x + self.self_attn(x, mask, position_ids, norm=(n1.weight, n1.eps))
+            gate, up = grouped_linear(x, (self.gate_proj, self.up_proj), norm=(n2.weight, n2.eps))
+            if self.down_proj.config.get("mi355q_fused_activation", False):
+                return x + self.down_proj.forward_after(gate, "silu_mul", up)
+            return x + self.down_proj(F.silu(gate) * up)
         x = x + self.self_attn(self.input_layernorm(x), mask, position_ids)
         h = self.post_attention_layernorm(x)
         if self.gate_proj.config.get("mi355q_grouped_linear", False):

@@ -400,22 +400,33 @@ class _LinearBase(nn.Linear):
             self.config.get("bias_width", "NA"))
 
 
-def grouped_linear(x, layers):
+def grouped_linear(x, layers, norm=None):
     """[layer(x) for layer in layers] for block_fp PTQ Linear layers that take the SAME input and have the same shape and
     widths -- the q / k / v projections of an attention block, gate / up of a gated MLP, which the reference's modules
     call one after the other (modeling_opt.py:231-245, modeling_llama.py:216, 283-287) -- as ONE activation quantisation
     and ONE launch of the tile GEMM over all their column tiles (ops.bfp_gemm_aligned_multi): the separate products
     leave compute units idle (2048 -> 2048: 128 tiles each) or waste most of a second round (4096 -> 11008: 344 tiles).
     Bit-identical to the separate calls; falls back to them whenever the group does not qualify (first PTQ forward,
-    other arithmetics, the per-block bf16 route, differing shapes ...)."""
+    other arithmetics, the per-block bf16 route, differing shapes ...).
+
+    `norm` = (weight, eps): the layers take LlamaRMSNorm(x) (modeling_llama.py:81-92, 236-238: the input of q / k / v and of
+    gate / up, which nothing else reads) and the quantiser -- which holds a whole row per workgroup -- applies the norm
+    itself, so the normalised tensor is never written.  Then the mean of squares is summed in the kernel's own fixed
+    order: results agree with the separate norm to within the last-bit differences any two fp32 summation orders
+    show (torch's own CPU and GPU reductions included), not bit for bit."""
     layers = list(layers)
     first = layers[0]
-    ok = (len(layers) in (2, 3) and all(isinstance(l, _LinearBase) and l.arith == "block_fp" and l.is_ptq and not l.bypass
+
+    def normed():
+        w, eps = norm
+        v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        return w * (x * torch.rsqrt(v + eps)).to(x.dtype)
+    ok = (len(layers) in ((1, 2, 3) if norm is not None else (2, 3)) and all(isinstance(l, _LinearBase) and l.arith == "block_fp" and l.is_ptq and not l.bypass
                                          and not l.weight_requires_quantisation for l in layers)
           and not (torch.is_grad_enabled() and x.requires_grad))
     if ok:
         plan = first._int8_plan(x)
-        ok = plan is not None and all(
+        ok = plan is not None and (norm is None or (x.is_cuda and x.dtype == torch.float32)) and all(
             l._packed_is_current() and l._align_mode == "rows" and not l._uses_bf16_route() and l._w_packed is None
             and l.in_features == first.in_features and l.out_features == first.out_features and l._x_cap == first._x_cap
             and l._x_cap == ops.ROW_BUCKET_CAP and l._int8_plan(x) == plan
@@ -426,11 +437,13 @@ def grouped_linear(x, layers):
         x2 = x.reshape(-1, first.in_features)
         with torch.no_grad():
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
-                                                    bucket_cap=first._x_cap)
+                                                    bucket_cap=first._x_cap,
+                                                    pre=None if norm is None else ("rmsnorm", norm[0], norm[1]))
             outs = ops.bfp_gemm_aligned_multi(xa, [l._packed[0] for l in layers], [l.bias for l in layers])
         if outs is not None:
             return [y.reshape(*x.shape[:-1], first.out_features) for y in outs]
-    return [l(x) for l in layers]
+    h = x if norm is None else normed()
+    return [l(h) for l in layers]
 
 
 def _linear_class(name: str, arith: str):

@@ -769,3 +769,48 @@ def test_rope_tables_are_quantised_once():
     QF._ROPE_TABLES.clear()
     d = f(q, k, cos, sin, ids, cfg)
     assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])
+
+
+@pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 4096, 512, 2), (77, 1024, 256, 1), (64, 11008 // 2 + 384, 256, 2)])
+def test_grouped_linear_with_the_norm_inside_the_quantiser(M, K, N, n):
+    """grouped_linear(x, layers, norm=(weight, eps)) -- LlamaRMSNorm applied by the row quantiser itself -- against the layers
+    on the separately normalised tensor: the quantised operand agrees except where the last bit of the mean moved an
+    element across a rounding boundary (a handful in a million), outputs to that accuracy; identical run after run; equal
+    to the oracle's norm + quantiser to the same accuracy"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    from oracle import np_oracle as O
+    dev = "cuda:0"
+    cfg = _lin_cfg(6, mi355q_align="rows")
+    torch.manual_seed(M + K)
+    layers = [Q.get_quantized_cls("linear", cfg)(K, N, bias=False, config=dict(cfg)).to(dev) for _ in range(n)]
+    x = torch.randn(M, K, device=dev)
+    if K > 2048:       # (long rows of normal values overflow the exception buckets: see test_grouped_linear_equals_separate_calls)
+        x = (torch.rand(M, K, device=dev) * 0.9 + 0.6) * torch.sign(x)
+    x = x * torch.exp(torch.randn(M, 1, device=dev))
+    x[::9, 32:48] *= 2.0 ** -9
+    w = (1 + 0.1 * torch.randn(K, device=dev)).contiguous()
+    eps = 1e-6
+    with torch.no_grad():
+        h = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+        first = Q.grouped_linear(x, layers, norm=(w, eps))        # first PTQ forward: torch norm + separate calls
+        ref = [l(h).clone() for l in layers]
+        for a, b in zip(first, ref):
+            assert torch.equal(a, b)
+        calls, real = [], ops.block_fp_quantize_aligned_rows
+        ops.block_fp_quantize_aligned_rows = lambda *a, **k: (calls.append(k.get("pre")), real(*a, **k))[1]
+        try:
+            got = Q.grouped_linear(x, layers, norm=(w, eps))
+            again = Q.grouped_linear(x, layers, norm=(w, eps))
+        finally:
+            ops.block_fp_quantize_aligned_rows = real
+        assert len(calls) == 2 and all(c is not None and c[0] == "rmsnorm" for c in calls)
+    for a, b, c in zip(ref, got, again):
+        assert torch.equal(b, c)                                  # reproducible
+        scale = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-3 * scale         # a few elements moved by one quantisation step
+        assert ((a - b).abs() > 1e-6 * scale).float().mean().item() < 0.2
+    hq = O.block_fp_quantize(h.cpu().numpy(), 6, 8, 127, [1, 16], skip_first_dim=False).astype(np.float64)
+    want = hq @ layers[0].weight.detach().cpu().numpy().astype(np.float64).T
+    np.testing.assert_allclose(got[0].cpu().numpy(), want, rtol=0, atol=2e-3 * float(np.abs(want).max()))
