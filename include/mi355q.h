@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 14
+#define MI355Q_ABI_VERSION 15
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -105,6 +105,7 @@ int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_ti
 #define MI355Q_PRE_RELU 1
 #define MI355Q_PRE_SILU_MUL 2
 #define MI355Q_PRE_RMSNORM 3        /* mi355q_block_fp_quantize_aligned_rows_norm only */
+#define MI355Q_PRE_LAYERNORM 4      /* mi355q_block_fp_quantize_aligned_rows_norm only */
 int mi355q_block_fp_quantize_bf16_tiled_pre(const float* x, const float* x2, int32_t pre_op, float* y, uint16_t* y_tiled,
                                             int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
                                             int32_t exponent_bias, void* workspace, void* stream);
@@ -118,8 +119,12 @@ int mi355q_block_fp_quantize_aligned_rows_pre(const float* x, const float* x2, i
  * weight [K] (16-byte aligned), eps its epsilon; the row kernel already holds the whole row, so the normalised tensor is
  * never written.  The products round to fp32 one by one as the reference's ops do; the mean is summed in a fixed order of
  * this kernel's own (reproducible; within an ulp or two of any other fp32 summation order, torch's reduction kernels
- * included).  Other pre_op values behave as in mi355q_block_fp_quantize_aligned_rows_pre (eps ignored). */
-int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, int32_t pre_op, float eps, int8_t* mant_tiled,
+ * included).  pre_op = MI355Q_PRE_LAYERNORM: nn.LayerNorm over the row instead (models/opt_quantized/modeling_opt.py:391-415,
+ * self_attn_layer_norm in front of q / k / v, final_layer_norm in front of fc1): (x - mean) * rsqrt(var + eps) * x2 + x3,
+ * biased variance, x3 = the norm's bias [K] or NULL.  Other pre_op values behave as in
+ * mi355q_block_fp_quantize_aligned_rows_pre (eps, x3 ignored). */
+int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, const float* x3, int32_t pre_op, float eps,
+                                               int8_t* mant_tiled,
                                                uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list,
                                                int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
                                                int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,

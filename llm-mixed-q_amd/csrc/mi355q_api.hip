@@ -120,11 +120,10 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
 }
 
 static bool pre_op_ok(int32_t pre_op, const float* x2, bool rows_kernel = false) {
-    if (pre_op == MI355Q_PRE_RMSNORM && !rows_kernel) return false;      // (needs the whole row in one workgroup)
-    if (pre_op != MI355Q_PRE_NONE && pre_op != MI355Q_PRE_RELU && pre_op != MI355Q_PRE_SILU_MUL && pre_op != MI355Q_PRE_RMSNORM)
-        return false;
-    return (pre_op != MI355Q_PRE_SILU_MUL && pre_op != MI355Q_PRE_RMSNORM) ||
-           (x2 != nullptr && reinterpret_cast<uintptr_t>(x2) % 16 == 0);
+    const bool norm = pre_op == MI355Q_PRE_RMSNORM || pre_op == MI355Q_PRE_LAYERNORM;
+    if (norm && !rows_kernel) return false;                              // (needs the whole row in one workgroup)
+    if (pre_op != MI355Q_PRE_NONE && pre_op != MI355Q_PRE_RELU && pre_op != MI355Q_PRE_SILU_MUL && !norm) return false;
+    return (pre_op != MI355Q_PRE_SILU_MUL && !norm) || (x2 != nullptr && reinterpret_cast<uintptr_t>(x2) % 16 == 0);
 }
 
 int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
@@ -393,17 +392,19 @@ int mi355q_block_fp_quantize_aligned_rows_pre(const float* x, const float* x2, i
                                               int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
                                               int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
                                               void* stream) {
-    return mi355q_block_fp_quantize_aligned_rows_norm(x, x2, pre_op, 0.f, mant_tiled, exp_out, rowflag, rowscale, list,
+    if (pre_op == MI355Q_PRE_LAYERNORM) return MI355Q_E_BADARG;          // (mi355q_block_fp_quantize_aligned_rows_norm)
+    return mi355q_block_fp_quantize_aligned_rows_norm(x, x2, nullptr, pre_op, 0.f, mant_tiled, exp_out, rowflag, rowscale, list,
                                                       list_to_clear, rows, K, width, exponent_width, exponent_bias, bucket_cap,
                                                       stream);
 }
 
-int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, int32_t pre_op, float eps, int8_t* mant_tiled,
+int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, const float* x3, int32_t pre_op, float eps,
+                                               int8_t* mant_tiled,
                                                uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list,
                                                int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
                                                int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
                                                void* stream) {
-    if (!pre_op_ok(pre_op, x2, true) || !(eps >= 0.f)) return MI355Q_E_BADARG;
+    if (!pre_op_ok(pre_op, x2, true) || !(eps >= 0.f) || reinterpret_cast<uintptr_t>(x3) % 16) return MI355Q_E_BADARG;
     if (rows < 0 || K < 0 || bucket_cap < MI355Q_ROW_NO_ALIGN || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
     if (rows == 0 || K == 0) return 0;
     if (!x || !mant_tiled || !exp_out || !rowflag || !rowscale || (!list && bucket_cap >= 0) || (list && list_to_clear == list))
@@ -418,6 +419,7 @@ int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, 
     a.x2 = x2;
     a.pre_op = pre_op;
     a.pre_eps = eps;
+    a.x3 = pre_op == MI355Q_PRE_LAYERNORM ? x3 : nullptr;
     a.code = exp_out;
     a.lead = 1; a.rows = rows; a.cols = K;
     a.b0 = 1; a.b1 = 16;

@@ -29,7 +29,8 @@ struct QuantArgs {
     // MI355Q_PRE_RMSNORM (x * rsqrt(mean(x^2) + eps)) * weight -- LlamaRMSNorm in front of q / k / v and gate / up
     const float* x2;
     int pre_op;
-    float pre_eps;        // MI355Q_PRE_RMSNORM (aligned-rows quantiser only): x2 = the norm's weight [cols], pre_eps its epsilon
+    float pre_eps;        // MI355Q_PRE_RMSNORM / _LAYERNORM (aligned-rows quantiser only): x2 = the norm's weight [cols],
+    const float* x3;      // pre_eps its epsilon, x3 = the LayerNorm's bias [cols] (null: none)
 };
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);

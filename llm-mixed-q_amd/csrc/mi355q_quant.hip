@@ -530,6 +530,44 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
                     v[it] = make_float4(w.x * h.x, w.y * h.y, w.z * h.z, w.w * h.w);
                 }
             }
+        } else if (a.pre_op == MI355Q_PRE_LAYERNORM) {                                          // (uniform)
+            // nn.LayerNorm over the row (OPT's self_attn_layer_norm / final_layer_norm, modeling_opt.py:391-415):
+            // (x - mean) * rsqrt(var + eps) * weight + bias, biased variance, mean first and the centred squares after it
+            // (the row sits in registers), both summed in the fixed order described above.
+            auto row_sum = [&](float part) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+                __syncthreads();
+                if (lane == 0) norm_part[wave] = part;
+                __syncthreads();
+                return ((norm_part[0] + norm_part[1]) + norm_part[2]) + norm_part[3];
+            };
+            float s1 = 0.f;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) s1 += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+            const float mean = row_sum(s1) * (1.0f / (float)K);
+            float s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int kb = it * 64 + wave * 16 + (lane >> 2);
+                if (FULL || (it < nit && kb < nkb)) {
+                    v[it] = make_float4(v[it].x - mean, v[it].y - mean, v[it].z - mean, v[it].w - mean);
+                    s2 += (v[it].x * v[it].x + v[it].y * v[it].y) + (v[it].z * v[it].z + v[it].w * v[it].w);
+                }
+            }
+            const float rs = rsqrtf(row_sum(s2) * (1.0f / (float)K) + a.pre_eps);
+            const float4* __restrict__ w4 = reinterpret_cast<const float4*>(a.x2);
+            const float4* __restrict__ b4 = reinterpret_cast<const float4*>(a.x3);
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int kb = it * 64 + wave * 16 + (lane >> 2);
+                if (FULL || (it < nit && kb < nkb)) {
+                    const float4 w = w4[it * 256 + tid];
+                    const float4 b = b4 ? b4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[it] = make_float4(v[it].x * rs * w.x + b.x, v[it].y * rs * w.y + b.y, v[it].z * rs * w.z + b.z,
+                                        v[it].w * rs * w.w + b.w);
+                }
+            }
         } else if (a.pre_op) {                                                                  // (uniform)
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {

@@ -50,7 +50,7 @@ class _Attention(nn.Module):
         for name in ("q_proj", "k_proj", "v_proj", "out_proj"):
             setattr(self, name, get_quantized_cls("linear", qc[name])(self.h, self.h, bias=True, config=qc[name]))
 
-    def forward(self, x, mask):
+    def forward(self, x, mask, norm=None):
         B, T, _ = x.shape
         shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2).contiguous().view(B * self.nh, T, self.hd)
         c1 = self.qc["bmm_1"]
@@ -59,7 +59,7 @@ class _Attention(nn.Module):
             # kernel reads the [heads, T, hd] views of the projections in place: no `_shape(...).contiguous()` copies
             heads = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
             if c1.get("mi355q_grouped_linear", False):       # q / k / v projections: one quantisation, one GEMM launch
-                qp, kp, vp = grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj))
+                qp, kp, vp = grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj), norm=norm)
             else:
                 qp, kp, vp = self.q_proj(x), self.k_proj(x), self.v_proj(x)
             o = get_quantized_func("attention", c1)(heads(qp * self.scaling), heads(kp), heads(vp), self.qc["bmm_0"], c1,
@@ -90,11 +90,24 @@ class _DecoderLayer(nn.Module):
         self.fc2 = get_quantized_cls("linear", qc["fc2"])(cfg.ffn_dim, cfg.hidden_size, bias=True, config=qc["fc2"])
 
     def forward(self, x, mask):
-        x = x + self.self_attn(self.self_attn_layer_norm(x), mask)
+        c1 = self.self_attn.qc["bmm_1"]
+        fused_norm = (self.fc1.config.get("mi355q_fused_norm", False) and c1.get("mi355q_grouped_linear", False)
+                      and c1.get("mi355q_fused_attention", False) and c1["name"] == "block_fp")
+        ln = lambda m: (m.weight, m.bias, m.eps)
+        if fused_norm:      # the LayerNorms are applied by the quantiser of the projections they feed (grouped_linear(norm=...))
+            x = x + self.self_attn(x, mask, norm=ln(self.self_attn_layer_norm))
+        else:
+            x = x + self.self_attn(self.self_attn_layer_norm(x), mask)
         shape = x.shape
         h = x.reshape(-1, shape[-1])                       # the MLP sees a 2-D activation (modeling_opt.py:412)
+        if fused_norm:
+            f1 = grouped_linear(h, (self.fc1,), norm=ln(self.final_layer_norm))[0]
+        else:
+            f1 = None
         if self.fc2.config.get("mi355q_fused_activation", False):    # relu read by fc2's x quantiser (Linear.forward_after)
-            h = h + self.fc2.forward_after(self.fc1(self.final_layer_norm(h)), "relu")
+            h = h + self.fc2.forward_after(f1 if fused_norm else self.fc1(self.final_layer_norm(h)), "relu")
+        elif fused_norm:
+            h = h + self.fc2(F.relu(f1))
         else:
             h = h + self.fc2(F.relu(self.fc1(self.final_layer_norm(h))))
         return h.view(shape)

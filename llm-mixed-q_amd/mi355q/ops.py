@@ -161,24 +161,27 @@ def block_fp_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exp
 _BF16_TILED_BUFFERS: dict = {}
 
 
-PRE_NONE, PRE_RELU, PRE_SILU_MUL, PRE_RMSNORM = 0, 1, 2, 3   # include/mi355q.h: the step folded into an operand quantiser
-PRE_OPS = {None: PRE_NONE, "relu": PRE_RELU, "silu_mul": PRE_SILU_MUL, "rmsnorm": PRE_RMSNORM}
+PRE_NONE, PRE_RELU, PRE_SILU_MUL, PRE_RMSNORM, PRE_LAYERNORM = 0, 1, 2, 3, 4   # include/mi355q.h: steps folded into a quantiser
+PRE_OPS = {None: PRE_NONE, "relu": PRE_RELU, "silu_mul": PRE_SILU_MUL, "rmsnorm": PRE_RMSNORM, "layernorm": PRE_LAYERNORM}
 
 
 def _pre_args(x, pre):
-    """(op code, second input, epsilon) of a `pre` = None | ("relu", None) | ("silu_mul", other) | ("rmsnorm", weight, eps)
-    request on x [rows, K]"""
+    """(op code, second input, epsilon, third input) of a `pre` = None | ("relu", None) | ("silu_mul", other) |
+    ("rmsnorm", weight, eps) | ("layernorm", weight, eps, bias) request on x [rows, K]"""
     if pre is None:
-        return PRE_NONE, None, 0.0
+        return PRE_NONE, None, 0.0, None
     op, other = pre[0], pre[1]
     code = PRE_OPS[op]
     if code == PRE_SILU_MUL:
         assert other is not None and other.shape == x.shape and other.dtype == torch.float32 and other.device == x.device
-        return code, other.contiguous(), 0.0
-    if code == PRE_RMSNORM:
-        assert other is not None and other.shape == (x.shape[1],) and other.dtype == torch.float32 and other.device == x.device
-        return code, other.detach().contiguous(), float(pre[2])
-    return code, None, 0.0
+        return code, other.contiguous(), 0.0, None
+    if code in (PRE_RMSNORM, PRE_LAYERNORM):
+        vec = lambda t: t is not None and t.shape == (x.shape[1],) and t.dtype == torch.float32 and t.device == x.device
+        assert vec(other)
+        bias = pre[3] if code == PRE_LAYERNORM and len(pre) > 3 else None
+        assert bias is None or vec(bias)
+        return code, other.detach().contiguous(), float(pre[2]), None if bias is None else bias.detach().contiguous()
+    return code, None, 0.0, None
 
 
 def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, *, out_fake: torch.Tensor = None,
@@ -201,7 +204,7 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
             yt = _BF16_TILED_BUFFERS[key] = torch.empty(nbytes, dtype=torch.int8, device=x.device)
     else:
         yt = torch.empty(nbytes, dtype=torch.int8, device=x.device)
-    pre_op, other, _ = _pre_args(x, pre)           # (`pre`: quantise relu(x) / silu(x) * other instead of x, one pass)
+    pre_op, other, _, _ = _pre_args(x, pre)        # (`pre`: quantise relu(x) / silu(x) * other instead of x, one pass)
     with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_bf16_tiled_pre(_ptr(x), _ptr(other), pre_op, _ptr(out_fake), _ptr(yt), rows, K,
                                                          int(width), int(exponent_width), _default_bias(exponent_bias),
@@ -697,7 +700,7 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     if again is not None:
         return again
     xc = x.contiguous()
-    pre_op, other, eps = _pre_args(xc, pre)        # (`pre`: quantise relu(x) / silu(x) * other / rmsnorm(x) instead of x)
+    pre_op, other, eps, third = _pre_args(xc, pre)    # (`pre`: quantise relu(x) / silu(x) * other / norm(x) instead of x)
     lib = _lib.load_library()
     if _capturing() and bucket_cap >= 0:
         # HIP-graph capture: a replayed node always sees the pointers it was captured with, so the two alternating lists
@@ -708,7 +711,7 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
         cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
         buf["calls"] += 1
     with _on_device(x.device):
-        rc = lib.mi355q_block_fp_quantize_aligned_rows_norm(_ptr(xc), _ptr(other), pre_op, eps, _ptr(buf["tiled"]),
+        rc = lib.mi355q_block_fp_quantize_aligned_rows_norm(_ptr(xc), _ptr(other), _ptr(third), pre_op, eps, _ptr(buf["tiled"]),
                                                             _ptr(buf["exp"]), _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur),
                                                             _ptr(nxt), rows, K, int(width), int(exponent_width), bias,
                                                             bucket_cap, sp)

@@ -410,14 +410,17 @@ def grouped_linear(x, layers, norm=None):
     other arithmetics, the per-block bf16 route, differing shapes ...).
 
     `norm` = (weight, eps): the layers take LlamaRMSNorm(x) (modeling_llama.py:81-92, 236-238: the input of q / k / v and of
-    gate / up, which nothing else reads) and the quantiser -- which holds a whole row per workgroup -- applies the norm
-    itself, so the normalised tensor is never written.  Then the mean of squares is summed in the kernel's own fixed
+    gate / up, which nothing else reads), `norm` = (weight, bias, eps): nn.LayerNorm(x) (OPT's self_attn_layer_norm in
+    front of q / k / v and final_layer_norm in front of fc1, modeling_opt.py:391-415) -- and the quantiser, which holds a
+    whole row per workgroup, applies the norm itself, so the normalised tensor is never written.  Then the mean of squares is summed in the kernel's own fixed
     order: results agree with the separate norm to within the last-bit differences any two fp32 summation orders
     show (torch's own CPU and GPU reductions included), not bit for bit."""
     layers = list(layers)
     first = layers[0]
 
     def normed():
+        if len(norm) == 3:
+            return F.layer_norm(x, (x.shape[-1],), norm[0], norm[1], norm[2])
         w, eps = norm
         v = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
         return w * (x * torch.rsqrt(v + eps)).to(x.dtype)
@@ -438,7 +441,9 @@ def grouped_linear(x, layers, norm=None):
         with torch.no_grad():
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
                                                     bucket_cap=first._x_cap,
-                                                    pre=None if norm is None else ("rmsnorm", norm[0], norm[1]))
+                                                    pre=None if norm is None else (
+                                                        ("rmsnorm", norm[0], norm[1]) if len(norm) == 2 else
+                                                        ("layernorm", norm[0], norm[2], norm[1])))
             outs = ops.bfp_gemm_aligned_multi(xa, [l._packed[0] for l in layers], [l.bias for l in layers])
         if outs is not None:
             return [y.reshape(*x.shape[:-1], first.out_features) for y in outs]

@@ -307,5 +307,6 @@ def test_reference_model_fixture_every_knob(tag):
         _check_fixture(tag, knobs, forwards=2)
     finally:
         ops.block_fp_quantize_aligned_rows = real
-    if _G5[tag]["family"] == "llama" and "mixed" not in tag:
-        assert sum(1 for p in pres if p is not None and p[0] == "rmsnorm") == 4, pres      # (two norms a layer, two layers)
+    if "mixed" not in tag:
+        kind = "rmsnorm" if _G5[tag]["family"] == "llama" else "layernorm"
+        assert sum(1 for p in pres if p is not None and p[0] == kind) == 4, pres           # (two norms a layer, two layers)

@@ -771,8 +771,9 @@ def test_rope_tables_are_quantised_once():
     assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])
 
 
+@pytest.mark.parametrize("kind", ["rms", "layer"])
 @pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 4096, 512, 2), (77, 1024, 256, 1), (64, 11008 // 2 + 384, 256, 2)])
-def test_grouped_linear_with_the_norm_inside_the_quantiser(M, K, N, n):
+def test_grouped_linear_with_the_norm_inside_the_quantiser(M, K, N, n, kind):
     """grouped_linear(x, layers, norm=(weight, eps)) -- LlamaRMSNorm applied by the row quantiser itself -- against the layers
     on the separately normalised tensor: the quantised operand agrees except where the last bit of the mean moved an
     element across a rounding boundary (a handful in a million), outputs to that accuracy; identical run after run; equal
@@ -792,20 +793,29 @@ def test_grouped_linear_with_the_norm_inside_the_quantiser(M, K, N, n):
     x[::9, 32:48] *= 2.0 ** -9
     w = (1 + 0.1 * torch.randn(K, device=dev)).contiguous()
     eps = 1e-6
+    if kind == "layer":
+        x = x + 0.3 * x.abs().mean(-1, keepdim=True)              # (a non-zero row mean)
+        b = (0.05 * torch.randn(K, device=dev)).contiguous()
+        norm, tag = (w, b, 1e-5), "layernorm"
+    else:
+        norm, tag = (w, eps), "rmsnorm"
     with torch.no_grad():
-        h = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
-        first = Q.grouped_linear(x, layers, norm=(w, eps))        # first PTQ forward: torch norm + separate calls
+        if kind == "layer":
+            h = torch.nn.functional.layer_norm(x, (K,), w, b, 1e-5)
+        else:
+            h = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+        first = Q.grouped_linear(x, layers, norm=norm)            # first PTQ forward: torch norm + separate calls
         ref = [l(h).clone() for l in layers]
         for a, b in zip(first, ref):
             assert torch.equal(a, b)
         calls, real = [], ops.block_fp_quantize_aligned_rows
         ops.block_fp_quantize_aligned_rows = lambda *a, **k: (calls.append(k.get("pre")), real(*a, **k))[1]
         try:
-            got = Q.grouped_linear(x, layers, norm=(w, eps))
-            again = Q.grouped_linear(x, layers, norm=(w, eps))
+            got = Q.grouped_linear(x, layers, norm=norm)
+            again = Q.grouped_linear(x, layers, norm=norm)
         finally:
             ops.block_fp_quantize_aligned_rows = real
-        assert len(calls) == 2 and all(c is not None and c[0] == "rmsnorm" for c in calls)
+        assert len(calls) == 2 and all(c is not None and c[0] == tag for c in calls)
     for a, b, c in zip(ref, got, again):
         assert torch.equal(b, c)                                  # reproducible
         scale = a.abs().max().item()
