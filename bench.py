@@ -153,6 +153,20 @@ def quantizer_workload(torch, ops, args, device):
     for sname, shp in shapes.items():
         skip = not sname.startswith("w[")
         x = torch.randn(*shp, generator=torch.Generator().manual_seed(7)).to(device) * 4.0
+        # the same 8 B per element as a plain device copy (torch's copy kernel): what this memory system gives a stream
+        # of that size -- SURVEY 8(d) asks for the fraction of it next to the fraction of the 8 TB/s figure
+        y = torch.empty_like(x)
+        for _ in range(args.warmup):
+            y.copy_(x)
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(args.steps):
+            y.copy_(x)
+        e.record()
+        torch.cuda.synchronize()
+        copy_gbs = 8.0 * x.numel() / (a.elapsed_time(e) / args.steps * 1e-3) / 1e9
+        del y
         for fname, fn in fns.items():
             for _ in range(args.warmup):
                 fn(x, skip)
@@ -166,7 +180,8 @@ def quantizer_workload(torch, ops, args, device):
             ms = a.elapsed_time(e) / args.steps
             gbs = 8.0 * x.numel() / (ms * 1e-3) / 1e9
             rows.append({"quantizer": fname, "shape": sname, "us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
-                         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 3)})
+                         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 3), "copy_GB/s": round(copy_gbs, 1),
+                         "frac_of_copy": round(gbs / copy_gbs, 3)})
             tot_bytes += 8.0 * x.numel()
             tot_t += ms * 1e-3
     worst = min(rows, key=lambda r: r["GB/s"])
@@ -178,7 +193,7 @@ def quantizer_workload(torch, ops, args, device):
                                    "Llama-7B activation, attention-probability and weight shapes, fp32 in -> fp32 out"},
             "roofline": {"bound": "hbm", "kernel": f"quant_vec_kernel ({worst['quantizer']} at {worst['shape']}: the slowest case)",
                          "achieved": worst["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(worst["GB/s"] / HBM_PEAK_GBS, 4),
-                         "traffic": None},
+                         "traffic": None, "copy_GB/s": worst["copy_GB/s"], "frac_of_copy": worst["frac_of_copy"]},
             "cases": rows}
 
 
