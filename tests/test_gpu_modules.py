@@ -448,7 +448,7 @@ def test_shared_activation_is_quantised_once():
     layers = [Q.get_quantized_cls("linear", cfg)(256, 128, bias=True, config=dict(cfg)).to(dev) for _ in range(3)]
     x = torch.randn(2, 96, 256, device=dev)
     lib = _lib.load_library()
-    real = lib.mi355q_block_fp_quantize_aligned_rows_pre
+    real = lib.mi355q_block_fp_quantize_aligned_rows_norm
     calls = []
 
     def counting(*a):
@@ -462,7 +462,7 @@ def test_shared_activation_is_quantised_once():
         ref = [l(x).clone() for l in layers]
         ops.REUSE_QUANTISED_INPUT = True
         layers[0](x.clone())                                 # (another tensor of the shape: the record no longer names x)
-        lib.mi355q_block_fp_quantize_aligned_rows_pre = counting
+        lib.mi355q_block_fp_quantize_aligned_rows_norm = counting
         try:
             out = [l(x).clone() for l in layers]
             assert len(calls) == 1, len(calls)
@@ -482,7 +482,7 @@ def test_shared_activation_is_quantised_once():
             ops.REUSE_QUANTISED_INPUT = False
             assert torch.equal(got, layers[2](z))
         finally:
-            lib.mi355q_block_fp_quantize_aligned_rows_pre = real
+            lib.mi355q_block_fp_quantize_aligned_rows_norm = real
             ops.REUSE_QUANTISED_INPUT = True
 
 
@@ -585,7 +585,8 @@ def test_linear_and_matmul_in_the_unblocked_arithmetics():
 
 
 @pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 2048, 2048, 3), (1000, 1024, 2816, 2),
-                                     (256, 8192, 256, 3), (130, 4096, 512, 2)])       # (the last two: split-K slices)
+                                     (256, 8192, 256, 3), (130, 4096, 512, 2),        # (split-K slices)
+                                     (2048, 4096, 4096, 3)])   # (384 tiles: one and a half rounds over the compute units)
 def test_grouped_linear_equals_separate_calls(M, K, N, n):
     """grouped_linear(x, [q, k, v]) -- one quantisation, ONE launch of the tile GEMM over all column tiles -- == the layers
     called one by one, bit for bit (exceptions of x and of every w included); groups that do not qualify fall back"""
