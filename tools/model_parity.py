@@ -21,7 +21,11 @@ one_pass = len(sys.argv) > 4 and sys.argv[4] == "one_pass"  # both products, mas
 W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
-if one_pass:
+all_knobs = len(sys.argv) > 4 and sys.argv[4] == "all_knobs"   # one-pass attention (token-major), grouped projections,
+if all_knobs:                                                   # activation and norms inside the x quantisers; 2nd forward
+    W6A6_model = dict(W6A6, mi355q_fused_attention=True, mi355q_token_major_output=True, mi355q_grouped_linear=True,
+                      mi355q_fused_activation=True, mi355q_fused_norm=True)
+elif one_pass:
     W6A6_model = dict(W6A6, mi355q_fused_attention=True)
 elif fused:
     W6A6_model = dict(W6A6, mi355q_fused_softmax=True)
@@ -47,9 +51,11 @@ dev = torch.device("cuda:0")
 model = model.to(dev)
 with torch.no_grad():
     loss = float(model(ids.to(dev), labels=ids.to(dev))[1])
+    if all_knobs:     # (the first PTQ forward packs the weights; the fused paths act from the second on)
+        first_loss, loss = loss, float(model(ids.to(dev), labels=ids.to(dev))[1])
 modes = sorted({m._align_mode + ({120: "", -1: "+blockwise"}.get(getattr(m, "_x_cap", 120), "+post-pass") if m._align_mode == "rows" else "")
                 for m in model.modules() if hasattr(m, "_align_mode") and m._align_mode})
-out = {"shape": f"{'Llama-160m' if family == 'llama' else 'OPT-125m'} width, {layers} layers, T={T}" + (", softmax stage folded" if fused else ", one-pass attention" if one_pass else ""), "gpu_loss": loss, "oracle_loss": ref, "abs_diff": abs(loss - ref),
+out = {"shape": f"{'Llama-160m' if family == 'llama' else 'OPT-125m'} width, {layers} layers, T={T}" + (", softmax stage folded" if fused else ", one-pass attention" if one_pass else ", every knob on (second forward)" if all_knobs else ""), "gpu_loss": loss, "oracle_loss": ref, "abs_diff": abs(loss - ref),
        "ppl_gpu": round(math.exp(loss), 3), "ppl_oracle": round(math.exp(ref), 3), "oracle_seconds": round(t_cpu, 1),
        "linear_align_modes": modes}
 # GPU timing at the perplexity-run shape (B=1, T=2048)
@@ -63,4 +69,6 @@ with torch.no_grad():
         model(ids2, labels=ids2)
     torch.cuda.synchronize()
 out["gpu_ms_per_forward_T2048"] = round((time.time() - t0) / 5 * 1e3, 2)
+if all_knobs:
+    out["gpu_loss_first_forward"] = first_loss
 print(json.dumps(out))
