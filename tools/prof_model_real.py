@@ -7,7 +7,8 @@ from mi355q.harness import (TinyOPTConfig, TinyOPTForCausalLM, TinyLlamaConfig, 
 W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
             data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
             weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16],
-            mi355q_fused_attention=True, mi355q_grouped_linear=True)
+            mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_token_major_output=True,
+            mi355q_fused_norm=True)
 torch.manual_seed(0)
 if len(sys.argv) > 1 and sys.argv[1] == "opt1.3b":
     cfg = TinyOPTConfig(vocab_size=2048, hidden_size=2048, ffn_dim=8192, num_layers=2, num_heads=32, max_positions=2048)
