@@ -31,6 +31,10 @@ for family in families:
     ids = torch.randint(0, cfg.vocab_size, (1, 2048)).to(dev)
 
     def timed(fn, n=10):
+        t_end = time.time() + 0.1            # (an idle MI355X needs tens of milliseconds of work to reach its clocks)
+        while time.time() < t_end:
+            fn()
+            torch.cuda.synchronize()
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
