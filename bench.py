@@ -129,11 +129,13 @@ def clock_ramp(torch, step, ms):
     Steady-state throughput is what the metric names.  Reported in the JSON line as `clock_ramp_ms`; --clock-ramp-ms 0 = off."""
     if ms <= 0:
         return
-    t_end = time.perf_counter() + ms * 1e-3
-    while time.perf_counter() < t_end:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
+    # a COUNT of launches, not a deadline: with several ranks the step holds a collective, and every rank must issue the
+    # same number of them (ten launches per requested millisecond: the step takes ~0.1 ms, the sharded one up to twice that)
+    for i in range(max(1, int(ms * 10))):
+        step()
+        if i % 20 == 19:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
 
 
 def timed(torch, dist, world, device, step, steps, warmup):
@@ -171,7 +173,7 @@ def quantizer_workload(torch, ops, args, device):
         # of that size -- SURVEY 8(d) asks for the fraction of it next to the fraction of the 8 TB/s figure
         y = torch.empty_like(x)
         if not rows:                         # (first case: leave the idle clocks first, see clock_ramp)
-            clock_ramp(torch, lambda: y.copy_(x), args.clock_ramp_ms)
+            clock_ramp(torch, lambda: y.copy_(x), args.clock_ramp_ms * 5)      # (a 10-us copy: 50 per millisecond)
         for _ in range(args.warmup):
             y.copy_(x)
         torch.cuda.synchronize()
