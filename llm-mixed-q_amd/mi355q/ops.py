@@ -527,6 +527,22 @@ def gemm_tile_rows(M: int, N: int) -> int:
     return 128 if -(-t128 // 256) * 0.82 < -(-t256 // 256) * 1.0 else 256
 
 
+def gemm_rounds(M: int, N: int, count: int = 1) -> float:
+    """rounds over the 256 compute units (in units of a 256 x 256 tile's time) that `count` M x N outputs of one launch of
+    the row-scale GEMM cost by its launch rule: whole rounds of 256-row tiles, or of 128-row tiles at 0.82 each"""
+    tn = -(-N // 256) * count
+    t256, t128 = -(-M // 256) * tn, -(-M // 128) * tn
+    return min(-(-t256 // 256) * 1.0, -(-t128 // 256) * 0.82)
+
+
+def grouped_launch_plan(M: int, N: int, count: int):
+    """how to spread `count` (2 or 3) equally shaped products over launches of the grouped tile GEMM: the split with the
+    fewest rounds over the chip, 0.1 round charged per launch.  2048 x 4096 x 3 (Llama-7B q / k / v): one launch is 384
+    tiles = two rounds with the second half empty; (2, 1) is one full round of 256-row tiles + one of 128-row tiles."""
+    plans = {2: [(2,), (1, 1)], 3: [(3,), (2, 1), (1, 1, 1)]}.get(count, [(count,)])
+    return min(plans, key=lambda p: sum(gemm_rounds(M, N, g) + 0.1 for g in p))
+
+
 def row_list_fill(lst, rows, bucket_cap=None):
     """(rows that overflowed their bucket, entries in the fullest bucket) of a row-aligned operand's list (host read)"""
     nb = (rows + ROW_BUCKET_ROWS - 1) // ROW_BUCKET_ROWS

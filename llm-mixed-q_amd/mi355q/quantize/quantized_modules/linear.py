@@ -444,7 +444,19 @@ def grouped_linear(x, layers, norm=None):
                                                     pre=None if norm is None else (
                                                         ("rmsnorm", norm[0], norm[1]) if len(norm) == 2 else
                                                         ("layernorm", norm[0], norm[2], norm[1])))
-            outs = ops.bfp_gemm_aligned_multi(xa, [l._packed[0] for l in layers], [l.bias for l in layers])
+            # one launch, or the split of the group that takes fewer rounds over the chip (ops.grouped_launch_plan)
+            outs, at = [], 0
+            for g in ops.grouped_launch_plan(x2.shape[0], first.out_features, len(layers)):
+                part = layers[at:at + g]
+                at += g
+                if g == 1:
+                    ys = [ops.bfp_gemm_aligned(xa, part[0]._packed[0], part[0].bias)]
+                else:
+                    ys = ops.bfp_gemm_aligned_multi(xa, [l._packed[0] for l in part], [l.bias for l in part])
+                if ys is None:
+                    outs = None
+                    break
+                outs.extend(ys)
         if outs is not None:
             return [y.reshape(*x.shape[:-1], first.out_features) for y in outs]
     h = x if norm is None else normed()
