@@ -297,6 +297,7 @@ class _LinearBase(nn.Linear):
             return F.linear(x, self.weight, self.bias)
         if self.is_ptq:
             plan = self._int8_plan(x)
+            differentiated = torch.is_grad_enabled() and x.requires_grad      # (someone wants d/dx through this layer)
             with torch.no_grad():
                 if self.weight_requires_quantisation:
                     self._quantise_weights_once(pack=plan is not None, x_sample=x)
@@ -307,11 +308,34 @@ class _LinearBase(nn.Linear):
                 if plan is not None and self._packed_is_current():
                     return self._forward_int8(x, plan)
                 x = self.x_quantizer(x)
+                if not differentiated and self._values_exact_in_bf16(x):
+                    return self._forward_bf16_values(x)
             return F.linear(x, self.weight, self.bias)
         x = self.x_quantizer(x)
         w = self.w_quantizer(self.weight)
         bias = self.b_quantizer(self.bias) if self.bias is not None else None
         return F.linear(x, w, bias)
+
+    def _values_exact_in_bf16(self, xq) -> bool:
+        """block_minifloat / block_log PTQ layers (linear.py:145-203): the fake-quantised values -- minifloats with at most 7
+        mantissa bits, signed powers of two -- are exact in bf16 and a product of two of them exact in fp32, so
+        `F.linear(x_q, W_q, b_q)` is the bf16 flavour of the tile GEMM (fp32 accumulation, fp32 output) instead of a
+        library fp32 GEMM at a seventh of its rate.  config["mi355q_values_gemm"] = "fp32" keeps F.linear."""
+        c = self.config
+        if self.arith not in ("block_minifloat", "block_log") or c.get("mi355q_values_gemm", "bf16") != "bf16":
+            return False
+        if self.arith == "block_minifloat" and not all(
+                0 <= c[f"{p}_width"] - c[f"{p}_exponent_width"] - 1 <= 7 for p in ("data_in", "weight")):
+            return False
+        return (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32 and xq.ndim >= 2
+                and self.in_features % 32 == 0 and not self.weight_requires_quantisation)
+
+    def _forward_bf16_values(self, xq):
+        x2 = xq.reshape(-1, self.in_features).contiguous()
+        if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != xq.device:
+            self._w_bf16 = (ops.bf16_tile(self.weight.data.contiguous()), self.weight._version)
+        y = ops.bf16_gemm_tiled(ops.bf16_tile(x2), self._w_bf16[0], x2.shape[0], self.out_features, self.in_features, self.bias)
+        return y.reshape(*xq.shape[:-1], self.out_features)
 
     def forward_after(self, x, op, other=None):
         """self(relu(x)) (op = "relu": OPT's fc2 behind its activation_fn, modeling_opt.py:412-420) or

@@ -825,3 +825,68 @@ def test_grouped_linear_with_the_norm_inside_the_quantiser(M, K, N, n, kind):
     hq = O.block_fp_quantize(h.cpu().numpy(), 6, 8, 127, [1, 16], skip_first_dim=False).astype(np.float64)
     want = hq @ layers[0].weight.detach().cpu().numpy().astype(np.float64).T
     np.testing.assert_allclose(got[0].cpu().numpy(), want, rtol=0, atol=2e-3 * float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("arith", ["block_minifloat", "block_log"])
+def test_minifloat_and_log_linear_take_the_bf16_tile_gemm(arith):
+    """PTQ LinearBlockMinifloat / LinearBlockLog (linear.py:145-203): their fake-quantised values are exact in bf16, so
+    F.linear(x_q, W_q, b_q) runs as the bf16 flavour of the tile GEMM; == the library fp32 GEMM on the same quantised
+    values to fp32 summation-order accuracy, == the oracle's quantisers + float64 contraction; 3-D input, QAT and grad
+    keep F.linear"""
+    import torch
+    import torch.nn.functional as F
+    import mi355q.quantize as Q
+    from mi355q import ops
+    from oracle import np_oracle as O
+    dev = "cuda:0"
+    if arith == "block_minifloat":
+        cfg = dict(name=arith, is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4, data_in_exponent_bias_width=8,
+                   data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4, weight_exponent_bias_width=8,
+                   weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4, bias_exponent_bias_width=8, bias_block_size=[16])
+        scale = 40.0        # (quirk 5: blocks with max < 2 quantise to zeros; give the layer something to do)
+    else:
+        cfg = dict(name=arith, is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_bias_width=8, data_in_block_size=[1, 16],
+                   weight_width=8, weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8,
+                   bias_exponent_bias_width=8, bias_block_size=[16])
+        scale = 1.0
+    torch.manual_seed(3)
+    M, K, N = 300, 512, 272
+    lin = Q.get_quantized_cls("linear", cfg)(K, N, bias=True, config=cfg).to(dev)
+    with torch.no_grad():
+        lin.weight.mul_(scale * 20)
+        lin.bias.mul_(scale * 20)
+    w0, b0 = lin.weight.detach().cpu().numpy().copy(), lin.bias.detach().cpu().numpy().copy()
+    x = torch.randn(2, M // 2, K, device=dev) * scale
+    calls, real = [], ops.bf16_gemm_tiled
+    ops.bf16_gemm_tiled = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y = lin(x)
+            y2 = lin(x)
+            assert len(calls) == 2 and torch.equal(y, y2)
+            xq = lin.x_quantizer(x)
+            want = F.linear(xq, lin.weight, lin.bias)
+            slow = Q.get_quantized_cls("linear", cfg)(K, N, bias=True, config=dict(cfg, mi355q_values_gemm="fp32")).to(dev)
+            slow.load_state_dict({"weight": torch.from_numpy(w0), "bias": torch.from_numpy(b0)})
+            n0 = len(calls)
+            ys = slow(x)
+            assert len(calls) == n0
+        yg = lin(x.clone().requires_grad_(True))                     # d/dx wanted: the differentiable library product
+        assert len(calls) == n0 and yg.requires_grad
+        lin(x)                                                       # (grad mode on, nothing to differentiate: tile GEMM)
+        assert len(calls) == n0 + 1
+    finally:
+        ops.bf16_gemm_tiled = real
+    mx = want.abs().max().item()
+    assert (y - want).abs().max().item() <= 2e-6 * mx and (ys - want).abs().max().item() <= 2e-6 * mx
+    assert torch.equal(lin.weight, slow.weight)
+    if arith == "block_minifloat":
+        qx = O.block_minifloat_quantize(x.cpu().numpy(), 8, 4, 8, [1, 16], True)
+        qw = O.block_minifloat_quantize(w0, 8, 4, 8, [1, 16], False)
+        qb = O.block_minifloat_quantize(b0, 8, 4, 8, [16], False)
+    else:
+        qx = O.block_log_quantize(x.cpu().numpy(), 8, 8, [1, 16], True)
+        qw = O.block_log_quantize(w0, 8, 8, [1, 16], False)
+        qb = O.block_log_quantize(b0, 8, 8, [16], False)
+    ref = qx.astype(np.float64) @ qw.astype(np.float64).T + qb
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=3e-6 * float(np.abs(ref).max()))
