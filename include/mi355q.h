@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 15
+#define MI355Q_ABI_VERSION 16
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -92,6 +92,15 @@ int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int
  *   row-scale int8 GEMM with v_mfma_f32_16x16x32_bf16. */
 int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
                                         int32_t exponent_width, int32_t exponent_bias, void* workspace, void* stream);
+
+/* block_minifloat values straight into the same tiled bf16 operand (quantized_modules/linear.py:174-203, the x quantiser of
+ * PTQ LinearBlockMinifloat in front of its F.linear): x fp32 [rows, K], [1,16] blocks along K, each block's shared exponent
+ * bias and elements as mi355q_block_minifloat_quantize forms them (block_minifloat.py:22-74, minifloat.py:134-196); a
+ * minifloat of <= 7 mantissa bits is exact in bf16 (more: MI355Q_E_UNSUPPORTED).  K % 32 == 0.  All-zero blocks give zeros
+ * (as the reference's do: its fill value only moves their bias). */
+int mi355q_block_minifloat_quantize_bf16_tiled(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
+                                               int32_t exponent_width, int32_t exponent_bias_width, void* workspace,
+                                               void* stream);
 
 /* ---- the elementwise step in front of fc2 / down_proj folded into the operand quantisers ---------------
  * replaces: models/opt_quantized/modeling_opt.py:412-420 (`fc2(relu(fc1(x)))`: the activation_fn between the two quantised

@@ -154,6 +154,25 @@ int mi355q_block_fp_quantize_bf16_tiled_pre(const float* x, const float* x2, int
     return launch_quant_bf16_tiled(a, y_tiled, static_cast<hipStream_t>(stream));
 }
 
+int mi355q_block_minifloat_quantize_bf16_tiled(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t width,
+                                               int32_t exponent_width, int32_t exponent_bias_width, void* workspace,
+                                               void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, nullptr, workspace, 1, rows, K, 1, 16, MI355Q_ZERO_BLOCK_FAST);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y_tiled == nullptr) return MI355Q_E_BADARG;
+    const int mbits = width - exponent_width - 1;
+    if (exponent_width < 1 || exponent_width > 8 || mbits < 0 || mbits > 23) return MI355Q_E_BADARG;
+    if (exponent_bias_width < 1 || exponent_bias_width > 8) return MI355Q_E_BADARG;
+    if (mbits > 7 || K % 32 != 0) return MI355Q_E_UNSUPPORTED;      // bf16's 8 significant bits; whole 64-byte K-steps
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y_tiled)) % 16) return MI355Q_E_ALIGN;
+    a.span = (1 << exponent_width) - 1;
+    a.bias_max = (1 << exponent_bias_width) - 1;
+    set_mantissa(a, mbits);
+    return launch_quant_bf16_tiled(a, y_tiled, static_cast<hipStream_t>(stream), false, 1);
+}
+
 size_t mi355q_bfp_packed_bytes(int64_t rows, int64_t K, int32_t width) {
     return (rows <= 0 || K <= 0 || width < 2 || width > 8) ? 0 : (size_t)rows * (size_t)(K / 16) * (size_t)width * 2;
 }

@@ -34,7 +34,7 @@ struct QuantArgs {
 };
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
-int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only = false);
+int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only = false, int fmt = 0 /* FMT_BFP; 1 = FMT_BM */);
 int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
                        int* list, int list_cap, int* list_to_clear, hipStream_t st);
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,

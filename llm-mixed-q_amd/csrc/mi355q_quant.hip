@@ -705,9 +705,10 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
 // [8-value group 0..3][row 0..15][16 bytes] inside (mi355q_gemm_v2.h with K counted in bytes).  One workgroup per row;
 // optionally also the fp32 fake-quantised values in place of / next to x (the weights' first-forward overwrite).
 // ---------------------------------------------------------------------------------------
+template <int FMT>          // FMT_BFP, or FMT_BM: block_minifloat with the same [1,16] blocks (values of <= 7 mantissa bits: exact in bf16)
 __global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantArgs a, uint16_t* __restrict__ yt, int cast_only) {
     __shared__ Lut lut;
-    load_lut<FMT_BFP>(lut);
+    load_lut<FMT>(lut);
     const long long K = a.cols, kp = (K * 2) >> 6;
     const int nhalf = (int)(K >> 3);                      // 8-value half blocks: one lane each, 16 bytes of bf16
     const int mbits_int = (int)__builtin_log2f(a.shift);
@@ -739,11 +740,19 @@ __global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantAr
                 for (int t = 0; t < 8; ++t) m = max(m, __float_as_uint(o[t]) & 0x7FFFFFFFu);
                 m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true));   // the block's other half
                 const float bm1 = m != 0u ? __uint_as_float(m) : 1.0f;
+                if (FMT == FMT_BM) {                                    // (all-zero block: fill 1, every element stays 0)
+                    unsigned code;
+                    const BlockParam bp = block_param<FMT_BM>(bm1, a, lut, code);
+                    int q;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) o[t] = quant_elem<FMT_BM>(o[t], bp, a, lut, q);
+                }
                 const int k = __builtin_amdgcn_frexp_expf(bm1) - 1;
                 const unsigned f = __float_as_uint(__builtin_amdgcn_frexp_mantf(bm1)) & 0x7FFFFFu;
                 const int e = clampi(k + ((f != 0u && f >= lut.a[lut_index(k)]) ? 1 : 0), a.e_min, a.e_max);
                 const int up = mbits_int - e;
-                if (__any(up >= 28)) {                                  // blocks below 2^-23: the general rule
+                if (FMT == FMT_BM) {
+                } else if (__any(up >= 28)) {                           // blocks below 2^-23: the general rule
                     BlockParam bp;
                     bp.p = e;
                     bp.eps = 0.f;
@@ -776,11 +785,12 @@ __global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantAr
     }
 }
 
-int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only) {
+int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only, int fmt) {
     long long grid = a.rows;
     if (grid > 65536) grid = 65536;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(bfp_quant_bf16_tiled_kernel, (unsigned)grid, 256, 0, st, a, yt, cast_only ? 1 : 0);
+    if (fmt == FMT_BM) hipLaunchKernelGGL(bfp_quant_bf16_tiled_kernel<FMT_BM>, (unsigned)grid, 256, 0, st, a, yt, cast_only ? 1 : 0);
+    else hipLaunchKernelGGL(bfp_quant_bf16_tiled_kernel<FMT_BFP>, (unsigned)grid, 256, 0, st, a, yt, cast_only ? 1 : 0);
     return (int)hipGetLastError();
 }
 

@@ -215,6 +215,28 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
     return yt
 
 
+def block_minifloat_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: int, exponent_bias_width: int) -> torch.Tensor:
+    """x [rows, K] fp32 -> the block_minifloat values ([1,16] blocks along K) as tiled bf16, the operand of `bf16_gemm_tiled`
+    (exact for <= 7 mantissa bits); the buffer is shared by calls of the same shape on the same stream, like the block_fp
+    one's (consume it before quantising again)."""
+    _require_device(x, "block_minifloat_quantize_bf16_tiled")
+    assert x.ndim == 2 and x.shape[1] % 32 == 0 and x.is_contiguous() and int(width) - int(exponent_width) - 1 <= 7
+    rows, K = x.shape
+    lib = _lib.load_library()
+    key = (x.device.index, _stream_ptr(x.device), rows, K)
+    yt = _BF16_TILED_BUFFERS.get(key)
+    if yt is None:
+        if len(_BF16_TILED_BUFFERS) > 64:
+            _BF16_TILED_BUFFERS.clear()
+        yt = _BF16_TILED_BUFFERS[key] = torch.empty(lib.mi355q_bfp_tiled_bytes(rows, 2 * K), dtype=torch.int8, device=x.device)
+    with _on_device(x.device):
+        rc = lib.mi355q_block_minifloat_quantize_bf16_tiled(_ptr(x), _ptr(yt), rows, K, int(width), int(exponent_width),
+                                                            int(exponent_bias_width), _ptr(_workspace(x.device)),
+                                                            _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_minifloat_quantize_bf16_tiled")
+    return yt
+
+
 # ---------------------------------------------------------------------------------------
 # true width-bit weight storage (include/mi355q.h: mi355q_bfp_pack_bits / mi355q_bfp_expand)
 # ---------------------------------------------------------------------------------------

@@ -307,16 +307,16 @@ class _LinearBase(nn.Linear):
                     self._repack_quantised_weights(x)        # the module was moved: same (quantised) values, new device
                 if plan is not None and self._packed_is_current():
                     return self._forward_int8(x, plan)
-                x = self.x_quantizer(x)
                 if not differentiated and self._values_exact_in_bf16(x):
                     return self._forward_bf16_values(x)
+                x = self.x_quantizer(x)
             return F.linear(x, self.weight, self.bias)
         x = self.x_quantizer(x)
         w = self.w_quantizer(self.weight)
         bias = self.b_quantizer(self.bias) if self.bias is not None else None
         return F.linear(x, w, bias)
 
-    def _values_exact_in_bf16(self, xq) -> bool:
+    def _values_exact_in_bf16(self, xq) -> bool:   # (xq: the layer's input, quantised or not: only its placement matters)
         """block_minifloat / block_log PTQ layers (linear.py:145-203): the fake-quantised values -- minifloats with at most 7
         mantissa bits, signed powers of two -- are exact in bf16 and a product of two of them exact in fp32, so
         `F.linear(x_q, W_q, b_q)` is the bf16 flavour of the tile GEMM (fp32 accumulation, fp32 output) instead of a
@@ -330,12 +330,23 @@ class _LinearBase(nn.Linear):
         return (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32 and xq.ndim >= 2
                 and self.in_features % 32 == 0 and not self.weight_requires_quantisation)
 
-    def _forward_bf16_values(self, xq):
-        x2 = xq.reshape(-1, self.in_features).contiguous()
-        if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != xq.device:
+    def _forward_bf16_values(self, x):
+        """x (NOT yet quantised) -> x quantiser -> tiled bf16 -> tile GEMM against the tiled quantised weights"""
+        c = self.config
+        x2 = x.reshape(-1, self.in_features).contiguous()
+        if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:
             self._w_bf16 = (ops.bf16_tile(self.weight.data.contiguous()), self.weight._version)
-        y = ops.bf16_gemm_tiled(ops.bf16_tile(x2), self._w_bf16[0], x2.shape[0], self.out_features, self.in_features, self.bias)
-        return y.reshape(*xq.shape[:-1], self.out_features)
+        xs = [1, self.in_features] if x.ndim == 2 else [1, x.shape[-2], self.in_features]
+        row_blocks = x.ndim <= 3 and ops.resolve_blocking(xs, c["data_in_block_size"], True)[3:] == (1, 16)
+        if self.arith == "block_minifloat" and row_blocks:
+            # one pass: the block_minifloat values straight into the tiled bf16 operand
+            xt = ops.block_minifloat_quantize_bf16_tiled(x2, c["data_in_width"], c["data_in_exponent_width"],
+                                                         c["data_in_exponent_bias_width"])
+        else:
+            # (block_log's all-zero blocks take their value from a reduction over the whole tensor: its own two launches)
+            xt = ops.bf16_tile(self.x_quantizer(x).reshape(-1, self.in_features).contiguous())
+        y = ops.bf16_gemm_tiled(xt, self._w_bf16[0], x2.shape[0], self.out_features, self.in_features, self.bias)
+        return y.reshape(*x.shape[:-1], self.out_features)
 
     def forward_after(self, x, op, other=None):
         """self(relu(x)) (op = "relu": OPT's fc2 behind its activation_fn, modeling_opt.py:412-420) or

@@ -185,3 +185,24 @@ def test_elementwise_quantizers_bit_exact():
     xg = torch.randn(64, 33, device="cuda:0", requires_grad=True)
     QUANTIZER_MAP["minifloat_ieee"](xg, 8, 4, None).sum().backward()
     assert torch.equal(xg.grad, torch.ones_like(xg))
+
+
+@pytest.mark.parametrize("rows,K,w,ew,ebw", [(300, 512, 8, 4, 8), (64, 2752, 8, 4, 8), (17, 96, 6, 3, 4), (128, 256, 9, 1, 8)])
+def test_block_minifloat_straight_into_tiled_bf16(rows, K, w, ew, ebw):
+    """mi355q_block_minifloat_quantize_bf16_tiled writes the fake-quantiser's values (zero blocks, tiny and huge magnitudes
+    included): the tile GEMM of that operand against a tiled identity returns them bit for bit"""
+    import torch
+    from mi355q import ops
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * torch.exp(3 * torch.randn(rows, 1, generator=g))).to("cuda:0")
+    x[1, :32] = 0
+    x[2, 16:32] = torch.tensor([0.0, -0.0, 1e-9, -1e-9, 1e-8, 5e-9, 1e-30, 3e38, -3e38, 0.5, 2.0, 255.0, 256.0, 1.999, 4.0, -7.5])
+    fq = ops.block_minifloat_quantize(x, w, ew, ebw, [1, 16], False)
+    eye = ops.bf16_tile(torch.eye(K, device="cuda:0"))
+    got = ops.bf16_gemm_tiled(ops.block_minifloat_quantize_bf16_tiled(x.contiguous(), w, ew, ebw), eye, rows, K, K)
+    two = ops.bf16_gemm_tiled(ops.bf16_tile(fq.contiguous()), eye, rows, K, K)
+    # (|x| <= 1e-8 passes through the quantiser unquantised and is rounded to bf16 in the operand: compare the operands'
+    #  images, and the image with the fake-quantised values wherever those are bf16 numbers)
+    assert torch.equal(got, two)
+    exact = fq.to(torch.bfloat16).float() == fq
+    assert torch.equal(got[exact], fq[exact]) and exact.float().mean().item() > 0.99
