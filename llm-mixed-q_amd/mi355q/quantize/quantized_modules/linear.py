@@ -317,15 +317,21 @@ class _LinearBase(nn.Linear):
         return F.linear(x, w, bias)
 
     def _values_exact_in_bf16(self, xq) -> bool:   # (xq: the layer's input, quantised or not: only its placement matters)
-        """block_minifloat / block_log PTQ layers (linear.py:145-203): the fake-quantised values -- minifloats with at most 7
-        mantissa bits, signed powers of two -- are exact in bf16 and a product of two of them exact in fp32, so
+        """block_minifloat / block_log PTQ layers (linear.py:145-203; likewise the un-blocked minifloat_ieee / minifloat_denorm
+        and integer ones, :104-110, 206-263): the fake-quantised values -- minifloats with at most 7 mantissa bits, signed
+        powers of two, fixed point of at most 9 bits -- are exact in bf16 and a product of two of them exact in fp32, so
         `F.linear(x_q, W_q, b_q)` is the bf16 flavour of the tile GEMM (fp32 accumulation, fp32 output) instead of a
         library fp32 GEMM at a seventh of its rate.  config["mi355q_values_gemm"] = "fp32" keeps F.linear."""
         c = self.config
-        if self.arith not in ("block_minifloat", "block_log") or c.get("mi355q_values_gemm", "bf16") != "bf16":
+        if c.get("mi355q_values_gemm", "bf16") != "bf16":
             return False
-        if self.arith == "block_minifloat" and not all(
-                0 <= c[f"{p}_width"] - c[f"{p}_exponent_width"] - 1 <= 7 for p in ("data_in", "weight")):
+        if self.arith in ("block_minifloat", "minifloat_ieee", "minifloat_denorm"):     # <= 7 mantissa bits
+            if not all(0 <= c[f"{p}_width"] - c[f"{p}_exponent_width"] - 1 <= 7 for p in ("data_in", "weight")):
+                return False
+        elif self.arith == "integer":                          # fixed point of <= 9 bits: <= 8 significant bits
+            if not all(2 <= c[f"{p}_width"] <= 9 for p in ("data_in", "weight")):
+                return False
+        elif self.arith != "block_log":                        # (signed powers of two)
             return False
         return (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32 and xq.ndim >= 2
                 and self.in_features % 32 == 0 and not self.weight_requires_quantisation)
@@ -337,8 +343,8 @@ class _LinearBase(nn.Linear):
         if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:
             self._w_bf16 = (ops.bf16_tile(self.weight.data.contiguous()), self.weight._version)
         xs = [1, self.in_features] if x.ndim == 2 else [1, x.shape[-2], self.in_features]
-        row_blocks = x.ndim <= 3 and ops.resolve_blocking(xs, c["data_in_block_size"], True)[3:] == (1, 16)
-        if self.arith == "block_minifloat" and row_blocks:
+        if (self.arith == "block_minifloat" and x.ndim <= 3
+                and ops.resolve_blocking(xs, c["data_in_block_size"], True)[3:] == (1, 16)):
             # one pass: the block_minifloat values straight into the tiled bf16 operand
             xt = ops.block_minifloat_quantize_bf16_tiled(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                          c["data_in_exponent_bias_width"])

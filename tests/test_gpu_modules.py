@@ -827,7 +827,7 @@ def test_grouped_linear_with_the_norm_inside_the_quantiser(M, K, N, n, kind):
     np.testing.assert_allclose(got[0].cpu().numpy(), want, rtol=0, atol=2e-3 * float(np.abs(want).max()))
 
 
-@pytest.mark.parametrize("arith", ["block_minifloat", "block_log"])
+@pytest.mark.parametrize("arith", ["block_minifloat", "block_log", "minifloat_ieee", "minifloat_denorm", "integer"])
 def test_minifloat_and_log_linear_take_the_bf16_tile_gemm(arith):
     """PTQ LinearBlockMinifloat / LinearBlockLog (linear.py:145-203): their fake-quantised values are exact in bf16, so
     F.linear(x_q, W_q, b_q) runs as the bf16 flavour of the tile GEMM; == the library fp32 GEMM on the same quantised
@@ -844,6 +844,15 @@ def test_minifloat_and_log_linear_take_the_bf16_tile_gemm(arith):
                    data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4, weight_exponent_bias_width=8,
                    weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4, bias_exponent_bias_width=8, bias_block_size=[16])
         scale = 40.0        # (quirk 5: blocks with max < 2 quantise to zeros; give the layer something to do)
+    elif arith in ("minifloat_ieee", "minifloat_denorm"):
+        cfg = dict(name=arith, is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4, data_in_exponent_bias=None,
+                   weight_width=8, weight_exponent_width=4, weight_exponent_bias=None, bias_width=8, bias_exponent_width=4,
+                   bias_exponent_bias=None)
+        scale = 1.0
+    elif arith == "integer":
+        cfg = dict(name=arith, is_ptq=True, bypass=False, data_in_width=8, data_in_frac_width=4, weight_width=8, weight_frac_width=6,
+                   bias_width=8, bias_frac_width=6)
+        scale = 1.0
     else:
         cfg = dict(name=arith, is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_bias_width=8, data_in_block_size=[1, 16],
                    weight_width=8, weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8,
@@ -880,6 +889,8 @@ def test_minifloat_and_log_linear_take_the_bf16_tile_gemm(arith):
     mx = want.abs().max().item()
     assert (y - want).abs().max().item() <= 2e-6 * mx and (ys - want).abs().max().item() <= 2e-6 * mx
     assert torch.equal(lin.weight, slow.weight)
+    if arith in ("minifloat_ieee", "minifloat_denorm", "integer"):
+        return                                                # (their quantisers have their own bit-exact tests)
     if arith == "block_minifloat":
         qx = O.block_minifloat_quantize(x.cpu().numpy(), 8, 4, 8, [1, 16], True)
         qw = O.block_minifloat_quantize(w0, 8, 4, 8, [1, 16], False)
