@@ -668,7 +668,8 @@ def test_grouped_linear_bucket_overflow_takes_the_blockwise_product(which):
 
 @pytest.mark.parametrize("op", ["relu", "silu_mul"])
 @pytest.mark.parametrize("route", ["bf16", "rows"])
-def test_forward_after_equals_torch_ops_then_forward(op, route):
+@pytest.mark.parametrize("M,K", [(777, 2048), (130, 11008)])
+def test_forward_after_equals_torch_ops_then_forward(op, route, M, K):
     """Linear.forward_after(x, op[, other]) -- relu / silu(x) * other read by the layer's x quantiser itself -- == the
     layer called on the torch result (fc2(relu(.)), modeling_opt.py:412-420; down_proj(act(gate) * up),
     modeling_llama.py:216), bit for bit: the fused arithmetic rounds operation by operation like the separate kernels"""
@@ -677,11 +678,13 @@ def test_forward_after_equals_torch_ops_then_forward(op, route):
     import mi355q.quantize as Q
     from mi355q import ops
     dev = "cuda:0"
-    M, K, N = 777, 2048, 512
+    N = 512
     cfg = _lin_cfg(6, mi355q_align="rows")
     torch.manual_seed(5)
     lin = Q.get_quantized_cls("linear", cfg)(K, N, bias=True, config=cfg).to(dev)
     x = torch.randn(M, K, device=dev) * 3
+    if K > 2048 and route == "rows":     # (long rows: magnitudes within a factor of two, so that no bucket overflows)
+        x = (torch.rand(M, K, device=dev) * 0.9 + 0.6) * torch.sign(x) * 3
     other = torch.randn(M, K, device=dev) if op == "silu_mul" else None
     x[3, :40] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1e-9, -1e-9, 12.0, -12.0, 20.0, -20.0] * 4, device=dev)[:40]
     x[5, :16] = 0
@@ -773,7 +776,8 @@ def test_rope_tables_are_quantised_once():
 
 
 @pytest.mark.parametrize("kind", ["rms", "layer"])
-@pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 4096, 512, 2), (77, 1024, 256, 1), (64, 11008 // 2 + 384, 256, 2)])
+@pytest.mark.parametrize("M,K,N,n", [(300, 512, 256, 3), (2048, 4096, 512, 2), (77, 1024, 256, 1), (64, 11008 // 2 + 384, 256, 2),
+                                     (40, 16384, 256, 1)])
 def test_grouped_linear_with_the_norm_inside_the_quantiser(M, K, N, n, kind):
     """grouped_linear(x, layers, norm=(weight, eps)) -- LlamaRMSNorm applied by the row quantiser itself -- against the layers
     on the separately normalised tensor: the quantised operand agrees except where the last bit of the mean moved an
