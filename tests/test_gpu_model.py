@@ -29,7 +29,10 @@ def _oracle_forward(model, cfg_default, ids):
     dict(name="block_log", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_bias_width=8,
          data_in_block_size=[1, 16], weight_width=8, weight_exponent_bias_width=8, weight_block_size=[1, 16],
          bias_width=8, bias_exponent_bias_width=8, bias_block_size=[16]),
-], ids=["bfp_w6a6", "bfp_w4a4", "block_log_w8"])
+    dict(name="block_minifloat", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4, data_in_exponent_bias_width=8,
+         data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4, weight_exponent_bias_width=8,
+         weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4, bias_exponent_bias_width=8, bias_block_size=[16]),
+], ids=["bfp_w6a6", "bfp_w4a4", "block_log_w8", "block_minifloat_w8"])
 def test_tiny_opt_loss_parity(toml_default):
     import torch
     from mi355q.harness import TinyOPTConfig, TinyOPTForCausalLM, eval_lm_perplexity, expand_quant_config
@@ -310,3 +313,42 @@ def test_reference_model_fixture_every_knob(tag):
     if "mixed" not in tag:
         kind = "rmsnorm" if _G5[tag]["family"] == "llama" else "layernorm"
         assert sum(1 for p in pres if p is not None and p[0] == kind) == 4, pres           # (two norms a layer, two layers)
+
+
+@pytest.mark.parametrize("arith", ["block_log", "block_minifloat"])
+def test_tiny_llama_loss_parity_other_block_arithmetics(arith):
+    """BASELINE configs 3 / 5 name Llama with block_minifloat and block_log: the Llama-style harness under those
+    arithmetics (HIP fake-quantisers, products of the Linear layers on the bf16 tile GEMM, the registry's matmul / rotary
+    functions of that arithmetic) against the oracle's model forward"""
+    import torch
+    from mi355q import ops
+    from mi355q.harness import TinyLlamaConfig, TinyLlamaForCausalLM, eval_lm_perplexity, expand_llama_quant_config
+    if arith == "block_log":
+        d = dict(name="block_log", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_bias_width=8,
+                 data_in_block_size=[1, 16], weight_width=8, weight_exponent_bias_width=8, weight_block_size=[1, 16],
+                 bias_width=8, bias_exponent_bias_width=8, bias_block_size=[16])
+    else:
+        d = dict(name="block_minifloat", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4,
+                 data_in_exponent_bias_width=8, data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4,
+                 weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4,
+                 bias_exponent_bias_width=8, bias_block_size=[16])
+    torch.manual_seed(1)
+    cfg = TinyLlamaConfig(vocab_size=384, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=64)
+    model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(d, cfg.num_layers))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim == 2 and "embed" not in n:
+                p.mul_(40.0 if arith == "block_minifloat" else 4.0)      # (quirk 5: minifloat blocks below 2 quantise to zeros)
+    ids = torch.randint(0, cfg.vocab_size, (2, 48))
+    ref_loss = _oracle_llama_forward(model, d, ids.numpy())
+    model = model.to("cuda:0")
+    calls, real = [], ops.bf16_gemm_tiled
+    ops.bf16_gemm_tiled = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        res = eval_lm_perplexity(model, [ids], device="cuda:0")
+        res2 = eval_lm_perplexity(model, [ids], device="cuda:0")
+    finally:
+        ops.bf16_gemm_tiled = real
+    assert len(calls) == 2 * 2 * 7                                     # (every Linear of both forwards took the tile GEMM)
+    assert abs(res["loss"] - ref_loss) < 5e-4 * max(1.0, abs(ref_loss)), (res["loss"], ref_loss)
+    assert abs(res2["loss"] - res["loss"]) < 1e-6
