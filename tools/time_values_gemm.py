@@ -35,3 +35,19 @@ for arith, cfg in CFGS.items():
                 out[f"{mode}_us"] = round(timed(lambda: lin(x)), 1)
         out["speedup"] = round(out["fp32_us"] / out["bf16_us"], 2)
         print(json.dumps(out), flush=True)
+
+# two decoder layers + head at the Llama-7B width under each arithmetic (attention stepped as the reference does it)
+from mi355q.harness import TinyLlamaConfig, TinyLlamaForCausalLM, expand_llama_quant_config
+for arith, cfg in CFGS.items():
+    out = {"model": f"Llama-7B width, 2 layers, T=2048, {arith} W8"}
+    for mode in ("bf16", "fp32"):
+        torch.manual_seed(0)
+        mc = TinyLlamaConfig(vocab_size=2048, hidden_size=4096, intermediate_size=11008, num_layers=2, num_heads=32, max_positions=2048)
+        model = TinyLlamaForCausalLM(mc, expand_llama_quant_config(dict(cfg, mi355q_values_gemm=mode), mc.num_layers)).to(dev).eval()
+        ids = torch.randint(0, mc.vocab_size, (1, 2048)).to(dev)
+        with torch.no_grad():
+            model(ids)
+            out[f"{mode}_ms"] = round(timed(lambda: model(ids), n=5) / 1e3, 3)
+        del model
+        torch.cuda.empty_cache()
+    print(json.dumps(out), flush=True)
