@@ -52,4 +52,4 @@ def test_quantizers_line():
     d = _run([sys.executable, "bench.py", "--workload", "quantizers", "--steps", "3", "--warmup", "1"])
     _common(d, 3, 1)
     assert d["unit"] == "GB/s" and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
-    assert len(d["cases"]) == 15 and all(c["GB/s"] > 0 and c["copy_GB/s"] > 0 for c in d["cases"])
+    assert len(d["cases"]) == 18 and all(c["GB/s"] > 0 and c["copy_GB/s"] > 0 for c in d["cases"])

@@ -206,3 +206,24 @@ def test_block_minifloat_straight_into_tiled_bf16(rows, K, w, ew, ebw):
     assert torch.equal(got, two)
     exact = fq.to(torch.bfloat16).float() == fq
     assert torch.equal(got[exact], fq[exact]) and exact.float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("name", ["block_log", "block_fp", "block_minifloat"])
+def test_many_all_zero_blocks_like_causal_probabilities(name):
+    """a causal attention-probability tensor: half of its [1,16] blocks are exactly zero (the fix-up pass rewrites them with
+    the tensor-global fill, block_fp.py:54-58 -- for block_log a non-zero value): == the oracle, incl. -0.0 elements"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    T = 272
+    g = torch.Generator().manual_seed(0)
+    p = torch.softmax(torch.randn(3, T, T, generator=g) * 3 + torch.full((T, T), float("-inf")).triu(1), dim=-1)
+    p[0, 5, :16] = -0.0
+    x = p.to("cuda:0")
+    kw = {"block_log": dict(width=8, exponent_bias_width=8, block_size=[1, 16]),
+          "block_fp": dict(width=6, exponent_width=8, exponent_bias=None, block_size=[1, 16]),
+          "block_minifloat": dict(width=8, exponent_width=4, exponent_bias_width=8, block_size=[1, 16])}[name]
+    got = Q.get_quantizer("", dict(name=name))(x, **kw, skip_first_dim=True).cpu().numpy()
+    want = getattr(O, name + "_quantize")(p.numpy(), **kw, skip_first_dim=True)
+    assert np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).view(np.uint32))
+    assert (p == 0).float().mean().item() > 0.4
