@@ -31,6 +31,9 @@ struct QuantArgs {
     int pre_op;
     float pre_eps;        // MI355Q_PRE_RMSNORM / _LAYERNORM (aligned-rows quantiser only): x2 = the norm's weight [cols],
     const float* x3;      // pre_eps its epsilon, x3 = the LayerNorm's bias [cols] (null: none)
+    // exact zero-block mode, [1,16] row blocks: kernel 1 leaves one 64-bit ballot per 64 float4 slots (bit 4 b set: block b
+    // of those sixteen is all zero) for the fix-up pass, which then visits the zero blocks without reading x again
+    unsigned long long* zmap;
 };
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);

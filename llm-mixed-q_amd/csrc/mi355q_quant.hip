@@ -21,6 +21,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "mi355q.h"
 #include "mi355q_internal.h"
 #include "mi355q_align.h"
@@ -80,6 +84,16 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
         if (valid) v = x4[i];
         float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         bmax = group_max<LPB>(bmax);
+        if (LPB == 4 && a.zmap) {   // (uniform) one ballot per wave iteration: which of its sixteen blocks are all zero
+            const unsigned long long zb = __ballot(bmax == 0.f && valid);
+            if ((threadIdx.x & 63) == 0) a.zmap[i >> 6] = zb;
+            // ... and those blocks are left to the fix-up pass altogether, which writes every one of them (it runs whenever
+            // this kernel has seen one): no arithmetic, no stores for them here
+            if (bmax == 0.f) {
+                saw_zero = saw_zero || valid;
+                continue;
+            }
+        }
         if (bmax == 0.f) {          // all-zero block: provisional fill 1.0 (what an all-zero tensor gets)
             saw_zero = saw_zero || valid;
             bmax = 1.0f;
@@ -222,6 +236,22 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
         int q0;
         const float zv = quant_elem<FMT>(0.0f, bp, a, lut, q0);
         const float4 z4 = make_float4(zv, zv, zv, zv);
+        if (a.zmap) {
+            // kernel 1 left a map of the all-zero blocks: x is not read again (a causal probability tensor: 0.46 -> 0.2x ms)
+            const long long nthreads = (long long)gridDim.x * blockDim.x;
+            const int m4 = (q0 & 255) * 0x01010101;
+            // one lane per float4 slot, as kernel 1 walked them (a wave and its map word cover the same sixteen blocks):
+            // the stores of a wave are 1 KiB of consecutive bytes
+            const long long n4 = a.n_elems >> 2;
+            float4* __restrict__ y4 = reinterpret_cast<float4*>(a.y);
+            unsigned* __restrict__ mant4 = reinterpret_cast<unsigned*>(a.mant);
+            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += nthreads) {
+                if (((a.zmap[i >> 6] >> (i & 60)) & 1ull) == 0ull) continue;
+                if (a.y) y4[i] = z4;
+                if (FMT == FMT_BFP && a.mant) mant4[i] = (unsigned)m4;
+                if (a.code && (i & 3) == 0) a.code[i >> 2] = (uint8_t)code;
+            }
+        } else {
         const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
         const long long nthreads = (long long)gridDim.x * blockDim.x;
         for (long long bid = (long long)blockIdx.x * blockDim.x + threadIdx.x; bid < a.n_blocks; bid += nthreads) {
@@ -241,6 +271,7 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
                 *reinterpret_cast<int4*>(a.mant + bid * 16) = make_int4(m4, m4, m4, m4);
             }
             if (a.code) a.code[bid] = (uint8_t)code;
+        }
         }
     } else
     for (long long bid = g0; bid < a.n_blocks; bid += groups) {
@@ -350,6 +381,29 @@ static int grid_for(long long work_items, int per_block) {
     return (int)g;
 }
 
+// the zero-block map of the exact mode: library-owned, one per (device, stream), grow-only (like the split-K workspace of
+// mi355q_gemm_v8.hip; a stream's launches are ordered, so one map per stream is enough)
+static unsigned long long* zmap_workspace(hipStream_t st, size_t bytes) {
+    struct Buf { void* p = nullptr; size_t n = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> all;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Buf& b = all[{dev, st}];
+    if (b.n < bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;   // (no allocation under capture)
+        if (b.p) (void)hipFree(b.p);                      // (synchronises: nothing of this map is in flight after)
+        b.p = nullptr;
+        b.n = 0;
+        const size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        if (hipMalloc(&b.p, want) != hipSuccess) return nullptr;
+        b.n = want;
+    }
+    return static_cast<unsigned long long*>(b.p);
+}
+
 template <int FMT>
 static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st) {
     // kernel 1 leaves the zero-block state in the workspace only when the fix-up launch follows (and clears it)
@@ -362,6 +416,13 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
                         (a.mant == nullptr || reinterpret_cast<uintptr_t>(a.mant) % 4 == 0);
     const int lpb = a.b1 / 4;
     int grid;
+    a.zmap = nullptr;
+    if (vec_ok && lpb == 4 && needs_fixup && (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u && (a.cols & 15) == 0 &&
+        (a.y == nullptr || reinterpret_cast<uintptr_t>(a.y) % 16 == 0) &&
+        (a.mant == nullptr || reinterpret_cast<uintptr_t>(a.mant) % 16 == 0) && a.n_elems >= (1 << 25))
+        // (tensors of 128 MiB and more -- the attention-probability class, where half of the blocks can be zero; below that
+        //  the map's bookkeeping on the host costs a launch-bound call more than a second read of x would)
+        a.zmap = zmap_workspace(st, (size_t)((((a.n_elems >> 2) + 63) & ~63ll) >> 6) * 8);      // (null: the pass reads x again)
     if (vec_ok && (lpb == 1 || lpb == 2 || lpb == 4 || lpb == 8 || lpb == 16 || lpb == 32 || lpb == 64)) {
         grid = grid_for(a.n_elems >> 2, 256);
         switch (lpb) {

@@ -227,3 +227,26 @@ def test_many_all_zero_blocks_like_causal_probabilities(name):
     want = getattr(O, name + "_quantize")(p.numpy(), **kw, skip_first_dim=True)
     assert np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).view(np.uint32))
     assert (p == 0).float().mean().item() > 0.4
+
+
+def test_zero_block_map_path_on_a_large_tensor():
+    """tensors of 128 MiB and more take the zero-block map (kernel 1 leaves the all-zero blocks to the fix-up pass, which
+    finds them through the map instead of reading x again): block_log on causal probabilities [17, 2048, 1024] == the same
+    rows quantised in small pieces through the re-reading pass, given the same tensor-global fill"""
+    import torch
+    import mi355q.quantize as Q
+    g = torch.Generator().manual_seed(1)
+    T = 1024
+    p = torch.softmax(torch.randn(17, 2048, T, generator=g) * 3 + torch.full((2048, T), float("-inf")).triu(1), dim=-1).to("cuda:0")
+    assert p.numel() >= 1 << 25
+    q = Q.get_quantizer("", dict(name="block_log"))
+    kw = dict(width=8, exponent_bias_width=8, block_size=[1, 16], skip_first_dim=True)
+    big = q(p, **kw)
+    # the fill is the smallest non-zero block maximum of the WHOLE tensor: give every piece a row that carries it
+    bm = p.view(-1, 16).abs().amax(1)
+    row = int((bm == bm[bm > 0].min()).nonzero()[0, 0]) * 16 // T
+    carrier = p.view(-1, T)[row:row + 1]
+    for i in (0, 5, 16):
+        piece = torch.cat([p[i], carrier], 0).unsqueeze(0)
+        small = q(piece, **kw)[0, :-1]
+        assert torch.equal(small.view(torch.int32), big[i].view(torch.int32)), i
