@@ -24,6 +24,10 @@
  *   - `workspace`: MI355Q_WORKSPACE_BYTES bytes of device memory, ZERO-INITIALISED once by
  *     the caller, private to one stream; the library leaves its control words zeroed after
  *     every call (the per-workgroup slots behind them are scratch).
+ *   - Scratch the library owns itself, one per (device, stream), grow-only, allocated with hipMalloc on first need and
+ *     therefore NOT while the stream is being captured into a graph (run the call once un-captured first, as
+ *     mi355q.graphs.GraphedForward's warm-up does): the split-K slabs and tickets of the tile GEMM, and the zero-block map
+ *     of the exact quantiser mode on tensors of 128 MiB and more (without it that mode reads x a second time instead).
  */
 #ifndef MI355Q_H
 #define MI355Q_H
