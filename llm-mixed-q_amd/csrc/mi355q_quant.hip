@@ -442,7 +442,8 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (needs_fixup && (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u) {
-        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), FIXUP_GRID, 256, 0, st, a, grid);
+        // (a grid that exits at once costs its dispatch: 256 workgroups for the launch-bound sizes)
+        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), a.n_elems >= (1 << 24) ? FIXUP_GRID : 256, 256, 0, st, a, grid);
         e = hipGetLastError();
     }
     return (int)e;

@@ -43,6 +43,32 @@ int main(int argc, char** argv) {
         std::printf("step_driver matmul: %d calls, out[0..3] = %g %g %g %g\n", steps, h[0], h[1], h[2], h[3]);
         return 0;
     }
+    if (argc > 2 && std::string(argv[2]) == "quantizers") {  // BASELINE config 5: the streaming fake-quantisers at Llama-7B shapes
+        const int64_t shapes[2][2] = {{2048, 4096}, {2048, 11008}};
+        std::mt19937 gen(7);
+        std::normal_distribution<float> nd(0.f, 4.f);
+        void* ws = dalloc<unsigned char>(MI355Q_WORKSPACE_BYTES, true);
+        for (const auto& shp : shapes) {
+            const int64_t rows = shp[0], cols = shp[1];
+            std::vector<float> hx(rows * cols);
+            for (auto& v : hx) v = nd(gen);
+            float *x = dalloc<float>(hx.size()), *y = dalloc<float>(hx.size());
+            HIP_OK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+            for (int s = 0; s < steps; ++s) {
+                Q_OK(mi355q_block_fp_quantize(x, y, nullptr, nullptr, 1, rows, cols, 1, 16, 6, 8, 127, MI355Q_ZERO_BLOCK_FAST, ws, nullptr));
+                Q_OK(mi355q_block_minifloat_quantize(x, y, nullptr, 1, rows, cols, 1, 16, 8, 4, 8, MI355Q_ZERO_BLOCK_FAST, ws, nullptr));
+                Q_OK(mi355q_block_log_quantize(x, y, nullptr, 1, rows, cols, 1, 16, 8, 8, 0, ws, nullptr));
+            }
+            HIP_OK(hipDeviceSynchronize());
+            float h[4];
+            HIP_OK(hipMemcpy(h, y, 16, hipMemcpyDeviceToHost));
+            std::printf("step_driver quantizers [%lld, %lld]: %d rounds of block_fp / block_minifloat / block_log, y[0..3] = %g %g %g %g\n",
+                        (long long)rows, (long long)cols, steps, h[0], h[1], h[2], h[3]);
+            HIP_OK(hipFree(x));
+            HIP_OK(hipFree(y));
+        }
+        return 0;
+    }
     if (argc > 2 && std::string(argv[2]) == "attention") {   // the one-pass attention core: [heads] [head_dim], T = 2048, causal
         const int64_t B = argc > 3 ? std::atoi(argv[3]) : 12, T = 2048, D = argc > 4 ? std::atoi(argv[4]) : 64;
         std::mt19937 gen(1);
