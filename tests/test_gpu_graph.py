@@ -73,3 +73,36 @@ def test_graph_linear_with_exceptions():
     with torch.no_grad():
         for x, e in zip(xs, eager):
             assert torch.equal(lin(x), e)
+
+
+@pytest.mark.parametrize("family", ["opt", "llama"])
+def test_graph_replay_with_every_knob(family):
+    """the forward with every implementation knob on (norms and activations inside the quantisers, grouped projections,
+    one-pass attention writing token-major) captured into a HIP graph: replays == the eager forward, bit for bit, also on
+    new token ids"""
+    import torch
+    from mi355q import harness as H
+    from mi355q.graphs import GraphedForward
+    qc = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+              data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+              weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16],
+              mi355q_fused_attention=True, mi355q_token_major_output=True, mi355q_grouped_linear=True,
+              mi355q_fused_activation=True, mi355q_fused_norm=True)
+    torch.manual_seed(3)
+    if family == "opt":
+        cfg = H.TinyOPTConfig(vocab_size=512, hidden_size=256, ffn_dim=1024, num_layers=3, num_heads=4, max_positions=512)
+        m = H.TinyOPTForCausalLM(cfg, H.expand_quant_config(qc, cfg.num_layers))
+    else:
+        cfg = H.TinyLlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=768, num_layers=3, num_heads=4, max_positions=512)
+        m = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(qc, cfg.num_layers))
+    m = m.to("cuda:0").eval()
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, cfg.vocab_size, (1, 384), generator=g).to("cuda:0")
+    ids2 = torch.randint(0, cfg.vocab_size, (1, 384), generator=g).to("cuda:0")
+    with torch.no_grad():
+        m(ids)
+        want, want2 = m(ids)[0].clone(), m(ids2)[0].clone()
+        fwd = GraphedForward(lambda t: m(t)[0], (ids,))
+        assert torch.equal(fwd(ids), want)
+        assert torch.equal(fwd(ids2), want2)
+        assert torch.equal(fwd(ids), want)
