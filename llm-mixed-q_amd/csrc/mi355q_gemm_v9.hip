@@ -1,0 +1,651 @@
+// mi355q_gemm_v9.hip -- the 256 x 256 tile of the row-scale block-floating-point GEMM (gfx950), round 3.
+//
+//     y[m,n] = sx[m] * sw[n] * ( sum_k xm'[m,k] * wm'[n,k] )  (+ bias[n])  (+ exception blocks),  K <= 16384, K % 128 == 0
+// on ROW-aligned tiled operands (mi355q_align_row.h, mi355q_gemm_v2.h); the arithmetic of mi355q_gemm_v8.hip, whose
+// 128-row tile and staggered schedules stay there.  Reference path: quantized_modules/linear.py:59-76 (F.linear on the
+// fake-quantised operands).  What is different from the v8 kernel, each change measured in tools/ubench/kloop.hip
+// (profiles/r03_kloop_*.txt):
+//   * LDS rings of FOUR A halves and THREE B halves (16 KiB each, 112 KiB): two K-steps of LDS-DMA in flight instead of
+//     one.  A step's B fragments are read one step ahead of its A fragments (they wait in registers), so a B half is dead
+//     one barrier earlier than the A half of the same step and three B slots give the flight time of four A slots.
+//   * LDS-DMA by buffer_load ... lds: per-lane offsets fixed for the whole loop, the K-step in the scalar offset (no
+//     per-piece 64-bit vector adds); steps past the end are requested out of bounds (no memory traffic, zeros).
+//   * one filler (fragment read / LDS-DMA piece) in front of each MFMA instead of clumps in front of groups of four.
+//   * operands swapped in the MFMA: a lane then holds four CONSECUTIVE columns of one row, the epilogue stores 16 bytes
+//     per lane (a quarter of the store instructions, the store tail 2 us shorter).
+//   * exception add-back without a prologue of its own: the K loop starts as soon as its first stage has landed; the
+//     tile's bucket bookkeeping runs in K-step 1 and from K-step 2 on every wave serves one entry per K-step (gather the
+//     other operand's 256 blocks at the entry's K position into registers in one step, multiply and accumulate the
+//     entry's vector of 256 products in spare LDS in the next), hidden behind the other wave of its SIMD.  The entries of
+//     one tile row / column are chained in ascending block order and summed by ONE wave in that order: reproducible.
+//     The epilogue looks rows up once per 16-row fragment and columns once per wave.
+// Roofline: int8 MFMA, 2*M*N*K ops.  y leaves as full fp32: 64 MiB at 4096^2, ~10 us at the rate the fabric takes
+// write-backs, none of it overlapped with one tile per compute unit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "mi355q_gemm_tile.h"
+
+namespace mi355q {
+
+constexpr int V9_HALF = 256 * 64, V9_NA = 4, V9_NB = 3, V9_NT = 512, V9_NW = 8;
+constexpr int V9_B0 = V9_NA * V9_HALF;                       // B ring behind the A ring
+constexpr int V9_STAGES = (V9_NA + V9_NB) * V9_HALF;         // 112 KiB
+constexpr int V9_XB = 0, V9_WB = V9_XB + 4096, V9_MAP = V9_WB + 4096;      // (offsets in the side area)
+constexpr int V9_SXT = V9_MAP + 2048, V9_SWT = V9_SXT + 1024, V9_BIAS = V9_SWT + 1024;
+constexpr int V9_FLAGS = V9_BIAS + 1024, V9_OVF = V9_FLAGS + 256, V9_CORR = V9_OVF + 512;
+constexpr int V9_LDS = 159 * 1024, V9_SIDE = V9_LDS - V9_STAGES;
+constexpr int V9_FAST_MAX = (V9_SIDE - V9_CORR) / 1024;       // entries (x + w) whose vectors fit beside the rings
+constexpr int V9_SLOW_MAX = V9_STAGES / 1024 - 32;           // ... that fit the ring area after the K loop (+ 8 x 4 KiB of scratch)
+static_assert(ROW_BUCKET_WORDS * 4 <= 4096, "bucket copy");
+static_assert(V9_FAST_MAX >= 32, "spare LDS for correction vectors");
+
+typedef __bf16 v9_bf16x8 __attribute__((ext_vector_type(8)));
+// (w fragment as the MFMA's A operand, x fragment as its B operand: D[n = 4 (lane / 16) + r][m = lane % 16])
+__device__ __forceinline__ i32x4 v9_mma(const i32x4& fw, const i32x4& fx, const i32x4& c) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(fw, fx, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 v9_mma(const i32x4& fw, const i32x4& fx, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v9_bf16x8, fw), __builtin_bit_cast(v9_bf16x8, fx), c, 0, 0, 0);
+}
+
+#define V9_WAITV(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define V9_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define V9_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+#define V9_SB() __builtin_amdgcn_sched_barrier(0)
+// LDS-DMA as inline assembly: the compiler must not know that LDS-DMA is pending -- it orders every LDS read of its own
+// behind ALL of it (s_waitcnt vmcnt(0)), which would drain the operand stream at each step of the exception service.
+// M0 (the LDS destination of the wave's lane 0) is written in the statement that uses it; nothing else in this kernel
+// keeps a value in M0.  16 / 4 bytes per lane by 64-bit lane address, 16 / 4 by buffer descriptor + lane offset + scalar offset.
+#define V9_GLDS16(gp, lds) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds) : "memory")
+#define V9_GLDS4(gp, lds) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gp), "s"(lds) : "memory")
+#define V9_BLDS16(vo, rs, so, lds) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so), "s"(lds) : "memory")
+#define V9_BLDS4(vo, rs, so, lds) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so), "s"(lds) : "memory")
+__device__ __forceinline__ i32x4 v9_desc(const void* base, int bytes) {       // raw buffer descriptor of `bytes` bytes at `base`
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    return i32x4{(int)(unsigned)b, (int)(unsigned)(b >> 32), bytes, 0x00020000};
+}
+
+// FIX 1: with the exception add-back.  STAMP: diagnostic build, workgroups leave their phase times in a.stamps.
+template <int FIX, bool BF16, bool STAMP>
+__global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, const float* __restrict__ sx,
+                                                        const float* __restrict__ sw_in, const int* __restrict__ xlist,
+                                                        const int* __restrict__ wlist_in, const uint8_t* __restrict__ xf,
+                                                        const uint8_t* __restrict__ wf_in) {
+    static_assert(!BF16 || FIX == 0, "the bf16 arithmetic has no exception lists");
+    // Two LDS objects: the operand rings (filled by LDS-DMA, read by inline-asm ds_read_b128 only) and everything else.
+    // The compiler orders its own LDS reads behind every LDS-DMA that may alias them -- with one array each of its reads
+    // in the K loop (the exception service) would drain the operand stream (s_waitcnt vmcnt(0)).
+    __shared__ __attribute__((aligned(16))) unsigned char ring[V9_STAGES];
+    __shared__ __attribute__((aligned(16))) unsigned char side[V9_SIDE];
+    unsigned char* const smem = side;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
+    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0};
+    if (STAMP) st_t[0] = __builtin_amdgcn_s_memrealtime();
+
+    GemmArgs a = a_in;
+    const float* __restrict__ sw = sw_in;
+    const int* __restrict__ wlist = wlist_in;
+    const uint8_t* __restrict__ wf = wf_in;
+    const int ngroup = a.ngroup > 1 ? a.ngroup : 1;
+    const int Mi = (int)a.M, Ni = (int)a.N;
+    const int tiles_m = (Mi + 255) >> 8, tiles_n1 = (Ni + 255) >> 8, tiles_n = tiles_n1 * ngroup;
+    const int S = a.splits > 1 ? a.splits : 1;                 // workgroups per tile (split-K)
+    const int nwg = tiles_m * tiles_n * S;
+    int pid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int split = S > 1 ? pid % S : 0, tile_id = S > 1 ? pid / S : pid;
+    const int GM = 4, in_group = GM * tiles_n, group_id = tile_id / in_group, first_m = group_id * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int tm = first_m + (tile_id % in_group) % gsz;
+    int tn = (tile_id % in_group) / gsz;
+    if (ngroup > 1) {
+        const int which = tn / tiles_n1;                        // (wave-uniform: scalar loads from the argument block)
+        tn -= which * tiles_n1;
+        // (selects over constant indices: a runtime index would put the argument block in scratch memory)
+#define V9_PICK(f) (which == 0 ? a_in.f[0] : which == 1 ? a_in.f[1] : a_in.f[2])
+        a.wm = V9_PICK(g_wm); a.we = V9_PICK(g_we); a.bias = V9_PICK(g_bias); a.y = V9_PICK(g_y);
+        sw = V9_PICK(g_sw); wlist = V9_PICK(g_wlist); wf = V9_PICK(g_wf);
+#undef V9_PICK
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int kp = (int)(a.K >> 6);                             // 1-KiB pieces per 16 rows
+    const int kstep0 = S > 1 ? (int)((long long)kp * split / S) : 0;       // this workgroup's slice of the K-steps
+    const int nsteps = S > 1 ? (int)((long long)kp * (split + 1) / S) - kstep0 : kp;
+
+    int* xb = reinterpret_cast<int*>(smem + V9_XB);
+    int* wb = reinterpret_cast<int*>(smem + V9_WB);
+    int* rowslot = reinterpret_cast<int*>(smem + V9_MAP);
+    int* colslot = rowslot + 256;
+    float* sxt = reinterpret_cast<float*>(smem + V9_SXT);
+    float* swt = reinterpret_cast<float*>(smem + V9_SWT);
+    float* bst = reinterpret_cast<float*>(smem + V9_BIAS);
+    float* corr = reinterpret_cast<float*>(smem + V9_CORR);
+
+    // ---- in front of the operand stream (same queue, so landed by the first counted wait): the tile's scale / bias
+    //      slices, its two exception buckets and the lists' overflow words
+    const int ring_lds = (int)(size_t)(lptr_t)ring, side_lds = (int)(size_t)(lptr_t)side;     // the objects' own LDS addresses
+    if (wave == 0 || wave == 1) {
+        if (FIX && !(wave == 0 && a.x_post)) {
+            const int* b = wave == 0 ? row_bucket(xlist, m0) : row_bucket(wlist, n0);
+            const int d = side_lds + (wave == 0 ? V9_XB : V9_WB);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q * 256 + lane * 4 < ROW_BUCKET_WORDS) V9_GLDS16(b + q * 256 + lane * 4, d + q * 1024);
+        }
+    } else if (!BF16 && wave == 2) {
+        V9_GLDS16(sx + m0 + lane * 4, side_lds + V9_SXT);
+    } else if (!BF16 && wave == 3) {
+        V9_GLDS16(sw + n0 + lane * 4, side_lds + V9_SWT);
+    } else if (wave == 4) {
+        // (bounds-checked by the descriptor: columns past N read as zero, no address past the array is touched)
+        if (a.bias) {
+            const i32x4 rb = v9_desc(a.bias + n0, (Ni - n0) * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) V9_BLDS4(lane * 4 + q * 256, rb, 0, side_lds + V9_BIAS + q * 256);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bst[q * 64 + lane] = 0.f;
+        }
+    } else if (FIX && (wave == 5 || wave == 6)) {
+        V9_GLDS4((wave == 5 ? xlist : wlist) + lane, side_lds + V9_OVF + (wave - 5) * 256);
+    }
+    if (FIX) {                                                  // (maps cleared before the bookkeeping of K-step 1 writes them)
+        rowslot[tid & 255] = -1;
+        if (tid >= 256) colslot[tid & 255] = -1;
+        if (tid == 0) *reinterpret_cast<int*>(smem + V9_FLAGS) = 0;
+    }
+
+    // ---- the operand stream.  Piece p of a K-step: 16 rows of A (p < 16) or of B; this wave stages pieces wave + 8 q.
+    //      One descriptor per operand, rooted at the tile's first piece row and ending with its last (rows past the
+    //      operand read as zero); the lane's part of the address is fixed, the K-step rides in the scalar offset.
+    const long long row_bytes = (long long)kp * 1024;           // one piece row (16 rows x K bytes)
+    const int pa_rows = min(16, ((Mi + 127) >> 7) * 8 - (m0 >> 4)), pb_rows = min(16, ((Ni + 127) >> 7) * 8 - (n0 >> 4));
+    const int8_t* xbase = a.xm + (long long)(m0 >> 4) * row_bytes + (long long)kstep0 * 1024;
+    const int8_t* wbase = a.wm + (long long)(n0 >> 4) * row_bytes + (long long)kstep0 * 1024;
+    // (the range check covers the lane's offset only, not the scalar one: a K-step past the end of the slice is requested
+    //  through a descriptor of zero bytes -- no memory traffic, zeros land in the slot)
+    const int x_nrec = (int)(pa_rows * row_bytes), w_nrec = (int)(pb_rows * row_bytes);
+    int voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) voff[q] = (wave + 8 * (q & 1)) * (int)row_bytes + lane * 16;
+    // piece q (literal) of K-step `step` into ring slots at byte offsets sa (A) / sb (B)
+#define V9_PIECE(q, rxd, rwd, soff, sa, sb)                                                                             \
+    V9_BLDS16(voff[q], (q) < 2 ? rxd : rwd, soff, ring_lds + ((q) < 2 ? (sa) : V9_B0 + (sb)) + (wave + 8 * ((q) & 1)) * 1024)
+#define V9_DESCS(step)                                                                                                  \
+    const bool more_ = (step) < nsteps;                                                                                 \
+    const i32x4 rxd_ = v9_desc(xbase, more_ ? x_nrec : 0), rwd_ = v9_desc(wbase, more_ ? w_nrec : 0);                   \
+    const int soff_ = (step) * 1024;
+#define V9_STAGE(step, sa, sb) { V9_DESCS(step) V9_PIECE(0, rxd_, rwd_, soff_, sa, sb); V9_PIECE(1, rxd_, rwd_, soff_, sa, sb); V9_PIECE(2, rxd_, rwd_, soff_, sa, sb); V9_PIECE(3, rxd_, rwd_, soff_, sa, sb); }
+    V9_STAGE(0, 0, 0)
+    V9_STAGE(1, V9_HALF, V9_HALF)
+    V9_STAGE(2, 2 * V9_HALF, 2 * V9_HALF)
+    if (STAMP) st_t[1] = __builtin_amdgcn_s_memrealtime();
+
+    using acc_t = typename std::conditional<BF16, f32x4, i32x4>::type;
+    acc_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+    // ---- exception service.  Waves 0-3 (one per SIMD: the ones that win the matrix pipe and then wait at the barrier)
+    //      serve the tile's entries while the K loop runs, a QUARTER of an entry per K-step: one LDS-DMA gathers the other
+    //      operand's 16-byte blocks at the entry's K position for 64 tile columns / rows into the wave's 1-KiB scratch (a load
+    //      into registers cannot be used: the compiler would wait for it with s_waitcnt vmcnt(0), draining the operand stream,
+    //      or, kept from knowing about it, move its destination registers while it is in flight); the next step multiplies,
+    //      adds to the vector of the entry's chain (one LDS round trip) and requests the next quarter.  What a wave serves and
+    //      in which order is laid down by the bookkeeping of K-steps 1 and 2: whole chains, chain starts s with s % 4 == wave
+    //      in ascending order, each chain in ascending block order (word 3 of an entry's LDS copy: successor in the low half,
+    //      the wave's next chain start in the high half of a start's word).
+    int cx = 0, cw = 0, nent = 0, mode = 0;   // mode 0: no entries, 1: vectors in LDS (the first V9_FAST_MAX beside the rings,
+                                              // formed while the K loop runs; the rest in the ring area behind it), 3: more
+                                              // than LDS holds, added with atomics after the stores
+    constexpr int NSV = 4;                    // serving waves
+    int sv_on = 0;                            // 1: this wave has entries to serve, -1: a bucket overflowed (uniform over the grid)
+    int sv_cur = -1, sv_head = -1, sv_q = -1, sv_link = -1, sv_nexts = -1;      // entry / chain / quarter in flight
+    int e_isx = 0, e_sh = 0, e_kb = 0, e_code = 0, e_koff = 0;
+    int4 e_pv = int4{0, 0, 0, 0};
+    // scratch of wave w < 4 while the loop runs: the upper halves of the two bucket copies (the loop serves at most
+    // V9_FAST_MAX entries: the lower 2 KiB of each copy hold 63)
+    const int scr_off = (wave < 2 ? V9_XB : V9_WB) + 2048 + (wave & 1) * 1024;
+    const int glane = (lane >> 4) * (int)row_bytes + (lane & 15) * 16;     // row `lane` of a quarter inside the tile's piece rows
+    const i32x4 xg = v9_desc(a.xm + (long long)(m0 >> 4) * row_bytes, x_nrec), wg = v9_desc(a.wm + (long long)(n0 >> 4) * row_bytes, w_nrec);
+    // fields of entry i into scalars (one LDS round trip)
+    auto serve_load = [&](int i) {
+        const int* e = v8_entry(xb, wb, cx, i);
+        const int4 h = *reinterpret_cast<const int4*>(e), m = *reinterpret_cast<const int4*>(e + 4);
+        e_isx = i < cx ? 1 : 0;
+        e_kb = __builtin_amdgcn_readfirstlane(h.y);
+        e_code = __builtin_amdgcn_readfirstlane(h.z);
+        const int l3 = __builtin_amdgcn_readfirstlane(h.w);
+        sv_link = (int)(short)(l3 & 0xffff);
+        if (i == sv_head) sv_nexts = l3 >> 16;                  // (a chain start carries the wave's next start)
+        e_sh = e_code - (e_isx ? +a.x_off : +a.w_off);
+        e_koff = (e_kb >> 2) * 1024 + (e_kb & 3) * 256;
+        e_pv = int4{__builtin_amdgcn_readfirstlane(m.x), __builtin_amdgcn_readfirstlane(m.y), __builtin_amdgcn_readfirstlane(m.z),
+                    __builtin_amdgcn_readfirstlane(m.w)};
+        sv_cur = i;
+    };
+    // request quarter c of the current entry: rows c * 64 + lane of the other operand's tile rows (rows past the operand
+    // read as zero), the K position in the scalar offset
+    auto serve_issue = [&](int c, int dst_lds) {
+        const int vo = glane + c * 4 * (int)row_bytes;
+        const int ko = __builtin_amdgcn_readfirstlane(e_koff), dl = __builtin_amdgcn_readfirstlane(dst_lds);     // (provably scalar for the asm)
+        V9_LGKM(0);                                             // (this wave's reads of the scratch have returned)
+        if (e_isx) { V9_BLDS16(vo, wg, ko, dl); } else { V9_BLDS16(vo, xg, ko, dl); }
+    };
+    // quarter c of the current entry: 64 products, added to the vector of the entry's chain
+    auto serve_finish = [&](int c, const unsigned char* scr, float* area) {
+        const float* sc = e_isx ? swt : sxt;
+        float* v = area + sv_head * 256 + c * 64 + lane;
+        const int4 q = *reinterpret_cast<const int4*>(scr + lane * 16);
+        const float scl = sc[c * 64 + lane];
+        const float old = sv_cur == sv_head ? 0.f : *v;
+        *v = old + __builtin_ldexpf((float)dot16(e_pv, q), e_sh) * scl;
+    };
+    // the exception x exception terms of the current x entry (same K position in both lists), behind its four quarters
+    auto serve_cross = [&](float* area) {
+        float* v = area + sv_head * 256;
+        for (int f0 = 0; f0 < cw; f0 += 64) {                   // uniform
+            const int fi = f0 + lane;
+            if (fi < cw) {
+                const int* f = wb + EXC_HEADER + EXC_ENTRY * fi;
+                if ((short)(f[3] & 0xffff) != -2 && f[1] == e_kb) {
+                    const int d = dot16(e_pv, *reinterpret_cast<const int4*>(f + 4));
+                    v[f[0] - n0] += __builtin_ldexpf((float)d, e_code + f[2] - a.scale_bias);
+                }
+            }
+        }
+    };
+    // behind the last quarter of an entry: its cross terms, then the chain's successor or the wave's next chain
+    auto serve_advance = [&](float* area) {
+        if (e_isx && cw > 0) serve_cross(area);
+        const int nxt = sv_link >= 0 ? sv_link : sv_nexts;
+        if (nxt < 0) { sv_cur = -1; return; }
+        if (sv_link < 0) sv_head = nxt;
+        serve_load(nxt);
+    };
+
+    // lane-constant part of the fragment addresses; fragment i is i KiB further (immediate offset)
+    const int va = ring_lds + piece_lds_off(wm * 128 + l16, lq), vb = ring_lds + V9_B0 + piece_lds_off(wn * 64 + l16, lq);
+    i32x4 fa[4], fb0[4], fb1[4];
+    V9_WAITV(8);                                                // everything but the pieces of K-steps 1 and 2
+    __builtin_amdgcn_s_barrier();
+    V9_DSR(fb0[0], vb, 0); V9_DSR(fb0[1], vb, 1024); V9_DSR(fb0[2], vb, 2048); V9_DSR(fb0[3], vb, 3072);
+    V9_DSR(fa[0], va, 0); V9_DSR(fa[1], va, 1024);
+    V9_SB();
+    unsigned long long c_loop = 0;
+    if (STAMP) { st_t[2] = __builtin_amdgcn_s_memrealtime(); c_loop = __builtin_amdgcn_s_memtime(); }
+
+    // K-step t between barrier(t) and barrier(t + 1): MFMA group i (A fragment i against the four B fragments of the step,
+    // held in registers) with, in front of its MFMAs: the read of A fragment i + 2 (the last two groups: fragments 0 and 1
+    // of step t + 1) and the counted wait for fragment i; the read of B fragment i - 2 of step t + 1 (groups 2-5); LDS-DMA
+    // piece i of step t + 3 (groups 0-3).  At barrier(t) every wave has waited for its own pieces of step t + 1 and has
+    // retired every read of the A half of step t - 1 and of the B half of step t: those are the slots step t + 3 goes to.
+    auto body = [&](i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db) {
+        V9_LGKM(2);                                             // (the B reads of the slot about to be refilled)
+        V9_WAITV(4);
+        __builtin_amdgcn_s_barrier();
+        if (FIX && sv_on > 0) {
+            if (t == 1) {
+                // ---- bookkeeping of the tile's two buckets (they rode in front of the operand stream), first half
+                const int* ovf = reinterpret_cast<const int*>(smem + V9_OVF);
+                if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) { sv_on = -1; }
+                else {
+                    cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+                    cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
+                    nent = cx + cw;
+                    mode = nent == 0 ? 0 : (nent <= V9_FAST_MAX + V9_SLOW_MAX ? 1 : 3);
+                    if (mode) {
+                        // chains: the entries of one tile row / column linked by ASCENDING block index (successor in word 3
+                        // of the entry's LDS copy, -1 ends a chain, -2 marks a void entry), the first one in rowslot /
+                        // colslot.  The order is a property of the data, not of which workgroup reserved its list slots
+                        // first.  16 lanes share an entry (each scans every 16th entry of the same operand).
+                        for (int i0 = 0; i0 < nent; i0 += V9_NT / 16) {            // uniform
+                            const int i = i0 + (tid >> 4), sub = tid & 15;
+                            const bool valid = i < nent;
+                            const bool is_x = i < cx;
+                            int* e = v8_entry(xb, wb, cx, valid ? i : 0);
+                            const int r = e[0], kb = e[1];
+                            const bool live = valid && (is_x ? (r >= m0 && r < m0 + 256 && r < Mi) : (r >= n0 && r < n0 + 256 && r < Ni));
+                            const int lo = is_x ? 0 : cx, hi = is_x ? cx : nent;
+                            int key = 0x7fffffff, earlier = 0;            // key = (block << 8 | index) of the best successor
+                            if (live)
+                                for (int j = lo + sub; j < hi; j += 16) {
+                                    const int* f = v8_entry(xb, wb, cx, j);
+                                    if (f[0] != r) continue;
+                                    const int kj = f[1];
+                                    if (kj > kb) key = min(key, (kj << 8) | (j - lo));
+                                    earlier |= kj < kb ? 1 : 0;
+                                }
+#pragma unroll
+                            for (int o = 1; o < 16; o <<= 1) {
+                                key = min(key, __shfl_xor(key, o));
+                                earlier |= __shfl_xor(earlier, o);
+                            }
+                            if (valid && sub == 0) {
+                                if (!live) {
+                                    e[3] = 0xffff0000 | (unsigned short)-2;
+                                } else {
+                                    e[3] = 0xffff0000 | (unsigned short)(key != 0x7fffffff ? lo + (key & 255) : -1);
+                                    if (!earlier) (is_x ? rowslot : colslot)[r - (is_x ? m0 : n0)] = i;
+                                }
+                            }
+                        }
+                    }
+                    if (mode != 1) sv_on = 0;                   // nothing to serve
+                }
+                V9_LGKM(0);                                     // (read by other waves behind the next barrier)
+            } else if (t == 2) {
+                // ---- second half: every chain start s < V9_FAST_MAX learns the next such start s' > s with s' % 4 == s % 4
+                //      (the chains one serving wave works through), the first of each class goes to the flag words
+                int* svfirst = reinterpret_cast<int*>(smem + V9_FLAGS) + 16;
+                const int lim = min(nent, V9_FAST_MAX);
+                for (int i0 = 0; i0 < lim; i0 += V9_NT / 16) {                    // uniform
+                    const int i = i0 + (tid >> 4), sub = tid & 15;
+                    auto is_start = [&](int j) {
+                        if (j >= lim) return false;
+                        const int* f = v8_entry(xb, wb, cx, j);
+                        if ((short)(f[3] & 0xffff) == -2) return false;
+                        return (j < cx ? rowslot[f[0] - m0] : colslot[f[0] - n0]) == j;
+                    };
+                    // candidates i + 4 (sub + 1); 16 lanes cover the 8 there can be
+                    int cand = i + 4 * (sub + 1);
+                    int best = (i < lim && is_start(cand)) ? cand : 0x7fff;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) best = min(best, __shfl_xor(best, o));
+                    if (i < lim && sub == 0 && is_start(i)) {
+                        int* e = v8_entry(xb, wb, cx, i);
+                        e[3] = (e[3] & 0xffff) | ((best == 0x7fff ? -1 : best) << 16);
+                    }
+                }
+                if (tid < NSV) {                                 // the first start of class tid
+                    int first = -1;
+                    for (int j = tid; j < lim; j += NSV) {
+                        const int* f = v8_entry(xb, wb, cx, j);
+                        if ((short)(f[3] & 0xffff) == -2) continue;
+                        if ((j < cx ? rowslot[f[0] - m0] : colslot[f[0] - n0]) == j) { first = j; break; }
+                    }
+                    svfirst[tid] = first;
+                }
+                V9_LGKM(0);
+                if (wave >= NSV || (a.dbg & 1)) sv_on = 0;      // (dbg 1, diagnostic: all of it behind the loop)
+            } else if (t >= 3) {
+                // ---- a quarter of an entry per serving wave and K-step: the quarter requested in the previous step has
+                //      landed (it is older than that step's pieces, which the counted wait above left in flight)
+                if (sv_q < 0) {                                  // first service step: the wave's first chain
+                    const int first = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + V9_FLAGS)[16 + wave]);
+                    if (first < 0) sv_on = 0;
+                    else { sv_head = first; serve_load(first); sv_q = 0; serve_issue(0, side_lds + scr_off); }
+                } else {
+                    serve_finish(sv_q, side + scr_off, corr);
+                    if (++sv_q == 4) { sv_q = 0; serve_advance(corr); }
+                    if (sv_cur < 0) sv_on = 0; else serve_issue(sv_q, side_lds + scr_off);
+                }
+            }
+            V9_SB();
+        }
+        const int ac = va + sa_c, an = va + sa_n, bn = vb + sb_n;
+        V9_DESCS(t + 3)
+#define V9_GROUP(i, wait)                                                                                                \
+        if (i < 6) V9_DSR(fa[(i + 2) & 3], ac, (i + 2) * 1024); else V9_DSR(fa[(i + 2) & 3], an, (i - 6) * 1024);          \
+        V9_LGKM(wait);                                                                                                   \
+        V9_SB();                                                                                                         \
+        acc[i][0] = v9_mma(fb[0], fa[i & 3], acc[i][0]);                                                                 \
+        V9_SB();                                                                                                         \
+        if (i >= 2 && i < 6) V9_DSR(fbn[i - 2], bn, (i - 2) * 1024);                                                     \
+        V9_SB();                                                                                                         \
+        acc[i][1] = v9_mma(fb[1], fa[i & 3], acc[i][1]);                                                                 \
+        V9_SB();                                                                                                         \
+        if (i < 4) V9_PIECE(i, rxd_, rwd_, soff_, da, db);                                                                            \
+        V9_SB();                                                                                                         \
+        acc[i][2] = v9_mma(fb[2], fa[i & 3], acc[i][2]);                                                                 \
+        V9_SB();                                                                                                         \
+        acc[i][3] = v9_mma(fb[3], fa[i & 3], acc[i][3]);                                                                 \
+        V9_SB();
+        V9_GROUP(0, 2) V9_GROUP(1, 2) V9_GROUP(2, 2) V9_GROUP(3, 3) V9_GROUP(4, 4) V9_GROUP(5, 4) V9_GROUP(6, 4) V9_GROUP(7, 3)
+#undef V9_GROUP
+    };
+    if (FIX) sv_on = 1;                                         // (until the bookkeeping of K-steps 1 and 2 knows better)
+    // ring positions (byte offsets): A half of step t in a0, t + 1 in a1, ..., the slot step t + 3 goes to in a3;
+    // B half of step t + 1 in b1, the slot step t + 3 goes to (= where step t's B half was) in b0
+    int a0 = 0, a1 = V9_HALF, a2 = 2 * V9_HALF, a3 = 3 * V9_HALF, b0 = 0, b1 = V9_HALF, b2 = 2 * V9_HALF;
+    for (int t = 0; t < nsteps; t += 2) {                       // (nsteps is even: K % 128 == 0, even slices)
+        body(fb0, fb1, t, a0, a1, b1, a3, b0);
+        { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }
+        { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
+        if (FIX && sv_on < 0) break;
+        body(fb1, fb0, t + 1, a0, a1, b1, a3, b0);
+        { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }
+        { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
+    }
+    V9_WAITV(0);
+    V9_LGKM(0);                                                 // (the compiler does not know these reads are in flight)
+    V9_SB();
+    if (STAMP) { st_t[3] = __builtin_amdgcn_s_memrealtime(); c_loop = __builtin_amdgcn_s_memtime() - c_loop; }
+    __builtin_amdgcn_s_barrier();                               // (every wave is out of the rings)
+    if (FIX && sv_on < 0) {
+        // a bucket overflowed somewhere (uniform over the grid): the row-scale product does not apply; the workgroups of
+        // this launch share the blockwise-exact product instead.  Nothing is pending.
+        v8_fallback(a, xf, wf, xlist, wlist, ring, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
+                    ngroup > 1 ? tiles_m * tiles_n1 * S : nwg);
+        return;
+    }
+
+    if (S > 1) {
+        // ---- split-K: every slice leaves its raw accumulators in its slab (16 bytes a lane, 1 KiB a wave instruction);
+        //      the slice that arrives last at the tile's ticket sums all slabs IN SLICE ORDER (reproducible for the fp32
+        //      flavour too; the int32 sums are exact in any order) and goes on to the epilogue, the others leave.
+        //      Hand-off: plain stores, every wave's vmcnt(0), workgroup barrier, agent-scope release by one lane, relaxed
+        //      ticket; the reducer acquires once, then loads plainly (cdna guide, Guideline 16).
+        constexpr long long SLAB = 256ll * 256 * 4;
+        acc_t* slab = reinterpret_cast<acc_t*>(static_cast<unsigned char*>(a.slabs) + ((long long)tile_id * S + split) * SLAB);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab[((wave * 8 + i) * 4 + j) * 64 + lane] = acc[i][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flagw = reinterpret_cast<int*>(smem + V9_FLAGS) + 8;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t = __hip_atomic_fetch_add(&a.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == S - 1 ? 1 : 0;
+            if (last) {
+                __hip_atomic_store(&a.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle again
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flagw = last;
+        }
+        __syncthreads();
+        if (*flagw == 0) return;
+        const acc_t* tslabs = reinterpret_cast<const acc_t*>(static_cast<unsigned char*>(a.slabs) + (long long)tile_id * S * SLAB);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+        for (int sl = 0; sl < S; ++sl) {
+            const acc_t* sp = tslabs + (long long)sl * (SLAB / 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += sp[((wave * 8 + i) * 4 + j) * 64 + lane];
+        }
+    }
+
+    if (FIX && mode == 1) {
+        // ---- behind the loop: what it did not get to (short K) and the chains it cannot hold (starts from V9_FAST_MAX on:
+        //      their vectors go to the ring area, free now).  Whole entries: four quarters requested together into 4 KiB of
+        //      scratch per wave (ring area), one exposed round trip each.  Waves 0-3 finish their own sequences, waves 4-7
+        //      take the overflow chains.
+        float* const rcorr = reinterpret_cast<float*>(ring);
+        const int rscr = V9_SLOW_MAX * 1024 + wave * 4096;
+        auto batch = [&](int qfrom, float* area) {              // the rest of the current entry, then on to the next
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c >= qfrom) serve_issue(c, ring_lds + rscr + c * 1024);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c >= qfrom) serve_finish(c, ring + rscr + c * 1024, area);
+        };
+        if (wave < NSV) {
+            int qfrom = 0;
+            if (sv_on > 0 && sv_q >= 0) {                        // a quarter the loop left in flight (landed: drained above)
+                serve_finish(sv_q, side + scr_off, corr);
+                qfrom = sv_q + 1;
+            } else if (sv_q < 0) {                               // the loop never served (short K, or the diagnostic switch)
+                const int first = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + V9_FLAGS)[16 + wave]);
+                sv_cur = -1;
+                if (first >= 0) { sv_head = first; serve_load(first); }
+            } else {
+                sv_cur = -1;                                     // its sequence is complete
+            }
+            while (sv_cur >= 0) {
+                if (qfrom < 4) batch(qfrom, corr);
+                qfrom = 0;
+                serve_advance(corr);
+            }
+        } else {
+            for (int s0 = V9_FAST_MAX + wave - NSV; s0 < nent; s0 += NSV) {       // uniform
+                const int* e = v8_entry(xb, wb, cx, s0);
+                const int l3 = __builtin_amdgcn_readfirstlane(e[3]);
+                if ((short)(l3 & 0xffff) == -2) continue;
+                const int r = __builtin_amdgcn_readfirstlane(e[0]) - (s0 < cx ? m0 : n0);
+                if (__builtin_amdgcn_readfirstlane((s0 < cx ? rowslot : colslot)[r]) != s0) continue;
+                sv_head = s0;
+                sv_nexts = -1;
+                serve_load(s0);
+                sv_nexts = -1;                                   // (no sequence: the outer loop finds the next start)
+                float* const area = rcorr - V9_FAST_MAX * 256;   // (vector of chain s at area + 256 s)
+                while (sv_cur >= 0) {
+                    batch(0, area);
+                    serve_advance(area);
+                }
+            }
+        }
+        V9_LGKM(0);
+        __syncthreads();
+    }
+    if (STAMP) st_t[4] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- epilogue: y = float(acc) * sx[m] * sw[n] + bias[n] (+ correction vectors).  The lane holds, for fragment (i, j),
+    //      row wm * 128 + 16 i + l16 and the four columns wn * 64 + 16 j + 4 lq + 0..3: one 16-byte store.  Nothing is loaded
+    //      from global memory between the stores.
+    const bool look = FIX && mode == 1;
+    // (vector of chain s: beside the rings for s < V9_FAST_MAX, else in the ring area)
+    const float* const rvec = reinterpret_cast<const float*>(ring) - V9_FAST_MAX * 256;
+#define V9_VEC(s_) (((s_) < V9_FAST_MAX ? corr : rvec) + (s_) * 256)
+    f32x4 swv[4], bv[4];
+    int4 cs[4];
+    unsigned cmask = 0;                                         // bit 4 j + r: some lane of the wave has a vector for that column
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cl = wn * 64 + j * 16 + lq * 4;
+        swv[j] = BF16 ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(&swt[cl]);
+        bv[j] = *reinterpret_cast<const f32x4*>(&bst[cl]);
+        cs[j] = look ? *reinterpret_cast<const int4*>(&colslot[cl]) : int4{-1, -1, -1, -1};
+        if (look) {
+            if (__any(cs[j].x >= 0)) cmask |= 1u << (4 * j);
+            if (__any(cs[j].y >= 0)) cmask |= 2u << (4 * j);
+            if (__any(cs[j].z >= 0)) cmask |= 4u << (4 * j);
+            if (__any(cs[j].w >= 0)) cmask |= 8u << (4 * j);
+        }
+    }
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.y) | (uintptr_t)(a.ldy * 4)) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rl = wm * 128 + i * 16 + l16;
+        const float sxv = BF16 ? 1.f : sxt[rl];
+        f32x4 val[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[j][r] = BF16 ? (float)acc[i][j][r] + bv[j][r] : (float)acc[i][j][r] * sxv * swv[j][r] + bv[j][r];
+        if (look) {
+            const int rs = rowslot[rl];                          // the row's vector: 256 products, one per tile column
+            if (__any(rs >= 0)) {
+                const float* v = V9_VEC(max(rs, 0)) + wn * 64 + lq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(v + j * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[j][r] += rs >= 0 ? c4[r] : 0.f;
+                }
+            }
+            if (cmask) {                                         // the columns' vectors: one product per tile row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c4[4] = {cs[j].x, cs[j].y, cs[j].z, cs[j].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (cmask & (1u << (4 * j + r))) val[j][r] += c4[r] >= 0 ? V9_VEC(max(c4[r], 0))[rl] : 0.f;
+                }
+            }
+        }
+        const long long row = (long long)m0 + rl;
+        float* yrow = a.y + row * a.ldy + n0 + wn * 64 + lq * 4;
+        if (row < a.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + lq * 4;
+                if (vec_ok && col + 3 < Ni) {
+                    *reinterpret_cast<f32x4*>(yrow + j * 16) = val[j];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < Ni) yrow[j * 16 + r] = val[j][r];
+                }
+            }
+        }
+    }
+    if (STAMP) {
+        st_t[5] = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps && (tid & 63) == 0 && (wave == 0 || wave == 7)) {
+            unsigned long long* d = a.stamps + ((long long)blockIdx.x * 2 + (wave == 7)) * 8;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) d[q] = st_t[q];
+            d[6] = c_loop;
+            d[7] = ((unsigned long long)(unsigned)nent << 32) | (unsigned)mode;
+        }
+    }
+    if (FIX && mode == 3) {
+        V9_WAITV(0);
+        __syncthreads();
+        v8_fix_atomic(a, xb, wb, cx, cw, sxt, swt, m0, n0, 256);
+    }
+}
+
+static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/v9_stamps.py): where the stamps build writes
+
+// 256 x 256 tiles, K % 128 == 0 (even slices under split-K).  Returns -1000 when the shape is not this kernel's
+// (the caller then launches the v8 kernel).
+int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
+                       hipStream_t st, const uint8_t* xf, const uint8_t* wf, bool bf16) {
+    GemmArgs a = a_in;
+    static const bool want_stamps = getenv("MI355Q_V9_STAMPS") != nullptr;
+    if (want_stamps) a.stamps = g_v9_stamps;
+    const bool fix = xlist && wlist;
+    if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
+    const unsigned grid = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256) * (a.ngroup > 1 ? a.ngroup : 1) * (a.splits > 1 ? a.splits : 1));
+    if (bf16) hipLaunchKernelGGL((bfp_gemm_v9<0, true, false>), grid, V9_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else if (fix && want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<1, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (fix) hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else hipLaunchKernelGGL((bfp_gemm_v9<0, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mi355q
+
+// diagnostic hook, not part of include/mi355q.h: the buffer ([workgroups][2][8] 64-bit words) the MI355Q_V9_STAMPS build fills
+extern "C" __attribute__((visibility("default"))) void mi355q_debug_v9_stamps(void* buf) { mi355q::g_v9_stamps = static_cast<unsigned long long*>(buf); }
