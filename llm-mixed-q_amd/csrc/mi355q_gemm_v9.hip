@@ -35,10 +35,12 @@ constexpr int V9_B0 = V9_NA * V9_HALF;                       // B ring behind th
 constexpr int V9_STAGES = (V9_NA + V9_NB) * V9_HALF;         // 112 KiB
 constexpr int V9_XB = 0, V9_WB = V9_XB + 4096, V9_MAP = V9_WB + 4096;      // (offsets in the side area)
 constexpr int V9_SXT = V9_MAP + 2048, V9_SWT = V9_SXT + 1024, V9_BIAS = V9_SWT + 1024;
-constexpr int V9_FLAGS = V9_BIAS + 1024, V9_OVF = V9_FLAGS + 256, V9_CORR = V9_OVF + 512;
+constexpr int V9_FLAGS = V9_BIAS + 1024, V9_OVF = V9_FLAGS + 256, V9_NXT = V9_OVF + 512, V9_CORR = V9_NXT + 1024;
 constexpr int V9_LDS = 159 * 1024, V9_SIDE = V9_LDS - V9_STAGES;
 constexpr int V9_FAST_MAX = (V9_SIDE - V9_CORR) / 1024;       // entries (x + w) whose vectors fit beside the rings
-constexpr int V9_SLOW_MAX = V9_STAGES / 1024 - 32;           // ... that fit the ring area after the K loop (+ 8 x 4 KiB of scratch)
+constexpr int V9_NB_ENT = 2;                                 // entries a wave gathers per batch behind the K loop
+constexpr int V9_GSCR = V9_NW * V9_NB_ENT * 4096;            // ... their blocks: scratch at the start of the ring area
+constexpr int V9_SLOW_MAX = (V9_STAGES - V9_GSCR) / 1024;    // vectors that fit the ring area behind the K loop
 static_assert(ROW_BUCKET_WORDS * 4 <= 4096, "bucket copy");
 static_assert(V9_FAST_MAX >= 32, "spare LDS for correction vectors");
 
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
-    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0}, st_x[3] = {0, 0, 0};
     if (STAMP) st_t[0] = __builtin_amdgcn_s_memrealtime();
 
     GemmArgs a = a_in;
@@ -157,10 +159,16 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     } else if (FIX && (wave == 5 || wave == 6)) {
         V9_GLDS4((wave == 5 ? xlist : wlist) + lane, side_lds + V9_OVF + (wave - 5) * 256);
     }
-    if (FIX) {                                                  // (maps cleared before the bookkeeping of K-step 1 writes them)
+    if (FIX) {
+        // (cleared before the bookkeeping of the first K-step writes them; the vectors beside the rings start at zero:
+        //  every product is ADDED to its row's / column's vector)
         rowslot[tid & 255] = -1;
         if (tid >= 256) colslot[tid & 255] = -1;
-        if (tid == 0) *reinterpret_cast<int*>(smem + V9_FLAGS) = 0;
+        if (tid < 16) reinterpret_cast<int*>(smem + V9_FLAGS)[16 + tid] = -1;
+#pragma unroll
+        for (int q = 0; q < (V9_FAST_MAX * 1024 + V9_NT * 16 - 1) / (V9_NT * 16); ++q)
+            if ((q * V9_NT + tid) * 16 < V9_FAST_MAX * 1024)
+                *reinterpret_cast<f32x4*>(smem + V9_CORR + (q * V9_NT + tid) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // ---- the operand stream.  Piece p of a K-step: 16 rows of A (p < 16) or of B; this wave stages pieces wave + 8 q.
@@ -190,98 +198,34 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     if (STAMP) st_t[1] = __builtin_amdgcn_s_memrealtime();
 
     using acc_t = typename std::conditional<BF16, f32x4, i32x4>::type;
-    acc_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
-    // ---- exception service.  Waves 0-3 (one per SIMD: the ones that win the matrix pipe and then wait at the barrier)
-    //      serve the tile's entries while the K loop runs, a QUARTER of an entry per K-step: one LDS-DMA gathers the other
-    //      operand's 16-byte blocks at the entry's K position for 64 tile columns / rows into the wave's 1-KiB scratch (a load
-    //      into registers cannot be used: the compiler would wait for it with s_waitcnt vmcnt(0), draining the operand stream,
-    //      or, kept from knowing about it, move its destination registers while it is in flight); the next step multiplies,
-    //      adds to the vector of the entry's chain (one LDS round trip) and requests the next quarter.  What a wave serves and
-    //      in which order is laid down by the bookkeeping of K-steps 1 and 2: whole chains, chain starts s with s % 4 == wave
-    //      in ascending order, each chain in ascending block order (word 3 of an entry's LDS copy: successor in the low half,
-    //      the wave's next chain start in the high half of a start's word).
-    int cx = 0, cw = 0, nent = 0, mode = 0;   // mode 0: no entries, 1: vectors in LDS (the first V9_FAST_MAX beside the rings,
-                                              // formed while the K loop runs; the rest in the ring area behind it), 3: more
-                                              // than LDS holds, added with atomics after the stores
-    constexpr int NSV = 4;                    // serving waves
-    int sv_on = 0;                            // 1: this wave has entries to serve, -1: a bucket overflowed (uniform over the grid)
-    int sv_cur = -1, sv_head = -1, sv_q = -1, sv_link = -1, sv_nexts = -1;      // entry / chain / quarter in flight
-    int e_isx = 0, e_sh = 0, e_kb = 0, e_code = 0, e_koff = 0;
-    int4 e_pv = int4{0, 0, 0, 0};
-    // scratch of wave w < 4 while the loop runs: the upper halves of the two bucket copies (the loop serves at most
-    // V9_FAST_MAX entries: the lower 2 KiB of each copy hold 63)
-    const int scr_off = (wave < 2 ? V9_XB : V9_WB) + 2048 + (wave & 1) * 1024;
-    const int glane = (lane >> 4) * (int)row_bytes + (lane & 15) * 16;     // row `lane` of a quarter inside the tile's piece rows
-    const i32x4 xg = v9_desc(a.xm + (long long)(m0 >> 4) * row_bytes, x_nrec), wg = v9_desc(a.wm + (long long)(n0 >> 4) * row_bytes, w_nrec);
-    // fields of entry i into scalars (one LDS round trip)
-    auto serve_load = [&](int i) {
-        const int* e = v8_entry(xb, wb, cx, i);
-        const int4 h = *reinterpret_cast<const int4*>(e), m = *reinterpret_cast<const int4*>(e + 4);
-        e_isx = i < cx ? 1 : 0;
-        e_kb = __builtin_amdgcn_readfirstlane(h.y);
-        e_code = __builtin_amdgcn_readfirstlane(h.z);
-        const int l3 = __builtin_amdgcn_readfirstlane(h.w);
-        sv_link = (int)(short)(l3 & 0xffff);
-        if (i == sv_head) sv_nexts = l3 >> 16;                  // (a chain start carries the wave's next start)
-        e_sh = e_code - (e_isx ? +a.x_off : +a.w_off);
-        e_koff = (e_kb >> 2) * 1024 + (e_kb & 3) * 256;
-        e_pv = int4{__builtin_amdgcn_readfirstlane(m.x), __builtin_amdgcn_readfirstlane(m.y), __builtin_amdgcn_readfirstlane(m.z),
-                    __builtin_amdgcn_readfirstlane(m.w)};
-        sv_cur = i;
-    };
-    // request quarter c of the current entry: rows c * 64 + lane of the other operand's tile rows (rows past the operand
-    // read as zero), the K position in the scalar offset
-    auto serve_issue = [&](int c, int dst_lds) {
-        const int vo = glane + c * 4 * (int)row_bytes;
-        const int ko = __builtin_amdgcn_readfirstlane(e_koff), dl = __builtin_amdgcn_readfirstlane(dst_lds);     // (provably scalar for the asm)
-        V9_LGKM(0);                                             // (this wave's reads of the scratch have returned)
-        if (e_isx) { V9_BLDS16(vo, wg, ko, dl); } else { V9_BLDS16(vo, xg, ko, dl); }
-    };
-    // quarter c of the current entry: 64 products, added to the vector of the entry's chain
-    auto serve_finish = [&](int c, const unsigned char* scr, float* area) {
-        const float* sc = e_isx ? swt : sxt;
-        float* v = area + sv_head * 256 + c * 64 + lane;
-        const int4 q = *reinterpret_cast<const int4*>(scr + lane * 16);
-        const float scl = sc[c * 64 + lane];
-        const float old = sv_cur == sv_head ? 0.f : *v;
-        *v = old + __builtin_ldexpf((float)dot16(e_pv, q), e_sh) * scl;
-    };
-    // the exception x exception terms of the current x entry (same K position in both lists), behind its four quarters
-    auto serve_cross = [&](float* area) {
-        float* v = area + sv_head * 256;
-        for (int f0 = 0; f0 < cw; f0 += 64) {                   // uniform
-            const int fi = f0 + lane;
-            if (fi < cw) {
-                const int* f = wb + EXC_HEADER + EXC_ENTRY * fi;
-                if ((short)(f[3] & 0xffff) != -2 && f[1] == e_kb) {
-                    const int d = dot16(e_pv, *reinterpret_cast<const int4*>(f + 4));
-                    v[f[0] - n0] += __builtin_ldexpf((float)d, e_code + f[2] - a.scale_bias);
-                }
-            }
-        }
-    };
-    // behind the last quarter of an entry: its cross terms, then the chain's successor or the wave's next chain
-    auto serve_advance = [&](float* area) {
-        if (e_isx && cw > 0) serve_cross(area);
-        const int nxt = sv_link >= 0 ? sv_link : sv_nexts;
-        if (nxt < 0) { sv_cur = -1; return; }
-        if (sv_link < 0) sv_head = nxt;
-        serve_load(nxt);
-    };
+    int cx = 0, cw = 0, nent = 0, mode = 0;   // exception entries of this tile (set behind the K loop)
 
     // lane-constant part of the fragment addresses; fragment i is i KiB further (immediate offset)
     const int va = ring_lds + piece_lds_off(wm * 128 + l16, lq), vb = ring_lds + V9_B0 + piece_lds_off(wn * 64 + l16, lq);
     i32x4 fa[4], fb0[4], fb1[4];
     V9_WAITV(8);                                                // everything but the pieces of K-steps 1 and 2
     __builtin_amdgcn_s_barrier();
+    if (FIX) {
+        // a bucket overflowed somewhere (uniform over the grid): the row-scale product does not apply; the workgroups of
+        // this launch share the blockwise-exact product instead (the operand loads in flight land in LDS only)
+        const int* ovf = reinterpret_cast<const int*>(smem + V9_OVF);
+        if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
+            V9_WAITV(0);
+            __syncthreads();
+            v8_fallback(a, xf, wf, xlist, wlist, ring, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
+                        ngroup > 1 ? tiles_m * tiles_n1 * S : nwg);
+            return;
+        }
+    }
     V9_DSR(fb0[0], vb, 0); V9_DSR(fb0[1], vb, 1024); V9_DSR(fb0[2], vb, 2048); V9_DSR(fb0[3], vb, 3072);
     V9_DSR(fa[0], va, 0); V9_DSR(fa[1], va, 1024);
     V9_SB();
+    acc_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
     unsigned long long c_loop = 0;
     if (STAMP) { st_t[2] = __builtin_amdgcn_s_memrealtime(); c_loop = __builtin_amdgcn_s_memtime(); }
 
@@ -294,105 +238,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_LGKM(2);                                             // (the B reads of the slot about to be refilled)
         V9_WAITV(4);
         __builtin_amdgcn_s_barrier();
-        if (FIX && sv_on > 0) {
-            if (t == 1) {
-                // ---- bookkeeping of the tile's two buckets (they rode in front of the operand stream), first half
-                const int* ovf = reinterpret_cast<const int*>(smem + V9_OVF);
-                if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) { sv_on = -1; }
-                else {
-                    cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
-                    cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
-                    nent = cx + cw;
-                    mode = nent == 0 ? 0 : (nent <= V9_FAST_MAX + V9_SLOW_MAX ? 1 : 3);
-                    if (mode) {
-                        // chains: the entries of one tile row / column linked by ASCENDING block index (successor in word 3
-                        // of the entry's LDS copy, -1 ends a chain, -2 marks a void entry), the first one in rowslot /
-                        // colslot.  The order is a property of the data, not of which workgroup reserved its list slots
-                        // first.  16 lanes share an entry (each scans every 16th entry of the same operand).
-                        for (int i0 = 0; i0 < nent; i0 += V9_NT / 16) {            // uniform
-                            const int i = i0 + (tid >> 4), sub = tid & 15;
-                            const bool valid = i < nent;
-                            const bool is_x = i < cx;
-                            int* e = v8_entry(xb, wb, cx, valid ? i : 0);
-                            const int r = e[0], kb = e[1];
-                            const bool live = valid && (is_x ? (r >= m0 && r < m0 + 256 && r < Mi) : (r >= n0 && r < n0 + 256 && r < Ni));
-                            const int lo = is_x ? 0 : cx, hi = is_x ? cx : nent;
-                            int key = 0x7fffffff, earlier = 0;            // key = (block << 8 | index) of the best successor
-                            if (live)
-                                for (int j = lo + sub; j < hi; j += 16) {
-                                    const int* f = v8_entry(xb, wb, cx, j);
-                                    if (f[0] != r) continue;
-                                    const int kj = f[1];
-                                    if (kj > kb) key = min(key, (kj << 8) | (j - lo));
-                                    earlier |= kj < kb ? 1 : 0;
-                                }
-#pragma unroll
-                            for (int o = 1; o < 16; o <<= 1) {
-                                key = min(key, __shfl_xor(key, o));
-                                earlier |= __shfl_xor(earlier, o);
-                            }
-                            if (valid && sub == 0) {
-                                if (!live) {
-                                    e[3] = 0xffff0000 | (unsigned short)-2;
-                                } else {
-                                    e[3] = 0xffff0000 | (unsigned short)(key != 0x7fffffff ? lo + (key & 255) : -1);
-                                    if (!earlier) (is_x ? rowslot : colslot)[r - (is_x ? m0 : n0)] = i;
-                                }
-                            }
-                        }
-                    }
-                    if (mode != 1) sv_on = 0;                   // nothing to serve
-                }
-                V9_LGKM(0);                                     // (read by other waves behind the next barrier)
-            } else if (t == 2) {
-                // ---- second half: every chain start s < V9_FAST_MAX learns the next such start s' > s with s' % 4 == s % 4
-                //      (the chains one serving wave works through), the first of each class goes to the flag words
-                int* svfirst = reinterpret_cast<int*>(smem + V9_FLAGS) + 16;
-                const int lim = min(nent, V9_FAST_MAX);
-                for (int i0 = 0; i0 < lim; i0 += V9_NT / 16) {                    // uniform
-                    const int i = i0 + (tid >> 4), sub = tid & 15;
-                    auto is_start = [&](int j) {
-                        if (j >= lim) return false;
-                        const int* f = v8_entry(xb, wb, cx, j);
-                        if ((short)(f[3] & 0xffff) == -2) return false;
-                        return (j < cx ? rowslot[f[0] - m0] : colslot[f[0] - n0]) == j;
-                    };
-                    // candidates i + 4 (sub + 1); 16 lanes cover the 8 there can be
-                    int cand = i + 4 * (sub + 1);
-                    int best = (i < lim && is_start(cand)) ? cand : 0x7fff;
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) best = min(best, __shfl_xor(best, o));
-                    if (i < lim && sub == 0 && is_start(i)) {
-                        int* e = v8_entry(xb, wb, cx, i);
-                        e[3] = (e[3] & 0xffff) | ((best == 0x7fff ? -1 : best) << 16);
-                    }
-                }
-                if (tid < NSV) {                                 // the first start of class tid
-                    int first = -1;
-                    for (int j = tid; j < lim; j += NSV) {
-                        const int* f = v8_entry(xb, wb, cx, j);
-                        if ((short)(f[3] & 0xffff) == -2) continue;
-                        if ((j < cx ? rowslot[f[0] - m0] : colslot[f[0] - n0]) == j) { first = j; break; }
-                    }
-                    svfirst[tid] = first;
-                }
-                V9_LGKM(0);
-                if (wave >= NSV || (a.dbg & 1)) sv_on = 0;      // (dbg 1, diagnostic: all of it behind the loop)
-            } else if (t >= 3) {
-                // ---- a quarter of an entry per serving wave and K-step: the quarter requested in the previous step has
-                //      landed (it is older than that step's pieces, which the counted wait above left in flight)
-                if (sv_q < 0) {                                  // first service step: the wave's first chain
-                    const int first = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + V9_FLAGS)[16 + wave]);
-                    if (first < 0) sv_on = 0;
-                    else { sv_head = first; serve_load(first); sv_q = 0; serve_issue(0, side_lds + scr_off); }
-                } else {
-                    serve_finish(sv_q, side + scr_off, corr);
-                    if (++sv_q == 4) { sv_q = 0; serve_advance(corr); }
-                    if (sv_cur < 0) sv_on = 0; else serve_issue(sv_q, side_lds + scr_off);
-                }
-            }
-            V9_SB();
-        }
         const int ac = va + sa_c, an = va + sa_n, bn = vb + sb_n;
         V9_DESCS(t + 3)
 #define V9_GROUP(i, wait)                                                                                                \
@@ -411,10 +256,9 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_SB();                                                                                                         \
         acc[i][3] = v9_mma(fb[3], fa[i & 3], acc[i][3]);                                                                 \
         V9_SB();
-        V9_GROUP(0, 2) V9_GROUP(1, 2) V9_GROUP(2, 2) V9_GROUP(3, 3) V9_GROUP(4, 4) V9_GROUP(5, 4) V9_GROUP(6, 4) V9_GROUP(7, 3)
-#undef V9_GROUP
+        V9_GROUP(0, 2) V9_GROUP(1, 2) V9_GROUP(2, 2) V9_GROUP(3, 3)
+        V9_GROUP(4, 4) V9_GROUP(5, 4) V9_GROUP(6, 4) V9_GROUP(7, 3)
     };
-    if (FIX) sv_on = 1;                                         // (until the bookkeeping of K-steps 1 and 2 knows better)
     // ring positions (byte offsets): A half of step t in a0, t + 1 in a1, ..., the slot step t + 3 goes to in a3;
     // B half of step t + 1 in b1, the slot step t + 3 goes to (= where step t's B half was) in b0
     int a0 = 0, a1 = V9_HALF, a2 = 2 * V9_HALF, a3 = 3 * V9_HALF, b0 = 0, b1 = V9_HALF, b2 = 2 * V9_HALF;
@@ -422,7 +266,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         body(fb0, fb1, t, a0, a1, b1, a3, b0);
         { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }
         { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
-        if (FIX && sv_on < 0) break;
         body(fb1, fb0, t + 1, a0, a1, b1, a3, b0);
         { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }
         { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
@@ -432,14 +275,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     V9_SB();
     if (STAMP) { st_t[3] = __builtin_amdgcn_s_memrealtime(); c_loop = __builtin_amdgcn_s_memtime() - c_loop; }
     __builtin_amdgcn_s_barrier();                               // (every wave is out of the rings)
-    if (FIX && sv_on < 0) {
-        // a bucket overflowed somewhere (uniform over the grid): the row-scale product does not apply; the workgroups of
-        // this launch share the blockwise-exact product instead.  Nothing is pending.
-        v8_fallback(a, xf, wf, xlist, wlist, ring, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
-                    ngroup > 1 ? tiles_m * tiles_n1 * S : nwg);
-        return;
-    }
-
     if (S > 1) {
         // ---- split-K: every slice leaves its raw accumulators in its slab (16 bytes a lane, 1 KiB a wave instruction);
         //      the slice that arrives last at the tile's ticket sums all slabs IN SLICE ORDER (reproducible for the fp32
@@ -483,131 +318,216 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         }
     }
 
-    if (FIX && mode == 1) {
-        // ---- behind the loop: what it did not get to (short K) and the chains it cannot hold (starts from V9_FAST_MAX on:
-        //      their vectors go to the ring area, free now).  Whole entries: four quarters requested together into 4 KiB of
-        //      scratch per wave (ring area), one exposed round trip each.  Waves 0-3 finish their own sequences, waves 4-7
-        //      take the overflow chains.
-        float* const rcorr = reinterpret_cast<float*>(ring);
-        const int rscr = V9_SLOW_MAX * 1024 + wave * 4096;
-        auto batch = [&](int qfrom, float* area) {              // the rest of the current entry, then on to the next
+    // ---- epilogue: y = float(acc) * sx[m] * sw[n] + bias[n] (+ exception blocks).  The lane holds, for tile (i, j) of its
+    //      wave, row wm * 128 + 16 i + l16 and the four columns wn * 64 + 16 j + 4 lq + 0..3: one 16-byte store.
+    //
+    //      Exception blocks (blocks outside their row's exponent window, zero in the operand, listed exactly in the tile's
+    //      two buckets; a few dozen per tile in the usual case) are added back here, behind the K loop, which does not know
+    //      of them at all: every entry contributes one VECTOR of 256 products (x entry (row r, block kb): 2^(code - x_off) *
+    //      sw[n] * dot16(entry, w'[n, kb]) for the tile's 256 columns n; w entries the mirror image over the rows), all
+    //      entries of a tile row / column add into one vector (`slot` = the smallest list index of that row / column), and
+    //      the stores of the rows / columns that have a vector add it.  Order of events: (1) bookkeeping -- slots and the
+    //      row / column maps, one pass, one barrier; (2) every wave requests the blocks its entries need (wave = slot % 8;
+    //      its entries in ascending (slot, block, index) order -- a property of the data, not of the order in which rows
+    //      reserved their list slots: reproducible; LDS-DMA gathers of 4 KiB per entry into the ring area, free now); (3)
+    //      vectors formed, one barrier; (4) the stores.  (Tried and not kept, profiles/r03_v9_exception_designs.txt: serving
+    //      the entries while the K loop runs -- by gathers into scratch, or picking the blocks up from the operand rings
+    //      as they stream by: every served entry stalls one wave for an LDS round trip and with it, at the next barrier,
+    //      the workgroup; and storing the untouched tiles while the gathers fly: the gathers queue behind the stores.)
+    float* const rvec = reinterpret_cast<float*>(ring) + (V9_GSCR - V9_FAST_MAX * 1024) / 4;   // (vector of slot s >= V9_FAST_MAX)
+#define V9_VEC(s_) (((s_) < V9_FAST_MAX ? corr : rvec) + (s_) * 256)
+    bool look = false;
+    int mykeys[2] = {0x7fffffff, 0x7fffffff};                   // (slot << 18 | block << 8 | index) of the entries at list
+                                                                // positions lane, lane + 64 that this wave serves
+    if (FIX) {
+        cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+        cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
+        nent = cx + cw;
+        mode = nent == 0 ? 0 : (nent <= min(128, V9_FAST_MAX + V9_SLOW_MAX) ? 1 : 3);
+        if (mode) {                                             // (uniform over the workgroup: the barrier below is met by all)
+            // (1) 16 lanes share an entry: slot = the smallest list index with the same tile row / column; -2 marks a void
+            //     entry (also for the atomics pass of mode 3); rows / columns without a vector keep -1 in the maps
+            for (int i0 = 0; i0 < nent; i0 += V9_NT / 16) {    // uniform
+                const int i = i0 + (tid >> 4), sub = tid & 15;
+                const bool valid = i < nent, is_x = i < cx;
+                int* e = v8_entry(xb, wb, cx, valid ? i : 0);
+                const int r = e[0], base = is_x ? m0 : n0;
+                const bool live = valid && (is_x ? (r >= m0 && r < m0 + 256 && r < Mi) : (r >= n0 && r < n0 + 256 && r < Ni));
+                const int lo = is_x ? 0 : cx, hi = is_x ? cx : nent;
+                int slot = i;
+                if (live)
+                    for (int j = lo + sub; j < hi; j += 16)
+                        if (v8_entry(xb, wb, cx, j)[0] == r) slot = min(slot, j);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c >= qfrom) serve_issue(c, ring_lds + rscr + c * 1024);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c >= qfrom) serve_finish(c, ring + rscr + c * 1024, area);
-        };
-        if (wave < NSV) {
-            int qfrom = 0;
-            if (sv_on > 0 && sv_q >= 0) {                        // a quarter the loop left in flight (landed: drained above)
-                serve_finish(sv_q, side + scr_off, corr);
-                qfrom = sv_q + 1;
-            } else if (sv_q < 0) {                               // the loop never served (short K, or the diagnostic switch)
-                const int first = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + V9_FLAGS)[16 + wave]);
-                sv_cur = -1;
-                if (first >= 0) { sv_head = first; serve_load(first); }
-            } else {
-                sv_cur = -1;                                     // its sequence is complete
-            }
-            while (sv_cur >= 0) {
-                if (qfrom < 4) batch(qfrom, corr);
-                qfrom = 0;
-                serve_advance(corr);
-            }
-        } else {
-            for (int s0 = V9_FAST_MAX + wave - NSV; s0 < nent; s0 += NSV) {       // uniform
-                const int* e = v8_entry(xb, wb, cx, s0);
-                const int l3 = __builtin_amdgcn_readfirstlane(e[3]);
-                if ((short)(l3 & 0xffff) == -2) continue;
-                const int r = __builtin_amdgcn_readfirstlane(e[0]) - (s0 < cx ? m0 : n0);
-                if (__builtin_amdgcn_readfirstlane((s0 < cx ? rowslot : colslot)[r]) != s0) continue;
-                sv_head = s0;
-                sv_nexts = -1;
-                serve_load(s0);
-                sv_nexts = -1;                                   // (no sequence: the outer loop finds the next start)
-                float* const area = rcorr - V9_FAST_MAX * 256;   // (vector of chain s at area + 256 s)
-                while (sv_cur >= 0) {
-                    batch(0, area);
-                    serve_advance(area);
+                for (int o = 1; o < 16; o <<= 1) slot = min(slot, __shfl_xor(slot, o));
+                if (valid && sub == 0) {
+                    e[3] = live ? slot : -2;
+                    if (live && slot == i) (is_x ? rowslot : colslot)[r - base] = i;
                 }
             }
+            V9_LGKM(0);
+            __builtin_amdgcn_s_barrier();
+            look = mode == 1 && !(a.dbg & 2);                   // (dbg 2, diagnostic: no add-back, results invalid)
+            if (STAMP) st_x[0] = __builtin_amdgcn_s_memrealtime();
         }
-        V9_LGKM(0);
-        __syncthreads();
     }
-    if (STAMP) st_t[4] = __builtin_amdgcn_s_memrealtime();
-
-    // ---- epilogue: y = float(acc) * sx[m] * sw[n] + bias[n] (+ correction vectors).  The lane holds, for fragment (i, j),
-    //      row wm * 128 + 16 i + l16 and the four columns wn * 64 + 16 j + 4 lq + 0..3: one 16-byte store.  Nothing is loaded
-    //      from global memory between the stores.
-    const bool look = FIX && mode == 1;
-    // (vector of chain s: beside the rings for s < V9_FAST_MAX, else in the ring area)
-    const float* const rvec = reinterpret_cast<const float*>(ring) - V9_FAST_MAX * 256;
-#define V9_VEC(s_) (((s_) < V9_FAST_MAX ? corr : rvec) + (s_) * 256)
-    f32x4 swv[4], bv[4];
-    int4 cs[4];
-    unsigned cmask = 0;                                         // bit 4 j + r: some lane of the wave has a vector for that column
+    // gathers of one entry: the other operand's 16-byte blocks at the entry's K position for the tile's 256 rows / columns,
+    // four LDS-DMA quarters (rows past the operand read as zero) into 4 KiB of this wave's scratch
+    const int glane = (lane >> 4) * (int)row_bytes + (lane & 15) * 16;     // row `lane` of a quarter inside the tile's piece rows
+    const i32x4 xg = v9_desc(a.xm + (long long)(m0 >> 4) * row_bytes, x_nrec), wg = v9_desc(a.wm + (long long)(n0 >> 4) * row_bytes, w_nrec);
+    auto gather = [&](int i, int b) {
+        const int kb = __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, i)[1]);
+        const int koff = (kb >> 2) * 1024 + (kb & 3) * 256;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int cl = wn * 64 + j * 16 + lq * 4;
-        swv[j] = BF16 ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(&swt[cl]);
-        bv[j] = *reinterpret_cast<const f32x4*>(&bst[cl]);
-        cs[j] = look ? *reinterpret_cast<const int4*>(&colslot[cl]) : int4{-1, -1, -1, -1};
-        if (look) {
-            if (__any(cs[j].x >= 0)) cmask |= 1u << (4 * j);
-            if (__any(cs[j].y >= 0)) cmask |= 2u << (4 * j);
-            if (__any(cs[j].z >= 0)) cmask |= 4u << (4 * j);
-            if (__any(cs[j].w >= 0)) cmask |= 8u << (4 * j);
+        for (int c = 0; c < 4; ++c) {
+            const int vo = glane + c * 4 * (int)row_bytes, dl = ring_lds + (wave * V9_NB_ENT + b) * 4096 + c * 1024;
+            if (i < cx) { V9_BLDS16(vo, wg, koff, dl); } else { V9_BLDS16(vo, xg, koff, dl); }
         }
+    };
+    // one entry: multiply, add to its slot's vector (`first`: the vector is in the ring area and this is its first
+    // entry); an x entry also takes the exception x exception terms (same K position in both lists)
+    auto finish = [&](int i, int b, int slot, bool first) {
+        const bool is_x = i < cx;
+        const int* e = v8_entry(xb, wb, cx, i);
+        const int kb = e[1], code = e[2];
+        const int4 pv = *reinterpret_cast<const int4*>(e + 4);
+        const int sh = code - (is_x ? +a.x_off : +a.w_off);
+        const float* sc = is_x ? swt : sxt;
+        float* v = V9_VEC(slot);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int4 q = *reinterpret_cast<const int4*>(ring + (wave * V9_NB_ENT + b) * 4096 + c * 1024 + lane * 16);
+            const float p = __builtin_ldexpf((float)dot16(pv, q), sh) * sc[c * 64 + lane];
+            v[c * 64 + lane] = first ? p : v[c * 64 + lane] + p;
+        }
+        if (is_x)
+            for (int f0 = 0; f0 < cw; f0 += 64) {               // uniform
+                const int fi = f0 + lane;
+                if (fi < cw) {
+                    const int* f = wb + EXC_HEADER + EXC_ENTRY * fi;
+                    if (f[3] != -2 && f[1] == kb) {
+                        const int d = dot16(pv, *reinterpret_cast<const int4*>(f + 4));
+                        v[f[0] - n0] += __builtin_ldexpf((float)d, code + f[2] - a.scale_bias);
+                    }
+                }
+            }
+    };
+    // the wave's next entry: the smallest key above `last` among the two this lane holds, over the wave
+    auto next_key = [&](int last) {
+        int best = mykeys[0] > last ? mykeys[0] : 0x7fffffff;
+        if (mykeys[1] > last) best = min(best, mykeys[1]);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) best = min(best, __shfl_xor(best, o));
+        return __builtin_amdgcn_readfirstlane(best);
+    };
+    if (look) {
+        // (2) this wave's entries
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < nent) {
+                const int* f = v8_entry(xb, wb, cx, j);
+                const int s3 = f[3];
+                if (s3 != -2 && (s3 & 7) == wave) mykeys[q] = (s3 << 18) | (f[1] << 8) | j;
+            }
+        }
+    }
+    // (masks only -- scales, bias and slots are read again where they are used: the accumulators take half the registers)
+    unsigned cmask = 0, jmask = 0;      // bit 4 j + r: some lane of the wave has a vector for that column; bit j: tile column j has one
+    unsigned rmask = 0;                 // bit i: some row of fragment i has a vector
+    if (look) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int4 c = *reinterpret_cast<const int4*>(&colslot[wn * 64 + j * 16 + lq * 4]);
+            if (__any(c.x >= 0)) cmask |= 1u << (4 * j);
+            if (__any(c.y >= 0)) cmask |= 2u << (4 * j);
+            if (__any(c.z >= 0)) cmask |= 4u << (4 * j);
+            if (__any(c.w >= 0)) cmask |= 8u << (4 * j);
+            if (cmask >> (4 * j) & 15) jmask |= 1u << j;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (__any(rowslot[wm * 128 + i * 16 + l16] >= 0)) rmask |= 1u << i;
     }
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.y) | (uintptr_t)(a.ldy * 4)) & 15) == 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    // tiles of fragment i: pass 0 the ones no vector touches, pass 1 the others (with their vectors)
+    auto store_rows = [&](int i, int pass) {
+        const bool rowv = (rmask >> i) & 1;
+        if (pass == 0 && rowv) return;
+        if (pass == 1 && !rowv && jmask == 0) return;
         const int rl = wm * 128 + i * 16 + l16;
         const float sxv = BF16 ? 1.f : sxt[rl];
-        f32x4 val[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) val[j][r] = BF16 ? (float)acc[i][j][r] + bv[j][r] : (float)acc[i][j][r] * sxv * swv[j][r] + bv[j][r];
-        if (look) {
-            const int rs = rowslot[rl];                          // the row's vector: 256 products, one per tile column
-            if (__any(rs >= 0)) {
-                const float* v = V9_VEC(max(rs, 0)) + wn * 64 + lq * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(v + j * 16);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) val[j][r] += rs >= 0 ? c4[r] : 0.f;
-                }
-            }
-            if (cmask) {                                         // the columns' vectors: one product per tile row
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c4[4] = {cs[j].x, cs[j].y, cs[j].z, cs[j].w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (cmask & (1u << (4 * j + r))) val[j][r] += c4[r] >= 0 ? V9_VEC(max(c4[r], 0))[rl] : 0.f;
-                }
-            }
-        }
+        const int rs = rowv ? rowslot[rl] : -1;
         const long long row = (long long)m0 + rl;
         float* yrow = a.y + row * a.ldy + n0 + wn * 64 + lq * 4;
-        if (row < a.M) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + lq * 4;
+        for (int j = 0; j < 4; ++j) {
+            const bool touched = rowv || ((jmask >> j) & 1);
+            if ((pass == 1) != touched) continue;               // (uniform)
+            const int cl = wn * 64 + j * 16 + lq * 4;
+            const f32x4 swv = BF16 ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(&swt[cl]);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&bst[cl]);
+            f32x4 val;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[r] = BF16 ? (float)acc[i][j][r] + bv[r] : (float)acc[i][j][r] * sxv * swv[r] + bv[r];
+            if (pass == 1) {
+                if (rowv) {                                      // the row's vector: 256 products, one per tile column
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(V9_VEC(max(rs, 0)) + cl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[r] += rs >= 0 ? c4[r] : 0.f;
+                }
+                if ((jmask >> j) & 1) {                          // the columns' vectors: one product per tile row
+                    const int4 c = *reinterpret_cast<const int4*>(&colslot[cl]);
+                    const int c4[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (cmask & (1u << (4 * j + r))) val[r] += c4[r] >= 0 ? V9_VEC(max(c4[r], 0))[rl] : 0.f;
+                }
+            }
+            if (row < a.M) {
+                const int col = n0 + cl;
                 if (vec_ok && col + 3 < Ni) {
-                    *reinterpret_cast<f32x4*>(yrow + j * 16) = val[j];
+                    *reinterpret_cast<f32x4*>(yrow + j * 16) = val;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (col + r < Ni) yrow[j * 16 + r] = val[j][r];
+                        if (col + r < Ni) yrow[j * 16 + r] = val[r];
                 }
             }
+            V9_SB();        // (tile by tile: the scheduler would otherwise pull the reads of many tiles ahead and spill)
         }
+    };
+    // (2), (3): batches of this wave's entries -- blocks requested (one round trip, exposed: the stores of the whole chip
+    // start together behind it, and a gather issued beside them would queue behind the compute unit's own stores), vectors
+    // formed; a second batch is rare
+    int lastkey = -1, lastslot = -1;
+    bool more = look;
+    while (more) {
+        int bkey[V9_NB_ENT];
+#pragma unroll
+        for (int b = 0; b < V9_NB_ENT; ++b) {
+            bkey[b] = next_key(lastkey);
+            if (bkey[b] != 0x7fffffff) { lastkey = bkey[b]; gather(bkey[b] & 255, b); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < V9_NB_ENT; ++b)
+            if (bkey[b] != 0x7fffffff) {
+                const int slot = bkey[b] >> 18;
+                finish(bkey[b] & 255, b, slot, slot >= V9_FAST_MAX && slot != lastslot);
+                lastslot = slot;
+            }
+        V9_LGKM(0);                                             // (this wave's reads of its scratch have returned)
+        more = bkey[V9_NB_ENT - 1] != 0x7fffffff;
+    }
+    if (STAMP) st_x[2] = __builtin_amdgcn_s_memrealtime();
+    if (look) __builtin_amdgcn_s_barrier();
+    if (STAMP) st_t[4] = __builtin_amdgcn_s_memrealtime();
+    // (4) the stores: fragment by fragment, first its tiles that no vector touches, then the others
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        store_rows(i, 0);
+        if (look) store_rows(i, 1);
     }
     if (STAMP) {
         st_t[5] = __builtin_amdgcn_s_memrealtime();
@@ -617,6 +537,8 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             for (int q = 0; q < 6; ++q) d[q] = st_t[q];
             d[6] = c_loop;
             d[7] = ((unsigned long long)(unsigned)nent << 32) | (unsigned)mode;
+            // (the post-loop phases, x 10 ns, 12 bits each, instead of the stage-request stamp: bookkeeping, first-pass stores, vectors)
+            d[1] = ((st_x[0] - st_t[3]) & 0xfff) | (((st_x[1] - st_x[0]) & 0xfff) << 12) | (((st_x[2] - st_x[1]) & 0xfff) << 24);
         }
     }
     if (FIX && mode == 3) {
