@@ -31,5 +31,5 @@ for rep in range(3):
         cps = s[:, wv, 6] / 64.0
         clk = s[:, wv, 6] / np.maximum(t[:, 3] - t[:, 2], 1) * 100.0
         print(f"{name}: start->loop {np.median((t[:,2]-t[:,0])*0.01):5.2f}  loop {np.median(d[:,2]):6.2f} (max {d[:,2].max():6.2f})  "
-              f"behind the loop {np.median(d[:,3]):5.2f} (max {d[:,3].max():5.2f}) = bookkeeping {np.median(bk):4.2f} (max {bk.max():4.2f}) + first-pass stores {np.median(st0):4.2f} (max {st0.max():4.2f}) + vectors {np.median(vec):4.2f} (max {vec.max():4.2f}) + barrier;  epilogue {np.median(d[:,4]):5.2f} (max {d[:,4].max():5.2f}) us | "
+              f"behind the loop {np.median(d[:,3]):5.2f} (max {d[:,3].max():5.2f})  epilogue {np.median(d[:,4]):5.2f} (max {d[:,4].max():5.2f}) us | "
               f"{np.median(clk):5.0f} MHz {np.median(cps):7.1f} clk/K-step | span {(t[:,5].max()-t[:,0].min())*0.01:6.2f} us | entries med {np.median(nent):.0f} max {nent.max()} modes {np.bincount(mode.astype(int))}")
