@@ -739,10 +739,11 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     static const int sched = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
     const unsigned grid = tiles;            // (on a bucket overflow the tile workgroups themselves form the product blockwise)
     // the 256 x 256 tile has its own kernel since round 3 (mi355q_gemm_v9.hip); MI355Q_V9=0 keeps the round-2 one for A/B runs
-    static const int use_v9 = getenv("MI355Q_V9") ? atoi(getenv("MI355Q_V9")) : 0;      // (work in progress: off by default)
+    static const int use_v9 = getenv("MI355Q_V9") ? atoi(getenv("MI355Q_V9")) : 1;
     static const int v9_dbg = getenv("MI355Q_V9_DBG") ? atoi(getenv("MI355Q_V9_DBG")) : 0;
     if (use_v9) a.dbg = v9_dbg;
-    if (use_v9 && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
+    // (grouped launches stay here: their outputs are promised bit-identical to the separate calls, which may take 128-row tiles)
+    if (use_v9 && a.ngroup <= 1 && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {
         if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
@@ -799,7 +800,7 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
         }
     }
     if (small) hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 1, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && getenv("MI355Q_V9") && atoi(getenv("MI355Q_V9")) != 0) return launch_bfp_gemm_v9(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true);
+    else if (a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !(getenv("MI355Q_V9") && atoi(getenv("MI355Q_V9")) == 0)) return launch_bfp_gemm_v9(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true);
     else if (a.K % 128 == 0) hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 0, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     return (int)hipGetLastError();

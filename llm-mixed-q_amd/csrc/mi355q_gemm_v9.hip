@@ -24,7 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "mi355q_gemm_tile.h"
 
@@ -35,10 +38,19 @@ constexpr int V9_B0 = V9_NA * V9_HALF;                       // B ring behind th
 constexpr int V9_STAGES = (V9_NA + V9_NB) * V9_HALF;         // 112 KiB
 constexpr int V9_XB = 0, V9_WB = V9_XB + 4096, V9_MAP = V9_WB + 4096;      // (offsets in the side area)
 constexpr int V9_SXT = V9_MAP + 2048, V9_SWT = V9_SXT + 1024, V9_BIAS = V9_SWT + 1024;
-constexpr int V9_FLAGS = V9_BIAS + 1024, V9_OVF = V9_FLAGS + 256, V9_CORR = V9_OVF + 512;     // (V9_CORR: 8 x 4 KiB of gather scratch)
+constexpr int V9_FLAGS = V9_BIAS + 1024, V9_OVF = V9_FLAGS + 256, V9_HDR = V9_OVF + 512, V9_CORR = V9_HDR + 256;
 constexpr int V9_LDS = 159 * 1024, V9_SIDE = V9_LDS - V9_STAGES;
-static_assert(V9_CORR + V9_NW * 4096 <= V9_SIDE, "gather scratch");
+constexpr int V9_FAST_MAX = (V9_SIDE - V9_CORR) / 1024;       // entries (x + w) whose vectors fit beside the rings
+constexpr int V9_NB_ENT = 2;                                 // entries a wave gathers per batch behind the K loop
+constexpr int V9_GSCR = V9_NW * V9_NB_ENT * 4096;            // ... their blocks: scratch at the start of the ring area
+constexpr int V9_SLOW_MAX = (V9_STAGES - V9_GSCR) / 1024;    // vectors that fit the ring area behind the K loop
+// Record of a tile's exception add-back, written by the pre-pass launch and read back by the product launch (FIX 2 / 3): 1 KiB
+// of header {entries, mode, 1 if the vectors do not all fit beside the rings}, then the row / column maps and the
+// V9_FAST_MAX vectors exactly as they lie in LDS.
+constexpr int V9_REC_MAPS = 1024, V9_REC_VEC = V9_REC_MAPS + 2048, V9_REC = V9_REC_VEC + V9_FAST_MAX * 1024;
+constexpr int V9_RDMA = (2 + V9_FAST_MAX + 1 + V9_NW - 1) / V9_NW;      // LDS-DMA instructions per wave that fetch a record
 static_assert(ROW_BUCKET_WORDS * 4 <= 4096, "bucket copy");
+static_assert(V9_FAST_MAX >= 32, "spare LDS for correction vectors");
 
 typedef __bf16 v9_bf16x8 __attribute__((ext_vector_type(8)));
 // (w fragment as the MFMA's A operand, x fragment as its B operand: D[n = 4 (lane / 16) + r][m = lane % 16])
@@ -66,13 +78,17 @@ __device__ __forceinline__ i32x4 v9_desc(const void* base, int bytes) {       //
     return i32x4{(int)(unsigned)b, (int)(unsigned)(b >> 32), bytes, 0x00020000};
 }
 
-// FIX 1: with the exception add-back.  STAMP: diagnostic build, workgroups leave their phase times in a.stamps.
-template <int FIX, bool BF16, bool STAMP>
+// FIX_ 1: with the exception add-back formed by the tile itself behind its K loop; 2: the PRE-PASS -- no product, the tile's
+// vectors and maps are formed and written to its record (a.exc_ws); 3: the product with the add-back read from the record
+// (a tile whose record says it does not fit falls back to 1's path).  STAMP: diagnostic build, phase times go to a.stamps.
+template <int FIX_, bool BF16, bool STAMP>
 __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, const float* __restrict__ sx,
                                                         const float* __restrict__ sw_in, const int* __restrict__ xlist,
                                                         const int* __restrict__ wlist_in, const uint8_t* __restrict__ xf,
                                                         const uint8_t* __restrict__ wf_in) {
-    static_assert(!BF16 || FIX == 0, "the bf16 arithmetic has no exception lists");
+    constexpr int FIX = FIX_ != 0 ? 1 : 0;
+    constexpr bool PRE = FIX_ == 2, REC = FIX_ == 3;
+    static_assert(!BF16 || FIX_ == 0, "the bf16 arithmetic has no exception lists");
     // Two LDS objects: the operand rings (filled by LDS-DMA, read by inline-asm ds_read_b128 only) and everything else.
     // The compiler orders its own LDS reads behind every LDS-DMA that may alias them -- with one array each of its reads
     // in the K loop (the exception service) would drain the operand stream (s_waitcnt vmcnt(0)).
@@ -82,7 +98,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
-    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0}, st_x[3] = {0, 0, 0};
     if (STAMP) st_t[0] = __builtin_amdgcn_s_memrealtime();
 
     GemmArgs a = a_in;
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_GLDS16(sx + m0 + lane * 4, side_lds + V9_SXT);
     } else if (!BF16 && wave == 3) {
         V9_GLDS16(sw + n0 + lane * 4, side_lds + V9_SWT);
-    } else if (wave == 4) {
+    } else if (!PRE && wave == 4) {
         // (bounds-checked by the descriptor: columns past N read as zero, no address past the array is touched)
         if (a.bias) {
             const i32x4 rb = v9_desc(a.bias + n0, (Ni - n0) * 4);
@@ -155,13 +171,17 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     } else if (FIX && (wave == 5 || wave == 6)) {
         V9_GLDS4((wave == 5 ? xlist : wlist) + lane, side_lds + V9_OVF + (wave - 5) * 256);
     }
-    if (FIX) {
-        // (cleared before the bookkeeping of the first K-step writes them; the vectors beside the rings start at zero:
-        //  every product is ADDED to its row's / column's vector)
+    // maps cleared, vectors beside the rings zero (every product is ADDED to its row's / column's vector) -- unless the
+    // tile's record brings them
+    auto clear_maps_and_vectors = [&]() {
         rowslot[tid & 255] = -1;
         if (tid >= 256) colslot[tid & 255] = -1;
-        if (tid < 16) reinterpret_cast<int*>(smem + V9_FLAGS)[tid] = 0;
-    }
+#pragma unroll
+        for (int q = 0; q < (V9_FAST_MAX * 1024 + V9_NT * 16 - 1) / (V9_NT * 16); ++q)
+            if ((q * V9_NT + tid) * 16 < V9_FAST_MAX * 1024)
+                *reinterpret_cast<f32x4*>(smem + V9_CORR + (q * V9_NT + tid) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    if (FIX && !REC) clear_maps_and_vectors();
 
     // ---- the operand stream.  Piece p of a K-step: 16 rows of A (p < 16) or of B; this wave stages pieces wave + 8 q.
     //      One descriptor per operand, rooted at the tile's first piece row and ending with its last (rows past the
@@ -184,99 +204,40 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const i32x4 rxd_ = v9_desc(xbase, more_ ? x_nrec : 0), rwd_ = v9_desc(wbase, more_ ? w_nrec : 0);                   \
     const int soff_ = (step) * 1024;
 #define V9_STAGE(step, sa, sb) { V9_DESCS(step) V9_PIECE(0, rxd_, rwd_, soff_, sa, sb); V9_PIECE(1, rxd_, rwd_, soff_, sa, sb); V9_PIECE(2, rxd_, rwd_, soff_, sa, sb); V9_PIECE(3, rxd_, rwd_, soff_, sa, sb); }
-    V9_STAGE(0, 0, 0)
-    V9_STAGE(1, V9_HALF, V9_HALF)
-    V9_STAGE(2, 2 * V9_HALF, 2 * V9_HALF)
+    if (!PRE) {
+        V9_STAGE(0, 0, 0)
+        V9_STAGE(1, V9_HALF, V9_HALF)
+        V9_STAGE(2, 2 * V9_HALF, 2 * V9_HALF)
+    }
+    const unsigned char* const rec = REC || PRE ? static_cast<const unsigned char*>(a.exc_ws) + (long long)(tm * tiles_n1 + tn) * V9_REC : nullptr;
+    if (REC) {
+        // the tile's record rides BEHIND the first three K-steps (it is needed behind the loop; the first counted waits
+        // leave it in flight): item r = wave + 8 q: the two halves of the maps, the vectors, the header (repeated to pad)
+#pragma unroll
+        for (int q = 0; q < V9_RDMA; ++q) {
+            const int r = wave + V9_NW * q;
+            if (r < 2) { V9_GLDS16(rec + V9_REC_MAPS + r * 1024 + lane * 16, side_lds + V9_MAP + r * 1024); }
+            else if (r < 2 + V9_FAST_MAX) { V9_GLDS16(rec + V9_REC_VEC + (r - 2) * 1024 + lane * 16, side_lds + V9_CORR + (r - 2) * 1024); }
+            else { V9_GLDS4(rec + lane * 4, side_lds + V9_HDR); }
+        }
+    }
     if (STAMP) st_t[1] = __builtin_amdgcn_s_memrealtime();
 
     using acc_t = typename std::conditional<BF16, f32x4, i32x4>::type;
 
-    // ---- exception add-back, the part that rides in the K loop.  Entry i of the tile's combined list (x bucket first, then
-    //      w) belongs to wave i % 8 and to ROUND i / 8; a round = the other operand's 256 blocks at the entry's K position
-    //      gathered by four LDS-DMA quarters into the wave's 4 KiB of scratch (requested behind the MFMAs of one K-step, left
-    //      in flight for two more -- the counted waits make room for them), then, four K-steps later, 256 products kept in
-    //      four REGISTERS per lane (rv[round]) until the loop is over.  All eight waves serve at the same K-steps, so a
-    //      round costs the workgroup one LDS round trip, not one per wave; nothing else about the lists is decided while the
-    //      loop runs.
-    constexpr int V9_ROUNDS = 4;
-    int cx = 0, cw = 0, nent = 0, mode = 0;   // mode 0: no entries, 1: vectors in LDS, 3: more than LDS holds (atomics after the stores)
-    float rv[V9_ROUNDS][4];
-#pragma unroll
-    for (int k = 0; k < V9_ROUNDS; ++k)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rv[k][c] = 0.f;
-    int r_kb[V9_ROUNDS], r_served = 0;        // block of the wave's entry of each round (-1: none / void); rounds consumed
-    int g_age = 0;                            // K-step tops that still keep the gathers in flight
-    const int scr_off = V9_CORR + wave * 4096;                              // this wave's scratch (side area)
-    const int glane = (lane >> 4) * (int)row_bytes + (lane & 15) * 16;     // row `lane` of a quarter inside the tile's piece rows
-    const i32x4 xg = v9_desc(a.xm + (long long)(m0 >> 4) * row_bytes, x_nrec), wg = v9_desc(a.wm + (long long)(n0 >> 4) * row_bytes, w_nrec);
-    // (entry i is live when its row / column lies inside the tile and the operand)
-    auto live_entry = [&](int i, int r) { return i < cx ? (r >= m0 && r < m0 + 256 && r < Mi) : (r >= n0 && r < n0 + 256 && r < Ni); };
-    // the lists' counts and the blocks of this wave's entries of all rounds: one LDS round trip, K-step 2
-    auto rounds_setup = [&]() {
-        cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
-        cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
-        nent = cx + cw;
-        mode = nent == 0 ? 0 : (nent <= V9_STAGES / 1024 ? 1 : 3);
-#pragma unroll
-        for (int k = 0; k < V9_ROUNDS; ++k) {
-            const int i = wave + 8 * k;
-            r_kb[k] = -1;
-            if (mode == 1 && i < nent) {
-                const int* e = v8_entry(xb, wb, cx, i);
-                const int r = __builtin_amdgcn_readfirstlane(e[0]), kb = __builtin_amdgcn_readfirstlane(e[1]);
-                if (live_entry(i, r) && !(a.dbg & 8)) r_kb[k] = kb;      // (dbg 8 / 16, diagnostic: no rounds / no products in the loop)
-            }
-        }
-    };
-    // request the blocks of entry i (block kb): rows past the operand read as zero
-    auto gather = [&](int i, int kb) {
-        const int koff = __builtin_amdgcn_readfirstlane((kb >> 2) * 1024 + (kb & 3) * 256);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int vo = glane + c * 4 * (int)row_bytes, dl = side_lds + scr_off + c * 1024;
-            if (i < cx) { V9_BLDS16(vo, wg, koff, dl); } else { V9_BLDS16(vo, xg, koff, dl); }
-        }
-    };
-    // entry i: 256 products (tile columns / rows c * 64 + lane) from the blocks in the scratch; its slot (the smallest list
-    // index with the same tile row / column, -2 on a void entry) goes to word 3 of its LDS copy, the first entry of a row /
-    // column also to the row / column map
-    int* multi = reinterpret_cast<int*>(smem + V9_FLAGS) + 4;   // set when some row / column has more than one entry
-    auto products = [&](int i, float (&out)[4]) {
-        const bool is_x = i < cx;
-        int* e = v8_entry(xb, wb, cx, i);
-        const int4 h = *reinterpret_cast<const int4*>(e), pv = *reinterpret_cast<const int4*>(e + 4);
-        const int lo = is_x ? 0 : cx, cnt = is_x ? cx : cw;
-        const int r0 = lane < cnt ? v8_entry(xb, wb, cx, lo + lane)[0] : -3, r1 = lane + 64 < cnt ? v8_entry(xb, wb, cx, lo + lane + 64)[0] : -3;
-        const float* sc = is_x ? swt : sxt;
-        float scl[4];
-        int4 q[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            q[c] = *reinterpret_cast<const int4*>(side + scr_off + c * 1024 + lane * 16);
-            scl[c] = sc[c * 64 + lane];
-        }
-        const int sh = h.z - (is_x ? +a.x_off : +a.w_off);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) out[c] = __builtin_ldexpf((float)dot16(pv, q[c]), sh) * scl[c];
-        const unsigned long long m0b = __ballot(r0 == h.x), m1b = __ballot(r1 == h.x);
-        const int slot = lo + (m0b ? __builtin_ctzll(m0b) : 64 + __builtin_ctzll(m1b));
-        if (lane == 0) {
-            e[3] = slot;
-            if (slot == i) (is_x ? rowslot : colslot)[h.x - (is_x ? m0 : n0)] = i; else *multi = 1;
-        }
-    };
+    int cx = 0, cw = 0, nent = 0, mode = 0;   // exception entries of this tile (set behind the K loop)
 
     // lane-constant part of the fragment addresses; fragment i is i KiB further (immediate offset)
     const int va = ring_lds + piece_lds_off(wm * 128 + l16, lq), vb = ring_lds + V9_B0 + piece_lds_off(wn * 64 + l16, lq);
     i32x4 fa[4], fb0[4], fb1[4];
-    V9_WAITV(8);                                                // everything but the pieces of K-steps 1 and 2
+    if (PRE) V9_WAITV(0); else if (REC) V9_WAITV(8 + V9_RDMA); else V9_WAITV(8);      // everything but the pieces of K-steps 1 and 2 (and the record)
     __builtin_amdgcn_s_barrier();
     if (FIX) {
         // a bucket overflowed somewhere (uniform over the grid): the row-scale product does not apply; the workgroups of
         // this launch share the blockwise-exact product instead (the operand loads in flight land in LDS only)
         const int* ovf = reinterpret_cast<const int*>(smem + V9_OVF);
         if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
+            if (PRE) return;                                    // (the product launch takes its blockwise path by itself)
             V9_WAITV(0);
             __syncthreads();
             v8_fallback(a, xf, wf, xlist, wlist, ring, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
@@ -284,8 +245,10 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             return;
         }
     }
-    V9_DSR(fb0[0], vb, 0); V9_DSR(fb0[1], vb, 1024); V9_DSR(fb0[2], vb, 2048); V9_DSR(fb0[3], vb, 3072);
-    V9_DSR(fa[0], va, 0); V9_DSR(fa[1], va, 1024);
+    if (!PRE) {
+        V9_DSR(fb0[0], vb, 0); V9_DSR(fb0[1], vb, 1024); V9_DSR(fb0[2], vb, 2048); V9_DSR(fb0[3], vb, 3072);
+        V9_DSR(fa[0], va, 0); V9_DSR(fa[1], va, 1024);
+    }
     V9_SB();
     acc_t acc[8][4];
 #pragma unroll
@@ -300,20 +263,10 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // of step t + 1) and the counted wait for fragment i; the read of B fragment i - 2 of step t + 1 (groups 2-5); LDS-DMA
     // piece i of step t + 3 (groups 0-3).  At barrier(t) every wave has waited for its own pieces of step t + 1 and has
     // retired every read of the A half of step t - 1 and of the B half of step t: those are the slots step t + 3 goes to.
-    auto body = [&](i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db, const bool hooks) {
+    auto body = [&](i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db, const bool first2) {
         V9_LGKM(2);                                             // (the B reads of the slot about to be refilled)
-        if (FIX && g_age > 0) { V9_WAITV(8); --g_age; } else { V9_WAITV(4); }      // (gathers of a round stay in flight)
+        if (REC && first2) V9_WAITV(4 + V9_RDMA); else V9_WAITV(4);          // (K-steps 0 and 1: the record stays in flight)
         __builtin_amdgcn_s_barrier();
-        if (FIX && hooks && t >= 2 && (t & 3) == 2 && (t >> 3) < V9_ROUNDS) {
-            // K-steps 2, 10, 18, 26: round (t - 2) / 8 is requested behind this step's MFMAs; 6, 14, 22, 30: consumed here
-            if (t == 2) rounds_setup();
-#define V9_CONSUME(k) if (t == 6 + 8 * (k) && r_kb[k] >= 0 && !(a.dbg & 16)) products(wave + 8 * (k), rv[k]);
-            V9_CONSUME(0) V9_CONSUME(1) V9_CONSUME(2) V9_CONSUME(3)
-#undef V9_CONSUME
-            if ((t & 7) == 6 && !(a.dbg & 16)) r_served = (t >> 3) + 1;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0), builtin form: the compiler's scoreboard is clean
-            V9_SB();
-        }
         const int ac = va + sa_c, an = va + sa_n, bn = vb + sb_n;
         V9_DESCS(t + 3)
 #define V9_GROUP(i, wait)                                                                                                \
@@ -332,25 +285,27 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_SB();                                                                                                         \
         acc[i][3] = v9_mma(fb[3], fa[i & 3], acc[i][3]);                                                                 \
         V9_SB();
-        V9_GROUP(0, 2) V9_GROUP(1, 2) V9_GROUP(2, 2) V9_GROUP(3, 3) V9_GROUP(4, 4) V9_GROUP(5, 4) V9_GROUP(6, 4) V9_GROUP(7, 3)
-        if (FIX && hooks && t >= 2 && (t & 7) == 2 && (t >> 3) < V9_ROUNDS) {
-#define V9_REQUEST(k) if (t == 2 + 8 * (k) && r_kb[k] >= 0) { gather(wave + 8 * (k), r_kb[k]); g_age = 2; }
-            V9_REQUEST(0) V9_REQUEST(1) V9_REQUEST(2) V9_REQUEST(3)
-#undef V9_REQUEST
-            V9_SB();
-        }
+        V9_GROUP(0, 2) V9_GROUP(1, 2) V9_GROUP(2, 2) V9_GROUP(3, 3)
+        V9_GROUP(4, 4) V9_GROUP(5, 4) V9_GROUP(6, 4) V9_GROUP(7, 3)
     };
     // ring positions (byte offsets): A half of step t in a0, t + 1 in a1, ..., the slot step t + 3 goes to in a3;
     // B half of step t + 1 in b1, the slot step t + 3 goes to (= where step t's B half was) in b0
     int a0 = 0, a1 = V9_HALF, a2 = 2 * V9_HALF, a3 = 3 * V9_HALF, b0 = 0, b1 = V9_HALF, b2 = 2 * V9_HALF;
-    for (int t = 0; t < nsteps; t += 2) {                       // (nsteps is even: K % 128 == 0, even slices)
-        body(fb0, fb1, t, a0, a1, b1, a3, b0, true);
-        { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }
-        { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
-        body(fb1, fb0, t + 1, a0, a1, b1, a3, b0, false);
-        { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }
-        { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
+    // (the first two K-steps apart: their counted waits differ when a record is in flight)
+#define V9_PAIR(t_, f2)                                                                                                  \
+    body(fb0, fb1, t_, a0, a1, b1, a3, b0, f2);                                                                          \
+    { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
+    { const int o = b0; b0 = b1; b1 = b2; b2 = o; }                                                                      \
+    body(fb1, fb0, (t_) + 1, a0, a1, b1, a3, b0, f2);                                                                    \
+    { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
+    { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
+    if (!PRE) {
+        if (REC) { V9_PAIR(0, true) }
+        for (int t = REC ? 2 : 0; t < nsteps; t += 2) {         // (nsteps is even: K % 128 == 0, even slices)
+            V9_PAIR(t, false)
+        }
     }
+#undef V9_PAIR
     V9_WAITV(0);
     V9_LGKM(0);                                                 // (the compiler does not know these reads are in flight)
     V9_SB();
@@ -415,92 +370,116 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     //      the entries while the K loop runs -- by gathers into scratch, or picking the blocks up from the operand rings
     //      as they stream by: every served entry stalls one wave for an LDS round trip and with it, at the next barrier,
     //      the workgroup; and storing the untouched tiles while the gathers fly: the gathers queue behind the stores.)
-#define V9_VEC(s_) (reinterpret_cast<float*>(ring) + (s_) * 256)        // vector of list entry s_ (ring area, free now)
+    float* const rvec = reinterpret_cast<float*>(ring) + (V9_GSCR - V9_FAST_MAX * 1024) / 4;   // (vector of slot s >= V9_FAST_MAX)
+#define V9_VEC(s_) (((s_) < V9_FAST_MAX ? corr : rvec) + (s_) * 256)
     bool look = false;
-    if (FIX && mode == 1) {
-        // (a) the rounds' products leave the registers
-#define V9_FLUSH(k)                                                                                                      \
-        if ((k) < r_served && wave + 8 * (k) < nent) {                                                                   \
-            if (r_kb[k] >= 0) {                                                                                          \
-                float* v = V9_VEC(wave + 8 * (k)) + lane;                                                                \
-                v[0] = rv[k][0]; v[64] = rv[k][1]; v[128] = rv[k][2]; v[192] = rv[k][3];                                 \
-            } else if (lane == 0) v8_entry(xb, wb, cx, wave + 8 * (k))[3] = -2;                                          \
-        }
-        V9_FLUSH(0) V9_FLUSH(1) V9_FLUSH(2) V9_FLUSH(3)
-#undef V9_FLUSH
-        // (b) entries the loop did not get to (more than 8 x V9_ROUNDS, or a short K): one at a time, the round trip exposed
-        for (int i = wave + 8 * r_served; i < nent; i += V9_NW) {             // uniform
-            int* e = v8_entry(xb, wb, cx, i);
-            const int r = __builtin_amdgcn_readfirstlane(e[0]), kb = __builtin_amdgcn_readfirstlane(e[1]);
-            if (!live_entry(i, r)) { if (lane == 0) e[3] = -2; continue; }
-            V9_LGKM(0);                                         // (this wave's reads of its scratch have returned)
-            gather(i, kb);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            float out[4];
-            products(i, out);
-            float* v = V9_VEC(i) + lane;
-            v[0] = out[0]; v[64] = out[1]; v[128] = out[2]; v[192] = out[3];
-        }
-        // (c) x entries: the exception x exception terms (same K position in both lists), into the entry's own vector
-        if (cw > 0)
-            for (int i = wave; i < cx; i += V9_NW) {            // uniform
-                const int* e = v8_entry(xb, wb, cx, i);
-                const int r = __builtin_amdgcn_readfirstlane(e[0]);
-                if (!live_entry(i, r)) continue;
-                const int kb = e[1], code = e[2];
-                const int4 pv = *reinterpret_cast<const int4*>(e + 4);
-                float* v = V9_VEC(i);
-                for (int f0 = 0; f0 < cw; f0 += 64) {           // uniform
-                    const int fi = f0 + lane;
-                    if (fi < cw) {
-                        const int* f = wb + EXC_HEADER + EXC_ENTRY * fi;
-                        const int n = f[0];
-                        if (n >= n0 && n < n0 + 256 && n < Ni && f[1] == kb) {
-                            const int d = dot16(pv, *reinterpret_cast<const int4*>(f + 4));
-                            v[n - n0] += __builtin_ldexpf((float)d, code + f[2] - a.scale_bias);
-                        }
-                    }
-                }
+    int mykeys[2] = {0x7fffffff, 0x7fffffff};                   // (slot << 18 | block << 8 | index) of the entries at list
+                                                                // positions lane, lane + 64 that this wave serves
+    bool have = false;                                          // the tile's record holds maps and vectors
+    if (FIX) {
+        cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+        cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
+        nent = cx + cw;
+        mode = nent == 0 ? 0 : (nent <= min(128, V9_FAST_MAX + V9_SLOW_MAX) ? 1 : 3);
+        if (REC) {
+            const int* hdr = reinterpret_cast<const int*>(smem + V9_HDR);
+            if (__builtin_amdgcn_readfirstlane(hdr[2]) == 0) {
+                have = true;
+                look = mode == 1 && !(a.dbg & 2);
+            } else {                                            // (does not fit a record: formed here after all)
+                __builtin_amdgcn_s_barrier();
+                clear_maps_and_vectors();
+                V9_LGKM(0);
+                __builtin_amdgcn_s_barrier();
             }
-        V9_LGKM(0);
-        __builtin_amdgcn_s_barrier();
-        // (d) rows / columns with several entries (uncommon): their vectors summed into the first entry's, in ascending
-        //     (block, index) order -- by the wave slot % 8, one row at a time: reproducible
-        if (__builtin_amdgcn_readfirstlane(*multi) != 0) {
-            for (int s0 = wave; s0 < nent; s0 += V9_NW) {       // uniform
-                if (__builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, s0)[3]) != s0) continue;
-                int k0 = 0x7fffffff, k1 = 0x7fffffff;
-                if (lane < nent) { const int* f = v8_entry(xb, wb, cx, lane); if (f[3] == s0) k0 = (f[1] << 8) | lane; }
-                if (lane + 64 < nent) { const int* f = v8_entry(xb, wb, cx, lane + 64); if (f[3] == s0) k1 = (f[1] << 8) | (lane + 64); }
-                if (__builtin_popcountll(__ballot(k0 != 0x7fffffff)) + __builtin_popcountll(__ballot(k1 != 0x7fffffff)) < 2) continue;
-                float sum[4] = {0.f, 0.f, 0.f, 0.f};
-                int last = -1;
-                for (;;) {
-                    int best = k0 > last ? k0 : 0x7fffffff;
-                    if (k1 > last) best = min(best, k1);
+        }
+        if (mode && !have) {                                    // (uniform over the workgroup: the barrier below is met by all)
+            // (1) 16 lanes share an entry: slot = the smallest list index with the same tile row / column; -2 marks a void
+            //     entry (also for the atomics pass of mode 3); rows / columns without a vector keep -1 in the maps
+            for (int i0 = 0; i0 < nent; i0 += V9_NT / 16) {    // uniform
+                const int i = i0 + (tid >> 4), sub = tid & 15;
+                const bool valid = i < nent, is_x = i < cx;
+                int* e = v8_entry(xb, wb, cx, valid ? i : 0);
+                const int r = e[0], base = is_x ? m0 : n0;
+                const bool live = valid && (is_x ? (r >= m0 && r < m0 + 256 && r < Mi) : (r >= n0 && r < n0 + 256 && r < Ni));
+                const int lo = is_x ? 0 : cx, hi = is_x ? cx : nent;
+                int slot = i;
+                if (live)
+                    for (int j = lo + sub; j < hi; j += 16)
+                        if (v8_entry(xb, wb, cx, j)[0] == r) slot = min(slot, j);
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) best = min(best, __shfl_xor(best, o));
-                    best = __builtin_amdgcn_readfirstlane(best);
-                    if (best == 0x7fffffff) break;
-                    last = best;
-                    const float* v = V9_VEC(best & 255) + lane;
-                    sum[0] += v[0]; sum[1] += v[64]; sum[2] += v[128]; sum[3] += v[192];
+                for (int o = 1; o < 16; o <<= 1) slot = min(slot, __shfl_xor(slot, o));
+                if (valid && sub == 0) {
+                    e[3] = live ? slot : -2;
+                    if (live && slot == i) (is_x ? rowslot : colslot)[r - base] = i;
                 }
-                float* v = V9_VEC(s0) + lane;
-                v[0] = sum[0]; v[64] = sum[1]; v[128] = sum[2]; v[192] = sum[3];
             }
             V9_LGKM(0);
             __builtin_amdgcn_s_barrier();
+            look = mode == 1 && !(a.dbg & 2);                   // (dbg 2, diagnostic: no add-back, results invalid)
+            if (STAMP) st_x[0] = __builtin_amdgcn_s_memrealtime();
         }
-        look = !(a.dbg & 2);                                    // (dbg 2, diagnostic: no add-back, results invalid)
-    } else if (FIX && mode == 3) {
-        // (the atomics pass after the stores skips entries marked void)
-        for (int i = tid; i < nent; i += V9_NT) {
-            int* e = v8_entry(xb, wb, cx, i);
-            e[3] = live_entry(i, e[0]) ? 0 : -2;
+    }
+    // gathers of one entry: the other operand's 16-byte blocks at the entry's K position for the tile's 256 rows / columns,
+    // four LDS-DMA quarters (rows past the operand read as zero) into 4 KiB of this wave's scratch
+    const int glane = (lane >> 4) * (int)row_bytes + (lane & 15) * 16;     // row `lane` of a quarter inside the tile's piece rows
+    const i32x4 xg = v9_desc(a.xm + (long long)(m0 >> 4) * row_bytes, x_nrec), wg = v9_desc(a.wm + (long long)(n0 >> 4) * row_bytes, w_nrec);
+    auto gather = [&](int i, int b) {
+        const int kb = __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, i)[1]);
+        const int koff = (kb >> 2) * 1024 + (kb & 3) * 256;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int vo = glane + c * 4 * (int)row_bytes, dl = ring_lds + (wave * V9_NB_ENT + b) * 4096 + c * 1024;
+            if (i < cx) { V9_BLDS16(vo, wg, koff, dl); } else { V9_BLDS16(vo, xg, koff, dl); }
         }
-        V9_LGKM(0);
-        __builtin_amdgcn_s_barrier();
+    };
+    // one entry: multiply, add to its slot's vector (`first`: the vector is in the ring area and this is its first
+    // entry); an x entry also takes the exception x exception terms (same K position in both lists)
+    auto finish = [&](int i, int b, int slot, bool first) {
+        const bool is_x = i < cx;
+        const int* e = v8_entry(xb, wb, cx, i);
+        const int kb = e[1], code = e[2];
+        const int4 pv = *reinterpret_cast<const int4*>(e + 4);
+        const int sh = code - (is_x ? +a.x_off : +a.w_off);
+        const float* sc = is_x ? swt : sxt;
+        float* v = V9_VEC(slot);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int4 q = *reinterpret_cast<const int4*>(ring + (wave * V9_NB_ENT + b) * 4096 + c * 1024 + lane * 16);
+            const float p = __builtin_ldexpf((float)dot16(pv, q), sh) * sc[c * 64 + lane];
+            v[c * 64 + lane] = first ? p : v[c * 64 + lane] + p;
+        }
+        if (is_x)
+            for (int f0 = 0; f0 < cw; f0 += 64) {               // uniform
+                const int fi = f0 + lane;
+                if (fi < cw) {
+                    const int* f = wb + EXC_HEADER + EXC_ENTRY * fi;
+                    if (f[3] != -2 && f[1] == kb) {
+                        const int d = dot16(pv, *reinterpret_cast<const int4*>(f + 4));
+                        v[f[0] - n0] += __builtin_ldexpf((float)d, code + f[2] - a.scale_bias);
+                    }
+                }
+            }
+    };
+    // the wave's next entry: the smallest key above `last` among the two this lane holds, over the wave
+    auto next_key = [&](int last) {
+        int best = mykeys[0] > last ? mykeys[0] : 0x7fffffff;
+        if (mykeys[1] > last) best = min(best, mykeys[1]);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) best = min(best, __shfl_xor(best, o));
+        return __builtin_amdgcn_readfirstlane(best);
+    };
+    if (look && !have) {
+        // (2) this wave's entries
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < nent) {
+                const int* f = v8_entry(xb, wb, cx, j);
+                const int s3 = f[3];
+                if (s3 != -2 && (s3 & 7) == wave) mykeys[q] = (s3 << 18) | (f[1] << 8) | j;
+            }
+        }
     }
     // (masks only -- scales, bias and slots are read again where they are used: the accumulators take half the registers)
     unsigned cmask = 0, jmask = 0;      // bit 4 j + r: some lane of the wave has a vector for that column; bit j: tile column j has one
@@ -567,6 +546,45 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             V9_SB();        // (tile by tile: the scheduler would otherwise pull the reads of many tiles ahead and spill)
         }
     };
+    // (2), (3): batches of this wave's entries -- blocks requested (one round trip, exposed: the stores of the whole chip
+    // start together behind it, and a gather issued beside them would queue behind the compute unit's own stores), vectors
+    // formed; a second batch is rare
+    int lastkey = -1, lastslot = -1;
+    bool more = look && !have;
+    while (more) {
+        int bkey[V9_NB_ENT];
+#pragma unroll
+        for (int b = 0; b < V9_NB_ENT; ++b) {
+            bkey[b] = next_key(lastkey);
+            if (bkey[b] != 0x7fffffff) { lastkey = bkey[b]; gather(bkey[b] & 255, b); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < V9_NB_ENT; ++b)
+            if (bkey[b] != 0x7fffffff) {
+                const int slot = bkey[b] >> 18;
+                finish(bkey[b] & 255, b, slot, slot >= V9_FAST_MAX && slot != lastslot);
+                lastslot = slot;
+            }
+        V9_LGKM(0);                                             // (this wave's reads of its scratch have returned)
+        more = bkey[V9_NB_ENT - 1] != 0x7fffffff;
+    }
+    if (STAMP) st_x[2] = __builtin_amdgcn_s_memrealtime();
+    if (look && !have) __builtin_amdgcn_s_barrier();
+    if (PRE) {
+        // the tile's record: header, then the maps and the vectors as they lie in LDS (a tile with more entries than fit
+        // beside the rings, or with too many for LDS at all, is marked: the product launch then forms its add-back itself)
+        unsigned char* out = const_cast<unsigned char*>(rec);
+        if (tid == 0) {
+            int* h = reinterpret_cast<int*>(out);
+            h[0] = nent; h[1] = mode; h[2] = (mode == 3 || nent > V9_FAST_MAX) ? 1 : 0; h[3] = 0;
+        }
+        const int nbytes = 2048 + min(nent, V9_FAST_MAX) * 1024;
+        for (int off = tid * 16; off < nbytes; off += V9_NT * 16)
+            *reinterpret_cast<f32x4*>(out + V9_REC_MAPS + off) =
+                *reinterpret_cast<const f32x4*>(off < 2048 ? smem + V9_MAP + off : smem + V9_CORR + (off - 2048));
+        return;
+    }
     if (STAMP) st_t[4] = __builtin_amdgcn_s_memrealtime();
     // (4) the stores: fragment by fragment, first its tiles that no vector touches, then the others
 #pragma unroll
@@ -582,6 +600,8 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             for (int q = 0; q < 6; ++q) d[q] = st_t[q];
             d[6] = c_loop;
             d[7] = ((unsigned long long)(unsigned)nent << 32) | (unsigned)mode;
+            // (the post-loop phases, x 10 ns, 12 bits each, instead of the stage-request stamp: bookkeeping, first-pass stores, vectors)
+            d[1] = ((st_x[0] - st_t[3]) & 0xfff) | (((st_x[1] - st_x[0]) & 0xfff) << 12) | (((st_x[2] - st_x[1]) & 0xfff) << 24);
         }
     }
     if (FIX && mode == 3) {
@@ -595,18 +615,60 @@ static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/v9_
 
 // 256 x 256 tiles, K % 128 == 0 (even slices under split-K).  Returns -1000 when the shape is not this kernel's
 // (the caller then launches the v8 kernel).
+// the tiles' exception records: library-owned, one buffer per (device, stream), grow-only, never (re)allocated while the
+// stream is capturing a graph (the product launch then forms its add-back itself)
+static void* exc_workspace(hipStream_t st, size_t bytes) {
+    struct Ws { void* p = nullptr; size_t n = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Ws> all;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Ws& w = all[{dev, st}];
+    if (w.n < bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+        if (w.p) (void)hipFree(w.p);                      // (synchronises: nothing of this buffer is in flight after)
+        w.p = nullptr;
+        w.n = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc(&w.p, want) != hipSuccess) return nullptr;
+        w.n = want;
+    }
+    return w.p;
+}
+
+// 256 x 256 tiles, K % 128 == 0, at least four K-steps per slice (even slices under split-K).
 int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        hipStream_t st, const uint8_t* xf, const uint8_t* wf, bool bf16) {
     GemmArgs a = a_in;
     static const bool want_stamps = getenv("MI355Q_V9_STAMPS") != nullptr;
+    // default: the product launch forms the exception add-back itself (one launch, the add-back exposed behind its K loop);
+    // MI355Q_V9_PREPASS=1: a pre-pass launch forms every tile's vectors and maps, the product launch reads them back (the
+    // product launch is then 58-60 us at 4096^3 instead of 66, but the pre-pass and its launch boundary cost 13-15:
+    // profiles/r03_v9_exception_designs.txt, design G)
+    static const int prepass = getenv("MI355Q_V9_PREPASS") ? atoi(getenv("MI355Q_V9_PREPASS")) : 0;
     if (want_stamps) a.stamps = g_v9_stamps;
     const bool fix = xlist && wlist;
     if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
-    const unsigned grid = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256) * (a.ngroup > 1 ? a.ngroup : 1) * (a.splits > 1 ? a.splits : 1));
+    const unsigned tiles = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256));
+    const unsigned grid = tiles * (a.ngroup > 1 ? a.ngroup : 1) * (a.splits > 1 ? a.splits : 1);
+    a.exc_ws = nullptr;
     if (bf16) hipLaunchKernelGGL((bfp_gemm_v9<0, true, false>), grid, V9_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (fix && want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<1, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-    else if (fix) hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-    else hipLaunchKernelGGL((bfp_gemm_v9<0, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (!fix) hipLaunchKernelGGL((bfp_gemm_v9<0, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else {
+        void* ws = prepass && a.ngroup <= 1 ? exc_workspace(st, (size_t)tiles * V9_REC) : nullptr;
+        if (ws) {
+            GemmArgs p = a;
+            p.splits = 1;
+            p.exc_ws = ws;
+            hipLaunchKernelGGL((bfp_gemm_v9<2, false, false>), tiles, V9_NT, 0, st, p, sx, sw, xlist, wlist, xf, wf);
+            a.exc_ws = ws;
+            if (want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<3, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+            else hipLaunchKernelGGL((bfp_gemm_v9<3, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+        } else if (want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<1, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+        else hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    }
     return (int)hipGetLastError();
 }
 
