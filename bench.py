@@ -89,6 +89,51 @@ def cpu_baseline(torch):
             "sample": f"full 4096x4096x4096 steady-state PTQ linear (fake-quant x + fp32 F.linear), median of {iters} iterations"}
 
 
+def cpu_baseline_config5(torch):
+    """BASELINE config 5's CPU side: the reference's block_minifloat / block_log fake-quantisers (torch-op-order ports,
+    oracle/torch_port.py) on this box's host cores at [4096, 4096] fp32 -- what BASELINE.md section 2 quotes (870 / 185 ms
+    per call on 8 cores in the survey container).  A few calls each, bounded to some seconds."""
+    from oracle import torch_port as P
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(min(cores, 32))
+    x = torch.randn(4096, 4096, generator=torch.Generator().manual_seed(7)) * 4.0
+    out = {"cores": torch.get_num_threads(), "kind": "port", "shape": "[4096, 4096] fp32, block [1,16]", "unit": "GB/s at 8 B per element"}
+    for name, fn in (("block_minifloat_w8e4", lambda: P.block_minifloat_quantize(x, 8, 4, 8, [1, 16], True)),
+                     ("block_log_w8", lambda: P.block_log_quantize(x, 8, 8, [1, 16], True))):
+        fn()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out[name] = {"ms": round(ts[1] * 1e3, 1), "GB/s": round(8.0 * x.numel() / ts[1] / 1e9, 2)}
+    return out
+
+
+def config5_summary(torch, ops, args, device, with_cpu):
+    """BASELINE config 5 inside the default line: the `--workload quantizers` cases at a short step count, condensed
+    (aggregate and slowest case, fractions of the 8 TB/s figure and of a device copy of the same tensor), with the CPU
+    side beside them.  Runs outside the timed region of the headline metric."""
+    class A:
+        pass
+    q = A()
+    q.steps, q.warmup, q.clock_ramp_ms = 30, 5, 0.0            # (the GPU is at its working clocks already)
+    r = quantizer_workload(torch, ops, q, device)
+    worst = min(r["cases"], key=lambda c: c["GB/s"])
+    per = {}
+    for c in r["cases"]:
+        d = per.setdefault(c["quantizer"], {"min_GB/s": 1e30, "max_GB/s": 0.0})
+        d["min_GB/s"] = min(d["min_GB/s"], c["GB/s"]); d["max_GB/s"] = max(d["max_GB/s"], c["GB/s"])
+    out = {"metric": r["metric"], "aggregate_GB/s": r["value"], "aggregate_frac_of_8TBs": round(r["value"] / HBM_PEAK_GBS, 3),
+           "worst_case": {k: worst[k] for k in ("quantizer", "shape", "us", "GB/s", "frac_of_8TBs", "copy_GB/s", "frac_of_copy")},
+           "per_quantizer": per, "cases": len(r["cases"]), "steps": q.steps,
+           "shapes": "act[2048,4096], act[2048,11008], probs / causal_probs[32,2048,2048], w[4096,4096], w[11008,4096]"}
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline_config5(torch)
+    return out
+
+
 def verify(torch, ops, x, w, b, y, rows=64):
     """Outside the timed region: (1) the activation quantiser's shared exponents and mantissas at the FULL
     4096 x 4096 size, bit for bit against the oracle (BASELINE config 2); (2) `rows` sampled rows x all columns of
@@ -113,7 +158,7 @@ def verify(torch, ops, x, w, b, y, rows=64):
 def committed_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (counters cannot be read inside a timed
     run: one counter per rocprofv3 pass over tools/cdriver/step_driver, which runs the same step through the C ABI)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(ROOT / "profiles" / name) as f:
                 return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]), name
@@ -232,6 +277,7 @@ def main():
                     help="un-timed launches of the step for this long before the warm-up steps (GPU clock ramp; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed step's output")
+    ap.add_argument("--no-config5", action="store_true", help="leave the fake-quantiser summary (BASELINE config 5) out of the line")
     ap.add_argument("--variant", type=int, default=0, help="GEMM kernel variant (0 = automatic)")
     ap.add_argument("--align", choices=["rows", "groups"], default="rows",
                     help="exponent alignment of the packed operands: whole rows (row-scale int8 GEMM) or 256-value groups")
@@ -306,6 +352,15 @@ def main():
 
     step, x, w, b, y = build(sharded, 0 if sharded or world == 1 else rank)
     ops.gemm_timing(False)
+    # the literal protocol first -- W warm-up steps, K timed steps, straight from the idle GPU (the clocks are still rising:
+    # reported as `no_ramp`); then the clock ramp and the steady-state figure the line's `value` carries
+    no_ramp = None
+    if args.clock_ramp_ms > 0:
+        ops.gemm_timing(True)
+        dt0 = timed(torch, dist, world, device, step, args.steps, args.warmup)
+        ops.gemm_timing(False)
+        n0, g0_avg, _ = ops.gemm_timing_read()
+        no_ramp = (dt0, g0_avg)
     clock_ramp(torch, step, args.clock_ramp_ms)
     for _ in range(args.warmup):
         step()
@@ -359,6 +414,12 @@ def main():
                                             "measured by this run") if traffic else None,
                          "avg_launch_ms": round(gemm_avg_ms, 4), "min_launch_ms": round(gemm_min_ms, 4), "launches_timed": n_timed},
         }
+        if no_ramp:
+            jobf = 2.0 * M * N * K * (1 if sharded or world == 1 else world)
+            out["no_ramp"] = {"value": round(jobf * args.steps / no_ramp[0] / 1e12, 2), "unit": "TFLOP/s",
+                              "ms_per_step": round(no_ramp[0] / args.steps * 1e3, 4),
+                              "roofline_frac": round(flops_kernel / (no_ramp[1] * 1e-3) / 1e12 / INT8_DENSE_PEAK_TFLOPS, 4),
+                              "what": f"{args.warmup} warm-up + {args.steps} timed steps straight from an idle GPU, before the clock ramp"}
         if replicas:
             out["replicas"] = replicas
         if rows_mode:
@@ -382,6 +443,8 @@ def main():
             failed = not out["verify"]["ok"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch)
+        if world == 1 and not args.no_config5:
+            out["config5"] = config5_summary(torch, ops, args, device, not args.no_cpu_baseline)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
     if world > 1 or force_dist:

@@ -32,6 +32,7 @@
 #include <mutex>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "mi355q_gemm_tile.h"
 
@@ -654,22 +655,38 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
 
 // ---- split-K workspace: raw accumulator slabs + one ticket per tile, owned by the library, one per (device, stream),
 //      grow-only; tickets are zero whenever no launch is in flight (the reducer of a tile clears its ticket).
+//      Under stream capture (a HIP graph being recorded) nothing is allocated or freed: a shape that needs growth then
+//      gets no workspace (null: the caller launches unsplit), and a workspace that a capture has been handed is never
+//      freed afterwards -- an instantiated graph keeps its pointers -- growth retires the old buffers instead.
 SplitWorkspace* split_workspace(hipStream_t st, size_t slab_bytes, int ntickets) {
+    struct Owned { SplitWorkspace w; bool in_graph = false; };
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, SplitWorkspace> all;
+    static std::map<std::pair<int, hipStream_t>, Owned> all;
+    static std::vector<void*> retired;                     // (buffers a recorded graph may still use: kept for good)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     std::lock_guard<std::mutex> lock(mu);
-    SplitWorkspace& w = all[{dev, st}];
+    Owned& o = all[{dev, st}];
+    SplitWorkspace& w = o.w;
+    const bool grow = w.slab_bytes < slab_bytes || w.ntickets < ntickets;
+    if (grow && capturing) return nullptr;
     if (w.slab_bytes < slab_bytes) {
-        if (w.slabs) (void)hipFree(w.slabs);              // (synchronises: nothing of this workspace is in flight after)
+        if (w.slabs) {
+            if (o.in_graph) retired.push_back(w.slabs);
+            else (void)hipFree(w.slabs);                  // (synchronises: nothing of this workspace is in flight after)
+        }
         w.slabs = nullptr;
         w.slab_bytes = 0;
         if (hipMalloc(&w.slabs, slab_bytes) != hipSuccess) return nullptr;
         w.slab_bytes = slab_bytes;
     }
     if (w.ntickets < ntickets) {
-        if (w.tickets) (void)hipFree(w.tickets);
+        if (w.tickets) {
+            if (o.in_graph) retired.push_back(w.tickets);
+            else (void)hipFree(w.tickets);
+        }
         w.tickets = nullptr;
         w.ntickets = 0;
         const int n = (ntickets + 1023) / 1024 * 1024;
@@ -677,6 +694,8 @@ SplitWorkspace* split_workspace(hipStream_t st, size_t slab_bytes, int ntickets)
         if (hipMemsetAsync(w.tickets, 0, (size_t)n * 4, st) != hipSuccess) return nullptr;
         w.ntickets = n;
     }
+    if (grow) o.in_graph = false;                          // (fresh buffers: no graph knows them yet)
+    if (capturing) o.in_graph = true;
     return &w;
 }
 // slices per tile for an under-filled grid: the largest S with tiles * S <= 256 (one workgroup per compute unit), whole
@@ -720,11 +739,12 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
         a.splits = 1;
         if (S > 1) {
             SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * (small ? 128 : 256) * 256 * 4, (int)tiles);
-            if (!w) return (int)hipErrorOutOfMemory;
-            a.splits = S;
-            a.slabs = w->slabs;
-            a.tickets = w->tickets;
-            tiles *= S;
+            if (w) {                                       // (none -- growth under graph capture, or no memory: unsplit)
+                a.splits = S;
+                a.slabs = w->slabs;
+                a.tickets = w->tickets;
+                tiles *= S;
+            }
         }
     }
     // diagnostic builds: MI355Q_V8_CLOCK prints the clock held over the K loop (no add-back),
@@ -795,11 +815,12 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
         a.splits = 1;
         if (S > 1) {
             SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * (small ? 128 : 256) * 256 * 4, (int)tiles);
-            if (!w) return (int)hipErrorOutOfMemory;
-            a.splits = S;
-            a.slabs = w->slabs;
-            a.tickets = w->tickets;
-            tiles *= S;
+            if (w) {                                       // (none -- growth under graph capture, or no memory: unsplit)
+                a.splits = S;
+                a.slabs = w->slabs;
+                a.tickets = w->tickets;
+                tiles *= S;
+            }
         }
     }
     if (small) hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 1, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);

@@ -34,6 +34,10 @@ class GraphedForward:
         self.static_in = [a.clone() for a in example_args]
         self.stream = torch.cuda.Stream(device=self.static_in[0].device)
         self.stream.wait_stream(torch.cuda.current_stream())
+        # every library buffer created on this stream from here on is one the captured kernels keep a pointer to: the
+        # per-stream caches in ops.py must never evict them
+        from . import ops
+        ops._StreamCache.pin_stream(self.static_in[0].device.index, self.stream.cuda_stream)
         # warm-up on the capture stream itself: the library's buffers (and the split-K workspace) are per stream
         with torch.cuda.stream(self.stream), torch.no_grad():
             for _ in range(max(1, warmup)):
@@ -52,6 +56,9 @@ class GraphedForward:
                 raise RuntimeError("mi355q.graphs: input shape / dtype differs from the captured one")
             dst.copy_(src)
         self.graph.replay()
+        # the replay rewrote the outputs in place behind autograd's back: bump their version so that nothing keyed on
+        # (data_ptr, _version) -- the quantised-activation reuse record of ops.py -- takes them for the previous replay's
+        _tree_map(lambda t: (torch.autograd.graph.increment_version(t), t)[1], self.static_out)
         return self.static_out
 
     def clone_output(self):

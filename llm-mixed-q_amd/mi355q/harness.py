@@ -220,6 +220,12 @@ class _LlamaAttention(nn.Module):
         if self.qc["matmul_1"].get("mi355q_grouped_linear", False):
             q, k, v = (shape(t) for t in grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj), norm=norm))
         else:
+            if norm is not None:
+                # (the layer asked for the fused norm but this module's own knobs do not group the projections -- the knobs
+                #  ride per node: the norm is applied here, the RMSNorm expression of the reference, never skipped)
+                weight, eps = norm
+                var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+                x = weight * (x * torch.rsqrt(var + eps)).to(x.dtype)
             q, k, v = shape(self.q_proj(x)), shape(self.k_proj(x)), shape(self.v_proj(x))
         rc = self.qc["rotary_positional_encoding"]
         q, k = get_quantized_func("rotary_positional_encoding", rc)(q, k, self.cos[:, :, :T], self.sin[:, :, :T],

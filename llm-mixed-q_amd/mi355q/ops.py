@@ -158,7 +158,49 @@ def block_fp_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exp
     return y
 
 
-_BF16_TILED_BUFFERS: dict = {}
+class _StreamCache:
+    """Per-(device, stream, shape ...) device buffers whose raw pointers the library's kernels are launched with.  Least-
+    recently-used eviction PER STREAM (never wholesale), and none at all for a stream that has recorded a HIP graph: the
+    captured kernels keep the pointers, so a buffer a graph may replay into must outlive the cache's appetite (the caching
+    allocator would hand a dropped buffer to the next tensor).  Key layout: (device index, stream handle, ...)."""
+    _pinned_streams: set = set()
+
+    def __init__(self, per_stream: int):
+        from collections import OrderedDict
+        self.per_stream, self._d = per_stream, OrderedDict()
+
+    @classmethod
+    def pin_stream(cls, device_index: int, stream_handle: int):
+        cls._pinned_streams.add((device_index, stream_handle))
+
+    def get(self, key):
+        v = self._d.get(key)
+        if v is not None:
+            self._d.move_to_end(key)
+        return v
+
+    def put(self, key, value):
+        sk = key[:2]
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self._pinned_streams.add(sk)
+        self._d[key] = value
+        if sk not in self._pinned_streams:
+            mine = [k for k in self._d if k[:2] == sk]
+            for k in mine[:max(0, len(mine) - self.per_stream)]:
+                del self._d[k]
+        return value
+
+    def __len__(self):
+        return len(self._d)
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def keys(self):
+        return self._d.keys()
+
+
+_BF16_TILED_BUFFERS = _StreamCache(32)
 
 
 PRE_NONE, PRE_RELU, PRE_SILU_MUL, PRE_RMSNORM, PRE_LAYERNORM = 0, 1, 2, 3, 4   # include/mi355q.h: steps folded into a quantiser
@@ -199,9 +241,7 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
         key = (x.device.index, _stream_ptr(x.device), rows, K)
         yt = _BF16_TILED_BUFFERS.get(key)
         if yt is None:
-            if len(_BF16_TILED_BUFFERS) > 64:
-                _BF16_TILED_BUFFERS.clear()
-            yt = _BF16_TILED_BUFFERS[key] = torch.empty(nbytes, dtype=torch.int8, device=x.device)
+            yt = _BF16_TILED_BUFFERS.put(key, torch.empty(nbytes, dtype=torch.int8, device=x.device))
     else:
         yt = torch.empty(nbytes, dtype=torch.int8, device=x.device)
     pre_op, other, _, _ = _pre_args(x, pre)        # (`pre`: quantise relu(x) / silu(x) * other instead of x, one pass)
@@ -226,9 +266,7 @@ def block_minifloat_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_wi
     key = (x.device.index, _stream_ptr(x.device), rows, K)
     yt = _BF16_TILED_BUFFERS.get(key)
     if yt is None:
-        if len(_BF16_TILED_BUFFERS) > 64:
-            _BF16_TILED_BUFFERS.clear()
-        yt = _BF16_TILED_BUFFERS[key] = torch.empty(lib.mi355q_bfp_tiled_bytes(rows, 2 * K), dtype=torch.int8, device=x.device)
+        yt = _BF16_TILED_BUFFERS.put(key, torch.empty(lib.mi355q_bfp_tiled_bytes(rows, 2 * K), dtype=torch.int8, device=x.device))
     with _on_device(x.device):
         rc = lib.mi355q_block_minifloat_quantize_bf16_tiled(_ptr(x), _ptr(yt), rows, K, int(width), int(exponent_width),
                                                             int(exponent_bias_width), _ptr(_workspace(x.device)),
@@ -628,7 +666,7 @@ def _capturing() -> bool:
 class _ActivationBuffers:
     """Reusable device buffers of the fused activation path, keyed by (device, stream, rows, K).  Two
     exception lists alternate: each quantise call fills one and zeroes the other's count for the next call."""
-    _cache: dict = {}
+    _cache = _StreamCache(32)
 
     @classmethod
     def get(cls, device, rows, K, row_aligned=False, sp=None, bucket_cap=0):
@@ -643,9 +681,7 @@ class _ActivationBuffers:
                 gscale=torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
                 sparse=[_new_row_list(device, rows, bucket_cap) for _ in range(2)] if bucket_cap >= 0 else [None, None],
                 calls=0)
-            if len(cls._cache) > 64:
-                cls._cache.clear()
-            cls._cache[key] = buf
+            cls._cache.put(key, buf)
         if buf is None:
             lib = _lib.load_library()
             groups = K // 256
@@ -656,9 +692,7 @@ class _ActivationBuffers:
                 gscale=torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
                 sparse=[_new_exception_list(device) for _ in range(2)],
                 calls=0)
-            if len(cls._cache) > 64:
-                cls._cache.clear()
-            cls._cache[key] = buf
+            cls._cache.put(key, buf)
         return buf
 
 
@@ -808,7 +842,7 @@ def bfp_gemm_aligned_multi(x: AlignedOperand, ws, biases=None):
     return outs
 
 
-_MATMUL_WS: dict = {}
+_MATMUL_WS = _StreamCache(8)
 
 
 def bfp_matmul_supported(x: torch.Tensor, y: torch.Tensor, x_width: int, y_width: int) -> bool:
@@ -839,9 +873,7 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
     key = (x.device.index, sp, B, K, N)
     ws = _MATMUL_WS.get(key)
     if ws is None:
-        if len(_MATMUL_WS) > 16:
-            _MATMUL_WS.clear()
-        ws = _MATMUL_WS[key] = torch.empty(lib.mi355q_bfp_matmul_workspace_bytes(B, K, N), dtype=torch.uint8, device=x.device)
+        ws = _MATMUL_WS.put(key, torch.empty(lib.mi355q_bfp_matmul_workspace_bytes(B, K, N), dtype=torch.uint8, device=x.device))
     args = (B, M, K, N, int(x_width), int(x_exponent_width), _default_bias(x_exponent_bias), int(y_width), int(y_exponent_width),
             _default_bias(y_exponent_bias), sp)
     with _on_device(x.device):
@@ -855,7 +887,7 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
     return out
 
 
-_ATTN_WS: dict = {}
+_ATTN_WS = _StreamCache(8)
 ATTENTION_MAX_KEYS, ATTENTION_MAX_HEAD_DIM = 1 << 20, 128      # (beyond 2048 keys: the streaming kernel, scores formed twice)
 
 
@@ -919,9 +951,7 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
     key = (q.device.index, sp, B, T, D)
     ws = _ATTN_WS.get(key)
     if ws is None:
-        if len(_ATTN_WS) > 16:
-            _ATTN_WS.clear()
-        ws = _ATTN_WS[key] = torch.empty(lib.mi355q_bfp_attention_workspace_bytes(B, T, D), dtype=torch.uint8, device=q.device)
+        ws = _ATTN_WS.put(key, torch.empty(lib.mi355q_bfp_attention_workspace_bytes(B, T, D), dtype=torch.uint8, device=q.device))
     if mask is not None:
         assert mask.shape == (M, T) and mask.dtype == torch.float32 and mask.is_contiguous() and mask.device == q.device
     pa = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(qk_params)])

@@ -82,6 +82,18 @@ def _generic_matmul(x, y, config, arith, style):
     return mm(xq, yq)
 
 
+def _mask_2d(mask, tq, tk):
+    """an additive mask that is the same for every leading index, as the [T_q, T_k] tensor the HIP entry points read --
+    [1, 1, T_q, T_k], [T_q, T_k], or a padding mask [1, 1, 1, T_k] expanded over the rows; None for anything else (per-
+    batch masks, shapes that do not broadcast to [T_q, T_k]): the caller then takes the generic route"""
+    if mask.ndim < 2 or mask.numel() != mask.shape[-2] * mask.shape[-1]:
+        return None
+    m2 = mask.reshape(mask.shape[-2:])
+    if m2.shape[0] not in (1, tq) or m2.shape[1] not in (1, tk):
+        return None
+    return m2.expand(tq, tk).to(torch.float32).contiguous()
+
+
 def _make_softmax(style):
     """`softmax_{matmul,bmm}_block_fp(scores, y, config, mask=None, causal=False)` =
     `{matmul,bmm}_block_fp(softmax(max(scores + mask, finfo.min), dim=-1), y, config)`: what the reference's attention
@@ -91,13 +103,11 @@ def _make_softmax(style):
     addition to the registry (keys "softmax_matmul" / "softmax_bmm"); callers that keep the reference's steps are served
     as before."""
     def f(scores, y, config, mask=None, causal=False):
-        m2 = None
-        if mask is not None:
-            m2 = mask.reshape(mask.shape[-2:]) if mask.numel() == mask.shape[-2] * mask.shape[-1] else None
+        m2 = None if mask is None else _mask_2d(mask, scores.shape[-2], scores.shape[-1])
         if (not config.get("bypass", False) and config.get("mi355q_fused_matmul", True) and (mask is None or m2 is not None)):
             for k in _KEYS["block_fp"]:
                 config[f"data_in_{k}"], config[f"weight_{k}"]
-            out = _fused_block_fp_matmul(scores, y, config, style, softmax=True, mask=None if m2 is None else m2.contiguous(),
+            out = _fused_block_fp_matmul(scores, y, config, style, softmax=True, mask=m2,
                                          causal=causal)
             if out is not None:
                 return out
@@ -129,9 +139,7 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
     contiguous [1, T, heads, hd] buffer (same values): the `transpose(1, 2).reshape(B, T, hidden)` that follows in both
     models is then free.  An addition to the registry (key "attention")."""
     from ... import ops
-    m2 = None
-    if mask is not None:
-        m2 = mask.reshape(mask.shape[-2:]) if mask.numel() == mask.shape[-2] * mask.shape[-1] else None
+    m2 = None if mask is None else _mask_2d(mask, q.shape[-2], k.shape[-2])
     both_fp = config_qk.get("name") == "block_fp" and config_pv.get("name") == "block_fp"
     fused_ok = (both_fp and not config_qk.get("bypass", False) and not config_pv.get("bypass", False)
                 and config_qk.get("mi355q_fused_matmul", True) and config_pv.get("mi355q_fused_matmul", True)
@@ -150,7 +158,7 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
         if blocks_ok and ops.bfp_attention_supported(q, k, v, widths) and (not causal or tk >= tq):
             par = lambda c: (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"], c["weight_width"],
                              c["weight_exponent_width"], c["weight_exponent_bias"])
-            return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=None if m2 is None else m2.contiguous(),
+            return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=m2,
                                      causal=causal, scale_div=scale_div,
                                      token_major=bool(config_pv.get("mi355q_token_major_output", False)))
     style = "bmm" if q.ndim == 3 else "matmul"

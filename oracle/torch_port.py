@@ -61,6 +61,56 @@ def block_fp_quantize(x: torch.Tensor, width: int, exponent_width: int = 8, expo
     return (~close) * out + close * x
 
 
+def _fill_zero_block_maxima(bmax: torch.Tensor) -> torch.Tensor:
+    """all-zero blocks take the smallest non-zero block maximum of the whole tensor (1 when every block is zero):
+    block_fp.py:54-58, block_minifloat.py:52-55, block_log.py:50-53"""
+    if torch.all(bmax == 0):
+        return torch.ones_like(bmax)
+    bmax[bmax == 0] = bmax[bmax != 0].min()
+    return bmax
+
+
+def block_minifloat_quantize(x: torch.Tensor, width: int, exponent_width: int, exponent_bias_width: int,
+                             block_size=(16,), skip_first_dim: bool = True) -> torch.Tensor:
+    """reference block_minifloat.py:22-74 -> minifloat.py:134-196, the same torch ops in the same order: shared bias
+    = clamp(floor(log2(block max)), 0, 2^ebw - 1); per element an IEEE-style minifloat with exponent range
+    [-bias, 2^ew - 1 - bias], subnormal where the clamped exponent equals -bias, |x| <= 1e-8 passed through."""
+    meta = block_meta(tuple(x.shape), block_size, skip_first_dim)
+    blocked = _to_blocks(x, meta)
+    bmax = _fill_zero_block_maxima(blocked.abs().max(dim=1, keepdim=True)[0])
+    bias = torch.floor(torch.log2(bmax)).clamp(0, 2 ** exponent_bias_width - 1)
+    mbits = width - exponent_width - 1
+    e_max, e_min = 2 ** exponent_width - 1 - bias, -bias
+    shift = 2 ** mbits
+    sign = torch.sign(blocked + 1e-9)
+    value = torch.abs(blocked)
+    e = torch.maximum(torch.minimum(torch.floor(torch.log2(value + 1e-9)), e_max), e_min)
+    mant = value / 2 ** e
+    normal = ~torch.isclose(e, -bias)
+    sm = normal * torch.round(mant * shift - shift).clamp(0, shift - 1) + (~normal) * torch.round(mant * shift / 2).clamp(0, shift - 1)
+    mant = normal * (1.0 + sm / shift) + (~normal) * (sm / shift * 2)
+    close = torch.isclose(value, torch.tensor([0.0], dtype=value.dtype))
+    q = (~close) * (sign * (2 ** e) * mant) + close * blocked
+    return _from_blocks(q, meta)
+
+
+def block_log_quantize(x: torch.Tensor, width: int, exponent_bias_width: int, block_size=(16,),
+                       skip_first_dim: bool = True) -> torch.Tensor:
+    """reference block_log.py:23-69 -> log.py:22-56: shared bias = clamp(2^(w-1) - 1 - ceil(log2(block max)), 0,
+    2^ebw - 1); per element sign(x + 0.1 * 2^-bias) * 2^clamp(round(log2(|x| + 0.1 * 2^-bias)), -bias, 2^(w-1) - 1 - bias)."""
+    meta = block_meta(tuple(x.shape), block_size, skip_first_dim)
+    blocked = _to_blocks(x, meta)
+    bmax = _fill_zero_block_maxima(blocked.abs().max(dim=1, keepdim=True)[0])
+    ebits = width - 1
+    bias = (2 ** ebits - 1 - torch.ceil(torch.log2(bmax))).clamp(0, 2 ** exponent_bias_width - 1)
+    e_max, e_min = 2 ** ebits - 1 - bias, -bias
+    min_pos = 2 ** e_min
+    sign = torch.sign(blocked + min_pos * 0.1)
+    value = torch.abs(blocked) + min_pos * 0.1
+    e = torch.maximum(torch.minimum(torch.round(torch.log2(value)), e_max), e_min)
+    return _from_blocks(sign * (2 ** e), meta)
+
+
 def linear_ptq_step(x: torch.Tensor, w_q: torch.Tensor, b_q, cfg: dict) -> torch.Tensor:
     """steady-state PTQ LinearBlockFP forward: quantise x, F.linear against already-quantised W"""
     xq = block_fp_quantize(x, cfg["data_in_width"], cfg["data_in_exponent_width"],

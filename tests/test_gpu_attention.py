@@ -112,6 +112,43 @@ def test_attention_mixed_widths_4d_and_fewer_queries():
     _check(out.cpu().numpy(), ref)
 
 
+def test_attention_masks_of_every_broadcastable_shape():
+    """a padding mask [1, 1, 1, T_k] is expanded over the rows and takes the kernel; a per-batch mask [B, 1, T_q, T_k] cannot
+    (the kernel reads ONE [T_q, T_k] mask) and takes the generic steps: both give the reference's values, neither asserts
+    (ADVICE r2); the same for the softmax_matmul function"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    c0, c1 = _cfg(6), _cfg(6)
+    B, H, T, hd = 2, 2, 320, 64
+    q, k, v = _inputs(B * H, T, T, hd, seed=21)
+    r = np.random.default_rng(5)
+    pad = np.zeros((1, 1, 1, T), np.float32)
+    pad[..., -37:] = FMIN
+    per_batch = (r.normal(size=(B, 1, T, T)) * 0.5).astype(np.float32)
+    t4 = lambda a: torch.from_numpy(a).to("cuda:0").reshape(B, H, -1, hd)
+    calls, real = [], ops.bfp_attention
+    ops.bfp_attention = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    try:
+        f = Q.get_quantized_func("attention", c1)
+        out = f(t4(q), t4(k), t4(v), c0, c1, mask=torch.from_numpy(pad).to("cuda:0"), causal=True)
+        assert len(calls) == 1
+        _check(out.cpu().numpy().reshape(B * H, T, hd), _oracle(q, k, v, c0, c1, mask=np.broadcast_to(pad[0, 0], (T, T)), causal=True))
+        out = f(t4(q), t4(k), t4(v), c0, c1, mask=torch.from_numpy(per_batch).to("cuda:0"))
+        assert len(calls) == 1                                              # (the generic steps)
+        ref = np.stack([_oracle(q[b * H:(b + 1) * H], k[b * H:(b + 1) * H], v[b * H:(b + 1) * H], c0, c1, mask=per_batch[b, 0])
+                        for b in range(B)]).reshape(B * H, T, hd)
+        _check(out.cpu().numpy().reshape(B * H, T, hd), ref)
+    finally:
+        ops.bfp_attention = real
+    # softmax_matmul with the padding mask against the same with the mask spelled out
+    scores = torch.randn(B, H, T, T, device="cuda:0")
+    g = Q.get_quantized_func("softmax_matmul", c1)
+    a = g(scores, t4(v), dict(c1), mask=torch.from_numpy(pad).to("cuda:0"))
+    b = g(scores, t4(v), dict(c1), mask=torch.from_numpy(np.ascontiguousarray(np.broadcast_to(pad[0, 0], (T, T)))).to("cuda:0"))
+    assert torch.equal(a, b)
+
+
 def test_attention_falls_back_outside_the_kernel_shapes():
     """T % 16 != 0: the same steps through bmm / softmax_bmm, same answer; T > 2048: the streaming kernel"""
     import torch

@@ -106,3 +106,39 @@ def test_graph_replay_with_every_knob(family):
         assert torch.equal(fwd(ids), want)
         assert torch.equal(fwd(ids2), want2)
         assert torch.equal(fwd(ids), want)
+
+
+def test_split_k_shape_first_seen_under_capture_and_eager_traffic_between_replays():
+    """(1) a split-K GEMM shape whose workspace does not exist yet when a stream starts recording launches
+    unsplit instead of allocating under capture; (2) eager calls with many other shapes between replays neither evict the
+    buffers the graph replays into nor make the reuse record take a replayed output for the previous one"""
+    from mi355q.graphs import GraphedForward
+    from mi355q.quantize import get_quantized_cls
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    lin = get_quantized_cls("linear", W6A6)(4096, 512, bias=False, config=dict(W6A6, mi355q_align="rows")).to(dev)   # 2 x 2 tiles: split
+    x = torch.randn(512, 4096, device=dev)
+    with torch.no_grad():
+        lin(torch.randn(64, 4096, device=dev))            # PTQ weight work + route decision outside the graph, another shape
+    st = torch.cuda.Stream(device=dev)                     # a stream the library has no workspace for
+    st.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st), torch.no_grad():
+        y = lin(x)
+    graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert torch.equal(y, lin(x))
+
+    tail = get_quantized_cls("linear", W6A6)(512, 256, bias=False, config=dict(W6A6, mi355q_align="rows")).to(dev)
+    xs = [torch.randn(512, 4096, generator=torch.Generator().manual_seed(s)).to(dev) for s in range(3)]
+    with torch.no_grad():
+        want = [tail(lin(t)).clone() for t in xs]
+    fwd = GraphedForward(lambda t: lin(t), (xs[0],))
+    for rep in range(2):
+        for t, w in zip(xs, want):
+            h = fwd(t)
+            with torch.no_grad():
+                assert torch.equal(tail(h), w), rep        # (an eager Linear on the graph's static output: never a stale hit)
+                for rows in range(16, 16 * 40, 16):        # variable-length eager traffic on the default stream
+                    lin(torch.randn(rows, 4096, device=dev))

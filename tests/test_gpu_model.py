@@ -315,6 +315,37 @@ def test_reference_model_fixture_every_knob(tag):
         assert sum(1 for p in pres if p is not None and p[0] == kind) == 4, pres           # (two norms a layer, two layers)
 
 
+@pytest.mark.parametrize("tag", sorted(t for t in _G5 if _G5[t]["family"] == "llama" and "mixed" not in t))
+def test_fused_norm_knobs_only_in_the_linear_section(tag):
+    """the knobs ride per node: set for the Linear layers only (a [linear] section, as search results are saved), the
+    decoder layer asks its attention module for the fused norm while that module's own matmul nodes do not group the
+    projections -- the norm must then be applied in front of q / k / v, never skipped: the reference's logits"""
+    import torch
+    from mi355q import harness as H
+    from oracle import np_models as NM
+    data = np.load(_GOLDEN / "models.npz")
+    sd, _, ids, ref_logits, ref_loss, m = NM.load_fixture(_G5, data, tag)
+    cfg = H.TinyLlamaConfig(vocab_size=m["vocab_size"], hidden_size=m["hidden_size"], intermediate_size=m["intermediate_size"],
+                            num_layers=m["num_layers"], num_heads=m["num_heads"], max_positions=m["max_positions"], rms_eps=m["rms_eps"])
+    qc = H.expand_llama_quant_config(m["quant_config"], cfg.num_layers)
+    for i in range(cfg.num_layers):             # the Linear nodes only: not rotary / matmul_0 / matmul_1
+        layer_qc = qc[f"model_layer_{i}"]
+        for node in [layer_qc["mlp"][n] for n in ("gate_proj", "up_proj", "down_proj")] + \
+                    [layer_qc["self_attn"][n] for n in ("q_proj", "k_proj", "v_proj", "o_proj")]:
+            node.update(mi355q_grouped_linear=True, mi355q_fused_norm=True)
+    model = H.TinyLlamaForCausalLM(cfg, qc)
+    layer = model.layers[0]
+    assert layer.gate_proj.config.get("mi355q_fused_norm") and not layer.self_attn.qc["matmul_1"].get("mi355q_grouped_linear", False)
+    model.load_reference_state_dict(sd).to("cuda:0").eval()
+    t = torch.from_numpy(ids).to("cuda:0")
+    with torch.no_grad():
+        for _ in range(2):
+            logits, loss = model(t, labels=t)
+    err = float(np.abs(logits.cpu().numpy() - ref_logits).max())
+    assert err < 1e-3 * max(1.0, float(np.abs(ref_logits).max())), err
+    assert abs(float(loss) - ref_loss) < 2e-5
+
+
 @pytest.mark.parametrize("arith", ["block_log", "block_minifloat"])
 def test_tiny_llama_loss_parity_other_block_arithmetics(arith):
     """BASELINE configs 3 / 5 name Llama with block_minifloat and block_log: the Llama-style harness under those

@@ -242,3 +242,46 @@ def test_pre_op_entry_points_validate_without_a_gpu():
     assert lib.mi355q_block_fp_quantize_bf16_tiled_pre(p, None, 2, None, p, 4, 64, 6, 8, 127, p, None) == E_BADARG
     assert lib.mi355q_block_fp_quantize_bf16_tiled_pre(p, None, -1, None, p, 4, 64, 6, 8, 127, p, None) == E_BADARG
     assert lib.mi355q_block_fp_quantize_bf16_tiled_pre(p, None, 1, None, p, 0, 64, 6, 8, 127, p, None) == 0       # nothing to do
+
+
+def test_stream_cache_evicts_per_stream_and_never_a_captured_streams_buffers():
+    """ops._StreamCache: least-recently-used per (device, stream); entries of a stream that recorded a HIP graph
+    are never dropped, whatever traffic other streams (or that stream) see afterwards"""
+    from mi355q.ops import _StreamCache
+    c = _StreamCache(4)
+    eager, graph = (0, 111), (0, 222)
+    for i in range(3):
+        c.put(graph + (i,), f"g{i}")
+    _StreamCache.pin_stream(*graph)
+    try:
+        for i in range(40):                       # variable-length prompts on the eager stream
+            c.put(eager + (i,), i)
+            if i >= 1:
+                assert c.get(eager + (i - 1,)) == i - 1       # the one just used is still there
+        assert sum(1 for k in c.keys() if k[:2] == eager) == 4
+        assert c.get(eager + (0,)) is None and c.get(eager + (39,)) == 39
+        assert [c.get(graph + (i,)) for i in range(3)] == ["g0", "g1", "g2"]
+        for i in range(3, 20):                    # more shapes on the pinned stream: kept, all of them
+            c.put(graph + (i,), f"g{i}")
+        assert sum(1 for k in c.keys() if k[:2] == graph) == 20
+        # use refreshes: the oldest-used entry goes first
+        d = _StreamCache(2)
+        d.put((0, 1, "a"), 1), d.put((0, 1, "b"), 2)
+        d.get((0, 1, "a"))
+        d.put((0, 1, "c"), 3)
+        assert d.get((0, 1, "b")) is None and d.get((0, 1, "a")) == 1
+    finally:
+        _StreamCache._pinned_streams.discard(graph)
+
+
+def test_mask_2d_accepts_only_masks_shared_by_every_leading_index():
+    import torch
+    from mi355q.quantize.quantized_functions import _mask_2d
+    T = 8
+    assert _mask_2d(torch.zeros(1, 1, T, T), T, T).shape == (T, T)
+    assert _mask_2d(torch.zeros(T, T), T, T).shape == (T, T)
+    m = _mask_2d(torch.arange(T, dtype=torch.float32).reshape(1, 1, 1, T), 4, T)       # padding mask: one row for all
+    assert m.shape == (4, T) and m.is_contiguous() and torch.equal(m[3], torch.arange(T, dtype=torch.float32))
+    assert _mask_2d(torch.zeros(2, 1, T, T), T, T) is None                              # per-batch
+    assert _mask_2d(torch.zeros(1, 1, T, 4), T, T) is None                              # does not broadcast
+    assert _mask_2d(torch.zeros(T), T, T) is None
