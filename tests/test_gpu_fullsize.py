@@ -101,3 +101,47 @@ def test_column_slice_output_matches_full():
         lo, hi = r * 512, (r + 1) * 512
         _step(x, w[lo:hi], b[lo:hi], out=buf[:, lo:hi])
     assert torch.equal(buf, full)
+
+
+_C5 = {"block_minifloat": dict(width=8, exponent_width=4, exponent_bias_width=8, block_size=[1, 16]),
+       "block_log": dict(width=8, exponent_bias_width=8, block_size=[1, 16]),
+       "block_fp": dict(width=6, exponent_width=8, exponent_bias=127, block_size=[1, 16])}
+
+
+@pytest.mark.parametrize("shape", [(2048, 4096), (2048, 11008)])
+@pytest.mark.parametrize("name", ["block_minifloat", "block_log"])
+def test_config5_activation_shapes_bit_exact(name, shape):
+    """BASELINE config 5's activation shapes (Llama-7B hidden / intermediate width, 2048 tokens), the bench's own inputs
+    (bench.py quantizer_workload: randn * 4, seed 7): every output word == the oracle's"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(7)) * 4.0
+    got = getattr(ops, name + "_quantize")(x.to("cuda:0"), *[_C5[name][k] for k in _C5[name]], True).cpu().numpy()
+    want = np.asarray(getattr(O, name + "_quantize")(x.numpy(), **_C5[name], skip_first_dim=True), dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["block_minifloat", "block_log", "block_fp"])
+def test_config5_causal_probabilities_planes_bit_exact(name):
+    """the worst case of config 5 at its full size: softmax rows under the causal mask, [32, 2048, 2048] (the zero-block-map
+    path: 512 MiB) -- 5 of the 32 planes word for word against the oracle.  The fill of an all-zero block is the smallest
+    non-zero block maximum of the WHOLE tensor (block_fp.py:54-58 and the same lines of block_minifloat.py / block_log.py):
+    the oracle quantises each plane together with the one row that carries it"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    shp = (32, 2048, 2048)
+    dev = "cuda:0"
+    x = torch.randn(*shp, generator=torch.Generator().manual_seed(7)).to(dev) * 4.0
+    p = torch.softmax(x + torch.full(shp[-2:], float("-inf"), device=dev).triu(1), dim=-1)
+    del x
+    got = getattr(ops, name + "_quantize")(p, *[_C5[name][k] for k in _C5[name]], True)
+    bm = p.view(-1, 16).abs().amax(1)
+    row = int((bm == bm[bm > 0].min()).nonzero()[0, 0]) * 16 // shp[-1]
+    carrier = p.view(-1, shp[-1])[row:row + 1].cpu().numpy()
+    assert (p[3] == 0).float().mean().item() > 0.45
+    for i in (0, 3, 13, 22, 31):
+        piece = np.concatenate([p[i].cpu().numpy(), carrier], 0)[None]
+        want = np.asarray(getattr(O, name + "_quantize")(piece, **_C5[name], skip_first_dim=True), dtype=np.float32)[0, :-1]
+        assert np.array_equal(got[i].cpu().numpy().view(np.uint32), want.view(np.uint32)), (name, i)

@@ -334,6 +334,7 @@ def test_packed_weight_storage(width, act):
     torch.manual_seed(3)
     K, N, M = 1024, 512, 300
     fp = torch.nn.Linear(K, N)
+    w0, b0 = fp.weight.detach().clone().numpy(), fp.bias.detach().clone().numpy()
     h = torch.randn(M, K) * torch.exp(torch.randn(M, 1))
     x = {"plain": h, "relu": torch.relu(h), "silu": torch.nn.functional.silu(h) * torch.randn(M, K)}[act].to("cuda:0")
     ref_cfg, cfg = _lin_cfg(width), _lin_cfg(width, mi355q_weight_storage="packed")
@@ -345,6 +346,10 @@ def test_packed_weight_storage(width, act):
     if act != "relu":                                       # (post-ReLU rows fit a window of 4 exponents, W5 has one)
         assert lin._w_packed.row_scale_flavour == (act == "plain")
     assert torch.equal(y, y_ref)
+    # ... and both the oracle's exact contraction of the quantised integers (not only each other)
+    from oracle import np_oracle as O
+    want = O.bfp_linear_int(x.cpu().numpy(), w0, b0, ref_cfg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want, rtol=0, atol=4e-6 * np.abs(want).max())
     bits = lin.weight_storage_bits()
     pw = lin._w_packed
     assert 8.0 * (pw.packed.numel() + pw.codes.numel()) / (K * N) == width + 0.5      # the format's own density
@@ -355,6 +360,7 @@ def test_packed_weight_storage(width, act):
     lin.release_fp32_weight()
     assert lin.weight.numel() == 0
     assert torch.equal(lin(x), y_ref)
+    np.testing.assert_allclose(lin(x).detach().cpu().numpy(), want, rtol=0, atol=4e-6 * np.abs(want).max())
 
 
 def test_pack_now_and_master_requantize():

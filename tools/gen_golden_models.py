@@ -8,6 +8,8 @@ the (fp32, un-quantised) weights, the token ids, the quant config as the TOML-le
 parser takes, the reference's PARSED per-layer config, and the reference's logits + loss.  Data only.
 
     python tools/gen_golden_models.py
+    python tools/gen_golden_models.py --wide     # models_wide.{npz,json}: 2 layers at OPT-1.3B / Llama-7B width; the
+                                                 # weights are a seeded recipe in the JSON, not data
 """
 from __future__ import annotations
 
@@ -170,7 +172,74 @@ def run_llama(llama, llamac, tag, qcfg, arrays, meta, hidden=64, inter=128, laye
     print(f"{tag}: loss {float(out.loss):.6f}")
 
 
+def seeded_weights(recipe, seed):
+    """the weights of a `wide` case from its recipe [(name, shape, std, mean)] -- numpy's PCG64 stream (stable across
+    versions and machines), so that the fixture holds the recipe instead of 0.4-1.6 GB of weights.  tests/ and
+    oracle/np_models.py regenerate them with the same lines (np_models.weights_from_recipe)."""
+    rng = np.random.default_rng(seed)
+    return {name: (rng.standard_normal(tuple(shape), dtype=np.float32) * np.float32(std) + np.float32(mean))
+            for name, shape, std, mean in recipe}
+
+
+def run_wide(mod, cmod, family, tag, qcfg, arrays, meta, hidden, inner, heads, vocab=512, T=128, B=2, layers=2, seed=0):
+    """2 decoder layers at a real model's width (OPT-1.3B: 2048 / 8192 / 32 heads; Llama-7B: 4096 / 11008 / 32 heads):
+    the shapes whose Linear layers take the 256 x 256-tile int8 GEMM and whose heads take the one-pass attention kernel"""
+    torch.manual_seed(seed)
+    if family == "opt":
+        cfg = cmod.OPTQuantizedConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers, ffn_dim=inner,
+                                      max_position_embeddings=T, num_attention_heads=heads, dropout=0.0,
+                                      word_embed_proj_dim=hidden, quant_config=json.loads(json.dumps(qcfg)))
+        model = mod.OPTQuantizedForCausalLM(cfg).eval()
+    else:
+        cfg = cmod.LlamaQuantizedConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=inner, num_hidden_layers=layers,
+                                        num_attention_heads=heads, max_position_embeddings=T,
+                                        quant_config=json.loads(json.dumps(qcfg)))
+        model = mod.LlamaQuantizedForCausalLM(cfg).eval()
+    recipe = []
+    for n, p in model.named_parameters():
+        if p.ndim == 1:
+            recipe.append([n, list(p.shape), 0.05, 1.0 if "norm" in n and n.endswith("weight") else 0.0])
+        else:
+            recipe.append([n, list(p.shape), 0.5 if "embed" in n else 0.02, 0.0])
+    w = seeded_weights(recipe, seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(w[n]))
+    # (tied / derived entries of the state dict -- lm_head.weight where tied -- follow from the named parameters)
+    sd_extra = [k for k in model.state_dict() if k not in w]
+    ids = torch.from_numpy(np.random.default_rng(seed + 1).integers(3, vocab, size=(B, T)))
+    # the first decoder layer's attention output (its first 128 channels): everything up to there is free of the activation
+    # function, whose last-bit differences between implementations move a W6 rounding here and there at these sizes
+    layer0 = (model.model.decoder.layers if family == "opt" else model.model.layers)[0]
+    caps = {}
+    layer0.self_attn.register_forward_hook(lambda mod, i, o: caps.__setitem__("attn0", (o[0] if isinstance(o, tuple) else o).detach()))
+    with torch.no_grad():
+        out = model(input_ids=ids, labels=ids)
+    arrays[f"{tag}/attn0"] = caps["attn0"].reshape(B, T, hidden)[:, :, :128].numpy().copy()
+    arrays[f"{tag}/input_ids"] = ids.numpy()
+    arrays[f"{tag}/logits"] = out.logits.numpy()
+    meta[tag] = dict(family=family, hidden_size=hidden, num_layers=layers, num_heads=heads, vocab_size=vocab, max_positions=T,
+                     loss=float(out.loss), quant_config=_jsonable(qcfg), weight_recipe=recipe, weight_seed=seed,
+                     state_dict_extra=sd_extra,
+                     parsed_quant_config=_jsonable({k: v for k, v in cfg.quant_config.items()}))
+    meta[tag].update(dict(ffn_dim=inner) if family == "opt" else dict(intermediate_size=inner, rms_eps=float(cfg.rms_norm_eps)))
+    print(f"{tag}: loss {float(out.loss):.6f}  max|logit| {float(out.logits.abs().max()):.3f}")
+
+
+def main_wide():
+    torch.set_num_threads(8)
+    opt, optc, llama, llamac = load_reference_models()
+    arrays, meta = {}, {}
+    run_wide(opt, optc, "opt", "opt1p3b_width_w6a6", {"default": bfp_default(6, 6)}, arrays, meta, 2048, 8192, 32, seed=200)
+    run_wide(llama, llamac, "llama", "llama7b_width_w6a6", {"default": bfp_default(6, 6)}, arrays, meta, 4096, 11008, 32, seed=210)
+    np.savez_compressed(OUT / "models_wide.npz", **arrays)
+    (OUT / "models_wide.json").write_text(json.dumps(meta, indent=1))
+    print(f"wide models: {len(meta)} cases, {sum(a.nbytes for a in arrays.values()) / 1e6:.2f} MB raw")
+
+
 def main():
+    if "--wide" in sys.argv:
+        return main_wide()
     torch.set_num_threads(4)
     opt, optc, llama, llamac = load_reference_models()
     arrays, meta = {}, {}
