@@ -53,7 +53,7 @@ def _inputs(B, M, T, hd, seed):
 def _check(out, ref):
     scale = np.abs(ref).max()
     # (a score or probability one ulp apart may round to the next mantissa step of one of T terms of a row)
-    assert np.abs(out - ref).max() <= 3e-3 * scale, (np.abs(out - ref).max(), scale)
+    assert np.abs(out - ref).max() <= 1e-3 * scale, (np.abs(out - ref).max(), scale)          # north_star: fp tolerance 1e-3
     assert np.abs(out - ref).mean() <= 3e-5 * scale, (np.abs(out - ref).mean(), scale)
 
 
@@ -94,7 +94,7 @@ def _attention_vs_oracle(B, T, hd, width, mode):
     # the step-by-step route through the registry's own functions
     steps = Q.get_quantized_func("attention", c1)(qt, kt, vt, dict(c0, mi355q_fused_matmul=False), dict(c1, mi355q_fused_matmul=False), **kw)
     _check(steps.cpu().numpy(), ref)
-    assert (out - steps).abs().max().item() <= 3e-3 * np.abs(ref).max()
+    assert (out - steps).abs().max().item() <= 1e-3 * np.abs(ref).max()
 
 
 def test_attention_mixed_widths_4d_and_fewer_queries():

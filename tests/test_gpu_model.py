@@ -193,9 +193,14 @@ def test_reference_model_fixture_at_real_widths(tag, knobs):
                                 rms_eps=m["rms_eps"])
         model = H.TinyLlamaForCausalLM(cfg, H.expand_llama_quant_config(_with_knob(m["quant_config"], **kn), cfg.num_layers))
     model.load_reference_state_dict(sd).to("cuda:0").eval()
-    del sd
-    taps = {}
+    taps, io = {}, {}
     model.layers[0].self_attn.register_forward_hook(lambda mod, i, o: taps.__setitem__("attn0", o.detach()))
+    if knobs == "plain":                                     # (every Linear's input and output as the forward saw them)
+        from mi355q.quantize import get_quantized_cls
+        lin_cls = get_quantized_cls("linear", m["quant_config"]["default"])
+        for name, mod in model.named_modules():
+            if isinstance(mod, lin_cls) and name.startswith("layers."):
+                mod.register_forward_hook(lambda mod, i, o, name=name: io.__setitem__(name, (i[0].detach().clone(), o.detach().clone())))
     t = torch.from_numpy(ids).to("cuda:0")
     with torch.no_grad():
         for _ in range(2):                                   # (the second forward runs on the packed weights)
@@ -219,7 +224,22 @@ def test_reference_model_fixture_at_real_widths(tag, knobs):
     print(f"{tag} [{knobs}]: attn0 rel err {ea:.2e}; logits max {d.max():.2e} mean {d.mean():.2e} of {scale:.2f}; |dloss| {dl:.2e}")
     assert ea < 1e-5, ea
     assert d.mean() < 5e-3 * scale and d.max() < 0.1 * scale, (float(d.max()), float(d.mean()))
-    assert dl < 2e-3, (float(loss), ref_loss)
+    assert dl < 5e-3, (float(loss), ref_loss)
+    # (3) every Linear of the run, teacher-forced: the oracle's steady-state PTQ Linear (linear.py:63-71 in float64) on the
+    #     very input the module saw and the fixture's un-quantised weights -- the GEMM's usual bound at K = 2048 ... 11008
+    from oracle import np_oracle as O
+    ref_name = (lambda n: "model.decoder." + n) if m["family"] == "opt" else \
+        (lambda n: "model." + n.replace(".gate_proj", ".mlp.gate_proj").replace(".up_proj", ".mlp.up_proj").replace(".down_proj", ".mlp.down_proj"))
+    worst = 0.0
+    for name, (xin, yout) in io.items():
+        w0, b0 = sd[ref_name(name) + ".weight"], sd.get(ref_name(name) + ".bias")
+        want = O.linear_ptq(xin.cpu().numpy().reshape(-1, xin.shape[-1]), w0, b0, dict(m["quant_config"]["default"]))[0]
+        e = float(np.abs(yout.cpu().numpy().reshape(want.shape) - want).max() / np.abs(want).max())
+        worst = max(worst, e)
+        assert e < 4e-6, (name, e)
+    if io:
+        print(f"{tag}: {len(io)} Linear layers teacher-forced against the oracle, worst relative error {worst:.2e}")
+        assert len(io) == (6 if m["family"] == "opt" else 7) * m["num_layers"]
 
 
 def test_fused_softmax_model_parity():
