@@ -34,11 +34,24 @@
 
 namespace mi355q {
 
-// Zero-block state of kernel 1 (exact mode only) for the fix-up launch that follows on the same stream, without a single
-// atomic: each workgroup stores the smallest non-zero block max it met -- as max(~bits) -- in its OWN workspace slot, and
-// a workgroup that met an all-zero block raises the flag word (a plain store of 1: every writer writes the same value).
-// (Thousands of waves finish together in these one-round launches; atomics on shared words serialised at the L2 and
-// cost 6-10 us per call.)
+// Zero-block state of kernel 1 (exact mode only) for the fix-up launch that follows on the same stream: each workgroup
+// folds the smallest non-zero block max it met -- as max(~bits) -- into workspace slot blockIdx % WS_SLOTS with one
+// result-less atomic max (2048 slots: a handful of workgroups per slot over the kernel's lifetime; atomics of thousands of
+// waves on ONE word serialised at the L2 and cost 6-10 us per call), and a workgroup that met an all-zero block raises the
+// flag word (a plain store of 1: every writer writes the same value).  The slots are zero between calls: the fix-up
+// launch clears them (zero_fixup_kernel).
+// The fill kernel 1 writes all-zero blocks with.  The reference's is the smallest non-zero block maximum of the WHOLE tensor
+// (block_fp.py:54-58), known only when kernel 1 is through: kernel 1 writes them with the fill the fix-up launch of the LAST
+// tensor with all-zero blocks found (a word of the workspace; 1.0 before there was one, and always in the fast mode), the
+// fix-up launch compares the block parameters that fill gives with the true ones and rewrites the blocks only if they
+// differ.  Attention probabilities under a causal mask -- half of the blocks all zero, the same tiny fill layer after layer
+// -- then cost one pass instead of two (r03: block_log on [32, 2048, 2048] 355 -> 2xx us); any other sequence of tensors
+// costs what it did.  Exact either way.
+__device__ __forceinline__ float zero_fill_guess(const unsigned* ws, bool exact) {
+    const unsigned g = exact ? ws[WS_FILL_GUESS] : 0u;
+    return g ? __uint_as_float(g) : 1.0f;
+}
+
 __device__ __forceinline__ void publish_zero_state(unsigned* ws, bool saw_zero, unsigned inv) {
     __shared__ unsigned wg_inv[4];
     __shared__ int wg_zero[4];
@@ -55,7 +68,7 @@ __device__ __forceinline__ void publish_zero_state(unsigned* ws, bool saw_zero, 
         unsigned m = wg_inv[0];
         int z = wg_zero[0];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = wg_inv[w] > m ? wg_inv[w] : m; z |= wg_zero[w]; }
-        ws[WS_SLOT0 + blockIdx.x] = m;
+        if (m) (void)__hip_atomic_fetch_max(&ws[WS_SLOT0 + (blockIdx.x & (WS_SLOTS - 1))], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (z) ws[WS_ZERO_FLAG] = 1u;
     }
 }
@@ -64,42 +77,39 @@ __device__ __forceinline__ void publish_zero_state(unsigned* ws, bool saw_zero, 
 // kernel 1, vector path: b0 == 1, cols % b1 == 0, b1 = 4 * LPB, 16-byte aligned x / y.
 // Flat over all elements: float4 slot i belongs to block i / LPB.
 // ---------------------------------------------------------------------------------------
-template <int FMT, int LPB>
+// PIECES > 0 (tensors beyond the memory-side cache: 256 MiB and more): a workgroup owns PIECES consecutive 4-KiB pieces of x
+// (256 float4 each) -- no grid-stride loop: with one piece per workgroup a 512-MiB copy runs at 6.2 TB/s on this memory
+// system, as a grid-stride loop of 2048 workgroups at 4.9, a pure write stream at 6.8 vs 4.35 (tools/ubench/stream.hip,
+// profiles/r03_stream_limits.txt).  PIECES == 0: the grid-stride loop, for everything smaller.
+template <int FMT, int LPB, int PIECES>
 __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
     __shared__ Lut lut;
-    load_lut<FMT>(lut);
     const long long n4 = a.n_elems >> 2;
     const long long n4_pad = (n4 + 63) & ~63ll;
-    const long long stride = (long long)gridDim.x * blockDim.x;
     const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
     float4* __restrict__ y4 = reinterpret_cast<float4*>(a.y);
     unsigned* __restrict__ m4 = reinterpret_cast<unsigned*>(a.mant);
     const bool exact = (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u;
     bool saw_zero = false;
     unsigned inv = 0u;          // max over non-zero blocks of ~bits(block max) = the smallest non-zero block max
+    const float guess = zero_fill_guess(a.ws, exact);
 
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4_pad; i += stride) {
+    auto process = [&](const long long i, const float4 v) {
         const bool valid = i < n4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) v = x4[i];
         float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         bmax = group_max<LPB>(bmax);
         if (LPB == 4 && a.zmap) {   // (uniform) one ballot per wave iteration: which of its sixteen blocks are all zero
             const unsigned long long zb = __ballot(bmax == 0.f && valid);
             if ((threadIdx.x & 63) == 0) a.zmap[i >> 6] = zb;
-            // ... and those blocks are left to the fix-up pass altogether, which writes every one of them (it runs whenever
-            // this kernel has seen one): no arithmetic, no stores for them here
-            if (bmax == 0.f) {
-                saw_zero = saw_zero || valid;
-                continue;
-            }
+            // (the fix-up pass finds the all-zero blocks through the map, without reading x again, should the fill they
+            //  are written with below turn out not to be the tensor's)
         }
-        if (bmax == 0.f) {          // all-zero block: provisional fill 1.0 (what an all-zero tensor gets)
+        if (bmax == 0.f) {          // all-zero block: provisional fill -- the last tensor's (exact mode), else 1.0
             saw_zero = saw_zero || valid;
-            bmax = 1.0f;
+            bmax = guess;
         } else if (exact) {
-            const unsigned v = ~__float_as_uint(bmax);
-            inv = v > inv ? v : inv;
+            const unsigned vb = ~__float_as_uint(bmax);
+            inv = vb > inv ? vb : inv;
         }
         unsigned code;
         const BlockParam bp = block_param<FMT>(bmax, a, lut, code);
@@ -117,6 +127,34 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
                 m4[i] = (unsigned)(q0 & 0xFF) | ((unsigned)(q1 & 0xFF) << 8) | ((unsigned)(q2 & 0xFF) << 16) |
                         ((unsigned)(q3 & 0xFF) << 24);
             if (a.code && (i & (LPB - 1)) == 0) a.code[i / LPB] = (uint8_t)code;
+        }
+    };
+    if constexpr (PIECES == 0) {
+        // tensors that stay in the 256-MiB memory-side cache between calls (activations, weights of one layer): the
+        // grid-stride loop of <= 2048 workgroups -- tables and zero-state once per workgroup, which is what these
+        // launch-bound sizes feel
+        load_lut<FMT>(lut);
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4_pad; i += stride) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n4) v = x4[i];
+            process(i, v);
+        }
+    } else {
+        constexpr int P = PIECES > 0 ? PIECES : 1;
+        const long long i = (long long)blockIdx.x * (256 * P) + threadIdx.x;
+        float4 v[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const long long iu = i + u * 256;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iu < n4) v[u] = x4[iu];
+        }
+        load_lut<FMT>(lut);         // (behind the loads of x: the tables' round trip -- L2 hits -- hides under theirs)
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const long long iu = i + u * 256;           // (a wave's 64 slots are in or out of the padded range together)
+            if (iu < n4_pad) process(iu, v[u]);
         }
     }
     if (exact) publish_zero_state(a.ws, saw_zero, inv);
@@ -166,11 +204,12 @@ __global__ __launch_bounds__(256) void quant_generic_kernel(const QuantArgs a) {
     const bool exact = (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u;
     bool saw_zero = false;
     unsigned inv = 0u;
+    const float guess = zero_fill_guess(a.ws, exact);
     // every lane of a group runs the same trip count (bid is group-uniform)
     for (long long bid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; bid < a.n_blocks; bid += groups) {
         const BlockCursor c = locate(a, bid);
         float bmax = block_absmax16(a, c, lane16);
-        if (bmax == 0.f) { saw_zero = true; bmax = 1.0f; }
+        if (bmax == 0.f) { saw_zero = true; bmax = guess; }
         else if (exact) { const unsigned v = ~__float_as_uint(bmax); inv = v > inv ? v : inv; }
         unsigned code;
         const BlockParam bp = block_param<FMT>(bmax, a, lut, code);
@@ -195,6 +234,7 @@ __global__ __launch_bounds__(256) void quant_generic_kernel(const QuantArgs a) {
 // grid barrier.  Returns at once when kernel 1 met no zero block.  The last workgroup out lowers the flag.
 // ---------------------------------------------------------------------------------------
 constexpr int FIXUP_GRID = 2048;     // (exits at once when kernel 1 met no all-zero block)
+constexpr int FIXUP_GRID_MAP = 2048; // with the zero-block map (tensors >= 128 MiB): 16 KiB of output per workgroup and trip
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -204,7 +244,11 @@ template <int FMT>
 __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int n_slots) {
     __shared__ Lut lut;
     __shared__ unsigned wg_inv[4];
-    if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) return;     // uniform over the grid: nothing to rewrite
+    if (ld_agent(&a.ws[WS_ZERO_FLAG]) == 0u) {           // uniform over the grid: nothing to rewrite
+        // (nobody of this launch reads the slots then: one workgroup clears them for the next call's atomic maxima)
+        if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_slots; i += blockDim.x) a.ws[WS_SLOT0 + i] = 0u;
+        return;
+    }
     load_lut<FMT>(lut);
     const int lane16 = threadIdx.x & 15;
     const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
@@ -226,6 +270,11 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
     const float fill = inv_all == 0u ? 1.0f : __uint_as_float(~inv_all);   // all blocks zero -> 1
     unsigned code;
     const BlockParam bp = block_param<FMT>(fill, a, lut, code);
+    // what kernel 1 wrote the all-zero blocks with: the same block parameters -> the same values, nothing to rewrite
+    unsigned gcode;
+    const BlockParam gbp = block_param<FMT>(zero_fill_guess(a.ws, true), a, lut, gcode);
+    const bool hit = gcode == code && gbp.p == bp.p && __float_as_uint(gbp.eps) == __float_as_uint(bp.eps);
+    if (!hit) {
 
     // Row-vector blocks of 16 (every shipped configuration): one lane per block, four 16-byte loads, and -- every element
     // of an all-zero block being (+/-)0 -- one value for all of them.  A causal attention-probability tensor has half
@@ -245,11 +294,26 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
             const long long n4 = a.n_elems >> 2;
             float4* __restrict__ y4 = reinterpret_cast<float4*>(a.y);
             unsigned* __restrict__ mant4 = reinterpret_cast<unsigned*>(a.mant);
-            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += nthreads) {
-                if (((a.zmap[i >> 6] >> (i & 60)) & 1ull) == 0ull) continue;
-                if (a.y) y4[i] = z4;
-                if (FMT == FMT_BFP && a.mant) mant4[i] = (unsigned)m4;
-                if (a.code && (i & 3) == 0) a.code[i >> 2] = (uint8_t)code;
+            // the non-empty words are broadcast from the lanes that loaded them -- no load in front of any store
+            (void)nthreads;
+            const long long words = (n4 + 63) >> 6;
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            // a workgroup takes 16 consecutive map words per trip (16 KiB of output, 4 words per wave: lanes 0-3 load them)
+            for (long long base = (long long)blockIdx.x * 16 + wave * 4; base < words; base += (long long)gridDim.x * 16) {
+                const unsigned long long mine = lane < 4 && base + lane < words ? a.zmap[base + lane] : 0ull;
+                unsigned long long todo = __ballot(mine != 0ull);
+                while (todo) {
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, j);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), j);
+                    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+                    const long long i = (base + j) * 64 + lane;
+                    if (((w >> (lane & 60)) & 1ull) == 0ull || i >= n4) continue;
+                    if (a.y) y4[i] = z4;
+                    if (FMT == FMT_BFP && a.mant) mant4[i] = (unsigned)m4;
+                    if (a.code && (i & 3) == 0) a.code[i >> 2] = (uint8_t)code;
+                }
             }
         } else {
         const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
@@ -288,12 +352,27 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
         }
         if (a.code && lane16 == 0) a.code[bid] = (uint8_t)code;
     }
-    // exit ticket: the last workgroup out lowers the flag for the next call (every workgroup has read it before it
-    // takes its ticket; the slots need no clearing -- kernel 1 rewrites every slot the next fix-up reads)
+    }
+    // exit ticket: the last workgroup out lowers the flag, clears the slots and leaves this tensor's fill for the next call
+    // (every workgroup has read them before it takes its ticket)
+    __shared__ int last_out;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(&a.ws[WS_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1u) {
+        const unsigned c = blockIdx.x % WS_TICKET_L1_N;
+        const unsigned mates = (gridDim.x + WS_TICKET_L1_N - 1u - c) / WS_TICKET_L1_N;          // workgroups on counter c
+        unsigned* l1 = &a.ws[WS_TICKET_L1 + c * WS_TICKET_L1_STRIDE];
+        last_out = 0;
+        if (__hip_atomic_fetch_add(l1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mates - 1u) {
+            __hip_atomic_store(l1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned groups = gridDim.x < (unsigned)WS_TICKET_L1_N ? gridDim.x : (unsigned)WS_TICKET_L1_N;
+            last_out = __hip_atomic_fetch_add(&a.ws[WS_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
+        }
+    }
+    __syncthreads();
+    if (last_out) {                                       // (every workgroup has read the slots before its ticket)
+        for (int i = threadIdx.x; i < n_slots; i += blockDim.x) a.ws[WS_SLOT0 + i] = 0u;
+        if (threadIdx.x == 0) {
+            a.ws[WS_FILL_GUESS] = __float_as_uint(fill);
             __hip_atomic_store(&a.ws[WS_TICKET], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.ws[WS_ZERO_FLAG], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -424,16 +503,30 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
         //  the map's bookkeeping on the host costs a launch-bound call more than a second read of x would)
         a.zmap = zmap_workspace(st, (size_t)((((a.n_elems >> 2) + 63) & ~63ll) >> 6) * 8);      // (null: the pass reads x again)
     if (vec_ok && (lpb == 1 || lpb == 2 || lpb == 4 || lpb == 8 || lpb == 16 || lpb == 32 || lpb == 64)) {
-        grid = grid_for(a.n_elems >> 2, 256);
+        // (measured, profiles/r03_quantizers_bench.json: the 512-MiB probability tensors gain 10-25 % from owned pieces --
+        //  block_log, whose three tables cost most per workgroup, with 4 of them, the others with 2; up to 172 MiB the
+        //  grid-stride loop is as fast or faster)
+        static const int pieces_env = getenv("MI355Q_QV_PIECES") ? atoi(getenv("MI355Q_QV_PIECES")) : -1;
+        const long long n4_pad = ((a.n_elems >> 2) + 63) & ~63ll;
+        const int pieces = pieces_env == 0 || pieces_env == 1 || pieces_env == 2 || pieces_env == 4 ? pieces_env
+                           : a.n_elems >= (1ll << 26) ? (FMT == FMT_BL ? 4 : 2) : 0;
+        grid = pieces ? (int)((n4_pad + 256ll * pieces - 1) / (256ll * pieces)) : grid_for(a.n_elems >> 2, 256);
+#define QV_LAUNCH(L) \
+        if (pieces == 0) hipLaunchKernelGGL((quant_vec_kernel<FMT, L, 0>), grid, 256, 0, st, a); \
+        else if (pieces == 1) hipLaunchKernelGGL((quant_vec_kernel<FMT, L, 1>), grid, 256, 0, st, a); \
+        else if (pieces == 2) hipLaunchKernelGGL((quant_vec_kernel<FMT, L, 2>), grid, 256, 0, st, a); \
+        else hipLaunchKernelGGL((quant_vec_kernel<FMT, L, 4>), grid, 256, 0, st, a)
+        if (lpb != 4) grid = grid_for(a.n_elems >> 2, 256);
         switch (lpb) {
-            case 1: hipLaunchKernelGGL((quant_vec_kernel<FMT, 1>), grid, 256, 0, st, a); break;
-            case 2: hipLaunchKernelGGL((quant_vec_kernel<FMT, 2>), grid, 256, 0, st, a); break;
-            case 4: hipLaunchKernelGGL((quant_vec_kernel<FMT, 4>), grid, 256, 0, st, a); break;
-            case 8: hipLaunchKernelGGL((quant_vec_kernel<FMT, 8>), grid, 256, 0, st, a); break;
-            case 16: hipLaunchKernelGGL((quant_vec_kernel<FMT, 16>), grid, 256, 0, st, a); break;
-            case 32: hipLaunchKernelGGL((quant_vec_kernel<FMT, 32>), grid, 256, 0, st, a); break;
-            default: hipLaunchKernelGGL((quant_vec_kernel<FMT, 64>), grid, 256, 0, st, a); break;
+            case 1: hipLaunchKernelGGL((quant_vec_kernel<FMT, 1, 0>), grid, 256, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((quant_vec_kernel<FMT, 2, 0>), grid, 256, 0, st, a); break;
+            case 4: QV_LAUNCH(4); break;
+            case 8: hipLaunchKernelGGL((quant_vec_kernel<FMT, 8, 0>), grid, 256, 0, st, a); break;
+            case 16: hipLaunchKernelGGL((quant_vec_kernel<FMT, 16, 0>), grid, 256, 0, st, a); break;
+            case 32: hipLaunchKernelGGL((quant_vec_kernel<FMT, 32, 0>), grid, 256, 0, st, a); break;
+            default: hipLaunchKernelGGL((quant_vec_kernel<FMT, 64, 0>), grid, 256, 0, st, a); break;
         }
+#undef QV_LAUNCH
     } else {
         if (a.ybf) return MI355Q_E_UNSUPPORTED;            // bf16 output: vector path only
         grid = grid_for(a.n_blocks, 16);
@@ -443,7 +536,9 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
     if (e != hipSuccess) return (int)e;
     if (needs_fixup && (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u) {
         // (a grid that exits at once costs its dispatch: 256 workgroups for the launch-bound sizes)
-        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), a.n_elems >= (1 << 24) ? FIXUP_GRID : 256, 256, 0, st, a, grid);
+        static const int fg_env = getenv("MI355Q_FIXUP_GRID") ? atoi(getenv("MI355Q_FIXUP_GRID")) : 0;
+        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), a.zmap ? (fg_env ? fg_env : FIXUP_GRID_MAP) : a.n_elems >= (1 << 24) ? FIXUP_GRID : 256, 256, 0, st, a,
+                           grid < WS_SLOTS ? grid : WS_SLOTS);
         e = hipGetLastError();
     }
     return (int)e;

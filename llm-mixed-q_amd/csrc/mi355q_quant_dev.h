@@ -21,9 +21,15 @@ constexpr float ATOL = 1e-8f;
 
 // workspace words
 constexpr int WS_ZERO_FLAG = 0;   // kernel 1 met an all-zero block
+constexpr int WS_FILL_GUESS = 4;  // fp32 bits of the last fix-up launch's fill (0: none yet), see zero_fill_guess
 constexpr int WS_TICKET = 2;      // fix-up kernel exit ticket (the last workgroup out lowers the flag)
 // one word per workgroup of kernel 1: max over its non-zero blocks of ~bits(block max)
 constexpr int WS_SLOT0 = 64, WS_SLOTS = 2048;
+// exit tickets of the fix-up kernel in two levels: 32 first-level counters a cache line apart (workgroup b takes counter
+// b % 32; the last of each takes a ticket of WS_TICKET) -- thousands of returning atomics on ONE word are served one after the
+// other at ~60 ns each (r03: 2048 workgroups = 125 us, the whole duration of the launch)
+constexpr int WS_TICKET_L1 = WS_SLOT0 + WS_SLOTS, WS_TICKET_L1_N = 32, WS_TICKET_L1_STRIDE = 32;
+static_assert((WS_TICKET_L1 + WS_TICKET_L1_N * WS_TICKET_L1_STRIDE) * 4 <= MI355Q_WORKSPACE_BYTES, "workspace too small for the exit tickets");
 static_assert((WS_SLOT0 + WS_SLOTS) * 4 <= MI355Q_WORKSPACE_BYTES, "workspace too small for the per-workgroup slots");
 
 struct Lut {

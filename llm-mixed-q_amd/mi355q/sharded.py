@@ -28,14 +28,15 @@ def shard_bounds(out_features: int, rank: int, world: int, multiple_of: int = 16
 class RowShardedLinear(nn.Module):
     """Wraps this rank's shard of a (quantised) Linear.  `local` is any module mapping [..., K] -> [..., O/P]."""
 
-    def __init__(self, local: nn.Module, out_features: int, group=None):
+    def __init__(self, local: nn.Module, out_features: int, group=None, always_gather: bool = False):
         super().__init__()
         self.local = local
         self.out_features = out_features
         self.group = group
+        self.always_gather = always_gather      # run the collective at world size 1 too (tests / bench on a 1-GPU box)
 
     @classmethod
-    def from_full(cls, cls_quantized, linear_fp32: nn.Linear, config: dict, group=None):
+    def from_full(cls, cls_quantized, linear_fp32: nn.Linear, config: dict, group=None, always_gather: bool = False):
         """Build this rank's shard from the full-precision layer (every rank holds the checkpoint)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -50,12 +51,12 @@ class RowShardedLinear(nn.Module):
             if part.bias is not None:
                 part.bias.copy_(linear_fp32.bias[lo:hi])
         local = cls_quantized.from_float(part, config).to(linear_fp32.weight.device)
-        return cls(local, linear_fp32.out_features, group)
+        return cls(local, linear_fp32.out_features, group, always_gather)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y_loc = self.local(x)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+        if world == 1 and not (self.always_gather and dist.is_initialized()):
             return y_loc
         lead = y_loc.shape[:-1]
         y2 = y_loc.detach().reshape(-1, y_loc.shape[-1]).contiguous()     # inference path: no autograd through the collective

@@ -40,8 +40,16 @@ def _worker(rank, world, port, q):
             full = torch.nn.Linear(K, N)
             x = (torch.randn(2, M // 2, K) * torch.exp(torch.randn(2, M // 2, 1))).to(dev)
             cls = Q.get_quantized_cls("linear", cfg)
-            sh = RowShardedLinear.from_full(cls, full.to(dev), cfg)
-            y = sh(x)
+            # (always_gather: all_gather_into_tensor over RCCL runs at world size 1 too -- the collective, its rank-major
+            #  layout and the un-permute are exercised on a 1-GPU box, counted below)
+            sh = RowShardedLinear.from_full(cls, full.to(dev), cfg, always_gather=True)
+            calls, real = [], dist.all_gather_into_tensor
+            dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            try:
+                y = sh(x)
+            finally:
+                dist.all_gather_into_tensor = real
+            assert len(calls) == 1, "the RCCL all-gather did not run"
             whole = cls.from_float(full, cfg).to(dev)
             y_ref = whole(x)
             same = bool(torch.equal(y, y_ref))
