@@ -14,7 +14,8 @@ pre-packed weights -> fp32 y (+bias).  FLOPs = 2*M*N*K per step.
 
 N > 1 (one process per GPU, RCCL): the partition BASELINE.json's north_star names -- W split by rows
 (out_features) over the ranks, x replicated, each rank computes y[:, shard], ONE all-gather of the fp32
-shards and the layout fix-up the sharded module does (mi355q/sharded.py) -- the same 4096^3 layer on
+shards into the rank-major [P, M, N/P] buffer, which the next layer's quantiser reads in place as P row segments
+(mi355q/sharded.py ShardedRows, mi355q_block_fp_quantize_aligned_rows_seg: no permute copy) -- the same 4096^3 layer on
 N GPUs: "scaling": "strong".  `--shard tokens` times independent replicas instead (each rank its own
 4096 rows, no collective: weak scaling); the default N > 1 run reports that number too ("replicas").
 
@@ -340,14 +341,14 @@ def main():
         n_out = w.shape[0]
         y = torch.empty(M, n_out, dtype=torch.float32, device=device)
         gathered = torch.empty(world, M, n_out, dtype=torch.float32, device=device) if shard_w else None
-        full = torch.empty(M, world, n_out, dtype=torch.float32, device=device) if shard_w else None
 
         def step():
             xa = quantize_x(x, xw, 8, 127)
             ops.bfp_gemm_aligned(xa, wa, bq, out=y)
             if shard_w:
-                dist.all_gather_into_tensor(gathered.view(world * M, n_out), y)     # rank-major [P, M, N/P]
-                full.copy_(gathered.permute(1, 0, 2))                               # -> y [M, N] (what the module returns)
+                # rank-major [P, M, N/P]: what the sharded module hands on (sharded.ShardedRows); the next mi355q Linear's
+                # quantiser reads the P row segments where they lie, so y [M, N] is never re-assembled
+                dist.all_gather_into_tensor(gathered.view(world * M, n_out), y)
         return step, x, w, b, y
 
     step, x, w, b, y = build(sharded, 0 if sharded or world == 1 else rank)
@@ -399,7 +400,7 @@ def main():
             "config": {"workload": "steady-state PTQ LinearBlockFP forward: x[4096,4096] fp32 -> fused quantise+pack+align (W6, block [1,16]) "
                                    "-> int8-MFMA block GEMM vs pre-packed W[4096,4096] (W6) + bias -> y fp32"
                                    + (f"; W split by out_features over {world} ranks, x replicated, RCCL all-gather of the fp32 shards "
-                                      "+ layout fix-up" if sharded else ""),
+                                      "into the rank-major buffer the next quantiser reads in place (no permute copy)" if sharded else ""),
                        "arithmetic": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 row/block scaling, fp32 y",
                        "M_per_gpu": M, "N": N, "N_per_gpu": n_out, "K": K, "shard": args.shard if world > 1 else "none",
                        "align": args.align, "gemm_variant": ops.set_gemm_variant(args.variant)},

@@ -142,6 +142,18 @@ int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, 
                                                int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
                                                int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
                                                void* stream);
+/* The same reading x as P ROW SEGMENTS: element k of row r at x[(k / seg_len) * seg_stride + r * seg_len + k % seg_len] --
+ * the rank-major result [P][rows][seg_len] of the all-gather that rebuilds a Linear's output from its out_features shards
+ * (BASELINE north_star: "partition the per-layer GEMMs row-wise across the 8 GPUs with RCCL all-gather"; SURVEY 8e;
+ * mi355q/sharded.py).  The next layer's quantiser reads the P pieces where the collective left them, so the [rows, K] tensor
+ * is never re-assembled (a permute copy of rows x K fp32: 20 us at 4096 x 4096).  seg_len % 4 == 0, K % seg_len == 0,
+ * seg_stride % 4 == 0; x2 of MI355Q_PRE_SILU_MUL lies like x; seg_len = 0: plain rows.  Outputs bit-identical to the
+ * plain call on the re-assembled tensor. */
+int mi355q_block_fp_quantize_aligned_rows_seg(const float* x, const float* x2, const float* x3, int32_t pre_op, float eps,
+                                              int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag, float* rowscale,
+                                              int32_t* list, int32_t* list_to_clear, int64_t rows, int64_t K, int64_t seg_len,
+                                              int64_t seg_stride, int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                                              int32_t bucket_cap, void* stream);
 /* ---- true width-bit weight storage ---------------------------------------------------
  * replaces: nothing the reference executes -- it realises the storage its profiler accounts for
  * (quantized_layer_profiler.py:18-27: width bits per value + exponent_width bits per block; README.md:11, 5x memory

@@ -423,6 +423,18 @@ int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, 
                                                int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
                                                int32_t exponent_width, int32_t exponent_bias, int32_t bucket_cap,
                                                void* stream) {
+    return mi355q_block_fp_quantize_aligned_rows_seg(x, x2, x3, pre_op, eps, mant_tiled, exp_out, rowflag, rowscale, list,
+                                                     list_to_clear, rows, K, 0, 0, width, exponent_width, exponent_bias,
+                                                     bucket_cap, stream);
+}
+
+int mi355q_block_fp_quantize_aligned_rows_seg(const float* x, const float* x2, const float* x3, int32_t pre_op, float eps,
+                                              int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag, float* rowscale,
+                                              int32_t* list, int32_t* list_to_clear, int64_t rows, int64_t K, int64_t seg_len,
+                                              int64_t seg_stride, int32_t width, int32_t exponent_width, int32_t exponent_bias,
+                                              int32_t bucket_cap, void* stream) {
+    if (seg_len < 0 || seg_stride < 0) return MI355Q_E_BADARG;
+    if (seg_len > 0 && (seg_len % 4 || seg_stride % 4 || K % seg_len || seg_stride < rows * seg_len)) return MI355Q_E_BADARG;
     if (!pre_op_ok(pre_op, x2, true) || !(eps >= 0.f) || reinterpret_cast<uintptr_t>(x3) % 16) return MI355Q_E_BADARG;
     if (rows < 0 || K < 0 || bucket_cap < MI355Q_ROW_NO_ALIGN || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
     if (rows == 0 || K == 0) return 0;
@@ -449,6 +461,8 @@ int mi355q_block_fp_quantize_aligned_rows_norm(const float* x, const float* x2, 
     a.code_bias = exponent_bias;
     a.e_min = -exponent_bias;
     a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    a.seg_len = seg_len == K ? 0 : seg_len;                 // (one segment: plain rows)
+    a.seg_stride = seg_stride;
     set_mantissa(a, width - 1);
     return launch_quant_align_rows(a, mant_tiled, rowflag, rowscale, exponent_bias + width - 1, list, list_to_clear,
                                    static_cast<hipStream_t>(stream), bucket_cap < 0 ? -1 : bucket_cap_of(bucket_cap));

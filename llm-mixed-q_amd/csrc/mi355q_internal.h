@@ -34,6 +34,9 @@ struct QuantArgs {
     // exact zero-block mode, [1,16] row blocks: kernel 1 leaves one 64-bit ballot per 64 float4 slots (bit 4 b set: block b
     // of those sixteen is all zero) for the fix-up pass, which then visits the zero blocks without reading x again
     unsigned long long* zmap;
+    // aligned-rows quantiser only: x (and the second input of silu_mul) as P row segments, [P][rows][seg_len] with the
+    // segments seg_stride elements apart (0: plain rows) -- mi355q_block_fp_quantize_aligned_rows_seg
+    long long seg_len, seg_stride;
 };
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);

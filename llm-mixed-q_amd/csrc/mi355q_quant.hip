@@ -683,13 +683,19 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
         const long long grp = wi >> 7, in = wi & 127;       // 128 rows = 8 piece rows, one per XCD
         return (grp << 7) + ((in & 7) << 4) + (in >> 3);
     };
+    // float4 f of a row of `base`.  Plain rows: base[row][K].  Segmented rows (a.seg_len > 0: the rank-major result of an
+    // all-gather over out_features shards, [P][rows][seg_len] with the segments a.seg_stride elements apart): element k of
+    // the row sits in segment k / seg_len -- the consumer reads the P pieces where they lie instead of a permuted copy.
+    auto row_f4 = [&](const float* base, long long row, int f) -> const float4* {
+        if (a.seg_len == 0) return reinterpret_cast<const float4*>(base + row * K) + f;
+        const long long k = (long long)f * 4, sgm = k / a.seg_len;
+        return reinterpret_cast<const float4*>(base + sgm * a.seg_stride + row * a.seg_len + (k - sgm * a.seg_len));
+    };
     auto load_row = [&](float4 (&v)[MAXIT], long long row) {
-        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
-        const float4* __restrict__ u4 = reinterpret_cast<const float4*>(a.x2 + row * K);      // (read under pre_op only)
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int kb = it * 64 + wave * 16 + (lane >> 2);
-            v[it] = (FULL || (it < nit && kb < nkb)) ? x4[it * 256 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[it] = (FULL || (it < nit && kb < nkb)) ? *row_f4(a.x, row, it * 256 + tid) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (a.pre_op == MI355Q_PRE_RMSNORM) {                                                  // (uniform)
             // LlamaRMSNorm (modeling_llama.py:88-92): x * rsqrt(mean(x^2) + eps), then weight * that, each product rounded
@@ -759,7 +765,8 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
                 const int kb = it * 64 + wave * 16 + (lane >> 2);
-                if (FULL || (it < nit && kb < nkb)) v[it] = apply_pre(a, v[it], u4, it * 256 + tid);
+                // (the second input of silu_mul lies like x)
+                if (FULL || (it < nit && kb < nkb)) v[it] = apply_pre(a, v[it], row_f4(a.x2, row, it * 256 + tid) - (it * 256 + tid), it * 256 + tid);
             }
         }
     };

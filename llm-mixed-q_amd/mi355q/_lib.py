@@ -21,6 +21,8 @@ SIGNATURES = {
                                                             _i32, _i32, _i32, _vp]),
     "mi355q_block_fp_quantize_aligned_rows_norm": (C.c_int, [_vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                                              _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_block_fp_quantize_aligned_rows_seg": (C.c_int, [_vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                                            _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_block_minifloat_quantize_bf16_tiled": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_bfp_packed_bytes": (C.c_size_t, [_i64, _i64, _i32]),
     "mi355q_bfp_pack_bits": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),

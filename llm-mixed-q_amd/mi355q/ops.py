@@ -752,27 +752,38 @@ def _record_operand(buf, x, sig, operand):
 
 
 def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: int, exponent_bias,
-                                   bucket_cap: int = None, pre=None) -> AlignedOperand:
+                                   bucket_cap: int = None, pre=None, segments: bool = False) -> AlignedOperand:
     """Fused activation path, ROW-aligned flavour: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack +
     row-align + tile in one kernel (K % 64 == 0, K <= ROW_ALIGN_MAX_K).  Buffers are reused per shape and
     stream like block_fp_quantize_aligned's.  `bucket_cap`: exception entries per 256 rows (default
     ACTIVATION_BUCKET_CAP); anything but 120 makes the GEMM add x's exceptions in its row post-pass; ROW_NO_ALIGN (-1):
-    no alignment at all, every block keeps its exponent and the GEMM takes its blockwise-exact kernel."""
+    no alignment at all, every block keeps its exponent and the GEMM takes its blockwise-exact kernel.
+    `segments`: x is [P, rows, K / P] -- the rank-major result of the all-gather over out_features shards
+    (sharded.ShardedRows): row r of the [rows, K] tensor is the concatenation of x[0, r], x[1, r], ...; read in place
+    (mi355q_block_fp_quantize_aligned_rows_seg), the same operand as from the re-assembled tensor."""
     bucket_cap = ACTIVATION_BUCKET_CAP if bucket_cap is None else int(bucket_cap)
     _require_device(x, "block_fp_quantize_aligned_rows")
-    assert x.ndim == 2 and x.shape[1] % 64 == 0 and x.shape[1] <= ROW_ALIGN_MAX_K
-    rows, K = x.shape
+    if segments:
+        assert x.ndim == 3 and x.is_contiguous() and x.shape[2] % 4 == 0 and (pre is None or pre[0] == "relu")
+        nseg, rows, seg_len = x.shape
+        K = nseg * seg_len
+    else:
+        assert x.ndim == 2
+        rows, K = x.shape
+        nseg, seg_len = 1, 0
+    assert K % 64 == 0 and K <= ROW_ALIGN_MAX_K
     sp = _stream_ptr(x.device)
     buf = _ActivationBuffers.get(x.device, rows, K, row_aligned=True, sp=sp, bucket_cap=bucket_cap)
     bias = _default_bias(exponent_bias)
     # (the record is only good inside the capture sequence -- or the eager stretch -- it was made in: a hit while a graph
     #  is being recorded on a record from the warm-up would leave the quantiser out of the graph)
-    sig = (int(width), int(exponent_width), bias, bucket_cap, _lib.load_library().mi355q_stream_capture_id(sp))
+    sig = (int(width), int(exponent_width), bias, bucket_cap, _lib.load_library().mi355q_stream_capture_id(sp), nseg)
     again = _recorded_operand(buf, x, sig) if pre is None else None
     if again is not None:
         return again
     xc = x.contiguous()
-    pre_op, other, eps, third = _pre_args(xc, pre)    # (`pre`: quantise relu(x) / silu(x) * other / norm(x) instead of x)
+    # (`pre`: quantise relu(x) / silu(x) * other / norm(x) instead of x)
+    pre_op, other, eps, third = (PRE_OPS[pre[0]] if pre else PRE_NONE, None, 0.0, None) if segments else _pre_args(xc, pre)
     lib = _lib.load_library()
     if _capturing() and bucket_cap >= 0:
         # HIP-graph capture: a replayed node always sees the pointers it was captured with, so the two alternating lists
@@ -783,11 +794,11 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
         cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
         buf["calls"] += 1
     with _on_device(x.device):
-        rc = lib.mi355q_block_fp_quantize_aligned_rows_norm(_ptr(xc), _ptr(other), _ptr(third), pre_op, eps, _ptr(buf["tiled"]),
-                                                            _ptr(buf["exp"]), _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur),
-                                                            _ptr(nxt), rows, K, int(width), int(exponent_width), bias,
-                                                            bucket_cap, sp)
-    _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows_norm")
+        rc = lib.mi355q_block_fp_quantize_aligned_rows_seg(_ptr(xc), _ptr(other), _ptr(third), pre_op, eps, _ptr(buf["tiled"]),
+                                                           _ptr(buf["exp"]), _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur),
+                                                           _ptr(nxt), rows, K, seg_len, rows * seg_len, int(width),
+                                                           int(exponent_width), bias, bucket_cap, sp)
+    _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows_seg")
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
     operand = AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
                              int(width) - 1, eb, row_aligned=True, bucket_cap=bucket_cap)

@@ -293,6 +293,17 @@ class _LinearBase(nn.Linear):
         return 8.0 * self._packed[1].numel() / n
 
     def forward(self, x):
+        from ...sharded import ShardedRows
+        if isinstance(x, ShardedRows):
+            # the gathered output of a row-sharded layer, still in the collective's rank-major layout: the row-aligned int8
+            # route reads it in place; every other route takes the re-assembled tensor
+            if (not self.bypass and self.is_ptq and not self.weight_requires_quantisation and self._packed_is_current()
+                    and self._align_mode == "rows" and not self._uses_bf16_route()):
+                plan = self._int8_plan(x.buf[0])
+                if plan is not None:
+                    with torch.no_grad():
+                        return self._forward_int8(x, plan)
+            x = x.dense()
         if self.bypass:
             return F.linear(x, self.weight, self.bias)
         if self.is_ptq:
@@ -380,7 +391,9 @@ class _LinearBase(nn.Linear):
     def _forward_int8(self, x, plan, pre=None):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
-        x2 = x.reshape(-1, self.in_features)
+        from ...sharded import ShardedRows
+        segments = isinstance(x, ShardedRows)                  # (forward() sends these here on the row-aligned route only)
+        x2 = x.buf if segments else x.reshape(-1, self.in_features)
         if self._uses_bf16_route():
             # Activations (or weights) no row window fits: every block keeps its exponent.  A block_fp value of width <= 9
             # is exact in bf16 and a product of two of them exact in fp32, so the product is the bf16 flavour of the tile
@@ -402,7 +415,8 @@ class _LinearBase(nn.Linear):
             return y.reshape(*x.shape[:-1], self.out_features)
         if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
             xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
-                                                    c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre)
+                                                    c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre,
+                                                    segments=segments)
         elif self.in_features % 256 == 0:    # the same per 256-value group
             xa = ops.block_fp_quantize_aligned(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                c["data_in_exponent_bias"])

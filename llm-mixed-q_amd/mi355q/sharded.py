@@ -25,18 +25,44 @@ def shard_bounds(out_features: int, rank: int, world: int, multiple_of: int = 16
     return rank * per, (rank + 1) * per
 
 
+class ShardedRows:
+    """The gathered output of a RowShardedLinear as the collective leaves it: `buf` [P, M, O/P], rank-major -- row m of the
+    [M, O] result is the concatenation of buf[0, m], buf[1, m], ...  A following mi355q Linear reads it in place (its x
+    quantiser takes P row segments: ops.block_fp_quantize_aligned_rows(segments=True)); anything else calls dense(), the
+    permute copy (M x O fp32 read and written: 20 us at 4096 x 4096) this object exists to avoid."""
+
+    def __init__(self, buf: torch.Tensor, lead: tuple):
+        assert buf.ndim == 3 and buf.is_contiguous()
+        self.buf, self.lead = buf, tuple(lead)
+
+    @property
+    def shape(self):
+        return torch.Size((*self.lead, self.buf.shape[0] * self.buf.shape[2]))
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def dense(self) -> torch.Tensor:
+        p, m, seg = self.buf.shape
+        return self.buf.permute(1, 0, 2).reshape(*self.lead, p * seg)
+
+
 class RowShardedLinear(nn.Module):
     """Wraps this rank's shard of a (quantised) Linear.  `local` is any module mapping [..., K] -> [..., O/P]."""
 
-    def __init__(self, local: nn.Module, out_features: int, group=None, always_gather: bool = False):
+    def __init__(self, local: nn.Module, out_features: int, group=None, always_gather: bool = False, gather: str = "dense"):
         super().__init__()
         self.local = local
         self.out_features = out_features
         self.group = group
         self.always_gather = always_gather      # run the collective at world size 1 too (tests / bench on a 1-GPU box)
+        assert gather in ("dense", "segments")
+        self.gather = gather                    # "segments": return the ShardedRows, no permute copy
 
     @classmethod
-    def from_full(cls, cls_quantized, linear_fp32: nn.Linear, config: dict, group=None, always_gather: bool = False):
+    def from_full(cls, cls_quantized, linear_fp32: nn.Linear, config: dict, group=None, always_gather: bool = False,
+                  gather: str = "dense"):
         """Build this rank's shard from the full-precision layer (every rank holds the checkpoint)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -51,15 +77,18 @@ class RowShardedLinear(nn.Module):
             if part.bias is not None:
                 part.bias.copy_(linear_fp32.bias[lo:hi])
         local = cls_quantized.from_float(part, config).to(linear_fp32.weight.device)
-        return cls(local, linear_fp32.out_features, group, always_gather)
+        return cls(local, linear_fp32.out_features, group, always_gather, gather)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y_loc = self.local(x)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1 and not (self.always_gather and dist.is_initialized()):
-            return y_loc
+            return ShardedRows(y_loc.detach().reshape(1, -1, y_loc.shape[-1]).contiguous(), y_loc.shape[:-1]) \
+                if self.gather == "segments" else y_loc
         lead = y_loc.shape[:-1]
         y2 = y_loc.detach().reshape(-1, y_loc.shape[-1]).contiguous()     # inference path: no autograd through the collective
         gathered = torch.empty(world * y2.shape[0], y2.shape[1], dtype=y2.dtype, device=y2.device)
         dist.all_gather_into_tensor(gathered, y2, group=self.group)          # rank-major: [P * M, O/P]
+        if self.gather == "segments":
+            return ShardedRows(gathered.view(world, y2.shape[0], y2.shape[1]), lead)
         return gathered.view(world, y2.shape[0], y2.shape[1]).permute(1, 0, 2).reshape(*lead, self.out_features)

@@ -454,7 +454,7 @@ def test_shared_activation_is_quantised_once():
     layers = [Q.get_quantized_cls("linear", cfg)(256, 128, bias=True, config=dict(cfg)).to(dev) for _ in range(3)]
     x = torch.randn(2, 96, 256, device=dev)
     lib = _lib.load_library()
-    real = lib.mi355q_block_fp_quantize_aligned_rows_norm
+    real = lib.mi355q_block_fp_quantize_aligned_rows_seg
     calls = []
 
     def counting(*a):
@@ -468,7 +468,7 @@ def test_shared_activation_is_quantised_once():
         ref = [l(x).clone() for l in layers]
         ops.REUSE_QUANTISED_INPUT = True
         layers[0](x.clone())                                 # (another tensor of the shape: the record no longer names x)
-        lib.mi355q_block_fp_quantize_aligned_rows_norm = counting
+        lib.mi355q_block_fp_quantize_aligned_rows_seg = counting
         try:
             out = [l(x).clone() for l in layers]
             assert len(calls) == 1, len(calls)
@@ -488,7 +488,7 @@ def test_shared_activation_is_quantised_once():
             ops.REUSE_QUANTISED_INPUT = False
             assert torch.equal(got, layers[2](z))
         finally:
-            lib.mi355q_block_fp_quantize_aligned_rows_norm = real
+            lib.mi355q_block_fp_quantize_aligned_rows_seg = real
             ops.REUSE_QUANTISED_INPUT = True
 
 

@@ -288,3 +288,43 @@ def test_zero_block_fill_speculation_hits_and_misses(name):
         gw, ww = got.view(np.uint32), want.view(np.uint32)
         assert np.array_equal(gw | np.where(got == 0, np.uint32(0x80000000), np.uint32(0)),
                               ww | np.where(want == 0, np.uint32(0x80000000), np.uint32(0))), (name, step)
+
+
+@pytest.mark.parametrize("rows,K,P,relu", [(300, 4096, 8, False), (256, 2048, 4, True), (256, 2048, 4, False), (70, 11008, 8, False),
+                                            (512, 1024, 1, False)])
+def test_aligned_rows_quantiser_reads_row_segments_in_place(rows, K, P, relu):
+    """mi355q_block_fp_quantize_aligned_rows_seg: x as the rank-major [P, rows, K / P] result of an all-gather over
+    out_features shards == the plain call on the re-assembled [rows, K] tensor, every output buffer byte for byte"""
+    import torch
+    from mi355q import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, 1, generator=g))).to(dev)
+    x[::5, 64:80] *= 2.0 ** -12                         # blocks below their row's window: exception entries
+    seg = x.view(rows, P, K // P).permute(1, 0, 2).contiguous()          # what the collective leaves
+    pre = ("relu", None) if relu else None
+    w = torch.randn(256, K, generator=g).to(dev) * 0.05
+    _, wm, we = ops.block_fp_quantize(w, 6, 8, 127, [1, 16], False, want_fake=False, want_packed=True, fast_zero_blocks=True)
+    wa = ops.bfp_align_rows(wm, we, 5, 127)
+    prev = ops.REUSE_QUANTISED_INPUT
+    ops.REUSE_QUANTISED_INPUT = False
+    try:
+        a = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127, pre=pre)
+        keep = [t.clone() for t in (a.tiled, a.exp, a.rowflag, a.gscale)]
+        ya = ops.bfp_gemm_aligned(a, wa).clone()
+        c = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127, pre=pre)
+        again = [t.clone() for t in (c.tiled, c.exp, c.rowflag, c.gscale)]
+        b = ops.block_fp_quantize_aligned_rows(seg, 6, 8, 127, pre=pre, segments=True)
+        yb = ops.bfp_gemm_aligned(b, wa)
+    finally:
+        ops.REUSE_QUANTISED_INPUT = prev
+    # (rows of one 256-row bucket take their exception slots in arrival order and settle for a wider window when the bucket
+    #  runs full: with contended buckets the operand's bytes differ from call to call -- never the product -- so the bytes
+    #  are compared whenever two plain calls agree on them)
+    if all(torch.equal(u, v) for u, v in zip(keep, again)):
+        for name, u, v in zip(("tiled", "exp", "rowflag", "rowscale"), keep, (b.tiled, b.exp, b.rowflag, b.gscale)):
+            assert torch.equal(u, v), name
+        assert torch.equal(ya, yb)
+    else:
+        assert relu
+    assert float((ya - yb).abs().max()) <= 2e-6 * float(ya.abs().max())

@@ -31,6 +31,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         import mi355q.quantize as Q
+        from mi355q import ops
         from mi355q.sharded import RowShardedLinear
         from oracle import np_oracle as O
         res = []
@@ -56,6 +57,22 @@ def _worker(rank, world, port, q):
             ref = O.bfp_linear_int(x[0, :16].cpu().numpy(), full.weight.detach().cpu().numpy(),
                                    full.bias.detach().cpu().numpy(), cfg)
             err = float((y[0, :16].cpu() - torch.from_numpy(ref)).abs().max() / abs(ref).max())
+            # gathered in the collective's own layout and handed to the next Linear as it lies (ShardedRows: the x quantiser reads
+            # P row segments): the same bits as from the re-assembled tensor
+            torch.manual_seed(8)
+            nxt = cls.from_float(torch.nn.Linear(N, 512), cfg).to(dev)
+            z_ref = nxt(y_ref)
+            z_ref = nxt(y_ref)                       # (second call: packed weights, row-aligned route decided)
+            seg = RowShardedLinear.from_full(cls, full.to(dev), cfg, always_gather=True, gather="segments")(x)
+            same = same and tuple(seg.buf.shape) == (world, M, N // world) and bool(torch.equal(seg.dense(), y_ref))
+            took = []
+            real_q = ops.block_fp_quantize_aligned_rows
+            ops.block_fp_quantize_aligned_rows = lambda *a, **k: (took.append(k.get("segments", False)), real_q(*a, **k))[1]
+            try:
+                z = nxt(seg)
+            finally:
+                ops.block_fp_quantize_aligned_rows = real_q
+            same = same and bool(torch.equal(z, z_ref)) and (took == [True] or nxt._align_mode != "rows")
             res.append((width, same, err, tuple(y.shape), sh.local._packed is not None))
         q.put((rank, res))
     except Exception as e:

@@ -30,7 +30,14 @@ def _worker(rank, world, port, out_q):
         x = torch.randn(3, 5, 64)
         y = sh(x)
         ref = full(x)
-        out_q.put((rank, bool(torch.allclose(y, ref, rtol=1e-5, atol=1e-6)), tuple(y.shape)))
+        # the same gathered in the collective's own rank-major layout (no permute copy): dense() re-assembles it, a following
+        # bypassed Linear takes it through dense() as well
+        seg = RowShardedLinear.from_full(cls, full, cfg, gather="segments")(x)
+        nxt = torch.nn.Linear(96, 16)
+        nq = cls.from_float(nxt, cfg)
+        ok = (tuple(seg.buf.shape) == (world, 15, 96 // world) and seg.shape == y.shape and torch.equal(seg.dense(), y)
+              and torch.allclose(nq(seg), nxt(ref), rtol=1e-5, atol=1e-6))
+        out_q.put((rank, bool(torch.allclose(y, ref, rtol=1e-5, atol=1e-6)) and bool(ok), tuple(y.shape)))
     except Exception as e:          # report instead of leaving the parent waiting on the queue
         out_q.put((rank, False, repr(e)))
     finally:
