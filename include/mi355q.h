@@ -83,6 +83,17 @@ int mi355q_block_fp_quantize(const float* x, float* y, int8_t* mant, uint8_t* ex
 int mi355q_block_fp_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int64_t rows, int64_t cols,
                                   int32_t b0, int32_t b1, int32_t width, int32_t exponent_width,
                                   int32_t exponent_bias, void* workspace, void* stream);
+/* The same for the other two block formats -- the operands of the reference's matmul_block_minifloat / matmul_block_log
+ * (quantized_functions/matmul.py:199-249, 252-297) when the product runs on bf16 MFMAs: block_minifloat values carry at most
+ * 7 mantissa bits here (more: MI355Q_E_UNSUPPORTED), block_log values are signed powers of two -- both exact in bf16, and a
+ * product of two of them exact in fp32.  block_minifloat: all-zero blocks stay zero (no fix-up pass); block_log: the exact
+ * zero-block rule (the tensor-global fill), [1,16] row blocks only (b0 == 1, b1 == 16, cols % 16 == 0, y 16-byte aligned),
+ * workspace as for mi355q_block_log_quantize. */
+int mi355q_block_minifloat_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int64_t rows, int64_t cols, int32_t b0,
+                                         int32_t b1, int32_t width, int32_t exponent_width, int32_t exponent_bias_width,
+                                         void* workspace, void* stream);
+int mi355q_block_log_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int64_t rows, int64_t cols, int32_t b0,
+                                   int32_t b1, int32_t width, int32_t exponent_bias_width, void* workspace, void* stream);
 
 /* ---- operands whose blocks keep their own exponents: bf16 flavour of the tile GEMM ----------------
  * replaces: quantized_modules/linear.py:59-76 for inputs no row window fits (post-SiLU / post-ReLU activations, weights

@@ -265,6 +265,45 @@ int mi355q_block_log_quantize(const float* x, float* y, uint8_t* bias, int64_t l
     return launch_quant(a, 2, /*needs_fixup=*/true, static_cast<hipStream_t>(stream));
 }
 
+// the block_minifloat / block_log fake-quantised values straight to bf16 (exact: <= 7 mantissa bits / signed powers of two;
+// elements with |x| <= 1e-8, which the reference passes through, are rounded to bf16): the operands of a bf16-MFMA product
+int mi355q_block_minifloat_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int64_t rows, int64_t cols, int32_t b0,
+                                         int32_t b1, int32_t width, int32_t exponent_width, int32_t exponent_bias_width,
+                                         void* workspace, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, nullptr, workspace, lead, rows, cols, b0, b1, MI355Q_ZERO_BLOCK_FAST);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y == nullptr) return MI355Q_E_BADARG;
+    const int mbits = width - exponent_width - 1;
+    if (exponent_width < 1 || exponent_width > 8 || mbits < 0) return MI355Q_E_BADARG;
+    if (mbits > 7) return MI355Q_E_UNSUPPORTED;              // a quantised value must fit bf16's 8 significant bits
+    if (exponent_bias_width < 1 || exponent_bias_width > 8) return MI355Q_E_BADARG;
+    a.ybf = y;
+    a.span = (1 << exponent_width) - 1;
+    a.bias_max = (1 << exponent_bias_width) - 1;
+    set_mantissa(a, mbits);
+    return launch_quant(a, 1, /*needs_fixup=*/false, static_cast<hipStream_t>(stream));     // (an all-zero block stays zero)
+}
+
+int mi355q_block_log_quantize_bf16(const float* x, uint16_t* y, int64_t lead, int64_t rows, int64_t cols, int32_t b0,
+                                   int32_t b1, int32_t width, int32_t exponent_bias_width, void* workspace, void* stream) {
+    QuantArgs a;
+    const int rc = fill_common(a, x, nullptr, workspace, lead, rows, cols, b0, b1, 0u);
+    if (rc == (1 << 30)) return 0;
+    if (rc) return rc;
+    if (y == nullptr) return MI355Q_E_BADARG;
+    if (width < 2 || width > 9) return MI355Q_E_BADARG;
+    if (exponent_bias_width < 1 || exponent_bias_width > 8) return MI355Q_E_BADARG;
+    // (all-zero blocks take the tensor-global fill -- a non-zero value here: the fix-up pass writes bf16 in its row-block form only)
+    if (b0 != 1 || b1 != 16 || cols % 16 || reinterpret_cast<uintptr_t>(y) % 16) return MI355Q_E_UNSUPPORTED;
+    a.ybf = y;
+    a.span = (1 << (width - 1)) - 1;
+    a.bias_max = (1 << exponent_bias_width) - 1;
+    set_mantissa(a, 0);
+    return launch_quant(a, 2, /*needs_fixup=*/true, static_cast<hipStream_t>(stream));
+}
+
 int mi355q_minifloat_quantize(const float* x, float* y, int64_t n, int32_t width, int32_t exponent_width, int32_t exponent_bias,
                               int32_t denorm, void* stream) {
     if (n < 0) return MI355Q_E_BADARG;

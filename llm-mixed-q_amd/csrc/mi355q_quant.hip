@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
         o.w = quant_elem<FMT>(v.w, bp, a, lut, q3);
         if (valid) {
             if (a.y) y4[i] = o;
-            if (FMT == FMT_BFP && a.ybf)
+            if (a.ybf)          // (block_fp of <= 9 bits, minifloats of <= 7 mantissa bits, signed powers of two: exact in bf16)
                 reinterpret_cast<uint2*>(a.ybf)[i] = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
             if (FMT == FMT_BFP && a.mant)
                 m4[i] = (unsigned)(q0 & 0xFF) | ((unsigned)(q1 & 0xFF) << 8) | ((unsigned)(q2 & 0xFF) << 16) |
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
                     const long long i = (base + j) * 64 + lane;
                     if (((w >> (lane & 60)) & 1ull) == 0ull || i >= n4) continue;
                     if (a.y) y4[i] = z4;
+                    if (a.ybf) reinterpret_cast<uint2*>(a.ybf)[i] = make_uint2(pack_bf16(zv, zv), pack_bf16(zv, zv));
                     if (FMT == FMT_BFP && a.mant) mant4[i] = (unsigned)m4;
                     if (a.code && (i & 3) == 0) a.code[i >> 2] = (uint8_t)code;
                 }
@@ -327,6 +328,11 @@ __global__ __launch_bounds__(256) void zero_fixup_kernel(const QuantArgs a, int 
             if (a.y) {
                 float4* __restrict__ y4 = reinterpret_cast<float4*>(a.y) + bid * 4;
                 y4[0] = z4; y4[1] = z4; y4[2] = z4; y4[3] = z4;
+            }
+            if (a.ybf) {
+                const unsigned zz = pack_bf16(zv, zv);
+                uint4* __restrict__ yb = reinterpret_cast<uint4*>(a.ybf + bid * 16);
+                yb[0] = make_uint4(zz, zz, zz, zz); yb[1] = make_uint4(zz, zz, zz, zz);
             }
             // (the mantissa of a zero element under the global fill is round(1e-9 * 2^(mbits - e)): not zero when the
             //  fill's exponent is tiny)

@@ -15,6 +15,8 @@ SIGNATURES = {
     "mi355q_abi_version": (C.c_int, []),
     "mi355q_error_string": (C.c_char_p, [C.c_int]),
     "mi355q_block_fp_quantize_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mi355q_block_minifloat_quantize_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mi355q_block_log_quantize_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize_bf16_tiled": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize_bf16_tiled_pre": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize_aligned_rows_pre": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,

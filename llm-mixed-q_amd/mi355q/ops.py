@@ -158,6 +158,42 @@ def block_fp_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exp
     return y
 
 
+def block_minifloat_quantize_bf16(x: torch.Tensor, width: int, exponent_width: int, exponent_bias_width: int, block_size,
+                                  skip_first_dim: bool) -> torch.Tensor:
+    """block_minifloat fake-quantisation straight to bf16 (<= 7 mantissa bits: exact), row-vector blocks tiling the last dim
+    through one kernel (4 B read + 2 B written per element), anything else through the fp32 quantiser and a cast"""
+    _require_device(x, "block_minifloat_quantize_bf16")
+    assert int(width) - int(exponent_width) - 1 <= 7, "a minifloat with more than 7 mantissa bits is not exact in bf16"
+    lead, rows, cols, b0, b1 = resolve_blocking(x.shape, block_size, skip_first_dim)
+    if b0 != 1 or cols % b1 != 0 or b1 % 4 != 0:
+        return block_minifloat_quantize(x, width, exponent_width, exponent_bias_width, block_size, skip_first_dim).to(torch.bfloat16)
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load_library()
+    with _on_device(x.device):
+        rc = lib.mi355q_block_minifloat_quantize_bf16(_ptr(xc), _ptr(y), lead, rows, cols, b0, b1, int(width), int(exponent_width),
+                                                      int(exponent_bias_width), _ptr(_workspace(x.device)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_minifloat_quantize_bf16")
+    return y
+
+
+def block_log_quantize_bf16(x: torch.Tensor, width: int, exponent_bias_width: int, block_size, skip_first_dim: bool) -> torch.Tensor:
+    """block_log fake-quantisation straight to bf16 (signed powers of two: exact), [1,16] row blocks through one kernel (+ the
+    zero-block fix-up when the fill guess misses), anything else through the fp32 quantiser and a cast"""
+    _require_device(x, "block_log_quantize_bf16")
+    lead, rows, cols, b0, b1 = resolve_blocking(x.shape, block_size, skip_first_dim)
+    if b0 != 1 or b1 != 16 or cols % 16 != 0:
+        return block_log_quantize(x, width, exponent_bias_width, block_size, skip_first_dim).to(torch.bfloat16)
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load_library()
+    with _on_device(x.device):
+        rc = lib.mi355q_block_log_quantize_bf16(_ptr(xc), _ptr(y), lead, rows, cols, b0, b1, int(width), int(exponent_bias_width),
+                                                _ptr(_workspace(x.device)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_log_quantize_bf16")
+    return y
+
+
 class _StreamCache:
     """Per-(device, stream, shape ...) device buffers whose raw pointers the library's kernels are launched with.  Least-
     recently-used eviction PER STREAM (never wholesale), and none at all for a stream that has recorded a HIP graph: the

@@ -73,11 +73,41 @@ class _LinearBase(nn.Linear):
         #   mi355q_keep_master = True: keep the fp32 weights / bias the layer was given, so that requantize() can quantise
         #       them again (other widths included) without a checkpoint reload (the search loop)
         self._w_packed = None
+        self._pending_flavour = None
         self._master = None
         self._fp32_released = False
         self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
         if not self.bypass:
             self._setup_quantizers(config)
+        if self._packs_at_load():
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module._loaded_new_weights())
+
+    # ---- mi355q_weight_storage = "packed": the weights are quantised and packed WHEN THEY ARRIVE -- when the module reaches
+    #      the GPU (from_float(...).to(device), model.to(device)) and when a state dict is loaded into it -- not at the first
+    #      forward: a model loaded for inference holds width + 0.5 bits per weight before it has seen a token (SURVEY 8f.2,
+    #      quantized_modules/linear.py:66-70 is where the reference does the same work, at the first forward)
+    def _packs_at_load(self) -> bool:
+        return (not self.bypass and self.is_ptq and self.arith == "block_fp"
+                and self.config.get("mi355q_weight_storage", "int8") == "packed")
+
+    def _pack_if_arrived(self):
+        if self._packs_at_load() and self.weight_requires_quantisation and self.weight.is_cuda and self.weight.numel():
+            self.pack_now()
+
+    def _loaded_new_weights(self):
+        with torch.no_grad():
+            self.weight_requires_quantisation = True          # (fresh fp32 values: quantise them again)
+            self._packed, self._w_bf16, self._w_packed, self._pending_flavour = None, None, None, None
+            if self._master is not None:
+                self._master = (self.weight.detach().clone(), None if self.bias is None else self.bias.detach().clone())
+            self._pack_if_arrived()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if self.__dict__.get("config") is not None:
+            with torch.no_grad():
+                self._pack_if_arrived()
+        return out
 
     def _setup_quantizers(self, config: dict):
         self.x_quantizer = _make_quantizer(self.arith, config, "data_in", True)
@@ -135,21 +165,39 @@ class _LinearBase(nn.Linear):
             self.bias.copy_(self.b_quantizer(self.bias.data))
         self.weight_requires_quantisation = False
         if pack:
-            self._align_weights(wm, we, self._choose_align_mode(wm, we, x_sample))
-            versions = (self.weight._version, None if self.bias is None else self.bias._version)
-            packed_storage = c.get("mi355q_weight_storage", "int8") == "packed" and self._align_mode == "rows"
-            if self._uses_bf16_route():
-                # per-block exponents: the quantised weights (already in .weight) as tiled bf16; the int8 operand is not
-                # needed on this route (the exact-integer blockwise kernel, mi355q_blocks_gemm = "int8", keeps it)
-                if packed_storage:
-                    self._w_packed = ops.pack_block_exponent_weights(wm, we, c["weight_width"], self._weight_bias_value())
-                    self._packed = (None, self._w_packed.packed, *versions)
-                else:
-                    self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
-                    self._packed = (None, self._w_bf16[0], *versions)
-            elif packed_storage and self._x_cap != ops.ROW_NO_ALIGN:
-                self._w_packed = ops.pack_row_aligned_weights(wm, we, self._packed[0], c["weight_width"], self._weight_bias_value())
+            self._pack_operands(wm, we, x_sample)
+            # packed on arrival (no activation seen yet, `_pack_if_arrived`): the integers stay until the first forward has
+            # decided which flavour the layer's activations call for (`_finalise_packed_flavour`)
+            self._pending_flavour = (wm, we) if x_sample is None and self._packs_at_load() else None
+
+    def _pack_operands(self, wm, we, x_sample):
+        c = self.config
+        self._align_weights(wm, we, self._choose_align_mode(wm, we, x_sample))
+        versions = (self.weight._version, None if self.bias is None else self.bias._version)
+        packed_storage = c.get("mi355q_weight_storage", "int8") == "packed" and self._align_mode == "rows"
+        self._w_packed = None
+        if self._uses_bf16_route():
+            # per-block exponents: the quantised weights (already in .weight) as tiled bf16; the int8 operand is not
+            # needed on this route (the exact-integer blockwise kernel, mi355q_blocks_gemm = "int8", keeps it)
+            if packed_storage:
+                self._w_packed = ops.pack_block_exponent_weights(wm, we, c["weight_width"], self._weight_bias_value())
                 self._packed = (None, self._w_packed.packed, *versions)
+            else:
+                self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+                self._packed = (None, self._w_bf16[0], *versions)
+        elif packed_storage and self._x_cap != ops.ROW_NO_ALIGN:
+            self._w_packed = ops.pack_row_aligned_weights(wm, we, self._packed[0], c["weight_width"], self._weight_bias_value())
+            self._packed = (None, self._w_packed.packed, *versions)
+
+    @torch.no_grad()
+    def _finalise_packed_flavour(self, x):
+        """first forward of a layer that packed its weights on arrival: the activation-dependent half of the route decision
+        (`_choose_align_mode`), from the kept integers; then they go"""
+        wm, we = self._pending_flavour
+        self._pending_flavour = None
+        if not self._fp32_released and self._packed is not None:
+            self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
+            self._pack_operands(wm, we, x)
 
     def _weight_bias_value(self):
         c = self.config
@@ -253,7 +301,7 @@ class _LinearBase(nn.Linear):
             raise RuntimeError("mi355q: requantize() needs fp32 weights: they were released and no master copy is kept")
         self.weight_requires_quantisation = True if self.is_ptq else False
         self._packed, self._align_mode, self._calls, self._row_overflows = None, None, 0, 0
-        self._w_bf16, self._w_packed = None, None
+        self._w_bf16, self._w_packed, self._pending_flavour = None, None, None
         self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
 
     @torch.no_grad()
@@ -298,6 +346,7 @@ class _LinearBase(nn.Linear):
             # the gathered output of a row-sharded layer, still in the collective's rank-major layout: the row-aligned int8
             # route reads it in place; every other route takes the re-assembled tensor
             if (not self.bypass and self.is_ptq and not self.weight_requires_quantisation and self._packed_is_current()
+                    and self._pending_flavour is None
                     and self._align_mode == "rows" and not self._uses_bf16_route()):
                 plan = self._int8_plan(x.buf[0])
                 if plan is not None:
@@ -312,6 +361,8 @@ class _LinearBase(nn.Linear):
             with torch.no_grad():
                 if self.weight_requires_quantisation:
                     self._quantise_weights_once(pack=plan is not None, x_sample=x)
+                elif self._pending_flavour is not None:
+                    self._finalise_packed_flavour(x)
                 p = self._packed
                 if (plan is not None and p is not None and p[1].device != self.weight.device
                         and p[2] == self.weight._version and (self.bias is None or p[3] == self.bias._version)):

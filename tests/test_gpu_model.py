@@ -422,11 +422,15 @@ def test_fused_norm_knobs_only_in_the_linear_section(tag):
     assert abs(float(loss) - ref_loss) < 2e-5
 
 
-@pytest.mark.parametrize("arith", ["block_log", "block_minifloat"])
-def test_tiny_llama_loss_parity_other_block_arithmetics(arith):
+@pytest.mark.parametrize("arith,products", [("block_log", "fp32"), ("block_minifloat", "fp32"), ("block_minifloat", "bf16")])
+def test_tiny_llama_loss_parity_other_block_arithmetics(arith, products):
     """BASELINE configs 3 / 5 name Llama with block_minifloat and block_log: the Llama-style harness under those
     arithmetics (HIP fake-quantisers, products of the Linear layers on the bf16 tile GEMM, the registry's matmul / rotary
-    functions of that arithmetic) against the oracle's model forward"""
+    functions of that arithmetic) against the oracle's model forward.  `products`: the 4-D attention products through the
+    fp32 fake-quantised tensors, or (block_minifloat's default) as bf16 operands on bf16 MFMAs -- every product within 4e-8
+    of the other route (summation order), but this model (weights x 40: a loss of 37) turns last-bit differences into
+    rounding flips: its loss moves by 0.4 %, so the bf16 route is held to 1 % here and to 2e-6 per product in
+    tests/test_gpu_modules.py::test_block_minifloat_and_block_log_products_on_bf16_mfma"""
     import torch
     from mi355q import ops
     from mi355q.harness import TinyLlamaConfig, TinyLlamaForCausalLM, eval_lm_perplexity, expand_llama_quant_config
@@ -439,6 +443,7 @@ def test_tiny_llama_loss_parity_other_block_arithmetics(arith):
                  data_in_exponent_bias_width=8, data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4,
                  weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4,
                  bias_exponent_bias_width=8, bias_block_size=[16])
+    d["mi355q_values_matmul"] = products
     torch.manual_seed(1)
     cfg = TinyLlamaConfig(vocab_size=384, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=64)
     model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(d, cfg.num_layers))
@@ -457,5 +462,6 @@ def test_tiny_llama_loss_parity_other_block_arithmetics(arith):
     finally:
         ops.bf16_gemm_tiled = real
     assert len(calls) == 2 * 2 * 7                                     # (every Linear of both forwards took the tile GEMM)
-    assert abs(res["loss"] - ref_loss) < 5e-4 * max(1.0, abs(ref_loss)), (res["loss"], ref_loss)
+    tol = 5e-4 if products == "fp32" else 1e-2
+    assert abs(res["loss"] - ref_loss) < tol * max(1.0, abs(ref_loss)), (res["loss"], ref_loss)
     assert abs(res2["loss"] - res["loss"]) < 1e-6
