@@ -22,12 +22,23 @@
  *         act    [B,T,C]  -> lead B, rows T, cols C, b0 B0, b1 B1      (skip_first_dim)
  *     with (b0,b1) the reference's right-aligned, clamped block shape (utils.py:42-66).
  *   - `workspace`: MI355Q_WORKSPACE_BYTES bytes of device memory, ZERO-INITIALISED once by
- *     the caller, private to one stream; the library leaves its control words zeroed after
- *     every call (the per-workgroup slots behind them are scratch).
+ *     the caller, private to one stream; the library leaves its control words and the zero-state slots zeroed
+ *     after every call.  One word survives from call to call on purpose: the fill the last tensor with all-zero
+ *     blocks ended up with (fp32 bits), which the next exact-mode call writes its all-zero blocks with before it
+ *     knows its own -- a guess that costs nothing when wrong (the fix-up pass rewrites them as before) and a whole
+ *     pass over the tensor less when right (attention probabilities under a causal mask, layer after layer).
  *   - Scratch the library owns itself, one per (device, stream), grow-only, allocated with hipMalloc on first need and
  *     therefore NOT while the stream is being captured into a graph (run the call once un-captured first, as
- *     mi355q.graphs.GraphedForward's warm-up does): the split-K slabs and tickets of the tile GEMM, and the zero-block map
- *     of the exact quantiser mode on tensors of 128 MiB and more (without it that mode reads x a second time instead).
+ *     mi355q.graphs.GraphedForward's warm-up does): the split-K slabs and tickets of the tile GEMM (a launch that would
+ *     have to grow them under capture runs unsplit instead; buffers a capture has seen are never freed), and the
+ *     zero-block map of the exact quantiser mode on tensors of 128 MiB and more (without it that mode reads x a second
+ *     time instead).
+ *   - Environment switches (diagnostics; read once per process): MI355Q_V9=0 keeps every launch on the round-2 tile kernel
+ *     (mi355q_gemm_v8.hip) -- by default launches WITHOUT exception lists (row-scale operands that carry none, the bf16
+ *     flavour) with K % 128 == 0 and >= 4 K-steps per slice take mi355q_gemm_v9.hip; MI355Q_V9_FIX=1 sends launches with
+ *     lists there too (add-back behind the K loop: no faster), MI355Q_V9_PREPASS=1 splits that into a pre-pass
+ *     and a product launch; MI355Q_QV_PIECES=0|1|2|4 pins the streaming quantisers' access shape (0: grid-stride loop;
+ *     default by tensor size); MI355Q_V8_TILE_ROWS, MI355Q_V8_SPLITS pin the tile GEMM's tile height / split-K.
  */
 #ifndef MI355Q_H
 #define MI355Q_H
@@ -39,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 16
+#define MI355Q_ABI_VERSION 17
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     float (&stat)[KW][16] = stat_[grp];
     f32x4 (&red)[KW][DT][64] = red_[grp];
     const int c16 = lane & 15, lg = lane >> 4;
-    const long long b = blockIdx.y, m0 = ((long long)blockIdx.x * QG + grp) * 16;
+    // (causal: the query blocks with the most visible keys first -- the launch then ends on its cheapest workgroups)
+    const long long b = blockIdx.y, m0 = ((long long)(g.causal_off >= 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * QG + grp) * 16;
     const long long qrow = min(m0 + c16, g.M - 1);
     const int D = DC * 32;
 

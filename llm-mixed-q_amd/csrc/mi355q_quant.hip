@@ -668,7 +668,7 @@ int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gsc
 // then writes the tiled mantissas, the effective exponents, rowflag[row] and the row scale.  cols % 64 == 0,
 // cols <= 1024 * MAXIT.
 // ---------------------------------------------------------------------------------------
-template <int MAXIT, bool FULL>
+template <int MAXIT, bool FULL, bool SEG>
 __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                                    uint8_t* __restrict__ flag, float* __restrict__ rscale,
                                                                    int exp_offset, int* __restrict__ list,
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     // all-gather over out_features shards, [P][rows][seg_len] with the segments a.seg_stride elements apart): element k of
     // the row sits in segment k / seg_len -- the consumer reads the P pieces where they lie instead of a permuted copy.
     auto row_f4 = [&](const float* base, long long row, int f) -> const float4* {
-        if (a.seg_len == 0) return reinterpret_cast<const float4*>(base + row * K) + f;
+        if (!SEG) return reinterpret_cast<const float4*>(base + row * K) + f;      // (compile-time: the plain rows' addressing costs 3 us at 4096 x 4096 otherwise)
         const long long k = (long long)f * 4, sgm = k / a.seg_len;
         return reinterpret_cast<const float4*>(base + sgm * a.seg_stride + row * a.seg_len + (k - sgm * a.seg_len));
     };
@@ -885,8 +885,10 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     if (grid > 65536) grid = 65536;
     if (grid < 1) grid = 1;
 #define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
-    hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
-                       exp_offset, list, list_to_clear, bcap)
+    if (a.seg_len) hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, false, true>), (unsigned)grid, 256, 0, st, a, mt, flag,  \
+                                      rscale, exp_offset, list, list_to_clear, bcap);                                  \
+    else hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_, false>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
+                            exp_offset, list, list_to_clear, bcap)
     if (a.cols == 4096) MI355Q_LAUNCH_ROWS(4, true);            // every lane holds a block in every slab: no guards
     else if (a.cols <= 4096) MI355Q_LAUNCH_ROWS(4, false);
     else if (a.cols == 8192) MI355Q_LAUNCH_ROWS(8, true);
