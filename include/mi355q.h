@@ -74,7 +74,10 @@ const char* mi355q_error_string(int code);
  * replaces: quantizers/block_fp.py:21-96  (_block_fp_quantize) behind
  *           QUANTIZER_MAP["block_fp"] (quantizers/__init__.py:8-16).
  * y    (nullable) fp32, same shape as x: the fake-quantised tensor the reference returns,
- *      including the |x| <= 1e-8 pass-through (block_fp.py:93-94).
+ *      including the |x| <= 1e-8 pass-through (block_fp.py:93-94).  Every value equals the reference's; the SIGN OF A
+ *      ZERO result is not pinned: a negative element whose mantissa rounds to 0 leaves the reference as -0.0 on its 2-D
+ *      activation path and as +0.0 on its 3-D activation / weight paths (the unblock step of those sums with +0.0),
+ *      and leaves this kernel as -0.0 (sign(x + 1e-9) * 0) on all of them.  No product can tell the two apart.
  * mant (nullable) int8, same shape as x: sign(x+1e-9) * integer mantissa, |mant| <= 2^(width-1)-1.
  * exp  (nullable, together with mant) uint8 [lead, ceil(rows/b0), ceil(cols/b1)]:
  *      shared exponent + exponent_bias (the stored, biased code).
