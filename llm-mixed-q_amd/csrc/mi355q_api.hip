@@ -544,6 +544,8 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
         // ONE launch: the row-scale GEMM forms the correction vectors of its tile's exception blocks itself and adds them
         // in its epilogue; if an exception bucket overflowed anywhere its workgroups form the whole product
         // blockwise-exact between them instead (decided on the device)
+        a.x_mbits = x->mbits;
+        a.w_mbits = w->mbits;
         hipEvent_t te = g_timing.begin(st);
         int rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st, x->rowflag, w->rowflag);
         g_timing.end(te, st);

@@ -765,7 +765,13 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     // (grouped launches stay here: their outputs are promised bit-identical to the separate calls, which may take 128-row tiles)
     // products WITH exception lists stay on the kernel below unless MI355Q_V9_FIX=1: on one box, bench.py, the two take 67.0
     // (here) and 70.0 us (there; profiles/r03_v9_exception_designs.txt); without lists the new kernel takes 55-57 against 57.4
-    static const int v9_fix = getenv("MI355Q_V9_FIX") ? atoi(getenv("MI355Q_V9_FIX")) : 0;
+    // launches WITH exception lists: the 256 x 256 kernel of mi355q_gemm_v9.hip (add-back behind its K loop, nothing in front
+    // of it) where the lists are all but empty -- operands of <= 5 bits, whose int8 container leaves a window of >= 4
+    // exponents: 54.0-55.0 us at 4096^3 W4A4 / W5A5 against 55.8-56.5 here -- and this kernel (add-back in the prologue,
+    // hidden behind the first stages) where every tile has its twenty entries: W6A6 62.3 against 65.0 (back-to-back
+    // launches, tools/dbg/v9_widths.py).  MI355Q_V9_FIX=0 / 1 pins either.
+    static const int v9_fix_env = getenv("MI355Q_V9_FIX") ? atoi(getenv("MI355Q_V9_FIX")) : -1;
+    const bool v9_fix = v9_fix_env >= 0 ? v9_fix_env != 0 : (a.x_mbits > 0 && a.x_mbits <= 4 && a.w_mbits > 0 && a.w_mbits <= 4);
     if (use_v9 && (v9_fix || !fix) && a.ngroup <= 1 && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {

@@ -99,6 +99,7 @@ struct GemmArgs {
     const float* g_bias[3];
     float* g_y[3];
     void* exc_ws;                 // 256 x 256 tile kernel: the tiles' exception records (pre-pass launch -> product launch), null: none
+    int x_mbits, w_mbits;         // mantissa bits of the operands (0: not given) -- the launcher's choice of kernel
     unsigned long long* stamps;   // diagnostic builds of the 256 x 256 tile kernel (MI355Q_V9_STAMPS): [workgroup][2][8] phase times
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
