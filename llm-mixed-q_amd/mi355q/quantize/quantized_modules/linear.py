@@ -105,6 +105,9 @@ class _LinearBase(nn.Linear):
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         if self.__dict__.get("config") is not None:
+            pend = self.__dict__.get("_pending_flavour")
+            if pend is not None and pend[0].device != self.weight.device:
+                self._pending_flavour = None        # (moved again before its first forward: the repack route decides, forward())
             with torch.no_grad():
                 self._pack_if_arrived()
         return out
