@@ -373,6 +373,15 @@ def main():
     dt_events = timed(torch, dist, world, device, step, args.steps, 0)
     ops.gemm_timing(False)
     n_timed, gemm_avg_ms, gemm_min_ms = ops.gemm_timing_read()
+    # ... and the dominant kernel alone, K launches back to back on the operands of the last step, no events: launch to
+    # launch, i.e. its duration plus one dispatch gap -- what the event pair (and the profiler's per-dispatch signals) add to
+    # a kernel's measured duration shows against this figure
+    b2b_ms = None
+    if not sharded and rows_mode:
+        xa_last = quantize_x(x, xw, 8, 127)
+        _, wm_b, we_b = ops.block_fp_quantize(w, ww, 8, 127, [1, 16], False, want_fake=False, want_packed=True, fast_zero_blocks=True)
+        wa_b, bq_b = ops.bfp_align_rows(wm_b, we_b, ww - 1, 127), ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
+        b2b_ms = timed(torch, dist, world, device, lambda: ops.bfp_gemm_aligned(xa_last, wa_b, bq_b, out=y), args.steps, args.warmup) / args.steps * 1e3
     n_out = w.shape[0]
     flops_kernel = 2.0 * M * n_out * K                        # one launch of the dominant kernel on this rank
     flops_job = 2.0 * M * N * K * (1 if sharded or world == 1 else world)
@@ -419,7 +428,9 @@ def main():
                          "avg_launch_ms": round(gemm_avg_ms, 4), "min_launch_ms": round(gemm_min_ms, 4), "launches_timed": n_timed,
                          "measured": f"second pass of {args.steps} steps with a HIP event pair around every launch (library, launch "
                                      "stream); `value` is the first pass, without them",
-                         "ms_per_step_with_events": round(dt_events / args.steps * 1e3, 4)},
+                         "ms_per_step_with_events": round(dt_events / args.steps * 1e3, 4),
+                         "back_to_back_launch_ms": None if b2b_ms is None else round(b2b_ms, 4),
+                         "back_to_back_note": "the same kernel alone, launch to launch without events (duration + one dispatch gap)"},
         }
         if no_ramp:
             jobf = 2.0 * M * N * K * (1 if sharded or world == 1 else world)
