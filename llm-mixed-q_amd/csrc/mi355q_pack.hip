@@ -49,11 +49,14 @@ __device__ __forceinline__ int unpack_value(unsigned long long lo, unsigned long
 
 // MODE 0: int8 row-scale operand (tiled, shifted; code 0xFF -> zeros).  MODE 1: tiled bf16 values m * 2^(code - off).
 // One thread = 16 output bytes; 64 consecutive threads = one 1-KiB piece, written contiguously.
-template <int MODE>
+// WIDTH_: the width as a compile-time constant (2 .. 8: every shift below an immediate, the block's bit string fetched
+// with 32-bit loads where it is 4-byte aligned), 0: taken from the argument.
+template <int MODE, int WIDTH_>
 __global__ __launch_bounds__(256) void bfp_expand_kernel(const uint16_t* __restrict__ packed, const uint8_t* __restrict__ codes,
-                                                         unsigned char* __restrict__ out, long long rows, long long K, int width,
+                                                         unsigned char* __restrict__ out, long long rows, long long K, int width_arg,
                                                          int off, long long npieces, const uint8_t* __restrict__ rowexp,
                                                          uint8_t* __restrict__ exp_out) {
+    const int width = WIDTH_ ? WIDTH_ : width_arg;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long piece = g >> 6;
     if (piece >= npieces) return;
@@ -66,9 +69,21 @@ __global__ __launch_bounds__(256) void bfp_expand_kernel(const uint16_t* __restr
         const long long blk = row * (K >> 4) + kb;
         const uint16_t* p = packed + blk * width;
         unsigned long long lo = 0ull, hi = 0ull;
-        for (int h = 0; h < width; ++h) {
-            const unsigned long long hw = p[h];
-            if (h < 4) lo |= hw << (16 * h); else hi |= hw << (16 * (h - 4));
+        if (WIDTH_ && WIDTH_ % 2 == 0) {                  // (blk * WIDTH_ halfwords: a multiple of 4 bytes)
+            const unsigned* p32 = reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+            for (int d = 0; d < WIDTH_ / 2; ++d) {
+                const unsigned long long dw = p32[d];
+                if (d < 2) lo |= dw << (32 * d); else hi |= dw << (32 * (d - 2));
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < (WIDTH_ ? WIDTH_ : 8); ++h) {
+                if (h < width) {
+                    const unsigned long long hw = p[h];
+                    if (h < 4) lo |= hw << (16 * h); else hi |= hw << (16 * (h - 4));
+                }
+            }
         }
         const int code = codes[blk];
         if (MODE == 0 && exp_out) exp_out[blk] = rowexp[row];          // (the aligned operand's per-block exponent: its row's)
@@ -110,10 +125,18 @@ int launch_bfp_expand(int mode, const uint16_t* packed, const uint8_t* codes, vo
     const long long rows_pad = (rows + 127) / 128 * 128;
     const long long npieces = (rows_pad >> 4) * (mode == 0 ? K >> 6 : K >> 5);
     const unsigned grid = (unsigned)((npieces * 64 + 255) / 256);
-    if (mode == 0)
-        hipLaunchKernelGGL((bfp_expand_kernel<0>), grid, 256, 0, st, packed, codes, static_cast<unsigned char*>(out), rows, K, width, off, npieces, rowexp, exp_out);
-    else
-        hipLaunchKernelGGL((bfp_expand_kernel<1>), grid, 256, 0, st, packed, codes, static_cast<unsigned char*>(out), rows, K, width, off, npieces, rowexp, exp_out);
+#define MI355Q_EXPAND(M, W) hipLaunchKernelGGL((bfp_expand_kernel<M, W>), grid, 256, 0, st, packed, codes, static_cast<unsigned char*>(out), rows, K, width, off, npieces, rowexp, exp_out)
+#define MI355Q_EXPAND_W(M)                                                                                      \
+    switch (width) {                                                                                            \
+        case 4: MI355Q_EXPAND(M, 4); break;                                                                     \
+        case 5: MI355Q_EXPAND(M, 5); break;                                                                     \
+        case 6: MI355Q_EXPAND(M, 6); break;                                                                     \
+        case 8: MI355Q_EXPAND(M, 8); break;                                                                     \
+        default: MI355Q_EXPAND(M, 0); break;                                                                    \
+    }
+    if (mode == 0) { MI355Q_EXPAND_W(0) } else { MI355Q_EXPAND_W(1) }
+#undef MI355Q_EXPAND_W
+#undef MI355Q_EXPAND
     return (int)hipGetLastError();
 }
 
