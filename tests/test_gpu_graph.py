@@ -142,3 +142,32 @@ def test_split_k_shape_first_seen_under_capture_and_eager_traffic_between_replay
                 assert torch.equal(tail(h), w), rep        # (an eager Linear on the graph's static output: never a stale hit)
                 for rows in range(16, 16 * 40, 16):        # variable-length eager traffic on the default stream
                     lin(torch.randn(rows, 4096, device=dev))
+
+
+def test_graph_replay_block_minifloat_model():
+    """a Llama-style model under block_minifloat (Linear layers on the bf16 tile GEMM, attention products as bf16 operands on
+    bf16 MFMAs, the streaming quantisers with their zero-block state): HIP-graph replay == eager, bit for bit"""
+    from mi355q.graphs import GraphedForward
+    from mi355q.harness import TinyLlamaConfig, TinyLlamaForCausalLM, expand_llama_quant_config
+    d = dict(name="block_minifloat", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4,
+             data_in_exponent_bias_width=8, data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4,
+             weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4,
+             bias_exponent_bias_width=8, bias_block_size=[16])
+    torch.manual_seed(2)
+    cfg = TinyLlamaConfig(vocab_size=384, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=128)
+    model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(d, cfg.num_layers))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim == 2 and "embed" not in n:
+                p.mul_(40.0)                                  # (quirk 5: minifloat blocks below 2 quantise to zeros)
+    model = model.to("cuda:0").eval()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    ids = [torch.randint(0, cfg.vocab_size, (1, 96), generator=g).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        eager = [model(i)[0].clone() for i in ids]
+    assert float(eager[0].abs().max()) > 0 and not torch.equal(eager[0], eager[1])
+    fwd = GraphedForward(lambda t: model(t)[0], (ids[0],))
+    for rep in range(2):
+        for i, e in zip(ids, eager):
+            assert torch.equal(fwd(i), e), rep
