@@ -144,22 +144,30 @@ def test_split_k_shape_first_seen_under_capture_and_eager_traffic_between_replay
                     lin(torch.randn(rows, 4096, device=dev))
 
 
-def test_graph_replay_block_minifloat_model():
-    """a Llama-style model under block_minifloat (Linear layers on the bf16 tile GEMM, attention products as bf16 operands on
-    bf16 MFMAs, the streaming quantisers with their zero-block state): HIP-graph replay == eager, bit for bit"""
+@pytest.mark.parametrize("arith", ["block_minifloat", "block_log"])
+def test_graph_replay_block_minifloat_and_block_log_models(arith):
+    """a Llama-style model under block_minifloat / block_log (Linear layers on the bf16 tile GEMM, block_minifloat's attention
+    products as bf16 operands on bf16 MFMAs, the streaming quantisers with their zero-block state -- block_log's fix-up
+    launches and the fill word they leave from call to call, causal probabilities included): HIP-graph replay == eager, bit
+    for bit"""
     from mi355q.graphs import GraphedForward
     from mi355q.harness import TinyLlamaConfig, TinyLlamaForCausalLM, expand_llama_quant_config
-    d = dict(name="block_minifloat", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4,
-             data_in_exponent_bias_width=8, data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4,
-             weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4,
-             bias_exponent_bias_width=8, bias_block_size=[16])
+    if arith == "block_minifloat":
+        d = dict(name="block_minifloat", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_width=4,
+                 data_in_exponent_bias_width=8, data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4,
+                 weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8, bias_exponent_width=4,
+                 bias_exponent_bias_width=8, bias_block_size=[16])
+    else:
+        d = dict(name="block_log", is_ptq=True, bypass=False, data_in_width=8, data_in_exponent_bias_width=8,
+                 data_in_block_size=[1, 16], weight_width=8, weight_exponent_bias_width=8, weight_block_size=[1, 16],
+                 bias_width=8, bias_exponent_bias_width=8, bias_block_size=[16])
     torch.manual_seed(2)
     cfg = TinyLlamaConfig(vocab_size=384, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, max_positions=128)
     model = TinyLlamaForCausalLM(cfg, expand_llama_quant_config(d, cfg.num_layers))
     with torch.no_grad():
         for n, p in model.named_parameters():
             if p.ndim == 2 and "embed" not in n:
-                p.mul_(40.0)                                  # (quirk 5: minifloat blocks below 2 quantise to zeros)
+                p.mul_(40.0 if arith == "block_minifloat" else 4.0)   # (quirk 5: minifloat blocks below 2 quantise to zeros)
     model = model.to("cuda:0").eval()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
