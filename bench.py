@@ -35,6 +35,10 @@ import sys
 import time
 from pathlib import Path
 
+# (the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between the ranks of one node
+#  fails with hipIpcGetMemHandle: invalid argument; set before anything initialises HIP)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "llm-mixed-q_amd"))
 sys.path.insert(0, str(ROOT))
