@@ -772,7 +772,13 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     // launches, tools/dbg/v9_widths.py).  MI355Q_V9_FIX=0 / 1 pins either.
     static const int v9_fix_env = getenv("MI355Q_V9_FIX") ? atoi(getenv("MI355Q_V9_FIX")) : -1;
     const bool v9_fix = v9_fix_env >= 0 ? v9_fix_env != 0 : (a.x_mbits > 0 && a.x_mbits <= 4 && a.w_mbits > 0 && a.w_mbits <= 4);
-    if (use_v9 && (v9_fix || !fix) && a.ngroup <= 1 && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
+    // launches whose exception add-back the PRODUCERS formed (a.corr, mi355q_corr.h; round 4): the 256 x 256 kernel reads it
+    // behind its first K-steps -- grouped launches included (the separate launches of the same weights take the same kernel
+    // whenever they take 256-row tiles; callers bind grouped weights only then).  MI355Q_CORR=0 ignores the binding.
+    static const int use_corr = getenv("MI355Q_CORR") ? atoi(getenv("MI355Q_CORR")) : 1;
+    const bool corr_ok = use_corr && fix && a.corr && a.splits <= 1 && !a.x_post;
+    if (!corr_ok) a.corr = nullptr;
+    if (use_v9 && (v9_fix || !fix || corr_ok) && (a.ngroup <= 1 || corr_ok) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {
         if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);

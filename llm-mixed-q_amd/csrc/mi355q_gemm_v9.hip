@@ -19,6 +19,9 @@
 //     entry's vector of 256 products in spare LDS in the next), hidden behind the other wave of its SIMD.  The entries of
 //     one tile row / column are chained in ascending block order and summed by ONE wave in that order: reproducible.
 //     The epilogue looks rows up once per 16-row fragment and columns once per wave.
+//   * round 4 (FIX_ = 2, mi355q_corr.h): the add-back READ, not formed -- the activation quantiser has written one vector
+//     per x row with exception blocks and one value per (row, W row with exception blocks); the tile fetches its two maps,
+//     <= 16 row vectors and one 16-KiB block of column values behind its first K-steps and adds them in its stores.
 // Roofline: int8 MFMA, 2*M*N*K ops.  y leaves as full fp32: 64 MiB at 4096^2, ~10 us at the rate the fabric takes
 // write-backs, none of it overlapped with one tile per compute unit.
 #include <hip/hip_runtime.h>
@@ -30,6 +33,7 @@
 #include <utility>
 
 #include "mi355q_gemm_tile.h"
+#include "mi355q_corr.h"
 
 namespace mi355q {
 
@@ -44,13 +48,9 @@ constexpr int V9_FAST_MAX = (V9_SIDE - V9_CORR) / 1024;       // entries (x + w)
 constexpr int V9_NB_ENT = 2;                                 // entries a wave gathers per batch behind the K loop
 constexpr int V9_GSCR = V9_NW * V9_NB_ENT * 4096;            // ... their blocks: scratch at the start of the ring area
 constexpr int V9_SLOW_MAX = (V9_STAGES - V9_GSCR) / 1024;    // vectors that fit the ring area behind the K loop
-// Record of a tile's exception add-back, written by the pre-pass launch and read back by the product launch (FIX 2 / 3): 1 KiB
-// of header {entries, mode, 1 if the vectors do not all fit beside the rings}, then the row / column maps and the
-// V9_FAST_MAX vectors exactly as they lie in LDS.
-constexpr int V9_REC_MAPS = 1024, V9_REC_VEC = V9_REC_MAPS + 2048, V9_REC = V9_REC_VEC + V9_FAST_MAX * 1024;
-constexpr int V9_RDMA = (2 + V9_FAST_MAX + 1 + V9_NW - 1) / V9_NW;      // LDS-DMA instructions per wave that fetch a record
 static_assert(ROW_BUCKET_WORDS * 4 <= 4096, "bucket copy");
 static_assert(V9_FAST_MAX >= 32, "spare LDS for correction vectors");
+static_assert(CORR_XV == 32 && CORR_WV == 16, "the corrections ride in the ring slots of two K-steps past the end: 32 + 16 + 2 pieces");
 
 typedef __bf16 v9_bf16x8 __attribute__((ext_vector_type(8)));
 // (w fragment as the MFMA's A operand, x fragment as its B operand: D[n = 4 (lane / 16) + r][m = lane % 16])
@@ -78,16 +78,16 @@ __device__ __forceinline__ i32x4 v9_desc(const void* base, int bytes) {       //
     return i32x4{(int)(unsigned)b, (int)(unsigned)(b >> 32), bytes, 0x00020000};
 }
 
-// FIX_ 1: with the exception add-back formed by the tile itself behind its K loop; 2: the PRE-PASS -- no product, the tile's
-// vectors and maps are formed and written to its record (a.exc_ws); 3: the product with the add-back read from the record
-// (a tile whose record says it does not fit falls back to 1's path).  STAMP: diagnostic build, phase times go to a.stamps.
+// FIX_ 1: with the exception add-back formed by the tile itself behind its K loop; 2: the add-back READ from what the
+// producers formed (a.corr, mi355q_corr.h; a launch whose rows / columns with exceptions did not fit their slots falls back
+// to 1's path, uniformly over the grid).  STAMP: diagnostic build, phase times go to a.stamps.
 template <int FIX_, bool BF16, bool STAMP>
 __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, const float* __restrict__ sx,
                                                         const float* __restrict__ sw_in, const int* __restrict__ xlist,
                                                         const int* __restrict__ wlist_in, const uint8_t* __restrict__ xf,
                                                         const uint8_t* __restrict__ wf_in) {
     constexpr int FIX = FIX_ != 0 ? 1 : 0;
-    constexpr bool PRE = FIX_ == 2, REC = FIX_ == 3;
+    constexpr bool REC = FIX_ == 2;
     static_assert(!BF16 || FIX_ == 0, "the bf16 arithmetic has no exception lists");
     // Two LDS objects: the operand rings (filled by LDS-DMA, read by inline-asm ds_read_b128 only) and everything else.
     // The compiler orders its own LDS reads behind every LDS-DMA that may alias them -- with one array each of its reads
@@ -120,8 +120,9 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const int gsz = min(tiles_m - first_m, GM);
     const int tm = first_m + (tile_id % in_group) % gsz;
     int tn = (tile_id % in_group) / gsz;
+    int which = REC ? a_in.corr_which : 0;                     // (weight of the binding; a grouped launch: the tile's group)
     if (ngroup > 1) {
-        const int which = tn / tiles_n1;                        // (wave-uniform: scalar loads from the argument block)
+        which = tn / tiles_n1;                                  // (wave-uniform: scalar loads from the argument block)
         tn -= which * tiles_n1;
         // (selects over constant indices: a runtime index would put the argument block in scratch memory)
 #define V9_PICK(f) (which == 0 ? a_in.f[0] : which == 1 ? a_in.f[1] : a_in.f[2])
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     //      slices, its two exception buckets and the lists' overflow words
     const int ring_lds = (int)(size_t)(lptr_t)ring, side_lds = (int)(size_t)(lptr_t)side;     // the objects' own LDS addresses
     if (wave == 0 || wave == 1) {
-        if (FIX && !(wave == 0 && a.x_post)) {
+        if (FIX && !REC && !(wave == 0 && a.x_post)) {      // (REC: the buckets are only fetched if the launch has to fall back)
             const int* b = wave == 0 ? row_bucket(xlist, m0) : row_bucket(wlist, n0);
             const int d = side_lds + (wave == 0 ? V9_XB : V9_WB);
 #pragma unroll
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_GLDS16(sx + m0 + lane * 4, side_lds + V9_SXT);
     } else if (!BF16 && wave == 3) {
         V9_GLDS16(sw + n0 + lane * 4, side_lds + V9_SWT);
-    } else if (!PRE && wave == 4) {
+    } else if (wave == 4) {
         // (bounds-checked by the descriptor: columns past N read as zero, no address past the array is touched)
         if (a.bias) {
             const i32x4 rb = v9_desc(a.bias + n0, (Ni - n0) * 4);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_GLDS4((wave == 5 ? xlist : wlist) + lane, side_lds + V9_OVF + (wave - 5) * 256);
     }
     // maps cleared, vectors beside the rings zero (every product is ADDED to its row's / column's vector) -- unless the
-    // tile's record brings them
+    // producers' corrections are read
     auto clear_maps_and_vectors = [&]() {
         rowslot[tid & 255] = -1;
         if (tid >= 256) colslot[tid & 255] = -1;
@@ -204,22 +205,45 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const i32x4 rxd_ = v9_desc(xbase, more_ ? x_nrec : 0), rwd_ = v9_desc(wbase, more_ ? w_nrec : 0);                   \
     const int soff_ = (step) * 1024;
 #define V9_STAGE(step, sa, sb) { V9_DESCS(step) V9_PIECE(0, rxd_, rwd_, soff_, sa, sb); V9_PIECE(1, rxd_, rwd_, soff_, sa, sb); V9_PIECE(2, rxd_, rwd_, soff_, sa, sb); V9_PIECE(3, rxd_, rwd_, soff_, sa, sb); }
-    if (!PRE) {
-        V9_STAGE(0, 0, 0)
-        V9_STAGE(1, V9_HALF, V9_HALF)
-        V9_STAGE(2, 2 * V9_HALF, 2 * V9_HALF)
-    }
-    const unsigned char* const rec = REC || PRE ? static_cast<const unsigned char*>(a.exc_ws) + (long long)(tm * tiles_n1 + tn) * V9_REC : nullptr;
+    V9_STAGE(0, 0, 0)
+    V9_STAGE(1, V9_HALF, V9_HALF)
+    V9_STAGE(2, 2 * V9_HALF, 2 * V9_HALF)
+    // REC: what the producers formed for this tile (mi355q_corr.h) is fetched by the LDS-DMA slots of the two K-steps PAST
+    // THE END of the loop (the pipeline requests step t + 3 during step t: steps nsteps and nsteps + 1 carry no operand data
+    // and their ring slots are free) -- "step nsteps": the <= 32 row vectors (piece p = the 1 KiB of vector slot p that
+    // covers this tile's 256 columns); "step nsteps + 1": the [256][CORR_WV] block of column values in the A half, the row
+    // map and the column map as pieces 0 and 1 of the B half.  A fetch that is not wanted (a slot past the bucket's count, no
+    // column of this tile has entries, the launch falls back) goes through a descriptor of zero bytes.  No LDS beside the
+    // rings, no extra instruction in the prologue, landed by the loop's own final wait.
+    int ncx = 0, ncw = 0;                       // rows / columns of this tile that have a correction
+    bool nofit = false;                         // REC: slots did not suffice somewhere (uniform over the grid): form the add-back here
+    const float* xv = nullptr;
+    const float* wv = nullptr;
+    const int *rmap = nullptr, *cmap = nullptr;
+    long long xv_stride = 0;
+    int wv_stride = 0;
     if (REC) {
-        // the tile's record rides BEHIND the first three K-steps (it is needed behind the loop; the first counted waits
-        // leave it in flight): item r = wave + 8 q: the two halves of the maps, the vectors, the header (repeated to pad)
-#pragma unroll
-        for (int q = 0; q < V9_RDMA; ++q) {
-            const int r = wave + V9_NW * q;
-            if (r < 2) { V9_GLDS16(rec + V9_REC_MAPS + r * 1024 + lane * 16, side_lds + V9_MAP + r * 1024); }
-            else if (r < 2 + V9_FAST_MAX) { V9_GLDS16(rec + V9_REC_VEC + (r - 2) * 1024 + lane * 16, side_lds + V9_CORR + (r - 2) * 1024); }
-            else { V9_GLDS4(rec + lane * 4, side_lds + V9_HDR); }
-        }
+        const CorrArgs* __restrict__ cp = a.corr;
+        const int* __restrict__ plan = cp->plan[which];
+        const long long ncorr = cp->N[which], npad = corr_pad256(ncorr);
+        nofit = (plan[0] | xlist[1]) != 0 || a.x_post;
+        ncx = nofit ? 0 : min(row_bucket(xlist, m0)[1], CORR_XV);
+        ncw = nofit ? 0 : plan[plan_ncols_off(ncorr) + tn];
+        // (uniform values all: pinned to scalar registers -- left to the compiler the four pointers and their arithmetic sit
+        //  in vector registers across the K loop, whose 256 are taken)
+        auto uni = [](const void* p) {
+            const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+            return reinterpret_cast<const void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+        };
+        xv = static_cast<const float*>(uni(cp->xvec[which] + ((long long)tm * CORR_XV) * npad + n0));
+        xv_stride = (long long)__builtin_amdgcn_readfirstlane((int)(npad * 4));
+        wv = static_cast<const float*>(uni(cp->wvec[which] + ((long long)m0 * plan_nb(ncorr) + tn) * CORR_WV));
+        wv_stride = __builtin_amdgcn_readfirstlane((int)plan_nb(ncorr) * CORR_WV * 4);     // bytes from one row's slice to the next row's
+        rmap = static_cast<const int*>(uni(cp->rowmap + m0));
+        cmap = static_cast<const int*>(uni(plan + plan_colmap_off() + n0));
+        ncx = __builtin_amdgcn_readfirstlane(ncx);
+        ncw = __builtin_amdgcn_readfirstlane(ncw);
     }
     if (STAMP) st_t[1] = __builtin_amdgcn_s_memrealtime();
 
@@ -230,14 +254,13 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // lane-constant part of the fragment addresses; fragment i is i KiB further (immediate offset)
     const int va = ring_lds + piece_lds_off(wm * 128 + l16, lq), vb = ring_lds + V9_B0 + piece_lds_off(wn * 64 + l16, lq);
     i32x4 fa[4], fb0[4], fb1[4];
-    if (PRE) V9_WAITV(0); else if (REC) V9_WAITV(8 + V9_RDMA); else V9_WAITV(8);      // everything but the pieces of K-steps 1 and 2 (and the record)
+    V9_WAITV(8);                                            // everything but the pieces of K-steps 1 and 2
     __builtin_amdgcn_s_barrier();
     if (FIX) {
         // a bucket overflowed somewhere (uniform over the grid): the row-scale product does not apply; the workgroups of
         // this launch share the blockwise-exact product instead (the operand loads in flight land in LDS only)
         const int* ovf = reinterpret_cast<const int*>(smem + V9_OVF);
         if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
-            if (PRE) return;                                    // (the product launch takes its blockwise path by itself)
             V9_WAITV(0);
             __syncthreads();
             v8_fallback(a, xf, wf, xlist, wlist, ring, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
@@ -245,10 +268,8 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             return;
         }
     }
-    if (!PRE) {
-        V9_DSR(fb0[0], vb, 0); V9_DSR(fb0[1], vb, 1024); V9_DSR(fb0[2], vb, 2048); V9_DSR(fb0[3], vb, 3072);
-        V9_DSR(fa[0], va, 0); V9_DSR(fa[1], va, 1024);
-    }
+    V9_DSR(fb0[0], vb, 0); V9_DSR(fb0[1], vb, 1024); V9_DSR(fb0[2], vb, 2048); V9_DSR(fb0[3], vb, 3072);
+    V9_DSR(fa[0], va, 0); V9_DSR(fa[1], va, 1024);
     V9_SB();
     acc_t acc[8][4];
 #pragma unroll
@@ -263,12 +284,34 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // of step t + 1) and the counted wait for fragment i; the read of B fragment i - 2 of step t + 1 (groups 2-5); LDS-DMA
     // piece i of step t + 3 (groups 0-3).  At barrier(t) every wave has waited for its own pieces of step t + 1 and has
     // retired every read of the A half of step t - 1 and of the B half of step t: those are the slots step t + 3 goes to.
-    auto body = [&](i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db, const bool first2) {
+    // `tail` (REC): 1 = this step requests "step nsteps" (the row vectors), 2 = "step nsteps + 1" (column values, maps)
+    // instead of operand pieces: piece q of this wave (ring piece pr = wave + 8 (q & 1) of the A half, q < 2, or of the B half)
+    // comes from its own source through a descriptor rooted pr piece rows in front of it, so that the lane offsets of the
+    // operand stream (voff[q]) address its 1 KiB.
+    int xa_ = 0, xb_ = 0, wa_ = 0, wb_ = 0;     // ring slots (byte offsets) the two tail steps went to
+    auto tail_desc = [&](int q, int tail) {
+        const int pr = wave + 8 * (q & 1);
+        const void* src = nullptr;
+        bool on = false;
+        if (tail == 1) { const int p = (q < 2 ? 0 : 16) + pr; src = reinterpret_cast<const char*>(xv) + p * xv_stride; on = p < ncx; }
+        else if (q < 2) { src = reinterpret_cast<const char*>(wv) + (long long)pr * 16 * wv_stride; on = ncw > 0; }
+        else { src = pr == 0 ? rmap : cmap; on = pr < 2 && !nofit; }
+        const bool strided = tail == 2 && q < 2;          // (the column values: 16 rows x 64 bytes, own lane offsets, see V9_TPIECE)
+        const unsigned long long b = reinterpret_cast<unsigned long long>(src) - (strided ? 0ull : (unsigned long long)pr * (unsigned long long)row_bytes);
+        return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)),
+                     __builtin_amdgcn_readfirstlane(on ? (strided ? 16 * wv_stride : pr * (int)row_bytes + 1024) : 0), 0x00020000};
+    };
+    auto body = [&](i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db, const int tail) {
         V9_LGKM(2);                                             // (the B reads of the slot about to be refilled)
-        if (REC && first2) V9_WAITV(4 + V9_RDMA); else V9_WAITV(4);          // (K-steps 0 and 1: the record stays in flight)
+        V9_WAITV(4);
         __builtin_amdgcn_s_barrier();
         const int ac = va + sa_c, an = va + sa_n, bn = vb + sb_n;
         V9_DESCS(t + 3)
+        if (REC && tail == 1) { xa_ = da; xb_ = db; }
+        if (REC && tail == 2) { wa_ = da; wb_ = db; }
+#define V9_TPIECE(q) { const i32x4 td_ = tail_desc(q, tail);                                                           \
+        const int tv_ = (tail == 2 && (q) < 2) ? (lane >> 2) * wv_stride + (lane & 3) * 16 : voff[q];                    \
+        V9_BLDS16(tv_, td_, 0, ring_lds + ((q) < 2 ? da : V9_B0 + db) + (wave + 8 * ((q) & 1)) * 1024); }
 #define V9_GROUP(i, wait)                                                                                                \
         if (i < 6) V9_DSR(fa[(i + 2) & 3], ac, (i + 2) * 1024); else V9_DSR(fa[(i + 2) & 3], an, (i - 6) * 1024);          \
         V9_LGKM(wait);                                                                                                   \
@@ -279,7 +322,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_SB();                                                                                                         \
         acc[i][1] = v9_mma(fb[1], fa[i & 3], acc[i][1]);                                                                 \
         V9_SB();                                                                                                         \
-        if (i < 4) V9_PIECE(i, rxd_, rwd_, soff_, da, db);                                                                            \
+        if (i < 4) { if (REC && tail) V9_TPIECE(i) else V9_PIECE(i, rxd_, rwd_, soff_, da, db); }                       \
         V9_SB();                                                                                                         \
         acc[i][2] = v9_mma(fb[2], fa[i & 3], acc[i][2]);                                                                 \
         V9_SB();                                                                                                         \
@@ -292,18 +335,20 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // B half of step t + 1 in b1, the slot step t + 3 goes to (= where step t's B half was) in b0
     int a0 = 0, a1 = V9_HALF, a2 = 2 * V9_HALF, a3 = 3 * V9_HALF, b0 = 0, b1 = V9_HALF, b2 = 2 * V9_HALF;
     // (the first two K-steps apart: their counted waits differ when a record is in flight)
-#define V9_PAIR(t_, f2)                                                                                                  \
-    body(fb0, fb1, t_, a0, a1, b1, a3, b0, f2);                                                                          \
+#define V9_PAIR(t_, tl0, tl1)                                                                                            \
+    body(fb0, fb1, t_, a0, a1, b1, a3, b0, tl0);                                                                         \
     { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
     { const int o = b0; b0 = b1; b1 = b2; b2 = o; }                                                                      \
-    body(fb1, fb0, (t_) + 1, a0, a1, b1, a3, b0, f2);                                                                    \
+    body(fb1, fb0, (t_) + 1, a0, a1, b1, a3, b0, tl1);                                                                   \
     { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
     { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
-    if (!PRE) {
-        if (REC) { V9_PAIR(0, true) }
-        for (int t = REC ? 2 : 0; t < nsteps; t += 2) {         // (nsteps is even: K % 128 == 0, even slices)
-            V9_PAIR(t, false)
-        }
+    // (nsteps is even and >= 4: K % 128 == 0, even slices; REC: the last two pairs request the corrections)
+    for (int t = 0; t < (REC ? nsteps - 4 : nsteps); t += 2) {
+        V9_PAIR(t, 0, 0)
+    }
+    if (REC) {
+        V9_PAIR(nsteps - 4, 0, 1)
+        V9_PAIR(nsteps - 2, 2, 0)
     }
 #undef V9_PAIR
     V9_WAITV(0);
@@ -375,25 +420,32 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     bool look = false;
     int mykeys[2] = {0x7fffffff, 0x7fffffff};                   // (slot << 18 | block << 8 | index) of the entries at list
                                                                 // positions lane, lane + 64 that this wave serves
-    bool have = false;                                          // the tile's record holds maps and vectors
-    if (FIX) {
+    bool have = false;                                          // maps and vectors are the producers' (REC), in LDS already
+    if (REC && !nofit) {
+        have = true;
+        look = ncx + ncw > 0 && !(a.dbg & 2);
+    } else if (FIX) {
+        if (REC) {
+            // the producers' slots did not suffice (uniform over the grid): the tile's two buckets after all, then as FIX_ 1
+            if (wave == 0 || wave == 1) {
+                const int* b = wave == 0 ? row_bucket(xlist, m0) : row_bucket(wlist, n0);
+                const int d = side_lds + (wave == 0 ? V9_XB : V9_WB);
+                if (!(wave == 0 && a.x_post)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q * 256 + lane * 4 < ROW_BUCKET_WORDS) V9_GLDS16(b + q * 256 + lane * 4, d + q * 1024);
+                }
+                V9_WAITV(0);
+            }
+            clear_maps_and_vectors();
+            V9_LGKM(0);
+            __builtin_amdgcn_s_barrier();
+        }
         cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
         nent = cx + cw;
         mode = nent == 0 ? 0 : (nent <= min(128, V9_FAST_MAX + V9_SLOW_MAX) ? 1 : 3);
-        if (REC) {
-            const int* hdr = reinterpret_cast<const int*>(smem + V9_HDR);
-            if (__builtin_amdgcn_readfirstlane(hdr[2]) == 0) {
-                have = true;
-                look = mode == 1 && !(a.dbg & 2);
-            } else {                                            // (does not fit a record: formed here after all)
-                __builtin_amdgcn_s_barrier();
-                clear_maps_and_vectors();
-                V9_LGKM(0);
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-        if (mode && !have) {                                    // (uniform over the workgroup: the barrier below is met by all)
+        if (mode) {                                    // (uniform over the workgroup: the barrier below is met by all)
             // (1) 16 lanes share an entry: slot = the smallest list index with the same tile row / column; -2 marks a void
             //     entry (also for the atomics pass of mode 3); rows / columns without a vector keep -1 in the maps
             for (int i0 = 0; i0 < nent; i0 += V9_NT / 16) {    // uniform
@@ -482,12 +534,16 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         }
     }
     // (masks only -- scales, bias and slots are read again where they are used: the accumulators take half the registers)
+    // the maps the stores consult: the tile's own (formed above) or the producers' (REC: pieces 0 and 1 of the B half of the
+    // second tail step)
+    const int* const rslot_r = have ? reinterpret_cast<const int*>(ring + V9_B0 + wb_) : rowslot;
+    const int* const cslot_r = rslot_r + 256;
     unsigned cmask = 0, jmask = 0;      // bit 4 j + r: some lane of the wave has a vector for that column; bit j: tile column j has one
     unsigned rmask = 0;                 // bit i: some row of fragment i has a vector
     if (look) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int4 c = *reinterpret_cast<const int4*>(&colslot[wn * 64 + j * 16 + lq * 4]);
+            const int4 c = *reinterpret_cast<const int4*>(&cslot_r[wn * 64 + j * 16 + lq * 4]);
             if (__any(c.x >= 0)) cmask |= 1u << (4 * j);
             if (__any(c.y >= 0)) cmask |= 2u << (4 * j);
             if (__any(c.z >= 0)) cmask |= 4u << (4 * j);
@@ -496,8 +552,9 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (__any(rowslot[wm * 128 + i * 16 + l16] >= 0)) rmask |= 1u << i;
+            if (__any(rslot_r[wm * 128 + i * 16 + l16] >= 0)) rmask |= 1u << i;
     }
+    const float* const wvl = reinterpret_cast<const float*>(ring + wa_);          // (REC: column values, [tile row][column slot])
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.y) | (uintptr_t)(a.ldy * 4)) & 15) == 0;
     // tiles of fragment i: pass 0 the ones no vector touches, pass 1 the others (with their vectors)
     auto store_rows = [&](int i, int pass) {
@@ -506,7 +563,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         if (pass == 1 && !rowv && jmask == 0) return;
         const int rl = wm * 128 + i * 16 + l16;
         const float sxv = BF16 ? 1.f : sxt[rl];
-        const int rs = rowv ? rowslot[rl] : -1;
+        const int rs = rowv ? rslot_r[rl] : -1;
         const long long row = (long long)m0 + rl;
         float* yrow = a.y + row * a.ldy + n0 + wn * 64 + lq * 4;
 #pragma unroll
@@ -521,22 +578,30 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             for (int r = 0; r < 4; ++r) val[r] = BF16 ? (float)acc[i][j][r] + bv[r] : (float)acc[i][j][r] * sxv * swv[r] + bv[r];
             if (pass == 1) {
                 if (rowv) {                                      // the row's vector: 256 products, one per tile column
-                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(V9_VEC(max(rs, 0)) + cl);
+                    const int rs0 = max(rs, 0);
+                    const float* rv = have ? reinterpret_cast<const float*>(ring + (rs0 < 16 ? xa_ : V9_B0 + xb_) + (rs0 & 15) * 1024)
+                                           : V9_VEC(rs0);
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(rv + cl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) val[r] += rs >= 0 ? c4[r] : 0.f;
                 }
                 if ((jmask >> j) & 1) {                          // the columns' vectors: one product per tile row
-                    const int4 c = *reinterpret_cast<const int4*>(&colslot[cl]);
+                    const int4 c = *reinterpret_cast<const int4*>(&cslot_r[cl]);
                     const int c4[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (cmask & (1u << (4 * j + r))) val[r] += c4[r] >= 0 ? V9_VEC(max(c4[r], 0))[rl] : 0.f;
+                        if (cmask & (1u << (4 * j + r)))
+                            val[r] += c4[r] >= 0 ? (have ? wvl[rl * CORR_WV + (c4[r] & (CORR_WV - 1))] : V9_VEC(max(c4[r], 0))[rl]) : 0.f;
                 }
             }
             if (row < a.M) {
                 const int col = n0 + cl;
                 if (vec_ok && col + 3 < Ni) {
-                    *reinterpret_cast<f32x4*>(yrow + j * 16) = val;
+                    // (experiment, MI355Q_V9_DBG bits 8 / 16 / 32: write-through / system-scope / non-temporal stores)
+                    if (a.dbg & 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(yrow + j * 16), "v"(val) : "memory");
+                    else if (a.dbg & 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(yrow + j * 16), "v"(val) : "memory");
+                    else if (a.dbg & 32) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(yrow + j * 16), "v"(val) : "memory");
+                    else *reinterpret_cast<f32x4*>(yrow + j * 16) = val;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -571,26 +636,86 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     }
     if (STAMP) st_x[2] = __builtin_amdgcn_s_memrealtime();
     if (look && !have) __builtin_amdgcn_s_barrier();
-    if (PRE) {
-        // the tile's record: header, then the maps and the vectors as they lie in LDS (a tile with more entries than fit
-        // beside the rings, or with too many for LDS at all, is marked: the product launch then forms its add-back itself)
-        unsigned char* out = const_cast<unsigned char*>(rec);
-        if (tid == 0) {
-            int* h = reinterpret_cast<int*>(out);
-            h[0] = nent; h[1] = mode; h[2] = (mode == 3 || nent > V9_FAST_MAX) ? 1 : 0; h[3] = 0;
-        }
-        const int nbytes = 2048 + min(nent, V9_FAST_MAX) * 1024;
-        for (int off = tid * 16; off < nbytes; off += V9_NT * 16)
-            *reinterpret_cast<f32x4*>(out + V9_REC_MAPS + off) =
-                *reinterpret_cast<const f32x4*>(off < 2048 ? smem + V9_MAP + off : smem + V9_CORR + (off - 2048));
-        return;
-    }
     if (STAMP) st_t[4] = __builtin_amdgcn_s_memrealtime();
     // (4) the stores: fragment by fragment, first its tiles that no vector touches, then the others
+    if (FIX && look && mode != 3) {
+        // with corrections (the tile's own vectors, or the producers'): ONE pass, a row of four fragments at a time.  The wave's slots, scales and bias go to
+        // registers first (the fragment registers of the K loop are free), so that the only LDS reads between a fragment's
+        // accumulators and its store are the corrections themselves, four fragments' worth in flight together.  (The
+        // two-pass form below, with its per-fragment look-ups, took 11-12 us against the plain epilogue's 7: stamps,
+        // profiles/r04_v9_corr_stamps.txt; it remains for the tiles without any correction and for mode 3.)
+        int rs[8];
+        float sxr[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        store_rows(i, 0);
-        if (look) store_rows(i, 1);
+        for (int i = 0; i < 8; ++i) {
+            const int rl = wm * 128 + i * 16 + l16;
+            rs[i] = rslot_r[rl];
+            sxr[i] = sxt[rl];
+        }
+        int4 cs[4];
+        f32x4 swr[4], bvr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cl = wn * 64 + j * 16 + lq * 4;
+            cs[j] = *reinterpret_cast<const int4*>(&cslot_r[cl]);
+            swr[j] = *reinterpret_cast<const f32x4*>(&swt[cl]);
+            bvr[j] = *reinterpret_cast<const f32x4*>(&bst[cl]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool rowv = (rmask >> i) & 1;
+            const int rl = wm * 128 + i * 16 + l16;
+            const long long row = (long long)m0 + rl;
+            float* yrow = a.y + row * a.ldy + n0 + wn * 64 + lq * 4;
+            const int rs0 = max(rs[i], 0);
+            const float* rv = (have ? reinterpret_cast<const float*>(ring + (rs0 < 16 ? xa_ : V9_B0 + xb_) + (rs0 & 15) * 1024) : V9_VEC(rs0)) + wn * 64 + lq * 4;
+            const float* wr = wvl + rl * CORR_WV;
+            f32x4 val[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[j][r] = (float)acc[i][j][r] * sxr[i] * swr[j][r] + bvr[j][r];
+            }
+            if (rowv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(rv + j * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[j][r] += rs[i] >= 0 ? c4[r] : 0.f;
+                }
+            }
+            if (jmask) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c4[4] = {cs[j].x, cs[j].y, cs[j].z, cs[j].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (cmask & (1u << (4 * j + r)))
+                            val[j][r] += c4[r] >= 0 ? (have ? wr[c4[r] & (CORR_WV - 1)] : V9_VEC(max(c4[r], 0))[rl]) : 0.f;
+                }
+            }
+            if (row < a.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wn * 64 + j * 16 + lq * 4;
+                    if (vec_ok && col + 3 < Ni) {
+                        if (a.dbg & 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(yrow + j * 16), "v"(val[j]) : "memory");
+                        else *reinterpret_cast<f32x4*>(yrow + j * 16) = val[j];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < Ni) yrow[j * 16 + r] = val[j][r];
+                    }
+                }
+            }
+            V9_SB();
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            store_rows(i, 0);
+            if (look) store_rows(i, 1);
+        }
     }
     if (STAMP) {
         st_t[5] = __builtin_amdgcn_s_memrealtime();
@@ -613,62 +738,26 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
 
 static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/v9_stamps.py): where the stamps build writes
 
-// 256 x 256 tiles, K % 128 == 0 (even slices under split-K).  Returns -1000 when the shape is not this kernel's
-// (the caller then launches the v8 kernel).
-// the tiles' exception records: library-owned, one buffer per (device, stream), grow-only, never (re)allocated while the
-// stream is capturing a graph (the product launch then forms its add-back itself)
-static void* exc_workspace(hipStream_t st, size_t bytes) {
-    struct Ws { void* p = nullptr; size_t n = 0; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Ws> all;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    Ws& w = all[{dev, st}];
-    if (w.n < bytes) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-        if (w.p) (void)hipFree(w.p);                      // (synchronises: nothing of this buffer is in flight after)
-        w.p = nullptr;
-        w.n = 0;
-        const size_t want = bytes + bytes / 4;
-        if (hipMalloc(&w.p, want) != hipSuccess) return nullptr;
-        w.n = want;
-    }
-    return w.p;
-}
-
 // 256 x 256 tiles, K % 128 == 0, at least four K-steps per slice (even slices under split-K).
 int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        hipStream_t st, const uint8_t* xf, const uint8_t* wf, bool bf16) {
     GemmArgs a = a_in;
     static const bool want_stamps = getenv("MI355Q_V9_STAMPS") != nullptr;
-    // default: the product launch forms the exception add-back itself (one launch, the add-back exposed behind its K loop);
-    // MI355Q_V9_PREPASS=1: a pre-pass launch forms every tile's vectors and maps, the product launch reads them back (the
-    // product launch is then 58-60 us at 4096^3 instead of 66, but the pre-pass and its launch boundary cost 13-15:
-    // profiles/r03_v9_exception_designs.txt, design G)
-    static const int prepass = getenv("MI355Q_V9_PREPASS") ? atoi(getenv("MI355Q_V9_PREPASS")) : 0;
     if (want_stamps) a.stamps = g_v9_stamps;
     const bool fix = xlist && wlist;
     if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
     const unsigned tiles = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256));
     const unsigned grid = tiles * (a.ngroup > 1 ? a.ngroup : 1) * (a.splits > 1 ? a.splits : 1);
-    a.exc_ws = nullptr;
+    // a.corr (mi355q_corr.h): the producers formed the exception add-back; the launch only reads it (and forms it itself,
+    // as without a.corr, when the producers' slots did not suffice: decided on the device)
+    const bool rec = fix && a.corr != nullptr && a.splits <= 1;
+    if (!rec) a.corr = nullptr;
     if (bf16) hipLaunchKernelGGL((bfp_gemm_v9<0, true, false>), grid, V9_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else if (!fix) hipLaunchKernelGGL((bfp_gemm_v9<0, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-    else {
-        void* ws = prepass && a.ngroup <= 1 ? exc_workspace(st, (size_t)tiles * V9_REC) : nullptr;
-        if (ws) {
-            GemmArgs p = a;
-            p.splits = 1;
-            p.exc_ws = ws;
-            hipLaunchKernelGGL((bfp_gemm_v9<2, false, false>), tiles, V9_NT, 0, st, p, sx, sw, xlist, wlist, xf, wf);
-            a.exc_ws = ws;
-            if (want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<3, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-            else hipLaunchKernelGGL((bfp_gemm_v9<3, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-        } else if (want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<1, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-        else hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-    }
+    else if (rec && want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<2, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (rec) hipLaunchKernelGGL((bfp_gemm_v9<2, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else if (want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<1, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    else hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();
 }
 

@@ -5,6 +5,7 @@ os.environ["MI355Q_V9_STAMPS"] = "1"
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import numpy as np, torch, bench
 from mi355q import ops, _lib
+ops.CORR = 'corr' in sys.argv
 import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False
 dev = torch.device('cuda:0')
 x, w, b = bench.make_inputs(torch, dev, 0)
@@ -13,7 +14,7 @@ wa = ops.bfp_align_rows(wm, we, 5, 127); bq = ops.block_fp_quantize(b, 6, 8, 127
 y = torch.empty(4096, 4096, device=dev)
 lib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.__file__), "libmi355q.so"))
 stamps = torch.zeros(256 * 2 * 8, dtype=torch.int64, device=dev)
-xa = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127)
+xa = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127, against=wa if 'corr' in sys.argv else None)   # (corr: producer-formed add-back)
 t_end = time.time() + 0.15
 while time.time() < t_end:
     for _ in range(10): ops.bfp_gemm_aligned(xa, wa, bq, out=y)
@@ -32,4 +33,4 @@ for rep in range(3):
         clk = s[:, wv, 6] / np.maximum(t[:, 3] - t[:, 2], 1) * 100.0
         print(f"{name}: start->loop {np.median((t[:,2]-t[:,0])*0.01):5.2f}  loop {np.median(d[:,2]):6.2f} (max {d[:,2].max():6.2f})  "
               f"behind the loop {np.median(d[:,3]):5.2f} (max {d[:,3].max():5.2f})  epilogue {np.median(d[:,4]):5.2f} (max {d[:,4].max():5.2f}) us | "
-              f"{np.median(clk):5.0f} MHz {np.median(cps):7.1f} clk/K-step | span {(t[:,5].max()-t[:,0].min())*0.01:6.2f} us | entries med {np.median(nent):.0f} max {nent.max()} modes {np.bincount(mode.astype(int))}")
+              f"epi pct 10/50/90/99 {np.percentile(d[:,4],10):.1f}/{np.percentile(d[:,4],50):.1f}/{np.percentile(d[:,4],90):.1f}/{np.percentile(d[:,4],99):.1f} | {np.median(clk):5.0f} MHz {np.median(cps):7.1f} clk/K-step | span {(t[:,5].max()-t[:,0].min())*0.01:6.2f} us | entries med {np.median(nent):.0f} max {nent.max()} modes {np.bincount(mode.astype(int))}")
