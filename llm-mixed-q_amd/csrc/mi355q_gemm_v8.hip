@@ -324,7 +324,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
     };
     int slot = 0;
     constexpr bool ONEPHASE = SCHED == 1;
-    if (SCHED == 2) {
+    if constexpr (SCHED == 2) {        // (discarded, not merely dead, for the 128-row tile: its groups index acc[0..7])
         // PIPELINED schedule: ONE barrier per K-step, no staggered wave groups.  Every wave keeps its MFMA stream fed from
         // registers: while the 4 MFMAs of A fragment i issue, fragment i + 2 is being read (the last two reads of a step
         // and the four B reads fetch step t + 1, from the next stage), and the wave's LDS-DMA pieces of step t + 2 go out
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
 //      gets no workspace (null: the caller launches unsplit), and a workspace that a capture has been handed is never
 //      freed afterwards -- an instantiated graph keeps its pointers -- growth retires the old buffers instead.
 SplitWorkspace* split_workspace(hipStream_t st, size_t slab_bytes, int ntickets) {
-    struct Owned { SplitWorkspace w; bool in_graph = false; };
+    struct Owned { SplitWorkspace w; bool slabs_in_graph = false, tickets_in_graph = false; };      // (per buffer: ADVICE r3)
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, Owned> all;
     static std::vector<void*> retired;                     // (buffers a recorded graph may still use: kept for good)
@@ -674,28 +674,29 @@ SplitWorkspace* split_workspace(hipStream_t st, size_t slab_bytes, int ntickets)
     if (grow && capturing) return nullptr;
     if (w.slab_bytes < slab_bytes) {
         if (w.slabs) {
-            if (o.in_graph) retired.push_back(w.slabs);
+            if (o.slabs_in_graph) retired.push_back(w.slabs);
             else (void)hipFree(w.slabs);                  // (synchronises: nothing of this workspace is in flight after)
         }
         w.slabs = nullptr;
         w.slab_bytes = 0;
+        o.slabs_in_graph = false;                         // (a fresh buffer: no graph knows it yet)
         if (hipMalloc(&w.slabs, slab_bytes) != hipSuccess) return nullptr;
         w.slab_bytes = slab_bytes;
     }
     if (w.ntickets < ntickets) {
         if (w.tickets) {
-            if (o.in_graph) retired.push_back(w.tickets);
+            if (o.tickets_in_graph) retired.push_back(w.tickets);
             else (void)hipFree(w.tickets);
         }
         w.tickets = nullptr;
         w.ntickets = 0;
+        o.tickets_in_graph = false;
         const int n = (ntickets + 1023) / 1024 * 1024;
         if (hipMalloc(reinterpret_cast<void**>(&w.tickets), (size_t)n * 4) != hipSuccess) return nullptr;
         if (hipMemsetAsync(w.tickets, 0, (size_t)n * 4, st) != hipSuccess) return nullptr;
         w.ntickets = n;
     }
-    if (grow) o.in_graph = false;                          // (fresh buffers: no graph knows them yet)
-    if (capturing) o.in_graph = true;
+    if (capturing) o.slabs_in_graph = o.tickets_in_graph = true;
     return &w;
 }
 // slices per tile for an under-filled grid: the largest S with tiles * S <= 256 (one workgroup per compute unit), whole

@@ -165,9 +165,12 @@ def block_minifloat_quantize_bf16(x: torch.Tensor, width: int, exponent_width: i
     _require_device(x, "block_minifloat_quantize_bf16")
     assert int(width) - int(exponent_width) - 1 <= 7, "a minifloat with more than 7 mantissa bits is not exact in bf16"
     lead, rows, cols, b0, b1 = resolve_blocking(x.shape, block_size, skip_first_dim)
-    if b0 != 1 or cols % b1 != 0 or b1 % 4 != 0:
-        return block_minifloat_quantize(x, width, exponent_width, exponent_bias_width, block_size, skip_first_dim).to(torch.bfloat16)
     xc = x.contiguous()
+    # the kernel's vector path (launch_format, csrc/mi355q_quant.hip) takes row blocks of 4, 8, ..., 256 values that tile the
+    # last dim, 16-byte aligned; its generic path has no bf16 output (T = 12 with block [1,16] fits the block to
+    # b1 = 12 -> b1 / 4 = 3 -> MI355Q_E_UNSUPPORTED)
+    if b0 != 1 or cols % b1 != 0 or b1 % 4 != 0 or (b1 // 4) not in (1, 2, 4, 8, 16, 32, 64) or xc.data_ptr() % 16 != 0:
+        return block_minifloat_quantize(x, width, exponent_width, exponent_bias_width, block_size, skip_first_dim).to(torch.bfloat16)
     y = torch.empty(xc.shape, dtype=torch.bfloat16, device=x.device)
     lib = _lib.load_library()
     with _on_device(x.device):

@@ -131,12 +131,14 @@ def _mask_2d(mask, tq, tk):
     """an additive mask that is the same for every leading index, as the [T_q, T_k] tensor the HIP entry points read --
     [1, 1, T_q, T_k], [T_q, T_k], or a padding mask [1, 1, 1, T_k] expanded over the rows; None for anything else (per-
     batch masks, shapes that do not broadcast to [T_q, T_k]): the caller then takes the generic route"""
-    if mask.ndim < 2 or mask.numel() != mask.shape[-2] * mask.shape[-1]:
+    # (fp32 additive masks only: a bool mask would become an additive 0 / 1 one under a plain cast, and a half-precision
+    #  mask's finfo.min is not fp32's -- both take the generic route, which treats them as torch does; ADVICE r3)
+    if mask.dtype != torch.float32 or mask.ndim < 2 or mask.numel() != mask.shape[-2] * mask.shape[-1]:
         return None
     m2 = mask.reshape(mask.shape[-2:])
     if m2.shape[0] not in (1, tq) or m2.shape[1] not in (1, tk):
         return None
-    return m2.expand(tq, tk).to(torch.float32).contiguous()
+    return m2.expand(tq, tk).contiguous()
 
 
 def _make_softmax(style):

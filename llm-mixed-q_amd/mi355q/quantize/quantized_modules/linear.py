@@ -428,7 +428,22 @@ class _LinearBase(nn.Linear):
         group flavour) the step runs as torch ops in front of forward()."""
         if op not in ("relu", "silu_mul") or (op == "silu_mul") != (other is not None):
             raise ValueError("forward_after: op is 'relu' (no other) or 'silu_mul' (with other)")
+        from ...sharded import ShardedRows
+        if isinstance(x, ShardedRows):
+            # fc1's gathered output in the collective's rank-major layout (sharded.shard_model(gather="segments")): the
+            # row-aligned route reads the P segments in place with the relu in front; anything else re-assembles it
+            if (op == "relu" and not self.bypass and self.is_ptq and not self.weight_requires_quantisation
+                    and self._packed_is_current() and self._pending_flavour is None
+                    and self._align_mode == "rows" and not self._uses_bf16_route()):
+                plan = self._int8_plan(x.buf[0])
+                if plan is not None:
+                    with torch.no_grad():
+                        return self._forward_int8(x, plan, pre=("relu", None))
+            x = x.dense()
+        # (a layer packed when its weights arrived still carries both flavours: its first forward must see the POST-op
+        #  activations to settle the route and drop the other one -- ADVICE r3 -- so it goes through forward() once)
         fused = (self.arith == "block_fp" and self.is_ptq and not self.bypass and not self.weight_requires_quantisation
+                 and getattr(self, "_pending_flavour", None) is None
                  and x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and (x.requires_grad or (
                      other is not None and other.requires_grad)))
                  and (other is None or (other.shape == x.shape and other.dtype == x.dtype and other.device == x.device)))
@@ -525,6 +540,11 @@ def grouped_linear(x, layers, norm=None):
     order: results agree with the separate norm to within the last-bit differences any two fp32 summation orders
     show (torch's own CPU and GPU reductions included), not bit for bit."""
     layers = list(layers)
+    from ...sharded import RowShardedLinear
+    if all(isinstance(l, RowShardedLinear) for l in layers):
+        # row-sharded projections (sharded.shard_model): this rank's shards as one group, one all-gather per projection
+        ys = grouped_linear(x, [l.local for l in layers], norm=norm)
+        return [l.gather_output(y) for l, y in zip(layers, ys)]
     first = layers[0]
 
     def normed():

@@ -79,8 +79,8 @@ class RowShardedLinear(nn.Module):
         local = cls_quantized.from_float(part, config).to(linear_fp32.weight.device)
         return cls(local, linear_fp32.out_features, group, always_gather, gather)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y_loc = self.local(x)
+    def gather_output(self, y_loc: torch.Tensor):
+        """this rank's [.., O/P] -> the layer's [.., O] (or its ShardedRows): the ONE collective of the layer"""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1 and not (self.always_gather and dist.is_initialized()):
             return ShardedRows(y_loc.detach().reshape(1, -1, y_loc.shape[-1]).contiguous(), y_loc.shape[:-1]) \
@@ -89,6 +89,67 @@ class RowShardedLinear(nn.Module):
         y2 = y_loc.detach().reshape(-1, y_loc.shape[-1]).contiguous()     # inference path: no autograd through the collective
         gathered = torch.empty(world * y2.shape[0], y2.shape[1], dtype=y2.dtype, device=y2.device)
         dist.all_gather_into_tensor(gathered, y2, group=self.group)          # rank-major: [P * M, O/P]
+        COLLECTIVES["all_gather"] += 1
+        COLLECTIVES["bytes"] += gathered.numel() * gathered.element_size()
         if self.gather == "segments":
             return ShardedRows(gathered.view(world, y2.shape[0], y2.shape[1]), lead)
         return gathered.view(world, y2.shape[0], y2.shape[1]).permute(1, 0, 2).reshape(*lead, self.out_features)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.gather_output(self.local(x))
+
+    def forward_after(self, x, op, other=None):
+        """the wrapped layer's fused elementwise step (quantized_modules.linear.forward_after) on this rank's shard"""
+        return self.gather_output(self.local.forward_after(x, op, other))
+
+    # what the harness reads of a projection
+    @property
+    def config(self):
+        return self.local.config
+
+    @property
+    def in_features(self):
+        return self.local.in_features
+
+
+# collectives issued by the sharded layers of this process (tests and the config-4 script read and reset it)
+COLLECTIVES = {"all_gather": 0, "bytes": 0}
+
+# the projections of the two harness families that BASELINE's north_star partitions ("the per-layer GEMMs row-wise across the
+# 8 GPUs ... for OPT / Llama >= 1.3B"): every quantised Linear of a decoder layer; embeddings, norms, the attention core
+# (heads replicated: SURVEY 8e) and the unquantised lm_head stay whole on every rank
+SHARDED_PROJECTIONS = {
+    "opt": (("self_attn", ("q_proj", "k_proj", "v_proj", "out_proj")), (None, ("fc1", "fc2"))),
+    "llama": (("self_attn", ("q_proj", "k_proj", "v_proj", "o_proj")), (None, ("gate_proj", "up_proj", "down_proj"))),
+}
+
+
+def shard_model(model: nn.Module, group=None, always_gather: bool = False, gather: str = "dense") -> nn.Module:
+    """Row-shard every quantised Linear of a harness model (mi355q.harness.TinyOPTForCausalLM / TinyLlamaForCausalLM) in place:
+    rank r keeps rows [r O/P, (r + 1) O/P) of each projection's weight and bias -- never cutting a [1,16] weight block or a
+    [16] bias block -- quantises and packs only those, and one all-gather per projection rebuilds its output.  Call it on the
+    full-precision model (before its first forward quantises the weights in place), on every rank, with identical weights.
+    The reference runs models of this size by LAYER placement instead (cli/eval_perplexity.py:66-75: accelerate's
+    infer_auto_device_map over decoder layers); this is the row partition BASELINE.json's north_star asks for.
+    `gather`: "dense" -- every projection hands on [.., O]; "segments" -- fc1 (OPT) hands its rank-major ShardedRows to fc2's
+    quantiser as it lies (no permute copy), everything else dense (the attention core and the gated product need [.., O])."""
+    from .quantize.quantized_modules.linear import _LinearBase
+    family = "llama" if hasattr(model.layers[0], "gate_proj") else "opt"
+    for layer in model.layers:
+        for owner_name, names in SHARDED_PROJECTIONS[family]:
+            owner = layer if owner_name is None else getattr(layer, owner_name)
+            for name in names:
+                lin = getattr(owner, name)
+                if isinstance(lin, RowShardedLinear):
+                    continue
+                if not isinstance(lin, _LinearBase):
+                    raise TypeError(f"{name}: expected a quantised Linear of the registry, found {type(lin).__name__}")
+                if not lin.weight_requires_quantisation and not lin.bypass:
+                    raise RuntimeError(f"{name}: shard the model before its first forward quantises the weights in place")
+                shim = nn.Linear(lin.in_features, lin.out_features, bias=lin.bias is not None, device="meta")
+                shim.weight, shim.bias = lin.weight, lin.bias               # (the full-precision parameters, no copy)
+                seg = gather == "segments" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
+                setattr(owner, name, RowShardedLinear.from_full(type(lin), shim, lin.config, group, always_gather,
+                                                                "segments" if seg else "dense"))
+    model.mi355q_sharded = True
+    return model

@@ -983,3 +983,53 @@ def test_block_minifloat_and_block_log_products_on_bf16_mfma(arith, style):
             assert float((got - old).abs().max()) <= 2e-6 * scale
     finally:
         setattr(ops, name, real)
+
+
+@pytest.mark.parametrize("T,block", [(12, [1, 16]), (24, [1, 32]), (20, [1, 32]), (28, [1, 32]), (48, [1, 16])])
+def test_block_minifloat_attention_products_at_token_counts_that_refit_the_block(T, block):
+    """T = 12 under block [1,16] re-fits the block to 12 values (b1 / 4 = 3), which the bf16-output quantiser's vector
+    path does not take -- the product must fall back to the fp32 quantiser instead of raising (quantized_functions/matmul.py:199-249)"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    cfg = dict(name="block_minifloat", bypass=False, data_in_width=8, data_in_exponent_width=4, data_in_exponent_bias_width=8,
+               data_in_block_size=block, weight_width=8, weight_exponent_width=4, weight_exponent_bias_width=8, weight_block_size=block)
+    g = torch.Generator().manual_seed(T)
+    probs = torch.softmax(torch.randn(2, 3, T, T, generator=g) * 2, dim=-1)
+    v = torch.randn(2, 3, T, 64, generator=g)
+    q = torch.randn(2, 3, T, 64, generator=g)
+    kt = torch.randn(2, 3, 64, T, generator=g)
+    f = Q.get_quantized_func("matmul", cfg)
+    for x, y in ((probs, v), (q, kt)):
+        got = f(x.to("cuda:0"), y.to("cuda:0"), dict(cfg))
+        ref = O.matmul_quantized(x.numpy(), y.numpy(), cfg)
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_forward_after_settles_a_layer_that_packed_on_arrival():
+    """a packed-storage layer packs when it reaches the GPU and keeps both flavours until its first forward; when that
+    first forward is the fused forward_after (fc2 behind relu), the post-op activations must still settle the route and the
+    int8 copies must be dropped (width + 0.5 bits at rest)"""
+    import torch
+    import mi355q.quantize as Q
+    torch.manual_seed(9)
+    fp = torch.nn.Linear(512, 256)
+    x = (torch.randn(64, 512) * torch.exp(torch.randn(64, 1))).to("cuda:0")
+    cfg = _lin_cfg(6, mi355q_weight_storage="packed")
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    assert lin._pending_flavour is not None
+    y = lin.forward_after(x, "relu")
+    assert lin._pending_flavour is None, "the first forward_after left both flavours resident"
+    ref = Q.get_quantized_cls("linear", _lin_cfg(6)).from_float(fp, _lin_cfg(6)).to("cuda:0")
+    assert torch.equal(y, ref(torch.relu(x)))
+    assert torch.equal(lin.forward_after(x, "relu"), y)          # (and the fused route afterwards gives the same bits)
+
+
+def test_non_fp32_masks_take_the_generic_route():
+    """only fp32 additive masks are handed to the fused kernels; a bool mask must not become an additive 0 / 1 mask"""
+    import torch
+    from mi355q.quantize import quantized_functions as QF
+    m = torch.zeros(1, 1, 8, 8, dtype=torch.bool, device="cuda:0")
+    assert QF._mask_2d(m, 8, 8) is None
+    assert QF._mask_2d(m.to(torch.float16), 8, 8) is None
+    assert QF._mask_2d(m.to(torch.float32), 8, 8) is not None

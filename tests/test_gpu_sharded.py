@@ -104,3 +104,89 @@ def test_row_sharded_linear_nccl(world):
             assert same, f"rank {rank} W{width}: sharded output differs from the unsharded layer"
             assert err < 1e-5, (rank, width, err)
             assert packed, "the shard did not take the int8 path"
+
+
+def _model_cfg(width, mixed, knobs):
+    d = _cfg(width)
+    if knobs:
+        d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_token_major_output=True)
+    cfg = {"default": d}
+    if mixed:       # per-layer widths, as a search result writes them (experiments/emnlp/configs/search/opt_1.3b_sst2.toml)
+        cfg["model_layer_1"] = {"self_attn": {"q_proj": dict(d, data_in_width=6, weight_width=5, bias_width=5)},
+                                "fc2": dict(d, data_in_width=5, weight_width=3, bias_width=3)}
+    return cfg
+
+
+def _model_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from mi355q import harness, sharded
+        res = []
+        for family, width, mixed, knobs, gather in (("opt", 4, True, False, "dense"), ("opt", 4, True, True, "segments"),
+                                                    ("llama", 6, False, True, "dense")):
+            def build():
+                torch.manual_seed(11)
+                if family == "opt":
+                    c = harness.TinyOPTConfig(vocab_size=512, hidden_size=512, ffn_dim=2048, num_layers=2, num_heads=8, max_positions=256)
+                    m = harness.TinyOPTForCausalLM(c, harness.expand_quant_config(_model_cfg(width, mixed, knobs), 2))
+                else:
+                    lc = _model_cfg(width, mixed, knobs)
+                    lc["rotary_positional_encoding"] = dict(name="integer", bypass=False, data_in_width=8, data_in_frac_width=7)
+                    c = harness.TinyLlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1536, num_layers=2, num_heads=8, max_positions=256)
+                    m = harness.TinyLlamaForCausalLM(c, harness.expand_llama_quant_config(lc, 2))
+                with torch.no_grad():
+                    for p in m.parameters():
+                        if p.ndim == 2:
+                            p.mul_(torch.exp(0.5 * torch.randn(p.shape[0], 1)))
+                return m.to(dev).eval()
+            ids = torch.randint(0, 512, (1, 256), generator=torch.Generator().manual_seed(5)).to(dev)
+            with torch.no_grad():
+                whole = build()
+                for _ in range(2):
+                    ref, ref_loss = whole(ids, labels=ids)
+                model = sharded.shard_model(build(), always_gather=True, gather=gather)
+                for _ in range(2):                      # (first forward packs, the second runs the settled routes)
+                    sharded.COLLECTIVES.update(all_gather=0, bytes=0)
+                    got, loss = model(ids, labels=ids)
+            n_proj = 6 if family == "opt" else 7
+            packed = model.layers[0].self_attn.q_proj.local._packed is not None
+            res.append((family, knobs, gather, bool(torch.equal(got, ref)), float(loss) == float(ref_loss),
+                        sharded.COLLECTIVES["all_gather"] == 2 * n_proj, packed))
+        q.put((rank, res))
+    except Exception as e:
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(e))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_row_sharded_model_nccl(world):
+    """row (h): every quantised Linear of a harness model row-sharded (sharded.shard_model), real RCCL all-gathers (at world size
+    1 too), QUANTISED layers -- W4A4 with mixed per-layer widths (BASELINE config 4's kind) and W6A6 Llama: logits and loss equal
+    the unsharded model's bit for bit, one all-gather per projection"""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert not isinstance(res, str), res
+        for family, knobs, gather, same, loss_same, coll, packed in res:
+            assert same and loss_same, f"rank {rank} {family} knobs={knobs} gather={gather}: sharded model differs from the unsharded one"
+            assert coll, f"rank {rank} {family}: unexpected number of all-gathers"
+            assert packed, "the shards did not take the int8 path"

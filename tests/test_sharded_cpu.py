@@ -86,3 +86,80 @@ def test_row_shards_quantise_identically(world):
         assert np.array_equal(part.exp, full.exp[lo * nb:hi * nb])
         assert np.array_equal(part.mant, full.mant[lo * nb:hi * nb])
         assert np.array_equal(O.block_fp_quantize(b[lo:hi], 6, 8, 127, [16], False), bq[lo:hi])
+
+
+def _full_cfg(**extra):
+    d = dict(name="block_fp", bypass=True, is_ptq=True,
+             data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127, data_in_block_size=[1, 16],
+             weight_width=6, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
+             bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+    d.update(extra)
+    return d
+
+
+def _build_model(family, torch, harness):
+    torch.manual_seed(0)                          # every rank holds the same full-precision model
+    if family == "opt":
+        c = harness.TinyOPTConfig(vocab_size=96, hidden_size=64, ffn_dim=128, num_layers=2, num_heads=4, max_positions=32)
+        return harness.TinyOPTForCausalLM(c, harness.expand_quant_config(_full_cfg(), 2))
+    c = harness.TinyLlamaConfig(vocab_size=96, hidden_size=64, intermediate_size=128, num_layers=2, num_heads=4, max_positions=32)
+    return harness.TinyLlamaForCausalLM(c, harness.expand_llama_quant_config(_full_cfg(), 2))
+
+
+def _model_worker(rank, world, port, out_q):
+    import torch
+    import torch.distributed as dist
+    from mi355q import harness, sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = []
+        # (the Llama family's rotary function quantises whatever `bypass` says, like the reference's, and there is no CPU
+        #  quantiser: the Llama harness is sharded in the GPU test, tests/test_gpu_sharded.py)
+        for family in ("opt",):
+            ids = torch.randint(0, 96, (2, 16), generator=torch.Generator().manual_seed(3))
+            ref, ref_loss = _build_model(family, torch, harness)(ids, labels=ids)
+            model = sharded.shard_model(_build_model(family, torch, harness))
+            lin = model.layers[0].self_attn.q_proj
+            assert isinstance(lin, sharded.RowShardedLinear) and lin.local.out_features == 64 // world
+            sharded.COLLECTIVES.update(all_gather=0, bytes=0)
+            got, loss = model(ids, labels=ids)
+            n_proj = 6 if family == "opt" else 7
+            res.append((family, bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-6)), abs(float(loss) - float(ref_loss)) < 1e-5,
+                        sharded.COLLECTIVES["all_gather"] == 2 * n_proj))
+        out_q.put((rank, res))
+    except Exception as e:
+        out_q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_model_gloo_world2():
+    """row (h): a sharded MODEL -- every quantised Linear of the OPT harness split over two gloo ranks, heads and norms
+    replicated -- gives the unsharded logits and loss, with one all-gather per projection"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        assert isinstance(r, list), f"rank {rank}: {r}"
+        for family, logits_ok, loss_ok, coll_ok in r:
+            assert logits_ok and loss_ok, f"rank {rank} {family}: sharded model differs from the unsharded one"
+            assert coll_ok, f"rank {rank} {family}: unexpected number of all-gathers"
+
+
+def test_shard_model_refuses_a_model_that_already_quantised_its_weights():
+    import torch
+    from mi355q import harness, sharded
+    m = _build_model("opt", torch, harness)
+    m.layers[0].fc1.bypass = False
+    m.layers[0].fc1.weight_requires_quantisation = False
+    with pytest.raises(RuntimeError):
+        sharded.shard_model(m)
