@@ -116,6 +116,28 @@ def cpu_baseline_config5(torch):
     return out
 
 
+def config3_summary(torch):
+    """BASELINE config 3 as one object: the Llama-7B-SHAPED decoder at full depth (32 layers, 4096 / 11008, 32 heads x 128; seeded
+    N(0, 0.02) weights -- no checkpoint here), W6A6 block_fp [1,16], B = 1, T = 2048, every knob on, eager and HIP-graph replay
+    (tools/config3_full_depth.py; the reference's loop: eval/eval_lm.py:41-63).  No perplexity claim: random weights."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("config3_full_depth", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "config3_full_depth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.cuda.empty_cache()
+    try:
+        r = mod.run(layers=32, tokens=2048, steps=3, storage="resident", graph=True, parity=False, knobs=True, spread=False)
+    except Exception as e:                       # (never takes the headline line down with it)
+        return {"error": repr(e)[:200]}
+    finally:
+        torch.cuda.empty_cache()
+    keep = ("layers", "tokens", "loss", "ms_per_forward_eager", "tokens_per_s_eager", "ms_per_forward_graph", "tokens_per_s_graph",
+            "graph_equals_eager", "resident_GiB_after_packing", "peak_GiB", "linear_routes")
+    out = {"what": "Llama-7B shape, 32 layers, W6A6 block_fp [1,16], B = 1, T = 2048, seeded random weights, every knob on"}
+    out.update({k: r[k] for k in keep if k in r})
+    return out
+
+
 def config5_summary(torch, ops, args, device, with_cpu):
     """BASELINE config 5 inside the default line: the `--workload quantizers` cases at a short step count, condensed
     (aggregate and slowest case, fractions of the 8 TB/s figure and of a device copy of the same tensor), with the CPU
@@ -283,6 +305,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed step's output")
     ap.add_argument("--no-config5", action="store_true", help="leave the fake-quantiser summary (BASELINE config 5) out of the line")
+    ap.add_argument("--no-config3", action="store_true", help="leave the full-depth Llama-7B-shape forward (BASELINE config 3) out of the line")
     ap.add_argument("--variant", type=int, default=0, help="GEMM kernel variant (0 = automatic)")
     ap.add_argument("--align", choices=["rows", "groups"], default="rows",
                     help="exponent alignment of the packed operands: whole rows (row-scale int8 GEMM) or 256-value groups")
@@ -467,6 +490,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(torch)
         if world == 1 and not args.no_config5:
             out["config5"] = config5_summary(torch, ops, args, device, not args.no_cpu_baseline)
+        if world == 1 and not args.no_config3:
+            out["config3"] = config3_summary(torch)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
     if world > 1 or force_dist:

@@ -10,6 +10,8 @@ parser takes, the reference's PARSED per-layer config, and the reference's logit
     python tools/gen_golden_models.py
     python tools/gen_golden_models.py --wide     # models_wide.{npz,json}: 2 layers at OPT-1.3B / Llama-7B width; the
                                                  # weights are a seeded recipe in the JSON, not data
+    python tools/gen_golden_models.py --wide2 [mixed|opt2048|llama2048]   # models_wide2: W4A4 + mixed per-layer widths at
+                                                 # OPT-1.3B width; T = 2048 cases (loss + 64 logit rows + attention rows)
 """
 from __future__ import annotations
 
@@ -237,7 +239,62 @@ def main_wide():
     print(f"wide models: {len(meta)} cases, {sum(a.nbytes for a in arrays.values()) / 1e6:.2f} MB raw")
 
 
+def mixed_wide_opt_config():
+    """BASELINE config 4's kind at OPT-1.3B width: [default] W4A4 (configs/quantization/bfp_4bit.toml) and per-layer overrides
+    as a search result writes them (experiments/emnlp/configs/search/opt_1.3b_sst2.toml:24-37: data_in 6 / 5 / 4 / 3, weight and
+    bias 5 / 4 / 3 / 2)"""
+    d = bfp_default(4, 4)
+    def node(xw, ww):
+        n = dict(d)
+        n.update(data_in_width=xw, weight_width=ww, bias_width=ww)
+        return n
+    return {"default": d,
+            "model_layer_0": {"self_attn": {"q_proj": node(6, 5), "k_proj": node(5, 4), "v_proj": node(4, 3), "out_proj": node(3, 5),
+                                            "bmm_0": node(6, 5), "bmm_1": node(5, 4)},
+                              "fc1": node(5, 2), "fc2": node(6, 3)}}
+
+
+def run_wide_sampled(mod, cmod, family, tag, qcfg, arrays, meta, hidden, inner, heads, T, vocab=512, layers=2, seed=0, rows=64):
+    """a `wide` case at T = 2048 (B = 1): the loss, `rows` sampled logit rows and the same rows of the first layer's attention
+    output (first 128 channels) instead of the full tensors"""
+    full_a, full_m = {}, {}
+    run_wide(mod, cmod, family, tag, qcfg, full_a, full_m, hidden, inner, heads, vocab=vocab, T=T, B=1, layers=layers, seed=seed)
+    pick = np.sort(np.random.default_rng(seed + 2).choice(T, size=rows, replace=False))
+    pick[:2] = (0, T - 1)
+    pick = np.sort(pick)
+    arrays[f"{tag}/rows"] = pick.astype(np.int64)
+    arrays[f"{tag}/input_ids"] = full_a[f"{tag}/input_ids"]
+    arrays[f"{tag}/logits_rows"] = full_a[f"{tag}/logits"][0, pick].copy()
+    arrays[f"{tag}/attn0_rows"] = full_a[f"{tag}/attn0"][0, pick].copy()
+    meta[tag] = dict(full_m[tag], sampled_rows=rows)
+
+
+def main_wide2():
+    """models_wide2.{npz,json}: (1) OPT-1.3B width under W4A4 with mixed per-layer widths (2 x 128 tokens, full logits);
+    (2), (3) one T = 2048 case per family at OPT-1.3B / Llama-7B width under W6A6 (sampled rows)"""
+    torch.set_num_threads(8)
+    opt, optc, llama, llamac = load_reference_models()
+    arrays, meta = {}, {}
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if not only or "mixed" in only:
+        run_wide(opt, optc, "opt", "opt1p3b_width_w4a4_mixed", mixed_wide_opt_config(), arrays, meta, 2048, 8192, 32, seed=220)
+    if not only or "opt2048" in only:
+        run_wide_sampled(opt, optc, "opt", "opt1p3b_width_w6a6_t2048", {"default": bfp_default(6, 6)}, arrays, meta, 2048, 8192, 32, T=2048, seed=230)
+    if not only or "llama2048" in only:
+        run_wide_sampled(llama, llamac, "llama", "llama7b_width_w6a6_t2048", {"default": bfp_default(6, 6)}, arrays, meta, 4096, 11008, 32, T=2048, seed=240)
+    out_npz, out_json = OUT / "models_wide2.npz", OUT / "models_wide2.json"
+    if only and out_npz.exists():                       # (one case at a time: merge into what is there)
+        old = np.load(out_npz)
+        arrays = {**{k: old[k] for k in old.files}, **arrays}
+        meta = {**json.loads(out_json.read_text()), **meta}
+    np.savez_compressed(out_npz, **arrays)
+    out_json.write_text(json.dumps(meta, indent=1))
+    print(f"wide2 models: {len(meta)} cases, {sum(a.nbytes for a in arrays.values()) / 1e6:.2f} MB raw")
+
+
 def main():
+    if "--wide2" in sys.argv:
+        return main_wide2()
     if "--wide" in sys.argv:
         return main_wide()
     torch.set_num_threads(4)
