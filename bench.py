@@ -185,7 +185,7 @@ def verify(torch, ops, x, w, b, y, rows=64):
 def committed_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (counters cannot be read inside a timed
     run: one counter per rocprofv3 pass over tools/cdriver/step_driver, which runs the same step through the C ABI)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(ROOT / "profiles" / name) as f:
                 return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]), name
@@ -425,7 +425,9 @@ def main():
     failed = False
     if rank == 0:
         achieved = flops_kernel / (gemm_avg_ms * 1e-3) / 1e12
-        kname = "mi355q::bfp_gemm_v8<1, 8, 2, false>"
+        # (the dominant kernel: the 256 x 256 tile GEMM of mi355q_gemm_v9.hip with its exception add-back -- round 4; MI355Q_V9_FIX=0
+        #  puts the round-2 kernel bfp_gemm_v8<1, 8, 2, false> back)
+        kname = "mi355q::bfp_gemm_v8<1, 8, 2, false>" if os.environ.get("MI355Q_V9_FIX") == "0" else "mi355q::bfp_gemm_v9<1, false, false>"
         traffic, tsrc = committed_traffic(kname) if rows_mode and not sharded else (None, None)
         ms_step = dt / args.steps * 1e3
         out = {
@@ -443,7 +445,7 @@ def main():
                        "arithmetic": "int8 mantissa x int8 mantissa -> int32 (MFMA), fp32 row/block scaling, fp32 y",
                        "M_per_gpu": M, "N": N, "N_per_gpu": n_out, "K": K, "shard": args.shard if world > 1 else "none",
                        "align": args.align, "gemm_variant": ops.set_gemm_variant(args.variant)},
-            "roofline": {"bound": "mfma", "kernel": "bfp_gemm_v8 (row-scale int8 GEMM)" if rows_mode else "bfp_gemm_v6 (int32-chain block GEMM)",
+            "roofline": {"bound": "mfma", "kernel": (kname.replace("mi355q::", "") + " (row-scale int8 tile GEMM)") if rows_mode else "bfp_gemm_v6 (int32-chain block GEMM)",
                          "achieved": round(achieved, 2), "peak": INT8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / INT8_DENSE_PEAK_TFLOPS, 4),
                          "step_frac": round(value / world / INT8_DENSE_PEAK_TFLOPS, 4),

@@ -771,14 +771,20 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     // exponents: 54.0-55.0 us at 4096^3 W4A4 / W5A5 against 55.8-56.5 here -- and this kernel (add-back in the prologue,
     // hidden behind the first stages) where every tile has its twenty entries: W6A6 62.3 against 65.0 (back-to-back
     // launches, tools/dbg/v9_widths.py).  MI355Q_V9_FIX=0 / 1 pins either.
+    // Round 4: the 256 x 256 kernel takes EVERY launch with lists -- its add-back now rides the K loop's tail (the gathers of the
+    // tile's first 24 entries in the LDS-DMA slots of the three K-steps past the end, one vector per entry formed by all waves,
+    // a one-pass store epilogue): W6A6 62.1 against 63.1 us here on one box, 60.7 against 62.0 on another
+    // (profiles/r04_v9_tail_prefetch.txt).  MI355Q_V9_FIX=0 keeps the round-2 kernel for A/B runs.
     static const int v9_fix_env = getenv("MI355Q_V9_FIX") ? atoi(getenv("MI355Q_V9_FIX")) : -1;
-    const bool v9_fix = v9_fix_env >= 0 ? v9_fix_env != 0 : (a.x_mbits > 0 && a.x_mbits <= 4 && a.w_mbits > 0 && a.w_mbits <= 4);
+    const bool v9_fix = v9_fix_env >= 0 ? v9_fix_env != 0 : true;
     // launches whose exception add-back the PRODUCERS formed (a.corr, mi355q_corr.h; round 4): the 256 x 256 kernel reads it
     // behind its first K-steps -- grouped launches included (the separate launches of the same weights take the same kernel
     // whenever they take 256-row tiles; callers bind grouped weights only then).  MI355Q_CORR=0 ignores the binding.
     static const int use_corr = getenv("MI355Q_CORR") ? atoi(getenv("MI355Q_CORR")) : 1;
     const bool corr_ok = use_corr && fix && a.corr && a.splits <= 1 && !a.x_post;
     if (!corr_ok) a.corr = nullptr;
+    // (grouped launches stay on the kernel below: their outputs are promised bit-identical to the separate calls, which may take
+    //  128-row tiles there -- the two kernels add a row's corrections in different fp32 orders)
     if (use_v9 && (v9_fix || !fix || corr_ok) && (a.ngroup <= 1 || corr_ok) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {

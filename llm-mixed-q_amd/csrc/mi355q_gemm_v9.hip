@@ -45,6 +45,8 @@ constexpr int V9_SXT = V9_MAP + 2048, V9_SWT = V9_SXT + 1024, V9_BIAS = V9_SWT +
 constexpr int V9_FLAGS = V9_BIAS + 1024, V9_OVF = V9_FLAGS + 256, V9_HDR = V9_OVF + 512, V9_CORR = V9_HDR + 256;
 constexpr int V9_LDS = 159 * 1024, V9_SIDE = V9_LDS - V9_STAGES;
 constexpr int V9_FAST_MAX = (V9_SIDE - V9_CORR) / 1024;       // entries (x + w) whose vectors fit beside the rings
+constexpr int V9_TPRE = 24;                                  // entries whose gathers ride in the three K-steps past the end (96 pieces)
+constexpr int V9_TVEC = 16;                                  // ... vectors beyond V9_FAST_MAX: in the ring half the last K-step leaves dead
 constexpr int V9_NB_ENT = 2;                                 // entries a wave gathers per batch behind the K loop
 constexpr int V9_GSCR = V9_NW * V9_NB_ENT * 4096;            // ... their blocks: scratch at the start of the ring area
 constexpr int V9_SLOW_MAX = (V9_STAGES - V9_GSCR) / 1024;    // vectors that fit the ring area behind the K loop
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
                                                         const uint8_t* __restrict__ wf_in) {
     constexpr int FIX = FIX_ != 0 ? 1 : 0;
     constexpr bool REC = FIX_ == 2;
+    constexpr bool TPF = FIX_ == 1;                       // the tile's gathers ride in the K-steps past the end (round 4)
     static_assert(!BF16 || FIX_ == 0, "the bf16 arithmetic has no exception lists");
     // Two LDS objects: the operand rings (filled by LDS-DMA, read by inline-asm ds_read_b128 only) and everything else.
     // The compiler orders its own LDS reads behind every LDS-DMA that may alias them -- with one array each of its reads
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, l16 = lane & 15, lq = lane >> 4;
-    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0}, st_x[3] = {0, 0, 0};
+    unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0}, st_x[3] = {0, 0, 0}, st_y[2] = {0, 0};
     if (STAMP) st_t[0] = __builtin_amdgcn_s_memrealtime();
 
     GemmArgs a = a_in;
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     auto clear_maps_and_vectors = [&]() {
         rowslot[tid & 255] = -1;
         if (tid >= 256) colslot[tid & 255] = -1;
+        if (tid == 0) reinterpret_cast<int*>(smem + V9_FLAGS)[16] = 0;      // (set by the bookkeeping: a row with several entries)
 #pragma unroll
         for (int q = 0; q < (V9_FAST_MAX * 1024 + V9_NT * 16 - 1) / (V9_NT * 16); ++q)
             if ((q * V9_NT + tid) * 16 < V9_FAST_MAX * 1024)
@@ -254,6 +258,51 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // lane-constant part of the fragment addresses; fragment i is i KiB further (immediate offset)
     const int va = ring_lds + piece_lds_off(wm * 128 + l16, lq), vb = ring_lds + V9_B0 + piece_lds_off(wn * 64 + l16, lq);
     i32x4 fa[4], fb0[4], fb1[4];
+    // (1) of the exception add-back, the bookkeeping: 16 lanes share an entry: slot = the list index of the first entry of the
+    //     same tile row / column; -2 marks a void entry (also for the atomics pass of mode 3); rows / columns without a vector
+    //     keep -1 in the maps.  Needs the two buckets in LDS; writes entry word 3 and the maps (all beside the rings).
+    auto bookkeep = [&](int cx, int nent) {
+        for (int i0 = 0; i0 < nent; i0 += V9_NT / 16) {    // uniform
+            const int i = i0 + (tid >> 4), sub = tid & 15;
+            const bool valid = i < nent, is_x = i < cx;
+            int* e = v8_entry(xb, wb, cx, valid ? i : 0);
+            const int r = e[0], base = is_x ? m0 : n0;
+            const bool live = valid && (is_x ? (r >= m0 && r < m0 + 256 && r < Mi) : (r >= n0 && r < n0 + 256 && r < Ni));
+            const int lo = is_x ? 0 : cx, hi = is_x ? cx : nent;
+            // (slot = the list index of the row's entry with the SMALLEST BLOCK: a property of the data, not of the order in
+            //  which rows reserved their list slots -- the sums below start from it and go on in ascending block order)
+            int skey = (e[1] << 8) | i;
+            if (live)
+                for (int j = lo + sub; j < hi; j += 16) {
+                    const int* ej = v8_entry(xb, wb, cx, j);
+                    if (ej[0] == r) skey = min(skey, (ej[1] << 8) | j);
+                }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) skey = min(skey, __shfl_xor(skey, o));
+            const int slot = skey & 255;
+            if (valid && sub == 0) {
+                e[3] = live ? slot : -2;
+                if (live && slot == i) (is_x ? rowslot : colslot)[r - base] = i;
+                if (live && slot != i) reinterpret_cast<int*>(smem + V9_FLAGS)[16] = 1;     // (a row with several entries)
+            }
+        }
+    };
+    // TPF: the bookkeeping runs HERE, in the shadow of the first stages' flight: the buckets, scales and header words were
+    // requested in front of the operand pieces, so twelve outstanding LDS-DMA instructions mean they have landed
+    bool early_bk = false;
+    if (TPF && !(a.dbg & 16)) {                                 // (dbg 16, A/B: bookkeeping behind the loop)
+        V9_WAITV(12);
+        V9_LGKM(0);                                             // (this thread's share of the cleared maps has landed)
+        __builtin_amdgcn_s_barrier();
+        const int ecx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+        const int ent = ecx + __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
+        const int* ovf0 = reinterpret_cast<const int*>(smem + V9_OVF);
+        if (ent > 0 && ent <= min(128, V9_FAST_MAX + V9_SLOW_MAX) && __builtin_amdgcn_readfirstlane(ovf0[0] | ovf0[64]) == 0) {
+            bookkeep(ecx, ent);
+            early_bk = true;
+        }
+        V9_LGKM(0);
+    }
     V9_WAITV(8);                                            // everything but the pieces of K-steps 1 and 2
     __builtin_amdgcn_s_barrier();
     if (FIX) {
@@ -288,7 +337,22 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // instead of operand pieces: piece q of this wave (ring piece pr = wave + 8 (q & 1) of the A half, q < 2, or of the B half)
     // comes from its own source through a descriptor rooted pr piece rows in front of it, so that the lane offsets of the
     // operand stream (voff[q]) address its 1 KiB.
-    int xa_ = 0, xb_ = 0, wa_ = 0, wb_ = 0;     // ring slots (byte offsets) the two tail steps went to
+    // (where the tail steps' pieces land is read off the ring positions behind the loop: step nsteps + j in a_j / b_j)
+    // FIX_ 1, round 4: the GATHERS of the tile's first V9_TPRE exception entries ride in the LDS-DMA slots of the THREE K-steps
+    // past the end (tails 3, 4, 5; 96 pieces = 24 entries x 4 quarters of 64 rows): piece P = 32 j + p of tail step j carries
+    // quarter P & 3 = wave & 3 of entry P >> 2 = 8 j + 2 q + wave / 4 -- the other operand's blocks at the entry's K position,
+    // what `gather` below fetches behind the loop (5.5 us exposed, 8.8 for the fullest tile: profiles/r04_corr_breakdown.txt).
+    // Only the entry's K position is needed to request it; the bookkeeping stays behind the loop.
+    const int glane = (lane >> 4) * (int)row_bytes + (lane & 15) * 16;     // row `lane` of a quarter inside the tile's piece rows
+    // (the descriptors are rebuilt where they are used: eight scalar registers less across the K loop)
+#define V9_XG() v9_desc(a.xm + (long long)(m0 >> 4) * row_bytes, x_nrec)
+#define V9_WG() v9_desc(a.wm + (long long)(n0 >> 4) * row_bytes, w_nrec)
+    const int gv = glane + (wave & 3) * 4 * (int)row_bytes;
+    int tcx = 0, tnent = 0;
+    if (TPF) {
+        tcx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
+        tnent = tcx + __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
+    }
     auto tail_desc = [&](int q, int tail) {
         const int pr = wave + 8 * (q & 1);
         const void* src = nullptr;
@@ -307,8 +371,12 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         __builtin_amdgcn_s_barrier();
         const int ac = va + sa_c, an = va + sa_n, bn = vb + sb_n;
         V9_DESCS(t + 3)
-        if (REC && tail == 1) { xa_ = da; xb_ = db; }
-        if (REC && tail == 2) { wa_ = da; wb_ = db; }
+#define V9_GPIECE(q) { const int e_ = 8 * (tail - 3) + 2 * (q) + (wave >> 2);                                            \
+        const int kb_ = __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, tcx, min(e_, max(tnent - 1, 0)))[1]);            \
+        const int koff_ = (kb_ >> 2) * 1024 + (kb_ & 3) * 256;                                                           \
+        i32x4 gd_ = e_ < tcx ? V9_WG() : V9_XG();                                                                        \
+        if (e_ >= tnent) gd_[2] = 0;                                                                                     \
+        V9_BLDS16(gv, gd_, koff_, ring_lds + ((q) < 2 ? da : V9_B0 + db) + (wave + 8 * ((q) & 1)) * 1024); }
 #define V9_TPIECE(q) { const i32x4 td_ = tail_desc(q, tail);                                                           \
         const int tv_ = (tail == 2 && (q) < 2) ? (lane >> 2) * wv_stride + (lane & 3) * 16 : voff[q];                    \
         V9_BLDS16(tv_, td_, 0, ring_lds + ((q) < 2 ? da : V9_B0 + db) + (wave + 8 * ((q) & 1)) * 1024); }
@@ -322,7 +390,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_SB();                                                                                                         \
         acc[i][1] = v9_mma(fb[1], fa[i & 3], acc[i][1]);                                                                 \
         V9_SB();                                                                                                         \
-        if (i < 4) { if (REC && tail) V9_TPIECE(i) else V9_PIECE(i, rxd_, rwd_, soff_, da, db); }                       \
+        if (i < 4) { if (REC && tail) V9_TPIECE(i) else if (TPF && tail >= 3) V9_GPIECE(i) else V9_PIECE(i, rxd_, rwd_, soff_, da, db); } \
         V9_SB();                                                                                                         \
         acc[i][2] = v9_mma(fb[2], fa[i & 3], acc[i][2]);                                                                 \
         V9_SB();                                                                                                         \
@@ -343,13 +411,22 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
     { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
     // (nsteps is even and >= 4: K % 128 == 0, even slices; REC: the last two pairs request the corrections)
-    for (int t = 0; t < (REC ? nsteps - 4 : nsteps); t += 2) {
+    for (int t = 0; t < (REC || TPF ? nsteps - 4 : nsteps); t += 2) {
         V9_PAIR(t, 0, 0)
     }
     if (REC) {
         V9_PAIR(nsteps - 4, 0, 1)
         V9_PAIR(nsteps - 2, 2, 0)
     }
+    if (TPF) {
+        V9_PAIR(nsteps - 4, 0, 3)
+        V9_PAIR(nsteps - 2, 4, 5)
+    }
+    const int dead_a = a3;            // (the A half of the last K-step: nothing was requested into it, dead behind the loop)
+    // ring slots (byte offsets) of the steps past the end: step nsteps + j went to a_j / b_j (the rotation above)
+    const int xa_ = a0, xb_ = b0, wa_ = a1, wb_ = b1;
+    const int ga_[3] = {a0, a1, a2}, gb_[3] = {b0, b1, b2};
+    const i32x4 xg = V9_XG(), wg = V9_WG();
 #undef V9_PAIR
     V9_WAITV(0);
     V9_LGKM(0);                                                 // (the compiler does not know these reads are in flight)
@@ -415,7 +492,8 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     //      the entries while the K loop runs -- by gathers into scratch, or picking the blocks up from the operand rings
     //      as they stream by: every served entry stalls one wave for an LDS round trip and with it, at the next barrier,
     //      the workgroup; and storing the untouched tiles while the gathers fly: the gathers queue behind the stores.)
-    float* const rvec = reinterpret_cast<float*>(ring) + (V9_GSCR - V9_FAST_MAX * 1024) / 4;   // (vector of slot s >= V9_FAST_MAX)
+    float* rvec = reinterpret_cast<float*>(ring) + (V9_GSCR - V9_FAST_MAX * 1024) / 4;   // (vector of slot s >= V9_FAST_MAX)
+    bool tmode = false;               // TPF: this tile's first V9_TPRE gathers are in the ring already
 #define V9_VEC(s_) (((s_) < V9_FAST_MAX ? corr : rvec) + (s_) * 256)
     bool look = false;
     int mykeys[2] = {0x7fffffff, 0x7fffffff};                   // (slot << 18 | block << 8 | index) of the entries at list
@@ -446,42 +524,49 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         nent = cx + cw;
         mode = nent == 0 ? 0 : (nent <= min(128, V9_FAST_MAX + V9_SLOW_MAX) ? 1 : 3);
         if (mode) {                                    // (uniform over the workgroup: the barrier below is met by all)
-            // (1) 16 lanes share an entry: slot = the smallest list index with the same tile row / column; -2 marks a void
-            //     entry (also for the atomics pass of mode 3); rows / columns without a vector keep -1 in the maps
-            for (int i0 = 0; i0 < nent; i0 += V9_NT / 16) {    // uniform
-                const int i = i0 + (tid >> 4), sub = tid & 15;
-                const bool valid = i < nent, is_x = i < cx;
-                int* e = v8_entry(xb, wb, cx, valid ? i : 0);
-                const int r = e[0], base = is_x ? m0 : n0;
-                const bool live = valid && (is_x ? (r >= m0 && r < m0 + 256 && r < Mi) : (r >= n0 && r < n0 + 256 && r < Ni));
-                const int lo = is_x ? 0 : cx, hi = is_x ? cx : nent;
-                int slot = i;
-                if (live)
-                    for (int j = lo + sub; j < hi; j += 16)
-                        if (v8_entry(xb, wb, cx, j)[0] == r) slot = min(slot, j);
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) slot = min(slot, __shfl_xor(slot, o));
-                if (valid && sub == 0) {
-                    e[3] = live ? slot : -2;
-                    if (live && slot == i) (is_x ? rowslot : colslot)[r - base] = i;
-                }
-            }
+            if (!early_bk) bookkeep(cx, nent);
             V9_LGKM(0);
             __builtin_amdgcn_s_barrier();
             look = mode == 1 && !(a.dbg & 2);                   // (dbg 2, diagnostic: no add-back, results invalid)
             if (STAMP) st_x[0] = __builtin_amdgcn_s_memrealtime();
+            // (the entries beyond the prefetched ones gather into 4-KiB chunks of the ring's six live halves: <= 24 of them)
+            tmode = TPF && look && nent <= min(V9_FAST_MAX + V9_TVEC, V9_TPRE + 24) && !(a.dbg & 4);      // (dbg 4, A/B: gathers behind the loop)
+            if (tmode && nent > V9_FAST_MAX) {
+                // vectors of slots >= V9_FAST_MAX: the dead ring half (the prefetched gathers fill the others), zeroed --
+                // their entries may be served in two phases, so every product is ADDED
+                rvec = reinterpret_cast<float*>(ring + dead_a) - V9_FAST_MAX * 256;
+                for (int o = tid * 16; o < V9_TVEC * 1024; o += V9_NT * 16)
+                    *reinterpret_cast<f32x4*>(ring + dead_a + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+                V9_LGKM(0);
+                __builtin_amdgcn_s_barrier();
+            }
         }
     }
     // gathers of one entry: the other operand's 16-byte blocks at the entry's K position for the tile's 256 rows / columns,
     // four LDS-DMA quarters (rows past the operand read as zero) into 4 KiB of this wave's scratch
-    const int glane = (lane >> 4) * (int)row_bytes + (lane & 15) * 16;     // row `lane` of a quarter inside the tile's piece rows
-    const i32x4 xg = v9_desc(a.xm + (long long)(m0 >> 4) * row_bytes, x_nrec), wg = v9_desc(a.wm + (long long)(n0 >> 4) * row_bytes, w_nrec);
+    // scratch chunk b of this wave (4 KiB: one entry's gathers).  tmode: anywhere in the ring but its dead half, which holds
+    // vectors -- by then (phase B) the prefetched gathers have been consumed
+    auto scratch = [&](int b) {
+        int o = (wave * V9_NB_ENT + b) * 4096;
+        if (tmode && o >= dead_a) o += V9_HALF;
+        return o;
+    };
+    // where quarter c of entry i's gathered blocks lies: prefetched (piece P = 4 i + c of the tail steps) or in scratch chunk b
+    auto gathered = [&](int i, int b, int c) {
+        if (tmode && i < V9_TPRE) {
+            const int P = 4 * i + c, j = P >> 5, pp = P & 31;
+            const int base = pp < 16 ? (j == 0 ? ga_[0] : j == 1 ? ga_[1] : ga_[2]) : V9_B0 + (j == 0 ? gb_[0] : j == 1 ? gb_[1] : gb_[2]);
+            return base + (pp & 15) * 1024;
+        }
+        return scratch(b) + c * 1024;
+    };
     auto gather = [&](int i, int b) {
+        if (tmode && i < V9_TPRE) return;                      // (already in the ring)
         const int kb = __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, i)[1]);
         const int koff = (kb >> 2) * 1024 + (kb & 3) * 256;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int vo = glane + c * 4 * (int)row_bytes, dl = ring_lds + (wave * V9_NB_ENT + b) * 4096 + c * 1024;
+            const int vo = glane + c * 4 * (int)row_bytes, dl = ring_lds + scratch(b) + c * 1024;
             if (i < cx) { V9_BLDS16(vo, wg, koff, dl); } else { V9_BLDS16(vo, xg, koff, dl); }
         }
     };
@@ -497,7 +582,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         float* v = V9_VEC(slot);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int4 q = *reinterpret_cast<const int4*>(ring + (wave * V9_NB_ENT + b) * 4096 + c * 1024 + lane * 16);
+            const int4 q = *reinterpret_cast<const int4*>(ring + gathered(i, b, c) + lane * 16);
             const float p = __builtin_ldexpf((float)dot16(pv, q), sh) * sc[c * 64 + lane];
             v[c * 64 + lane] = first ? p : v[c * 64 + lane] + p;
         }
@@ -514,14 +599,17 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             }
     };
     // the wave's next entry: the smallest key above `last` among the two this lane holds, over the wave
-    auto next_key = [&](int last) {
-        int best = mykeys[0] > last ? mykeys[0] : 0x7fffffff;
-        if (mykeys[1] > last) best = min(best, mykeys[1]);
+    // (`phase`: -1 all entries; 0 / 1 those whose gathers were / were not prefetched, tmode)
+    auto next_key = [&](int last, int phase) {
+        const bool in0 = phase < 0 || ((mykeys[0] & 255) >= V9_TPRE) == (phase == 1);
+        const bool in1 = phase < 0 || ((mykeys[1] & 255) >= V9_TPRE) == (phase == 1);
+        int best = mykeys[0] > last && in0 ? mykeys[0] : 0x7fffffff;
+        if (mykeys[1] > last && in1) best = min(best, mykeys[1]);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) best = min(best, __shfl_xor(best, o));
         return __builtin_amdgcn_readfirstlane(best);
     };
-    if (look && !have) {
+    if (look && !have && !tmode) {
         // (2) this wave's entries
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -539,21 +627,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const int* const rslot_r = have ? reinterpret_cast<const int*>(ring + V9_B0 + wb_) : rowslot;
     const int* const cslot_r = rslot_r + 256;
     unsigned cmask = 0, jmask = 0;      // bit 4 j + r: some lane of the wave has a vector for that column; bit j: tile column j has one
-    unsigned rmask = 0;                 // bit i: some row of fragment i has a vector
-    if (look) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int4 c = *reinterpret_cast<const int4*>(&cslot_r[wn * 64 + j * 16 + lq * 4]);
-            if (__any(c.x >= 0)) cmask |= 1u << (4 * j);
-            if (__any(c.y >= 0)) cmask |= 2u << (4 * j);
-            if (__any(c.z >= 0)) cmask |= 4u << (4 * j);
-            if (__any(c.w >= 0)) cmask |= 8u << (4 * j);
-            if (cmask >> (4 * j) & 15) jmask |= 1u << j;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (__any(rslot_r[wm * 128 + i * 16 + l16] >= 0)) rmask |= 1u << i;
-    }
+    unsigned rmask = 0;                 // bit i: some row of fragment i has a vector (set by the one-pass epilogue from its preloads)
     const float* const wvl = reinterpret_cast<const float*>(ring + wa_);          // (REC: column values, [tile row][column slot])
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.y) | (uintptr_t)(a.ldy * 4)) & 15) == 0;
     // tiles of fragment i: pass 0 the ones no vector touches, pass 1 the others (with their vectors)
@@ -614,25 +688,143 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // (2), (3): batches of this wave's entries -- blocks requested (one round trip, exposed: the stores of the whole chip
     // start together behind it, and a gather issued beside them would queue behind the compute unit's own stores), vectors
     // formed; a second batch is rare
-    int lastkey = -1, lastslot = -1;
-    bool more = look && !have;
-    while (more) {
-        int bkey[V9_NB_ENT];
-#pragma unroll
-        for (int b = 0; b < V9_NB_ENT; ++b) {
-            bkey[b] = next_key(lastkey);
-            if (bkey[b] != 0x7fffffff) { lastkey = bkey[b]; gather(bkey[b] & 255, b); }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int b = 0; b < V9_NB_ENT; ++b)
-            if (bkey[b] != 0x7fffffff) {
-                const int slot = bkey[b] >> 18;
-                finish(bkey[b] & 255, b, slot, slot >= V9_FAST_MAX && slot != lastslot);
-                lastslot = slot;
+    if (STAMP) st_x[1] = __builtin_amdgcn_s_memrealtime();
+    if (tmode) {
+        // ---- round 4: ONE VECTOR PER ENTRY, formed by all waves at once.  Quarter c of entry i is an independent item (64
+        //      products from blocks that are in the ring already): no sorting, no read-modify-write, nothing to wait for
+        //      between items -- the serial service below (one wave per slot, entries in key order, a shuffle search per entry)
+        //      took 3-4 us for ~20 entries, of which the gathers were 0.5 (profiles/r04_v9_tail_prefetch.txt).  Then the
+        //      exception x exception terms as one pass over the (x entry, w entry) pairs, then the rows with several entries
+        //      folded into their first one (smallest block) in ascending block order by one wave: same sums, same order.
+        // A wave takes entries wave, wave + 8, wave + 16: the operands of all three are read before any product is formed (one
+        // LDS round trip a wave, not one per entry), and the wave that wrote an x entry's vector adds that entry's exception x
+        // exception terms right behind it (LDS operations of a wave complete in order: no barrier in between).
+        struct Ent { int4 pv, q0, q1, q2, q3; float s0, s1, s2, s3; int e3, sh, kb, code; };
+        auto load_entry = [&](Ent& t, int i, bool on, int o0, int o1, int o2, int o3) {
+            const bool is_x = i < cx;
+            const int* e = v8_entry(xb, wb, cx, on ? i : 0);
+            t.e3 = on ? e[3] : -2;
+            t.kb = e[1];
+            t.code = e[2];
+            t.sh = e[2] - (is_x ? +a.x_off : +a.w_off);
+            t.pv = *reinterpret_cast<const int4*>(e + 4);
+            const float* sc = is_x ? swt : sxt;
+            t.q0 = *reinterpret_cast<const int4*>(ring + o0 + lane * 16); t.q1 = *reinterpret_cast<const int4*>(ring + o1 + lane * 16);
+            t.q2 = *reinterpret_cast<const int4*>(ring + o2 + lane * 16); t.q3 = *reinterpret_cast<const int4*>(ring + o3 + lane * 16);
+            t.s0 = sc[lane]; t.s1 = sc[64 + lane]; t.s2 = sc[128 + lane]; t.s3 = sc[192 + lane];
+        };
+        auto form_entry = [&](const Ent& t, int i) {
+            if (t.e3 == -2 || (a.dbg & 64)) return;             // (uniform: void / outside the tile -- no vector)
+            float* v = i < V9_FAST_MAX ? corr + i * 256 : rvec + i * 256;
+            v[lane] = __builtin_ldexpf((float)dot16(t.pv, t.q0), t.sh) * t.s0;
+            v[64 + lane] = __builtin_ldexpf((float)dot16(t.pv, t.q1), t.sh) * t.s1;
+            v[128 + lane] = __builtin_ldexpf((float)dot16(t.pv, t.q2), t.sh) * t.s2;
+            v[192 + lane] = __builtin_ldexpf((float)dot16(t.pv, t.q3), t.sh) * t.s3;
+            if (i < cx && !(a.dbg & 32))                        // exception x exception: w entries at the same K position
+                for (int f0 = 0; f0 < cw; f0 += 64) {           // (uniform)
+                    const int fi = f0 + lane;
+                    if (fi < cw) {
+                        const int* f = wb + EXC_HEADER + EXC_ENTRY * fi;
+                        if (f[3] != -2 && f[1] == t.kb)
+                            v[f[0] - n0] += __builtin_ldexpf((float)dot16(t.pv, *reinterpret_cast<const int4*>(f + 4)), t.code + f[2] - a.scale_bias);
+                    }
+                }
+        };
+        const int npre = min(nent, V9_TPRE);
+        // ONE copy of the code, looped (three inlined copies with all their reads in flight took longer: behind the K loop the
+        // instruction stream is what costs), and no address arithmetic to speak of: the four quarters of entry wave + 8 k are
+        // pieces 4 wave .. 4 wave + 3 of tail step k -- 4 KiB in a row in that step's A half (waves 0-3) or B half.
+        {
+            const int blk = ring_lds * 0 + (wave & 3) * 4096;
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                const int i = wave + V9_NW * k;
+                if (i >= npre) break;
+                const int half = wave < 4 ? (k == 0 ? ga_[0] : k == 1 ? ga_[1] : ga_[2]) : V9_B0 + (k == 0 ? gb_[0] : k == 1 ? gb_[1] : gb_[2]);
+                Ent t;
+                load_entry(t, i, true, half + blk, half + blk + 1024, half + blk + 2048, half + blk + 3072);
+                form_entry(t, i);
             }
-        V9_LGKM(0);                                             // (this wave's reads of its scratch have returned)
-        more = bkey[V9_NB_ENT - 1] != 0x7fffffff;
+        }
+        if (STAMP) st_y[0] = __builtin_amdgcn_s_memrealtime();
+        if (nent > V9_TPRE) {
+            // the entries beyond the prefetched ones: their gathers now, all in one round trip; chunk k of the scratch (4 KiB,
+            // anywhere in the ring but its dead half) takes entry V9_TPRE + k
+            V9_LGKM(0);
+            __builtin_amdgcn_s_barrier();                       // (the prefetched blocks are consumed: the ring is scratch now)
+            auto chunk = [&](int k) { const int o = k * 4096; return o >= dead_a ? o + V9_HALF : o; };
+            for (int it = wave; it < (nent - V9_TPRE) * 4; it += V9_NW) {
+                const int i = V9_TPRE + (it >> 2), c = it & 3;
+                const int kb = __builtin_amdgcn_readfirstlane(v8_entry(xb, wb, cx, i)[1]);
+                const int koff = (kb >> 2) * 1024 + (kb & 3) * 256;
+                const int vo = glane + c * 4 * (int)row_bytes, dl = ring_lds + chunk(it >> 2) + c * 1024;
+                if (i < cx) { V9_BLDS16(vo, wg, koff, dl); } else { V9_BLDS16(vo, xg, koff, dl); }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            Ent t0, t1, t2;
+            const int k0 = wave, k1 = wave + V9_NW, k2 = wave + 2 * V9_NW, nx = nent - V9_TPRE;
+            load_entry(t0, V9_TPRE + k0, k0 < nx, chunk(k0), chunk(k0) + 1024, chunk(k0) + 2048, chunk(k0) + 3072);
+            load_entry(t1, V9_TPRE + k1, k1 < nx, chunk(k1), chunk(k1) + 1024, chunk(k1) + 2048, chunk(k1) + 3072);
+            load_entry(t2, V9_TPRE + k2, k2 < nx, chunk(k2), chunk(k2) + 1024, chunk(k2) + 2048, chunk(k2) + 3072);
+            form_entry(t0, V9_TPRE + k0);
+            form_entry(t1, V9_TPRE + k1);
+            form_entry(t2, V9_TPRE + k2);
+        }
+        if (STAMP) st_y[1] = __builtin_amdgcn_s_memrealtime();
+        // rows / columns with several entries (flagged by the bookkeeping): the others added to the first (wave = slot % 8,
+        // ascending block) once every vector is complete
+        if (reinterpret_cast<const int*>(smem + V9_FLAGS)[16] != 0) {       // (uniform)
+            V9_LGKM(0);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = lane + 64 * q;
+                mykeys[q] = 0x7fffffff;
+                if (j < nent) {
+                    const int* f = v8_entry(xb, wb, cx, j);
+                    const int s3 = f[3];
+                    if (s3 >= 0 && s3 != j && (s3 & 7) == wave) mykeys[q] = (s3 << 18) | (f[1] << 8) | j;
+                }
+            }
+            if (__any(mykeys[0] != 0x7fffffff || mykeys[1] != 0x7fffffff)) {
+                int last = -1;
+                for (;;) {
+                    const int key = next_key(last, -1);
+                    if (key == 0x7fffffff) break;
+                    last = key;
+                    float* h = V9_VEC(key >> 18);
+                    const float* o = V9_VEC(key & 255);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) h[c * 64 + lane] += o[c * 64 + lane];
+                }
+            }
+        }
+        V9_LGKM(0);
+        mykeys[0] = mykeys[1] = 0x7fffffff;                     // (the serial service below has nothing left to do)
+    }
+    int lastkey = -1, lastslot = -1;
+    // the serial service (tiles whose entries do not fit the parallel one above; FIX_ 2 falling back)
+    for (int phase = -1; phase < 0; ++phase) {
+        bool more = look && !have && !tmode;
+        while (more) {
+            int bkey[V9_NB_ENT];
+#pragma unroll
+            for (int b = 0; b < V9_NB_ENT; ++b) {
+                bkey[b] = next_key(lastkey, phase);
+                if (bkey[b] != 0x7fffffff) { lastkey = bkey[b]; gather(bkey[b] & 255, b); }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int b = 0; b < V9_NB_ENT; ++b)
+                if (bkey[b] != 0x7fffffff) {
+                    const int slot = bkey[b] >> 18;
+                    finish(bkey[b] & 255, b, slot, !tmode && slot >= V9_FAST_MAX && slot != lastslot);
+                    lastslot = slot;
+                }
+            V9_LGKM(0);                                             // (this wave's reads of its scratch have returned)
+            more = bkey[V9_NB_ENT - 1] != 0x7fffffff;
+        }
     }
     if (STAMP) st_x[2] = __builtin_amdgcn_s_memrealtime();
     if (look && !have) __builtin_amdgcn_s_barrier();
@@ -661,6 +853,18 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             swr[j] = *reinterpret_cast<const f32x4*>(&swt[cl]);
             bvr[j] = *reinterpret_cast<const f32x4*>(&bst[cl]);
         }
+        // which fragments a vector touches at all (uniform masks, from the registers just loaded)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (__any(cs[j].x >= 0)) cmask |= 1u << (4 * j);
+            if (__any(cs[j].y >= 0)) cmask |= 2u << (4 * j);
+            if (__any(cs[j].z >= 0)) cmask |= 4u << (4 * j);
+            if (__any(cs[j].w >= 0)) cmask |= 8u << (4 * j);
+            if (cmask >> (4 * j) & 15) jmask |= 1u << j;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (__any(rs[i] >= 0)) rmask |= 1u << i;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const bool rowv = (rmask >> i) & 1;
@@ -724,7 +928,8 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
 #pragma unroll
             for (int q = 0; q < 6; ++q) d[q] = st_t[q];
             d[6] = c_loop;
-            d[7] = ((unsigned long long)(unsigned)nent << 32) | (unsigned)mode;
+            // (bits 8-19 / 20-31: the parallel service's first round and its second round, x 10 ns)
+            d[7] = ((unsigned long long)(unsigned)nent << 32) | (unsigned)mode | (((st_y[0] - st_x[1]) & 0xfff) << 8) | (((st_y[1] - st_y[0]) & 0xfff) << 20);
             // (the post-loop phases, x 10 ns, 12 bits each, instead of the stage-request stamp: bookkeeping, first-pass stores, vectors)
             d[1] = ((st_x[0] - st_t[3]) & 0xfff) | (((st_x[1] - st_x[0]) & 0xfff) << 12) | (((st_x[2] - st_x[1]) & 0xfff) << 24);
         }

@@ -27,10 +27,10 @@ for rep in range(3):
     for wv, name in ((0, "wave 0"), (1, "wave 7")):
         t = s[:, wv, :6]
         d = np.diff(t, axis=1) * 0.01
-        nent = s[:, wv, 7] >> 32; mode = s[:, wv, 7] & 0xff; nev = (s[:, wv, 7] >> 8) & 15; evc = (s[:, wv, 7] >> 12) & 0xfffff
+        nent = s[:, wv, 7] >> 32; mode = s[:, wv, 7] & 0xff; r1 = ((s[:, wv, 7] >> 8) & 0xfff) * 0.01; r2 = ((s[:, wv, 7] >> 20) & 0xfff) * 0.01; nev = (s[:, wv, 7] >> 8) & 15; evc = (s[:, wv, 7] >> 12) & 0xfffff
         px = s[:, wv, 1]; bk = (px & 0xfff) * 0.01; st0 = ((px >> 12) & 0xfff) * 0.01; vec = ((px >> 24) & 0xfff) * 0.01
         cps = s[:, wv, 6] / 64.0
         clk = s[:, wv, 6] / np.maximum(t[:, 3] - t[:, 2], 1) * 100.0
         print(f"{name}: start->loop {np.median((t[:,2]-t[:,0])*0.01):5.2f}  loop {np.median(d[:,2]):6.2f} (max {d[:,2].max():6.2f})  "
-              f"behind the loop {np.median(d[:,3]):5.2f} (max {d[:,3].max():5.2f})  epilogue {np.median(d[:,4]):5.2f} (max {d[:,4].max():5.2f}) us | "
+              f"behind the loop {np.median(d[:,3]):5.2f} (max {d[:,3].max():5.2f}) [bookkeeping {np.median(bk):.2f}, keys+masks {np.median(st0):.2f}, service {np.median(vec):.2f} max {vec.max():.2f} = round 1 {np.median(r1):.2f} + round 2 {np.median(r2):.2f} (max {r2.max():.2f}) + fold]  epilogue {np.median(d[:,4]):5.2f} (max {d[:,4].max():5.2f}) us | "
               f"epi pct 10/50/90/99 {np.percentile(d[:,4],10):.1f}/{np.percentile(d[:,4],50):.1f}/{np.percentile(d[:,4],90):.1f}/{np.percentile(d[:,4],99):.1f} | {np.median(clk):5.0f} MHz {np.median(cps):7.1f} clk/K-step | span {(t[:,5].max()-t[:,0].min())*0.01:6.2f} us | entries med {np.median(nent):.0f} max {nent.max()} modes {np.bincount(mode.astype(int))}")
