@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 18
+#define MI355Q_ABI_VERSION 19
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -448,6 +448,31 @@ int mi355q_bfp_softmax_matmul(const float* scores, const float* mask, int32_t ca
                               int64_t B, int64_t M, int64_t K, int64_t N, int32_t x_width, int32_t x_exponent_width,
                               int32_t x_exponent_bias, int32_t y_width, int32_t y_exponent_width, int32_t y_exponent_bias,
                               void* stream);
+
+/* ---- block_minifloat / block_log quantised batched matmul (ABI 19) ---------------------------------
+ * replaces: quantized_functions/matmul.py:199-249 (generic_matmul_block_minifloat behind matmul_block_minifloat /
+ *           bmm_block_minifloat) and :252-297 (generic_matmul_block_log behind matmul_block_log / bmm_block_log), operands
+ *           flattened to 3-D like mi355q_bfp_matmul's -- the same two kernels (y packed transposed, x quantised in registers
+ *           on its way into bf16 MFMAs, fp32 accumulation) with the other block quantisers:
+ *   block_minifloat: out[b] = Qx(x[b]) @ Qy(y[b]); both operands in [1,16] blocks, shared bias per block
+ *     (block_minifloat.py:13-79); width - exponent_width - 1 <= 7 mantissa bits (exact in bf16), else MI355Q_E_UNSUPPORTED.
+ *     The softmax variant is mi355q_bfp_softmax_matmul's with these quantisers.
+ *   block_log: out[b] = Qx(x[b]) @ y[b] -- the reference quantises x ONLY (matmul.py:278-297 passes y through).  x becomes
+ *     signed powers of two (exact in bf16); y enters as three bf16 planes hi + mid + lo = y exactly, so every product is
+ *     exact and the result is the fp32 product's up to summation order.  All-zero blocks of x take the reference's
+ *     tensor-wide fill (block_log.py:48-58 -> block_fp.py:54-58): a statistics pass over x finds it first.
+ *     workspace: mi355q_block_log_matmul_workspace_bytes.
+ * K % 16 == 0, N % 16 == 0, B <= 65535, 16-byte aligned pointers. */
+int mi355q_block_minifloat_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
+                                  int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias_width,
+                                  int32_t y_width, int32_t y_exponent_width, int32_t y_exponent_bias_width, void* stream);
+int mi355q_block_minifloat_softmax_matmul(const float* scores, const float* mask, int32_t causal, const float* y, float* out,
+                                          void* workspace, int64_t B, int64_t M, int64_t K, int64_t N, int32_t x_width,
+                                          int32_t x_exponent_width, int32_t x_exponent_bias_width, int32_t y_width,
+                                          int32_t y_exponent_width, int32_t y_exponent_bias_width, void* stream);
+size_t mi355q_block_log_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N);
+int mi355q_block_log_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
+                            int64_t N, int32_t x_width, int32_t x_exponent_bias_width, void* stream);
 
 /* ---- the quantised attention core in one pass ------------------------------------------------------------------
  * replaces, in the reference's attention modules (models/opt_quantized/modeling_opt.py:246-312,

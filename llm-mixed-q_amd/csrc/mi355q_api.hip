@@ -849,6 +849,72 @@ int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v,
                                 scale_div, static_cast<hipStream_t>(stream), strides ? st6 : nullptr);
 }
 
+// block_minifloat (fmt 1) / block_log (fmt 2) products: the same two kernels with the other quantisers' block parameters
+static int values_matmul_impl(int fmt, bool softmax, const float* mask, long long causal_off, const float* x, const float* y,
+                              float* out, void* workspace, int64_t B, int64_t M, int64_t K, int64_t N, int32_t x_width,
+                              int32_t x_exponent_width, int32_t x_exponent_bias_width, int32_t y_width, int32_t y_exponent_width,
+                              int32_t y_exponent_bias_width, void* stream) {
+    if (B < 0 || M < 0 || K < 0 || N < 0) return MI355Q_E_BADARG;
+    if (B == 0 || M == 0 || N == 0) return 0;
+    if (!out || B > 65535) return MI355Q_E_BADARG;
+    if (K == 0) return (int)hipMemsetAsync(out, 0, (size_t)B * M * N * 4, static_cast<hipStream_t>(stream));
+    if (!x || !y || !workspace) return MI355Q_E_BADARG;
+    QuantArgs ax{}, ay{};
+    ax.b0 = ay.b0 = 1; ax.b1 = ay.b1 = 16;
+    if (fmt == 1) {
+        auto fill = [](QuantArgs& a, int width, int ew, int ebw) -> int {
+            const int mbits = width - ew - 1;
+            if (ew < 1 || ew > 8 || mbits < 0 || mbits > 23 || ebw < 1 || ebw > 8) return MI355Q_E_BADARG;
+            if (mbits > 7) return MI355Q_E_UNSUPPORTED;          // a quantised value must fit bf16's 8 significant bits
+            a.span = (1 << ew) - 1;
+            a.bias_max = (1 << ebw) - 1;
+            set_mantissa(a, mbits);
+            return 0;
+        };
+        int rc = fill(ax, x_width, x_exponent_width, x_exponent_bias_width);
+        if (rc == 0) rc = fill(ay, y_width, y_exponent_width, y_exponent_bias_width);
+        if (rc) return rc;
+    } else {
+        if (x_width < 2 || x_width > 9 || x_exponent_bias_width < 1 || x_exponent_bias_width > 8) return MI355Q_E_BADARG;
+        ax.span = (1 << (x_width - 1)) - 1;
+        ax.bias_max = (1 << x_exponent_bias_width) - 1;
+        set_mantissa(ax, 0);
+        set_mantissa(ay, 0);
+    }
+    if (K % 16 != 0 || N % 16 != 0) return MI355Q_E_UNSUPPORTED;      // blocks of 16 along K (x) and N (y) tile the operands
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(workspace)) % 16)
+        return MI355Q_E_ALIGN;
+    return launch_bfp_qmatmul(ax, ay, x, y, out, workspace, B, M, K, N, static_cast<hipStream_t>(stream), softmax, mask, causal_off, fmt);
+}
+
+int mi355q_block_minifloat_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
+                                  int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias_width,
+                                  int32_t y_width, int32_t y_exponent_width, int32_t y_exponent_bias_width, void* stream) {
+    return values_matmul_impl(1, false, nullptr, -1, x, y, out, workspace, B, M, K, N, x_width, x_exponent_width,
+                              x_exponent_bias_width, y_width, y_exponent_width, y_exponent_bias_width, stream);
+}
+
+int mi355q_block_minifloat_softmax_matmul(const float* scores, const float* mask, int32_t causal, const float* y, float* out,
+                                          void* workspace, int64_t B, int64_t M, int64_t K, int64_t N, int32_t x_width,
+                                          int32_t x_exponent_width, int32_t x_exponent_bias_width, int32_t y_width,
+                                          int32_t y_exponent_width, int32_t y_exponent_bias_width, void* stream) {
+    if (K > 0 && (K <= 192 || N > 128)) return MI355Q_E_UNSUPPORTED;
+    if (causal && K < M) return MI355Q_E_BADARG;              // (query i sees keys 0 .. i + K - M)
+    if (mask && reinterpret_cast<uintptr_t>(mask) % 16) return MI355Q_E_ALIGN;
+    return values_matmul_impl(1, true, mask, causal ? (long long)(K - M) : -1, scores, y, out, workspace, B, M, K, N, x_width,
+                              x_exponent_width, x_exponent_bias_width, y_width, y_exponent_width, y_exponent_bias_width, stream);
+}
+
+size_t mi355q_block_log_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N) {
+    if (B <= 0 || K <= 0 || N <= 0) return 0;
+    return 3 * (size_t)B * (size_t)((K + 63) / 64 * 64) * (size_t)N * 2 + 64;      // three bf16 planes of y + the statistics word
+}
+
+int mi355q_block_log_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
+                            int64_t N, int32_t x_width, int32_t x_exponent_bias_width, void* stream) {
+    return values_matmul_impl(2, false, nullptr, -1, x, y, out, workspace, B, M, K, N, x_width, 0, x_exponent_bias_width, 0, 0, 0, stream);
+}
+
 int mi355q_bfp_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,
                       int64_t N, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, int32_t y_width,
                       int32_t y_exponent_width, int32_t y_exponent_bias, void* stream) {

@@ -495,8 +495,12 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     float* rvec = reinterpret_cast<float*>(ring) + (V9_GSCR - V9_FAST_MAX * 1024) / 4;   // (vector of slot s >= V9_FAST_MAX)
     bool tmode = false;               // TPF: this tile's first V9_TPRE gathers are in the ring already
 #define V9_VEC(s_) (((s_) < V9_FAST_MAX ? corr : rvec) + (s_) * 256)
+    // (the two exponent offsets as opaque scalars: `is_x ? a.x_off : a.w_off` on the by-value argument struct becomes an indexed
+    //  load of two adjacent fields, for which the compiler parks them in 16 bytes of scratch memory)
+    int x_off_s = a.x_off, w_off_s = a.w_off;
+    asm volatile("" : "+s"(x_off_s), "+s"(w_off_s));
     bool look = false;
-    int mykeys[2] = {0x7fffffff, 0x7fffffff};                   // (slot << 18 | block << 8 | index) of the entries at list
+    int mykeys0 = 0x7fffffff, mykeys1 = 0x7fffffff;                   // (slot << 18 | block << 8 | index) of the entries at list
                                                                 // positions lane, lane + 64 that this wave serves
     bool have = false;                                          // maps and vectors are the producers' (REC), in LDS already
     if (REC && !nofit) {
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         const int* e = v8_entry(xb, wb, cx, i);
         const int kb = e[1], code = e[2];
         const int4 pv = *reinterpret_cast<const int4*>(e + 4);
-        const int sh = code - (is_x ? +a.x_off : +a.w_off);
+        const int sh = code - (is_x ? x_off_s : w_off_s);
         const float* sc = is_x ? swt : sxt;
         float* v = V9_VEC(slot);
 #pragma unroll
@@ -601,25 +605,25 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // the wave's next entry: the smallest key above `last` among the two this lane holds, over the wave
     // (`phase`: -1 all entries; 0 / 1 those whose gathers were / were not prefetched, tmode)
     auto next_key = [&](int last, int phase) {
-        const bool in0 = phase < 0 || ((mykeys[0] & 255) >= V9_TPRE) == (phase == 1);
-        const bool in1 = phase < 0 || ((mykeys[1] & 255) >= V9_TPRE) == (phase == 1);
-        int best = mykeys[0] > last && in0 ? mykeys[0] : 0x7fffffff;
-        if (mykeys[1] > last && in1) best = min(best, mykeys[1]);
+        const bool in0 = phase < 0 || ((mykeys0 & 255) >= V9_TPRE) == (phase == 1);
+        const bool in1 = phase < 0 || ((mykeys1 & 255) >= V9_TPRE) == (phase == 1);
+        int best = mykeys0 > last && in0 ? mykeys0 : 0x7fffffff;
+        if (mykeys1 > last && in1) best = min(best, mykeys1);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) best = min(best, __shfl_xor(best, o));
         return __builtin_amdgcn_readfirstlane(best);
     };
     if (look && !have && !tmode) {
         // (2) this wave's entries
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int j = lane + 64 * q;
-            if (j < nent) {
-                const int* f = v8_entry(xb, wb, cx, j);
-                const int s3 = f[3];
-                if (s3 != -2 && (s3 & 7) == wave) mykeys[q] = (s3 << 18) | (f[1] << 8) | j;
-            }
-        }
+        // (two named scalars, not an array: a q loop the compiler keeps rolled would index it in scratch memory)
+        auto key_of = [&](int j) {
+            if (j >= nent) return 0x7fffffff;
+            const int* f = v8_entry(xb, wb, cx, j);
+            const int s3 = f[3];
+            return s3 != -2 && (s3 & 7) == wave ? (s3 << 18) | (f[1] << 8) | j : 0x7fffffff;
+        };
+        mykeys0 = key_of(lane);
+        mykeys1 = key_of(lane + 64);
     }
     // (masks only -- scales, bias and slots are read again where they are used: the accumulators take half the registers)
     // the maps the stores consult: the tile's own (formed above) or the producers' (REC: pieces 0 and 1 of the B half of the
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             t.e3 = on ? e[3] : -2;
             t.kb = e[1];
             t.code = e[2];
-            t.sh = e[2] - (is_x ? +a.x_off : +a.w_off);
+            t.sh = e[2] - (is_x ? x_off_s : w_off_s);
             t.pv = *reinterpret_cast<const int4*>(e + 4);
             const float* sc = is_x ? swt : sxt;
             t.q0 = *reinterpret_cast<const int4*>(ring + o0 + lane * 16); t.q1 = *reinterpret_cast<const int4*>(ring + o1 + lane * 16);
@@ -777,17 +781,15 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         if (reinterpret_cast<const int*>(smem + V9_FLAGS)[16] != 0) {       // (uniform)
             V9_LGKM(0);
             __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int j = lane + 64 * q;
-                mykeys[q] = 0x7fffffff;
-                if (j < nent) {
-                    const int* f = v8_entry(xb, wb, cx, j);
-                    const int s3 = f[3];
-                    if (s3 >= 0 && s3 != j && (s3 & 7) == wave) mykeys[q] = (s3 << 18) | (f[1] << 8) | j;
-                }
-            }
-            if (__any(mykeys[0] != 0x7fffffff || mykeys[1] != 0x7fffffff)) {
+            auto follower_key = [&](int j) {
+                if (j >= nent) return 0x7fffffff;
+                const int* f = v8_entry(xb, wb, cx, j);
+                const int s3 = f[3];
+                return s3 >= 0 && s3 != j && (s3 & 7) == wave ? (s3 << 18) | (f[1] << 8) | j : 0x7fffffff;
+            };
+            mykeys0 = follower_key(lane);
+            mykeys1 = follower_key(lane + 64);
+            if (__any(mykeys0 != 0x7fffffff || mykeys1 != 0x7fffffff)) {
                 int last = -1;
                 for (;;) {
                     const int key = next_key(last, -1);
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             }
         }
         V9_LGKM(0);
-        mykeys[0] = mykeys[1] = 0x7fffffff;                     // (the serial service below has nothing left to do)
+        mykeys0 = mykeys1 = 0x7fffffff;                     // (the serial service below has nothing left to do)
     }
     int lastkey = -1, lastslot = -1;
     // the serial service (tiles whose entries do not fit the parallel one above; FIX_ 2 falling back)

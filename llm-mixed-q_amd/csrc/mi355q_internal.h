@@ -51,7 +51,7 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
                             int* list_to_clear, hipStream_t st, int bcap, const CorrLaunch* corr = nullptr);
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
                        long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false,
-                       const float* mask = nullptr, long long causal_off = -1);
+                       const float* mask = nullptr, long long causal_off = -1, int fmt = 0);
 size_t attention_workspace_bytes(long long B, long long T, long long D);
 int attention_set_kernel(int which);
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,

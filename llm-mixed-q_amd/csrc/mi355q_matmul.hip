@@ -1,5 +1,6 @@
-// mi355q_matmul.hip -- block_fp quantised batched matmul  out[b] = Qx(x[b]) @ Qy(y[b])  (reference
-// quantized_functions/matmul.py:146-196: x quantised along its last dim = the contraction, y along ITS last dim = the
+// mi355q_matmul.hip -- block-quantised batched matmul  out[b] = Qx(x[b]) @ Qy(y[b])  for block_fp, block_minifloat and (x
+// only: the reference leaves y unquantised there, matmul.py:252-297) block_log operands  (reference
+// quantized_functions/matmul.py:146-297: x quantised along its last dim = the contraction, y along ITS last dim = the
 // output columns, then torch.matmul / torch.bmm on the fake-quantised fp32 tensors).
 //
 // The large operand is x (attention probabilities [heads, T, T], 4 B per element): the reference writes its
@@ -38,11 +39,20 @@ __host__ __device__ constexpr int mm_kperm(int k) {
 }
 
 // ---- kernel 1: y [B, K, N] fp32 -> fake-quantise along N -> yt [B, N, K] bf16 ------------------------------------
+// FMT: the block format y is fake-quantised in (round 4: block_minifloat beside block_fp -- its values have <= 7 mantissa bits,
+// exact in bf16 like block_fp's).  FMT_RAW: y is NOT quantised (block_log products, reference quirk: matmul.py:252-297 passes
+// the second operand through) and goes out as THREE bf16 planes hi / mid / lo with y = hi + mid + lo exactly (8 + 8 + 8
+// significant bits by truncation): x is a signed power of two there, so every x * plane product is exact in fp32 and the sum
+// of the three accumulations is the fp32 product's, up to summation order.  `plane_stride`: elements between planes.
+constexpr int FMT_RAW = 3;
+template <int FMT>
 __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a, const float* __restrict__ y,
-                                                               uint16_t* __restrict__ yt, long long K, long long Kp, long long N) {
+                                                               uint16_t* __restrict__ yt, long long K, long long Kp, long long N,
+                                                               long long plane_stride) {
     __shared__ Lut lut;
-    __shared__ uint16_t tile[64][64 + 8];                 // [n][k], row padded against bank conflicts
-    load_lut<FMT_BFP>(lut);
+    constexpr int NPL = FMT == FMT_RAW ? 3 : 1;
+    __shared__ uint16_t tile[NPL][64][64 + 8];            // [plane][n][k], row padded against bank conflicts
+    if (FMT != FMT_RAW) load_lut<(FMT == FMT_RAW ? FMT_BFP : FMT)>(lut);
     const int tid = threadIdx.x;
     const long long b = blockIdx.z, k0 = (long long)blockIdx.y * 64, n0 = (long long)blockIdx.x * 64;
     const int n4 = tid & 15, kr = tid >> 4;
@@ -55,17 +65,32 @@ __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a
         float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         bmax = group_max<4>(bmax);                        // 4 adjacent lanes = one [1,16] block along N
         float q[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bmax != 0.f) {
-            unsigned code;
-            const BlockParam bp = block_param<FMT_BFP>(bmax, a, lut, code);
-            int mant;
-            q[0] = quant_elem<FMT_BFP>(v.x, bp, a, lut, mant);
-            q[1] = quant_elem<FMT_BFP>(v.y, bp, a, lut, mant);
-            q[2] = quant_elem<FMT_BFP>(v.z, bp, a, lut, mant);
-            q[3] = quant_elem<FMT_BFP>(v.w, bp, a, lut, mant);
-        }
+        if (FMT == FMT_RAW) {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tile[n4 * 4 + j][mm_kperm(kr + 16 * i)] = (uint16_t)(pack_bf16(q[j], 0.f) & 0xFFFFu);
+            for (int j = 0; j < 4; ++j) {
+                float r = vv[j];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {         // truncation: every plane exact, the remainder exact
+                    const unsigned hb = __float_as_uint(r) & 0xFFFF0000u;
+                    tile[pl][n4 * 4 + j][mm_kperm(kr + 16 * i)] = (uint16_t)(hb >> 16);
+                    r -= __uint_as_float(hb);
+                }
+            }
+        } else {
+            constexpr int F = FMT == FMT_RAW ? FMT_BFP : FMT;
+            if (bmax != 0.f) {
+                unsigned code;
+                const BlockParam bp = block_param<F>(bmax, a, lut, code);
+                int mant;
+                q[0] = quant_elem<F>(v.x, bp, a, lut, mant);
+                q[1] = quant_elem<F>(v.y, bp, a, lut, mant);
+                q[2] = quant_elem<F>(v.z, bp, a, lut, mant);
+                q[3] = quant_elem<F>(v.w, bp, a, lut, mant);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[0][n4 * 4 + j][mm_kperm(kr + 16 * i)] = (uint16_t)(pack_bf16(q[j], 0.f) & 0xFFFFu);
+        }
     }
     __syncthreads();
     // 64 rows (n) x 64 k: thread writes 16 bytes (8 k) of one row
@@ -75,9 +100,12 @@ __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int slot = tid + 256 * i, ntl = slot >> 7, t = (slot >> 6) & 1, ln = slot & 63;
-        if (n0 + 16 * ntl < N)                            // (whole 64-groups: zeros behind K)
-            *reinterpret_cast<uint4*>(yt + ((((b * (N >> 4) + (n0 >> 4) + ntl) * Kp + blockIdx.y) * 2 + t) * 64 + ln) * 8) =
-                *reinterpret_cast<const uint4*>(&tile[16 * ntl + (ln & 15)][32 * t + 8 * (ln >> 4)]);
+        if (n0 + 16 * ntl < N) {                          // (whole 64-groups: zeros behind K)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                *reinterpret_cast<uint4*>(yt + pl * plane_stride + ((((b * (N >> 4) + (n0 >> 4) + ntl) * Kp + blockIdx.y) * 2 + t) * 64 + ln) * 8) =
+                    *reinterpret_cast<const uint4*>(&tile[pl][16 * ntl + (ln & 15)][32 * t + 8 * (ln >> 4)]);
+        }
     }
 }
 
@@ -120,10 +148,40 @@ __device__ __forceinline__ float quant_elem_fused(float x, int up, int down, flo
     return fabsf(x) <= ATOL ? x : q;
 }
 
+// One block_minifloat element given its block's bias, biased-exponent bounds eminb = 127 - bias, emaxb = 127 + span - bias
+// (minifloat.py:165-194 with exponent_bias = the block's), in ~18 VALU operations instead of quant_elem's ~40, same result:
+//   * floor(log2(v)) of the normal v = |x| + 1e-9 is its exponent field, except within a few ulps below a power of two where
+//     torch's fp32 log2 rounds up (the table's band, M >= FLOOR_THR_MIN): `near` reports those and the caller redoes the step
+//     with quant_elem -- about one step in a thousand;
+//   * mn * shift = ldexp(|x|, mbits - e) in one exact scaling (overflow gives inf either way, clamped to the top mantissa);
+//   * 2^e (1 + sm / shift) = ldexp(shift + sm, e - mbits), 2^e (sm / shift) 2 = ldexp(2 sm, e - mbits): integers below 2^9.
+__device__ __forceinline__ float bm_elem_fused(float x, int eminb, int emaxb, int mbits, float shift, float mant_max, bool& near) {
+    const float ax = fabsf(x);
+    const unsigned vb = __float_as_uint(ax + EPS9);
+    near |= (vb | 0xFF800000u) >= (MI355Q_LOG2_FLOOR_THR_MIN | 0xFF800000u);
+    const int eb = min(max((int)(vb >> 23), eminb), emaxb);
+    const float t = __builtin_ldexpf(ax, mbits + 127 - eb);
+    const float un = fminf(fmaxf(__builtin_rintf(t - shift), 0.f), mant_max) + shift;
+    const float us = fminf(__builtin_rintf(t * 0.5f), mant_max) * 2.0f;
+    const float q = __builtin_copysignf(__builtin_ldexpf(eb != eminb ? un : us, eb - 127 - mbits), x);
+    return ax <= ATOL ? x : q;
+}
+// One block_log element (log.py:47-56 with exponent_bias = the block's; eps = 0.1 * 2^-bias): sign(x + eps) * 2^clamp(round(
+// log2(|x| + eps))).  round(log2(v)) is the exponent field plus one when the fraction lies above sqrt(2)'s band; inside the
+// band ([RND_LO_MIN, RND_HI_MAX], 125 fraction values where torch's fp32 log2 decides) and for subnormal v: `near`, as above.
+__device__ __forceinline__ float bl_elem_fused(float x, float eps, int eminb, int emaxb, bool& near) {
+    const float sg = x + eps;
+    const unsigned vb = __float_as_uint(fabsf(x) + eps);
+    near |= ((vb & 0x7FFFFFu) - MI355Q_LOG2_RND_LO_MIN) <= (unsigned)(MI355Q_LOG2_RND_HI_MAX - MI355Q_LOG2_RND_LO_MIN) || vb < 0x00800000u;
+    const int rb = min(max((int)((vb + (0x7FFFFFu - MI355Q_LOG2_RND_HI_MAX)) >> 23), eminb), emaxb);
+    return __builtin_ldexpf(__builtin_copysignf(sg != 0.f ? 1.0f : 0.0f, sg), rb - 127);
+}
+
 // quantise the wave's step: lane (r, g) holds float4 g of blocks 0..3 of row r.  The shared exponent of block i is
 // worked out by lane group i only (threshold lookup and clamp once per block, not four times) and fetched by the others.
+template <int FMT>
 __device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a, const Lut& lut, int mbits, int lane,
-                                              bf16x8 (&afr)[2]) {
+                                              bf16x8 (&afr)[2], float zfill = 1.0f) {
     const int g = lane >> 4;
     float bm[4];
 #pragma unroll
@@ -135,17 +193,49 @@ __device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a,
     }
     const float mine = g == 0 ? bm[0] : (g == 1 ? bm[1] : (g == 2 ? bm[2] : bm[3]));
     unsigned code;
-    const int pmine = block_param<FMT_BFP>(mine, a, lut, code).p;         // (an all-zero block: any exponent, see below)
+    // (an all-zero block: block_fp / block_minifloat elements <= 1e-8 pass through as zeros whatever the parameter; block_log
+    //  has no pass-through -- its zeros become +2^-bias with the bias of the reference's tensor-wide fill, the smallest
+    //  non-zero block maximum of the whole tensor (block_fp.py:54-58 via block_log.py:48-58): `zfill`, from the statistics pass)
+    const int pmine = block_param<FMT>(mine > 0.f ? mine : zfill, a, lut, code).p;
     float q[16];
+    bool near = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = __shfl(pmine, (lane & 15) + 16 * i);
         const float4 v = s.v[i];
-        // (elements of an all-zero block are <= 1e-8 and pass through as zeros)
-        q[4 * i + 0] = quant_elem_fused(v.x, mbits - p, p - mbits, a.mant_max);
-        q[4 * i + 1] = quant_elem_fused(v.y, mbits - p, p - mbits, a.mant_max);
-        q[4 * i + 2] = quant_elem_fused(v.z, mbits - p, p - mbits, a.mant_max);
-        q[4 * i + 3] = quant_elem_fused(v.w, mbits - p, p - mbits, a.mant_max);
+        if (FMT == FMT_BFP) {
+            // (elements of an all-zero block are <= 1e-8 and pass through as zeros)
+            q[4 * i + 0] = quant_elem_fused(v.x, mbits - p, p - mbits, a.mant_max);
+            q[4 * i + 1] = quant_elem_fused(v.y, mbits - p, p - mbits, a.mant_max);
+            q[4 * i + 2] = quant_elem_fused(v.z, mbits - p, p - mbits, a.mant_max);
+            q[4 * i + 3] = quant_elem_fused(v.w, mbits - p, p - mbits, a.mant_max);
+        } else if (FMT == FMT_BM) {
+            q[4 * i + 0] = bm_elem_fused(v.x, 127 - p, 127 + a.span - p, mbits, a.shift, a.mant_max, near);
+            q[4 * i + 1] = bm_elem_fused(v.y, 127 - p, 127 + a.span - p, mbits, a.shift, a.mant_max, near);
+            q[4 * i + 2] = bm_elem_fused(v.z, 127 - p, 127 + a.span - p, mbits, a.shift, a.mant_max, near);
+            q[4 * i + 3] = bm_elem_fused(v.w, 127 - p, 127 + a.span - p, mbits, a.shift, a.mant_max, near);
+        } else {
+            const float eps = __builtin_ldexpf(0.1f, -p);
+            q[4 * i + 0] = bl_elem_fused(v.x, eps, 127 - p, 127 + a.span - p, near);
+            q[4 * i + 1] = bl_elem_fused(v.y, eps, 127 - p, 127 + a.span - p, near);
+            q[4 * i + 2] = bl_elem_fused(v.z, eps, 127 - p, 127 + a.span - p, near);
+            q[4 * i + 3] = bl_elem_fused(v.w, eps, 127 - p, 127 + a.span - p, near);
+        }
+    }
+    if (FMT != FMT_BFP && __any(near)) {                  // (rare, wave-uniform: the streaming quantisers' element functions)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            BlockParam bp;
+            bp.p = __shfl(pmine, (lane & 15) + 16 * i);
+            bp.eps = FMT == FMT_BL ? __builtin_ldexpf(0.1f, -bp.p) : 0.f;
+            const float4 v = s.v[i];
+            int mant;
+            constexpr int F = FMT == FMT_BFP ? FMT_BM : FMT;
+            q[4 * i + 0] = quant_elem<F>(v.x, bp, a, lut, mant);
+            q[4 * i + 1] = quant_elem<F>(v.y, bp, a, lut, mant);
+            q[4 * i + 2] = quant_elem<F>(v.z, bp, a, lut, mant);
+            q[4 * i + 3] = quant_elem<F>(v.w, bp, a, lut, mant);
+        }
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -245,15 +335,22 @@ __device__ __forceinline__ void mask_scores(XBlk& s, const float* __restrict__ m
     }
 }
 
-template <bool RESIDENT, int NT, bool SOFTMAX = false>
+// FMT: x's block format (block_fp, block_minifloat, block_log); PLANES: bf16 planes of y (3 for block_log's raw y, else 1)
+template <bool RESIDENT, int NT, bool SOFTMAX = false, int FMT = FMT_BFP, int PLANES = 1>
 __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
                                                           const uint16_t* __restrict__ yt, float* __restrict__ out,
                                                           long long M, long long K, long long Kp, long long N,
-                                                          const float* __restrict__ mask, long long causal_off) {
+                                                          const float* __restrict__ mask, long long causal_off,
+                                                          long long plane_stride, const unsigned* __restrict__ xstats) {
     __shared__ Lut lut;
     __shared__ f32x4 red[4][NT][64];                      // [wave][tile][lane]: split-K partial tiles
     __shared__ float stat[4][16];
-    load_lut<FMT_BFP>(lut);
+    load_lut<FMT>(lut);
+    float zfill = 1.0f;                                   // (block_log: the fill of all-zero blocks, bl_block_stats_kernel)
+    if (FMT == FMT_BL) {
+        const unsigned u = __builtin_amdgcn_readfirstlane(xstats[0]);
+        zfill = u == 0xFFFFFFFFu ? 1.0f : __uint_as_float(u);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const long long b = blockIdx.y, m0 = (long long)blockIdx.x * 16;
@@ -273,7 +370,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
             XBlk s;
             load_xblk(s, row, st * 64, g, K);
             mask_xblk(s, st * 64, K);
-            quantise_xblk(s, a, lut, mbits, lane, res[st]);
+            quantise_xblk<FMT>(s, a, lut, mbits, lane, res[st], zfill);
         }
         // Two fragment sets used alternately: the next chunk's yt fragments are requested BEFORE this chunk's stores --
         // vmcnt counts loads and stores in one queue, so fragments requested behind the stores could only be used once
@@ -281,19 +378,30 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
         BFrag<4> b0[NS], b1[NS];
         const long long step = 4 * MM_NCHUNK, nlast = ((N - 1) / MM_NCHUNK) * MM_NCHUNK;
         long long n0 = (long long)wave * MM_NCHUNK;
+        // (PLANES > 1: the planes of a chunk are taken one after the other through the same two fragment sets -- the
+        //  sequence (chunk, plane) alternates between them -- into one accumulator that is stored behind the last plane)
+        int pl = 0;
+        f32x4 acc[4];
 #pragma unroll
         for (int st = 0; st < NS; ++st) load_bfrag<4>(b0[st], ytb, min(n0, nlast), st * 64, Kp, N, lane);
 #define MI355Q_MM_CHUNK(USE_, FILL_)                                                                         \
         {                                                                                                   \
-            f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};                          \
+            if (PLANES == 1 || pl == 0)                                                                     \
+                _Pragma("unroll") for (int tile = 0; tile < 4; ++tile) acc[tile] = f32x4{0, 0, 0, 0};       \
             _Pragma("unroll") for (int st = 0; st < NS; ++st) mma_step<4>(res[st], USE_[st], n0, N, acc);   \
             __builtin_amdgcn_sched_barrier(0);                                                              \
+            const bool last_pl = PLANES == 1 || pl == PLANES - 1;                                           \
+            const long long nn = last_pl ? n0 + step : n0;                                                  \
+            const int npl = last_pl ? 0 : pl + 1;                                                           \
             _Pragma("unroll") for (int st = 0; st < NS; ++st)                                               \
-                load_bfrag<4>(FILL_[st], ytb, min(n0 + step, nlast), st * 64, Kp, N, lane);                 \
+                load_bfrag<4>(FILL_[st], ytb + npl * plane_stride, min(nn, nlast), st * 64, Kp, N, lane);   \
             __builtin_amdgcn_sched_barrier(0);                                                              \
-            _Pragma("unroll") for (int tile = 0; tile < 4; ++tile)                                          \
-                if (n0 + 16 * tile < N) store_tile(acc[tile], outb, m0, n0 + 16 * tile, M, N, lane);       \
-            n0 += step;                                                                                     \
+            if (last_pl) {                                                                                  \
+                _Pragma("unroll") for (int tile = 0; tile < 4; ++tile)                                      \
+                    if (n0 + 16 * tile < N) store_tile(acc[tile], outb, m0, n0 + 16 * tile, M, N, lane);   \
+            }                                                                                               \
+            n0 = nn;                                                                                        \
+            pl = npl;                                                                                       \
         }
         while (n0 < N) {
             MI355Q_MM_CHUNK(b0, b1)
@@ -362,27 +470,31 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
         load_xblk(xa, row, (long long)wave * 64, g, K);
         for (long long st = wave; st < nsteps; st += 8) {
             {
-                BFrag<NT> bf;
-                load_bfrag<NT>(bf, ytb, n0, st * 64, Kp, N, lane);
+                BFrag<NT> bf[PLANES];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) load_bfrag<NT>(bf[pl], ytb + pl * plane_stride, n0, st * 64, Kp, N, lane);
                 __builtin_amdgcn_sched_barrier(0);
                 load_xblk(xb, row, (st + 4) * 64, g, K);   // next step's x in flight under this one's work (behind K: a re-read)
                 __builtin_amdgcn_sched_barrier(0);
                 if (SOFTMAX) { mask_scores(xa, mrowp, st * 64, g, K, kvis); softmax_xblk(xa, row_max, row_sum, row_inv); }
                 if ((st + 1) * 64 > K) mask_xblk(xa, st * 64, K);          // (uniform: the last, partial step only)
-                quantise_xblk(xa, a, lut, mbits, lane, afr);
-                mma_step<NT>(afr, bf, n0, N, acc);
+                quantise_xblk<FMT>(xa, a, lut, mbits, lane, afr, zfill);
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) mma_step<NT>(afr, bf[pl], n0, N, acc);
             }
             if (st + 4 >= nsteps) break;
             {
-                BFrag<NT> bf;
-                load_bfrag<NT>(bf, ytb, n0, (st + 4) * 64, Kp, N, lane);
+                BFrag<NT> bf[PLANES];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) load_bfrag<NT>(bf[pl], ytb + pl * plane_stride, n0, (st + 4) * 64, Kp, N, lane);
                 __builtin_amdgcn_sched_barrier(0);
                 load_xblk(xa, row, (st + 8) * 64, g, K);
                 __builtin_amdgcn_sched_barrier(0);
                 if (SOFTMAX) { mask_scores(xb, mrowp, (st + 4) * 64, g, K, kvis); softmax_xblk(xb, row_max, row_sum, row_inv); }
                 if ((st + 5) * 64 > K) mask_xblk(xb, (st + 4) * 64, K);
-                quantise_xblk(xb, a, lut, mbits, lane, afr);
-                mma_step<NT>(afr, bf, n0, N, acc);
+                quantise_xblk<FMT>(xb, a, lut, mbits, lane, afr, zfill);
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) mma_step<NT>(afr, bf[pl], n0, N, acc);
             }
         }
         __syncthreads();                                   // (previous chunk's partials have been read)
@@ -403,33 +515,307 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
     }
 }
 
-int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
-                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax, const float* mask,
-                       long long causal_off) {
-    if (softmax && (K + 63) / 64 <= 3) return MI355Q_E_UNSUPPORTED;     // (short rows: the caller takes softmax + the plain entry)
-    dim3 g1((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)B);
-    const long long Kp = (K + 63) / 64;                    // 64-steps: yt is stored in fragment order (kernel 1)
-    hipLaunchKernelGGL(bfp_quant_pack_t_kernel, g1, 256, 0, st, ay, y, static_cast<uint16_t*>(yt), K, Kp, N);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+// ---- kernel 3: the tile product (round 4) -----------------------------------------------------------------------------
+// What bounded kernel 2 (profiles/r04_values_matmul.txt): a wave's yt fragments and its x prefetch share ONE in-order vector-
+// memory queue, so a fragment asked for "now" comes back behind every x prefetch issued before it -- a K-step cost an HBM
+// round trip however deep the prefetch, and the short-contraction form pulled the whole of yt[b] from L2 once per 16 rows
+// (2 GB of L2 traffic at [32, 2048, 128] x [32, 128, 2048]).  Here nothing is asked for "now": a workgroup of 8 waves x 16
+// rows streams EVERYTHING through LDS rings filled by LDS-DMA (global_load_lds_dwordx4) D - 1 pieces ahead --
+//   STREAM (long contraction, P V):  piece = the yt fragments of one 64-step for NT column tiles (NT x 2 KiB, shared by the 8
+//     waves), plus each wave's own x slab of that step (16 rows x 64 floats = 4 KiB, lane-for-lane the register layout of
+//     kernel 2, read back with one ds_read_b128 per block and quantised in registers); accumulators live across the steps;
+//   RESIDENT (short contraction, Q K^T): the wave's x is quantised once into registers; piece = the yt fragments of one
+//     64-column chunk for all NS steps (NS x 8 KiB, contiguous in yt); four 16 x 16 tiles stored per chunk;
+// one s_barrier per piece, hand-counted s_waitcnt vmcnt (the compiler must not see the DMA: it would drain it at every LDS read).
+// Counting only works if the number of LOADS per piece is fixed -- pieces and tiles beyond the end are clamped to the last valid
+// one (the same data lands on the same place twice), never skipped -- and if no STORES share the wave's counter: loads return in
+// order among themselves, stores among themselves, but not with respect to each other (a count that budgeted for the chunk
+// stores let pieces through that had not landed).  STREAM stores once, at the end.  RESIDENT stores every chunk, so there the
+// DMA is issued by a NINTH wave that does nothing else (wave specialisation): its counter sees loads only, and the eight
+// compute waves never wait on theirs.
+// PLANES > 1 (block_log's raw y as three bf16 planes): the planes of a step / chunk are consecutive pieces over the same x.
+constexpr int TP_WAVES = 8;
+#define MM_GLDS16(gp, lds) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds) : "memory")
+#define MM_WAITV(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// loads the issuing wave requests in the iteration of plane `pl`: its share of the yt piece (STREAM: an eighth, RESIDENT: the
+// whole piece), then (STREAM, plane 0) the four blocks of its x slab
+template <bool STREAM, int PLANES, int BW>
+constexpr int tp_tail_issues(int pl) { return STREAM && pl == 0 ? 4 : 0; }
+// instructions issued AFTER the DMA of the piece that iteration `it` (plane pl) needs, i.e. what may still be in flight when
+// that piece has landed: DB = ring depth in pieces (fetched DB - 1 iterations ahead), DX = x ring depth in steps
+template <bool STREAM, int PLANES, int BW, int DB, int DX>
+constexpr int tp_allowed(int pl) {
+    auto plane_of = [](int p) { return ((p % PLANES) + PLANES) % PLANES; };
+    int n = tp_tail_issues<STREAM, PLANES, BW>(plane_of(pl - (DB - 1)));
+    for (int d = DB - 2; d >= 1; --d) n += BW + tp_tail_issues<STREAM, PLANES, BW>(plane_of(pl - d));
+    if (STREAM && pl == 0) {                              // x of this step: issued (DX - 1) * PLANES iterations ago, last in its iteration
+        int m = 0;
+        for (int d = (DX - 1) * PLANES - 1; d >= 1; --d) m += BW + tp_tail_issues<STREAM, PLANES, BW>(plane_of(pl - d));
+        n = m < n ? m : n;
+    }
+    return n;
+}
+
+template <bool STREAM, int NTNS, int FMT, int PLANES>
+__global__ __launch_bounds__((TP_WAVES + (STREAM ? 0 : 1)) * 64) void bfp_qmatmul_tile_kernel(const QuantArgs a, const float* __restrict__ x,
+                                                                         const uint16_t* __restrict__ yt, float* __restrict__ out,
+                                                                         long long M, long long K, long long Kp, long long N,
+                                                                         long long plane_stride, const unsigned* __restrict__ xstats) {
+    constexpr int NT = STREAM ? NTNS : 4;                 // column tiles of a piece
+    constexpr int NS = STREAM ? 1 : NTNS;                 // 64-steps of a piece
+    constexpr int SUB = NT * NS * 2;                      // 1-KiB sub-pieces of a piece
+    constexpr int BW = STREAM ? SUB / TP_WAVES : SUB;     // DMA instructions per issuing wave and piece
+    static_assert(SUB % TP_WAVES == 0, "a piece is shared evenly by the waves");
+    constexpr int DB = STREAM ? 3 : 4, DX = PLANES > 1 ? 2 : 3;
+    constexpr int PIECE = SUB * 1024;
+    __shared__ Lut lut;
+    __shared__ __attribute__((aligned(16))) unsigned char bring[DB * PIECE];
+    __shared__ __attribute__((aligned(16))) unsigned char xring[STREAM ? DX * TP_WAVES * 4096 : 16];
+    load_lut<FMT>(lut);
+    float zfill = 1.0f;
+    if (FMT == FMT_BL) {
+        const unsigned u = __builtin_amdgcn_readfirstlane(xstats[0]);
+        zfill = u == 0xFFFFFFFFu ? 1.0f : __uint_as_float(u);
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const long long b = blockIdx.y, m0 = ((long long)blockIdx.x * TP_WAVES + min(wave, TP_WAVES - 1)) * 16;
+    const long long mrow = min(m0 + (lane & 15), M - 1);                 // (rows past M: the last row again)
+    const float* __restrict__ row = x + (b * M + mrow) * K;
+    const uint16_t* __restrict__ ytb = yt + b * (N >> 4) * Kp * 1024;
+    float* __restrict__ orow = out + (b * M + mrow) * N + 4 * g;
+    const int mbits = (int)__builtin_log2f(a.shift);
+    const int nsteps = (int)Kp, ntiles = (int)(N >> 4);
+    using lptr_t = __attribute__((address_space(3))) void*;
+    const unsigned bring0 = (unsigned)(size_t)(lptr_t)bring, xring0 = (unsigned)(size_t)(lptr_t)xring + wave * 4096;   // (the objects' own LDS addresses)
+
+    if (STREAM) {
+        for (int t0 = 0; t0 < ntiles; t0 += NT) {           // (more than NT column tiles: x is streamed again per group)
+            const int niter = nsteps * PLANES;
+            auto issue = [&](int j) {                       // iteration j's requests (j may lie before the start / behind the end)
+                int itp = j + DB - 1;
+                itp = itp < 0 ? 0 : (itp > niter - 1 ? niter - 1 : itp);
+                const int kb = itp / PLANES, plb = itp - kb * PLANES;
+                const unsigned dst = bring0 + (itp % DB) * PIECE;
+#pragma unroll
+                for (int i = 0; i < BW; ++i) {
+                    const int sub = wave * BW + i;          // (tile, t) = (sub / 2, sub % 2)
+                    const int tile = min(t0 + (sub >> 1), ntiles - 1);
+                    const uint16_t* gp = ytb + plb * plane_stride + (((long long)tile * Kp + kb) * 2 + (sub & 1)) * 512 + lane * 8;
+                    MM_GLDS16(gp, dst + sub * 1024);
+                }
+                if ((j + PLANES * DB) % PLANES == 0) {
+                    int kx = (j + PLANES * DB) / PLANES - DB + DX - 1;
+                    kx = kx < 0 ? 0 : (kx > nsteps - 1 ? nsteps - 1 : kx);
+                    const unsigned xd = xring0 + (kx % DX) * (TP_WAVES * 4096);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {           // (K % 16 == 0: a block lies inside or outside as a whole)
+                        const long long kk = (long long)kx * 64 + 16 * i;
+                        const float* gp = row + (kk < K ? kk : 0) + 4 * g;
+                        MM_GLDS16(gp, xd + i * 1024);
+                    }
+                }
+            };
+            constexpr int LEAD = (DB - 1) > (DX - 1) * PLANES ? (DB - 1) : (DX - 1) * PLANES;
+            for (int j = -LEAD; j < 0; ++j) issue(j);
+            f32x4 acc[NT];
+#pragma unroll
+            for (int tile = 0; tile < NT; ++tile) acc[tile] = f32x4{0, 0, 0, 0};
+            bf16x8 afr[2];
+            for (int k = 0; k < nsteps; ++k) {
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    const int it = k * PLANES + pl;
+                    MM_WAITV((tp_allowed<true, PLANES, BW, DB, DX>(pl)));
+                    __builtin_amdgcn_s_barrier();
+                    issue(it);
+                    if (pl == 0) {
+                        XBlk s;
+                        const unsigned char* xs = xring + wave * 4096 + (k % DX) * (TP_WAVES * 4096) + lane * 16;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s.v[i] = *reinterpret_cast<const float4*>(xs + i * 1024);
+                        if ((k + 1) * 64 > K) mask_xblk(s, (long long)k * 64, K);
+                        quantise_xblk<FMT>(s, a, lut, mbits, lane, afr, zfill);
+                    }
+                    const unsigned char* bs = bring + (it % DB) * PIECE + lane * 16;
+#pragma unroll
+                    for (int tile = 0; tile < NT; ++tile) {
+                        if (t0 + tile >= ntiles) break;     // (uniform)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + (tile * 2 + t) * 1024)), afr[t], acc[tile], 0, 0, 0);
+                    }
+                }
+            }
+            if (m0 + (lane & 15) < M) {
+#pragma unroll
+                for (int tile = 0; tile < NT; ++tile)
+                    if (t0 + tile < ntiles)
+                        *reinterpret_cast<float4*>(orow + (t0 + tile) * 16) = make_float4(acc[tile][0], acc[tile][1], acc[tile][2], acc[tile][3]);
+            }
+            MM_WAITV(0);                                    // (the clamped requests behind the end have landed: the rings are free)
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // RESIDENT: wave 8 feeds the ring, waves 0..7 quantise their 16 rows once and take the pieces as they land
+    const int nchunks = (ntiles + 3) >> 2, niter = nchunks * PLANES;
+    if (wave == TP_WAVES) {
+        auto issue = [&](int j) {
+            int itp = j + DB - 1;
+            itp = itp < 0 ? 0 : (itp > niter - 1 ? niter - 1 : itp);
+            const int cb = itp / PLANES, plb = itp - cb * PLANES;
+            const unsigned dst = bring0 + (itp % DB) * PIECE;
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {           // (tile, step, t) = (sub / (2 NS), ...): yt's own order
+                const int tile = min(cb * 4 + sub / (2 * NS), ntiles - 1);
+                const uint16_t* gp = ytb + plb * plane_stride + ((long long)tile * Kp * 2 + sub % (2 * NS)) * 512 + lane * 8;
+                MM_GLDS16(gp, dst + sub * 1024);
+            }
+        };
+        MM_WAITV(0);                                        // (the table loads: the counts below start from an empty queue)
+        for (int j = -(DB - 1); j < 0; ++j) issue(j);
+        for (int it = 0; it < niter; ++it) {
+            MM_WAITV((tp_allowed<false, 1, BW, DB, DX>(0)));
+            __builtin_amdgcn_s_barrier();
+            issue(it);
+        }
+        MM_WAITV(0);
+        return;
+    }
+    bf16x8 res[NS][2];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        XBlk s;
+        load_xblk(s, row, st * 64, g, K);
+        mask_xblk(s, st * 64, K);
+        quantise_xblk<FMT>(s, a, lut, mbits, lane, res[st], zfill);
+    }
+    f32x4 acc[4];
+    const bool live = m0 + (lane & 15) < M;
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+            const int it = c * PLANES + pl;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (pl == 0) {
+#pragma unroll
+                for (int tile = 0; tile < 4; ++tile) acc[tile] = f32x4{0, 0, 0, 0};
+            }
+            const unsigned char* bs = bring + (it % DB) * PIECE + lane * 16;
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile)
+#pragma unroll
+                for (int st = 0; st < NS; ++st)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + ((tile * NS + st) * 2 + t) * 1024)), res[st][t], acc[tile], 0, 0, 0);
+            if (pl == PLANES - 1 && live) {
+#pragma unroll
+                for (int tile = 0; tile < 4; ++tile)
+                    if (c * 4 + tile < ntiles)
+                        *reinterpret_cast<float4*>(orow + (c * 4 + tile) * 16) = make_float4(acc[tile][0], acc[tile][1], acc[tile][2], acc[tile][3]);
+            }
+        }
+    }
+}
+
+// block_log's statistics pass over x: the smallest non-zero [1,16]-block maximum of the whole tensor (as its bit pattern:
+// positive floats order like unsigned integers), the fill the reference gives all-zero blocks (block_fp.py:54-58).
+__global__ __launch_bounds__(256) void bl_block_stats_kernel(const float4* __restrict__ x4, long long n4, unsigned* __restrict__ stats) {
+    unsigned best = 0xFFFFFFFFu;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {   // (n4 % 4 == 0: whole blocks per quad)
+        const float4 v = x4[i];
+        const float bmax = group_max<4>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        if (bmax > 0.f) best = min(best, __float_as_uint(bmax));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
+    if ((threadIdx.x & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(stats, best);
+}
+
+template <int FMT, int PLANES>
+static int launch_qmatmul_fmt(const QuantArgs& ax, const float* x, const uint16_t* yt, float* out, long long B, long long M,
+                              long long K, long long Kp, long long N, hipStream_t st, bool softmax, const float* mask,
+                              long long causal_off, long long plane_stride, const unsigned* xstats) {
+    // plain products: the tile kernel (MI355Q_MATMUL_TILE=0: kernel 2, for comparisons); the softmax forms stay on kernel 2
+    static const bool tile_route = []() { const char* e = getenv("MI355Q_MATMUL_TILE"); return !(e && e[0] == '0'); }();
+    if (!softmax && tile_route) {
+        dim3 g3((unsigned)((M + TP_WAVES * 16 - 1) / (TP_WAVES * 16)), (unsigned)B);
+#define MI355Q_TP_LAUNCH(STREAM_, NTNS_)                                                                                   \
+        hipLaunchKernelGGL((bfp_qmatmul_tile_kernel<STREAM_, NTNS_, FMT, PLANES>), g3, (TP_WAVES + (STREAM_ ? 0 : 1)) * 64, 0, st, ax, x, yt, out, M, K, \
+                           Kp, N, plane_stride, xstats)
+        if (Kp == 1) MI355Q_TP_LAUNCH(false, 1);
+        else if (Kp == 2) MI355Q_TP_LAUNCH(false, 2);
+        else if (Kp == 3) MI355Q_TP_LAUNCH(false, 3);
+        else if (N <= 64) MI355Q_TP_LAUNCH(true, 4);
+        else MI355Q_TP_LAUNCH(true, 8);
+#undef MI355Q_TP_LAUNCH
+        return (int)hipGetLastError();
+    }
     dim3 g2((unsigned)((M + 15) / 16), (unsigned)B);
+#define MI355Q_MM_LAUNCH(...)                                                                                              \
+    hipLaunchKernelGGL((bfp_qmatmul_kernel<__VA_ARGS__, FMT, PLANES>), g2, 256, 0, st, ax, x, yt, out, M, K, Kp, N, mask,   \
+                       causal_off, plane_stride, xstats)
     if (Kp == 1)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 1>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
+        MI355Q_MM_LAUNCH(true, 1, false);
     else if (Kp == 2)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 2>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
+        MI355Q_MM_LAUNCH(true, 2, false);
     else if (Kp == 3)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<true, 3>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
-    else if (softmax && N <= 64)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
+        MI355Q_MM_LAUNCH(true, 3, false);
+    else if constexpr (PLANES > 1) {                       // (three fragment sets per step: column chunks of 64)
+        if (softmax) return MI355Q_E_UNSUPPORTED;
+        MI355Q_MM_LAUNCH(false, 4, false);
+    } else if (softmax && N <= 64)
+        MI355Q_MM_LAUNCH(false, 4, true);
     else if (softmax && N <= 128)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8, true>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
+        MI355Q_MM_LAUNCH(false, 8, true);
     else if (softmax)
         return MI355Q_E_UNSUPPORTED;                       // (one pass over x only: head_dim <= 128)
     else if (N <= 64)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 4>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
+        MI355Q_MM_LAUNCH(false, 4, false);
     else    // (head_dim 128: both halves of the columns in one pass over x)
-        hipLaunchKernelGGL((bfp_qmatmul_kernel<false, 8>), g2, 256, 0, st, ax, x, static_cast<const uint16_t*>(yt), out, M, K, Kp, N, mask, causal_off);
+        MI355Q_MM_LAUNCH(false, 8, false);
+#undef MI355Q_MM_LAUNCH
     return (int)hipGetLastError();
+}
+
+// fmt: 0 block_fp, 1 block_minifloat (x and y), 2 block_log (x; y raw, as three exact bf16 planes).  `yt`: the workspace of
+// mi355q_bfp_matmul_workspace_bytes (block_log: mi355q_block_log_matmul_workspace_bytes: three planes + the statistics word).
+int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
+                       long long B, long long M, long long K, long long N, hipStream_t st, bool softmax, const float* mask,
+                       long long causal_off, int fmt) {
+    if (softmax && (K + 63) / 64 <= 3) return MI355Q_E_UNSUPPORTED;     // (short rows: the caller takes softmax + the plain entry)
+    if (softmax && fmt == FMT_BL) return MI355Q_E_UNSUPPORTED;          // (block_log zeros are not zeros: no causal short cut)
+    dim3 g1((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64), (unsigned)B);
+    const long long Kp = (K + 63) / 64;                    // 64-steps: yt is stored in fragment order (kernel 1)
+    const long long plane = B * Kp * 64 * N;               // elements of one plane
+    uint16_t* ytp = static_cast<uint16_t*>(yt);
+    hipError_t e;
+    if (fmt == FMT_BFP) {
+        hipLaunchKernelGGL(bfp_quant_pack_t_kernel<FMT_BFP>, g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        return launch_qmatmul_fmt<FMT_BFP, 1>(ax, x, ytp, out, B, M, K, Kp, N, st, softmax, mask, causal_off, plane, nullptr);
+    }
+    if (fmt == FMT_BM) {
+        hipLaunchKernelGGL(bfp_quant_pack_t_kernel<FMT_BM>, g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        return launch_qmatmul_fmt<FMT_BM, 1>(ax, x, ytp, out, B, M, K, Kp, N, st, softmax, mask, causal_off, plane, nullptr);
+    }
+    if (fmt != FMT_BL) return MI355Q_E_BADARG;
+    unsigned* stats = reinterpret_cast<unsigned*>(ytp + 3 * plane);
+    if ((e = hipMemsetAsync(stats, 0xFF, 4, st)) != hipSuccess) return (int)e;
+    const long long n4 = B * M * K / 4;
+    const unsigned gs = (unsigned)std::min<long long>((n4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(bl_block_stats_kernel, dim3(gs), 256, 0, st, reinterpret_cast<const float4*>(x), n4, stats);
+    hipLaunchKernelGGL(bfp_quant_pack_t_kernel<FMT_RAW>, g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    return launch_qmatmul_fmt<FMT_BL, 3>(ax, x, ytp, out, B, M, K, Kp, N, st, false, mask, causal_off, plane, stats);
 }
 
 }  // namespace mi355q

@@ -56,6 +56,10 @@ SIGNATURES = {
     "mi355q_bfp_matmul_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
     "mi355q_bfp_softmax_matmul": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_block_minifloat_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_block_minifloat_softmax_matmul": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mi355q_block_log_matmul_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
+    "mi355q_block_log_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
     "mi355q_bfp_attention_set_kernel": (C.c_int, [C.c_int]),
     "mi355q_bfp_attention_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
     "mi355q_bfp_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -91,7 +95,7 @@ class CorrTarget(C.Structure):
     _fields_ = [("w", _vp), ("plan", _vp), ("xvec", _vp), ("wvec", _vp), ("N", _i64), ("slots_in_use", _i32), ("reserved", _i32)]
 
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

@@ -68,7 +68,7 @@ class _Attention(nn.Module):
         q = shape(self.q_proj(x) * self.scaling)
         k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
         w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
-        if c1["name"] == "block_fp" and c1.get("mi355q_fused_softmax", False):
+        if c1["name"] in ("block_fp", "block_minifloat") and c1.get("mi355q_fused_softmax", False):
             # mask add, clamp and softmax folded into the product kernel (the harness' mask is the causal one)
             o = get_quantized_func("softmax_bmm", c1)(w, v, config=c1, causal=True)
         else:
@@ -235,7 +235,7 @@ class _LlamaAttention(nn.Module):
             o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd))
             return self.o_proj(o.transpose(1, 2).reshape(B, T, self.h))
         w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])
-        if c1["name"] == "block_fp" and c1.get("mi355q_fused_softmax", False):
+        if c1["name"] in ("block_fp", "block_minifloat") and c1.get("mi355q_fused_softmax", False):
             o = get_quantized_func("softmax_matmul", c1)(w / math.sqrt(self.hd), v, config=c1, causal=True)
         else:
             w = w / math.sqrt(self.hd) + mask

@@ -1066,6 +1066,60 @@ def bfp_matmul(x: torch.Tensor, y: torch.Tensor, x_width: int, x_exponent_width:
     return out
 
 
+def values_matmul_supported(x: torch.Tensor, y: torch.Tensor, arith: str, x_params, y_params=None, softmax: bool = False) -> bool:
+    """shapes / settings the fused block_minifloat / block_log products take (include/mi355q.h, ABI 19).
+    x_params / y_params: (width, exponent_width, exponent_bias_width) for block_minifloat, (width, exponent_bias_width) for
+    block_log (y is not quantised there)"""
+    if not (x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.ndim == 3 and y.ndim == 3
+            and x.shape[0] == y.shape[0] and x.shape[2] == y.shape[1] and x.shape[0] <= 65535 and x.shape[2] % 16 == 0
+            and y.shape[2] % 16 == 0 and x.shape[2] > 0):
+        return False
+    if softmax and not (arith == "block_minifloat" and x.shape[2] > 192 and y.shape[2] <= 128):
+        return False
+    if arith == "block_minifloat":
+        return all(1 <= int(ew) <= 8 and 1 <= int(ebw) <= 8 and 0 <= int(w) - int(ew) - 1 <= 7 for w, ew, ebw in (x_params, y_params))
+    if arith == "block_log":
+        return 2 <= int(x_params[0]) <= 9 and 1 <= int(x_params[1]) <= 8
+    return False
+
+
+def values_matmul(x: torch.Tensor, y: torch.Tensor, arith: str, x_params, y_params=None, *, softmax: bool = False,
+                  mask: torch.Tensor = None, causal: bool = False) -> torch.Tensor:
+    """out[b] = Qx(x[b]) @ Qy(y[b]) for block_minifloat (reference matmul.py:199-249), out[b] = Qx(x[b]) @ y[b] for block_log
+    (matmul.py:252-297: y is not quantised): x [B, M, K], y [B, K, N] fp32, [1,16] blocks along each operand's last dim, x
+    quantised on its way into the MFMAs -- bfp_matmul's two kernels with the other block quantisers."""
+    _require_device(x, "values_matmul")
+    assert values_matmul_supported(x, y, arith, x_params, y_params, softmax)
+    B, M, K = x.shape
+    N = y.shape[2]
+    xc, yc = x.contiguous(), y.contiguous()
+    out = torch.empty(B, M, N, dtype=torch.float32, device=x.device)
+    lib = _lib.load_library()
+    sp = _stream_ptr(x.device)
+    log = arith == "block_log"
+    key = (x.device.index, sp, B, K, N, log)
+    ws = _MATMUL_WS.get(key)
+    if ws is None:
+        nbytes = (lib.mi355q_block_log_matmul_workspace_bytes if log else lib.mi355q_bfp_matmul_workspace_bytes)(B, K, N)
+        ws = _MATMUL_WS.put(key, torch.empty(nbytes, dtype=torch.uint8, device=x.device))
+    with _on_device(x.device):
+        if log:
+            name = "mi355q_block_log_matmul"
+            rc = lib.mi355q_block_log_matmul(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), B, M, K, N, int(x_params[0]), int(x_params[1]), sp)
+        else:
+            args = (B, M, K, N, *(int(v) for v in x_params), *(int(v) for v in y_params), sp)
+            if softmax:
+                if mask is not None:
+                    assert mask.shape == (M, K) and mask.dtype == torch.float32 and mask.is_contiguous() and mask.device == x.device
+                name = "mi355q_block_minifloat_softmax_matmul"
+                rc = lib.mi355q_block_minifloat_softmax_matmul(_ptr(xc), _ptr(mask), int(bool(causal)), _ptr(yc), _ptr(out), _ptr(ws), *args)
+            else:
+                name = "mi355q_block_minifloat_matmul"
+                rc = lib.mi355q_block_minifloat_matmul(_ptr(xc), _ptr(yc), _ptr(out), _ptr(ws), *args)
+    _lib.check(rc, name)
+    return out
+
+
 _ATTN_WS = _StreamCache(8)
 ATTENTION_MAX_KEYS, ATTENTION_MAX_HEAD_DIM = 1 << 20, 128      # (beyond 2048 keys: the streaming kernel, scores formed twice)
 

@@ -78,7 +78,8 @@ def _bf16_values_matmul(x, y, config, arith):
     for P V, three times slower for Q K^T (same profile).  It stays on the fp32 route unless
     config["mi355q_values_matmul"] = "bf16_split" asks for it.  None: shapes / settings the route does not take."""
     from ... import ops
-    want = config.get("mi355q_values_matmul", "bf16")
+    want = config.get("mi355q_values_matmul", "fused")
+    want = "bf16" if want == "fused" else want           # (the fused route declined: block_minifloat takes the library product)
     if want not in ("bf16", "bf16_split") or (arith == "block_log" and want != "bf16_split") or not (x.is_cuda and y.is_cuda):
         return None
     if x.dtype != torch.float32 or y.dtype != torch.float32 or torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
@@ -107,6 +108,34 @@ def _bf16_values_matmul(x, y, config, arith):
     return out.reshape(*x.shape[:-1], y.shape[-1])
 
 
+def _fused_values_matmul(x, y, config, arith, softmax=False, mask=None, causal=False):
+    """matmul_block_minifloat / matmul_block_log (matmul.py:199-249, 252-297) in the library's own product kernels
+    (ops.values_matmul: y packed transposed once, x quantised in registers on its way into bf16 MFMAs -- one pass over x, no
+    quantised copy of either operand; block_log's unquantised y as three exact bf16 planes).  The default route
+    (config["mi355q_values_matmul"] = "fused"); None: shapes / settings it does not take -> the caller's next route."""
+    from ... import ops
+    if config.get("mi355q_values_matmul", "fused") != "fused" or not (x.is_cuda and y.is_cuda):
+        return None
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        return None
+    if x.ndim != y.ndim or x.ndim < 2 or x.shape[:-2] != y.shape[:-2] or x.shape[-1] != y.shape[-2]:
+        return None
+    many = x.ndim > 2
+    x3 = x.reshape(-1, *x.shape[-2:]) if x.ndim != 3 else x
+    y3 = y.reshape(-1, *y.shape[-2:]) if y.ndim != 3 else y
+    for t, prefix in ((x3, "data_in"),) + (((y3, "weight"),) if arith == "block_minifloat" else ()):
+        shape = t.shape if many else t.shape[-2:]
+        if ops.resolve_blocking(list(shape), config[f"{prefix}_block_size"], many)[3:] != (1, 16):
+            return None
+    keys = _KEYS[arith][:-1]
+    xp = tuple(config[f"data_in_{k}"] for k in keys)
+    yp = tuple(config[f"weight_{k}"] for k in keys) if arith == "block_minifloat" else None
+    if not ops.values_matmul_supported(x3, y3, arith, xp, yp, softmax):
+        return None
+    out = ops.values_matmul(x3, y3, arith, xp, yp, softmax=softmax, mask=mask, causal=causal)
+    return out.reshape(*x.shape[:-1], y.shape[-1])
+
+
 def _generic_matmul(x, y, config, arith, style):
     mm = _MATMUL[style]
     if config.get("bypass", False):
@@ -119,6 +148,9 @@ def _generic_matmul(x, y, config, arith, style):
         if out is not None:
             return out
     if arith in ("block_minifloat", "block_log"):
+        out = _fused_values_matmul(x, y, config, arith)
+        if out is not None:
+            return out
         out = _bf16_values_matmul(x, y, config, arith)
         if out is not None:
             return out
@@ -141,8 +173,8 @@ def _mask_2d(mask, tq, tk):
     return m2.expand(tq, tk).contiguous()
 
 
-def _make_softmax(style):
-    """`softmax_{matmul,bmm}_block_fp(scores, y, config, mask=None, causal=False)` =
+def _make_softmax(style, arith="block_fp"):
+    """`softmax_{matmul,bmm}_{block_fp,block_minifloat}(scores, y, config, mask=None, causal=False)` =
     `{matmul,bmm}_block_fp(softmax(max(scores + mask, finfo.min), dim=-1), y, config)`: what the reference's attention
     computes between its two products (modeling_opt.py:262-312, modeling_llama.py:318-344), as ONE call, so that neither
     the masked scores nor the probability tensor [heads, T, T] need exist.  `mask`: additive, [T_q, T_k]
@@ -152,10 +184,12 @@ def _make_softmax(style):
     def f(scores, y, config, mask=None, causal=False):
         m2 = None if mask is None else _mask_2d(mask, scores.shape[-2], scores.shape[-1])
         if (not config.get("bypass", False) and config.get("mi355q_fused_matmul", True) and (mask is None or m2 is not None)):
-            for k in _KEYS["block_fp"]:
+            for k in _KEYS[arith]:
                 config[f"data_in_{k}"], config[f"weight_{k}"]
-            out = _fused_block_fp_matmul(scores, y, config, style, softmax=True, mask=m2,
-                                         causal=causal)
+            if arith == "block_fp":
+                out = _fused_block_fp_matmul(scores, y, config, style, softmax=True, mask=m2, causal=causal)
+            else:
+                out = _fused_values_matmul(scores, y, config, arith, softmax=True, mask=m2, causal=causal)
             if out is not None:
                 return out
         w = scores
@@ -167,8 +201,8 @@ def _make_softmax(style):
         if causal or mask is not None:
             w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min))
         p = torch.nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(scores.dtype)
-        return _generic_matmul(p, y, config, "block_fp", style)
-    f.__name__ = f"softmax_{style}_block_fp"
+        return _generic_matmul(p, y, config, arith, style)
+    f.__name__ = f"softmax_{style}_{arith}"
     return f
 
 
@@ -238,6 +272,8 @@ matmul_minifloat_ieee, bmm_minifloat_ieee = _make("minifloat_ieee", "matmul"), _
 matmul_log, bmm_log = _make("log", "matmul"), _make("log", "bmm")
 matmul_block_fp, bmm_block_fp = _make("block_fp", "matmul"), _make("block_fp", "bmm")
 softmax_matmul_block_fp, softmax_bmm_block_fp = _make_softmax("matmul"), _make_softmax("bmm")
+softmax_matmul_block_minifloat = _make_softmax("matmul", "block_minifloat")
+softmax_bmm_block_minifloat = _make_softmax("bmm", "block_minifloat")
 matmul_block_minifloat, bmm_block_minifloat = _make("block_minifloat", "matmul"), _make("block_minifloat", "bmm")
 matmul_block_log, bmm_block_log = _make("block_log", "matmul"), _make("block_log", "bmm")
 
@@ -325,8 +361,8 @@ QUANTIZED_FUNC_MAP = {
         "integer": bmm_integer, "log": bmm_block_log, "minifloat_denorm": bmm_minifloat_denorm,
         "minifloat_ieee": bmm_minifloat_ieee,
     },
-    "softmax_matmul": {"block_fp": softmax_matmul_block_fp},
-    "softmax_bmm": {"block_fp": softmax_bmm_block_fp},
+    "softmax_matmul": {"block_fp": softmax_matmul_block_fp, "block_minifloat": softmax_matmul_block_minifloat},
+    "softmax_bmm": {"block_fp": softmax_bmm_block_fp, "block_minifloat": softmax_bmm_block_minifloat},
     "attention": {"block_fp": attention_block_fp},
     "rotary_positional_encoding": {
         "block_fp": apply_rotary_pos_emb_block_fp, "block_log": apply_rotary_pos_emb_block_log,

@@ -971,7 +971,8 @@ def test_block_minifloat_and_block_log_products_on_bf16_mfma(arith, style):
             xd, yd = x.to("cuda:0"), y.to("cuda:0")
             n0 = len(calls)
             # (block_log's unquantised y makes the bf16 product an opt-in: exact, but no faster -- see _bf16_values_matmul)
-            got = f(xd, yd, dict(cfg) if arith == "block_minifloat" else dict(cfg, mi355q_values_matmul="bf16_split"))
+            # (the default route is the library's own product kernel since round 4: tests/test_gpu_values_matmul.py)
+            got = f(xd, yd, dict(cfg, mi355q_values_matmul="bf16" if arith == "block_minifloat" else "bf16_split"))
             assert len(calls) > n0, "the bf16 route was not taken"
             if arith == "block_log":
                 f(xd, yd, dict(cfg))

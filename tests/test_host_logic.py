@@ -94,7 +94,7 @@ def test_registry_keys_match_reference():
     assert set(Q.QUANTIZED_FUNC_MAP) == ref_ops | {"softmax_matmul", "softmax_bmm", "attention"}
     for name in ref_ops:
         assert set(Q.QUANTIZED_FUNC_MAP[name]) == names
-    assert set(Q.QUANTIZED_FUNC_MAP["softmax_bmm"]) == {"block_fp"}
+    assert set(Q.QUANTIZED_FUNC_MAP["softmax_bmm"]) == set(Q.QUANTIZED_FUNC_MAP["softmax_matmul"]) == {"block_fp", "block_minifloat"}
     # reference quirk: "log" is served by the block_log functions
     assert Q.QUANTIZED_FUNC_MAP["matmul"]["log"] is Q.QUANTIZED_FUNC_MAP["matmul"]["block_log"]
     assert Q.get_quantized_cls("linear", {"name": "block_fp"}).__name__ == "LinearBlockFP"

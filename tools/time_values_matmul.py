@@ -42,8 +42,15 @@ def t(fn, n=10):
 for name, cfg in cfgs.items():
     f = Q.get_quantized_func("bmm", cfg)
     rec = {"arith": name, "shape": "p[32,2048,2048] x v[32,2048,128] ; q[32,2048,128] x k^T[32,128,2048]"}
-    for route in (("bf16", "fp32") if name != "block_fp" else ("fused",)):
-        c = dict(cfg) if route in ("bf16", "fused") else dict(cfg, mi355q_values_matmul="fp32")
+    # routes: "fused" the library's own product kernels (round 4: block_minifloat and block_log too); "bf16" / "bf16_split" the
+    # quantisers' bf16 output + the vendor's bf16 batched GEMM (round 3); "fp32" fake-quantised fp32 tensors + the vendor's fp32 GEMM
+    routes = {"block_fp": ("fused",), "block_minifloat": ("fused", "bf16", "fp32"), "block_log": ("fused", "bf16_split", "fp32")}[name]
+    for route in routes:
+        c = dict(cfg, mi355q_values_matmul=route)
         rec[f"pv_{route}_us"] = round(t(lambda: f(p, v, c)), 1)
         rec[f"qk_{route}_us"] = round(t(lambda: f(qq, kt, c)), 1)
-    print(json.dumps(rec))
+    if name == "block_minifloat":
+        fs = Q.get_quantized_func("softmax_bmm", cfg)
+        sc = torch.randn(H, T, T, generator=torch.Generator().manual_seed(1)).to(dev) * 3
+        rec["softmax_pv_fused_us"] = round(t(lambda: fs(sc, v, dict(cfg), causal=True)), 1)
+    print(json.dumps(rec), flush=True)
