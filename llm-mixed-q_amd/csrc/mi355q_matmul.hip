@@ -37,6 +37,11 @@ constexpr int MM_NCHUNK = 64;            // output columns per accumulator set (
 __host__ __device__ constexpr int mm_kperm(int k) {
     return ((k >> 5) & 1) * 32 + ((k >> 2) & 3) * 8 + ((k >> 4) & 1) * 4 + (k & 3);
 }
+// the tile product kernel's (kernel 3): lane group g holds the WHOLE block g -- the block maximum and its parameter need no
+// cross-lane traffic -- and MFMA t takes its elements 8 t .. 8 t + 7.  k = 16 g + 8 t + e  ->  32 t + 8 g + e.
+__host__ __device__ constexpr int mm_kperm_lane(int k) {
+    return ((k >> 3) & 1) * 32 + ((k >> 4) & 3) * 8 + (k & 7);
+}
 
 // ---- kernel 1: y [B, K, N] fp32 -> fake-quantise along N -> yt [B, N, K] bf16 ------------------------------------
 // FMT: the block format y is fake-quantised in (round 4: block_minifloat beside block_fp -- its values have <= 7 mantissa bits,
@@ -45,7 +50,7 @@ __host__ __device__ constexpr int mm_kperm(int k) {
 // significant bits by truncation): x is a signed power of two there, so every x * plane product is exact in fp32 and the sum
 // of the three accumulations is the fp32 product's, up to summation order.  `plane_stride`: elements between planes.
 constexpr int FMT_RAW = 3;
-template <int FMT>
+template <int FMT, bool LANE = false>                      // LANE: the K order of the tile product kernel (mm_kperm_lane)
 __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a, const float* __restrict__ y,
                                                                uint16_t* __restrict__ yt, long long K, long long Kp, long long N,
                                                                long long plane_stride) {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {         // truncation: every plane exact, the remainder exact
                     const unsigned hb = __float_as_uint(r) & 0xFFFF0000u;
-                    tile[pl][n4 * 4 + j][mm_kperm(kr + 16 * i)] = (uint16_t)(hb >> 16);
+                    tile[pl][n4 * 4 + j][LANE ? mm_kperm_lane(kr + 16 * i) : mm_kperm(kr + 16 * i)] = (uint16_t)(hb >> 16);
                     r -= __uint_as_float(hb);
                 }
             }
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void bfp_quant_pack_t_kernel(const QuantArgs a
                 q[3] = quant_elem<F>(v.w, bp, a, lut, mant);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tile[0][n4 * 4 + j][mm_kperm(kr + 16 * i)] = (uint16_t)(pack_bf16(q[j], 0.f) & 0xFFFFu);
+            for (int j = 0; j < 4; ++j) tile[0][n4 * 4 + j][LANE ? mm_kperm_lane(kr + 16 * i) : mm_kperm(kr + 16 * i)] = (uint16_t)(pack_bf16(q[j], 0.f) & 0xFFFFu);
         }
     }
     __syncthreads();
@@ -235,6 +240,73 @@ __device__ __forceinline__ void quantise_xblk(const XBlk& s, const QuantArgs& a,
             q[4 * i + 1] = quant_elem<F>(v.y, bp, a, lut, mant);
             q[4 * i + 2] = quant_elem<F>(v.z, bp, a, lut, mant);
             q[4 * i + 3] = quant_elem<F>(v.w, bp, a, lut, mant);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        uint4 pk;
+        pk.x = pack_bf16(q[8 * t + 0], q[8 * t + 1]);
+        pk.y = pack_bf16(q[8 * t + 2], q[8 * t + 3]);
+        pk.z = pack_bf16(q[8 * t + 4], q[8 * t + 5]);
+        pk.w = pack_bf16(q[8 * t + 6], q[8 * t + 7]);
+        afr[t] = __builtin_bit_cast(bf16x8, pk);
+    }
+}
+
+// The same for kernel 3's layout: the lane holds the 16 values of ONE block (v[0..3] = its four float4s).  Block maximum and
+// parameter in the lane -- no shuffles, no LDS round trips (kernel 3 runs two waves a SIMD: nothing would hide them); the log2
+// tables are consulted only where they can matter (a maximum within 45 ulps above / 88 below a power of two, a subnormal one:
+// wave-uniform, rare), the elements go through the fused element functions above with the same rare way out.
+template <int FMT>
+__device__ __forceinline__ void quantise_lane(const f32x4 (&v)[4], const QuantArgs& a, const Lut& lut, int mbits, float zfill,
+                                              bf16x8 (&afr)[2]) {
+    float bmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bmax = fmaxf(fmaxf(bmax, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+    const float bm = bmax > 0.f ? bmax : zfill;           // (an all-zero block: see quantise_xblk)
+    const unsigned bb = __float_as_uint(bm), m = bb & 0x7FFFFFu;
+    const int k = (int)(bb >> 23) - 127;
+    int p;
+    bool near = bb < 0x00800000u;
+    if (FMT == FMT_BFP) {
+        near |= (m - 1u) < MI355Q_LOG2_CEIL_THR_MAX;
+        p = clampi(k + (m != 0u ? 1 : 0), a.e_min, a.e_max);
+    } else if (FMT == FMT_BM) {
+        near |= m >= MI355Q_LOG2_FLOOR_THR_MIN;
+        p = clampi(k, 0, a.bias_max);
+    } else {
+        near |= (m - 1u) < MI355Q_LOG2_CEIL_THR_MAX;
+        p = clampi(a.span - (k + (m != 0u ? 1 : 0)), 0, a.bias_max);
+    }
+    if (__any(near)) {
+        unsigned code;
+        p = block_param<FMT>(bm, a, lut, code).p;
+    }
+    float q[16];
+    bool near_e = false;
+    const float eps = FMT == FMT_BL ? __builtin_ldexpf(0.1f, -p) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float e4[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (FMT == FMT_BFP) q[4 * i + j] = quant_elem_fused(e4[j], mbits - p, p - mbits, a.mant_max);
+            else if (FMT == FMT_BM) q[4 * i + j] = bm_elem_fused(e4[j], 127 - p, 127 + a.span - p, mbits, a.shift, a.mant_max, near_e);
+            else q[4 * i + j] = bl_elem_fused(e4[j], eps, 127 - p, 127 + a.span - p, near_e);
+        }
+    }
+    if (FMT != FMT_BFP && __any(near_e)) {                // (rare, wave-uniform: the streaming quantisers' element functions)
+        BlockParam bp;
+        bp.p = p;
+        bp.eps = eps;
+        constexpr int F = FMT == FMT_BFP ? FMT_BM : FMT;
+        int mant;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q[4 * i + 0] = quant_elem<F>(v[i][0], bp, a, lut, mant);
+            q[4 * i + 1] = quant_elem<F>(v[i][1], bp, a, lut, mant);
+            q[4 * i + 2] = quant_elem<F>(v[i][2], bp, a, lut, mant);
+            q[4 * i + 3] = quant_elem<F>(v[i][3], bp, a, lut, mant);
         }
     }
 #pragma unroll
@@ -558,20 +630,23 @@ constexpr int tp_allowed(int pl) {
 }
 
 template <bool STREAM, int NTNS, int FMT, int PLANES>
-__global__ __launch_bounds__((TP_WAVES + (STREAM ? 0 : 1)) * 64) void bfp_qmatmul_tile_kernel(const QuantArgs a, const float* __restrict__ x,
+__global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(const QuantArgs a, const float* __restrict__ x,
                                                                          const uint16_t* __restrict__ yt, float* __restrict__ out,
                                                                          long long M, long long K, long long Kp, long long N,
-                                                                         long long plane_stride, const unsigned* __restrict__ xstats) {
+                                                                         long long plane_stride, const unsigned* __restrict__ xstats,
+                                                                         unsigned long long* __restrict__ stamps) {
     constexpr int NT = STREAM ? NTNS : 4;                 // column tiles of a piece
     constexpr int NS = STREAM ? 1 : NTNS;                 // 64-steps of a piece
     constexpr int SUB = NT * NS * 2;                      // 1-KiB sub-pieces of a piece
     constexpr int BW = STREAM ? SUB / TP_WAVES : SUB;     // DMA instructions per issuing wave and piece
     static_assert(SUB % TP_WAVES == 0, "a piece is shared evenly by the waves");
     constexpr int DB = STREAM ? 3 : 4, DX = PLANES > 1 ? 2 : 3;
+    constexpr int XD = FMT == FMT_BFP ? 3 : 2;            // STREAM: x slabs in rotation, XD - 1 steps ahead (the other formats' element
+                                                          // functions leave no registers for a third)
     constexpr int PIECE = SUB * 1024;
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) unsigned char bring[DB * PIECE];
-    __shared__ __attribute__((aligned(16))) unsigned char xring[STREAM ? DX * TP_WAVES * 4096 : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char xring[STREAM ? TP_WAVES * 4096 : 16];     // the waves' transpose patches
     load_lut<FMT>(lut);
     float zfill = 1.0f;
     if (FMT == FMT_BL) {
@@ -591,72 +666,134 @@ __global__ __launch_bounds__((TP_WAVES + (STREAM ? 0 : 1)) * 64) void bfp_qmatmu
     const unsigned bring0 = (unsigned)(size_t)(lptr_t)bring, xring0 = (unsigned)(size_t)(lptr_t)xring + wave * 4096;   // (the objects' own LDS addresses)
 
     if (STREAM) {
+        if (wave == TP_WAVES) {
+            // the feeder of the yt ring: plain loads into registers, ds_write into the slot.  (LDS-DMA moves ~22 bytes a clock
+            // and compute unit -- measured: 805 MB of DMA, x and yt, took 70 us with every byte in cache -- so the DMA path is
+            // left to the x slabs, which have no other way into LDS without passing the consumers' registers.)
+            for (int t0 = 0; t0 < ntiles; t0 += NT) {
+                const int niter = nsteps * PLANES;
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (a native vector: the HIP uint4 array stayed in scratch memory)
+                u32x4 pc[SUB];
+#define MM_FEED_LOAD(ITP_)                                                                                                   \
+                {                                                                                                            \
+                    const int itp_ = (ITP_) > niter - 1 ? niter - 1 : (ITP_);                                                \
+                    const int kb_ = itp_ / PLANES, plb_ = itp_ - kb_ * PLANES;                                               \
+                    _Pragma("unroll") for (int sub = 0; sub < SUB; ++sub) { /* (tile, t) = (sub / 2, sub % 2) */             \
+                        const int tile_ = min(t0 + (sub >> 1), ntiles - 1);                                                  \
+                        pc[sub] = *reinterpret_cast<const u32x4*>(ytb + plb_ * plane_stride +                                \
+                                                                  (((long long)tile_ * Kp + kb_) * 2 + (sub & 1)) * 512 + lane * 8); \
+                    }                                                                                                        \
+                }
+#define MM_FEED_STORE(ITP_)                                                                                                  \
+                {                                                                                                            \
+                    unsigned char* d_ = bring + ((ITP_) % DB) * PIECE + lane * 16;                                           \
+                    _Pragma("unroll") for (int sub = 0; sub < SUB; ++sub) *reinterpret_cast<u32x4*>(d_ + sub * 1024) = pc[sub]; \
+                }
+                MM_FEED_LOAD(0) MM_FEED_STORE(0)
+                MM_FEED_LOAD(1) MM_FEED_STORE(1)
+                MM_FEED_LOAD(2)
+                for (int it = 0; it < niter; ++it) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();               // piece `it` is there; the slot of piece it - 1 is free
+                    MM_FEED_STORE(it + 2)
+                    MM_FEED_LOAD(it + 3)
+                }
+#undef MM_FEED_LOAD
+#undef MM_FEED_STORE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
         for (int t0 = 0; t0 < ntiles; t0 += NT) {           // (more than NT column tiles: x is streamed again per group)
-            const int niter = nsteps * PLANES;
-            auto issue = [&](int j) {                       // iteration j's requests (j may lie before the start / behind the end)
-                int itp = j + DB - 1;
-                itp = itp < 0 ? 0 : (itp > niter - 1 ? niter - 1 : itp);
-                const int kb = itp / PLANES, plb = itp - kb * PLANES;
-                const unsigned dst = bring0 + (itp % DB) * PIECE;
+            // (x DMA: this lane's row inside each of the four row groups -- 4 i + lane / 16 -- rows past M: the last row again)
+            const int xrow_lo = lane >> 4;                  // row = 4 i + xrow_lo, so row & 7 = 4 (i & 1) + xrow_lo
+            // (addresses as ONE scalar base per step + four 32-bit lane offsets that never change: per-step 64-bit lane arithmetic
+            //  had its temporaries share registers with slabs still in flight, and the compiler waited for those)
+            const long long mbase = min(m0, M - 1);
+            const char* xbase = reinterpret_cast<const char*>(x + (b * M + mbase) * K);
+            unsigned xoff[4], xend[4];                      // (a workgroup's 128 rows: K < 2^23 keeps the offsets in 32 bits)
 #pragma unroll
-                for (int i = 0; i < BW; ++i) {
-                    const int sub = wave * BW + i;          // (tile, t) = (sub / 2, sub % 2)
-                    const int tile = min(t0 + (sub >> 1), ntiles - 1);
-                    const uint16_t* gp = ytb + plb * plane_stride + (((long long)tile * Kp + kb) * 2 + (sub & 1)) * 512 + lane * 8;
-                    MM_GLDS16(gp, dst + sub * 1024);
-                }
-                if ((j + PLANES * DB) % PLANES == 0) {
-                    int kx = (j + PLANES * DB) / PLANES - DB + DX - 1;
-                    kx = kx < 0 ? 0 : (kx > nsteps - 1 ? nsteps - 1 : kx);
-                    const unsigned xd = xring0 + (kx % DX) * (TP_WAVES * 4096);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned row0 = (unsigned)(min((long long)(4 * i + xrow_lo), M - 1 - mbase) * K * 4);
+                xoff[i] = row0 + 16u * ((lane & 15) ^ (4 * (i & 1) + xrow_lo));
+                xend[i] = row0 + (unsigned)K * 4u - 16u;
+            }
+            // x: plain loads into registers, two steps ahead (three slabs of 16 VGPRs in rotation), then through the wave's own
+            // 4-KiB patch of LDS into the block-per-lane order.  (As LDS-DMA the same bytes streamed at 3.7 TB/s whatever the
+            // access shape and ring depth -- profiles/r04_values_matmul.txt.)  Instruction i loads rows 4 i .. 4 i + 3 of the
+            // wave's 16, each as ONE 256-byte run over 16 lanes (whole cache lines); lane l writes its 16 bytes at l * 16, and
+            // the run's 16-byte chunks are dealt to the lanes XOR (row & 7): the read-back (16 rows x the same chunk) then
+            // meets no bank twice.
+            auto xload = [&](f32x4 (&d)[4], int kx) {
+                kx = kx > nsteps - 1 ? nsteps - 1 : kx;     // (behind the end: the last slab again, never used)
+                // (no branch, no 64-bit lane arithmetic: chunks behind K -- the last, partial step -- read the row's last chunk
+                //  instead and are zeroed with their block at the read-back)
+                const unsigned koff = (unsigned)kx * 256u;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {           // (K % 16 == 0: a block lies inside or outside as a whole)
-                        const long long kk = (long long)kx * 64 + 16 * i;
-                        const float* gp = row + (kk < K ? kk : 0) + 4 * g;
-                        MM_GLDS16(gp, xd + i * 1024);
-                    }
-                }
+                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const f32x4*>(xbase + min(xoff[i] + koff, xend[i]));
             };
-            constexpr int LEAD = (DB - 1) > (DX - 1) * PLANES ? (DB - 1) : (DX - 1) * PLANES;
-            for (int j = -LEAD; j < 0; ++j) issue(j);
             f32x4 acc[NT];
 #pragma unroll
             for (int tile = 0; tile < NT; ++tile) acc[tile] = f32x4{0, 0, 0, 0};
             bf16x8 afr[2];
-            for (int k = 0; k < nsteps; ++k) {
+            unsigned long long t_wait = 0, t_bar = 0;
+            const unsigned long long t_begin = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            unsigned char* xpatch = xring + wave * 4096;
+            f32x4 xq[XD][4];                   // (native vectors: arrays of HIP's float4 were left in scratch memory)
 #pragma unroll
-                for (int pl = 0; pl < PLANES; ++pl) {
-                    const int it = k * PLANES + pl;
-                    MM_WAITV((tp_allowed<true, PLANES, BW, DB, DX>(pl)));
-                    __builtin_amdgcn_s_barrier();
-                    issue(it);
-                    if (pl == 0) {
-                        XBlk s;
-                        const unsigned char* xs = xring + wave * 4096 + (k % DX) * (TP_WAVES * 4096) + lane * 16;
+            for (int u = 0; u < XD - 1; ++u) xload(xq[u], u);
+#define MM_STREAM_STEP(K_, CUR_, FILL_)                                                                                      \
+            {                                                                                                                \
+                const int k = (K_);                                                                                          \
+                xload(FILL_, k + XD - 1);                                                                                    \
+                _Pragma("unroll") for (int pl = 0; pl < PLANES; ++pl) {                                                      \
+                    const int it = k * PLANES + pl;                                                                          \
+                    const unsigned long long tw1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;                             \
+                    __builtin_amdgcn_s_barrier();                /* piece `it` is in the ring */                             \
+                    if (stamps) t_bar += __builtin_amdgcn_s_memtime() - tw1;                                                 \
+                    if (pl == 0) {                                                                                           \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+                            *reinterpret_cast<f32x4*>(xpatch + i * 1024 + lane * 16) = CUR_[i];                              \
+                        f32x4 xv[4];                                                                                         \
+                        const int r = lane & 15;                 /* lane (r, g) takes block g = chunks 4 g .. 4 g + 3 of row r */ \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                            xv[j] = *reinterpret_cast<const f32x4*>(xpatch + r * 256 + (((4 * g + j) ^ (r & 7)) << 4));      \
+                        if ((long long)k * 64 + 16 * g >= K) {   /* the last, partial step: blocks behind K */               \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j) xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};                 \
+                        }                                                                                                    \
+                        quantise_lane<FMT>(xv, a, lut, mbits, zfill, afr);                                                   \
+                    }                                                                                                        \
+                    const unsigned char* bs = bring + (it % DB) * PIECE + lane * 16;                                         \
+                    _Pragma("unroll") for (int tile = 0; tile < NT; ++tile) {                                                \
+                        if (t0 + tile >= ntiles) break;          /* (uniform) */                                             \
+                        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                        \
+                            acc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                             \
+                                __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + (tile * 2 + t) * 1024)), afr[t], acc[tile], 0, 0, 0); \
+                    }                                                                                                        \
+                }                                                                                                            \
+            }
+            for (int k0 = 0; k0 < nsteps; k0 += XD) {           // (XD steps per trip: the slabs keep their registers)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) s.v[i] = *reinterpret_cast<const float4*>(xs + i * 1024);
-                        if ((k + 1) * 64 > K) mask_xblk(s, (long long)k * 64, K);
-                        quantise_xblk<FMT>(s, a, lut, mbits, lane, afr, zfill);
-                    }
-                    const unsigned char* bs = bring + (it % DB) * PIECE + lane * 16;
-#pragma unroll
-                    for (int tile = 0; tile < NT; ++tile) {
-                        if (t0 + tile >= ntiles) break;     // (uniform)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            acc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + (tile * 2 + t) * 1024)), afr[t], acc[tile], 0, 0, 0);
-                    }
+                for (int u = 0; u < XD; ++u) {
+                    if (k0 + u >= nsteps) break;
+                    MM_STREAM_STEP(k0 + u, xq[u], xq[(u + XD - 1) % XD])
                 }
             }
+#undef MM_STREAM_STEP
+            (void)t_wait;
             if (m0 + (lane & 15) < M) {
 #pragma unroll
                 for (int tile = 0; tile < NT; ++tile)
                     if (t0 + tile < ntiles)
                         *reinterpret_cast<float4*>(orow + (t0 + tile) * 16) = make_float4(acc[tile][0], acc[tile][1], acc[tile][2], acc[tile][3]);
             }
-            MM_WAITV(0);                                    // (the clamped requests behind the end have landed: the rings are free)
-            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // (the group's last reads of the ring are through)
+            if (stamps && lane == 0 && (wave == 0 || wave == TP_WAVES - 1)) {      // diagnostic: cycles in the loop, waiting for loads, at barriers
+                unsigned long long* d = stamps + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 4;
+                d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_wait; d[2] = t_bar; d[3] = nsteps;
+            }
         }
         return;
     }
@@ -688,19 +825,28 @@ __global__ __launch_bounds__((TP_WAVES + (STREAM ? 0 : 1)) * 64) void bfp_qmatmu
     bf16x8 res[NS][2];
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-        XBlk s;
-        load_xblk(s, row, st * 64, g, K);
-        mask_xblk(s, st * 64, K);
-        quantise_xblk<FMT>(s, a, lut, mbits, lane, res[st], zfill);
+        f32x4 xv[4];
+        const long long kk = st * 64 + 16 * g;              // lane (r, g): block g of the step, whole
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(row + (kk < K ? kk : 0) + 4 * j);
+        if (kk >= K) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        quantise_lane<FMT>(xv, a, lut, mbits, zfill, res[st]);
     }
     f32x4 acc[4];
     const bool live = m0 + (lane & 15) < M;
+    unsigned long long t_bar = 0;
+    const unsigned long long t_begin = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
             const int it = c * PLANES + pl;
             asm volatile("" ::: "memory");
+            const unsigned long long tw1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             __builtin_amdgcn_s_barrier();
+            if (stamps) t_bar += __builtin_amdgcn_s_memtime() - tw1;
             asm volatile("" ::: "memory");
             if (pl == 0) {
 #pragma unroll
@@ -723,11 +869,16 @@ __global__ __launch_bounds__((TP_WAVES + (STREAM ? 0 : 1)) * 64) void bfp_qmatmu
             }
         }
     }
+    if (stamps && lane == 0 && (wave == 0 || wave == TP_WAVES - 1)) {
+        unsigned long long* d = stamps + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 4;
+        d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = 0; d[2] = t_bar; d[3] = niter;
+    }
 }
 
 // block_log's statistics pass over x: the smallest non-zero [1,16]-block maximum of the whole tensor (as its bit pattern:
 // positive floats order like unsigned integers), the fill the reference gives all-zero blocks (block_fp.py:54-58).
 __global__ __launch_bounds__(256) void bl_block_stats_kernel(const float4* __restrict__ x4, long long n4, unsigned* __restrict__ stats) {
+    __shared__ unsigned part[4];
     unsigned best = 0xFFFFFFFFu;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {   // (n4 % 4 == 0: whole blocks per quad)
         const float4 v = x4[i];
@@ -736,20 +887,36 @@ __global__ __launch_bounds__(256) void bl_block_stats_kernel(const float4* __res
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
-    if ((threadIdx.x & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(stats, best);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+    __syncthreads();
+    // one atomic per workgroup, and only where it can lower the word (atomics on ONE word are served one after the other:
+    // 16 k of them -- one per wave of a 4096-workgroup grid -- took 200 us)
+    if (threadIdx.x == 0) {
+        best = min(min(part[0], part[1]), min(part[2], part[3]));
+        if (best < __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_min(stats, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
+
+static bool tile_route() {
+    static const bool on = []() { const char* e = getenv("MI355Q_MATMUL_TILE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static unsigned long long* g_tp_stamps = nullptr;      // diagnostic (tools/dbg/tp_stamps.py): per-workgroup cycle counts of the tile kernel
 
 template <int FMT, int PLANES>
 static int launch_qmatmul_fmt(const QuantArgs& ax, const float* x, const uint16_t* yt, float* out, long long B, long long M,
                               long long K, long long Kp, long long N, hipStream_t st, bool softmax, const float* mask,
                               long long causal_off, long long plane_stride, const unsigned* xstats) {
     // plain products: the tile kernel (MI355Q_MATMUL_TILE=0: kernel 2, for comparisons); the softmax forms stay on kernel 2
-    static const bool tile_route = []() { const char* e = getenv("MI355Q_MATMUL_TILE"); return !(e && e[0] == '0'); }();
-    if (!softmax && tile_route) {
+    // (diagnostic: MI355Q_MATMUL_DBG=1 stops behind the y pack [and block_log's statistics pass] -- tools/dbg/vm_breakdown.py)
+    static const bool pack_only = []() { const char* e = getenv("MI355Q_MATMUL_DBG"); return e && e[0] == '1'; }();
+    if (pack_only) return 0;
+    if (!softmax && tile_route()) {
         dim3 g3((unsigned)((M + TP_WAVES * 16 - 1) / (TP_WAVES * 16)), (unsigned)B);
 #define MI355Q_TP_LAUNCH(STREAM_, NTNS_)                                                                                   \
-        hipLaunchKernelGGL((bfp_qmatmul_tile_kernel<STREAM_, NTNS_, FMT, PLANES>), g3, (TP_WAVES + (STREAM_ ? 0 : 1)) * 64, 0, st, ax, x, yt, out, M, K, \
-                           Kp, N, plane_stride, xstats)
+        hipLaunchKernelGGL((bfp_qmatmul_tile_kernel<STREAM_, NTNS_, FMT, PLANES>), g3, (TP_WAVES + 1) * 64, 0, st, ax, x, yt, out, M, K, \
+                           Kp, N, plane_stride, xstats, g_tp_stamps)
         if (Kp == 1) MI355Q_TP_LAUNCH(false, 1);
         else if (Kp == 2) MI355Q_TP_LAUNCH(false, 2);
         else if (Kp == 3) MI355Q_TP_LAUNCH(false, 3);
@@ -797,13 +964,17 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
     const long long plane = B * Kp * 64 * N;               // elements of one plane
     uint16_t* ytp = static_cast<uint16_t*>(yt);
     hipError_t e;
+    const bool lane_order = !softmax && tile_route();       // which product kernel follows: its K order inside a 64-step
+#define MI355Q_PACK(FMT_)                                                                                                  \
+    if (lane_order) hipLaunchKernelGGL((bfp_quant_pack_t_kernel<FMT_, true>), g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);   \
+    else hipLaunchKernelGGL((bfp_quant_pack_t_kernel<FMT_, false>), g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane)
     if (fmt == FMT_BFP) {
-        hipLaunchKernelGGL(bfp_quant_pack_t_kernel<FMT_BFP>, g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);
+        MI355Q_PACK(FMT_BFP);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
         return launch_qmatmul_fmt<FMT_BFP, 1>(ax, x, ytp, out, B, M, K, Kp, N, st, softmax, mask, causal_off, plane, nullptr);
     }
     if (fmt == FMT_BM) {
-        hipLaunchKernelGGL(bfp_quant_pack_t_kernel<FMT_BM>, g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);
+        MI355Q_PACK(FMT_BM);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
         return launch_qmatmul_fmt<FMT_BM, 1>(ax, x, ytp, out, B, M, K, Kp, N, st, softmax, mask, causal_off, plane, nullptr);
     }
@@ -811,11 +982,16 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
     unsigned* stats = reinterpret_cast<unsigned*>(ytp + 3 * plane);
     if ((e = hipMemsetAsync(stats, 0xFF, 4, st)) != hipSuccess) return (int)e;
     const long long n4 = B * M * K / 4;
-    const unsigned gs = (unsigned)std::min<long long>((n4 + 255) / 256, 256 * 16);
+    const unsigned gs = (unsigned)std::min<long long>((n4 + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(bl_block_stats_kernel, dim3(gs), 256, 0, st, reinterpret_cast<const float4*>(x), n4, stats);
-    hipLaunchKernelGGL(bfp_quant_pack_t_kernel<FMT_RAW>, g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);
+    MI355Q_PACK(FMT_RAW);
+#undef MI355Q_PACK
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     return launch_qmatmul_fmt<FMT_BL, 3>(ax, x, ytp, out, B, M, K, Kp, N, st, false, mask, causal_off, plane, stats);
 }
 
 }  // namespace mi355q
+
+// diagnostic hook, not part of include/mi355q.h: a device buffer ([workgroups][2][4] 64-bit words) the tile product kernel
+// fills with {cycles in its loop, cycles waiting for its loads, cycles at barriers, pieces}; NULL switches it off
+extern "C" __attribute__((visibility("default"))) void mi355q_debug_tp_stamps(void* buf) { mi355q::g_tp_stamps = static_cast<unsigned long long*>(buf); }
