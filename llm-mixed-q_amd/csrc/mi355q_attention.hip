@@ -236,7 +236,6 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     // (causal: the query blocks with the most visible keys first -- the launch then ends on its cheapest workgroups)
     const long long b = blockIdx.y, m0 = ((long long)(g.causal_off >= 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * QG + grp) * 16;
     const long long qrow = min(m0 + c16, g.M - 1);
-    const int D = DC * 32;
 
     // Q fragments: lane (query c16, g) holds d = 32 c + 8 g .. + 7; a [1,16] block = the lanes g, g ^ 1 of a chunk
     bf16x8 qf[DC];
@@ -434,7 +433,6 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
     const long long wg0 = (long long)(g.causal_off >= 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 64;   // heavy blocks first
     const long long m0 = wg0 + 16 * wave;
     const long long qrow = min(m0 + c16, g.M - 1);
-    const int D = DC * 32;
     bf16x8 qf[DC];
     {
         const int mb = (int)__builtin_log2f(aq.shift);

@@ -353,7 +353,6 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, float* __restrict__
     if (m < M) *reinterpret_cast<float4*>(outb + m * N + n + 4 * (lane >> 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
-constexpr int MM_RESIDENT_STEPS = 3;     // contraction steps (of 64) whose quantised x stays in registers
 
 // (two instantiations: the short-contraction one keeps quantised x in registers, the streaming one stays lean)
 // SOFTMAX (streaming instantiations only): x holds attention SCORES; the rows' softmax (fp32: exp(x - max) / sum, the
@@ -663,7 +662,7 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
     const int mbits = (int)__builtin_log2f(a.shift);
     const int nsteps = (int)Kp, ntiles = (int)(N >> 4);
     using lptr_t = __attribute__((address_space(3))) void*;
-    const unsigned bring0 = (unsigned)(size_t)(lptr_t)bring, xring0 = (unsigned)(size_t)(lptr_t)xring + wave * 4096;   // (the objects' own LDS addresses)
+    const unsigned bring0 = (unsigned)(size_t)(lptr_t)bring;       // (the object's own LDS address)
 
     if (STREAM) {
         if (wave == TP_WAVES) {
