@@ -864,7 +864,7 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
 #pragma unroll
                 for (int tile = 0; tile < 4; ++tile)
                     if (c * 4 + tile < ntiles)
-                        *reinterpret_cast<float4*>(orow + (c * 4 + tile) * 16) = make_float4(acc[tile][0], acc[tile][1], acc[tile][2], acc[tile][3]);
+                        *reinterpret_cast<f32x4*>(orow + (c * 4 + tile) * 16) = acc[tile];      // (non-temporal stores: no difference, 191.9 / 191.3 us)
             }
         }
     }
