@@ -166,7 +166,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
     constexpr bool LATE_STAGE1 = SCHED == 2 && FIXMODE;
     stage(0, 0);
     if (!LATE_STAGE1 && nsteps > 1) stage(1, 1);
-    if (TI == 4 && nsteps > 2) stage(2, 2);
+    if (TI == 4 && SCHED == 1 && nsteps > 2) stage(2, 2);       // (the one-phase schedule runs three steps ahead)
 
     // ---- exception bookkeeping of this tile.  Its buckets rode in front of the operand stream; once they have landed
     //      (the first two stages stay in flight) the workgroup counts the entries, clears the row / column maps, links
@@ -333,7 +333,10 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
         //   barrier(t): every wave has waited for its own pieces of step t + 1 (requested a whole step earlier) and has
         //   finished every read of step t - 1 (all consumed by MFMAs it has issued)  =>  behind it stage t + 1 may be read
         //   and stage t - 1 = stage t + 2 of the ring of three may be re-filled.
-        static_assert(SCHED != 2 || (NS == 3 && TI == 8 && LPW == 4), "pipelined schedule: 256 x 256 tile, ring of three");
+        // Round 4: the 128 x 256 tile takes the same schedule (TI = 4: four MFMA groups a step, three DMA pieces a wave, a ring
+        // of three of its four 24-KiB stages): its one-phase schedule ran 1400 clocks a K-step against 515 of MFMA work
+        // (profiles/r04_shard_shapes.txt).  Reads of a step there: group i issues A(i + 2) and B(i) of the next step.
+        static_assert(SCHED != 2 || (NS == 3 && TI == 8 && LPW == 4) || (NS == 4 && TI == 4 && LPW == 3), "pipelined schedule: ring of three");
         i32x4 fa[4], fb0[TJ], fb1[TJ];
         // Fragment reads are inline assembly with hand-counted waits (LDS reads of a wave return in issue order): left to
         // the compiler every read sinks to just in front of its first use behind an lgkmcnt(0).  Lane-constant part of
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
         // fragments from the stage it is on (unused values: the hand-counted waits stay the same) and the last two steps
         // request the final step once more (into the free stage of the ring; drained behind the loop, never read).
         const int dbg = FIXMODE_ == 3 ? a.dbg : 0;            // (diagnostic build: knock parts of the loop out, results invalid)
+        constexpr int B0 = TI == 8 ? 2 : 0;                   // first MFMA group that reads a B fragment of the next step
         auto body = [&](i32x4 (&fb)[TJ], i32x4 (&fbn)[TJ], int t, int sc, int sn, int dslot) {
             V8_WAIT(0);
             if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
             if (!(dbg & 4)) {                                                                                          \
             if (i < TI - 2) V8_DSR(fa[(i + 2) & 3], ac, (i + 2) * 1024);                                               \
             else V8_DSR(fa[(i + 2) & 3], an, (i + 2 - TI) * 1024);                                                     \
-            if (i >= 2 && i < 2 + TJ) V8_DSR(fbn[(i - 2) & 3], bn, ((i - 2) & 3) * 1024);                              \
+            if (i >= B0 && i < B0 + TJ) V8_DSR(fbn[(i - B0) & 3], bn, ((i - B0) & 3) * 1024);                          \
             }                                                                                                          \
             if (i < LPW && !(dbg & 1))                                                                                 \
                 __builtin_amdgcn_global_load_lds((gptr_t)(src[i & 3] + dstep), (lptr_t)(smem + dslot * STAGE + dst[i & 3]), \
@@ -371,7 +375,14 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
             _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                             \
                 acc[i][j] = v8_mma(fa[i & 3], fb[j], acc[i][j]);                                                                        \
             __builtin_amdgcn_sched_barrier(0);
-            V8_GROUP(0, 2) V8_GROUP(1, 2) V8_GROUP(2, 3) V8_GROUP(3, 4) V8_GROUP(4, 5) V8_GROUP(5, 5) V8_GROUP(6, 4) V8_GROUP(7, 3)
+            if constexpr (TI == 8) {
+                V8_GROUP(0, 2) V8_GROUP(1, 2) V8_GROUP(2, 3) V8_GROUP(3, 4) V8_GROUP(4, 5) V8_GROUP(5, 5) V8_GROUP(6, 4) V8_GROUP(7, 3)
+            } else {
+                // reads in issue order: .. A0' B2' | A1' B3' || A2 B0" | A3 B1" | A0" B2" | A1" B3" ..  (' this step, " the next).
+                // Group 0 needs the whole of B' (B3' is the youngest: two reads behind it), group 1 A1' (older still: the four
+                // of groups 0 and 1 may fly), groups 2 / 3 their A issued two groups earlier (five behind it)
+                V8_GROUP(0, 2) V8_GROUP(1, 4) V8_GROUP(2, 5) V8_GROUP(3, 5)
+            }
 #undef V8_GROUP
         };
         int s0 = 0, s1 = 1, s2 = 2;
@@ -733,10 +744,12 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     const double cost256 = (double)((t256 + 255) / 256) * 1.0, cost128 = (double)((t128 + 255) / 256) * 0.82;
     const char* force = getenv("MI355Q_V8_TILE_ROWS");          // (tests pin either flavour)
     const bool small = force && atoi(force) ? atoi(force) == 128 : cost128 < cost256;
+    // K-loop schedule of the 128 x 256 tile: 2 = the pipelined one of the 256 x 256 tile (round 4, default), 1 = one phase per step
+    static const int small_sched = getenv("MI355Q_V8_SMALL_SCHED") ? atoi(getenv("MI355Q_V8_SMALL_SCHED")) : 2;
     unsigned tiles = (unsigned)(small ? t128 : t256);
     {   // under-filled grid: split K (the 128-row tile's schedule takes any slice length, the 256-row one even ones)
         static const int sched_ = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
-        const int S = choose_splits(tiles, (int)(a.K >> 6), !small && sched_ == 2, xlist && wlist ? 32 : 8);
+        const int S = choose_splits(tiles, (int)(a.K >> 6), sched_ == 2 && (!small || small_sched == 2), xlist && wlist ? 32 : 8);
         a.splits = 1;
         if (S > 1) {
             SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * (small ? 128 : 256) * 256 * 4, (int)tiles);
@@ -788,7 +801,10 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     if (use_v9 && (v9_fix || !fix || corr_ok) && (a.ngroup <= 1 || corr_ok) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {
-        if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+        const bool piped = small_sched == 2 && a.K % 128 == 0 && (((a.K >> 6) / (a.splits > 1 ? a.splits : 1)) & 1) == 0;
+        if (fix && piped) hipLaunchKernelGGL((bfp_gemm_v8<1, 4, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+        else if (piped) hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+        else if (fix) hipLaunchKernelGGL((bfp_gemm_v8<1, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
         else hipLaunchKernelGGL((bfp_gemm_v8<0, 4>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     } else if (fix && want_stamps && sched == 2) hipLaunchKernelGGL((bfp_gemm_v8<3, 8, 2>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else if (fix && want_stamps) hipLaunchKernelGGL((bfp_gemm_v8<3, 8>), grid, V8_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
