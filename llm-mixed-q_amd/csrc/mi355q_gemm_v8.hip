@@ -223,7 +223,8 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
     if (FIXMODE) {
         // (the buckets are older than the operand stages requested above)
         if (FIXMODE_ == 3) pst[0] = __builtin_amdgcn_s_memrealtime();
-        if (TI == 4 && nsteps > 2) V8_WAIT(3 * LPW); else if (nsteps > 1 && !LATE_STAGE1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
+        // (what may still fly: the stages requested above, nothing older)
+        if (TI == 4 && SCHED == 1 && nsteps > 2) V8_WAIT(3 * LPW); else if (nsteps > 1 && !LATE_STAGE1) V8_WAIT(2 * LPW); else V8_WAIT(LPW);
         __builtin_amdgcn_s_barrier();
         if (FIXMODE_ == 3) pst[1] = __builtin_amdgcn_s_memrealtime();
         // a bucket overflowed somewhere (uniform over the grid): the row-scale product does not apply; the workgroups of

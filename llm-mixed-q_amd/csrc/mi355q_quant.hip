@@ -702,12 +702,15 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
         const long long k = (long long)f * 4, sgm = k / a.seg_len;
         return reinterpret_cast<const float4*>(base + sgm * a.seg_stride + row * a.seg_len + (k - sgm * a.seg_len));
     };
-    auto load_row = [&](float4 (&v)[MAXIT], long long row) {
+    auto load_raw = [&](float4 (&v)[MAXIT], long long row) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int kb = it * 64 + wave * 16 + (lane >> 2);
             v[it] = (FULL || (it < nit && kb < nkb)) ? *row_f4(a.x, row, it * 256 + tid) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto load_row = [&](float4 (&v)[MAXIT], long long row) {
+        load_raw(v, row);
         if (a.pre_op == MI355Q_PRE_RMSNORM) {                                                  // (uniform)
             // LlamaRMSNorm (modeling_llama.py:88-92): x * rsqrt(mean(x^2) + eps), then weight * that, each product rounded
             // to fp32 like the reference's separate ops.  The mean is summed in a fixed order (lane partials over the
@@ -802,9 +805,13 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     __syncthreads();
     int cslot = -1;
     long long crow = 0;
+    // Several rows per workgroup (round 4, plain rows: launch_quant_align_rows): the NEXT row is requested as soon as this one's
+    // values are dead -- behind the mantissas, in front of the exponent decision, its barriers and the stores -- into the same
+    // registers: a row's life was load round trip + arithmetic + decision + stores in sequence, 4 workgroups a compute unit.
+    const bool early = a.pre_op == 0 && !CORR && !SEG;
     for (long long wi = blockIdx.x; wi < a.rows && (!CORR || wi == (long long)blockIdx.x); wi += gridDim.x) {     // (CORR: one row per workgroup)
         const long long row = row_of(wi);
-        if (wi != (long long)blockIdx.x) load_row(v, row);
+        if (wi != (long long)blockIdx.x && !early) load_row(v, row);
         unsigned pk[MAXIT];
         int amax[MAXIT], code[MAXIT];
         // Pass 1: block maxima, shared exponents, scale exponents (the threshold table is read unconditionally: no
@@ -866,6 +873,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
                 pk[it] = lo | hi;
             }
         }
+        if (early && wi + gridDim.x < a.rows) load_raw(v, row_of(wi + gridDim.x));
         int E = 0;
         // bcap < 0: no alignment at all -- every block keeps its own exponent, rowflag 0 (operands for the blockwise
         // kernel: inputs whose block exponents spread too far for any row window, e.g. SiLU-gated MLP activations)
@@ -928,6 +936,10 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
                             int* list_to_clear, hipStream_t st, int bcap, const CorrLaunch* corr) {
     long long grid = a.rows;
     if (grid > 65536) grid = 65536;
+    // plain rows: a fixed grid of 4 workgroups per compute unit, several rows each with the next row's loads in flight
+    // (MI355Q_QROWS_GRID: 0 = one workgroup per row as before)
+    static const int qgrid = getenv("MI355Q_QROWS_GRID") ? atoi(getenv("MI355Q_QROWS_GRID")) : 1024;
+    if (qgrid > 0 && a.pre_op == 0 && !corr && !a.seg_len && grid > qgrid) grid = qgrid;
     if (grid < 1) grid = 1;
     CorrLaunch c = corr ? *corr : CorrLaunch{};
     static const int corr_dbg = getenv("MI355Q_CORR_DBG") ? atoi(getenv("MI355Q_CORR_DBG")) : 0;

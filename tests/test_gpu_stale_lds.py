@@ -63,6 +63,8 @@ def _lin_cfg(width, **extra):
 
 @pytest.mark.parametrize("M,K,N,align,act", [
     (1024, 1024, 1024, "rows", "plain"),        # 128-row tiles, in-tile exception vectors
+    (300, 512, 256, "rows", "plain"),           # 128-row tiles, few K-steps: the buckets must have landed before they are read
+    (256, 256, 256, "rows", "plain"),           #   (round 4: the pipelined schedule of that tile waited for too little)
     (4096, 2048, 2048, "rows", "plain"),        # 256-row tiles
     (256, 4096, 256, "rows", "uniform"),        # split-K slices
     (512, 2048, 512, "rows", "overflow"),       # bucket overflow -> the blockwise product inside the launch
