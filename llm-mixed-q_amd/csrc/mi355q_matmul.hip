@@ -639,13 +639,13 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
     constexpr int SUB = NT * NS * 2;                      // 1-KiB sub-pieces of a piece
     constexpr int BW = STREAM ? SUB / TP_WAVES : SUB;     // DMA instructions per issuing wave and piece
     static_assert(SUB % TP_WAVES == 0, "a piece is shared evenly by the waves");
-    constexpr int DB = STREAM ? 3 : 4, DX = PLANES > 1 ? 2 : 3;
+    constexpr int DB = STREAM ? 3 : 2, DX = PLANES > 1 ? 2 : 3;     // (RESIDENT: two pieces -- with the patches two workgroups still share a compute unit's LDS up to 128 columns of x)
     constexpr int XD = FMT == FMT_BFP ? 3 : 2;            // STREAM: x slabs in rotation, XD - 1 steps ahead (the other formats' element
                                                           // functions leave no registers for a third)
     constexpr int PIECE = SUB * 1024;
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) unsigned char bring[DB * PIECE];
-    __shared__ __attribute__((aligned(16))) unsigned char xring[STREAM ? TP_WAVES * 4096 : 16];     // the waves' transpose patches
+    __shared__ __attribute__((aligned(16))) unsigned char xring[TP_WAVES * 4096];     // the waves' transpose patches (STREAM: x in, RESIDENT: out)
     load_lut<FMT>(lut);
     float zfill = 1.0f;
     if (FMT == FMT_BL) {
@@ -835,7 +835,11 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
         quantise_lane<FMT>(xv, a, lut, mbits, zfill, res[st]);
     }
     f32x4 acc[4];
-    const bool live = m0 + (lane & 15) < M;
+    unsigned char* opatch = xring + wave * 4096;
+    char* obase = reinterpret_cast<char*>(out + (b * M + min(m0, M - 1)) * N);      // (scalar base + constant 32-bit lane offsets)
+    unsigned ooff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ooff[j] = (unsigned)(((long long)(4 * j + g) * N + 4 * ((lane & 15) ^ (4 * j + g))) * 4);
     unsigned long long t_bar = 0;
     const unsigned long long t_begin = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int c = 0; c < nchunks; ++c) {
@@ -860,11 +864,21 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
                     for (int t = 0; t < 2; ++t)
                         acc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + ((tile * NS + st) * 2 + t) * 1024)), res[st][t], acc[tile], 0, 0, 0);
-            if (pl == PLANES - 1 && live) {
+            if (pl == PLANES - 1) {
+                // The chunk's 16 x 64 outputs through the wave's 4-KiB patch of LDS, so that a store instruction writes four
+                // rows x 256 contiguous bytes instead of sixteen rows x 64 (the MFMA layout): whole cache lines per request.
+                // Chunks of 16 bytes XOR (row & 15): no bank twice either way.  (Non-temporal stores: no difference.)
+                const int r = lane & 15;
 #pragma unroll
                 for (int tile = 0; tile < 4; ++tile)
-                    if (c * 4 + tile < ntiles)
-                        *reinterpret_cast<f32x4*>(orow + (c * 4 + tile) * 16) = acc[tile];      // (non-temporal stores: no difference, 191.9 / 191.3 us)
+                    *reinterpret_cast<f32x4*>(opatch + r * 256 + (((tile * 4 + g) ^ r) << 4)) = acc[tile];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rw = 4 * j + g, ch = (lane & 15) ^ rw;              // this lane's row and (logical) chunk of it
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(opatch + rw * 256 + ((lane & 15) << 4));
+                    if (m0 + rw < M && c * 4 + (ch >> 2) < ntiles)
+                        *reinterpret_cast<f32x4*>(obase + ooff[j] + (unsigned)c * 256u) = v4;
+                }
             }
         }
     }
