@@ -590,43 +590,25 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
 // What bounded kernel 2 (profiles/r04_values_matmul.txt): a wave's yt fragments and its x prefetch share ONE in-order vector-
 // memory queue, so a fragment asked for "now" comes back behind every x prefetch issued before it -- a K-step cost an HBM
 // round trip however deep the prefetch, and the short-contraction form pulled the whole of yt[b] from L2 once per 16 rows
-// (2 GB of L2 traffic at [32, 2048, 128] x [32, 128, 2048]).  Here nothing is asked for "now": a workgroup of 8 waves x 16
-// rows streams EVERYTHING through LDS rings filled by LDS-DMA (global_load_lds_dwordx4) D - 1 pieces ahead --
-//   STREAM (long contraction, P V):  piece = the yt fragments of one 64-step for NT column tiles (NT x 2 KiB, shared by the 8
-//     waves), plus each wave's own x slab of that step (16 rows x 64 floats = 4 KiB, lane-for-lane the register layout of
-//     kernel 2, read back with one ds_read_b128 per block and quantised in registers); accumulators live across the steps;
+// (2 GB of L2 traffic at [32, 2048, 128] x [32, 128, 2048]).  Here a workgroup is 8 waves x 16 rows of x plus a NINTH wave that
+// only feeds a ring of yt pieces in LDS (wave specialisation: no wave asks for a fragment "now", and every wave's queue holds one
+// kind of traffic) --
+//   STREAM (long contraction, P V):  piece = the yt fragments of one 64-step for NT column tiles (NT x 2 KiB): the feeder loads it
+//     into registers a step ahead and ds_writes it (LDS-DMA moved no more than ~22 bytes a clock and compute unit); every compute
+//     wave loads its own x slab (16 rows x 256 bytes) XD - 1 steps ahead into registers, passes it through its 4-KiB LDS patch
+//     into a block-per-lane order and quantises in registers (quantise_lane); accumulators live across the steps;
 //   RESIDENT (short contraction, Q K^T): the wave's x is quantised once into registers; piece = the yt fragments of one
-//     64-column chunk for all NS steps (NS x 8 KiB, contiguous in yt); four 16 x 16 tiles stored per chunk;
-// one s_barrier per piece, hand-counted s_waitcnt vmcnt (the compiler must not see the DMA: it would drain it at every LDS read).
-// Counting only works if the number of LOADS per piece is fixed -- pieces and tiles beyond the end are clamped to the last valid
-// one (the same data lands on the same place twice), never skipped -- and if no STORES share the wave's counter: loads return in
-// order among themselves, stores among themselves, but not with respect to each other (a count that budgeted for the chunk
-// stores let pieces through that had not landed).  STREAM stores once, at the end.  RESIDENT stores every chunk, so there the
-// DMA is issued by a NINTH wave that does nothing else (wave specialisation): its counter sees loads only, and the eight
-// compute waves never wait on theirs.
+//     64-column chunk for all NS steps (NS x 8 KiB, contiguous in yt), fetched by the feeder with LDS-DMA (hand-counted
+//     s_waitcnt vmcnt; the compiler must not see the DMA: it would drain it at every LDS read); the chunk's 16 x 64 outputs leave
+//     through the wave's LDS patch as four stores of 4 rows x 256 bytes;
+// one s_barrier per piece.  Counting vmcnt only works where the number of LOADS per piece is fixed -- pieces and tiles beyond
+// the end are clamped to the last valid one (the same data lands on the same place twice), never skipped -- and where no
+// STORES share the wave's counter: loads return in order among themselves, stores among themselves, but not with respect to
+// each other (a count that budgeted for the chunk stores let pieces through that had not landed).  Hence the feeder.
 // PLANES > 1 (block_log's raw y as three bf16 planes): the planes of a step / chunk are consecutive pieces over the same x.
 constexpr int TP_WAVES = 8;
 #define MM_GLDS16(gp, lds) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds) : "memory")
 #define MM_WAITV(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-
-// loads the issuing wave requests in the iteration of plane `pl`: its share of the yt piece (STREAM: an eighth, RESIDENT: the
-// whole piece), then (STREAM, plane 0) the four blocks of its x slab
-template <bool STREAM, int PLANES, int BW>
-constexpr int tp_tail_issues(int pl) { return STREAM && pl == 0 ? 4 : 0; }
-// instructions issued AFTER the DMA of the piece that iteration `it` (plane pl) needs, i.e. what may still be in flight when
-// that piece has landed: DB = ring depth in pieces (fetched DB - 1 iterations ahead), DX = x ring depth in steps
-template <bool STREAM, int PLANES, int BW, int DB, int DX>
-constexpr int tp_allowed(int pl) {
-    auto plane_of = [](int p) { return ((p % PLANES) + PLANES) % PLANES; };
-    int n = tp_tail_issues<STREAM, PLANES, BW>(plane_of(pl - (DB - 1)));
-    for (int d = DB - 2; d >= 1; --d) n += BW + tp_tail_issues<STREAM, PLANES, BW>(plane_of(pl - d));
-    if (STREAM && pl == 0) {                              // x of this step: issued (DX - 1) * PLANES iterations ago, last in its iteration
-        int m = 0;
-        for (int d = (DX - 1) * PLANES - 1; d >= 1; --d) m += BW + tp_tail_issues<STREAM, PLANES, BW>(plane_of(pl - d));
-        n = m < n ? m : n;
-    }
-    return n;
-}
 
 template <bool STREAM, int NTNS, int FMT, int PLANES>
 __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(const QuantArgs a, const float* __restrict__ x,
@@ -639,7 +621,8 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
     constexpr int SUB = NT * NS * 2;                      // 1-KiB sub-pieces of a piece
     constexpr int BW = STREAM ? SUB / TP_WAVES : SUB;     // DMA instructions per issuing wave and piece
     static_assert(SUB % TP_WAVES == 0, "a piece is shared evenly by the waves");
-    constexpr int DB = STREAM ? 3 : 2, DX = PLANES > 1 ? 2 : 3;     // (RESIDENT: two pieces -- with the patches two workgroups still share a compute unit's LDS up to 128 columns of x)
+    constexpr int DB = STREAM ? 3 : 2;                    // ring depth in pieces (RESIDENT: two -- with the patches two workgroups still
+                                                          // share a compute unit's LDS up to 128 columns of x)
     constexpr int XD = FMT == FMT_BFP ? 3 : 2;            // STREAM: x slabs in rotation, XD - 1 steps ahead (the other formats' element
                                                           // functions leave no registers for a third)
     constexpr int PIECE = SUB * 1024;
@@ -814,7 +797,7 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
         MM_WAITV(0);                                        // (the table loads: the counts below start from an empty queue)
         for (int j = -(DB - 1); j < 0; ++j) issue(j);
         for (int it = 0; it < niter; ++it) {
-            MM_WAITV((tp_allowed<false, 1, BW, DB, DX>(0)));
+            MM_WAITV(((DB - 2) * BW));                      // (piece `it` has landed; the DB - 2 pieces requested behind it may fly)
             __builtin_amdgcn_s_barrier();
             issue(it);
         }
