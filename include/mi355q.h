@@ -34,11 +34,14 @@
  *     zero-block map of the exact quantiser mode on tensors of 128 MiB and more (without it that mode reads x a second
  *     time instead).
  *   - Environment switches (diagnostics; read once per process): MI355Q_V9=0 keeps every launch on the round-2 tile kernel
- *     (mi355q_gemm_v8.hip) -- by default launches WITHOUT exception lists (row-scale operands that carry none, the bf16
- *     flavour) with K % 128 == 0 and >= 4 K-steps per slice take mi355q_gemm_v9.hip; MI355Q_V9_FIX=1 sends launches with
- *     lists there too (add-back behind the K loop: no faster), MI355Q_V9_PREPASS=1 splits that into a pre-pass
- *     and a product launch; MI355Q_QV_PIECES=0|1|2|4 pins the streaming quantisers' access shape (0: grid-stride loop;
- *     default by tensor size); MI355Q_V8_TILE_ROWS, MI355Q_V8_SPLITS pin the tile GEMM's tile height / split-K.
+ *     (mi355q_gemm_v8.hip) -- by default every launch of the 256 x 256 tile, with or without exception lists, the bf16
+ *     flavour too, with K % 128 == 0 and >= 4 K-steps per slice takes mi355q_gemm_v9.hip (round 4; grouped launches and the
+ *     128-row tile stay in v8); MI355Q_V9_FIX=0 sends the launches with lists back to v8 (A/B runs); MI355Q_V8_SMALL_SCHED=1
+ *     gives the 128-row tile its round-3 one-phase K-loop schedule; MI355Q_QROWS_GRID=0 launches the row quantiser with one
+ *     workgroup per row (default: 1024 workgroups, several rows each); MI355Q_MATMUL_TILE=0 sends the plain attention products
+ *     back to kernel 2 of mi355q_matmul.hip; MI355Q_QV_PIECES=0|1|2|4 pins the streaming quantisers' access shape (0:
+ *     grid-stride loop; default by tensor size); MI355Q_V8_TILE_ROWS, MI355Q_V8_SPLITS pin the tile GEMM's tile height /
+ *     split-K.  (MI355Q_CORR=1, read by the Python layer: producer-formed exception corrections, ABI 18.)
  */
 #ifndef MI355Q_H
 #define MI355Q_H
