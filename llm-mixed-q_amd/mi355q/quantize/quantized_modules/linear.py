@@ -374,6 +374,8 @@ class _LinearBase(nn.Linear):
                     return self._forward_int8(x, plan)
                 if not differentiated and self._values_exact_in_bf16(x):
                     return self._forward_bf16_values(x)
+                if not differentiated and self._padded_block_fp_ok(x):
+                    return self._forward_block_fp_padded(x)
                 x = self.x_quantizer(x)
             return F.linear(x, self.weight, self.bias)
         x = self.x_quantizer(x)
@@ -400,6 +402,33 @@ class _LinearBase(nn.Linear):
             return False
         return (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32 and xq.ndim >= 2
                 and self.in_features % 32 == 0 and not self.weight_requires_quantisation)
+
+    def _padded_block_fp_ok(self, x) -> bool:
+        """block_fp layers whose in_features is a multiple of the block (16) but not of the tile kernels' K-step (64): the
+        contraction is padded with all-zero blocks -- they quantise to zeros and add nothing -- and runs on the bf16 flavour of
+        the tile GEMM (a block_fp value of width <= 9 is exact in bf16, products exact in fp32) instead of dropping to the
+        library fp32 GEMM.  config["mi355q_pad_k"] = False keeps F.linear."""
+        c, K = self.config, self.in_features
+        if self.arith != "block_fp" or not c.get("mi355q_pad_k", True) or K % 16 or K % 64 == 0:
+            return False
+        if not (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and 2 <= x.ndim <= 3):
+            return False
+        if not (2 <= c["data_in_width"] <= 9 and 2 <= c["weight_width"] <= 9) or self.weight_requires_quantisation:
+            return False
+        xs = [1, K] if x.ndim == 2 else [1, x.shape[-2], K]
+        return (ops.resolve_blocking(xs, c["data_in_block_size"], True)[3:] == (1, 16)
+                and ops.resolve_blocking([self.out_features, K], c["weight_block_size"], False)[3:] == (1, 16))
+
+    def _forward_block_fp_padded(self, x):
+        c, K = self.config, self.in_features
+        Kp = (K + 63) // 64 * 64
+        x2 = F.pad(x.reshape(-1, K), (0, Kp - K))
+        w = self.__dict__.get("_w_bf16_padded")
+        if w is None or w[1] != self.weight._version or w[0].device != x.device:
+            w = self.__dict__["_w_bf16_padded"] = (ops.bf16_tile(F.pad(self.weight.data, (0, Kp - K))), self.weight._version)
+        xt = ops.block_fp_quantize_bf16_tiled(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"])
+        y = ops.bf16_gemm_tiled(xt, w[0], x2.shape[0], self.out_features, Kp, self.bias)
+        return y.reshape(*x.shape[:-1], self.out_features)
 
     def _forward_bf16_values(self, x):
         """x (NOT yet quantised) -> x quantiser -> tiled bf16 -> tile GEMM against the tiled quantised weights"""

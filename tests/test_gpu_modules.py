@@ -74,6 +74,41 @@ def test_linear_int8_path_vs_oracle(wx, ww, has_bias):
         assert np.array_equal(lin.bias.detach().cpu().numpy(), bq)
 
 
+@pytest.mark.parametrize("K", [48, 80, 144, 1104])
+def test_linear_block_fp_with_in_features_not_a_multiple_of_64(K):
+    """in_features a multiple of the block but not of the tile kernels' K-step: the contraction is padded with all-zero
+    blocks and runs on the bf16 tile GEMM (no library GEMM); same weights / bias overwrite, output vs the oracle"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    from oracle import np_oracle as O
+    cfg = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8,
+               data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=5, weight_exponent_width=8,
+               weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8,
+               bias_exponent_bias=127, bias_block_size=[16])
+    torch.manual_seed(K)
+    fp = torch.nn.Linear(K, 112, bias=True)
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    w0, b0 = fp.weight.detach().numpy().copy(), fp.bias.detach().numpy().copy()
+    x = torch.randn(3, 37, K) * torch.exp(torch.randn(3, 37, 1))
+    calls, real = [], ops.bf16_gemm_tiled
+    ops.bf16_gemm_tiled = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    try:
+        for call in range(2):
+            y = lin(x.to("cuda:0"))
+            ref = O.bfp_linear_int(x.numpy().reshape(-1, K), w0, b0, cfg).reshape(3, 37, 112)
+            np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+        assert len(calls) == 2, "the padded tile-GEMM route was not taken"
+        off = Q.get_quantized_cls("linear", dict(cfg, mi355q_pad_k=False)).from_float(fp, dict(cfg, mi355q_pad_k=False)).to("cuda:0")
+        y2 = off(x.to("cuda:0"))
+        assert len(calls) == 2
+        np.testing.assert_allclose(y2.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=0, atol=4e-6 * np.abs(ref).max())
+    finally:
+        ops.bf16_gemm_tiled = real
+    _, wq, bq = O.linear_ptq(x.numpy().reshape(-1, K), w0, b0, cfg)
+    assert np.array_equal(lin.weight.detach().cpu().numpy(), wq) and np.array_equal(lin.bias.detach().cpu().numpy(), bq)
+
+
 @pytest.mark.parametrize("align", ["auto", "rows", "rows_post", "blocks", "groups"])
 @pytest.mark.parametrize("outliers", [False, True])
 def test_linear_int8_align_modes(align, outliers):
