@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 19
+#define MI355Q_ABI_VERSION 20
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -206,6 +206,14 @@ int mi355q_bfp_expand(const uint8_t* packed, const uint8_t* codes, void* out_til
 int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, void* stream);
 int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
                            int64_t K, int64_t ldy, void* stream);
+/* The same with x as `x_segments` COLUMN segments (ABI 20): segment s is the tiled bf16 operand of columns
+ * [s K / x_segments, (s + 1) K / x_segments) of x -- [row piece][K-steps of the segment][1 KiB], what
+ * mi355q_block_fp_quantize_bf16_tiled writes for that slice -- and the segments lie x_segment_stride_bytes apart: the
+ * rank-major buffer an all-gather of per-rank QUANTISED output slices leaves (mi355q.sharded, gather = "quantised": 2 bytes per
+ * value travel instead of 4, and every rank quantises only its own slice).  Bit-identical to the plain call on the
+ * re-assembled operand.  K % (32 x_segments) == 0. */
+int mi355q_bf16_gemm_tiled_seg(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
+                               int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream);
 
 /* ---- block minifloat ----------------------------------------------------------------
  * replaces: quantizers/block_minifloat.py:22-74 -> quantizers/minifloat.py:134-196 behind

@@ -214,8 +214,23 @@ int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K,
     return launch_quant_bf16_tiled(a, y_tiled, static_cast<hipStream_t>(stream), /*cast_only=*/true);
 }
 
+static int bf16_gemm_tiled_impl(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
+                                int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream);
+
 int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
                            int64_t K, int64_t ldy, void* stream) {
+    return bf16_gemm_tiled_impl(x_tiled, w_tiled, bias, y, M, N, K, ldy, 1, 0, stream);
+}
+
+int mi355q_bf16_gemm_tiled_seg(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
+                               int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream) {
+    if (x_segments < 1 || (x_segments > 1 && (x_segment_stride_bytes <= 0 || x_segment_stride_bytes % 16))) return MI355Q_E_BADARG;
+    if (x_segments > 1 && K > 0 && (K % (32 * (int64_t)x_segments) != 0)) return MI355Q_E_UNSUPPORTED;   // whole 64-byte K-steps per segment
+    return bf16_gemm_tiled_impl(x_tiled, w_tiled, bias, y, M, N, K, ldy, x_segments, x_segment_stride_bytes, stream);
+}
+
+static int bf16_gemm_tiled_impl(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
+                                int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
     if (M == 0 || N == 0) return 0;
     if (!y || (K > 0 && (!x_tiled || !w_tiled))) return MI355Q_E_BADARG;
@@ -227,6 +242,8 @@ int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, con
     a.bias = bias;
     a.y = y;
     a.M = M; a.N = N; a.K = 2 * K; a.ldy = ldy;      // (the tile kernel counts the contraction in bytes)
+    a.x_segs = x_segments;
+    a.x_seg_stride = x_segment_stride_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t te = g_timing.begin(st);
     const int rc = launch_bf16_gemm_tiled(a, st);

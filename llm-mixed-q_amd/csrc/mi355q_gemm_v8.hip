@@ -140,20 +140,30 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
     const long long kp = a.K >> 6;
     const long long pa_max = ((a.M + 127) / 128) * 8 - 1, pb_max = ((a.N + 127) / 128) * 8 - 1;
     // piece p of a stage: p < BM / 16 -> 16 rows of A, else 16 rows of B; this wave stages pieces wave + 8 q
+    // (bf16 flavour, a.x_segs > 1: x lies as column segments -- [segment][row piece][K-steps of the segment] -- where an
+    //  all-gather of per-rank quantised slices left them; a K-step of a row piece is then found through its segment)
+    const bool xseg = BF16 && a.x_segs > 1;
+    const int sps = xseg ? (int)(kp / a.x_segs) : (int)kp;                  // K-steps per segment
     const int8_t* src[LPW];
     int dst[LPW];
 #pragma unroll
     for (int q = 0; q < LPW; ++q) {
         const int p = wave + V8_NW * q;
-        src[q] = (p < BM / 16 ? a.xm + min((m0 >> 4) + p, pa_max) * kp * 1024 + lane * 16
-                              : a.wm + min((n0 >> 4) + (p - BM / 16), pb_max) * kp * 1024 + lane * 16) + (long long)kstep0 * 1024;
+        src[q] = p < BM / 16 ? a.xm + min((m0 >> 4) + p, pa_max) * (long long)sps * 1024 + lane * 16 + (xseg ? 0ll : (long long)kstep0 * 1024)
+                             : a.wm + min((n0 >> 4) + (p - BM / 16), pb_max) * kp * 1024 + lane * 16 + (long long)kstep0 * 1024;
         dst[q] = p * 1024;
     }
+    auto piece_src = [&](int q, int step) -> const int8_t* {                // piece q of the slice's K-step `step`
+        if (xseg && wave + V8_NW * q < BM / 16) {
+            const int ks = kstep0 + step, sg = ks / sps;
+            return src[q] + sg * a.x_seg_stride + (long long)(ks - sg * sps) * 1024;
+        }
+        return src[q] + (long long)step * 1024;
+    };
     auto stage = [&](int step, int slot) {
 #pragma unroll
         for (int q = 0; q < LPW; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
-                                             (lptr_t)(smem + slot * STAGE + dst[q]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)piece_src(q, step), (lptr_t)(smem + slot * STAGE + dst[q]), 16, 0, 0);
     };
     int aoff[TI], boff[TJ];
 #pragma unroll
@@ -320,8 +330,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
 #pragma unroll
         for (int q = 0; q < LPW; ++q)
             if (q >= q0 && q < q1)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src[q] + (long long)step * 1024),
-                                                 (lptr_t)(smem + sl * STAGE + dst[q]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)piece_src(q, step), (lptr_t)(smem + sl * STAGE + dst[q]), 16, 0, 0);
     };
     int slot = 0;
     constexpr bool ONEPHASE = SCHED == 1;
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
             V8_WAIT(0);
             if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
             const int ac = va + sc, an = va + sn, bn = vb + sn;
-            const long long dstep = (long long)min(t + 2, nsteps - 1) * 1024;
+            const int dstep = min(t + 2, nsteps - 1);
 #define V8_GROUP(i, wait)                                                                                              \
             if (!(dbg & 4)) {                                                                                          \
             if (i < TI - 2) V8_DSR(fa[(i + 2) & 3], ac, (i + 2) * 1024);                                               \
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
             if (i >= B0 && i < B0 + TJ) V8_DSR(fbn[(i - B0) & 3], bn, ((i - B0) & 3) * 1024);                          \
             }                                                                                                          \
             if (i < LPW && !(dbg & 1))                                                                                 \
-                __builtin_amdgcn_global_load_lds((gptr_t)(src[i & 3] + dstep), (lptr_t)(smem + dslot * STAGE + dst[i & 3]), \
+                __builtin_amdgcn_global_load_lds((gptr_t)piece_src(i & 3, dstep), (lptr_t)(smem + dslot * STAGE + dst[i & 3]), \
                                                  16, 0, 0);                                                            \
             V8_LGKM(wait);                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -863,7 +872,7 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
     if (small && small_sched == 2 && a.K % 128 == 0 && (((a.K >> 6) / (a.splits > 1 ? a.splits : 1)) & 1) == 0)
         hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else if (small) hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 1, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !(getenv("MI355Q_V9") && atoi(getenv("MI355Q_V9")) == 0)) return launch_bfp_gemm_v9(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true);
+    else if (a.x_segs <= 1 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !(getenv("MI355Q_V9") && atoi(getenv("MI355Q_V9")) == 0)) return launch_bfp_gemm_v9(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true);
     else if (a.K % 128 == 0) hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 0, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     return (int)hipGetLastError();

@@ -106,6 +106,10 @@ struct GemmArgs {
     int corr_which;               // ... which weight of the binding a single (not grouped) launch multiplies
     int x_mbits, w_mbits;         // mantissa bits of the operands (0: not given) -- the launcher's choice of kernel
     unsigned long long* stamps;   // diagnostic builds of the 256 x 256 tile kernel (MI355Q_V9_STAMPS): [workgroup][2][8] phase times
+    // bf16 flavour: x as `x_segs` column segments (the rank-major result of an all-gather of per-rank quantised slices,
+    // mi355q_bf16_gemm_tiled_seg): segment s holds K-steps s * steps / x_segs .. of every row piece, x_seg_stride bytes apart
+    int x_segs;
+    long long x_seg_stride;
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mi355q_bfp_expand": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mi355q_bf16_tile": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "mi355q_bf16_gemm_tiled": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "mi355q_bf16_gemm_tiled_seg": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i64, _vp]),
     "mi355q_block_fp_quantize": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                            _i32, _i32, _i32, _u32, _vp, _vp]),
     "mi355q_block_minifloat_quantize": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
@@ -95,7 +96,7 @@ class CorrTarget(C.Structure):
     _fields_ = [("w", _vp), ("plan", _vp), ("xvec", _vp), ("wvec", _vp), ("N", _i64), ("slots_in_use", _i32), ("reserved", _i32)]
 
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

@@ -415,9 +415,11 @@ def bf16_tile(x: torch.Tensor) -> torch.Tensor:
     return yt
 
 
-def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, bias=None, out: torch.Tensor = None):
+def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, bias=None, out: torch.Tensor = None,
+                    segments: int = 1):
     """y[M, N] = x . w^T (+ bias) on tiled bf16 operands (block_fp_quantize_bf16_tiled), fp32 accumulation and output:
-    the tile GEMM's bf16 arithmetic -- operands whose blocks keep their own exponents."""
+    the tile GEMM's bf16 arithmetic -- operands whose blocks keep their own exponents.  `segments` > 1: xt is [segments,
+    bytes] -- column segment s of x as its own tiled operand, rank-major as an all-gather leaves them (sharded.py)."""
     if not (xt.is_cuda and wt.is_cuda):
         raise RuntimeError("mi355q.bf16_gemm_tiled: operands must be on a HIP device; there is no CPU fallback")
     given = out is not None
@@ -426,9 +428,14 @@ def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, 
     assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
     ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
     with _on_device(xt.device):
-        rc = _lib.load_library().mi355q_bf16_gemm_tiled(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy,
-                                                       _stream_ptr(xt.device))
-    _lib.check(rc, "mi355q_bf16_gemm_tiled")
+        if segments > 1:
+            assert xt.ndim == 2 and xt.shape[0] == segments and xt.is_contiguous()
+            rc = _lib.load_library().mi355q_bf16_gemm_tiled_seg(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy, int(segments),
+                                                               xt.stride(0) * xt.element_size(), _stream_ptr(xt.device))
+        else:
+            rc = _lib.load_library().mi355q_bf16_gemm_tiled(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy,
+                                                           _stream_ptr(xt.device))
+    _lib.check(rc, "mi355q_bf16_gemm_tiled_seg" if segments > 1 else "mi355q_bf16_gemm_tiled")
     if given:
         _wrote_into(out)
     return out

@@ -567,3 +567,32 @@ def test_bf16_tiled_gemm_vs_oracle(M, N, K, style, wx, ww):
     ref = O.linear_ptq(x, w, b, dict(cfg, bias_width=ww))[0]
     scale = np.abs(ref).max() + 1e-30
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
+
+
+@pytest.mark.parametrize("M,K,N,P", [(300, 512, 272, 2), (300, 512, 272, 4), (1024, 2048, 512, 8), (130, 192, 64, 2), (4096, 1024, 256, 4),
+                                     (77, 256, 48, 8)])
+def test_bf16_tile_gemm_with_x_in_column_segments(M, K, N, P):
+    """mi355q_bf16_gemm_tiled_seg (ABI 20): x handed over as P column segments, each its own tiled bf16 operand, rank-major --
+    what an all-gather of per-rank quantised output slices leaves (sharded.py, gather = "quantised") -- gives the plain call's
+    result on the re-assembled operand, and the oracle's"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    r = np.random.default_rng(M + K + P)
+    x = (r.normal(size=(M, K)) * np.exp(r.normal(size=(M, 1)))).astype(np.float32)
+    w = (r.normal(size=(N, K)) * 0.05).astype(np.float32)
+    b = r.normal(size=(N,)).astype(np.float32)
+    xt_, wt_, bt = (torch.from_numpy(a).to("cuda:0") for a in (x, w, b))
+    wt = ops.block_fp_quantize_bf16_tiled(wt_, 6, 8, 127, reuse=False)
+    plain = ops.bf16_gemm_tiled(ops.block_fp_quantize_bf16_tiled(xt_, 6, 8, 127, reuse=False), wt, M, N, K, bt)
+    segs = [ops.block_fp_quantize_bf16_tiled(xt_[:, s * K // P:(s + 1) * K // P].contiguous(), 6, 8, 127, reuse=False) for s in range(P)]
+    stacked = torch.stack([s_.reshape(-1) for s_ in segs]).contiguous()
+    got = ops.bf16_gemm_tiled(stacked, wt, M, N, K, bt, segments=P)
+    xq = O.block_fp_quantize(x, 6, 8, 127, [1, 16], True).astype(np.float64)
+    wq = O.block_fp_quantize(w, 6, 8, 127, [1, 16], False).astype(np.float64)
+    ref = xq @ wq.T + b
+    scale = np.abs(ref).max()
+    assert np.abs(got.cpu().numpy() - ref).max() <= 2e-6 * scale
+    assert (got - plain).abs().max().item() <= 1e-6 * scale
+    if K % 128:                                  # (both calls on the same kernel: the same bits)
+        assert torch.equal(got, plain)
