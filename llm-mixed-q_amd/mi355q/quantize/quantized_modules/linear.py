@@ -356,6 +356,11 @@ class _LinearBase(nn.Linear):
                     with torch.no_grad():
                         return self._forward_int8(x, plan)
             x = x.dense()
+        from ...sharded import ShardedTiledBf16
+        if isinstance(x, ShardedTiledBf16):
+            if x.pre_applied is not None:
+                raise RuntimeError(f"mi355q: a quantised gather that applied {x.pre_applied!r} reached forward(); call forward_after")
+            return self._forward_quantised_gather(x)
         if self.bypass:
             return F.linear(x, self.weight, self.bias)
         if self.is_ptq:
@@ -402,6 +407,28 @@ class _LinearBase(nn.Linear):
             return False
         return (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32 and xq.ndim >= 2
                 and self.in_features % 32 == 0 and not self.weight_requires_quantisation)
+
+    @torch.no_grad()
+    def _forward_quantised_gather(self, x):
+        """x: sharded.ShardedTiledBf16 -- this layer's operand as the ranks quantised and gathered it (one tiled bf16 segment
+        per rank): the bf16 flavour of the tile GEMM with x in column segments against the tiled quantised weights"""
+        c = self.config
+        if (self.arith != "block_fp" or self.bypass or not self.is_ptq
+                or x.quantiser != (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"]) or x.features != self.in_features):
+            raise RuntimeError("mi355q: this quantised gather was prepared for another layer / quantiser")
+        if self.weight_requires_quantisation:
+            self._quantise_weights_once(pack=False)          # (linear.py:66-70: weights and bias quantised in place; no int8 operand needed)
+        if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:
+            if getattr(self, "_fp32_released", False):
+                raise RuntimeError("mi355q: the fp32 weights were released; this layer cannot take the bf16 route any more")
+            self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+        M = 1
+        for d in x.lead:
+            M *= int(d)
+        P = x.buf.shape[0]
+        y = ops.bf16_gemm_tiled(x.buf if P > 1 else x.buf[0], self._w_bf16[0], M, self.out_features, self.in_features, self.bias,
+                                segments=P)
+        return y.reshape(*x.lead, self.out_features)
 
     def _padded_block_fp_ok(self, x) -> bool:
         """block_fp layers whose in_features is a multiple of the block (16) but not of the tile kernels' K-step (64): the
@@ -457,7 +484,11 @@ class _LinearBase(nn.Linear):
         group flavour) the step runs as torch ops in front of forward()."""
         if op not in ("relu", "silu_mul") or (op == "silu_mul") != (other is not None):
             raise ValueError("forward_after: op is 'relu' (no other) or 'silu_mul' (with other)")
-        from ...sharded import ShardedRows
+        from ...sharded import ShardedRows, ShardedTiledBf16
+        if isinstance(x, ShardedTiledBf16):
+            if x.pre_applied != op:
+                raise RuntimeError(f"mi355q: a quantised gather that applied {x.pre_applied!r} reached forward_after({op!r})")
+            return self._forward_quantised_gather(x)
         if isinstance(x, ShardedRows):
             # fc1's gathered output in the collective's rank-major layout (sharded.shard_model(gather="segments")): the
             # row-aligned route reads the P segments in place with the relu in front; anything else re-assembles it

@@ -48,6 +48,32 @@ class ShardedRows:
         return self.buf.permute(1, 0, 2).reshape(*self.lead, p * seg)
 
 
+class ShardedTiledBf16:
+    """The gathered output of a RowShardedLinear in gather = "quantised" mode: `buf` [P, bytes], rank-major -- segment r is rank
+    r's output slice [M, O/P], already passed through the CONSUMER's elementwise step (`pre_applied`: None or "relu") and its
+    block_fp activation quantiser into the tiled bf16 operand of the tile GEMM (ops.block_fp_quantize_bf16_tiled: [1,16] blocks
+    never straddle a slice, so every rank's blocks are the unsharded layer's).  2 bytes per value cross the links instead of
+    4, and each rank quantises 1 / P of the tensor instead of all of it.  Only the consumer it was quantised for can read it
+    (`quantiser` = its (width, exponent_width, exponent_bias)): Linear.forward / forward_after on the bf16 flavour of the tile
+    GEMM with x in column segments (C ABI mi355q_bf16_gemm_tiled_seg)."""
+
+    def __init__(self, buf: torch.Tensor, lead: tuple, features: int, quantiser: tuple, pre_applied):
+        assert buf.ndim == 2 and buf.is_contiguous()
+        self.buf, self.lead, self.features, self.quantiser, self.pre_applied = buf, tuple(lead), int(features), tuple(quantiser), pre_applied
+
+    @property
+    def shape(self):
+        return torch.Size((*self.lead, self.features))
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def dense(self):
+        raise RuntimeError("mi355q.sharded: a quantised gather holds the consumer's operand, not the fp32 tensor -- shard the "
+                           "producer with gather='dense' where something else reads its output")
+
+
 class RowShardedLinear(nn.Module):
     """Wraps this rank's shard of a (quantised) Linear.  `local` is any module mapping [..., K] -> [..., O/P]."""
 
@@ -57,8 +83,12 @@ class RowShardedLinear(nn.Module):
         self.out_features = out_features
         self.group = group
         self.always_gather = always_gather      # run the collective at world size 1 too (tests / bench on a 1-GPU box)
-        assert gather in ("dense", "segments")
+        assert gather in ("dense", "segments", "quantised")
         self.gather = gather                    # "segments": return the ShardedRows, no permute copy
+        # "quantised": the consumer's quantiser parameters and elementwise step (set by shard_model / the caller):
+        # (width, exponent_width, exponent_bias) of its data_in, and None or "relu"
+        self.consumer_quantiser = None
+        self.consumer_pre = None
 
     @classmethod
     def from_full(cls, cls_quantized, linear_fp32: nn.Linear, config: dict, group=None, always_gather: bool = False,
@@ -82,6 +112,8 @@ class RowShardedLinear(nn.Module):
     def gather_output(self, y_loc: torch.Tensor):
         """this rank's [.., O/P] -> the layer's [.., O] (or its ShardedRows): the ONE collective of the layer"""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if self.gather == "quantised":
+            return self._gather_quantised(y_loc, world)
         if world == 1 and not (self.always_gather and dist.is_initialized()):
             return ShardedRows(y_loc.detach().reshape(1, -1, y_loc.shape[-1]).contiguous(), y_loc.shape[:-1]) \
                 if self.gather == "segments" else y_loc
@@ -94,6 +126,28 @@ class RowShardedLinear(nn.Module):
         if self.gather == "segments":
             return ShardedRows(gathered.view(world, y2.shape[0], y2.shape[1]), lead)
         return gathered.view(world, y2.shape[0], y2.shape[1]).permute(1, 0, 2).reshape(*lead, self.out_features)
+
+    def _gather_quantised(self, y_loc: torch.Tensor, world: int):
+        """this rank's [.., O/P] -> relu (if the consumer applies one) -> the consumer's block_fp quantiser -> tiled bf16 ->
+        ONE all-gather of 2 bytes per value (the collective of the layer)"""
+        from . import ops
+        if self.consumer_quantiser is None:
+            raise RuntimeError("RowShardedLinear(gather='quantised'): consumer_quantiser is not set (shard_model wires it)")
+        if y_loc.shape[-1] % 32:
+            raise ValueError("gather='quantised': the shard's out_features must be a multiple of 32 (whole K-steps of the consumer)")
+        lead = y_loc.shape[:-1]
+        y2 = y_loc.detach().reshape(-1, y_loc.shape[-1]).contiguous()
+        w, ew, eb = self.consumer_quantiser
+        mine = ops.block_fp_quantize_bf16_tiled(y2, w, ew, eb, reuse=True,
+                                                pre=None if self.consumer_pre is None else (self.consumer_pre, None)).reshape(-1)
+        if world == 1 and not (self.always_gather and dist.is_initialized()):
+            buf = mine.reshape(1, -1)
+        else:
+            buf = torch.empty(world, mine.numel(), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(buf.view(-1), mine, group=self.group)
+            COLLECTIVES["all_gather"] += 1
+            COLLECTIVES["bytes"] += buf.numel() * buf.element_size()
+        return ShardedTiledBf16(buf, lead, self.out_features, self.consumer_quantiser, self.consumer_pre)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.gather_output(self.local(x))
@@ -124,6 +178,16 @@ SHARDED_PROJECTIONS = {
 }
 
 
+def _quantised_gather_fits(consumer, features: int, group) -> bool:
+    """fc2 can read a quantised gather: block_fp with [1,16] blocks along in_features, width <= 9 (exact in bf16), and whole
+    64-byte K-steps per rank's slice"""
+    c = consumer.local.config if isinstance(consumer, RowShardedLinear) else consumer.config
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    bs = c.get("data_in_block_size")
+    return (c.get("name") == "block_fp" and not c.get("bypass", False) and c.get("is_ptq", False) and 2 <= c["data_in_width"] <= 9
+            and list(bs)[-1] == 16 and all(b == 1 for b in list(bs)[:-1]) and features % (32 * world) == 0)
+
+
 def shard_model(model: nn.Module, group=None, always_gather: bool = False, gather: str = "dense") -> nn.Module:
     """Row-shard every quantised Linear of a harness model (mi355q.harness.TinyOPTForCausalLM / TinyLlamaForCausalLM) in place:
     rank r keeps rows [r O/P, (r + 1) O/P) of each projection's weight and bias -- never cutting a [1,16] weight block or a
@@ -132,7 +196,10 @@ def shard_model(model: nn.Module, group=None, always_gather: bool = False, gathe
     The reference runs models of this size by LAYER placement instead (cli/eval_perplexity.py:66-75: accelerate's
     infer_auto_device_map over decoder layers); this is the row partition BASELINE.json's north_star asks for.
     `gather`: "dense" -- every projection hands on [.., O]; "segments" -- fc1 (OPT) hands its rank-major ShardedRows to fc2's
-    quantiser as it lies (no permute copy), everything else dense (the attention core and the gated product need [.., O])."""
+    quantiser as it lies (no permute copy), everything else dense (the attention core and the gated product need [.., O]);
+    "quantised" -- fc1 (OPT) applies fc2's relu and fc2's activation quantiser to ITS OWN slice and gathers the tiled bf16
+    operand (2 bytes per value instead of 4, 1 / P of the quantiser's work per rank); fc2 then multiplies on the bf16 flavour
+    of the tile GEMM with x in column segments (results as the per-block route's: exact products, fp32 accumulation)."""
     from .quantize.quantized_modules.linear import _LinearBase
     family = "llama" if hasattr(model.layers[0], "gate_proj") else "opt"
     for layer in model.layers:
@@ -149,7 +216,14 @@ def shard_model(model: nn.Module, group=None, always_gather: bool = False, gathe
                 shim = nn.Linear(lin.in_features, lin.out_features, bias=lin.bias is not None, device="meta")
                 shim.weight, shim.bias = lin.weight, lin.bias               # (the full-precision parameters, no copy)
                 seg = gather == "segments" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
-                setattr(owner, name, RowShardedLinear.from_full(type(lin), shim, lin.config, group, always_gather,
-                                                                "segments" if seg else "dense"))
+                qnt = (gather == "quantised" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
+                       and _quantised_gather_fits(getattr(owner, "fc2"), lin.out_features, group))
+                wrapped = RowShardedLinear.from_full(type(lin), shim, lin.config, group, always_gather,
+                                                     "segments" if seg else ("quantised" if qnt else "dense"))
+                if qnt:
+                    c2 = owner.fc2.local.config if isinstance(owner.fc2, RowShardedLinear) else owner.fc2.config
+                    wrapped.consumer_quantiser = (c2["data_in_width"], c2["data_in_exponent_width"], c2["data_in_exponent_bias"])
+                    wrapped.consumer_pre = "relu"
+                setattr(owner, name, wrapped)
     model.mi355q_sharded = True
     return model

@@ -190,3 +190,106 @@ def test_row_sharded_model_nccl(world):
             assert same and loss_same, f"rank {rank} {family} knobs={knobs} gather={gather}: sharded model differs from the unsharded one"
             assert coll, f"rank {rank} {family}: unexpected number of all-gathers"
             assert packed, "the shards did not take the int8 path"
+
+
+def _quantised_gather_worker(rank, world, port, q):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import mi355q.quantize as Q
+        from mi355q import harness, sharded
+        from mi355q.sharded import RowShardedLinear, ShardedTiledBf16
+        from oracle import np_oracle as O
+        res = {}
+        # layer level: fc1 (sharded, gather="quantised": relu + fc2's quantiser on the rank's own slice, 2 bytes per value
+        # gathered) -> fc2 on the gathered operand, against the oracle's exact contraction of relu(fc1(x)) and against the
+        # unsharded pair
+        cfg1, cfg2 = _cfg(4), dict(_cfg(4), data_in_width=5, weight_width=6)
+        torch.manual_seed(3)
+        K, F_, N, M = 512, 2048, 512, 200
+        l1, l2 = torch.nn.Linear(K, F_), torch.nn.Linear(F_, N)
+        x = (torch.randn(2, M // 2, K) * torch.exp(torch.randn(2, M // 2, 1))).to(dev)
+        cls = Q.get_quantized_cls("linear", cfg1)
+        fc1 = RowShardedLinear.from_full(cls, l1.to(dev), cfg1, always_gather=True, gather="quantised")
+        fc1.consumer_quantiser, fc1.consumer_pre = (cfg2["data_in_width"], cfg2["data_in_exponent_width"], cfg2["data_in_exponent_bias"]), "relu"
+        fc2 = cls.from_float(l2, cfg2).to(dev)
+        sharded.COLLECTIVES.update(all_gather=0, bytes=0)
+        with torch.no_grad():
+            g = fc1(x)
+            y = fc2.forward_after(g, "relu")
+            y = fc2.forward_after(fc1(x), "relu")
+        res["gathered"] = isinstance(g, ShardedTiledBf16) and tuple(g.buf.shape)[0] == world and sharded.COLLECTIVES["all_gather"] == 2
+        res["bytes_per_value"] = sharded.COLLECTIVES["bytes"] / 2 / (M * F_)          # 2 (+ row padding of the tiles)
+        w1, w2 = cls.from_float(l1, cfg1).to(dev), cls.from_float(l2, cfg2).to(dev)
+        with torch.no_grad():
+            h = w1(x)
+            y_ref = w2(torch.relu(h))
+        href = O.bfp_linear_int(x.reshape(-1, K).cpu().numpy(), l1.weight.detach().cpu().numpy(), l1.bias.detach().cpu().numpy(), cfg1)
+        res["fc1_exact"] = bool(np.abs(h.reshape(-1, F_).cpu().numpy() - href).max() <= 1e-5 * np.abs(href).max())
+        yo = O.bfp_linear_int(np.maximum(h.reshape(-1, F_).cpu().numpy(), 0), l2.weight.detach().cpu().numpy(), l2.bias.detach().cpu().numpy(), cfg2)
+        res["err_vs_oracle"] = float(np.abs(y.reshape(-1, N).cpu().numpy() - yo).max() / np.abs(yo).max())
+        res["err_vs_unsharded"] = float((y - y_ref).abs().max() / y_ref.abs().max())
+        try:
+            g.dense()
+            res["dense_raises"] = False
+        except RuntimeError:
+            res["dense_raises"] = True
+        # model level: OPT harness, W4A4 mixed, every knob on; fc1 -> fc2 through the quantised gather
+        def build():
+            torch.manual_seed(11)
+            c = harness.TinyOPTConfig(vocab_size=512, hidden_size=512, ffn_dim=2048, num_layers=2, num_heads=8, max_positions=256)
+            m = harness.TinyOPTForCausalLM(c, harness.expand_quant_config(_model_cfg(4, True, True), 2))
+            return m.to(dev).eval()
+        ids = torch.randint(0, 512, (1, 256), generator=torch.Generator().manual_seed(5)).to(dev)
+        with torch.no_grad():
+            whole = build()
+            for _ in range(2):
+                ref, ref_loss = whole(ids, labels=ids)
+            model = sharded.shard_model(build(), always_gather=True, gather="quantised")
+            for _ in range(2):
+                sharded.COLLECTIVES.update(all_gather=0, bytes=0)
+                got, loss = model(ids, labels=ids)
+        res["model_modes"] = [model.layers[i].fc1.gather for i in range(2)]
+        res["model_collectives"] = sharded.COLLECTIVES["all_gather"]
+        res["model_logits_err"] = float((got - ref).abs().max() / ref.abs().max())
+        res["model_loss_err"] = abs(float(loss) - float(ref_loss))
+        q.put((rank, res))
+    except Exception as e:
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(e))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_quantised_gather_nccl(world):
+    """gather = "quantised": a rank applies the consumer's relu and activation quantiser to its OWN output slice and the ranks
+    all-gather the tiled bf16 operand (2 bytes per value instead of 4; 1 / P of the quantiser's work each); the consumer's product
+    runs on the bf16 tile GEMM with x in column segments.  Layer pair against the oracle's exact contraction; a sharded OPT
+    harness model against the unsharded one (another route for fc2: equal up to fp32 summation order, then W4 re-rounding)"""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_quantised_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert not isinstance(res, str), res
+        assert res["gathered"] and res["dense_raises"] and res["fc1_exact"], res
+        assert 2.0 <= res["bytes_per_value"] <= 2.7, res
+        assert res["err_vs_oracle"] <= 4e-6 and res["err_vs_unsharded"] <= 4e-6, res
+        assert res["model_modes"] == ["quantised", "quantised"] and res["model_collectives"] == 12, res
+        assert res["model_logits_err"] <= 5e-2 and res["model_loss_err"] <= 5e-3, res

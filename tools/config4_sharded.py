@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--heads", type=int, default=32)
     ap.add_argument("--vocab", type=int, default=50272)
     ap.add_argument("--no-knobs", action="store_true", help="the reference's step-by-step attention / separate launches")
-    ap.add_argument("--gather", default="dense", choices=["dense", "segments"])
+    ap.add_argument("--gather", default="dense", choices=["dense", "segments", "quantised"])
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     force = world == 1 and os.environ.get("MI355Q_FORCE_DIST") == "1"
