@@ -482,9 +482,9 @@ class _LinearBase(nn.Linear):
         (three passes over the [tokens, ffn] tensor instead of one).  Same arithmetic, rounded to fp32 operation by
         operation; whenever the fused quantisers do not apply (first PTQ forward, QAT, bypass, other arithmetics, the
         group flavour) the step runs as torch ops in front of forward()."""
-        if op not in ("relu", "silu_mul") or (op == "silu_mul") != (other is not None):
-            raise ValueError("forward_after: op is 'relu' (no other) or 'silu_mul' (with other)")
         from ...sharded import ShardedRows, ShardedTiledBf16
+        if op not in ("relu", "silu_mul") or ((op == "silu_mul") != (other is not None) and not isinstance(x, ShardedTiledBf16)):
+            raise ValueError("forward_after: op is 'relu' (no other) or 'silu_mul' (with other)")
         if isinstance(x, ShardedTiledBf16):
             if x.pre_applied != op:
                 raise RuntimeError(f"mi355q: a quantised gather that applied {x.pre_applied!r} reached forward_after({op!r})")
@@ -604,6 +604,11 @@ def grouped_linear(x, layers, norm=None):
     if all(isinstance(l, RowShardedLinear) for l in layers):
         # row-sharded projections (sharded.shard_model): this rank's shards as one group, one all-gather per projection
         ys = grouped_linear(x, [l.local for l in layers], norm=norm)
+        if len(layers) == 2 and layers[0].gather == "quantised" and layers[0].consumer_pre == "silu_mul":
+            # Llama's gate / up in front of down_proj (sharded.shard_model(gather="quantised")): both shards of a rank cover the
+            # same columns, so silu(gate) * up and down_proj's quantiser run on the rank's own slice; ONE all-gather, of the
+            # tiled bf16 operand.  The second result is None: down_proj.forward_after(gate, "silu_mul", None) reads the first
+            return [layers[0].gather_output(ys[0], other=ys[1]), None]
         return [l.gather_output(y) for l, y in zip(layers, ys)]
     first = layers[0]
 

@@ -109,11 +109,12 @@ class RowShardedLinear(nn.Module):
         local = cls_quantized.from_float(part, config).to(linear_fp32.weight.device)
         return cls(local, linear_fp32.out_features, group, always_gather, gather)
 
-    def gather_output(self, y_loc: torch.Tensor):
-        """this rank's [.., O/P] -> the layer's [.., O] (or its ShardedRows): the ONE collective of the layer"""
+    def gather_output(self, y_loc: torch.Tensor, other: torch.Tensor = None):
+        """this rank's [.., O/P] -> the layer's [.., O] (or its ShardedRows): the ONE collective of the layer.  `other`:
+        (quantised mode, consumer_pre = "silu_mul") the partner projection's local output, same columns"""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if self.gather == "quantised":
-            return self._gather_quantised(y_loc, world)
+            return self._gather_quantised(y_loc, world, other)
         if world == 1 and not (self.always_gather and dist.is_initialized()):
             return ShardedRows(y_loc.detach().reshape(1, -1, y_loc.shape[-1]).contiguous(), y_loc.shape[:-1]) \
                 if self.gather == "segments" else y_loc
@@ -127,9 +128,9 @@ class RowShardedLinear(nn.Module):
             return ShardedRows(gathered.view(world, y2.shape[0], y2.shape[1]), lead)
         return gathered.view(world, y2.shape[0], y2.shape[1]).permute(1, 0, 2).reshape(*lead, self.out_features)
 
-    def _gather_quantised(self, y_loc: torch.Tensor, world: int):
-        """this rank's [.., O/P] -> relu (if the consumer applies one) -> the consumer's block_fp quantiser -> tiled bf16 ->
-        ONE all-gather of 2 bytes per value (the collective of the layer)"""
+    def _gather_quantised(self, y_loc: torch.Tensor, world: int, other: torch.Tensor = None):
+        """this rank's [.., O/P] -> the consumer's elementwise step (relu; silu(.) * other) -> its block_fp quantiser -> tiled
+        bf16 -> ONE all-gather of 2 bytes per value (the collective of the layer)"""
         from . import ops
         if self.consumer_quantiser is None:
             raise RuntimeError("RowShardedLinear(gather='quantised'): consumer_quantiser is not set (shard_model wires it)")
@@ -138,8 +139,11 @@ class RowShardedLinear(nn.Module):
         lead = y_loc.shape[:-1]
         y2 = y_loc.detach().reshape(-1, y_loc.shape[-1]).contiguous()
         w, ew, eb = self.consumer_quantiser
+        if (self.consumer_pre == "silu_mul") != (other is not None):
+            raise RuntimeError("gather='quantised': consumer_pre 'silu_mul' needs the partner projection's local output (grouped_linear)")
+        o2 = None if other is None else other.detach().reshape(-1, other.shape[-1]).contiguous()
         mine = ops.block_fp_quantize_bf16_tiled(y2, w, ew, eb, reuse=True,
-                                                pre=None if self.consumer_pre is None else (self.consumer_pre, None)).reshape(-1)
+                                                pre=None if self.consumer_pre is None else (self.consumer_pre, o2)).reshape(-1)
         if world == 1 and not (self.always_gather and dist.is_initialized()):
             buf = mine.reshape(1, -1)
         else:
@@ -199,7 +203,8 @@ def shard_model(model: nn.Module, group=None, always_gather: bool = False, gathe
     quantiser as it lies (no permute copy), everything else dense (the attention core and the gated product need [.., O]);
     "quantised" -- fc1 (OPT) applies fc2's relu and fc2's activation quantiser to ITS OWN slice and gathers the tiled bf16
     operand (2 bytes per value instead of 4, 1 / P of the quantiser's work per rank); fc2 then multiplies on the bf16 flavour
-    of the tile GEMM with x in column segments (results as the per-block route's: exact products, fp32 accumulation)."""
+    of the tile GEMM with x in column segments (results as the per-block route's: exact products, fp32 accumulation).  Llama:
+    gate / up (grouped) -> silu(gate) * up and down_proj's quantiser on the rank's slice, ONE gather for the pair."""
     from .quantize.quantized_modules.linear import _LinearBase
     family = "llama" if hasattr(model.layers[0], "gate_proj") else "opt"
     for layer in model.layers:
@@ -218,12 +223,18 @@ def shard_model(model: nn.Module, group=None, always_gather: bool = False, gathe
                 seg = gather == "segments" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
                 qnt = (gather == "quantised" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
                        and _quantised_gather_fits(getattr(owner, "fc2"), lin.out_features, group))
+                # Llama: gate / up -> silu(gate) * up -> down_proj (needs the grouped launch: the pair is gathered as one)
+                gated = (gather == "quantised" and name in ("gate_proj", "up_proj") and lin.config.get("mi355q_fused_activation", False)
+                         and lin.config.get("mi355q_grouped_linear", False)
+                         and _quantised_gather_fits(getattr(owner, "down_proj"), lin.out_features, group))
+                qnt = qnt or gated
                 wrapped = RowShardedLinear.from_full(type(lin), shim, lin.config, group, always_gather,
                                                      "segments" if seg else ("quantised" if qnt else "dense"))
                 if qnt:
-                    c2 = owner.fc2.local.config if isinstance(owner.fc2, RowShardedLinear) else owner.fc2.config
+                    nxt = owner.down_proj if gated else owner.fc2
+                    c2 = nxt.local.config if isinstance(nxt, RowShardedLinear) else nxt.config
                     wrapped.consumer_quantiser = (c2["data_in_width"], c2["data_in_exponent_width"], c2["data_in_exponent_bias"])
-                    wrapped.consumer_pre = "relu"
+                    wrapped.consumer_pre = "silu_mul" if gated else "relu"
                 setattr(owner, name, wrapped)
     model.mi355q_sharded = True
     return model

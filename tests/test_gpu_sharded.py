@@ -258,6 +258,26 @@ def _quantised_gather_worker(rank, world, port, q):
         res["model_collectives"] = sharded.COLLECTIVES["all_gather"]
         res["model_logits_err"] = float((got - ref).abs().max() / ref.abs().max())
         res["model_loss_err"] = abs(float(loss) - float(ref_loss))
+        # Llama: gate / up (one grouped launch) -> silu(gate) * up -> down_proj's quantiser, all on the rank's own slice
+        def build_llama():
+            torch.manual_seed(12)
+            lc = _model_cfg(6, False, True)
+            lc["default"]["mi355q_fused_norm"] = False
+            lc["rotary_positional_encoding"] = dict(name="integer", bypass=False, data_in_width=8, data_in_frac_width=7)
+            c = harness.TinyLlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1536, num_layers=2, num_heads=8, max_positions=256)
+            return harness.TinyLlamaForCausalLM(c, harness.expand_llama_quant_config(lc, 2)).to(dev).eval()
+        with torch.no_grad():
+            whole = build_llama()
+            for _ in range(2):
+                ref, ref_loss = whole(ids, labels=ids)
+            model = sharded.shard_model(build_llama(), always_gather=True, gather="quantised")
+            for _ in range(2):
+                sharded.COLLECTIVES.update(all_gather=0, bytes=0)
+                got, loss = model(ids, labels=ids)
+        res["llama_modes"] = [model.layers[i].gate_proj.gather for i in range(2)] + [model.layers[i].down_proj.gather for i in range(2)]
+        res["llama_collectives"] = sharded.COLLECTIVES["all_gather"]          # q, k, v, o, (gate + up as one), down per layer
+        res["llama_logits_err"] = float((got - ref).abs().max() / ref.abs().max())
+        res["llama_loss_err"] = abs(float(loss) - float(ref_loss))
         q.put((rank, res))
     except Exception as e:
         import traceback
@@ -293,3 +313,5 @@ def test_quantised_gather_nccl(world):
         assert res["err_vs_oracle"] <= 4e-6 and res["err_vs_unsharded"] <= 4e-6, res
         assert res["model_modes"] == ["quantised", "quantised"] and res["model_collectives"] == 12, res
         assert res["model_logits_err"] <= 5e-2 and res["model_loss_err"] <= 5e-3, res
+        assert res["llama_modes"] == ["quantised", "quantised", "dense", "dense"] and res["llama_collectives"] == 12, res
+        assert res["llama_logits_err"] <= 5e-2 and res["llama_loss_err"] <= 5e-3, res
