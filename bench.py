@@ -422,6 +422,32 @@ def main():
                     "ms_per_step": round(dt_r / args.steps * 1e3, 4),
                     "what": "each rank its own 4096 rows against replicated packed weights, no collective"}
 
+    qgather = None
+    if sharded and N % (32 * world) == 0 and N == K:
+        # the same layer as one link of a CHAIN of sharded layers under gather = "quantised" (sharded.py): the x operand
+        # arrives as the previous layer's gathered tiled-bf16 segments; this rank multiplies on the bf16 tile GEMM, quantises its
+        # own output slice with the next layer's quantiser and the ranks all-gather THAT (2 bytes per value).  Reported beside the
+        # headline step, never instead of it; any failure is reported, not raised.
+        try:
+            xq, wq, _ = make_inputs(torch, device, 0)
+            n_loc = N // world
+            wt_q = ops.block_fp_quantize_bf16_tiled((wq[rank * n_loc:(rank + 1) * n_loc] * 0.5).contiguous(), ww, 8, 127, reuse=False)
+            segs = torch.stack([ops.block_fp_quantize_bf16_tiled(xq[:, r * n_loc:(r + 1) * n_loc].contiguous(), xw, 8, 127, reuse=False).reshape(-1)
+                                for r in range(world)]).contiguous()
+            y_q = torch.empty(M, n_loc, dtype=torch.float32, device=device)
+
+            def step_q():
+                ops.bf16_gemm_tiled(segs if world > 1 else segs[0], wt_q, M, n_loc, K, None, out=y_q, segments=world)
+                mine = ops.block_fp_quantize_bf16_tiled(y_q, xw, 8, 127).reshape(-1)
+                dist.all_gather_into_tensor(segs.view(-1), mine)          # (the next link's operand: the chain feeds itself)
+            dt_q = timed(torch, dist, world, device, step_q, args.steps, args.warmup)
+            qgather = {"value": round(2.0 * M * N * K * args.steps / dt_q / 1e12, 2), "unit": "TFLOP/s", "scaling": "strong",
+                       "ms_per_step": round(dt_q / args.steps * 1e3, 4), "gathered_MiB_per_rank": round(segs.numel() * (world - 1) / world / 2**20, 1),
+                       "what": "one link of a chain of row-sharded layers with the NEXT layer's quantised operand gathered (tiled bf16, 2 bytes "
+                               "per value; bf16 tile GEMM with x in column segments + quantiser on the rank's own slice + all-gather)"}
+        except Exception as e:                                       # noqa: BLE001
+            qgather = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     failed = False
     if rank == 0:
         achieved = flops_kernel / (gemm_avg_ms * 1e-3) / 1e12
@@ -467,6 +493,8 @@ def main():
                               "ms_per_step": round(no_ramp[0] / args.steps * 1e3, 4),
                               "step_frac": round(jobf * args.steps / no_ramp[0] / 1e12 / world / INT8_DENSE_PEAK_TFLOPS, 4),
                               "what": f"{args.warmup} warm-up + {args.steps} timed steps straight from an idle GPU, before the clock ramp"}
+        if qgather:
+            out["quantised_gather"] = qgather
         if replicas:
             out["replicas"] = replicas
         if rows_mode:
