@@ -7,6 +7,9 @@ block and every shard's exponents / mantissas are bit-identical to the unsharded
 rank quantises it (O(M K), redundant) and computes y[:, shard] with the int8-MFMA path; ONE collective --
 all-gather of the fp32 output shards (torch.distributed backend "nccl" = RCCL over xGMI on ROCm; "gloo"
 in the CPU tests) -- rebuilds y.  Message size: M x O/P fp32 per rank (4096 x 512 x 4 B = 8 MiB at P = 8).
+gather = "quantised" (round 4): where the output only feeds another mi355q Linear through an elementwise step, the rank runs
+that step and the CONSUMER's activation quantiser on its own slice and the collective moves the tiled bf16 operand instead
+(2 bytes per value; ShardedTiledBf16 below, C ABI mi355q_bf16_gemm_tiled_seg on the consumer's side).
 """
 from __future__ import annotations
 
