@@ -103,5 +103,11 @@ int choose_splits(long long tiles, int nsteps_all, bool need_even, int min_steps
 int launch_bfp_gemm_v9(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                        const uint8_t* xf, const uint8_t* wf, bool bf16);
 
+// the small tiles (mi355q_gemm_v10.hip; geometry 1: 128 x 256, 2: 256 x 128, 3: 128 x 128): K % 64 == 0, a.splits / a.slabs /
+// a.tickets set by the caller (slabs of one tile's fp32 / int32 accumulators)
+int launch_bfp_gemm_v10(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
+                        const uint8_t* xf, const uint8_t* wf, bool bf16, int geom);
+void v10_tile_shape(int geom, int& bm, int& bn);
+
 }  // namespace mi355q
 #endif

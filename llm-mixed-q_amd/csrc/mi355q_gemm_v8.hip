@@ -741,9 +741,56 @@ int choose_splits(long long tiles, int nsteps_all, bool need_even, int min_steps
     return best;
 }
 
+// the small tiles of mi355q_gemm_v10.hip under a forced geometry (MI355Q_V10 = 1 | 2 | 3; sweeps and tests) -- split-K as the
+// environment pins it (MI355Q_V8_SPLITS) or none
+static int v10_forced_launch(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
+                             const uint8_t* xf, const uint8_t* wf, bool bf16, int geom) {
+    GemmArgs a = a_in;
+    int bm, bn;
+    v10_tile_shape(geom, bm, bn);
+    const long long tiles = ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (a.ngroup > 1 ? a.ngroup : 1);
+    const int forced = getenv("MI355Q_V8_SPLITS") ? atoi(getenv("MI355Q_V8_SPLITS")) : 0;
+    const int nsteps_all = (int)(a.K >> 6);
+    int S = forced > 1 ? forced : 1;
+    while (S > 1 && (nsteps_all % S || nsteps_all / S < 2)) --S;
+    a.splits = 1;
+    if (S > 1) {
+        SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * bm * bn * 4, (int)tiles);
+        if (w) {
+            a.splits = S;
+            a.slabs = w->slabs;
+            a.tickets = w->tickets;
+        }
+    }
+    a.corr = nullptr;
+    return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, bf16, geom);
+}
+static int v10_forced() {                       // (read per launch: the tests pin one geometry after the other in one process)
+    const char* e = getenv("MI355Q_V10");
+    const int g = e ? atoi(e) : 0;
+    return g >= 1 && g <= 3 ? g : 0;
+}
+
 int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
     (void)list_cap;
+    if (v10_forced() && a_in.K % 64 == 0 && (!(xlist && wlist) || (xf && wf))) return v10_forced_launch(a_in, sx, sw, xlist, wlist, st, xf, wf, false, v10_forced());
+    // Round 5: grids of at most 128 tiles of 256 x 256 -- half the compute units or fewer -- take 128 x 128 tiles, two
+    // four-wave workgroups a compute unit, unsplit (mi355q_gemm_v10.hip; profiles/r05_small_tiles.txt: 4096 x 512 x 4096 36.7 ->
+    // 27.7 us, Llama-7B v_proj 47.1 -> 41.7, 2048^3 23.6 -> 19.0).  MI355Q_V10_AUTO=0 keeps the round-4 choice for A/B runs; a
+    // pinned tile height (MI355Q_V8_TILE_ROWS, tests of the other kernels) does too.
+    {
+        static const int v10_auto = getenv("MI355Q_V10_AUTO") ? atoi(getenv("MI355Q_V10_AUTO")) : 1;
+        const long long t256 = ((a_in.M + 255) / 256) * ((a_in.N + 255) / 256) * (a_in.ngroup > 1 ? a_in.ngroup : 1);
+        const char* pinned = getenv("MI355Q_V8_TILE_ROWS");
+        if (v10_auto && t256 <= 128 && a_in.K % 64 == 0 && !(pinned && atoi(pinned)) && !getenv("MI355Q_V8_SPLITS") && (!(xlist && wlist) || (xf && wf)) &&
+            !getenv("MI355Q_V8_CLOCK") && !getenv("MI355Q_V8_STAMPS")) {
+            GemmArgs a = a_in;
+            a.splits = 1;
+            a.corr = nullptr;
+            return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, false, 3);
+        }
+    }
     GemmArgs a = a_in;
     const int ngroup = a.ngroup > 1 ? a.ngroup : 1;            // grouped launch: that many weight operands' column tiles
     // 256 x 256 tiles unless they would leave too many of the 256 compute units idle: a 128 x 256 tile does half the
@@ -808,7 +855,10 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     if (!corr_ok) a.corr = nullptr;
     // (grouped launches stay on the kernel below: their outputs are promised bit-identical to the separate calls, which may take
     //  128-row tiles there -- the two kernels add a row's corrections in different fp32 orders)
-    if (use_v9 && (v9_fix || !fix || corr_ok) && (a.ngroup <= 1 || corr_ok) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
+    // (round 5: grouped launches too -- the small-tile kernel their separate launches may take adds a row's corrections in this
+    //  kernel's order, tests/test_gpu_gemm.py::test_small_tiles_equal_the_256_tile_bit_for_bit)
+    static const int v9_groups = getenv("MI355Q_V9_GROUPS") ? atoi(getenv("MI355Q_V9_GROUPS")) : 1;
+    if (use_v9 && (v9_fix || !fix || corr_ok) && (a.ngroup <= 1 || corr_ok || v9_groups) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {
         const bool piped = small_sched == 2 && a.K % 128 == 0 && (((a.K >> 6) / (a.splits > 1 ? a.splits : 1)) & 1) == 0;
@@ -830,6 +880,7 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
 // y = x . w^T (+ bias) on TILED bf16 operands (the same 1-KiB pieces: 16 rows x 32 values): a.xm / a.wm point at the
 // bf16 pieces and a.K is the contraction length IN BYTES (2 K).  K % 32 == 0.
 int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
+    if (v10_forced() && a_in.K % 64 == 0 && a_in.x_segs <= 1) return v10_forced_launch(a_in, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, v10_forced());
     GemmArgs a = a_in;
     const long long tn = (a.N + V8_BN - 1) / V8_BN;
     const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
@@ -853,6 +904,20 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
             const double rounds = (double)((t * sp + 255) / 256);
             const double est = rounds * (nsteps_all / sp) * (kind ? 0.56 : 0.70) + (sp > 1 ? 12.0 + 0.7 * out_mib * sp : 0.0);
             if (est < best_t) { best_t = est; small = kind == 1; S = sp; }
+        }
+    }
+    // Round 5: the small tiles of mi355q_gemm_v10.hip, unsplit, where their estimate is lower -- per K-step and tile 0.19 us
+    // (128 x 128, up to two a compute unit side by side) / 0.39 us (128 x 256, one a compute unit), + 8 us per launch
+    // (profiles/r05_small_tiles.txt: 2048 x 2048 x 8192 81.3 -> 59.0 us, Llama-7B o_proj 74.8 -> 54.6, down_proj 156 -> 142)
+    {
+        static const int v10_auto = getenv("MI355Q_V10_AUTO") ? atoi(getenv("MI355Q_V10_AUTO")) : 1;
+        if (v10_auto && !force && !getenv("MI355Q_V8_SPLITS") && a.x_segs <= 1 && a.K % 64 == 0) {
+            const long long g3 = ((a.M + 127) / 128) * ((a.N + 127) / 128), g1 = ((a.M + 127) / 128) * ((a.N + 255) / 256);
+            const double est3 = nsteps_all * 0.19 * (double)((g3 + 255) / 256) + 8.0, est1 = g1 <= 256 ? nsteps_all * 0.39 + 8.0 : 1e30;
+            if (est3 < best_t || est1 < best_t) {
+                a.splits = 1;
+                return launch_bfp_gemm_v10(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, est1 < est3 ? 1 : 3);
+            }
         }
     }
     unsigned tiles = (unsigned)(small ? t128 : t256);

@@ -596,3 +596,102 @@ def test_bf16_tile_gemm_with_x_in_column_segments(M, K, N, P):
     assert (got - plain).abs().max().item() <= 1e-6 * scale
     if K % 128:                                  # (both calls on the same kernel: the same bits)
         assert torch.equal(got, plain)
+
+
+# ---- round 5: the small tiles (csrc/mi355q_gemm_v10.hip) ----------------------------------------------------------------
+V10_GEOMS = [(1, 0), (1, 6), (2, 0), (3, 0), (3, 4), (3, 8)]          # (geometry, ring stages; 0 = the launcher's depth rule)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 130, 1024), (100, 72, 384), (33, 16, 128), (520, 260, 512), (64, 64, 192),
+                                   (640, 384, 64)])
+@pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
+@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
+@pytest.mark.parametrize("geom,ns", V10_GEOMS)
+@pytest.mark.parametrize("splits", [0, 2])
+def test_small_tile_gemm_vs_oracle(M, N, K, style, wx, ww, geom, ns, splits, monkeypatch):
+    """every geometry / ring depth of the small-tile kernel (128 x 256, 256 x 128, 128 x 128; two or three workgroups a compute
+    unit or one with a deep ring; unsplit and split in two) against the oracle's exact integer contraction: exception
+    add-back from buckets fetched in front of the K loop or behind it, odd numbers of K-steps, ragged edges, overflowing
+    buckets (the blockwise fallback inside the launch)"""
+    from oracle import np_oracle as O
+    if splits and (K // 64) % splits:
+        pytest.skip("K-steps do not split evenly")
+    monkeypatch.setenv("MI355Q_V10", str(geom))
+    if ns:
+        monkeypatch.setenv("MI355Q_V10_NS", str(ns))
+    if splits:
+        monkeypatch.setenv("MI355Q_V8_SPLITS", str(splits))
+    x, w, b = _inputs(M, N, K, 7000 + M + N + K, style)
+    cfg = _cfg(wx, ww)
+    y = _run(x, w, b, cfg, aligned="rows")
+    ref = O.bfp_linear_int(x, w, b, cfg)
+    scale = np.abs(ref).max() + 1e-30
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
+
+
+def _exception_rich_operands(M, N, K, seed=4321):
+    x, w, b = _inputs(M, N, K, seed, "rowscale")
+    x[::12, 256:272] *= 300.0
+    w[::16, 256:272] *= 300.0                   # (the same K position in both lists: exception x exception terms)
+    x[::28, 512:528] *= 1e-3
+    x[::36, 64:80] *= 300.0                     # rows with two or three exception blocks
+    w[5::24, 128:144] *= 200.0
+    return x, w, b
+
+
+def test_small_tiles_equal_the_256_tile_bit_for_bit(monkeypatch):
+    """the small-tile kernel forms and adds a row's / column's corrections in the 256 x 256 kernel's order (one vector per
+    entry, exception x exception terms behind it, rows with several entries folded in ascending block order, row vector then
+    column vectors in the store): every geometry gives the 256 x 256 kernel's bits -- what lets the launcher pick a tile per
+    shape, and a grouped launch differ from its separate launches in tile size, without changing a result"""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    M, N, K = 520, 300, 768
+    x, w, b = _exception_rich_operands(M, N, K)
+    xt = torch.from_numpy(x).to(dev)
+    _, wm, we = ops.block_fp_quantize(torch.from_numpy(w).to(dev), 6, 8, 127, [1, 16], False, want_fake=False, want_packed=True,
+                                      fast_zero_blocks=True)
+    wa = ops.bfp_align_rows(wm, we, 5, 127)
+    bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), 6, 8, 127, [16], False)
+    xa = ops.block_fp_quantize_aligned_rows(xt, 6, 8, 127)
+    assert int(xa.sparse[0]) == 0 and int(wa.sparse[0]) == 0
+    monkeypatch.setenv("MI355Q_V8_TILE_ROWS", "256")            # (a pinned tile height keeps the launch on the 256 x 256 kernel)
+    ref = ops.bfp_gemm_aligned(xa, wa, bq).clone()
+    monkeypatch.delenv("MI355Q_V8_TILE_ROWS")
+    for geom, ns in V10_GEOMS:
+        monkeypatch.setenv("MI355Q_V10", str(geom))
+        monkeypatch.setenv("MI355Q_V10_NS", str(ns)) if ns else monkeypatch.delenv("MI355Q_V10_NS", raising=False)
+        for _ in range(2):
+            xa = ops.block_fp_quantize_aligned_rows(xt, 6, 8, 127)      # (slot order inside the buckets differs run to run)
+            y = ops.bfp_gemm_aligned(xa, wa, bq)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref), (geom, ns, float((y - ref).abs().max()))
+    monkeypatch.delenv("MI355Q_V10")
+    monkeypatch.delenv("MI355Q_V10_NS", raising=False)
+    y = ops.bfp_gemm_aligned(xa, wa, bq)                         # the launcher's own choice for this shape (6 tiles of 256 x 256)
+    assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 130, 1024), (100, 72, 96), (520, 260, 4096), (1024, 768, 3072), (2048, 512, 704)])
+@pytest.mark.parametrize("geom,ns", V10_GEOMS)
+def test_small_tile_bf16_gemm_vs_oracle(M, N, K, geom, ns, monkeypatch):
+    """the bf16 flavour of every small-tile geometry (operands whose blocks keep their own exponents) against the oracle"""
+    import torch
+    from mi355q import ops
+    from oracle import np_oracle as O
+    if (2 * K) % 64:
+        pytest.skip("K bytes not a multiple of the K-step")
+    monkeypatch.setenv("MI355Q_V10", str(geom))
+    if ns:
+        monkeypatch.setenv("MI355Q_V10_NS", str(ns))
+    dev = torch.device("cuda:0")
+    x, w, b = _inputs(M, N, K, 9000 + M + N + K, "outlier")
+    cfg = _cfg(6, 6)
+    xt = ops.block_fp_quantize_bf16_tiled(torch.from_numpy(x).to(dev), 6, 8, 127)
+    wt = ops.block_fp_quantize_bf16_tiled(torch.from_numpy(w).to(dev), 6, 8, 127, reuse=False)
+    bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), 6, 8, 127, [16], False)
+    y = ops.bf16_gemm_tiled(xt, wt, M, N, K, bq).cpu().numpy()
+    ref = O.linear_ptq(x, w, b, cfg)[0]
+    scale = np.abs(ref).max() + 1e-30
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))

@@ -74,3 +74,47 @@ def test_oracle_model_forward_at_real_widths(tag):
     else:
         scale = np.abs(ref_logits).max()
         assert d.mean() < 5e-3 * scale and d.max() < 0.1 * scale and abs(loss - ref_loss) < 5e-3, (d.max(), d.mean(), loss, ref_loss)
+
+
+# ---- trained weights (tools/gen_trained_fixture.py): a 4-layer byte-level LM trained with the reference's own classes ----
+TRAINED = json.loads((GOLDEN / "trained.json").read_text()) if (GOLDEN / "trained.json").exists() else {}
+
+
+def load_trained(tag):
+    """(state dict fp32 from the fp16-rounded fixture weights, chunks [16, 512], meta)"""
+    data = np.load(GOLDEN / "trained.npz")
+    pre = tag + "/w/"
+    sd = {k[len(pre):]: data[k].astype(np.float32) for k in data.files if k.startswith(pre)}
+    return sd, data["input_ids"], TRAINED[tag], data
+
+
+@pytest.mark.parametrize("name", ["w6a6", "w4a4"])
+@pytest.mark.parametrize("tag", sorted(TRAINED))
+def test_oracle_on_trained_weights(tag, name):
+    """the model-level oracle on weights that are NOT noise (train loss 1.4 / 0.7 nats per byte, held-out perplexity 29 / 12
+    against 260 for a random model): the reference's per-chunk losses of the first three 512-token chunks (eval_lm.py:41-63
+    evaluates chunk by chunk).  The bound is the reference's own spread -- the fixture's control: the reference against itself
+    with every Linear output moved by one fp32 ulp moves a chunk loss by 5e-3 ... 5e-2.  Measured over all 16 chunks
+    (float64-accumulating numpy against torch's fp32 CPU GEMM): OPT W4A4 5e-7 (every rounding agrees), OPT W6A6 6e-4, Llama
+    W6A6 1.2e-3, Llama W4A4 6e-3; perplexity +3e-7 / +8e-4 / +2.3e-3 / -6.1e-3.  Trained weights do not make the W6 / W4
+    rounding flips go away: a flipped mantissa moves everything downstream of it."""
+    sd, chunks, m, data = load_trained(tag)
+    ev = m["evals"][name]
+    ref = data[f"{tag}/{name}/chunk_losses"]
+    bound = max(r["max_d_chunk_loss"] for r in ev["control"]["runs"])
+    for c in range(3):
+        ids = chunks[c][None]
+        if m["family"] == "opt":
+            _, loss = NM.opt_forward(sd, ev["parsed_quant_config"], ids, m["num_heads"])
+        else:
+            _, loss = NM.llama_forward(sd, ev["parsed_quant_config"], ids, m["num_heads"], m["rms_eps"])
+        assert abs(loss - ref[c]) <= bound, (c, loss, float(ref[c]), bound)
+        if tag == "opt_trained" and name == "w4a4":
+            assert abs(loss - ref[c]) < 5e-6                     # (the case in which no rounding flips: the arithmetic itself agrees)
+
+
+def test_trained_fixture_is_a_language_model():
+    for tag, m in TRAINED.items():
+        assert m["evals"]["bypass"]["perplexity"] < 40.0, (tag, m["evals"]["bypass"]["perplexity"])      # (a random model: ~260)
+        assert abs(m["evals"]["w6a6"]["perplexity"] / m["evals"]["bypass"]["perplexity"] - 1.0) < 0.01
+        assert m["evals"]["w4a4"]["perplexity"] > m["evals"]["w6a6"]["perplexity"]
