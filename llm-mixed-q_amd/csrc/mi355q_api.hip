@@ -226,6 +226,8 @@ int mi355q_bf16_gemm_tiled_seg(const uint16_t* x_tiled, const uint16_t* w_tiled,
                                int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream) {
     if (x_segments < 1 || (x_segments > 1 && (x_segment_stride_bytes <= 0 || x_segment_stride_bytes % 16))) return MI355Q_E_BADARG;
     if (x_segments > 1 && K > 0 && (K % (32 * (int64_t)x_segments) != 0)) return MI355Q_E_UNSUPPORTED;   // whole 64-byte K-steps per segment
+    // (a stride shorter than one tiled segment would make the kernel read overlapping segments: wrong results with rc 0)
+    if (x_segments > 1 && M > 0 && K > 0 && x_segment_stride_bytes < (int64_t)mi355q_bfp_tiled_bytes(M, 2 * K / x_segments)) return MI355Q_E_BADARG;
     return bf16_gemm_tiled_impl(x_tiled, w_tiled, bias, y, M, N, K, ldy, x_segments, x_segment_stride_bytes, stream);
 }
 

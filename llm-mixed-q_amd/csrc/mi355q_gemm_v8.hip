@@ -934,10 +934,11 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
         }
     }
     static const int small_sched = getenv("MI355Q_V8_SMALL_SCHED") ? atoi(getenv("MI355Q_V8_SMALL_SCHED")) : 2;
+    static const bool use_v9_bf16 = !(getenv("MI355Q_V9") && atoi(getenv("MI355Q_V9")) == 0);        // (read once: ADVICE r4)
     if (small && small_sched == 2 && a.K % 128 == 0 && (((a.K >> 6) / (a.splits > 1 ? a.splits : 1)) & 1) == 0)
         hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else if (small) hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 1, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (a.x_segs <= 1 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !(getenv("MI355Q_V9") && atoi(getenv("MI355Q_V9")) == 0)) return launch_bfp_gemm_v9(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true);
+    else if (a.x_segs <= 1 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && use_v9_bf16) return launch_bfp_gemm_v9(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true);
     else if (a.K % 128 == 0) hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((bfp_gemm_v8<0, 8, 0, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     return (int)hipGetLastError();

@@ -430,6 +430,8 @@ def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, 
     with _on_device(xt.device):
         if segments > 1:
             assert xt.ndim == 2 and xt.shape[0] == segments and xt.is_contiguous()
+            # (each segment is a whole tiled operand of M rows x K / segments values: ADVICE r4)
+            assert xt.shape[1] * xt.element_size() == _lib.load_library().mi355q_bfp_tiled_bytes(M, 2 * K // segments), (xt.shape, M, K, segments)
             rc = _lib.load_library().mi355q_bf16_gemm_tiled_seg(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy, int(segments),
                                                                xt.stride(0) * xt.element_size(), _stream_ptr(xt.device))
         else:

@@ -416,6 +416,9 @@ class _LinearBase(nn.Linear):
         if (self.arith != "block_fp" or self.bypass or not self.is_ptq
                 or x.quantiser != (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"]) or x.features != self.in_features):
             raise RuntimeError("mi355q: this quantised gather was prepared for another layer / quantiser")
+        if not 2 <= c["weight_width"] <= 9:
+            raise RuntimeError(f"mi355q: a quantised gather feeds the bf16 tile GEMM, whose operands hold block_fp values of at most 9 "
+                               f"bits exactly; this layer's weight_width is {c['weight_width']} (shard it with gather='dense')")
         if self.weight_requires_quantisation:
             self._quantise_weights_once(pack=False)          # (linear.py:66-70: weights and bias quantised in place; no int8 operand needed)
         if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:

@@ -186,12 +186,15 @@ SHARDED_PROJECTIONS = {
 
 
 def _quantised_gather_fits(consumer, features: int, group) -> bool:
-    """fc2 can read a quantised gather: block_fp with [1,16] blocks along in_features, width <= 9 (exact in bf16), and whole
-    64-byte K-steps per rank's slice"""
+    """the consumer (fc2 / down_proj) can read a quantised gather: block_fp with [1,16] blocks along in_features, activation AND
+    weight widths <= 9 (both operands go to the bf16 tile GEMM: wider values would be rounded there -- ADVICE r4), whole 64-byte
+    K-steps per rank's slice, and the consumer itself configured for the fused elementwise step (the harness decides from the
+    CONSUMER's config whether it calls forward_after: ADVICE r4)"""
     c = consumer.local.config if isinstance(consumer, RowShardedLinear) else consumer.config
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     bs = c.get("data_in_block_size")
     return (c.get("name") == "block_fp" and not c.get("bypass", False) and c.get("is_ptq", False) and 2 <= c["data_in_width"] <= 9
+            and 2 <= c["weight_width"] <= 9 and c.get("mi355q_fused_activation", False)
             and list(bs)[-1] == 16 and all(b == 1 for b in list(bs)[:-1]) and features % (32 * world) == 0)
 
 
@@ -220,15 +223,24 @@ def shard_model(model: nn.Module, group=None, always_gather: bool = False, gathe
                 if not isinstance(lin, _LinearBase):
                     raise TypeError(f"{name}: expected a quantised Linear of the registry, found {type(lin).__name__}")
                 if not lin.weight_requires_quantisation and not lin.bypass:
+                    if lin.config.get("mi355q_weight_storage", "int8") == "packed" and getattr(lin, "_master", None) is None:
+                        raise RuntimeError(f"{name}: its weights were quantised and packed when they arrived on the GPU "
+                                           "(mi355q_weight_storage = 'packed' packs on arrival): shard the model on the CPU, before "
+                                           ".to(device), or keep master weights (mi355q_keep_master)")
                     raise RuntimeError(f"{name}: shard the model before its first forward quantises the weights in place")
                 shim = nn.Linear(lin.in_features, lin.out_features, bias=lin.bias is not None, device="meta")
                 shim.weight, shim.bias = lin.weight, lin.bias               # (the full-precision parameters, no copy)
-                seg = gather == "segments" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
+                def _cfg_of(mod):
+                    return mod.local.config if isinstance(mod, RowShardedLinear) else mod.config
+                seg = (gather == "segments" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
+                       and _cfg_of(getattr(owner, "fc2")).get("mi355q_fused_activation", False))
                 qnt = (gather == "quantised" and name == "fc1" and lin.config.get("mi355q_fused_activation", False)
                        and _quantised_gather_fits(getattr(owner, "fc2"), lin.out_features, group))
                 # Llama: gate / up -> silu(gate) * up -> down_proj (needs the grouped launch: the pair is gathered as one)
-                gated = (gather == "quantised" and name in ("gate_proj", "up_proj") and lin.config.get("mi355q_fused_activation", False)
-                         and lin.config.get("mi355q_grouped_linear", False)
+                # (decided for the PAIR: both quantised or both dense -- the gated product needs its partner's shard on the rank)
+                gated = (gather == "quantised" and name in ("gate_proj", "up_proj")
+                         and all(_cfg_of(getattr(owner, n)).get("mi355q_fused_activation", False)
+                                 and _cfg_of(getattr(owner, n)).get("mi355q_grouped_linear", False) for n in ("gate_proj", "up_proj"))
                          and _quantised_gather_fits(getattr(owner, "down_proj"), lin.out_features, group))
                 qnt = qnt or gated
                 wrapped = RowShardedLinear.from_full(type(lin), shim, lin.config, group, always_gather,

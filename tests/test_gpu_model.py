@@ -563,6 +563,7 @@ def test_perplexity_on_trained_weights(tag, name, knobs):
     ref_chunks = data[f"{tag}/{name}/chunk_losses"]
     losses = []
     with torch.no_grad():
+        model(chunks[0][None].to("cuda:0"))        # (the first forward quantises and packs the weights; the knobs act from the second on)
         for c in chunks:
             _, loss = model(c[None].to("cuda:0"), labels=c[None].to("cuda:0"))
             losses.append(float(loss))
@@ -576,6 +577,13 @@ def test_perplexity_on_trained_weights(tag, name, knobs):
     print(f"{tag} {name} [{knobs}]: ppl {ppl:.5f} vs reference {ev['perplexity']:.5f} (d {d_ppl:+.2e}; the reference against itself "
           f"under 1-ulp jitter: {spread:.1e}); max |d chunk loss| {d_chunk:.2e} (reference: {spread_chunk:.1e}); "
           f"3 d.p.: {round(ppl, 3)} vs {round(ev['perplexity'], 3)}")
+    import os
+    if os.path.isdir("gpurun_out"):                                    # (scratch on the GPU box; the committed copy: profiles/)
+        with open("gpurun_out/r05_trained_perplexity.jsonl", "a") as f:
+            f.write(_json.dumps({"model": tag, "config": name, "knobs": knobs, "perplexity": round(ppl, 6), "reference_perplexity": round(ev["perplexity"], 6),
+                                 "d_perplexity": round(d_ppl, 6), "same_to_3dp": round(ppl, 3) == round(ev["perplexity"], 3),
+                                 "reference_vs_itself_1ulp_jitter": round(spread, 5), "max_d_chunk_loss": round(d_chunk, 6),
+                                 "reference_vs_itself_chunk": round(spread_chunk, 5), "bypass_perplexity": round(m["evals"]["bypass"]["perplexity"], 4)}) + "\n")
     assert abs(d_ppl) <= spread and d_chunk <= spread_chunk, (d_ppl, spread, d_chunk, spread_chunk)
     assert abs(d_ppl) < 1e-3 * ev["perplexity"]                       # (and in any case a per-mille of the perplexity)
     assert ppl < 1.05 * m["evals"]["bypass"]["perplexity"]            # (the quantised model is still the language model it was)

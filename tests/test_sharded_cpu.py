@@ -163,3 +163,54 @@ def test_shard_model_refuses_a_model_that_already_quantised_its_weights():
     m.layers[0].fc1.weight_requires_quantisation = False
     with pytest.raises(RuntimeError):
         sharded.shard_model(m)
+
+
+def _bfp_cfg(xw=6, ww=6, **extra):
+    c = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=xw, data_in_exponent_width=8, data_in_exponent_bias=127,
+             data_in_block_size=[1, 16], weight_width=ww, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
+             bias_width=ww, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+    c.update(extra)
+    return c
+
+
+def test_quantised_gather_needs_a_consumer_that_can_take_it():
+    """a quantised gather feeds the bf16 tile GEMM, so the CONSUMER's weights must be exact in bf16 too (width <= 9:
+    a search result with weight_width 12 would be rounded silently), and the consumer itself must be configured for the fused
+    elementwise step -- the harness decides from ITS config whether it calls forward_after"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q.sharded import _quantised_gather_fits
+    mk = lambda cfg: Q.get_quantized_cls("linear", cfg)(256, 64, bias=True, config=cfg)
+    assert _quantised_gather_fits(mk(_bfp_cfg(6, 6, mi355q_fused_activation=True)), 256, None)
+    assert not _quantised_gather_fits(mk(_bfp_cfg(6, 12, mi355q_fused_activation=True)), 256, None)      # wide weights
+    assert not _quantised_gather_fits(mk(_bfp_cfg(12, 6, mi355q_fused_activation=True)), 256, None)      # wide activations
+    assert not _quantised_gather_fits(mk(_bfp_cfg(6, 6)), 256, None)                                     # consumer without the knob
+    assert not _quantised_gather_fits(mk(_bfp_cfg(6, 6, mi355q_fused_activation=True, bypass=True)), 256, None)
+
+
+def test_shard_model_decides_gathers_from_both_ends_of_the_pair():
+    """per-layer overrides in which producer and consumer disagree about the fused elementwise step (a search TOML
+    entry without mi355q_* keys), or only one of gate / up qualifies: every such projection gathers densely instead of handing
+    the harness an object it then applies F.relu / F.silu to"""
+    import torch
+    from mi355q import harness as H
+    from mi355q.sharded import RowShardedLinear, shard_model
+    knobs = dict(mi355q_fused_activation=True, mi355q_grouped_linear=True)
+    base = _bfp_cfg(6, 6, bypass=True, **knobs)
+    # OPT: fc2 of layer 0 without the knob -> fc1 of layer 0 dense, layer 1 as asked
+    qc = H.expand_quant_config(dict(base), 2)
+    qc["model_layer_0"]["fc2"] = {k: v for k, v in qc["model_layer_0"]["fc2"].items() if not k.startswith("mi355q_")}
+    cfg = H.TinyOPTConfig(vocab_size=64, hidden_size=64, ffn_dim=128, num_layers=2, num_heads=2, max_positions=32)
+    for gather in ("segments", "quantised"):
+        m = shard_model(H.TinyOPTForCausalLM(cfg, qc), gather=gather)
+        assert m.layers[0].fc1.gather == "dense", gather
+        # (bypassed layers cannot take a quantised gather either way; segments need nothing of the arithmetic)
+        assert m.layers[1].fc1.gather == ("segments" if gather == "segments" else "dense")
+    # Llama: up_proj of layer 0 without the grouped knob -> gate AND up dense
+    lq = H.expand_llama_quant_config(_bfp_cfg(6, 6, **knobs), 2)
+    lq["model_layer_0"]["mlp"]["up_proj"] = {k: v for k, v in lq["model_layer_0"]["mlp"]["up_proj"].items() if k != "mi355q_grouped_linear"}
+    lcfg = H.TinyLlamaConfig(vocab_size=64, hidden_size=64, intermediate_size=128, num_layers=2, num_heads=2, max_positions=32)
+    m = shard_model(H.TinyLlamaForCausalLM(lcfg, lq), gather="quantised")
+    assert m.layers[0].gate_proj.gather == "dense" and m.layers[0].up_proj.gather == "dense"
+    assert m.layers[1].gate_proj.gather == "quantised" and m.layers[1].up_proj.gather == "quantised"
+    assert isinstance(m.layers[0].down_proj, RowShardedLinear)
