@@ -41,7 +41,8 @@
  *     workgroup per row (default: 1024 workgroups, several rows each); MI355Q_MATMUL_TILE=0 sends the plain attention products
  *     back to kernel 2 of mi355q_matmul.hip; MI355Q_QV_PIECES=0|1|2|4 pins the streaming quantisers' access shape (0:
  *     grid-stride loop; default by tensor size); MI355Q_V8_TILE_ROWS, MI355Q_V8_SPLITS pin the tile GEMM's tile height /
- *     split-K.  (MI355Q_CORR=1, read by the Python layer: producer-formed exception corrections, ABI 18.)
+ *     split-K; MI355Q_V10=1|2|3 (+ MI355Q_V10_NS) pins a geometry of the small-tile kernel (mi355q_gemm_v10.hip), MI355Q_V10_AUTO=0
+ *     keeps launches off it.
  */
 #ifndef MI355Q_H
 #define MI355Q_H
@@ -53,7 +54,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 20
+#define MI355Q_ABI_VERSION 21
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -363,63 +364,6 @@ typedef struct mi355q_bfp_operand {
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);
-
-/* ---- exception corrections formed by the PRODUCERS (round 4) --------------------------------------------------------
- * replaces: nothing the reference executes separately -- the exception blocks are part of x_q / W_q in
- *           F.linear(x_q, W_q, b_q) (quantized_modules/linear.py:59-76); this is how the row-scale product gets their
- *           share WITHOUT forming it inside the product launch (seven in-launch schedules cost ~10 us of a 66-us kernel,
- *           profiles/r03_v9_exception_designs.txt).
- * The weights' entries are static: mi355q_bfp_corr_plan sorts every bucket's entries by (row, block) and gives each W row
- * with entries a column slot (once per packed weight).  mi355q_bfp_corr_bind writes, once per (activation buffers, weight
- * set), a small device-resident binding that names the weights (up to 3: q / k / v, gate / up) and the buffers the
- * vectors go to.  mi355q_block_fp_quantize_aligned_rows_corr is mi355q_block_fp_quantize_aligned_rows_norm whose row
- * workgroups ALSO write, per bound weight: one fp32 value per (row of x, column slot of W) -- the row's exact products with
- * that W row's exception blocks, x's own exception blocks included with their own exponents -- and, for rows that have
- * exception blocks themselves, the row's vector over all N columns against the aligned W operand; `rowmap` gets the row's
- * vector slot (-1 none).  mi355q_bfp_gemm_aligned_corr / _multi_corr are mi355q_bfp_gemm_aligned / _multi whose tiles READ
- * those values (two 1-KiB maps, <= 16 row vectors of 1 KiB, one 16-KiB block of column values per 256 x 256 tile) behind
- * their first K-steps and add them in their stores: same sums of exact integer block products, fp32 order per element
- * "product, + bias, + x-row vector, + W-row value".  More than MI355Q_CORR_X_ROWS rows with exception blocks in a 256-row
- * bucket of x, or more than MI355Q_CORR_W_ROWS in a bucket of W: flagged on the device and the product launch forms the
- * add-back itself as mi355q_bfp_gemm_aligned does (same results up to fp32 summation order).  The lists of both operands are
- * still complete, so any launch may ignore the binding.
- *   plan     int32 [mi355q_bfp_corr_plan_bytes(N) / 4], written by mi355q_bfp_corr_plan (w: row-aligned, 120-entry buckets)
- *   rowmap   int32 [M padded to 256]
- *   xvec     fp32  [mi355q_bfp_corr_xvec_bytes(M, N) / 4]   per weight
- *   wvec     fp32  [mi355q_bfp_corr_wvec_bytes(M, N) / 4]   per weight
- *   binding  mi355q_bfp_corr_binding_bytes() bytes of device memory, written by mi355q_bfp_corr_bind on `stream`
- * All pointers 16-byte aligned; K as for the row-aligned product; pre_op / eps / x2 / x3 as mi355q_block_fp_quantize_aligned_rows_norm. */
-#define MI355Q_CORR_X_ROWS 32
-#define MI355Q_CORR_W_ROWS 16
-#define MI355Q_CORR_MAX_WEIGHTS 3
-typedef struct mi355q_bfp_corr_target {
-    const mi355q_bfp_operand* w;   /* row-aligned weight operand */
-    const int32_t* plan;           /* its correction plan */
-    float* xvec;
-    float* wvec;
-    int64_t N;                     /* rows of w */
-    int32_t slots_in_use;          /* info[1] of mi355q_bfp_corr_plan, or -1: not known (the quantiser then fetches 256 records) */
-    int32_t reserved;
-} mi355q_bfp_corr_target;
-size_t mi355q_bfp_corr_plan_bytes(int64_t N);
-size_t mi355q_bfp_corr_xvec_bytes(int64_t M, int64_t N);
-size_t mi355q_bfp_corr_wvec_bytes(int64_t M, int64_t N);
-size_t mi355q_bfp_corr_binding_bytes(void);
-/* info (host, nullable): when given the call synchronises `stream` once and returns {1 if the plan is not usable, column slots
- * in use} -- packing a weight is a one-off; never under graph capture. */
-int mi355q_bfp_corr_plan(const mi355q_bfp_operand* w, int64_t N, int32_t* plan, int32_t* info, void* stream);
-int mi355q_bfp_corr_bind(void* binding, int32_t* rowmap, int64_t M, int32_t x_mbits, int32_t x_exp_bias,
-                         const mi355q_bfp_corr_target* targets, int32_t count, void* stream);
-int mi355q_block_fp_quantize_aligned_rows_corr(const float* x, const float* x2, const float* x3, int32_t pre_op, float eps,
-                                               int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag, float* rowscale,
-                                               int32_t* list, int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
-                                               int32_t exponent_width, int32_t exponent_bias, const void* binding,
-                                               void* stream);
-int mi355q_bfp_gemm_aligned_corr(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const void* binding, int32_t which,
-                                 const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream);
-int mi355q_bfp_gemm_aligned_multi_corr(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const void* binding,
-                                       const float* const* bias, float* const* y, int32_t count, int64_t M, int64_t N,
-                                       int64_t K, int64_t ldy, void* stream);
 
 /* Several weight operands of the SAME shape against ONE activation operand in one launch (the q / k / v projections of an
  * attention block, gate / up of a gated MLP: reference modules called one after the other on the same input,

@@ -51,11 +51,10 @@ __device__ __forceinline__ unsigned shl_packed(unsigned pk, int s) {
 
 // Returns true when the row carries one exponent (E); pk[] is rewritten in place (shifted / zeroed).
 // When it returns false nothing was changed.  All 256 threads must call it (workgroup barriers inside).
-// exc_bits (optional): bit `it` set where this lane's block of slab `it` became an exception (0 when the row has none).
 template <int MAXIT, bool FULL = false>
 __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&amax)[MAXIT], const int (&code)[MAXIT], int nit,
                                           int nkb, long long row, int* __restrict__ list, RowAlignSmem& sm, int& E,
-                                          int bcap = ROW_BCAP, unsigned* exc_bits = nullptr) {
+                                          int bcap = ROW_BCAP) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int BIG = 1 << 20;
     bool has[MAXIT];
@@ -89,7 +88,6 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
     const int lomax = max(max(sm.wkey[0], sm.wkey[1]), max(sm.wkey[2], sm.wkey[3]));
     const int code0 = sm.code0;
     // every block can be shifted onto emin  <=>  emin >= code - head-room for every block  (one barrier decides)
-    if (exc_bits) *exc_bits = 0u;
     if (emin >= lomax) {
         E = emin == BIG ? code0 : emin;
 #pragma unroll
@@ -138,7 +136,6 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         if (exc[it]) {
-            if (exc_bits) *exc_bits |= 1u << it;
             int* e = bucket + EXC_HEADER + EXC_ENTRY * (base + slot[it]);
             if ((lane & 3) == 0) { e[0] = (int)row; e[1] = it * 64 + wave * 16 + (lane >> 2); e[2] = code[it]; e[3] = 0; }
             e[4 + (lane & 3)] = (int)pk[it];

@@ -11,7 +11,6 @@
 #include <mutex>
 
 #include "mi355q_internal.h"
-#include "mi355q_corr.h"
 #include "mi355q_align_row.h"
 
 using namespace mi355q;
@@ -494,7 +493,7 @@ static int quantize_aligned_rows_impl(const float* x, const float* x2, const flo
                                       int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag, float* rowscale,
                                       int32_t* list, int32_t* list_to_clear, int64_t rows, int64_t K, int64_t seg_len,
                                       int64_t seg_stride, int32_t width, int32_t exponent_width, int32_t exponent_bias,
-                                      int32_t bucket_cap, void* stream, const CorrLaunch* corr) {
+                                      int32_t bucket_cap, void* stream) {
     if (seg_len < 0 || seg_stride < 0) return MI355Q_E_BADARG;
     if (seg_len > 0 && (seg_len % 4 || seg_stride % 4 || K % seg_len || seg_stride < rows * seg_len)) return MI355Q_E_BADARG;
     if (!pre_op_ok(pre_op, x2, true) || !(eps >= 0.f) || reinterpret_cast<uintptr_t>(x3) % 16) return MI355Q_E_BADARG;
@@ -527,7 +526,7 @@ static int quantize_aligned_rows_impl(const float* x, const float* x2, const flo
     a.seg_stride = seg_stride;
     set_mantissa(a, width - 1);
     return launch_quant_align_rows(a, mant_tiled, rowflag, rowscale, exponent_bias + width - 1, list, list_to_clear,
-                                   static_cast<hipStream_t>(stream), bucket_cap < 0 ? -1 : bucket_cap_of(bucket_cap), corr);
+                                   static_cast<hipStream_t>(stream), bucket_cap < 0 ? -1 : bucket_cap_of(bucket_cap));
 }
 
 int mi355q_block_fp_quantize_aligned_rows_seg(const float* x, const float* x2, const float* x3, int32_t pre_op, float eps,
@@ -536,99 +535,11 @@ int mi355q_block_fp_quantize_aligned_rows_seg(const float* x, const float* x2, c
                                               int64_t seg_stride, int32_t width, int32_t exponent_width, int32_t exponent_bias,
                                               int32_t bucket_cap, void* stream) {
     return quantize_aligned_rows_impl(x, x2, x3, pre_op, eps, mant_tiled, exp_out, rowflag, rowscale, list, list_to_clear, rows, K,
-                                      seg_len, seg_stride, width, exponent_width, exponent_bias, bucket_cap, stream, nullptr);
-}
-
-// ---- exception corrections formed by the producers (mi355q_corr.h)
-size_t mi355q_bfp_corr_plan_bytes(int64_t N) { return N > 0 ? (size_t)plan_words(N) * 4 : 0; }
-size_t mi355q_bfp_corr_xvec_bytes(int64_t M, int64_t N) { return M > 0 && N > 0 ? (size_t)corr_xvec_floats(M, N) * 4 : 0; }
-size_t mi355q_bfp_corr_wvec_bytes(int64_t M, int64_t N) { return M > 0 && N > 0 ? (size_t)corr_wvec_floats(M, N) * 4 : 0; }
-size_t mi355q_bfp_corr_binding_bytes(void) { return (sizeof(CorrArgs) + 255) / 256 * 256; }
-
-int mi355q_bfp_corr_plan(const mi355q_bfp_operand* w, int64_t N, int32_t* plan, int32_t* info, void* stream) {
-    if (!w || !plan || N <= 0) return MI355Q_E_BADARG;
-    if (w->row_aligned != 1 || !w->list || bucket_cap_of(w->list_cap) != ROW_BCAP) return MI355Q_E_UNSUPPORTED;
-    if (reinterpret_cast<uintptr_t>(plan) % 16) return MI355Q_E_ALIGN;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch_corr_plan(w->list, N, plan, st);
-    if (rc == 0 && info) {
-        rc = (int)hipMemcpyAsync(info, plan, 8, hipMemcpyDeviceToHost, st);
-        if (rc == 0) rc = (int)hipStreamSynchronize(st);
-    }
-    return rc;
-}
-
-// host-side copies of the bindings written by mi355q_bfp_corr_bind (keyed by the device address): what a launch needs of a
-// binding as kernel ARGUMENTS -- a pointer read from the device-resident struct inside the kernel is a dependent scalar load in
-// front of the first prefetch
-struct BindingShadow { CorrArgs c; int ntab; };
-static std::mutex g_bind_mu;
-static std::map<const void*, BindingShadow> g_bindings;
-
-__global__ void corr_bind_kernel(CorrArgs* out, const CorrArgs v) {
-    if (threadIdx.x == 0) *out = v;
-}
-
-int mi355q_bfp_corr_bind(void* binding, int32_t* rowmap, int64_t M, int32_t x_mbits, int32_t x_exp_bias,
-                         const mi355q_bfp_corr_target* targets, int32_t count, void* stream) {
-    if (!binding || !rowmap || !targets || M <= 0 || count < 1 || count > CORR_MAX_W) return MI355Q_E_BADARG;
-    if (x_mbits < 1 || x_mbits > 7) return MI355Q_E_BADARG;
-    CorrArgs c{};
-    c.count = count;
-    c.x_off = x_exp_bias + x_mbits;
-    c.rowmap = rowmap;
-    c.mpad = corr_pad256(M);
-    uintptr_t al = reinterpret_cast<uintptr_t>(binding) | reinterpret_cast<uintptr_t>(rowmap);
-    for (int g = 0; g < count; ++g) {
-        const mi355q_bfp_corr_target& t = targets[g];
-        if (!t.w || !t.plan || !t.xvec || !t.wvec || t.N <= 0 || !t.w->mant || !t.w->gscale) return MI355Q_E_BADARG;
-        if (t.w->row_aligned != 1 || t.w->mbits < 1 || t.w->mbits > 7) return MI355Q_E_UNSUPPORTED;
-        // one exponent offset for all weights of a binding (q / k / v, gate / up share their quantiser configuration)
-        if (g > 0 && t.w->exp_bias + t.w->mbits != c.w_off) return MI355Q_E_UNSUPPORTED;
-        c.w_off = t.w->exp_bias + t.w->mbits;
-        c.N[g] = t.N;
-        c.wm[g] = t.w->mant;
-        c.sw[g] = t.w->gscale;
-        c.plan[g] = t.plan;
-        c.xvec[g] = t.xvec;
-        c.wvec[g] = t.wvec;
-        al |= reinterpret_cast<uintptr_t>(t.plan) | reinterpret_cast<uintptr_t>(t.xvec) | reinterpret_cast<uintptr_t>(t.wvec) |
-              reinterpret_cast<uintptr_t>(t.w->mant);
-    }
-    if (al % 16) return MI355Q_E_ALIGN;
-    {
-        const int used = targets[0].slots_in_use;
-        BindingShadow sh{c, used < 0 || used > CORR_TAB ? CORR_TAB : (used + 31) / 32 * 32};
-        std::lock_guard<std::mutex> lock(g_bind_mu);
-        g_bindings[binding] = sh;
-    }
-    hipLaunchKernelGGL(corr_bind_kernel, 1, 64, 0, static_cast<hipStream_t>(stream), static_cast<CorrArgs*>(binding), c);
-    return (int)hipGetLastError();
-}
-
-int mi355q_block_fp_quantize_aligned_rows_corr(const float* x, const float* x2, const float* x3, int32_t pre_op, float eps,
-                                               int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag, float* rowscale,
-                                               int32_t* list, int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,
-                                               int32_t exponent_width, int32_t exponent_bias, const void* binding,
-                                               void* stream) {
-    if (!binding || !list) return MI355Q_E_BADARG;
-    CorrLaunch cl{};
-    {
-        std::lock_guard<std::mutex> lock(g_bind_mu);
-        auto it = g_bindings.find(binding);
-        if (it == g_bindings.end()) return MI355Q_E_BADARG;          // (not written by mi355q_bfp_corr_bind)
-        cl.dev = static_cast<const CorrArgs*>(binding);
-        cl.plan0 = it->second.c.plan[0];
-        cl.dense0 = reinterpret_cast<const char*>(it->second.c.plan[0] + plan_dense_off(it->second.c.N[0]));
-        cl.ntab = it->second.ntab;
-        if (it->second.c.mpad < rows) return MI355Q_E_BADARG;
-    }
-    return quantize_aligned_rows_impl(x, x2, x3, pre_op, eps, mant_tiled, exp_out, rowflag, rowscale, list, list_to_clear, rows, K,
-                                      0, 0, width, exponent_width, exponent_bias, 0, stream, &cl);
+                                      seg_len, seg_stride, width, exponent_width, exponent_bias, bucket_cap, stream);
 }
 
 static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
-                            int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream, const CorrArgs* corr, int which) {
+                            int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     if (!x || !w || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
     if (M == 0 || N == 0) return 0;
     if (!y || (K > 0 && (!x->mant || !x->exp || !w->mant || !w->exp || !x->rowflag || !w->rowflag)))
@@ -666,11 +577,6 @@ static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_opera
         // blockwise-exact between them instead (decided on the device)
         a.x_mbits = x->mbits;
         a.w_mbits = w->mbits;
-        if (corr && !a.x_post) {
-            // (a single launch of weight `which` of the binding: the kernel picks plan / vectors by the group index)
-            a.corr = corr;
-            a.corr_which = which;
-        }
         hipEvent_t te = g_timing.begin(st);
         int rc = launch_bfp_gemm_v8(a, x->gscale, w->gscale, x->list, w->list, 0, st, x->rowflag, w->rowflag);
         g_timing.end(te, st);
@@ -697,18 +603,11 @@ static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_opera
 
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
                             int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
-    return gemm_aligned_impl(x, w, bias, y, M, N, K, ldy, stream, nullptr, 0);
-}
-
-int mi355q_bfp_gemm_aligned_corr(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const void* binding, int32_t which,
-                                 const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
-    if (!binding || which < 0 || which >= CORR_MAX_W) return MI355Q_E_BADARG;
-    return gemm_aligned_impl(x, w, bias, y, M, N, K, ldy, stream, static_cast<const CorrArgs*>(binding), which);
+    return gemm_aligned_impl(x, w, bias, y, M, N, K, ldy, stream);
 }
 
 static int gemm_aligned_multi_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const float* const* bias,
-                                  float* const* y, int32_t count, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream,
-                                  const CorrArgs* corr) {
+                                  float* const* y, int32_t count, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     if (!x || !w || !y || count < 1 || count > 3 || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
     if (M == 0 || N == 0) return 0;
     for (int i = 0; i < count; ++i) {
@@ -725,7 +624,7 @@ static int gemm_aligned_multi_impl(const mi355q_bfp_operand* x, const mi355q_bfp
         return MI355Q_E_UNSUPPORTED;                  // (callers then launch mi355q_bfp_gemm_aligned per weight)
     if (x->mbits < 1 || x->mbits > 7 || w[0]->mbits < 1 || w[0]->mbits > 7) return MI355Q_E_BADARG;
     if (reinterpret_cast<uintptr_t>(x->mant) % 16) return MI355Q_E_ALIGN;
-    if (count == 1) return gemm_aligned_impl(x, w[0], bias ? bias[0] : nullptr, y[0], M, N, K, ldy, stream, corr, 0);
+    if (count == 1) return gemm_aligned_impl(x, w[0], bias ? bias[0] : nullptr, y[0], M, N, K, ldy, stream);
     GemmArgs a{x->mant, x->exp, w[0]->mant, w[0]->exp, bias ? bias[0] : nullptr, y[0], M, N, K, ldy,
                x->exp_bias + x->mbits + w[0]->exp_bias + w[0]->mbits, 1,
                x->exp_bias + x->mbits, w[0]->exp_bias + w[0]->mbits,
@@ -737,21 +636,13 @@ static int gemm_aligned_multi_impl(const mi355q_bfp_operand* x, const mi355q_bfp
     }
     a.x_mbits = x->mbits;
     a.w_mbits = w[0]->mbits;
-    a.corr = corr;
     return launch_bfp_gemm_v8(a, x->gscale, w[0]->gscale, x->list, w[0]->list, 0, static_cast<hipStream_t>(stream), x->rowflag,
                               w[0]->rowflag);
 }
 
 int mi355q_bfp_gemm_aligned_multi(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const float* const* bias,
                                   float* const* y, int32_t count, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
-    return gemm_aligned_multi_impl(x, w, bias, y, count, M, N, K, ldy, stream, nullptr);
-}
-
-int mi355q_bfp_gemm_aligned_multi_corr(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const void* binding,
-                                       const float* const* bias, float* const* y, int32_t count, int64_t M, int64_t N,
-                                       int64_t K, int64_t ldy, void* stream) {
-    if (!binding) return MI355Q_E_BADARG;
-    return gemm_aligned_multi_impl(x, w, bias, y, count, M, N, K, ldy, stream, static_cast<const CorrArgs*>(binding));
+    return gemm_aligned_multi_impl(x, w, bias, y, count, M, N, K, ldy, stream);
 }
 
 size_t mi355q_bfp_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N) {

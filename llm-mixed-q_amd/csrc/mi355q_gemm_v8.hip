@@ -762,7 +762,6 @@ static int v10_forced_launch(const GemmArgs& a_in, const float* sx, const float*
             a.tickets = w->tickets;
         }
     }
-    a.corr = nullptr;
     return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, bf16, geom);
 }
 static int v10_forced() {                       // (read per launch: the tests pin one geometry after the other in one process)
@@ -787,7 +786,6 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
             !getenv("MI355Q_V8_CLOCK") && !getenv("MI355Q_V8_STAMPS")) {
             GemmArgs a = a_in;
             a.splits = 1;
-            a.corr = nullptr;
             return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, false, 3);
         }
     }
@@ -847,18 +845,12 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     // (profiles/r04_v9_tail_prefetch.txt).  MI355Q_V9_FIX=0 keeps the round-2 kernel for A/B runs.
     static const int v9_fix_env = getenv("MI355Q_V9_FIX") ? atoi(getenv("MI355Q_V9_FIX")) : -1;
     const bool v9_fix = v9_fix_env >= 0 ? v9_fix_env != 0 : true;
-    // launches whose exception add-back the PRODUCERS formed (a.corr, mi355q_corr.h; round 4): the 256 x 256 kernel reads it
-    // behind its first K-steps -- grouped launches included (the separate launches of the same weights take the same kernel
-    // whenever they take 256-row tiles; callers bind grouped weights only then).  MI355Q_CORR=0 ignores the binding.
-    static const int use_corr = getenv("MI355Q_CORR") ? atoi(getenv("MI355Q_CORR")) : 1;
-    const bool corr_ok = use_corr && fix && a.corr && a.splits <= 1 && !a.x_post;
-    if (!corr_ok) a.corr = nullptr;
     // (grouped launches stay on the kernel below: their outputs are promised bit-identical to the separate calls, which may take
     //  128-row tiles there -- the two kernels add a row's corrections in different fp32 orders)
     // (round 5: grouped launches too -- the small-tile kernel their separate launches may take adds a row's corrections in this
     //  kernel's order, tests/test_gpu_gemm.py::test_small_tiles_equal_the_256_tile_bit_for_bit)
     static const int v9_groups = getenv("MI355Q_V9_GROUPS") ? atoi(getenv("MI355Q_V9_GROUPS")) : 1;
-    if (use_v9 && (v9_fix || !fix || corr_ok) && (a.ngroup <= 1 || corr_ok || v9_groups) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
+    if (use_v9 && (v9_fix || !fix) && (a.ngroup <= 1 || v9_groups) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {
         const bool piped = small_sched == 2 && a.K % 128 == 0 && (((a.K >> 6) / (a.splits > 1 ? a.splits : 1)) & 1) == 0;

@@ -19,9 +19,8 @@
 //     entry's vector of 256 products in spare LDS in the next), hidden behind the other wave of its SIMD.  The entries of
 //     one tile row / column are chained in ascending block order and summed by ONE wave in that order: reproducible.
 //     The epilogue looks rows up once per 16-row fragment and columns once per wave.
-//   * round 4 (FIX_ = 2, mi355q_corr.h): the add-back READ, not formed -- the activation quantiser has written one vector
-//     per x row with exception blocks and one value per (row, W row with exception blocks); the tile fetches its two maps,
-//     <= 16 row vectors and one 16-KiB block of column values behind its first K-steps and adds them in its stores.
+//   * (round 4's FIX_ = 2 -- the add-back READ from vectors the activation quantiser formed -- measured a net loss, the
+//     quantiser paying more than the product saved, profiles/r04_corr_breakdown.txt, and was removed in round 5.)
 // Roofline: int8 MFMA, 2*M*N*K ops.  y leaves as full fp32: 64 MiB at 4096^2, ~10 us at the rate the fabric takes
 // write-backs, none of it overlapped with one tile per compute unit.
 #include <hip/hip_runtime.h>
@@ -33,7 +32,6 @@
 #include <utility>
 
 #include "mi355q_gemm_tile.h"
-#include "mi355q_corr.h"
 
 namespace mi355q {
 
@@ -52,7 +50,6 @@ constexpr int V9_GSCR = V9_NW * V9_NB_ENT * 4096;            // ... their blocks
 constexpr int V9_SLOW_MAX = (V9_STAGES - V9_GSCR) / 1024;    // vectors that fit the ring area behind the K loop
 static_assert(ROW_BUCKET_WORDS * 4 <= 4096, "bucket copy");
 static_assert(V9_FAST_MAX >= 32, "spare LDS for correction vectors");
-static_assert(CORR_XV == 32 && CORR_WV == 16, "the corrections ride in the ring slots of two K-steps past the end: 32 + 16 + 2 pieces");
 
 typedef __bf16 v9_bf16x8 __attribute__((ext_vector_type(8)));
 // (w fragment as the MFMA's A operand, x fragment as its B operand: D[n = 4 (lane / 16) + r][m = lane % 16])
@@ -80,16 +77,14 @@ __device__ __forceinline__ i32x4 v9_desc(const void* base, int bytes) {       //
     return i32x4{(int)(unsigned)b, (int)(unsigned)(b >> 32), bytes, 0x00020000};
 }
 
-// FIX_ 1: with the exception add-back formed by the tile itself behind its K loop; 2: the add-back READ from what the
-// producers formed (a.corr, mi355q_corr.h; a launch whose rows / columns with exceptions did not fit their slots falls back
-// to 1's path, uniformly over the grid).  STAMP: diagnostic build, phase times go to a.stamps.
+// FIX_ 1: with the exception add-back formed by the tile itself behind its K loop.  STAMP: diagnostic build, phase times go
+// to a.stamps.
 template <int FIX_, bool BF16, bool STAMP>
 __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, const float* __restrict__ sx,
                                                         const float* __restrict__ sw_in, const int* __restrict__ xlist,
                                                         const int* __restrict__ wlist_in, const uint8_t* __restrict__ xf,
                                                         const uint8_t* __restrict__ wf_in) {
     constexpr int FIX = FIX_ != 0 ? 1 : 0;
-    constexpr bool REC = FIX_ == 2;
     constexpr bool TPF = FIX_ == 1;                       // the tile's gathers ride in the K-steps past the end (round 4)
     static_assert(!BF16 || FIX_ == 0, "the bf16 arithmetic has no exception lists");
     // Two LDS objects: the operand rings (filled by LDS-DMA, read by inline-asm ds_read_b128 only) and everything else.
@@ -123,9 +118,8 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const int gsz = min(tiles_m - first_m, GM);
     const int tm = first_m + (tile_id % in_group) % gsz;
     int tn = (tile_id % in_group) / gsz;
-    int which = REC ? a_in.corr_which : 0;                     // (weight of the binding; a grouped launch: the tile's group)
     if (ngroup > 1) {
-        which = tn / tiles_n1;                                  // (wave-uniform: scalar loads from the argument block)
+        const int which = tn / tiles_n1;                                  // (wave-uniform: scalar loads from the argument block)
         tn -= which * tiles_n1;
         // (selects over constant indices: a runtime index would put the argument block in scratch memory)
 #define V9_PICK(f) (which == 0 ? a_in.f[0] : which == 1 ? a_in.f[1] : a_in.f[2])
@@ -151,7 +145,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     //      slices, its two exception buckets and the lists' overflow words
     const int ring_lds = (int)(size_t)(lptr_t)ring, side_lds = (int)(size_t)(lptr_t)side;     // the objects' own LDS addresses
     if (wave == 0 || wave == 1) {
-        if (FIX && !REC && !(wave == 0 && a.x_post)) {      // (REC: the buckets are only fetched if the launch has to fall back)
+        if (FIX && !(wave == 0 && a.x_post)) {
             const int* b = wave == 0 ? row_bucket(xlist, m0) : row_bucket(wlist, n0);
             const int d = side_lds + (wave == 0 ? V9_XB : V9_WB);
 #pragma unroll
@@ -175,8 +169,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     } else if (FIX && (wave == 5 || wave == 6)) {
         V9_GLDS4((wave == 5 ? xlist : wlist) + lane, side_lds + V9_OVF + (wave - 5) * 256);
     }
-    // maps cleared, vectors beside the rings zero (every product is ADDED to its row's / column's vector) -- unless the
-    // producers' corrections are read
+    // maps cleared, vectors beside the rings zero (every product is ADDED to its row's / column's vector)
     auto clear_maps_and_vectors = [&]() {
         rowslot[tid & 255] = -1;
         if (tid >= 256) colslot[tid & 255] = -1;
@@ -186,7 +179,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             if ((q * V9_NT + tid) * 16 < V9_FAST_MAX * 1024)
                 *reinterpret_cast<f32x4*>(smem + V9_CORR + (q * V9_NT + tid) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    if (FIX && !REC) clear_maps_and_vectors();
+    if (FIX) clear_maps_and_vectors();
 
     // ---- the operand stream.  Piece p of a K-step: 16 rows of A (p < 16) or of B; this wave stages pieces wave + 8 q.
     //      One descriptor per operand, rooted at the tile's first piece row and ending with its last (rows past the
@@ -212,43 +205,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     V9_STAGE(0, 0, 0)
     V9_STAGE(1, V9_HALF, V9_HALF)
     V9_STAGE(2, 2 * V9_HALF, 2 * V9_HALF)
-    // REC: what the producers formed for this tile (mi355q_corr.h) is fetched by the LDS-DMA slots of the two K-steps PAST
-    // THE END of the loop (the pipeline requests step t + 3 during step t: steps nsteps and nsteps + 1 carry no operand data
-    // and their ring slots are free) -- "step nsteps": the <= 32 row vectors (piece p = the 1 KiB of vector slot p that
-    // covers this tile's 256 columns); "step nsteps + 1": the [256][CORR_WV] block of column values in the A half, the row
-    // map and the column map as pieces 0 and 1 of the B half.  A fetch that is not wanted (a slot past the bucket's count, no
-    // column of this tile has entries, the launch falls back) goes through a descriptor of zero bytes.  No LDS beside the
-    // rings, no extra instruction in the prologue, landed by the loop's own final wait.
-    int ncx = 0, ncw = 0;                       // rows / columns of this tile that have a correction
-    bool nofit = false;                         // REC: slots did not suffice somewhere (uniform over the grid): form the add-back here
-    const float* xv = nullptr;
-    const float* wv = nullptr;
-    const int *rmap = nullptr, *cmap = nullptr;
-    long long xv_stride = 0;
-    int wv_stride = 0;
-    if (REC) {
-        const CorrArgs* __restrict__ cp = a.corr;
-        const int* __restrict__ plan = cp->plan[which];
-        const long long ncorr = cp->N[which], npad = corr_pad256(ncorr);
-        nofit = (plan[0] | xlist[1]) != 0 || a.x_post;
-        ncx = nofit ? 0 : min(row_bucket(xlist, m0)[1], CORR_XV);
-        ncw = nofit ? 0 : plan[plan_ncols_off(ncorr) + tn];
-        // (uniform values all: pinned to scalar registers -- left to the compiler the four pointers and their arithmetic sit
-        //  in vector registers across the K loop, whose 256 are taken)
-        auto uni = [](const void* p) {
-            const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-            return reinterpret_cast<const void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
-                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
-        };
-        xv = static_cast<const float*>(uni(cp->xvec[which] + ((long long)tm * CORR_XV) * npad + n0));
-        xv_stride = (long long)__builtin_amdgcn_readfirstlane((int)(npad * 4));
-        wv = static_cast<const float*>(uni(cp->wvec[which] + ((long long)m0 * plan_nb(ncorr) + tn) * CORR_WV));
-        wv_stride = __builtin_amdgcn_readfirstlane((int)plan_nb(ncorr) * CORR_WV * 4);     // bytes from one row's slice to the next row's
-        rmap = static_cast<const int*>(uni(cp->rowmap + m0));
-        cmap = static_cast<const int*>(uni(plan + plan_colmap_off() + n0));
-        ncx = __builtin_amdgcn_readfirstlane(ncx);
-        ncw = __builtin_amdgcn_readfirstlane(ncw);
-    }
     if (STAMP) st_t[1] = __builtin_amdgcn_s_memrealtime();
 
     using acc_t = typename std::conditional<BF16, f32x4, i32x4>::type;
@@ -333,11 +289,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // of step t + 1) and the counted wait for fragment i; the read of B fragment i - 2 of step t + 1 (groups 2-5); LDS-DMA
     // piece i of step t + 3 (groups 0-3).  At barrier(t) every wave has waited for its own pieces of step t + 1 and has
     // retired every read of the A half of step t - 1 and of the B half of step t: those are the slots step t + 3 goes to.
-    // `tail` (REC): 1 = this step requests "step nsteps" (the row vectors), 2 = "step nsteps + 1" (column values, maps)
-    // instead of operand pieces: piece q of this wave (ring piece pr = wave + 8 (q & 1) of the A half, q < 2, or of the B half)
-    // comes from its own source through a descriptor rooted pr piece rows in front of it, so that the lane offsets of the
-    // operand stream (voff[q]) address its 1 KiB.
-    // (where the tail steps' pieces land is read off the ring positions behind the loop: step nsteps + j in a_j / b_j)
     // FIX_ 1, round 4: the GATHERS of the tile's first V9_TPRE exception entries ride in the LDS-DMA slots of the THREE K-steps
     // past the end (tails 3, 4, 5; 96 pieces = 24 entries x 4 quarters of 64 rows): piece P = 32 j + p of tail step j carries
     // quarter P & 3 = wave & 3 of entry P >> 2 = 8 j + 2 q + wave / 4 -- the other operand's blocks at the entry's K position,
@@ -353,18 +304,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         tcx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         tnent = tcx + __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
     }
-    auto tail_desc = [&](int q, int tail) {
-        const int pr = wave + 8 * (q & 1);
-        const void* src = nullptr;
-        bool on = false;
-        if (tail == 1) { const int p = (q < 2 ? 0 : 16) + pr; src = reinterpret_cast<const char*>(xv) + p * xv_stride; on = p < ncx; }
-        else if (q < 2) { src = reinterpret_cast<const char*>(wv) + (long long)pr * 16 * wv_stride; on = ncw > 0; }
-        else { src = pr == 0 ? rmap : cmap; on = pr < 2 && !nofit; }
-        const bool strided = tail == 2 && q < 2;          // (the column values: 16 rows x 64 bytes, own lane offsets, see V9_TPIECE)
-        const unsigned long long b = reinterpret_cast<unsigned long long>(src) - (strided ? 0ull : (unsigned long long)pr * (unsigned long long)row_bytes);
-        return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)),
-                     __builtin_amdgcn_readfirstlane(on ? (strided ? 16 * wv_stride : pr * (int)row_bytes + 1024) : 0), 0x00020000};
-    };
     auto body = [&](i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db, const int tail) {
         V9_LGKM(2);                                             // (the B reads of the slot about to be refilled)
         V9_WAITV(4);
@@ -377,9 +316,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         i32x4 gd_ = e_ < tcx ? V9_WG() : V9_XG();                                                                        \
         if (e_ >= tnent) gd_[2] = 0;                                                                                     \
         V9_BLDS16(gv, gd_, koff_, ring_lds + ((q) < 2 ? da : V9_B0 + db) + (wave + 8 * ((q) & 1)) * 1024); }
-#define V9_TPIECE(q) { const i32x4 td_ = tail_desc(q, tail);                                                           \
-        const int tv_ = (tail == 2 && (q) < 2) ? (lane >> 2) * wv_stride + (lane & 3) * 16 : voff[q];                    \
-        V9_BLDS16(tv_, td_, 0, ring_lds + ((q) < 2 ? da : V9_B0 + db) + (wave + 8 * ((q) & 1)) * 1024); }
 #define V9_GROUP(i, wait)                                                                                                \
         if (i < 6) V9_DSR(fa[(i + 2) & 3], ac, (i + 2) * 1024); else V9_DSR(fa[(i + 2) & 3], an, (i - 6) * 1024);          \
         V9_LGKM(wait);                                                                                                   \
@@ -390,7 +326,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_SB();                                                                                                         \
         acc[i][1] = v9_mma(fb[1], fa[i & 3], acc[i][1]);                                                                 \
         V9_SB();                                                                                                         \
-        if (i < 4) { if (REC && tail) V9_TPIECE(i) else if (TPF && tail >= 3) V9_GPIECE(i) else V9_PIECE(i, rxd_, rwd_, soff_, da, db); } \
+        if (i < 4) { if (TPF && tail >= 3) V9_GPIECE(i) else V9_PIECE(i, rxd_, rwd_, soff_, da, db); } \
         V9_SB();                                                                                                         \
         acc[i][2] = v9_mma(fb[2], fa[i & 3], acc[i][2]);                                                                 \
         V9_SB();                                                                                                         \
@@ -410,13 +346,9 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     body(fb1, fb0, (t_) + 1, a0, a1, b1, a3, b0, tl1);                                                                   \
     { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
     { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
-    // (nsteps is even and >= 4: K % 128 == 0, even slices; REC: the last two pairs request the corrections)
-    for (int t = 0; t < (REC || TPF ? nsteps - 4 : nsteps); t += 2) {
+    // (nsteps is even and >= 4: K % 128 == 0, even slices; TPF: the last two pairs request the gathers)
+    for (int t = 0; t < (TPF ? nsteps - 4 : nsteps); t += 2) {
         V9_PAIR(t, 0, 0)
-    }
-    if (REC) {
-        V9_PAIR(nsteps - 4, 0, 1)
-        V9_PAIR(nsteps - 2, 2, 0)
     }
     if (TPF) {
         V9_PAIR(nsteps - 4, 0, 3)
@@ -424,7 +356,6 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     }
     const int dead_a = a3;            // (the A half of the last K-step: nothing was requested into it, dead behind the loop)
     // ring slots (byte offsets) of the steps past the end: step nsteps + j went to a_j / b_j (the rotation above)
-    const int xa_ = a0, xb_ = b0, wa_ = a1, wb_ = b1;
     const int ga_[3] = {a0, a1, a2}, gb_[3] = {b0, b1, b2};
     const i32x4 xg = V9_XG(), wg = V9_WG();
 #undef V9_PAIR
@@ -502,27 +433,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     bool look = false;
     int mykeys0 = 0x7fffffff, mykeys1 = 0x7fffffff;                   // (slot << 18 | block << 8 | index) of the entries at list
                                                                 // positions lane, lane + 64 that this wave serves
-    bool have = false;                                          // maps and vectors are the producers' (REC), in LDS already
-    if (REC && !nofit) {
-        have = true;
-        look = ncx + ncw > 0 && !(a.dbg & 2);
-    } else if (FIX) {
-        if (REC) {
-            // the producers' slots did not suffice (uniform over the grid): the tile's two buckets after all, then as FIX_ 1
-            if (wave == 0 || wave == 1) {
-                const int* b = wave == 0 ? row_bucket(xlist, m0) : row_bucket(wlist, n0);
-                const int d = side_lds + (wave == 0 ? V9_XB : V9_WB);
-                if (!(wave == 0 && a.x_post)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (q * 256 + lane * 4 < ROW_BUCKET_WORDS) V9_GLDS16(b + q * 256 + lane * 4, d + q * 1024);
-                }
-                V9_WAITV(0);
-            }
-            clear_maps_and_vectors();
-            V9_LGKM(0);
-            __builtin_amdgcn_s_barrier();
-        }
+    if (FIX) {
         cx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         cw = __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
         nent = cx + cw;
@@ -613,7 +524,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         for (int o = 1; o < 64; o <<= 1) best = min(best, __shfl_xor(best, o));
         return __builtin_amdgcn_readfirstlane(best);
     };
-    if (look && !have && !tmode) {
+    if (look && !tmode) {
         // (2) this wave's entries
         // (two named scalars, not an array: a q loop the compiler keeps rolled would index it in scratch memory)
         auto key_of = [&](int j) {
@@ -626,13 +537,11 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         mykeys1 = key_of(lane + 64);
     }
     // (masks only -- scales, bias and slots are read again where they are used: the accumulators take half the registers)
-    // the maps the stores consult: the tile's own (formed above) or the producers' (REC: pieces 0 and 1 of the B half of the
-    // second tail step)
-    const int* const rslot_r = have ? reinterpret_cast<const int*>(ring + V9_B0 + wb_) : rowslot;
+    // the maps the stores consult
+    const int* const rslot_r = rowslot;
     const int* const cslot_r = rslot_r + 256;
     unsigned cmask = 0, jmask = 0;      // bit 4 j + r: some lane of the wave has a vector for that column; bit j: tile column j has one
     unsigned rmask = 0;                 // bit i: some row of fragment i has a vector (set by the one-pass epilogue from its preloads)
-    const float* const wvl = reinterpret_cast<const float*>(ring + wa_);          // (REC: column values, [tile row][column slot])
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.y) | (uintptr_t)(a.ldy * 4)) & 15) == 0;
     // tiles of fragment i: pass 0 the ones no vector touches, pass 1 the others (with their vectors)
     auto store_rows = [&](int i, int pass) {
@@ -657,8 +566,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             if (pass == 1) {
                 if (rowv) {                                      // the row's vector: 256 products, one per tile column
                     const int rs0 = max(rs, 0);
-                    const float* rv = have ? reinterpret_cast<const float*>(ring + (rs0 < 16 ? xa_ : V9_B0 + xb_) + (rs0 & 15) * 1024)
-                                           : V9_VEC(rs0);
+                    const float* rv = V9_VEC(rs0);
                     const f32x4 c4 = *reinterpret_cast<const f32x4*>(rv + cl);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) val[r] += rs >= 0 ? c4[r] : 0.f;
@@ -669,7 +577,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (cmask & (1u << (4 * j + r)))
-                            val[r] += c4[r] >= 0 ? (have ? wvl[rl * CORR_WV + (c4[r] & (CORR_WV - 1))] : V9_VEC(max(c4[r], 0))[rl]) : 0.f;
+                            val[r] += c4[r] >= 0 ? V9_VEC(max(c4[r], 0))[rl] : 0.f;
                 }
             }
             if (row < a.M) {
@@ -808,7 +716,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     int lastkey = -1, lastslot = -1;
     // the serial service (tiles whose entries do not fit the parallel one above; FIX_ 2 falling back)
     for (int phase = -1; phase < 0; ++phase) {
-        bool more = look && !have && !tmode;
+        bool more = look && !tmode;
         while (more) {
             int bkey[V9_NB_ENT];
 #pragma unroll
@@ -829,7 +737,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         }
     }
     if (STAMP) st_x[2] = __builtin_amdgcn_s_memrealtime();
-    if (look && !have) __builtin_amdgcn_s_barrier();
+    if (look) __builtin_amdgcn_s_barrier();
     if (STAMP) st_t[4] = __builtin_amdgcn_s_memrealtime();
     // (4) the stores: fragment by fragment, first its tiles that no vector touches, then the others
     if (FIX && look && mode != 3) {
@@ -874,8 +782,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             const long long row = (long long)m0 + rl;
             float* yrow = a.y + row * a.ldy + n0 + wn * 64 + lq * 4;
             const int rs0 = max(rs[i], 0);
-            const float* rv = (have ? reinterpret_cast<const float*>(ring + (rs0 < 16 ? xa_ : V9_B0 + xb_) + (rs0 & 15) * 1024) : V9_VEC(rs0)) + wn * 64 + lq * 4;
-            const float* wr = wvl + rl * CORR_WV;
+            const float* rv = V9_VEC(rs0) + wn * 64 + lq * 4;
             f32x4 val[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -897,7 +804,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (cmask & (1u << (4 * j + r)))
-                            val[j][r] += c4[r] >= 0 ? (have ? wr[c4[r] & (CORR_WV - 1)] : V9_VEC(max(c4[r], 0))[rl]) : 0.f;
+                            val[j][r] += c4[r] >= 0 ? V9_VEC(max(c4[r], 0))[rl] : 0.f;
                 }
             }
             if (row < a.M) {
@@ -955,14 +862,8 @@ int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, c
     if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
     const unsigned tiles = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256));
     const unsigned grid = tiles * (a.ngroup > 1 ? a.ngroup : 1) * (a.splits > 1 ? a.splits : 1);
-    // a.corr (mi355q_corr.h): the producers formed the exception add-back; the launch only reads it (and forms it itself,
-    // as without a.corr, when the producers' slots did not suffice: decided on the device)
-    const bool rec = fix && a.corr != nullptr && a.splits <= 1;
-    if (!rec) a.corr = nullptr;
     if (bf16) hipLaunchKernelGGL((bfp_gemm_v9<0, true, false>), grid, V9_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else if (!fix) hipLaunchKernelGGL((bfp_gemm_v9<0, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-    else if (rec && want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<2, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
-    else if (rec) hipLaunchKernelGGL((bfp_gemm_v9<2, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else if (want_stamps && a.stamps) hipLaunchKernelGGL((bfp_gemm_v9<1, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     else hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();

@@ -7,9 +7,6 @@
 namespace mi355q {
 
 // One quantiser launch: `lead` planes of rows x cols fp32 tiled by b0 x b1 blocks.
-struct CorrArgs;     // mi355q_corr.h
-struct CorrLaunch;
-
 struct QuantArgs {
     const float* x;
     float* y;          // fake-quantised fp32 (nullable for block_fp)
@@ -46,9 +43,8 @@ int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
 int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only = false, int fmt = 0 /* FMT_BFP; 1 = FMT_BM */);
 int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
                        int* list, int list_cap, int* list_to_clear, hipStream_t st);
-// corr (mi355q_corr.h, device memory): the weight operands whose correction vectors the activation quantiser forms (null: none)
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
-                            int* list_to_clear, hipStream_t st, int bcap, const CorrLaunch* corr = nullptr);
+                            int* list_to_clear, hipStream_t st, int bcap);
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
                        long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false,
                        const float* mask = nullptr, long long causal_off = -1, int fmt = 0);
@@ -102,8 +98,6 @@ struct GemmArgs {
     const uint8_t* g_wf[3];
     const float* g_bias[3];
     float* g_y[3];
-    const CorrArgs* corr;         // 256 x 256 tile kernel: the exception add-back as the producers formed it (mi355q_corr.h, device memory), null: none
-    int corr_which;               // ... which weight of the binding a single (not grouped) launch multiplies
     int x_mbits, w_mbits;         // mantissa bits of the operands (0: not given) -- the launcher's choice of kernel
     unsigned long long* stamps;   // diagnostic builds of the 256 x 256 tile kernel (MI355Q_V9_STAMPS): [workgroup][2][8] phase times
     // bf16 flavour: x as `x_segs` column segments (the rank-major result of an all-gather of per-rank quantised slices,

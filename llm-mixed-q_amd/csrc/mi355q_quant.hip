@@ -29,7 +29,6 @@
 #include "mi355q_internal.h"
 #include "mi355q_align.h"
 #include "mi355q_align_row.h"
-#include "mi355q_corr.h"
 
 #include "mi355q_quant_dev.h"
 
@@ -669,18 +668,14 @@ int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gsc
 // then writes the tiled mantissas, the effective exponents, rowflag[row] and the row scale.  cols % 64 == 0,
 // cols <= 1024 * MAXIT.
 // ---------------------------------------------------------------------------------------
-template <int MAXIT, bool FULL, bool SEG, bool CORR>
+template <int MAXIT, bool FULL, bool SEG>
 __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                                    uint8_t* __restrict__ flag, float* __restrict__ rscale,
                                                                    int exp_offset, int* __restrict__ list,
-                                                                   int* __restrict__ list_to_clear, int bcap, const CorrLaunch c) {
+                                                                   int* __restrict__ list_to_clear, int bcap) {
     __shared__ Lut lut;
     __shared__ RowAlignSmem rsm;
     __shared__ float norm_part[4];
-    // CORR (mi355q_corr.h): the row as the product's correction terms see it -- every block's 16 mantissa bytes (exception
-    // blocks as they were, the others shifted onto the row's exponent), its effective exponent, the row's exception blocks
-    // as one ballot per (slab, wave), the row's vector slot --, the binding and the first weight's plan records
-    __shared__ CorrSmem<CORR ? MAXIT : 1> csm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long K = a.cols;
     const int nkb = (int)(K >> 4), nit = (nkb + 63) >> 6;
@@ -788,7 +783,6 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
     // list clearing below run while it is in flight (a workgroup usually has exactly one row)
     float4 v[MAXIT];
     if ((long long)blockIdx.x < a.rows) load_row(v, row_of(blockIdx.x));
-    if constexpr (CORR) { if (!(c.dbg & 1)) corr_prefetch(c, csm); }
     load_lut<FMT_BFP>(lut);
     if (list_to_clear && blockIdx.x == 0) {
         const int cb = bcap < 0 ? ROW_BCAP : bcap;
@@ -796,20 +790,16 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
         if (tid < EXC_HEADER) list_to_clear[tid] = 0;
         for (long long b = EXC_HEADER + (long long)tid * bw; b < words; b += 256ll * bw) {
             list_to_clear[b] = 0;
-            list_to_clear[b + 1] = 0;                      // (rows of the bucket that took a vector slot, mi355q_corr.h)
+            list_to_clear[b + 1] = 0;
         }
     }
-    if (CORR && blockIdx.x == 0)                            // (rows past the operand have no vector)
-        for (long long r = a.rows + tid; r < c.dev->mpad; r += 256) c.dev->rowmap[r] = -1;
     const int mbits_int = (int)__builtin_log2f(a.shift);
     __syncthreads();
-    int cslot = -1;
-    long long crow = 0;
     // Several rows per workgroup (round 4, plain rows: launch_quant_align_rows): the NEXT row is requested as soon as this one's
     // values are dead -- behind the mantissas, in front of the exponent decision, its barriers and the stores -- into the same
     // registers: a row's life was load round trip + arithmetic + decision + stores in sequence, 4 workgroups a compute unit.
-    const bool early = a.pre_op == 0 && !CORR && !SEG;
-    for (long long wi = blockIdx.x; wi < a.rows && (!CORR || wi == (long long)blockIdx.x); wi += gridDim.x) {     // (CORR: one row per workgroup)
+    const bool early = a.pre_op == 0 && !SEG;
+    for (long long wi = blockIdx.x; wi < a.rows; wi += gridDim.x) {
         const long long row = row_of(wi);
         if (wi != (long long)blockIdx.x && !early) load_row(v, row);
         unsigned pk[MAXIT];
@@ -877,33 +867,7 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
         int E = 0;
         // bcap < 0: no alignment at all -- every block keeps its own exponent, rowflag 0 (operands for the blockwise
         // kernel: inputs whose block exponents spread too far for any row window, e.g. SiLU-gated MLP activations)
-        // CORR: the row as the correction terms see it goes to LDS around align_row -- first every block as quantised with
-        // its own exponent, then the blocks that joined the row's exponent shifted onto it (exception blocks stay)
-        if constexpr (CORR) {
-          if (!(c.dbg & 2)) {
-#pragma unroll
-            for (int it = 0; it < MAXIT; ++it) {
-                const int kb = it * 64 + wave * 16 + (lane >> 2);
-                const bool in = FULL || (it < nit && kb < nkb);
-                csm.blk[it * 256 + tid] = in ? pk[it] : 0u;
-                if ((lane & 3) == 0 && in) csm.eff[kb] = (unsigned char)code[it];
-            }
-          }
-        }
-        unsigned excb = 0u;
-        const bool flagged = bcap < 0 ? false : align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap, CORR ? &excb : nullptr);
-        if constexpr (CORR) {
-            if (flagged && !(c.dbg & 2)) {
-#pragma unroll
-                for (int it = 0; it < MAXIT; ++it) {
-                    const int kb = it * 64 + wave * 16 + (lane >> 2);
-                    if ((FULL || (it < nit && kb < nkb)) && !((excb >> it) & 1u)) {
-                        csm.blk[it * 256 + tid] = pk[it];
-                        if ((lane & 3) == 0) csm.eff[kb] = (unsigned char)E;
-                    }
-                }
-            }
-        }
+        const bool flagged = bcap < 0 ? false : align_row<MAXIT, FULL>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap);
         // tiled address of this lane's 4 bytes in slab 0 (block 16 wave + lane / 4: K-step 4 wave + lane / 16, 16-byte
         // block (lane / 4) & 3 of the piece, 256 bytes apart); a slab further on is 16 K-steps = 16 KiB further
         int8_t* dst = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + ((lane >> 2) & 3) * 256 +
@@ -921,39 +885,24 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             flag[row] = flagged ? 1 : 0;
             rscale[row] = flagged ? __builtin_ldexpf(1.0f, E - exp_offset) : 0.0f;
         }
-        // (behind the row's stores: only the packed mantissas are live across it)
-        if constexpr (CORR) { if (!(c.dbg & 4)) { cslot = corr_row<MAXIT>(csm, excb, flagged, row, list, bcap, c.dbg); crow = row; } }
         if (wi + gridDim.x < a.rows) __syncthreads();       // (the next row reuses the decision words in LDS)
-    }
-    // CORR: the vector of a row with exception blocks of its own, here where nothing of the row's arithmetic is live any more
-    // (its sixteen gathers per thread take the registers; inside the loop they cost the kernel a wave of occupancy)
-    if constexpr (CORR) {
-        if (cslot >= 0 && !(c.dbg & 8)) corr_xvec<MAXIT>(csm, K, crow, cslot);
     }
 }
 
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
-                            int* list_to_clear, hipStream_t st, int bcap, const CorrLaunch* corr) {
+                            int* list_to_clear, hipStream_t st, int bcap) {
     long long grid = a.rows;
     if (grid > 65536) grid = 65536;
     // plain rows: a fixed grid of 4 workgroups per compute unit, several rows each with the next row's loads in flight
     // (MI355Q_QROWS_GRID: 0 = one workgroup per row as before)
     static const int qgrid = getenv("MI355Q_QROWS_GRID") ? atoi(getenv("MI355Q_QROWS_GRID")) : 1024;
-    if (qgrid > 0 && a.pre_op == 0 && !corr && !a.seg_len && grid > qgrid) grid = qgrid;
+    if (qgrid > 0 && a.pre_op == 0 && !a.seg_len && grid > qgrid) grid = qgrid;
     if (grid < 1) grid = 1;
-    CorrLaunch c = corr ? *corr : CorrLaunch{};
-    static const int corr_dbg = getenv("MI355Q_CORR_DBG") ? atoi(getenv("MI355Q_CORR_DBG")) : 0;
-    c.dbg = corr_dbg;
-    // (the guarded flavour for every width: with the corrections the unguarded one allocates 139 registers -- three waves per
-    //  SIMD instead of four --, the guarded one 126)
-    const bool with_corr = corr && !a.seg_len && bcap >= 0 && list && a.rows <= 65536;       // (one row per workgroup)
 #define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
-    if (a.seg_len) hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, false, true, false>), (unsigned)grid, 256, 0, st, a, mt, flag,  \
-                                      rscale, exp_offset, list, list_to_clear, bcap, c);                               \
-    else if (with_corr) hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, false, false, true>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
-                            exp_offset, list, list_to_clear, bcap, c);                                                 \
-    else hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_, false, false>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
-                            exp_offset, list, list_to_clear, bcap, c)
+    if (a.seg_len) hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, false, true>), (unsigned)grid, 256, 0, st, a, mt, flag,  \
+                                      rscale, exp_offset, list, list_to_clear, bcap);                                  \
+    else hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_, false>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
+                            exp_offset, list, list_to_clear, bcap)
     if (a.cols == 4096) MI355Q_LAUNCH_ROWS(4, true);            // every lane holds a block in every slab: no guards
     else if (a.cols <= 4096) MI355Q_LAUNCH_ROWS(4, false);
     else if (a.cols == 8192) MI355Q_LAUNCH_ROWS(8, true);

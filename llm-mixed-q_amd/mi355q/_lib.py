@@ -69,16 +69,6 @@ SIGNATURES = {
     "mi355q_rope_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_bfp_gemm_aligned_multi": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp]),
-    "mi355q_bfp_corr_plan_bytes": (C.c_size_t, [_i64]),
-    "mi355q_bfp_corr_xvec_bytes": (C.c_size_t, [_i64, _i64]),
-    "mi355q_bfp_corr_wvec_bytes": (C.c_size_t, [_i64, _i64]),
-    "mi355q_bfp_corr_binding_bytes": (C.c_size_t, []),
-    "mi355q_bfp_corr_plan": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
-    "mi355q_bfp_corr_bind": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
-    "mi355q_block_fp_quantize_aligned_rows_corr": (C.c_int, [_vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                                             _i64, _i32, _i32, _i32, _vp, _vp]),
-    "mi355q_bfp_gemm_aligned_corr": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "mi355q_bfp_gemm_aligned_multi_corr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_gemm_timing_enable": (C.c_int, [C.c_int]),
     "mi355q_gemm_timing_read": (C.c_int, [_vp, _vp, _vp]),
     "mi355q_bfp_gemm_set_variant": (C.c_int, [C.c_int]),
@@ -91,12 +81,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-class CorrTarget(C.Structure):
-    """struct mi355q_bfp_corr_target"""
-    _fields_ = [("w", _vp), ("plan", _vp), ("xvec", _vp), ("wvec", _vp), ("N", _i64), ("slots_in_use", _i32), ("reserved", _i32)]
-
-
-ABI_VERSION = 20
+ABI_VERSION = 21
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

@@ -699,103 +699,6 @@ def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: 
                           bucket_cap=bucket_cap)
 
 
-# ---- exception corrections formed by the producers (include/mi355q.h, "exception corrections formed by the PRODUCERS";
-#      csrc/mi355q_corr.h): the activation quantiser writes what the exception blocks of both operands contribute, the
-#      row-scale GEMM only reads it.  OFF by default: at 4096^3 W6A6 the product launch drops from 64.0 to 58.3 us, but the
-#      quantiser's share (staging the row, 111 column values per row, the 219 row vectors) costs it 17 us
-#      (profiles/r04_corr_breakdown.txt); MI355Q_CORR=1 / ops.CORR = True switches it on.
-CORR = _os.environ.get("MI355Q_CORR", "0") == "1"
-CORR_MAX_WEIGHTS = 3
-
-
-def corr_plan(w: "AlignedOperand") -> torch.Tensor:
-    """the weight operand's correction plan (entries sorted, column slots, column map, dense records), built once; its
-    header {not usable, column slots in use} is read back once (w._corr_info) unless a graph is being captured"""
-    plan = getattr(w, "_corr_plan", None)
-    if plan is None:
-        import ctypes
-        lib = _lib.load_library()
-        plan = torch.zeros(lib.mi355q_bfp_corr_plan_bytes(w.rows) // 4, dtype=torch.int32, device=w.tiled.device)
-        w.c_struct()
-        info = (ctypes.c_int32 * 2)(0, -1)
-        with _on_device(w.tiled.device):
-            rc = lib.mi355q_bfp_corr_plan(w._cs_addr, w.rows, _ptr(plan), None if _capturing() else ctypes.addressof(info),
-                                          _stream_ptr(w.tiled.device))
-        _lib.check(rc, "mi355q_bfp_corr_plan")
-        w._corr_plan = plan
-        w._corr_info = (int(info[0]), int(info[1]))
-    return plan
-
-
-def corr_supported(M: int, K: int, ws, bucket_cap: int) -> bool:
-    """whether a launch of x [M, K] against the weight operands `ws` (one launch: a single weight or a q / k / v group) takes
-    the kernel that reads producer-formed corrections: row-aligned weights with 120-entry buckets and lists, equal shapes and
-    exponent offsets, 256-row tiles (the launch rule of mi355q_gemm_v8.hip), no split-K"""
-    if not CORR or not ws or len(ws) > CORR_MAX_WEIGHTS or bucket_cap != ROW_BUCKET_CAP or not row_align_supported(K):
-        return False
-    w0 = ws[0]
-    for w in ws:
-        if (not w.row_aligned or w.unaligned or w.sparse is None or w.list_cap != ROW_BUCKET_CAP or w.K != K
-                or w.rows != w0.rows or w.mbits + w.exp_bias != w0.mbits + w0.exp_bias):
-            return False
-    N = w0.rows
-    tn = -(-N // 256) * len(ws)
-    t256, t128 = -(-M // 256) * tn, -(-M // 128) * tn
-    if -(-t128 // 256) * 0.82 < -(-t256 // 256) * 1.0:           # (128-row tiles: the round-2 kernel, which forms its own)
-        return False
-    return t256 >= 129 or (K // 64) < 64                          # (under-filled grids split K: not with a binding)
-
-
-class CorrBinding:
-    """device-resident description of what the quantiser of x [M, K] forms for the weight operands `ws` (the vectors live in
-    buffers shared by every weight set of the same shapes on the stream: they are transient, written by the quantiser and
-    read by the GEMM launch(es) right behind it)"""
-    __slots__ = ("ws", "M", "shared", "buf", "keep")
-
-    def index_of(self, w) -> int:
-        for i, v in enumerate(self.ws):
-            if v is w:
-                return i
-        return -1
-
-
-_CORR_SHARED = _StreamCache(32)
-
-
-def _corr_binding(device, sp, M: int, K: int, x_mbits: int, x_exp_bias: int, ws) -> CorrBinding:
-    import ctypes
-    key = (sp, M, x_mbits, x_exp_bias) + tuple(id(w) for w in ws[1:])
-    table = ws[0].__dict__.setdefault("_corr_bindings", {})
-    b = table.get(key)
-    if b is not None:
-        return b
-    lib = _lib.load_library()
-    N = ws[0].rows
-    skey = (device.index, sp, "corr", M, N, len(ws))
-    shared = _CORR_SHARED.get(skey)
-    if shared is None:
-        shared = dict(
-            rowmap=torch.full(((M + 255) // 256 * 256,), -1, dtype=torch.int32, device=device),
-            xvec=[torch.empty(lib.mi355q_bfp_corr_xvec_bytes(M, N) // 4, dtype=torch.float32, device=device) for _ in ws],
-            wvec=[torch.empty(lib.mi355q_bfp_corr_wvec_bytes(M, N) // 4, dtype=torch.float32, device=device) for _ in ws])
-        _CORR_SHARED.put(skey, shared)
-    b = CorrBinding()
-    b.ws, b.M, b.shared = tuple(ws), M, shared
-    b.buf = torch.zeros(lib.mi355q_bfp_corr_binding_bytes(), dtype=torch.uint8, device=device)
-    targets = (_lib.CorrTarget * len(ws))()
-    plans = [corr_plan(w) for w in ws]
-    for i, w in enumerate(ws):
-        w.c_struct()
-        targets[i] = _lib.CorrTarget(w._cs_addr, _ptr(plans[i]), _ptr(shared["xvec"][i]), _ptr(shared["wvec"][i]), N, w._corr_info[1], 0)
-    b.keep = (targets, plans)
-    with _on_device(device):
-        rc = lib.mi355q_bfp_corr_bind(_ptr(b.buf), _ptr(shared["rowmap"]), M, x_mbits, x_exp_bias, ctypes.addressof(targets),
-                                      len(ws), sp)
-    _lib.check(rc, "mi355q_bfp_corr_bind")
-    table[key] = b
-    return b
-
-
 def _wrote_into(t: torch.Tensor) -> None:
     """a kernel of this library has just written into a caller-provided tensor through its raw pointer: move its version
     counter like an in-place torch op would (version-keyed caches -- the quantised-activation reuse below, autograd's
@@ -897,7 +800,7 @@ def _record_operand(buf, x, sig, operand):
 
 
 def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: int, exponent_bias,
-                                   bucket_cap: int = None, pre=None, segments: bool = False, against=None) -> AlignedOperand:
+                                   bucket_cap: int = None, pre=None, segments: bool = False) -> AlignedOperand:
     """Fused activation path, ROW-aligned flavour: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack +
     row-align + tile in one kernel (K % 64 == 0, K <= ROW_ALIGN_MAX_K).  Buffers are reused per shape and
     stream like block_fp_quantize_aligned's.  `bucket_cap`: exception entries per 256 rows (default
@@ -905,11 +808,7 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     no alignment at all, every block keeps its exponent and the GEMM takes its blockwise-exact kernel.
     `segments`: x is [P, rows, K / P] -- the rank-major result of the all-gather over out_features shards
     (sharded.ShardedRows): row r of the [rows, K] tensor is the concatenation of x[0, r], x[1, r], ...; read in place
-    (mi355q_block_fp_quantize_aligned_rows_seg), the same operand as from the re-assembled tensor.
-    `against`: the row-aligned weight operand(s) ONE launch of the GEMM will multiply this x with (a list of up to three: a
-    q / k / v or gate / up group) -- the quantiser then also forms the exception corrections of those products
-    (mi355q_block_fp_quantize_aligned_rows_corr) and the operand carries the binding (`operand.corr`) that
-    bfp_gemm_aligned / bfp_gemm_aligned_multi hand to the product launch.  Results never depend on it."""
+    (mi355q_block_fp_quantize_aligned_rows_seg), the same operand as from the re-assembled tensor."""
     bucket_cap = ACTIVATION_BUCKET_CAP if bucket_cap is None else int(bucket_cap)
     _require_device(x, "block_fp_quantize_aligned_rows")
     if segments:
@@ -926,14 +825,7 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     bias = _default_bias(exponent_bias)
     # (the record is only good inside the capture sequence -- or the eager stretch -- it was made in: a hit while a graph
     #  is being recorded on a record from the warm-up would leave the quantiser out of the graph)
-    if against is not None and not isinstance(against, (list, tuple)):
-        against = [against]
-    binding = None
-    if against and not segments and corr_supported(rows, K, against, bucket_cap):
-        eb_ = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
-        binding = _corr_binding(x.device, sp, rows, K, int(width) - 1, eb_, list(against))
-    sig = (int(width), int(exponent_width), bias, bucket_cap, _lib.load_library().mi355q_stream_capture_id(sp), nseg,
-           id(binding) if binding is not None else 0)
+    sig = (int(width), int(exponent_width), bias, bucket_cap, _lib.load_library().mi355q_stream_capture_id(sp), nseg)
     again = _recorded_operand(buf, x, sig) if pre is None else None
     if again is not None:
         return again
@@ -950,21 +842,14 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
         cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
         buf["calls"] += 1
     with _on_device(x.device):
-        if binding is not None:
-            rc = lib.mi355q_block_fp_quantize_aligned_rows_corr(_ptr(xc), _ptr(other), _ptr(third), pre_op, eps, _ptr(buf["tiled"]),
-                                                                _ptr(buf["exp"]), _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur),
-                                                                _ptr(nxt), rows, K, int(width), int(exponent_width), bias,
-                                                                _ptr(binding.buf), sp)
-        else:
-            rc = lib.mi355q_block_fp_quantize_aligned_rows_seg(_ptr(xc), _ptr(other), _ptr(third), pre_op, eps, _ptr(buf["tiled"]),
-                                                               _ptr(buf["exp"]), _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur),
-                                                               _ptr(nxt), rows, K, seg_len, rows * seg_len, int(width),
-                                                               int(exponent_width), bias, bucket_cap, sp)
-    _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows_corr" if binding is not None else "mi355q_block_fp_quantize_aligned_rows_seg")
+        rc = lib.mi355q_block_fp_quantize_aligned_rows_seg(_ptr(xc), _ptr(other), _ptr(third), pre_op, eps, _ptr(buf["tiled"]),
+                                                           _ptr(buf["exp"]), _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur),
+                                                           _ptr(nxt), rows, K, seg_len, rows * seg_len, int(width),
+                                                           int(exponent_width), bias, bucket_cap, sp)
+    _lib.check(rc, "mi355q_block_fp_quantize_aligned_rows_seg")
     eb = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
     operand = AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
                              int(width) - 1, eb, row_aligned=True, bucket_cap=bucket_cap)
-    operand.corr = binding
     if pre is None:
         _record_operand(buf, x, sig, operand)
     else:
@@ -984,14 +869,8 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     lib = _lib.load_library()
     sp = _stream_ptr(x.tiled.device)
     x.c_struct(), w.c_struct()
-    binding = getattr(x, "corr", None)
-    which = binding.index_of(w) if binding is not None else -1
     with _on_device(x.tiled.device):
-        if which >= 0:
-            rc = lib.mi355q_bfp_gemm_aligned_corr(x._cs_addr, w._cs_addr, _ptr(binding.buf), which, _ptr(bias), _ptr(out), M, N, K,
-                                                  ldy, sp)
-        else:
-            rc = lib.mi355q_bfp_gemm_aligned(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(out), M, N, K, ldy, sp)
+        rc = lib.mi355q_bfp_gemm_aligned(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(out), M, N, K, ldy, sp)
     _lib.check(rc, "mi355q_bfp_gemm_aligned")
     if given:
         _wrote_into(out)
@@ -1013,17 +892,9 @@ def bfp_gemm_aligned_multi(x: AlignedOperand, ws, biases=None):
     wp = (ctypes.c_void_p * n)(*[w._cs_addr for w in ws])
     bp = (ctypes.c_void_p * n)(*[(_ptr(b) if b is not None else None) for b in (biases or [None] * n)])
     yp = (ctypes.c_void_p * n)(*[_ptr(o) for o in outs])
-    binding = getattr(x, "corr", None)
-    if binding is not None and not (len(binding.ws) == n and all(a is b for a, b in zip(binding.ws, ws))):
-        binding = None                                  # (formed for another weight set: the launch forms its own add-back)
     with _on_device(x.tiled.device):
-        if binding is not None:
-            rc = _lib.load_library().mi355q_bfp_gemm_aligned_multi_corr(x._cs_addr, ctypes.addressof(wp), _ptr(binding.buf),
-                                                                       ctypes.addressof(bp), ctypes.addressof(yp), n, M, N, K, N,
-                                                                       _stream_ptr(x.tiled.device))
-        else:
-            rc = _lib.load_library().mi355q_bfp_gemm_aligned_multi(x._cs_addr, ctypes.addressof(wp), ctypes.addressof(bp), ctypes.addressof(yp),
-                                                                  n, M, N, K, N, _stream_ptr(x.tiled.device))
+        rc = _lib.load_library().mi355q_bfp_gemm_aligned_multi(x._cs_addr, ctypes.addressof(wp), ctypes.addressof(bp), ctypes.addressof(yp),
+                                                              n, M, N, K, N, _stream_ptr(x.tiled.device))
     if rc == _lib.E_UNSUPPORTED:
         return None
     _lib.check(rc, "mi355q_bfp_gemm_aligned_multi")

@@ -5,7 +5,6 @@ os.environ["MI355Q_V9_STAMPS"] = "1"
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import numpy as np, torch, bench
 from mi355q import ops, _lib
-ops.CORR = 'corr' in sys.argv
 import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False
 dev = torch.device('cuda:0')
 x, w, b = bench.make_inputs(torch, dev, 0)
@@ -14,7 +13,7 @@ wa = ops.bfp_align_rows(wm, we, 5, 127); bq = ops.block_fp_quantize(b, 6, 8, 127
 y = torch.empty(4096, 4096, device=dev)
 lib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.__file__), "libmi355q.so"))
 stamps = torch.zeros(256 * 2 * 8, dtype=torch.int64, device=dev)
-xa = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127, against=wa if 'corr' in sys.argv else None)   # (corr: producer-formed add-back)
+xa = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127)
 t_end = time.time() + 0.15
 while time.time() < t_end:
     for _ in range(10): ops.bfp_gemm_aligned(xa, wa, bq, out=y)
