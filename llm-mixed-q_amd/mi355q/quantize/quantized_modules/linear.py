@@ -49,6 +49,50 @@ def _make_quantizer(arith: str, config: dict, prefix: str, skip_first_dim: bool)
     return partial(QUANTIZER_MAP[arith], **kw)
 
 
+def _bf16_planes(t):
+    """fp32 [rows, K] -> (hi, lo) with hi + lo = t to 2^-17 relative: hi = t rounded to bf16, lo the remainder (rounded to bf16
+    when it is tiled).  A gradient is not a quantised value: one bf16 plane would cost it 2^-9."""
+    hi = t.to(torch.bfloat16).to(torch.float32)
+    return hi, t - hi
+
+
+class _TileLinear(torch.autograd.Function):
+    """y = x_q . W_q^T + b_q on the bf16 tile GEMM (operands exact in bf16, fp32 accumulation), and its backward as two more
+    products on the same kernel: dX = dY . W_q, dW = dY^T . x_q, db = sum dY (reference: torch.autograd through F.linear,
+    quantized_modules/linear.py:72-76; the quantisers' straight-through estimators stay where they are).  dY enters as two
+    bf16 planes (hi + lo): four launches per backward."""
+
+    @staticmethod
+    def forward(ctx, xq, wq, bq):
+        K, N = wq.shape[1], wq.shape[0]
+        x2 = xq.reshape(-1, K).contiguous()
+        y = ops.bf16_gemm_tiled(ops.bf16_tile(x2), ops.bf16_tile(wq.contiguous()), x2.shape[0], N, K, bq)
+        ctx.save_for_backward(x2, wq)
+        ctx.lead, ctx.has_bias = xq.shape[:-1], bq is not None
+        return y.reshape(*xq.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wq = ctx.saved_tensors
+        M, K, N = x2.shape[0], x2.shape[1], wq.shape[0]
+        dy2 = dy.reshape(M, N).contiguous().to(torch.float32)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:                              # dX [M, K] = dY [M, N] . (W_q^T [K, N])^T
+            wt = ops.bf16_tile(wq.t().contiguous())
+            hi, lo = _bf16_planes(dy2)
+            dx = ops.bf16_gemm_tiled(ops.bf16_tile(hi), wt, M, K, N)
+            dx += ops.bf16_gemm_tiled(ops.bf16_tile(lo), wt, M, K, N)
+            dx = dx.reshape(*ctx.lead, K)
+        if ctx.needs_input_grad[1]:                              # dW [N, K] = dY^T [N, M] . (x_q^T [K, M])^T
+            xt = ops.bf16_tile(x2.t().contiguous())
+            hi, lo = _bf16_planes(dy2.t().contiguous())
+            dw = ops.bf16_gemm_tiled(ops.bf16_tile(hi), xt, N, K, M)
+            dw += ops.bf16_gemm_tiled(ops.bf16_tile(lo), xt, N, K, M)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
 class _LinearBase(nn.Linear):
     arith: str = None
 
@@ -386,7 +430,26 @@ class _LinearBase(nn.Linear):
         x = self.x_quantizer(x)
         w = self.w_quantizer(self.weight)
         bias = self.b_quantizer(self.bias) if self.bias is not None else None
+        if self._qat_on_tile_gemm(x):
+            return _TileLinear.apply(x, w, bias)
         return F.linear(x, w, bias)
+
+    def _qat_on_tile_gemm(self, xq) -> bool:
+        """QAT (is_ptq = False, linear.py:72-76: x, W and b re-quantised every call, straight-through gradients): the product
+        F.linear(x_q, W_q, b_q) and its two backward products on the bf16 flavour of the tile GEMM instead of the library's fp32
+        GEMM at a sixteenth of its rate -- when the quantised values are exact in bf16 (block_fp of <= 9 bits, minifloats of
+        <= 7 mantissa bits, powers of two) and every contraction length is a whole number of 64-byte K-steps.
+        config["mi355q_qat_gemm"] = "fp32" keeps F.linear."""
+        c = self.config
+        if c.get("mi355q_qat_gemm", "bf16") != "bf16" or not (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32):
+            return False
+        if self.arith == "block_fp":
+            if not (2 <= c["data_in_width"] <= 9 and 2 <= c["weight_width"] <= 9):
+                return False
+        elif not self._values_exact_in_bf16(xq):
+            return False
+        M = xq.numel() // self.in_features
+        return self.in_features % 32 == 0 and self.out_features % 32 == 0 and M % 32 == 0 and M > 0
 
     def _values_exact_in_bf16(self, xq) -> bool:   # (xq: the layer's input, quantised or not: only its placement matters)
         """block_minifloat / block_log PTQ layers (linear.py:145-203; likewise the un-blocked minifloat_ieee / minifloat_denorm

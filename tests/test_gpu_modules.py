@@ -219,6 +219,62 @@ def test_qat_forward_backward_ste():
     np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), np.tile(xq.sum(0), (32, 1)), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("arith", ["block_fp", "block_minifloat", "block_log"])
+def test_qat_on_the_tile_gemm_gradients(arith):
+    """is_ptq = False at an OPT-350m layer shape (fc1: 1024 -> 4096, 512 tokens): forward and both backward products on the bf16
+    tile GEMM (quantised operands exact in bf16; the gradient dY as two bf16 planes) against the oracle's quantisers and
+    float64 products -- reference: autograd through F.linear(x_q, W_q, b_q), quantized_modules/linear.py:72-76, with the
+    quantisers' straight-through estimators (block_fp.py:119-124); mi355q_qat_gemm = "fp32" gives the library route and the
+    same numbers to fp32 accuracy"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q.quantize.quantized_modules import linear as L
+    from oracle import np_oracle as O
+    cfg6 = dict(name="block_fp", bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127, data_in_block_size=[1, 16],
+                weight_width=6, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=6,
+                bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+    cfg = {"block_fp": dict(cfg6, is_ptq=False),
+           "block_minifloat": dict(name="block_minifloat", is_ptq=False, bypass=False, data_in_width=8, data_in_exponent_width=4, data_in_exponent_bias_width=8,
+                                   data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4, weight_exponent_bias_width=8, weight_block_size=[1, 16],
+                                   bias_width=8, bias_exponent_width=4, bias_exponent_bias_width=8, bias_block_size=[16]),
+           "block_log": dict(name="block_log", is_ptq=False, bypass=False, data_in_width=8, data_in_exponent_bias_width=8, data_in_block_size=[1, 16],
+                             weight_width=8, weight_exponent_bias_width=8, weight_block_size=[1, 16], bias_width=8, bias_exponent_bias_width=8,
+                             bias_block_size=[16])}[arith]
+    M, K, N = 512, 1024, 4096
+    torch.manual_seed(3)
+    scale = 4.0 if arith == "block_minifloat" else 1.0           # (block_minifloat flushes |w| << 1 to zero: SURVEY quirk 5)
+    lin = Q.get_quantized_cls("linear", cfg)(K, N, config=cfg).to("cuda:0")
+    with torch.no_grad():
+        lin.weight.mul_(32.0 * scale)
+    x = (torch.randn(M, K, device="cuda:0") * scale).requires_grad_(True)
+    dy = torch.randn(M, N, device="cuda:0")
+    calls, real = [], L.ops.bf16_gemm_tiled
+    L.ops.bf16_gemm_tiled = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        y = lin(x)
+        y.backward(dy)
+    finally:
+        L.ops.bf16_gemm_tiled = real
+    assert len(calls) == 5, len(calls)                           # forward + 2 planes x (dX, dW)
+    quant = {"block_fp": lambda t, p, skip: O.block_fp_quantize(t, cfg[p + "_width"], 8, 127, cfg[p + "_block_size"], skip),
+             "block_minifloat": lambda t, p, skip: O.block_minifloat_quantize(t, 8, 4, 8, cfg[p + "_block_size"], skip),
+             "block_log": lambda t, p, skip: O.block_log_quantize(t, 8, 8, cfg[p + "_block_size"], skip)}[arith]
+    xq = quant(x.detach().cpu().numpy(), "data_in", True).astype(np.float64)
+    wq = quant(lin.weight.detach().cpu().numpy(), "weight", False).astype(np.float64)
+    bq = quant(lin.bias.detach().cpu().numpy(), "bias", False).astype(np.float64)
+    g = dy.cpu().numpy().astype(np.float64)
+    for name, got, ref in (("y", y, xq @ wq.T + bq), ("dX", x.grad, g @ wq), ("dW", lin.weight.grad, g.T @ xq), ("db", lin.bias.grad, g.sum(0))):
+        err = float(np.abs(got.detach().cpu().numpy() - ref).max() / np.abs(ref).max())
+        assert err < 2e-5, (arith, name, err)
+    # the library route (F.linear forward and backward) on the same module: same numbers to fp32 accuracy
+    lin2 = Q.get_quantized_cls("linear", dict(cfg, mi355q_qat_gemm="fp32"))(K, N, config=dict(cfg, mi355q_qat_gemm="fp32")).to("cuda:0")
+    lin2.load_state_dict(lin.state_dict())
+    x2 = x.detach().clone().requires_grad_(True)
+    lin2(x2).backward(dy)
+    assert float((x2.grad - x.grad).abs().max() / x.grad.abs().max()) < 2e-5
+    assert float((lin2.weight.grad - lin.weight.grad).abs().max() / lin.weight.grad.abs().max()) < 2e-5
+
+
 def test_requantize_after_weight_reload():
     import torch
     import mi355q.quantize as Q
