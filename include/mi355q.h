@@ -365,6 +365,31 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);
 
+/* ---- W4A4 / W5A5 block_fp Linear on the MX scaled matrix instruction (ABI 21) -------------------------------------------
+ * replaces: quantized_modules/linear.py:59-76 (F.linear(x_q, W_q, b_q)) at the widths of
+ *           experiments/emnlp/configs/quantization/bfp_4bit.toml and the section-4.4 search
+ *           (experiments/emnlp/configs/search/opt_1.3b_sst2.toml:24-37): block_fp mantissas of <= 4 bits are exact in FP6 e2m3,
+ *           the [1,16] blocks' shared exponents go into the E8M0 scales of v_mfma_scale_f32_16x16x128_f8f6f4 (twice the int8
+ *           MFMA rate per unit of K): no row alignment, no exception lists.
+ * mi355q_block_fp_quantize_mx: x [rows, K] fp32 (K % 128 == 0, K <= MI355Q_ROW_ALIGN_MAX_K, width <= 5; the weights go
+ *   through the same call with their own parameters) -> three planes in the product's tile order, each
+ *   mi355q_mx_plane_bytes(rows, K, plane) bytes (plane 0: 16 of a lane's 24 code bytes, 1: the other 8, 2: scales); 16-byte
+ *   aligned.  The two blocks of a 32-group share a scale; the block with the larger exponent carries its mantissas shifted
+ *   left by the difference.  A group whose blocks lie too far apart for that (> 3 exponents at W4, > 2 at W5) RAISES *bad
+ *   (never cleared by the call that raises it; `bad_to_clear`, nullable, != bad, is zeroed: callers alternate between two
+ *   words, each call clearing the next call's).
+ * mi355q_mx_gemm: y = x_q . w_q^T (+ bias), fp32 accumulation.  bad2[0] / bad2[1]: the flag words of x / w.  If either is
+ *   raised the launch forms the exact product from x_fp32 (quantised in registers with x's parameters) and w_fp32 (the
+ *   fake-quantised weights) itself -- decided on the device, uniform over the grid, ~10x slower: callers move such a layer to
+ *   another route (quantized_modules/linear.py here: `auto`).  Results within fp32 accumulation of the exact integer
+ *   contraction either way. */
+size_t mi355q_mx_plane_bytes(int64_t rows, int64_t K, int32_t plane);
+int mi355q_block_fp_quantize_mx(const float* x, uint8_t* codes16, uint8_t* codes8, uint8_t* scales, int32_t* bad, int32_t* bad_to_clear,
+                                int64_t rows, int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias, void* stream);
+int mi355q_mx_gemm(const uint8_t* x16, const uint8_t* x8, const uint8_t* xs, const uint8_t* w16, const uint8_t* w8, const uint8_t* ws,
+                   const int32_t* bad2, const float* x_fp32, const float* w_fp32, const float* bias, float* y, int64_t M, int64_t N,
+                   int64_t K, int64_t ldy, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, void* stream);
+
 /* Several weight operands of the SAME shape against ONE activation operand in one launch (the q / k / v projections of an
  * attention block, gate / up of a gated MLP: reference modules called one after the other on the same input,
  * modeling_opt.py:231-245, modeling_llama.py:216,283-287): y[i] = x . w[i]^T + bias[i].  The column tiles of all of them

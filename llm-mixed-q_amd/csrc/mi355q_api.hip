@@ -645,6 +645,69 @@ int mi355q_bfp_gemm_aligned_multi(const mi355q_bfp_operand* x, const mi355q_bfp_
     return gemm_aligned_multi_impl(x, w, bias, y, count, M, N, K, ldy, stream);
 }
 
+// ---- W4A4 / W5A5 on the MX scaled matrix instruction (mi355q_mx.hip)
+size_t mi355q_mx_plane_bytes(int64_t rows, int64_t K, int32_t plane) {
+    if (rows <= 0 || K <= 0 || plane < 0 || plane > 2) return 0;
+    const size_t rp = (size_t)((rows + 255) / 256 * 256), kp = (size_t)((K + 127) / 128 * 128);
+    return plane == 0 ? rp * kp / 2 : (plane == 1 ? rp * kp / 4 : rp * kp / 32);
+}
+
+static int mx_quant_args(QuantArgs& a, const float* x, int64_t rows, int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias) {
+    if (rows < 0 || K < 0) return MI355Q_E_BADARG;
+    if (K % 128 != 0 || K > MI355Q_ROW_ALIGN_MAX_K) return MI355Q_E_UNSUPPORTED;
+    if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 5) return MI355Q_E_UNSUPPORTED;   // <= 4 mantissa bits: exact in e2m3
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias < 0) return MI355Q_E_UNSUPPORTED;
+    a = QuantArgs{};
+    a.x = x;
+    a.lead = 1; a.rows = rows; a.cols = K;
+    a.b0 = 1; a.b1 = 16;
+    a.n_elems = rows * K;
+    a.nbr = rows; a.nbc = K / 16;
+    a.n_blocks = rows * (K / 16);
+    a.flags = MI355Q_ZERO_BLOCK_FAST;
+    a.code_bias = exponent_bias;
+    a.e_min = -exponent_bias;
+    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    set_mantissa(a, width - 1);
+    return 0;
+}
+
+int mi355q_block_fp_quantize_mx(const float* x, uint8_t* codes16, uint8_t* codes8, uint8_t* scales, int32_t* bad, int32_t* bad_to_clear,
+                                int64_t rows, int64_t K, int32_t width, int32_t exponent_width, int32_t exponent_bias, void* stream) {
+    QuantArgs a;
+    if (const int rc = mx_quant_args(a, x, rows, K, width, exponent_width, exponent_bias)) return rc;
+    if (rows == 0 || K == 0) return 0;
+    if (!x || !codes16 || !codes8 || !scales || !bad) return MI355Q_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(codes16) | reinterpret_cast<uintptr_t>(codes8) | reinterpret_cast<uintptr_t>(scales)) % 16)
+        return MI355Q_E_ALIGN;
+    if (bad_to_clear == bad) return MI355Q_E_BADARG;
+    return launch_quant_mx_rows(a, codes16, codes8, scales, bad, bad_to_clear, static_cast<hipStream_t>(stream));
+}
+
+int mi355q_mx_gemm(const uint8_t* x16, const uint8_t* x8, const uint8_t* xs, const uint8_t* w16, const uint8_t* w8, const uint8_t* ws,
+                   const int32_t* bad2, const float* x_fp32, const float* w_fp32, const float* bias, float* y, int64_t M, int64_t N,
+                   int64_t K, int64_t ldy, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, void* stream) {
+    if (M < 0 || N < 0 || ldy < N) return MI355Q_E_BADARG;
+    MxGemmArgs a{};
+    if (const int rc = mx_quant_args(a.qx, x_fp32, M, K, x_width, x_exponent_width, x_exponent_bias)) return rc;
+    if (M == 0 || N == 0) return 0;
+    if (K == 0 || !x16 || !x8 || !xs || !w16 || !w8 || !ws || !bad2 || !x_fp32 || !w_fp32 || !y) return MI355Q_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x16) | reinterpret_cast<uintptr_t>(x8) | reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(w16) |
+         reinterpret_cast<uintptr_t>(w8) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(x_fp32) | reinterpret_cast<uintptr_t>(w_fp32)) % 16)
+        return MI355Q_E_ALIGN;
+    a.x16 = x16; a.x8 = x8; a.xs = xs; a.w16 = w16; a.w8 = w8; a.ws = ws;
+    a.bad = bad2;
+    a.xf = x_fp32; a.wf = w_fp32;
+    a.bias = bias; a.y = y;
+    a.M = M; a.N = N; a.K = K; a.ldy = ldy;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t te = g_timing.begin(st);
+    const int rc = launch_mx_gemm(a, st);
+    g_timing.end(te, st);
+    return rc;
+}
+
 size_t mi355q_bfp_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N) {
     if (B <= 0 || K <= 0 || N <= 0) return 0;
     return (size_t)B * (size_t)((K + 63) / 64 * 64) * (size_t)N * 2 + 64;

@@ -123,6 +123,18 @@ int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf
 int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
                      long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
                      long long K, hipStream_t st);
+// W4A4 / W5A5 on the MX scaled matrix instruction (mi355q_mx.hip; operand planes: mi355q_quant.hip, MxOut)
+int launch_quant_mx_rows(const QuantArgs& a, uint8_t* c16, uint8_t* c8, uint8_t* sc, int* bad, int* bad_clear, hipStream_t st);
+struct MxGemmArgs {
+    const uint8_t *x16, *x8, *xs, *w16, *w8, *ws;     // the two operands
+    const int* bad;                                   // [2]: raised by the quantisers of x / w
+    const float *xf, *wf;                             // the fp32 tensors the operands were made from (x: NOT quantised, w: fake-quantised)
+    const float* bias;
+    float* y;
+    long long M, N, K, ldy;
+    QuantArgs qx;                                     // x's quantiser parameters (the exact route)
+};
+int launch_mx_gemm(const MxGemmArgs& a, hipStream_t st);
 int launch_bfp_gemm_v6(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
                        const int* xlist, const int* wlist, int list_cap, hipStream_t st);
 

@@ -668,11 +668,25 @@ int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gsc
 // then writes the tiled mantissas, the effective exponents, rowflag[row] and the row scale.  cols % 64 == 0,
 // cols <= 1024 * MAXIT.
 // ---------------------------------------------------------------------------------------
-template <int MAXIT, bool FULL, bool SEG>
+// MX flavour (round 5, mi355q_mx.hip): the same row arithmetic, the operand written for v_mfma_scale_f32_16x16x128_f8f6f4
+// instead -- FP6 e2m3 codes of the integer mantissas (32 values = 24 bytes per lane of the MFMA: 16 bytes in one plane, 8 in
+// another, both in the tile order of the product's LDS stages) and one E8M0 scale byte per 32 values.  The two [1,16] blocks
+// of a 32-group share the scale: the block with the larger exponent carries its mantissas shifted left by the difference
+// (|m| << s <= 60 with <= 4 significant bits is exact in e2m3: s <= 3 at W4, s <= 2 at W5).  A pair that does not fit raises
+// *mx.bad: the product launch then forms the exact product from the fp32 tensors itself (uniform over its grid).
+struct MxOut {
+    uint8_t* c16;     // [rows / 16][K / 128] pieces of 1 KiB: [32-group 0..3][row 0..15][16 bytes]
+    uint8_t* c8;      // [rows / 32][K / 128] pieces of 1 KiB: [16-row half 0..1][32-group 0..3][row 0..15][8 bytes]
+    uint8_t* sc;      // [rows / 64][K / 128] pieces of 256 B: [32-group 0..3][row 0..15][16-row quarter 0..3]
+    int* bad;
+    int* bad_clear;   // the flag word of the NEXT call (callers alternate between two): cleared here, by one thread
+};
+
+template <int MAXIT, bool FULL, bool SEG, bool MX = false>
 __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                                    uint8_t* __restrict__ flag, float* __restrict__ rscale,
                                                                    int exp_offset, int* __restrict__ list,
-                                                                   int* __restrict__ list_to_clear, int bcap) {
+                                                                   int* __restrict__ list_to_clear, int bcap, const MxOut mx = MxOut{}) {
     __shared__ Lut lut;
     __shared__ RowAlignSmem rsm;
     __shared__ float norm_part[4];
@@ -864,6 +878,55 @@ __global__ __launch_bounds__(256) void bfp_quant_align_rows_kernel(const QuantAr
             }
         }
         if (early && wi + gridDim.x < a.rows) load_raw(v, row_of(wi + gridDim.x));
+        if constexpr (MX) {
+            if (wi == 0 && tid == 0 && mx.bad_clear) *mx.bad_clear = 0;
+            const long long kp = K >> 7;
+            const int q = lane & 3;
+            bool bad = false;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int kb = it * 64 + wave * 16 + (lane >> 2);
+                // the partner block kb ^ 1 of the 32-group lives four lanes away
+                const int pc = __shfl_xor(code[it], 4), pa = __shfl_xor(amax[it], 4);
+                const bool nz = amax[it] > 0, pnz = pa > 0;
+                const int elo = nz ? (pnz ? min(code[it], pc) : code[it]) : (pnz ? pc : code[it]);
+                const int sft = nz ? code[it] - elo : 0;
+                int S = 127 + elo - a.code_bias - mbits_int + 3;          // E8M0: code 2^s m / 8 times 2^(S - 127) = m 2^(e - mbits)
+                const bool ok = (!nz || (sft <= 3 && (amax[it] << sft) <= 60)) && S >= 0 && S <= 254;
+                bad = bad || ((FULL || (it < nit && kb < nkb)) && !ok);
+                S = clampi(S, 0, 254);
+                const int sh = min(sft, 3);
+                unsigned c24 = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = (int)(signed char)(pk[it] >> (8 * j));
+                    // e2m3 code of the integer vv = |m| << s (<= 60, <= 4 significant bits: exact): vv / 8 below 1, else exponent
+                    // and top three fraction bits of float(vv), re-biased (a group that does not fit encodes garbage: it is flagged)
+                    const unsigned vv = (unsigned)abs(m) << sh;
+                    const unsigned enc = vv < 8u ? vv : (__float_as_uint((float)vv) >> 20) - 1032u;
+                    c24 |= ((m < 0 ? 32u : 0u) | enc) << (6 * j);
+                }
+                // the block's 12 bytes as three dwords, dword q by lane q of the block: bits [32 q, 32 q + 32) of the 96
+                const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)c24, 0x39, 0xF, 0xF, true);      // quad_perm [1,2,3,0]: lane q + 1
+                const unsigned dq = (c24 >> (8 * q)) | (nb << (24 - 8 * q));
+                if (FULL || (it < nit && kb < nkb)) {
+                    const int blk = kb & 1, g4 = (kb >> 1) & 3;
+                    const long long ks = kb >> 3;
+                    uint8_t* p16 = mx.c16 + (((row >> 4) * kp + ks) << 10) + g4 * 256 + (row & 15) * 16;
+                    uint8_t* p8 = mx.c8 + (((row >> 5) * kp + ks) << 10) + ((row >> 4) & 1) * 512 + g4 * 128 + (row & 15) * 8;
+                    if (blk == 0) {
+                        if (q < 3) *reinterpret_cast<unsigned*>(p16 + q * 4) = dq;
+                        else mx.sc[(((row >> 6) * kp + ks) << 8) + g4 * 64 + (row & 15) * 4 + ((row >> 4) & 3)] = (uint8_t)S;
+                    } else {
+                        if (q == 0) *reinterpret_cast<unsigned*>(p16 + 12) = dq;
+                        else if (q < 3) *reinterpret_cast<unsigned*>(p8 + (q - 1) * 4) = dq;
+                    }
+                }
+            }
+            if (__any(bad) && lane == 0) *mx.bad = 1;                   // (plain store of the same value by whoever saw one)
+            if (wi + gridDim.x < a.rows) __syncthreads();
+            continue;
+        }
         int E = 0;
         // bcap < 0: no alignment at all -- every block keeps its own exponent, rowflag 0 (operands for the blockwise
         // kernel: inputs whose block exponents spread too far for any row window, e.g. SiLU-gated MLP activations)
@@ -912,6 +975,29 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     else
         return MI355Q_E_UNSUPPORTED;
 #undef MI355Q_LAUNCH_ROWS
+    return (int)hipGetLastError();
+}
+
+// block_fp -> MX operand (mi355q_mx.hip): rows x K fp32, K % 128 == 0, width <= 5; `bad` is RAISED, never cleared here
+int launch_quant_mx_rows(const QuantArgs& a, uint8_t* c16, uint8_t* c8, uint8_t* sc, int* bad, int* bad_clear, hipStream_t st) {
+    long long grid = a.rows;
+    static const int qgrid = getenv("MI355Q_QROWS_GRID") ? atoi(getenv("MI355Q_QROWS_GRID")) : 1024;
+    if (qgrid > 0 && a.pre_op == 0 && grid > qgrid) grid = qgrid;
+    if (grid > 65536) grid = 65536;
+    if (grid < 1) grid = 1;
+    const MxOut mx{c16, c8, sc, bad, bad_clear};
+#define MI355Q_LAUNCH_MX(MAXIT_, FULL_)                                                                               \
+    hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_, false, true>), (unsigned)grid, 256, 0, st, a, nullptr, nullptr, nullptr, \
+                       0, nullptr, nullptr, -1, mx)
+    if (a.cols == 4096) MI355Q_LAUNCH_MX(4, true);
+    else if (a.cols <= 4096) MI355Q_LAUNCH_MX(4, false);
+    else if (a.cols == 8192) MI355Q_LAUNCH_MX(8, true);
+    else if (a.cols <= 8192) MI355Q_LAUNCH_MX(8, false);
+    else if (a.cols == 16384) MI355Q_LAUNCH_MX(16, true);
+    else if (a.cols <= 16384) MI355Q_LAUNCH_MX(16, false);
+    else
+        return MI355Q_E_UNSUPPORTED;
+#undef MI355Q_LAUNCH_MX
     return (int)hipGetLastError();
 }
 

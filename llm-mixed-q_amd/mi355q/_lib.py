@@ -69,6 +69,9 @@ SIGNATURES = {
     "mi355q_rope_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_bfp_gemm_aligned_multi": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp]),
+    "mi355q_mx_plane_bytes": (C.c_size_t, [_i64, _i64, _i32]),
+    "mi355q_block_fp_quantize_mx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "mi355q_mx_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "mi355q_gemm_timing_enable": (C.c_int, [C.c_int]),
     "mi355q_gemm_timing_read": (C.c_int, [_vp, _vp, _vp]),
     "mi355q_bfp_gemm_set_variant": (C.c_int, [C.c_int]),

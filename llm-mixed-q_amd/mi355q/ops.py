@@ -699,6 +699,80 @@ def bfp_align_rows(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: 
                           bucket_cap=bucket_cap)
 
 
+# ---- W4A4 / W5A5 on the MX scaled matrix instruction (include/mi355q.h, "MX scaled matrix instruction"; csrc/mi355q_mx.hip)
+class MxOperand:
+    """block_fp values of <= 5 bits as FP6 e2m3 codes + one E8M0 scale per 32 values, in the MX product's tile order.  `bad`:
+    one int32 word the quantiser raises when some 32-group's two blocks lie too far apart for one scale (the product launch
+    then forms the exact product from the fp32 tensors: slow -- callers read the word now and then and leave the route)"""
+    __slots__ = ("rows", "K", "c16", "c8", "sc", "bad", "width", "exponent_width", "exponent_bias", "source", "_wbad_of", "_buf")
+
+
+_MX_BUFFERS = _StreamCache(16)
+
+
+def mx_supported(K: int, x_width: int, w_width: int) -> bool:
+    return K % 128 == 0 and 0 < K <= ROW_ALIGN_MAX_K and 2 <= int(x_width) <= 5 and 2 <= int(w_width) <= 5
+
+
+def block_fp_quantize_mx(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, reuse: bool = True) -> MxOperand:
+    """x [rows, K] fp32 ([1,16] blocks along K) -> MxOperand.  `reuse`: the planes are shared by calls of the same shape on the
+    same stream (activations: consume before quantising again), else freshly allocated (weights).  The operand keeps `x`
+    (`source`): the product launch reads it if a flag is raised."""
+    _require_device(x, "block_fp_quantize_mx")
+    assert x.ndim == 2 and x.is_contiguous() and x.dtype == torch.float32 and x.shape[1] % 128 == 0 and 2 <= int(width) <= 5
+    rows, K = x.shape
+    lib = _lib.load_library()
+    sp = _stream_ptr(x.device)
+    key = (x.device.index, sp, "mx", rows, K)
+    buf = _MX_BUFFERS.get(key) if reuse else None
+    if buf is None:
+        buf = dict(c16=torch.empty(lib.mi355q_mx_plane_bytes(rows, K, 0), dtype=torch.uint8, device=x.device),
+                   c8=torch.empty(lib.mi355q_mx_plane_bytes(rows, K, 1), dtype=torch.uint8, device=x.device),
+                   sc=torch.empty(lib.mi355q_mx_plane_bytes(rows, K, 2), dtype=torch.uint8, device=x.device),
+                   bad=torch.zeros(8, dtype=torch.int32, device=x.device), calls=0)
+        if reuse:
+            _MX_BUFFERS.put(key, buf)
+    op = MxOperand()
+    # (flag words: call n raises word 2 (n & 1) and clears the other call's; word 2 (n & 1) + 1 holds the weights' flag for the product)
+    par = buf["calls"] & 1
+    buf["calls"] += 1
+    op.rows, op.K, op.c16, op.c8, op.sc = rows, K, buf["c16"], buf["c8"], buf["sc"]
+    op.bad, nxt = buf["bad"][2 * par:2 * par + 2], buf["bad"][2 * (1 - par):2 * (1 - par) + 1]
+    op._wbad_of = buf.get("wbad_of")
+    op._buf = buf
+    op.width, op.exponent_width, op.exponent_bias, op.source = int(width), int(exponent_width), _default_bias(exponent_bias), x
+    with _on_device(x.device):
+        rc = lib.mi355q_block_fp_quantize_mx(_ptr(x), _ptr(op.c16), _ptr(op.c8), _ptr(op.sc), _ptr(op.bad), _ptr(nxt) if not _capturing() else None, rows, K, int(width),
+                                            int(exponent_width), op.exponent_bias, sp)
+    _lib.check(rc, "mi355q_block_fp_quantize_mx")
+    return op
+
+
+def mx_gemm(x: MxOperand, w: MxOperand, w_fp32: torch.Tensor, bias=None, out: torch.Tensor = None) -> torch.Tensor:
+    """y [M, N] = x_q . w_q^T (+ bias) on the MX scaled MFMA (fp32 accumulation); `w_fp32`: the fake-quantised weights [N, K]
+    (read only if a flag word is raised).  x.bad / w.bad: word 0 of each."""
+    M, K, N = x.rows, x.K, w.rows
+    assert w.K == K and w_fp32.shape == (N, K) and w_fp32.is_contiguous() and w_fp32.dtype == torch.float32
+    given = out is not None
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.c16.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    # the two flag words side by side: x's own word and a copy slot for w's (weights are static: copied once per pairing)
+    if getattr(x, "_wbad_of", None) is not w:
+        x._buf["bad"][1::2].copy_(w.bad[0:1].expand(4))         # (both parities' slots)
+        x._buf["wbad_of"] = x._wbad_of = w
+    lib = _lib.load_library()
+    with _on_device(x.c16.device):
+        rc = lib.mi355q_mx_gemm(_ptr(x.c16), _ptr(x.c8), _ptr(x.sc), _ptr(w.c16), _ptr(w.c8), _ptr(w.sc), _ptr(x.bad), _ptr(x.source),
+                                _ptr(w_fp32), _ptr(bias), _ptr(out), M, N, K, ldy, x.width, x.exponent_width, x.exponent_bias,
+                                _stream_ptr(x.c16.device))
+    _lib.check(rc, "mi355q_mx_gemm")
+    if given:
+        _wrote_into(out)
+    return out
+
+
 def _wrote_into(t: torch.Tensor) -> None:
     """a kernel of this library has just written into a caller-provided tensor through its raw pointer: move its version
     counter like an in-place torch op would (version-keyed caches -- the quantised-activation reuse below, autograd's

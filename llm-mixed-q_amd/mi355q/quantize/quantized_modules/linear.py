@@ -49,6 +49,10 @@ def _make_quantizer(arith: str, config: dict, prefix: str, skip_first_dim: bool)
     return partial(QUANTIZER_MAP[arith], **kw)
 
 
+def _capturing_graph() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _bf16_planes(t):
     """fp32 [rows, K] -> (hi, lo) with hi + lo = t to 2^-17 relative: hi = t rounded to bf16, lo the remainder (rounded to bf16
     when it is tiled).  A gradient is not a quantised value: one bf16 plane would cost it 2^-9."""
@@ -111,6 +115,7 @@ class _LinearBase(nn.Linear):
         self.align = config.get("mi355q_align", "auto")
         self._align_mode, self._calls, self._row_overflows = None, 0, 0
         self._w_bf16 = None          # (tiled bf16 weights, weight._version) of the per-block-exponent route
+        self._mx_w, self._mx_calls, self._mx_version = None, 0, -1      # W4A4 on the MX scaled MFMA: the weights' operand
         # implementation knobs next to "mi355q_align" (not part of the reference config):
         #   mi355q_weight_storage = "packed": keep the weights at rest as width-bit mantissas + one byte per block
         #       (width + 0.5 bits per value, ops.PackedWeights) and stream them into a shared scratch operand every forward;
@@ -201,6 +206,14 @@ class _LinearBase(nn.Linear):
         c = self.config
         if c.get("mi355q_keep_master", False) and self._master is None:
             self._master = (self.weight.detach().clone(), None if self.bias is None else self.bias.detach().clone())
+        self._mx_w = None
+        if pack and self._mx_config_ok():
+            # W4A4 on the MX scaled MFMA (csrc/mi355q_mx.hip): the operand from the RAW weights (block_fp is not idempotent), kept
+            # only if every 32-group of W fits the format (one host read, here where the weights are packed anyway)
+            mw = ops.block_fp_quantize_mx(self.weight.data.contiguous(), c["weight_width"], c["weight_exponent_width"], c["weight_exponent_bias"],
+                                          reuse=False)
+            if _capturing_graph() or int(mw.bad[0]) == 0:
+                self._mx_w = mw
         if pack:
             wq, wm, we = ops.block_fp_quantize(self.weight.data, c["weight_width"], c["weight_exponent_width"],
                                                c["weight_exponent_bias"], c["weight_block_size"], False,
@@ -211,6 +224,7 @@ class _LinearBase(nn.Linear):
         if self.bias is not None:
             self.bias.copy_(self.b_quantizer(self.bias.data))
         self.weight_requires_quantisation = False
+        self._mx_version = self.weight._version
         if pack:
             self._pack_operands(wm, we, x_sample)
             # packed on arrival (no activation seen yet, `_pack_if_arrived`): the integers stay until the first forward has
@@ -419,6 +433,8 @@ class _LinearBase(nn.Linear):
                 if (plan is not None and p is not None and p[1].device != self.weight.device
                         and p[2] == self.weight._version and (self.bias is None or p[3] == self.bias._version)):
                     self._repack_quantised_weights(x)        # the module was moved: same (quantised) values, new device
+                if plan is not None and self._mx_w is not None and self._mx_takes(x):
+                    return self._forward_mx(x)
                 if plan is not None and self._packed_is_current():
                     return self._forward_int8(x, plan)
                 if not differentiated and self._values_exact_in_bf16(x):
@@ -450,6 +466,44 @@ class _LinearBase(nn.Linear):
             return False
         M = xq.numel() // self.in_features
         return self.in_features % 32 == 0 and self.out_features % 32 == 0 and M % 32 == 0 and M > 0
+
+    # -- W4A4 on the MX scaled matrix instruction ------------------------------------------------------------------------
+    def _mx_config_ok(self) -> bool:
+        """config["mi355q_mx"]: "auto" (default) -- block_fp operands of <= 4 bits each (every mantissa exact in FP6 e2m3 with
+        three exponents of reach inside a 32-group; at 5 bits the reach is two and Gaussian data already trips it), [1,16] blocks
+        along in_features, in_features % 128 == 0, launches of >= 192 tiles of 256 x 256 (below that the small-tile int8 kernel
+        wins: profiles/r05_mx_w4a4.txt); True -- every launch that fits the format (<= 5 bits); False -- never"""
+        c = self.config
+        knob = c.get("mi355q_mx", "auto")
+        if knob in (False, "off", None) or self.arith != "block_fp" or not self.is_ptq or self.bypass:
+            return False
+        wmax = 5 if knob is True else 4
+        return (ops.mx_supported(self.in_features, c["data_in_width"], c["weight_width"]) and c["data_in_width"] <= wmax
+                and c["weight_width"] <= wmax and self.weight.is_cuda and self.weight.dtype == torch.float32
+                and c.get("mi355q_weight_storage", "int8") != "packed" and not getattr(self, "_fp32_released", False))
+
+    def _mx_takes(self, x) -> bool:
+        if not (x.is_cuda and x.dtype == torch.float32 and 2 <= x.ndim <= 3) or self._mx_w is None:
+            return False
+        if self._mx_w.c16.device != x.device or self._mx_version != self.weight._version:
+            return False
+        if self.config.get("mi355q_mx", "auto") is True:
+            return True
+        M = x.numel() // self.in_features
+        return -(-M // 256) * -(-self.out_features // 256) >= 192
+
+    def _forward_mx(self, x):
+        c = self.config
+        x2 = x.reshape(-1, self.in_features).contiguous()
+        xop = ops.block_fp_quantize_mx(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"])
+        y = ops.mx_gemm(xop, self._mx_w, self.weight.data, self.bias)
+        # a 32-group of the activations that does not fit the format sends the launch to its exact (slow) route: look at the
+        # flag on a doubling schedule of calls and leave this route if it is ever up (never while a graph is being recorded)
+        self._mx_calls += 1
+        if self._mx_calls & (self._mx_calls - 1) == 0 and not _capturing_graph():
+            if int(xop.bad[0]) != 0:
+                self._mx_w = None
+        return y.reshape(*x.shape[:-1], self.out_features)
 
     def _values_exact_in_bf16(self, xq) -> bool:   # (xq: the layer's input, quantised or not: only its placement matters)
         """block_minifloat / block_log PTQ layers (linear.py:145-203; likewise the un-blocked minifloat_ieee / minifloat_denorm
