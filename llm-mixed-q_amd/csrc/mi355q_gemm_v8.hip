@@ -876,7 +876,7 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     const long long tn = (a.N + V8_BN - 1) / V8_BN;
     const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
-    // Tile height and split together, by a small cost model fitted to tools/sweep_bf16_tile_split.py (us): rounds x steps
+    // Tile height and split together, by a small cost model fitted to tools/timing/sweep_bf16_tile_split.py (us): rounds x steps
     // per slice x 0.70 (256 rows) or 0.56 (128 rows) per K-step, plus, when split, 12 + 0.7 per MiB of slab traffic (S x
     // the fp32 output through memory twice).  It ranks the measured settings of the post-activation layer shapes
     // correctly: 2048 x 11008 x 4096 -> 256 rows in two slices (177 vs 192 us), 2048 x 8192 x 2048 -> 256 rows in four.

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     }
 }
 
-static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/v9_stamps.py): where the stamps build writes
+static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/dbg/v9_stamps.py): where the stamps build writes
 
 // 256 x 256 tiles, K % 128 == 0, at least four K-steps per slice (even slices under split-K).
 int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,

@@ -66,48 +66,6 @@ def _fused_block_fp_matmul(x, y, config, style, softmax=False, mask=None, causal
     return out.reshape(*x.shape[:-1], y.shape[-1])
 
 
-def _bf16_values_matmul(x, y, config, arith):
-    """matmul_block_minifloat / matmul_block_log (matmul.py:199-249, 252-297) on bf16 MFMAs: the quantisers write the
-    operands straight as bf16 (half the bytes of the fake-quantised fp32 tensors -- the [heads, T, T] probabilities are
-    the big one), the product accumulates in fp32 and leaves as fp32 (torch.bmm(out_dtype=float32) = the vendor's bf16
-    batched GEMM: a plain library GEMM on exactly representable operands).  block_minifloat: both operands are minifloats of
-    <= 7 mantissa bits, exact in bf16: 1.9-2.1x the fp32 route at the Llama-7B attention shapes
-    (profiles/r03_values_matmul.jsonl).  block_log: x is signed powers of two (exact) but y is NOT quantised by the reference
-    (matmul.py:278-297): it would go in as three bf16 terms y = y1 + y2 + y3 (8 + 8 + 8 significant bits, exact), one
-    product against [y1 | y2 | y3] and a sum of the three column groups -- exact, but three times the output: no faster
-    for P V, three times slower for Q K^T (same profile).  It stays on the fp32 route unless
-    config["mi355q_values_matmul"] = "bf16_split" asks for it.  None: shapes / settings the route does not take."""
-    from ... import ops
-    want = config.get("mi355q_values_matmul", "fused")
-    want = "bf16" if want == "fused" else want           # (the fused route declined: block_minifloat takes the library product)
-    if want not in ("bf16", "bf16_split") or (arith == "block_log" and want != "bf16_split") or not (x.is_cuda and y.is_cuda):
-        return None
-    if x.dtype != torch.float32 or y.dtype != torch.float32 or torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
-        return None
-    if x.ndim != y.ndim or x.ndim < 2 or x.shape[:-2] != y.shape[:-2] or x.shape[-1] != y.shape[-2]:
-        return None
-    many = x.ndim > 2
-    x3 = torch.flatten(x, 0, -3) if many else x
-    y3 = torch.flatten(y, 0, -3) if many else y
-    if arith == "block_minifloat":
-        if not all(0 <= config[f"{p}_width"] - config[f"{p}_exponent_width"] - 1 <= 7 for p in ("data_in", "weight")):
-            return None
-        xq = ops.block_minifloat_quantize_bf16(x3, *(config[f"data_in_{k}"] for k in _KEYS[arith]), many)
-        yq = ops.block_minifloat_quantize_bf16(y3, *(config[f"weight_{k}"] for k in _KEYS[arith]), many)
-        out = torch.bmm(xq, yq, out_dtype=torch.float32) if many else torch.mm(xq, yq, out_dtype=torch.float32)
-    else:
-        xq = ops.block_log_quantize_bf16(x3, *(config[f"data_in_{k}"] for k in _KEYS[arith]), many)
-        y1 = y3.to(torch.bfloat16)
-        r1 = y3 - y1.float()
-        y2 = r1.to(torch.bfloat16)
-        y3b = (r1 - y2.float()).to(torch.bfloat16)
-        ycat = torch.cat([y1, y2, y3b], dim=-1)
-        o = torch.bmm(xq, ycat, out_dtype=torch.float32) if many else torch.mm(xq, ycat, out_dtype=torch.float32)
-        n = y.shape[-1]
-        out = (o[..., 2 * n:] + o[..., n:2 * n]) + o[..., :n]            # (smallest terms first)
-    return out.reshape(*x.shape[:-1], y.shape[-1])
-
-
 def _fused_values_matmul(x, y, config, arith, softmax=False, mask=None, causal=False):
     """matmul_block_minifloat / matmul_block_log (matmul.py:199-249, 252-297) in the library's own product kernels
     (ops.values_matmul: y packed transposed once, x quantised in registers on its way into bf16 MFMAs -- one pass over x, no
@@ -149,9 +107,6 @@ def _generic_matmul(x, y, config, arith, style):
             return out
     if arith in ("block_minifloat", "block_log"):
         out = _fused_values_matmul(x, y, config, arith)
-        if out is not None:
-            return out
-        out = _bf16_values_matmul(x, y, config, arith)
         if out is not None:
             return out
     xq = _quantise_operand(x, arith, config, "data_in")

@@ -283,14 +283,14 @@ class _LinearBase(nn.Linear):
         if x_sample is not None:
             # activations: the GEMM's in-LDS add-back while a tile's entries fit it; otherwise (post-activation inputs:
             # hundreds of exception blocks per 256 rows after a ReLU, no usable row window at all after a SiLU gate) no
-            # alignment -- measured faster than the row post-pass wherever that one applies (tools/time_linear_modes.py;
+            # alignment -- measured faster than the row post-pass wherever that one applies (tools/timing/time_linear_modes.py;
             # "rows_post" remains available explicitly)
             xa = ops.block_fp_quantize_aligned_rows(x_sample.reshape(-1, self.in_features), c["data_in_width"],
                                                     c["data_in_exponent_width"], c["data_in_exponent_bias"],
                                                     bucket_cap=ops.ROW_BUCKET_CAP_MAX)
             x_over, x_max = ops.row_list_fill(xa.sparse, xa.rows, xa.list_cap)
             # (a 128-row tile carries about half of its 256-row bucket's activation entries; 15 % margin for the busier
-            # half.  Measured at 2048 x 4096 -> 4096, tools/time_exception_density.py: the row-scale route wins up to a
+            # half.  Measured at 2048 x 4096 -> 4096, tools/timing/time_exception_density.py: the row-scale route wins up to a
             # fullest activation bucket of ~60 there, the per-block route beyond ~85)
             # Between 48 and 96 entries a tile forms its vectors behind the K loop: still ahead of the per-block route where
             # that one runs 256-row tiles (2048 x 4096 -> 11008: 163 vs 208 us at a fullest bucket of 87), behind it on

@@ -1029,54 +1029,6 @@ def test_minifloat_and_log_linear_take_the_bf16_tile_gemm(arith):
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=3e-6 * float(np.abs(ref).max()))
 
 
-@pytest.mark.parametrize("arith", ["block_minifloat", "block_log"])
-@pytest.mark.parametrize("style", ["bmm", "matmul"])
-def test_block_minifloat_and_block_log_products_on_bf16_mfma(arith, style):
-    """matmul_block_minifloat / matmul_block_log (matmul.py:199-297) with the operands written as bf16 and the product on bf16
-    MFMAs (fp32 accumulation and output; block_log's unquantised y as three exact bf16 terms): == the route through the
-    fp32 fake-quantised tensors and the library fp32 GEMM up to summation order, == the oracle.  Causal attention
-    probabilities as x (half of their blocks all zero: the fix-up pass writes bf16 too), a plain activation as x"""
-    import torch
-    import mi355q.quantize as Q
-    from mi355q import ops
-    from oracle import np_oracle as O
-    cfg = {"block_minifloat": dict(name="block_minifloat", bypass=False, data_in_width=8, data_in_exponent_width=4,
-                                   data_in_exponent_bias_width=8, data_in_block_size=[1, 16], weight_width=8, weight_exponent_width=4,
-                                   weight_exponent_bias_width=8, weight_block_size=[1, 16]),
-           "block_log": dict(name="block_log", bypass=False, data_in_width=8, data_in_exponent_bias_width=8, data_in_block_size=[1, 16],
-                             weight_width=8, weight_exponent_bias_width=8, weight_block_size=[1, 16])}[arith]
-    g = torch.Generator().manual_seed(12)
-    B, H, T, hd = 2, 3, 160, 64
-    probs = torch.softmax(torch.randn(B, H, T, T, generator=g) * 3 + torch.full((T, T), float("-inf")).triu(1), dim=-1)
-    v = torch.randn(B, H, T, hd, generator=g)
-    q = torch.randn(B, H, T, hd, generator=g) * 0.7
-    k = torch.randn(B, H, hd, T, generator=g)
-    f = Q.get_quantized_func(style, cfg)
-    calls, real = [], (ops.block_minifloat_quantize_bf16 if arith == "block_minifloat" else ops.block_log_quantize_bf16)
-    name = real.__name__
-    setattr(ops, name, lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
-    try:
-        for x, y in ((probs, v), (q, k)):
-            if style == "bmm":
-                x, y = x.flatten(0, 1), y.flatten(0, 1)
-            xd, yd = x.to("cuda:0"), y.to("cuda:0")
-            n0 = len(calls)
-            # (block_log's unquantised y makes the bf16 product an opt-in: exact, but no faster -- see _bf16_values_matmul)
-            # (the default route is the library's own product kernel since round 4: tests/test_gpu_values_matmul.py)
-            got = f(xd, yd, dict(cfg, mi355q_values_matmul="bf16" if arith == "block_minifloat" else "bf16_split"))
-            assert len(calls) > n0, "the bf16 route was not taken"
-            if arith == "block_log":
-                f(xd, yd, dict(cfg))
-                assert len(calls) == n0 + 1, "block_log takes the bf16 product only when asked"
-            old = f(xd, yd, dict(cfg, mi355q_values_matmul="fp32"))
-            ref = O.matmul_quantized(x.numpy(), y.numpy(), cfg)
-            scale = np.abs(ref).max()
-            assert np.abs(got.cpu().numpy() - ref).max() <= 2e-6 * scale
-            assert float((got - old).abs().max()) <= 2e-6 * scale
-    finally:
-        setattr(ops, name, real)
-
-
 @pytest.mark.parametrize("T,block", [(12, [1, 16]), (24, [1, 32]), (20, [1, 32]), (28, [1, 32]), (48, [1, 16])])
 def test_block_minifloat_attention_products_at_token_counts_that_refit_the_block(T, block):
     """T = 12 under block [1,16] re-fits the block to 12 values (b1 / 4 = 3), which the bf16-output quantiser's vector

@@ -1,4 +1,4 @@
-"""The per-rank GEMM shapes of the row-sharded layer (tools/time_shard_shapes.py) under forced tile heights / K splits: which
+"""The per-rank GEMM shapes of the row-sharded layer (tools/timing/time_shard_shapes.py) under forced tile heights / K splits: which
 (tile rows, splits) the launcher should pick where the grid is under-filled.  TOPS per shape and setting."""
 import json, os, subprocess, sys
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")

@@ -3,7 +3,7 @@
       called in random order on one stream -- the zero-block fill speculation sees hits, misses and foreign fills;
   (2) the aligned-rows quantiser reading P row segments == the plain call (products compared);
   (3) block_minifloat products on bf16 MFMAs == the fp32 route.
-    python tools/fuzz_round3.py [seed]"""
+    python tools/fuzz/fuzz_round3.py [seed]"""
 import sys
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import numpy as np, torch

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Randomised cross-check of round 4's product kernels: block_fp / block_minifloat / block_log products at random shapes (rows that
 do not fill a workgroup, contractions of 1 .. 40 steps with partial last ones, column counts around the chunk / ring sizes), with
-all-zero blocks, tiny blocks and rows of very different magnitude, against the oracle.  python tools/fuzz_round4.py [seeds]"""
+all-zero blocks, tiny blocks and rows of very different magnitude, against the oracle.  python tools/fuzz/fuzz_round4.py [seeds]"""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "llm-mixed-q_amd")); sys.path.insert(0, str(ROOT))
 import numpy as np
 import torch

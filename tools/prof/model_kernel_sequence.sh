@@ -1,9 +1,9 @@
 #!/bin/bash
-# The kernel sequence of one decoder layer in steady state (rocprofv3 kernel trace of tools/prof_model.py): name and duration
+# The kernel sequence of one decoder layer in steady state (rocprofv3 kernel trace of tools/prof/prof_model.py): name and duration
 # of ~80 consecutive dispatches from the last forward.  Run on the GPU box from the repo root.
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rm -rf gpurun_out/_pm
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/_pm -o p -- python3 tools/prof_model.py "$@" > /dev/null 2> gpurun_out/pm.err
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/_pm -o p -- python3 tools/prof/prof_model.py "$@" > /dev/null 2> gpurun_out/pm.err
 F=$(find gpurun_out/_pm -name '*kernel_trace.csv' | head -1)
 python3 - "$F" <<'PY'
 import csv, sys

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 counter passes over the one-pass attention kernel (C driver): bash tools/pmc_attention.sh <heads> <head_dim>
+# rocprofv3 counter passes over the one-pass attention kernel (C driver): bash tools/prof/pmc_attention.sh <heads> <head_dim>
 export TMPDIR=/tmp
 H=${1:-12}; D=${2:-64}
 for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 counter passes over the C-ABI step driver (one counter set per pass; --pmc passes over the Python bench do
-# not finish on this pool).  Run on the GPU box from the repo root:  bash tools/pmc_passes.sh [matmul]
+# not finish on this pool).  Run on the GPU box from the repo root:  bash tools/prof/pmc_passes.sh [matmul]
 # Output: gpurun_out/pmc_<set>/…_counter_collection.csv ; tools/pmc_summary.py turns FETCH/WRITE into profiles/*.json
 export TMPDIR=/tmp
 MODE=${1:-}

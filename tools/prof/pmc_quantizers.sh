@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes over the streaming fake-quantisers at the Llama-7B activation shapes (C driver, one counter per
-# pass): bash tools/pmc_quantizers.sh   ->  gpurun_out/r02_pmc_quantizers.txt  (FETCH_SIZE is tallied at 64 B per 128-B
-# request on gfx950: x 2, as tools/pmc_traffic.py does; rocprofv3 reports KiB)
+# pass): bash tools/prof/pmc_quantizers.sh   ->  gpurun_out/r02_pmc_quantizers.txt  (FETCH_SIZE is tallied at 64 B per 128-B
+# request on gfx950: x 2, as tools/prof/pmc_traffic.py does; rocprofv3 reports KiB)
 export TMPDIR=/tmp
 OUT=gpurun_out/r02_pmc_quantizers.txt
 : > $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-dispatch kernel durations of `bench.py --workload quantizers` (rocprofv3 kernel trace), grouped in dispatch order
-# by (shape, quantiser).  Run on the GPU box from the repo root:  bash tools/prof_quantizers.sh <tag>
+# by (shape, quantiser).  Run on the GPU box from the repo root:  bash tools/prof/prof_quantizers.sh <tag>
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 TAG=${1:-q}; STEPS=20; WARM=5
 rm -rf gpurun_out/_prof_$TAG

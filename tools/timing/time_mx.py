@@ -1,5 +1,5 @@
 """W4A4 / W5A5 4096^3 step on the MX scaled MFMA (quantiser + product) against the int8 row-scale route, HIP events.
-    python tools/time_mx.py [M N K [width]]"""
+    python tools/timing/time_mx.py [M N K [width]]"""
 import json, sys
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch

@@ -4,7 +4,7 @@ width-bit storage (the expand pass into the scratch operand in front of every GE
 import json, sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "llm-mixed-q_amd"))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "llm-mixed-q_amd"))
 import mi355q.quantize as Q
 from mi355q import ops
 ops.REUSE_QUANTISED_INPUT = False

@@ -1,5 +1,5 @@
 """QAT (is_ptq = False) forward + backward of one LinearBlockFP on the bf16 tile GEMM (own kernels: 1 + 4 launches) against the
-library route (F.linear: fp32 GEMM forward and two backward), HIP events.  python tools/time_qat.py [M K N]"""
+library route (F.linear: fp32 GEMM forward and two backward), HIP events.  python tools/timing/time_qat.py [M K N]"""
 import json, sys
 sys.path.insert(0, 'llm-mixed-q_amd'); sys.path.insert(0, '.')
 import torch

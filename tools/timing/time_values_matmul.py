@@ -6,7 +6,7 @@ import json
 import sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "llm-mixed-q_amd"))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "llm-mixed-q_amd"))
 import mi355q.quantize as Q
 
 dev = torch.device("cuda:0")
@@ -44,7 +44,7 @@ for name, cfg in cfgs.items():
     rec = {"arith": name, "shape": "p[32,2048,2048] x v[32,2048,128] ; q[32,2048,128] x k^T[32,128,2048]"}
     # routes: "fused" the library's own product kernels (round 4: block_minifloat and block_log too); "bf16" / "bf16_split" the
     # quantisers' bf16 output + the vendor's bf16 batched GEMM (round 3); "fp32" fake-quantised fp32 tensors + the vendor's fp32 GEMM
-    routes = {"block_fp": ("fused",), "block_minifloat": ("fused", "bf16", "fp32"), "block_log": ("fused", "bf16_split", "fp32")}[name]
+    routes = {"block_fp": ("fused",), "block_minifloat": ("fused", "fp32"), "block_log": ("fused", "fp32")}[name]
     for route in routes:
         c = dict(cfg, mi355q_values_matmul=route)
         rec[f"pv_{route}_us"] = round(t(lambda: f(p, v, c)), 1)
