@@ -33,16 +33,15 @@
  *     have to grow them under capture runs unsplit instead; buffers a capture has seen are never freed), and the
  *     zero-block map of the exact quantiser mode on tensors of 128 MiB and more (without it that mode reads x a second
  *     time instead).
- *   - Environment switches (diagnostics; read once per process): MI355Q_V9=0 keeps every launch on the round-2 tile kernel
- *     (mi355q_gemm_v8.hip) -- by default every launch of the 256 x 256 tile, with or without exception lists, the bf16
- *     flavour too, with K % 128 == 0 and >= 4 K-steps per slice takes mi355q_gemm_v9.hip (round 4; grouped launches and the
- *     128-row tile stay in v8); MI355Q_V9_FIX=0 sends the launches with lists back to v8 (A/B runs); MI355Q_V8_SMALL_SCHED=1
- *     gives the 128-row tile its round-3 one-phase K-loop schedule; MI355Q_QROWS_GRID=0 launches the row quantiser with one
- *     workgroup per row (default: 1024 workgroups, several rows each); MI355Q_MATMUL_TILE=0 sends the plain attention products
- *     back to kernel 2 of mi355q_matmul.hip; MI355Q_QV_PIECES=0|1|2|4 pins the streaming quantisers' access shape (0:
- *     grid-stride loop; default by tensor size); MI355Q_V8_TILE_ROWS, MI355Q_V8_SPLITS pin the tile GEMM's tile height /
- *     split-K; MI355Q_V10=1|2|3 (+ MI355Q_V10_NS) pins a geometry of the small-tile kernel (mi355q_gemm_v10.hip), MI355Q_V10_AUTO=0
- *     keeps launches off it.
+ *   - Environment switches (diagnostics and A/B runs only; the default route never needs one): MI355Q_V9=0 keeps every
+ *     launch on the round-2 tile kernel (mi355q_gemm_v8.hip) -- by default every launch of the 256 x 256 tile, grouped or
+ *     not, with or without exception lists, the bf16 flavour too, with K % 128 == 0 and >= 4 K-steps per slice takes
+ *     mi355q_gemm_v9.hip; MI355Q_V9_FIX=0 sends the launches with lists back to v8; MI355Q_V10=1|2|3 (+ MI355Q_V10_NS) pins a
+ *     geometry of the small-tile kernel (mi355q_gemm_v10.hip), MI355Q_V10_AUTO=0 keeps launches off it; MI355Q_V8_TILE_ROWS,
+ *     MI355Q_V8_SPLITS pin the tile GEMM's tile height / split-K (tests do); MI355Q_MATMUL_TILE=0 sends the plain attention
+ *     products back to kernel 2 of mi355q_matmul.hip; MI355Q_V8_STAMPS / MI355Q_V8_CLOCK / MI355Q_V9_STAMPS / MI355Q_V9_DBG /
+ *     MI355Q_MATMUL_DBG are the phase-stamp diagnostics behind DESIGN.md section 5.  (Round 5 removed MI355Q_V8_SCHED,
+ *     MI355Q_V8_SMALL_SCHED, MI355Q_V8_DBG, MI355Q_V9_GROUPS, MI355Q_QROWS_GRID, MI355Q_QV_PIECES, MI355Q_FIXUP_GRID, MI355Q_CORR.)
  */
 #ifndef MI355Q_H
 #define MI355Q_H
@@ -254,54 +253,21 @@ int mi355q_bfp_gemm(const int8_t* xm, const uint8_t* xe, const int8_t* wm, const
                     int32_t x_mbits, int32_t x_exp_bias, int32_t w_mbits, int32_t w_exp_bias,
                     void* stream);
 
-/* ---- exponent-aligned operands for the fast GEMM ------------------------------------------
- * K is cut into groups of 16 blocks (256 values).  mi355q_bfp_align rewrites a packed operand so
- * that each (row, group) carries ONE effective exponent E (rowflag 1): blocks are shifted left onto
- * E where that keeps their mantissas inside int8.  Blocks that cannot join (exponent below E, or too
- * far above it) are EXCEPTIONS: they are zeroed in the rewritten operand and appended, exactly, to the
- * operand's exception list; (rewritten operand) + (its exceptions) denotes the same values as the
- * input.  E is the smallest exponent of the group when every block fits (no exceptions; the common
- * case), otherwise the candidate that leaves the fewest exceptions.  A row-group whose exceptions do
- * not fit the list any more is copied unchanged (rowflag 0, own exponents); list[0] then exceeds
- * list_cap and mi355q_bfp_gemm_aligned takes its blockwise kernel.  Without a list (list == NULL)
- * row-groups that would need exceptions are copied unchanged.
- *   rowflag uint8 [rows, G], G = ceil(K/256)
- *   gscale  fp32  [G, rows_pad] (nullable), rows_pad = mi355q_bfp_rows_pad(rows): per (group,row)
- *           2^(E - exp_offset) where rowflag is 1, else 0;
- *           exp_offset = exponent_bias + (width-1) of the operand
- *   list    int32 [mi355q_bfp_list_bytes(list_cap) / 4] (nullable): list[0] = exception blocks
- *           reserved (may exceed list_cap), list[1..7] spare, then 8 words per entry:
- *           {row (-1 = void), block index (k/16), biased exponent, 0, 16 mantissa bytes}
- *   mant_tiled int8 [mi355q_bfp_tiled_bytes(rows, K)] (nullable, needs K % 64 == 0): the aligned
- *           mantissas in the tile order the GEMM kernels stream: 1-KiB pieces of 16 rows x 64 K-bytes, piece
- *           (row / 16) * (K / 64) + k / 64, laid out [block (k / 16) % 4][row % 16][16 bytes] inside (the LDS image
- *           of the kernels; the 16 rows' blocks at one K position are 256 contiguous bytes); rows padded to 128
- *           -- this is what mi355q_bfp_gemm_aligned reads;
- *   mant_out int8 [rows, K] (nullable): the same mantissas row-major, for inspection / mi355q_bfp_gemm.
- * In-place (mant_out == mant_in, exp_out == exp_in) is allowed. */
-size_t mi355q_bfp_list_bytes(int32_t list_cap);
+/* ---- tiled operands ---------------------------------------------------------------------------
+ * The tile GEMMs stream an operand's mantissas in TILE ORDER: int8 [mi355q_bfp_tiled_bytes(rows, K)] (K % 64 == 0): 1-KiB
+ * pieces of 16 rows x 64 K-bytes, piece (row / 16) * (K / 64) + k / 64, laid out [block (k / 16) % 4][row % 16][16 bytes]
+ * inside (the LDS image of the kernels; the 16 rows' blocks at one K position are 256 contiguous bytes); rows padded to 128.
+ * Exception lists (int32): list[0] = overflow word, list[1..7] spare, then entries of 8 words {row (-1 = void), block
+ * index (k / 16), biased exponent, 0, 16 mantissa bytes}.
+ * (Round 5 removed the alignment per 256-value GROUP -- mi355q_bfp_align, mi355q_block_fp_quantize_aligned, the int32-chain
+ * kernel behind them -- which the row alignment below superseded in round 1.) */
 size_t mi355q_bfp_tiled_bytes(int64_t rows, int64_t K);
 size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K);
 int64_t mi355q_bfp_rows_pad(int64_t rows);
-int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, int8_t* mant_tiled,
-                     uint8_t* exp_out, uint8_t* rowflag, float* gscale, int32_t* list, int32_t list_cap,
-                     int32_t exp_offset, int64_t rows, int64_t K, void* stream);
-
-/* Fused activation path: block_fp quantise ([1,16] blocks, MI355Q_ZERO_BLOCK_FAST semantics) + pack +
- * align + tile in ONE pass over x [rows, K] fp32, K % 256 == 0.  Produces exactly what
- * mi355q_block_fp_quantize followed by mi355q_bfp_align would (mant_tiled, exp_out, rowflag, gscale,
- * list).  `list` must hold list[0] == 0 on entry.  Two ways to keep it so without a memset per call:
- * alternate between two lists and pass the OTHER one as `list_to_clear` (this kernel zeroes its count for
- * the next call -- safe on one stream, where the previous consumer of that list has finished), or
- * clear list[0] yourself (hipMemsetAsync of 4 bytes) and pass list_to_clear = NULL. */
-int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
-                                     float* gscale, int32_t* list, int32_t list_cap, int32_t* list_to_clear,
-                                     int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
-                                     int32_t exponent_bias, void* stream);
 
 /* ---- ROW-aligned operands -------------------------------------------------------------------
- * The same rewrite with the whole row (all K/16 blocks) as ONE group: one effective exponent and one fp32
- * scale per row, so the contraction becomes a plain int8 x int8 -> int32 GEMM with a row scale and a column
+ * A packed operand rewritten so that a whole row (all K/16 blocks) carries ONE effective exponent E and one fp32 scale:
+ * blocks are shifted left onto E where that keeps their mantissas inside int8; the contraction becomes a plain int8 x int8 -> int32 GEMM with a row scale and a column
  * scale applied once (no rescale inside the K loop).  Blocks outside the row's exponent window are exceptions,
  * kept in a list with one BUCKET per 256 rows:
  *   rowflag  uint8 [rows];  rowscale fp32 [mi355q_bfp_rows_pad(rows)] = 2^(E - exp_offset), 0 where rowflag is 0
@@ -314,8 +280,8 @@ int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t
  *            by a row post-pass after the GEMM (see mi355q_bfp_gemm_aligned), which has no per-tile limit.
  * K % 64 == 0, K <= MI355Q_ROW_ALIGN_MAX_K (int32 accumulation cannot overflow; the row is decided by one
  * workgroup that keeps it in registers).  mi355q_block_fp_quantize_aligned_rows is the fused activation form
- * (same contract as mi355q_block_fp_quantize_aligned; `list_to_clear`: the OTHER list of an alternating pair,
- * emptied for the next call). */
+ * (one pass over x [rows, K] fp32: quantise + pack + align + tile; `list` must hold zero counts on entry: alternate between
+ * two lists and pass the OTHER one as `list_to_clear` -- this kernel empties it for the next call). */
 #define MI355Q_ROW_ALIGN_MAX_K 16384
 #define MI355Q_ROW_BUCKET_CAP_MAX 1016
 #define MI355Q_ROW_NO_ALIGN (-1)   /* bucket_cap of mi355q_block_fp_quantize_aligned_rows: tiled row format, every block keeps
@@ -331,26 +297,20 @@ int mi355q_block_fp_quantize_aligned_rows(const float* x, int8_t* mant_tiled, ui
 
 /* An aligned operand as one argument */
 typedef struct mi355q_bfp_operand {
-    const int8_t* mant;     /* tiled mantissas (mant_tiled of mi355q_bfp_align) */
+    const int8_t* mant;     /* tiled mantissas */
     const uint8_t* exp;     /* [rows, K/16] */
-    const uint8_t* rowflag; /* [rows, G] */
-    const float* gscale;    /* [G, rows_pad] */
-    const int32_t* list;    /* exception list, mi355q_bfp_list_bytes(list_cap) */
-    int32_t list_cap;       /* groups: entries of the list; rows: entries per bucket (0 = 120) */
+    const uint8_t* rowflag; /* [rows] */
+    const float* gscale;    /* row scales [rows_pad] */
+    const int32_t* list;    /* exception list, mi355q_bfp_row_list_bytes(rows, list_cap) */
+    int32_t list_cap;       /* entries per bucket (0 = 120) */
     int32_t mbits;          /* width - 1 */
     int32_t exp_bias;
-    int32_t row_aligned;    /* 0: 256-value groups (mi355q_bfp_align); 2: row format, nothing aligned (x only: MI355Q_ROW_NO_ALIGN;
+    int32_t row_aligned;    /* 2: row format, nothing aligned (x only: MI355Q_ROW_NO_ALIGN;
                              * the GEMM takes its blockwise-exact kernel: inputs no row window fits); 1: whole rows (mi355q_bfp_align_rows):
                              * rowflag [rows], gscale = rowscale [rows_pad], list = bucketed row list */
 } mi355q_bfp_operand;
 
-/* Same contraction as mi355q_bfp_gemm on operands rewritten by mi355q_bfp_align (K % 64 == 0).
- * With both exception lists within capacity the int32-chain kernel (one int32 MFMA chain + one fp32
- * rescale per 256-group) forms the product of the rewritten operands and a second, short launch adds
- * the exception blocks back exactly (fp32 atomics on y).  If a list overflowed, the blockwise-exact
- * kernel forms the whole product instead.  The choice is made on the device from the list counts.
- * Both lists must have the same list_cap; operands without gscale / list (or K % 256 != 0) use the
- * blockwise-exact kernel directly.
+/* Same contraction as mi355q_bfp_gemm on ROW-aligned tiled operands (K % 64 == 0).
  * ROW-aligned operands (row_aligned = 1 in both): the row-scale int8 GEMM (256 x 256 or 128 x 256 tiles, whole K in
  * int32, one fp32 scale per row and per column).  Each tile multiplies the exception blocks of its own rows / columns
  * with the other operand itself (one fp32 vector of products per exception, kept in LDS) and adds them in its store

@@ -387,56 +387,13 @@ size_t mi355q_bfp_rowflag_bytes(int64_t rows, int64_t K) {
 
 int64_t mi355q_bfp_rows_pad(int64_t rows) { return rows <= 0 ? 0 : (rows + 255) / 256 * 256 + 256; }
 
-size_t mi355q_bfp_list_bytes(int32_t list_cap) { return list_cap < 0 ? 0 : (size_t)(8 + 8 * (size_t)list_cap) * 4; }
 
 size_t mi355q_bfp_tiled_bytes(int64_t rows, int64_t K) {
     if (rows <= 0 || K <= 0) return 0;
     return static_cast<size_t>((rows + 127) / 128 * 128) * static_cast<size_t>((K + 63) / 64 * 64);
 }
 
-int mi355q_bfp_align(const int8_t* mant_in, const uint8_t* exp_in, int8_t* mant_out, int8_t* mant_tiled,
-                     uint8_t* exp_out, uint8_t* rowflag, float* gscale, int32_t* list, int32_t list_cap,
-                     int32_t exp_offset, int64_t rows, int64_t K, void* stream) {
-    if (rows < 0 || K < 0 || list_cap < 0) return MI355Q_E_BADARG;
-    if (rows == 0 || K == 0) return 0;
-    if (!mant_in || !exp_in || !exp_out || !rowflag || (!mant_out && !mant_tiled)) return MI355Q_E_BADARG;
-    if (K % 16 != 0 || (mant_tiled && K % 64 != 0)) return MI355Q_E_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(mant_in) | reinterpret_cast<uintptr_t>(mant_out) |
-         reinterpret_cast<uintptr_t>(mant_tiled)) % 4)
-        return MI355Q_E_ALIGN;
-    return launch_bfp_align(mant_in, exp_in, mant_out, exp_out, rowflag, gscale, mi355q_bfp_rows_pad(rows), exp_offset,
-                            list, list_cap, mant_tiled, rows, K, static_cast<hipStream_t>(stream));
-}
 
-int mi355q_block_fp_quantize_aligned(const float* x, int8_t* mant_tiled, uint8_t* exp_out, uint8_t* rowflag,
-                                     float* gscale, int32_t* list, int32_t list_cap, int32_t* list_to_clear,
-                                     int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
-                                     int32_t exponent_bias, void* stream) {
-    if (rows < 0 || K < 0 || list_cap < 0) return MI355Q_E_BADARG;
-    if (rows == 0 || K == 0) return 0;
-    if (!x || !mant_tiled || !exp_out || !rowflag || !gscale || !list) return MI355Q_E_BADARG;
-    if (K % 256 != 0) return MI355Q_E_UNSUPPORTED;
-    if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 8) return MI355Q_E_BADARG;
-    if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(mant_tiled) % 16) return MI355Q_E_ALIGN;
-    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
-    if (exponent_bias < 0) return MI355Q_E_UNSUPPORTED;          // biased uint8 exponent codes: non-negative biases only
-    QuantArgs a{};
-    a.x = x;
-    a.code = exp_out;
-    a.lead = 1; a.rows = rows; a.cols = K;
-    a.b0 = 1; a.b1 = 16;
-    a.n_elems = rows * K;
-    a.nbr = rows; a.nbc = K / 16;
-    a.n_blocks = rows * (K / 16);
-    a.flags = MI355Q_ZERO_BLOCK_FAST;
-    a.code_bias = exponent_bias;
-    a.e_min = -exponent_bias;
-    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
-    set_mantissa(a, width - 1);
-    if (list_to_clear == list) return MI355Q_E_BADARG;
-    return launch_quant_align(a, mant_tiled, rowflag, gscale, mi355q_bfp_rows_pad(rows), exponent_bias + width - 1, list,
-                              list_cap, list_to_clear, static_cast<hipStream_t>(stream));
-}
 
 
 static int bucket_cap_of(int32_t cap) { return cap == 0 ? ROW_BCAP : cap; }
@@ -583,22 +540,7 @@ static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_opera
         if (rc == 0 && a.x_post) rc = launch_bfp_gemm_rowpost(a, x->list, w->list, x->gscale, w->gscale, st);
         return rc;
     }
-    const long long mpad = mi355q_bfp_rows_pad(M), npad = mi355q_bfp_rows_pad(N);
-    const bool chain_ok = x->gscale && w->gscale && K % 256 == 0;
-    if (variant == 6 && chain_ok)   // int32-chain kernel alone, no exception add-back (benchmarks only)
-        return launch_bfp_gemm_v6(a, x->gscale, w->gscale, mpad, npad, nullptr, nullptr, 0, st);
-    const bool lists_ok = x->list && w->list && x->list_cap > 0;
-    if (variant == 2 || !chain_ok || !lists_ok)     // blockwise-exact kernel alone (+ per-tile exception add-back)
-        return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list,
-                                       x->list ? x->list_cap : w->list_cap, 0, st);
-    // default: int32-chain kernel, then one tail launch -- the exception add-back, or, when either operand has
-    // more exception blocks than its list holds, the whole product by the blockwise-exact body (the chain kernel
-    // returns at once then; the choice is made on the device from the list counts).
-    hipEvent_t te = g_timing.begin(st);
-    int rc = launch_bfp_gemm_v6(a, x->gscale, w->gscale, mpad, npad, x->list, w->list, x->list_cap, st);
-    g_timing.end(te, st);
-    if (rc) return rc;
-    return launch_bfp_gemm_tail(a, x->rowflag, w->rowflag, x->list, w->list, x->list_cap, st);
+    return MI355Q_E_UNSUPPORTED;      // (operands aligned per 256-value group: the format went with its kernel in round 5)
 }
 
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,

@@ -137,54 +137,6 @@ __global__ __launch_bounds__(256) void bfp_gemm_v1(const GemmArgs a) {
 }
 
 
-// =======================================================================================
-// Exponent-aligned operands ("aligned format")
-//   K is cut into groups of ALIGN_G = 16 blocks (256 values).  For a row and a group, if every
-//   block's mantissas can be shifted left onto the group's smallest exponent without leaving int8
-//   (5-bit W6 mantissas have 2 spare bits, W4 has 4), the row-group is stored shifted with ONE
-//   effective exponent and flagged 1; otherwise it is stored unchanged and flagged 0.
-//   (mant', eff_exp) denote exactly the same values as (mant, exp) -- variant 1 accepts them too.
-//   Variant 2 runs an int32 MFMA chain over a whole group (8 x v_mfma_i32_32x32x32_i8 per 32x32
-//   tile) when all 128 + 128 rows of the workgroup tile are flagged, and rescales ONCE per group;
-//   any other group takes the exact blockwise path.  Which path runs never changes the value.
-// =======================================================================================
-
-__global__ __launch_bounds__(256) void bfp_align_kernel(const int8_t* __restrict__ mi, const uint8_t* __restrict__ ei,
-                                                        int8_t* __restrict__ mo, uint8_t* __restrict__ eo,
-                                                        uint8_t* __restrict__ flag, float* __restrict__ gscale,
-                                                        long long rows_pad, int exp_offset, int* __restrict__ list,
-                                                        int list_cap, int8_t* __restrict__ mt, long long rows,
-                                                        long long K) {
-    const long long nkb = K >> 4, ngroups = (nkb + ALIGN_G - 1) / ALIGN_G;
-    const int lane = threadIdx.x & 63;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long pair = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; pair < rows * ngroups; pair += nwaves) {
-        const long long row = pair / ngroups, g = pair - row * ngroups;
-        const long long kb = g * ALIGN_G + (lane >> 2);
-        const bool valid = kb < nkb;
-        const long long moff = row * K + kb * 16 + (lane & 3) * 4;
-        const unsigned v = valid ? *reinterpret_cast<const unsigned*>(mi + moff) : 0u;
-        int q[4] = {(int)(int8_t)(v & 0xFF), (int)(int8_t)((v >> 8) & 0xFF), (int)(int8_t)((v >> 16) & 0xFF),
-                    (int)(int8_t)(v >> 24)};
-        int amax = max(max(abs(q[0]), abs(q[1])), max(abs(q[2]), abs(q[3])));
-        amax = max(amax, __shfl_xor(amax, 1));
-        amax = max(amax, __shfl_xor(amax, 2));
-        const int e = valid ? (int)ei[row * nkb + kb] : 0;
-        const AlignResult r = align_group(q, amax, e, valid, row, (int)kb, list, list_cap);
-        const unsigned out = (unsigned)(q[0] & 0xFF) | ((unsigned)(q[1] & 0xFF) << 8) | ((unsigned)(q[2] & 0xFF) << 16) |
-                             ((unsigned)(q[3] & 0xFF) << 24);
-        if (valid) {
-            if (mo) *reinterpret_cast<unsigned*>(mo + moff) = out;
-            if ((lane & 3) == 0) eo[row * nkb + kb] = (uint8_t)r.eout;
-            if (mt) *reinterpret_cast<unsigned*>(mt + tiled_offset(row, kb * 16 + (lane & 3) * 4, K)) = out;
-        }
-        if (lane == 0) {
-            flag[row * ngroups + g] = r.flagged ? 1 : 0;
-            // fast-GEMM view: one fp32 scale per (group, row); 0 neutralises a row-group that stayed unaligned
-            if (gscale) gscale[g * rows_pad + row] = r.flagged ? __builtin_ldexpf(1.0f, r.eout - exp_offset) : 0.0f;
-        }
-    }
-}
 
 // Row alignment of a packed operand (mi355q_align_row.h): one workgroup per row.  K % 64 == 0, K <= 1024 * MAXIT.
 template <int MAXIT>
@@ -268,21 +220,6 @@ __global__ __launch_bounds__(256, 2) void bfp_gemm_v2(const GemmArgs a, const ui
     }
 }
 
-int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
-                     long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
-                     long long K, hipStream_t st) {
-    const long long ngroups = ((K >> 4) + ALIGN_G - 1) / ALIGN_G;
-    long long grid = (rows * ngroups + 3) / 4;
-    if (grid > 4096) grid = 4096;
-    if (grid < 1) grid = 1;
-    if (list) {
-        const hipError_t e = hipMemsetAsync(list, 0, 32, st);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(bfp_align_kernel, (unsigned)grid, 256, 0, st, mi, ei, mo, eo, flag, gscale, rows_pad, exp_offset,
-                       list, list_cap, mt, rows, K);
-    return (int)hipGetLastError();
-}
 
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
                             const int* wlist, int list_cap, int guard, hipStream_t st) {

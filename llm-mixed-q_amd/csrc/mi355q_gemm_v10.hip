@@ -58,6 +58,17 @@ template <int OFF> __device__ __forceinline__ void v10_dsr(i32x4& d, int addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 #define V10_SB() __builtin_amdgcn_sched_barrier(0)
+// split-K slabs: 16-byte stores / loads at AGENT scope (sc1: through the workgroup's own L2 to the level every XCD sees) -- the
+// release / acquire fences they replace write back and invalidate the whole L2 of the XCD (buffer_wbl2 / buffer_inv), with every
+// workgroup of the grid doing so at once: ~10 us of a 24-us launch (tools/dbg/v10_stamps.py, round 5)
+template <class T> __device__ __forceinline__ void v10_store_agent(T* p, const T& v) {
+    static_assert(sizeof(T) == 16, "one dwordx4");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <class T> __device__ __forceinline__ void v10_load_agent(T& v, const T* p) {
+    static_assert(sizeof(T) == 16, "one dwordx4");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
 // LDS-DMA as inline assembly (the compiler must not know it is pending: mi355q_gemm_v9.hip); M0 written in the statement
 #define V10_BLDS16(vo, rs, so, lds) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so), "s"(lds) : "memory")
 #define V10_BLDS4(vo, rs, so, lds) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so), "s"(lds) : "memory")
@@ -253,7 +264,11 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     using acc_t = typename std::conditional<BF16, f32x4, i32x4>::type;
     // lane-constant part of the fragment addresses; fragment i is i KiB further (immediate offset)
     const int va = ring_lds + piece_lds_off(wm * WM + l16, lq), vb = ring_lds + PA * 1024 + piece_lds_off(wn * WN + l16, lq);
-    i32x4 fa[4], fb[2][TJ];
+    // DEEP (the 64-row wave tile): ALL of the next K-step's fragments are read during this step -- a wave that is alone on its SIMD
+    // (grids of <= 256 workgroups: every launch this tile is chosen for) has no partner whose MFMAs cover the ~130 clocks of an LDS
+    // round trip, and a two-group window leaves them exposed (tools/ubench/vmem_issue.hip: 455 -> 355 clocks a K-step)
+    constexpr bool DEEP = TI == 4;
+    i32x4 fa[DEEP ? 2 * TI : 4], fb[2][TJ];
 
     // ---- exception bookkeeping state.  Buckets: LDS copies of the tile's two buckets (EARLY: beside the ring, else in the ring
     //      behind the K loop); vectors: VLEN floats per entry in the ring behind the K loop
@@ -385,6 +400,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     v10_for<0, TJ>([&](auto ji) { constexpr int j = decltype(ji)::value; v10_dsr<j * 1024>(fb[0][j], vb); });
     v10_dsr<0>(fa[0], va);
     v10_dsr<1024>(fa[1], va);
+    if constexpr (DEEP) {
+        v10_dsr<2048>(fa[2], va);
+        v10_dsr<3072>(fa[3], va);
+    }
     V10_SB();
     acc_t acc[TI][TJ];
 #pragma unroll
@@ -400,8 +419,28 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     auto body = [&](auto ci, int t, int sc, int sn, int sd) {
         constexpr int C = decltype(ci)::value;
         v10_waitv<(NS - 3) * LPW>();
+        if constexpr (DEEP) v10_lgkm<0>();                      // this step's fragments, read during the last one
         __builtin_amdgcn_s_barrier();
         const int ac = va + sc, an = va + sn, bn = vb + sn;
+        if constexpr (DEEP) {
+            // group 0: the next step's four B fragments, one behind each MFMA; group 1: its four A fragments; one LDS-DMA piece a
+            // group behind MFMA 1
+            (void)ac;
+            v10_for<0, TI>([&](auto gi) {
+                constexpr int g = decltype(gi)::value;
+                v10_for<0, TJ>([&](auto ji) {
+                    constexpr int j = decltype(ji)::value;
+                    V10_SB();
+                    acc[g][j] = v10_mma(fb[C][j], fa[C * TI + g], acc[g][j]);
+                    V10_SB();
+                    if constexpr (g == 0) v10_dsr<j * 1024>(fb[1 - C][j], bn);
+                    if constexpr (g == 1) v10_dsr<j * 1024>(fa[(1 - C) * TI + j], an);
+                    if constexpr (j == 1 && g < LPW) piece(std::integral_constant<int, g>{}, t + NS - 1, sd);
+                    if constexpr (j == 3 && g + TI < LPW) piece(std::integral_constant<int, (g + TI < LPW ? g + TI : 0)>{}, t + NS - 1, sd);
+                });
+            });
+            V10_SB();
+        } else
         v10_for<0, TI>([&](auto gi) {
             constexpr int g = decltype(gi)::value;
             if constexpr (g + 2 < TI) v10_dsr<(g + 2) * 1024>(fa[(g + 2) & 3], ac);
@@ -453,42 +492,81 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     __builtin_amdgcn_s_barrier();                               // (every wave is out of the ring)
 
     if (S_ > 1) {
-        // ---- split-K: every slice leaves its raw accumulators in its slab; the slice that arrives last at the tile's ticket
-        //      sums all slabs IN SLICE ORDER and goes on to the epilogue, the others leave (mi355q_gemm_v9.hip, Guideline 16)
+        // ---- split-K.  a.tickets holds two words a tile: arrivals, published slabs.
+        // Order-free sums (int32: exact whatever the order; two slices of fp32: a + b == b + a): a slice takes its ticket FIRST; every
+        // slice but the last to arrive publishes its raw accumulators in the slab of its arrival number and leaves; the last one keeps
+        // its own in registers, waits until the others' slabs are published -- they took their tickets before it, so they are past their
+        // K loops and publish without waiting for anybody: no co-residency is assumed -- and adds them.  Half the slab traffic of
+        // everybody-stores, and no store in front of the finisher's ticket.
+        // Ordered sums (fp32, more than two slices): every slice stores, the last arriver sums all slabs IN SLICE ORDER
+        // (reproducible; mi355q_gemm_v9.hip, Guideline 16).
+        // Slab accesses at agent scope (v10_store_agent / v10_load_agent) instead of release / acquire fences.
         constexpr long long SLAB = (long long)BM * BN * 4;
-        acc_t* slab = reinterpret_cast<acc_t*>(static_cast<unsigned char*>(a.slabs) + ((long long)tile_id * S_ + split) * SLAB);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) slab[((wave * TI + i) * TJ + j) * 64 + lane] = acc[i][j];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        acc_t* tslabs = reinterpret_cast<acc_t*>(static_cast<unsigned char*>(a.slabs) + (long long)tile_id * S_ * SLAB);
+        int* arrivals = a.tickets + 2 * tile_id;
+        int* published = arrivals + 1;
         int* flagw = flags + 8;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int tk = __hip_atomic_fetch_add(&a.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = tk == S_ - 1 ? 1 : 0;
-            if (last) {
-                __hip_atomic_store(&a.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle again
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            *flagw = last;
-        }
-        __syncthreads();
-        if (*flagw == 0) return;
-        const acc_t* tslabs = reinterpret_cast<const acc_t*>(static_cast<unsigned char*>(a.slabs) + (long long)tile_id * S_ * SLAB);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-        for (int sl = 0; sl < S_; ++sl) {
-            const acc_t* sp = tslabs + (long long)sl * (SLAB / 16);
+        const bool ordered = BF16 && S_ > 2;
+        if (ordered) {
+            acc_t* slab = tslabs + (long long)split * (SLAB / 16);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] += sp[((wave * TI + i) * TJ + j) * 64 + lane];
+                for (int j = 0; j < TJ; ++j) v10_store_agent(&slab[((wave * TI + i) * TJ + j) * 64 + lane], acc[i][j]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (agent-scope stores: acknowledged where every XCD reads them)
+            __syncthreads();
+            if (tid == 0) {
+                const int tk = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == S_ - 1) __hip_atomic_store(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle again
+                *flagw = tk;
+            }
+            __syncthreads();
+            if (*flagw != S_ - 1) return;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+        } else {
+            if (tid == 0) *flagw = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int tk = __builtin_amdgcn_readfirstlane(*flagw);
+            if (tk != S_ - 1) {
+                acc_t* slab = tslabs + (long long)tk * (SLAB / 16);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) v10_store_agent(&slab[((wave * TI + i) * TJ + j) * 64 + lane], acc[i][j]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) (void)__hip_atomic_fetch_add(published, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (tid == 0) {
+                __hip_atomic_store(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                     // idle again
+                while (__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S_ - 1) __builtin_amdgcn_s_sleep(2);
+                __hip_atomic_store(published, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        const int nslabs = ordered ? S_ : S_ - 1;
+        for (int sl = 0; sl < nslabs; ++sl) {
+            const acc_t* sp = tslabs + (long long)sl * (SLAB / 16);
+            constexpr int CH = TI > 4 ? 2 : TI;                  // rows of tiles in flight together (registers: 16 CH)
+            v10_for<0, TI / CH>([&](auto ci) {
+                constexpr int i0 = decltype(ci)::value * CH;
+                acc_t part[CH][TJ];
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) v10_load_agent(part[i][j], &sp[((wave * TI + i0 + i) * TJ + j) * 64 + lane]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                V10_SB();                                       // (the compiler does not know the loads were in flight)
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) acc[i0 + i][j] += part[i][j];
+                V10_SB();
+            });
         }
     }
 

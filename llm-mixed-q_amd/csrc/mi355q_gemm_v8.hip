@@ -755,7 +755,7 @@ static int v10_forced_launch(const GemmArgs& a_in, const float* sx, const float*
     while (S > 1 && (nsteps_all % S || nsteps_all / S < 2)) --S;
     a.splits = 1;
     if (S > 1) {
-        SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * bm * bn * 4, (int)tiles);
+        SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * bm * bn * 4, 2 * (int)tiles);      // (two ticket words a tile)
         if (w) {
             a.splits = S;
             a.slabs = w->slabs;
@@ -800,10 +800,10 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     const char* force = getenv("MI355Q_V8_TILE_ROWS");          // (tests pin either flavour)
     const bool small = force && atoi(force) ? atoi(force) == 128 : cost128 < cost256;
     // K-loop schedule of the 128 x 256 tile: 2 = the pipelined one of the 256 x 256 tile (round 4, default), 1 = one phase per step
-    static const int small_sched = getenv("MI355Q_V8_SMALL_SCHED") ? atoi(getenv("MI355Q_V8_SMALL_SCHED")) : 2;
+    constexpr int small_sched = 2;          // (the one-phase schedule only serves K % 128 == 64 now; its switch went in round 5)
     unsigned tiles = (unsigned)(small ? t128 : t256);
     {   // under-filled grid: split K (the 128-row tile's schedule takes any slice length, the 256-row one even ones)
-        static const int sched_ = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
+        constexpr int sched_ = 2;
         const int S = choose_splits(tiles, (int)(a.K >> 6), sched_ == 2 && (!small || small_sched == 2), xlist && wlist ? 32 : 8);
         a.splits = 1;
         if (S > 1) {
@@ -821,11 +821,10 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     static const bool want_clock = getenv("MI355Q_V8_CLOCK") != nullptr, want_stamps = getenv("MI355Q_V8_STAMPS") != nullptr;
     const bool fix = xlist && wlist;
     if (fix && (!xf || !wf)) return MI355Q_E_BADARG;
-    static const int dbg = getenv("MI355Q_V8_DBG") ? atoi(getenv("MI355Q_V8_DBG")) : 0;    // (stamps build only: see a.dbg)
-    a.dbg = dbg;
+    a.dbg = 0;
     // K-loop schedule of the 256 x 256 tile: 2 = pipelined (one barrier per K-step, default: 71.0 vs 72.8 us at 4096^3),
     // 0 = two staggered wave groups, four barriers per K-step (kept for A/B runs: MI355Q_V8_SCHED=0)
-    static const int sched = getenv("MI355Q_V8_SCHED") ? atoi(getenv("MI355Q_V8_SCHED")) : 2;
+    constexpr int sched = 2;             // (the four-barrier schedule only serves K % 128 == 64 now; its switch went in round 5)
     const unsigned grid = tiles;            // (on a bucket overflow the tile workgroups themselves form the product blockwise)
     // the 256 x 256 tile has its own kernel since round 3 (mi355q_gemm_v9.hip); MI355Q_V9=0 keeps the round-2 one for A/B runs
     static const int use_v9 = getenv("MI355Q_V9") ? atoi(getenv("MI355Q_V9")) : 1;
@@ -849,8 +848,7 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
     //  128-row tiles there -- the two kernels add a row's corrections in different fp32 orders)
     // (round 5: grouped launches too -- the small-tile kernel their separate launches may take adds a row's corrections in this
     //  kernel's order, tests/test_gpu_gemm.py::test_small_tiles_equal_the_256_tile_bit_for_bit)
-    static const int v9_groups = getenv("MI355Q_V9_GROUPS") ? atoi(getenv("MI355Q_V9_GROUPS")) : 1;
-    if (use_v9 && (v9_fix || !fix) && (a.ngroup <= 1 || v9_groups) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
+        if (use_v9 && (v9_fix || !fix) && !small && sched == 2 && a.K % 128 == 0 && (a.K >> 6) / (a.splits > 1 ? a.splits : 1) >= 4 && !want_clock && !want_stamps)
         return launch_bfp_gemm_v9(a, sx, sw, xlist, wlist, st, xf, wf, false);
     if (small) {
         const bool piped = small_sched == 2 && a.K % 128 == 0 && (((a.K >> 6) / (a.splits > 1 ? a.splits : 1)) & 1) == 0;
@@ -925,7 +923,7 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
             }
         }
     }
-    static const int small_sched = getenv("MI355Q_V8_SMALL_SCHED") ? atoi(getenv("MI355Q_V8_SMALL_SCHED")) : 2;
+    constexpr int small_sched = 2;          // (the one-phase schedule only serves K % 128 == 64 now; its switch went in round 5)
     static const bool use_v9_bf16 = !(getenv("MI355Q_V9") && atoi(getenv("MI355Q_V9")) == 0);        // (read once: ADVICE r4)
     if (small && small_sched == 2 && a.K % 128 == 0 && (((a.K >> 6) / (a.splits > 1 ? a.splits : 1)) & 1) == 0)
         hipLaunchKernelGGL((bfp_gemm_v8<0, 4, 2, true>), tiles, V8_NT, 0, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);

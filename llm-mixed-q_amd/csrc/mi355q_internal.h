@@ -41,8 +41,6 @@ struct QuantArgs {
 
 int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
 int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only = false, int fmt = 0 /* FMT_BFP; 1 = FMT_BM */);
-int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
-                       int* list, int list_cap, int* list_to_clear, hipStream_t st);
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
                             int* list_to_clear, hipStream_t st, int bcap);
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
@@ -118,11 +116,6 @@ int launch_bfp_pack_bits(const int8_t* mant, uint16_t* out, long long rows, long
 int launch_bfp_expand(int mode, const uint16_t* packed, const uint8_t* codes, void* out, long long rows, long long K, int width,
                       int off, hipStream_t st, const uint8_t* rowexp = nullptr, uint8_t* exp_out = nullptr);
 int launch_bf16_gemm_tiled(const GemmArgs& a, hipStream_t st);
-int launch_bfp_gemm_tail(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist, const int* wlist,
-                         int list_cap, hipStream_t st, const float* xscale = nullptr, const float* wscale = nullptr);
-int launch_bfp_align(const int8_t* mi, const uint8_t* ei, int8_t* mo, uint8_t* eo, uint8_t* flag, float* gscale,
-                     long long rows_pad, int exp_offset, int* list, int list_cap, int8_t* mt, long long rows,
-                     long long K, hipStream_t st);
 // W4A4 / W5A5 on the MX scaled matrix instruction (mi355q_mx.hip; operand planes: mi355q_quant.hip, MxOut)
 int launch_quant_mx_rows(const QuantArgs& a, uint8_t* c16, uint8_t* c8, uint8_t* sc, int* bad, int* bad_clear, hipStream_t st);
 struct MxGemmArgs {
@@ -135,8 +128,6 @@ struct MxGemmArgs {
     QuantArgs qx;                                     // x's quantiser parameters (the exact route)
 };
 int launch_mx_gemm(const MxGemmArgs& a, hipStream_t st);
-int launch_bfp_gemm_v6(const GemmArgs& a, const float* gx, const float* gw, long long mpad, long long npad,
-                       const int* xlist, const int* wlist, int list_cap, hipStream_t st);
 
 }  // namespace mi355q
 #endif

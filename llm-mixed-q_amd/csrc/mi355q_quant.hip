@@ -27,7 +27,6 @@
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
-#include "mi355q_align.h"
 #include "mi355q_align_row.h"
 
 #include "mi355q_quant_dev.h"
@@ -512,10 +511,8 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
         // (measured, profiles/r03_quantizers_bench.json: the 512-MiB probability tensors gain 10-25 % from owned pieces --
         //  block_log, whose three tables cost most per workgroup, with 4 of them, the others with 2; up to 172 MiB the
         //  grid-stride loop is as fast or faster)
-        static const int pieces_env = getenv("MI355Q_QV_PIECES") ? atoi(getenv("MI355Q_QV_PIECES")) : -1;
         const long long n4_pad = ((a.n_elems >> 2) + 63) & ~63ll;
-        const int pieces = pieces_env == 0 || pieces_env == 1 || pieces_env == 2 || pieces_env == 4 ? pieces_env
-                           : a.n_elems >= (1ll << 26) ? (FMT == FMT_BL ? 4 : 2) : 0;
+        const int pieces = a.n_elems >= (1ll << 26) ? (FMT == FMT_BL ? 4 : 2) : 0;
         grid = pieces ? (int)((n4_pad + 256ll * pieces - 1) / (256ll * pieces)) : grid_for(a.n_elems >> 2, 256);
 #define QV_LAUNCH(L) \
         if (pieces == 0) hipLaunchKernelGGL((quant_vec_kernel<FMT, L, 0>), grid, 256, 0, st, a); \
@@ -542,8 +539,7 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
     if (e != hipSuccess) return (int)e;
     if (needs_fixup && (a.flags & MI355Q_ZERO_BLOCK_FAST) == 0u) {
         // (a grid that exits at once costs its dispatch: 256 workgroups for the launch-bound sizes)
-        static const int fg_env = getenv("MI355Q_FIXUP_GRID") ? atoi(getenv("MI355Q_FIXUP_GRID")) : 0;
-        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), a.zmap ? (fg_env ? fg_env : FIXUP_GRID_MAP) : a.n_elems >= (1 << 24) ? FIXUP_GRID : 256, 256, 0, st, a,
+        hipLaunchKernelGGL((zero_fixup_kernel<FMT>), a.zmap ? FIXUP_GRID_MAP : a.n_elems >= (1 << 24) ? FIXUP_GRID : 256, 256, 0, st, a,
                            grid < WS_SLOTS ? grid : WS_SLOTS);
         e = hipGetLastError();
     }
@@ -551,23 +547,6 @@ static int launch_format(const QuantArgs& a_in, bool needs_fixup, hipStream_t st
 }
 
 
-// ---------------------------------------------------------------------------------------
-// Fused activation path of the fast GEMM: block_fp quantise + pack + exponent-align + tile, one pass
-// over x (b0 = 1, b1 = 16, cols % 256 == 0).  One wave iteration = one (row, 256-value group): lane l
-// holds elements 4l..4l+3, block = l / 4.  Outputs are exactly what mi355q_bfp_align would produce from
-// the packed tensor (tests compare the two), with MI355Q_ZERO_BLOCK_FAST semantics for all-zero blocks:
-//   mt      tiled aligned mantissas (see mi355q_gemm.hip: tiled_offset)
-//   eo      effective exponent code per block, rowflag per (row, group), gscale fp32 per (group, row)
-//   list    (row, group) pairs that could not be aligned (count in list[0]; zero before the call)
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ long long tiled_offset_q(long long row, long long k, long long K) {
-    const long long piece = (row >> 4) * (K >> 6) + (k >> 6);
-    return piece * 1024 + ((k >> 4) & 3) * 256 + (row & 15) * 16 + (k & 15);
-}
-
-// DPP helpers on ints: rotate within a row of 16 lanes
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
 
 // ceil(log2(v)) for finite v > 0 without branches: v_frexp splits normals and subnormals alike
 __device__ __forceinline__ int ceil_log2_frexp(float v, const Lut& lut) {
@@ -582,85 +561,9 @@ __device__ __forceinline__ float mant_f(float x, int up, float mmax) {
     const float sm = __builtin_copysignf(m, t);
     return t == 0.f ? 0.f : sm;
 }
-// The same without the x + 1e-9 == 0 special case, valid when up < 28: there x = -1e-9 gives m = rne(2e-9 * 2^up) = 0
-// anyway, so the sign carrier being zero changes nothing.
-__device__ __forceinline__ float mant_f_small_up(float x, int up, float mmax) {
-    const float m = fminf(__builtin_rintf(__builtin_ldexpf(fabsf(x) + EPS9, up)), mmax);
-    return __builtin_copysignf(m, x + EPS9);
-}
-
-__global__ __launch_bounds__(256) void bfp_quant_align_kernel(const QuantArgs a, int8_t* __restrict__ mt,
-                                                              uint8_t* __restrict__ flag, float* __restrict__ gscale,
-                                                              long long rows_pad, int exp_offset, int* __restrict__ list,
-                                                              int list_cap, int* __restrict__ list_to_clear) {
-    __shared__ Lut lut;
-    load_lut<FMT_BFP>(lut);
-    const int lane = threadIdx.x & 63;
-    if (list_to_clear && blockIdx.x == 0 && threadIdx.x == 0) { list_to_clear[0] = 0; list_to_clear[1] = 0; }
-    const long long K = a.cols;
-    const int ngroups = (int)(K >> 8), nkb = (int)(K >> 4), kpieces = (int)(K >> 6);
-    const long long npairs = a.rows * ngroups;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
-    // One wave iteration = one (row, group) pair = 1 KiB of x; pair, row and g are wave-uniform (scalar
-    // registers), advanced without division; the next pair's load is issued before this pair's arithmetic.
-    long long pair = ((long long)blockIdx.x * (blockDim.x >> 6)) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    long long row = pair / ngroups;
-    int g = (int)(pair - row * ngroups);
-    const long long drow = nwaves / ngroups;
-    const int dg = (int)(nwaves - drow * ngroups);
-    // lane-constant part of the tiled address: chunk (lane >> 2) & 3 of piece lane >> 4, 4 bytes at (lane & 3) * 4
-    const int lane_chunk = (lane >> 2) & 3;
-    const int lane_off = (lane >> 4) * 1024 + lane_chunk * 256 + (lane & 3) * 4;
-    const int mbits_int = (int)__builtin_log2f(a.shift);
-    float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pair < npairs) vnext = x4[pair * 64 + lane];
-    for (; pair < npairs; pair += nwaves) {
-        const float4 v = vnext;
-        if (pair + nwaves < npairs) vnext = x4[(pair + nwaves) * 64 + lane];
-        float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        bmax = group_max<4>(bmax);
-        const bool nz = bmax != 0.f;
-        const float bm1 = nz ? bmax : 1.0f;                     // all-zero block: fill 1 (MI355Q_ZERO_BLOCK_FAST)
-        const int e = clampi(ceil_log2_frexp(bm1, lut), a.e_min, a.e_max);
-        const int up = mbits_int - e;
-        const float f0 = mant_f(v.x, up, a.mant_max), f1 = mant_f(v.y, up, a.mant_max);
-        const float f2 = mant_f(v.z, up, a.mant_max), f3 = mant_f(v.w, up, a.mant_max);
-        // largest |mantissa| of the block = mantissa of its largest element (rounding is monotone) -- except that an
-        // element equal to -1e-9 has mantissa 0 whatever the scale (blocks below 2^-23 only: take the formed maximum)
-        int amax = nz ? (int)mant_f(bmax, up, a.mant_max) : 0;
-        if (__any(up >= 28)) amax = (int)group_max<4>(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3))));
-        const int code = e + a.code_bias;
-        int q[4] = {(int)f0, (int)f1, (int)f2, (int)f3};
-        const AlignResult r = align_group(q, amax, code, true, row, g * 16 + (lane >> 2), list, list_cap);
-        const bool all_ok = r.flagged;
-        const int eout = r.eout;
-        const int q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);   // bytes: q0.b0, q1.b0
-        const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x04000c0cu);   // q2.b0 -> byte2, q3.b0 -> byte3
-        int8_t* prow = mt + ((row >> 4) * kpieces + g * 4) * 1024 + (row & 15) * 16;       // wave-uniform
-        *reinterpret_cast<unsigned*>(prow + lane_off) = lo | hi;
-        if ((lane & 3) == 0) a.code[row * nkb + g * 16 + (lane >> 2)] = (uint8_t)eout;
-        if (lane == 0) {
-            flag[row * ngroups + g] = all_ok ? 1 : 0;
-            gscale[g * rows_pad + row] = all_ok ? __builtin_ldexpf(1.0f, eout - exp_offset) : 0.0f;
-        }
-        row += drow;
-        g += dg;
-        if (g >= ngroups) { g -= ngroups; ++row; }
-    }
-}
-
-int launch_quant_align(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* gscale, long long rows_pad, int exp_offset,
-                       int* list, int list_cap, int* list_to_clear, hipStream_t st) {
-    const long long pairs = a.rows * (a.cols >> 8);
-    long long grid = (pairs + 3) / 4;
-    if (grid > 2048) grid = 2048;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(bfp_quant_align_kernel, (unsigned)grid, 256, 0, st, a, mt, flag, gscale, rows_pad, exp_offset, list,
-                       list_cap, list_to_clear);
-    return (int)hipGetLastError();
-}
+// DPP helpers on ints: rotate within a row of 16 lanes
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
 
 // ---------------------------------------------------------------------------------------
 // Fused activation path, ROW-aligned flavour (mi355q_align_row.h): one 256-thread workgroup per row keeps the
@@ -957,8 +860,7 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     long long grid = a.rows;
     if (grid > 65536) grid = 65536;
     // plain rows: a fixed grid of 4 workgroups per compute unit, several rows each with the next row's loads in flight
-    // (MI355Q_QROWS_GRID: 0 = one workgroup per row as before)
-    static const int qgrid = getenv("MI355Q_QROWS_GRID") ? atoi(getenv("MI355Q_QROWS_GRID")) : 1024;
+    constexpr int qgrid = 1024;
     if (qgrid > 0 && a.pre_op == 0 && !a.seg_len && grid > qgrid) grid = qgrid;
     if (grid < 1) grid = 1;
 #define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
@@ -981,7 +883,7 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
 // block_fp -> MX operand (mi355q_mx.hip): rows x K fp32, K % 128 == 0, width <= 5; `bad` is RAISED, never cleared here
 int launch_quant_mx_rows(const QuantArgs& a, uint8_t* c16, uint8_t* c8, uint8_t* sc, int* bad, int* bad_clear, hipStream_t st) {
     long long grid = a.rows;
-    static const int qgrid = getenv("MI355Q_QROWS_GRID") ? atoi(getenv("MI355Q_QROWS_GRID")) : 1024;
+    constexpr int qgrid = 1024;
     if (qgrid > 0 && a.pre_op == 0 && grid > qgrid) grid = qgrid;
     if (grid > 65536) grid = 65536;
     if (grid < 1) grid = 1;

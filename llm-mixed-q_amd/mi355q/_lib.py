@@ -46,10 +46,6 @@ SIGNATURES = {
     "mi355q_bfp_rowflag_bytes": (C.c_size_t, [_i64, _i64]),
     "mi355q_bfp_rows_pad": (_i64, [_i64]),
     "mi355q_bfp_tiled_bytes": (C.c_size_t, [_i64, _i64]),
-    "mi355q_bfp_list_bytes": (C.c_size_t, [C.c_int32]),
-    "mi355q_bfp_align": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp]),
-    "mi355q_block_fp_quantize_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32,
-                                                   _i32, _vp]),
     "mi355q_bfp_row_list_bytes": (C.c_size_t, [_i64, _i32]),
     "mi355q_bfp_align_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp]),
     "mi355q_block_fp_quantize_aligned_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,

@@ -545,30 +545,22 @@ def bfp_gemm(xm: torch.Tensor, xe: torch.Tensor, wm: torch.Tensor, we: torch.Ten
     return out
 
 
-SPARSE_LIST_CAP = 1024          # exception blocks an operand may carry before the GEMM falls back to its blockwise kernel
-
-
-def _new_exception_list(device):
-    n = _lib.load_library().mi355q_bfp_list_bytes(SPARSE_LIST_CAP) // 4
-    return torch.zeros(n, dtype=torch.int32, device=device)
-
-
 class AlignedOperand:
-    """A packed block-fp operand rewritten for the fast GEMM (include/mi355q.h, mi355q_bfp_align):
-    exponent-aligned mantissas, effective exponents, per (row, group) flags and fp32 group scales,
-    and the list of exception blocks (blocks outside their group's exponent window, kept aside exactly)."""
+    """A packed block-fp operand rewritten for the row-scale GEMM (include/mi355q.h, mi355q_bfp_align_rows):
+    exponent-aligned tiled mantissas, effective exponents, per-row flags and fp32 row scales, and the bucketed list of
+    exception blocks (blocks outside their row's exponent window, kept aside exactly)."""
 
-    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias, row_aligned=False,
+    def __init__(self, rows, K, mant, tiled, exp, rowflag, gscale, sparse, mbits, exp_bias, row_aligned=True,
                  bucket_cap=None):
+        assert row_aligned, "the 256-value-group flavour was removed in round 5"
         self.rows, self.K = int(rows), int(K)
         self.mant, self.tiled = mant, tiled          # row-major (may be None) / tiled (what the GEMM reads)
         self.exp, self.rowflag, self.gscale, self.sparse = exp, rowflag, gscale, sparse
         self.mbits, self.exp_bias = int(mbits), int(exp_bias)
-        self.row_aligned = bool(row_aligned)         # one exponent per ROW (mi355q_bfp_align_rows) instead of per 256 values
-        # entries the list holds: per 256-row bucket (rows) / in all (groups)
-        self.unaligned = bool(row_aligned) and bucket_cap is not None and int(bucket_cap) < 0   # row format, own exponents
-        self.list_cap = (int(bucket_cap) if bucket_cap and int(bucket_cap) > 0
-                         else (ROW_BUCKET_CAP if row_aligned else SPARSE_LIST_CAP))
+        self.row_aligned = True                      # one exponent per ROW (mi355q_bfp_align_rows)
+        # entries the list holds per 256-row bucket
+        self.unaligned = bucket_cap is not None and int(bucket_cap) < 0   # row format, own exponents
+        self.list_cap = int(bucket_cap) if bucket_cap and int(bucket_cap) > 0 else ROW_BUCKET_CAP
 
     def c_struct(self):
         cs = getattr(self, "_cs", None)
@@ -578,31 +570,6 @@ class AlignedOperand:
                                             2 if self.unaligned else int(self.row_aligned))
             self._cs_addr = __import__("ctypes").addressof(cs)
         return cs
-
-
-def bfp_align(mant: torch.Tensor, exp: torch.Tensor, mbits: int, exp_bias: int, inplace: bool = False,
-              keep_row_major: bool = False, with_list: bool = True) -> AlignedOperand:
-    """Rewrite a packed [rows, K] operand into the exponent-aligned, tiled format of the fast GEMM
-    (same values).  K % 64 == 0.  `keep_row_major` also returns the aligned mantissas row-major."""
-    if not mant.is_cuda:
-        raise RuntimeError("mi355q.bfp_align: operands must be on a HIP device; there is no CPU fallback")
-    rows, K = mant.shape
-    assert mant.dtype == torch.int8 and exp.dtype == torch.uint8 and mant.is_contiguous() and exp.is_contiguous()
-    assert exp.numel() == rows * (K // 16)
-    lib = _lib.load_library()
-    mo = (mant if inplace else torch.empty_like(mant)) if keep_row_major else None
-    eo = exp if inplace else torch.empty_like(exp)
-    tiled = torch.empty(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=mant.device)
-    groups = (K + 255) // 256
-    flag = torch.empty(rows, groups, dtype=torch.uint8, device=mant.device)
-    gscale = torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=mant.device)
-    sparse = _new_exception_list(mant.device) if with_list else None
-    with _on_device(mant.device):
-        rc = lib.mi355q_bfp_align(_ptr(mant), _ptr(exp), _ptr(mo), _ptr(tiled), _ptr(eo), _ptr(flag), _ptr(gscale),
-                                  _ptr(sparse), SPARSE_LIST_CAP, int(exp_bias) + int(mbits), rows, K,
-                                  _stream_ptr(mant.device))
-    _lib.check(rc, "mi355q_bfp_align")
-    return AlignedOperand(rows, K, mo, tiled, eo, flag, gscale, sparse, mbits, exp_bias)
 
 
 ROW_ALIGN_MAX_K = 16384
@@ -791,10 +758,10 @@ class _ActivationBuffers:
     _cache = _StreamCache(32)
 
     @classmethod
-    def get(cls, device, rows, K, row_aligned=False, sp=None, bucket_cap=0):
+    def get(cls, device, rows, K, row_aligned=True, sp=None, bucket_cap=0):
         key = (device.index, _stream_ptr(device) if sp is None else sp, rows, K, row_aligned, bucket_cap)
         buf = cls._cache.get(key)
-        if buf is None and row_aligned:
+        if buf is None:
             lib = _lib.load_library()
             buf = dict(
                 tiled=torch.zeros(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=device),
@@ -804,44 +771,7 @@ class _ActivationBuffers:
                 sparse=[_new_row_list(device, rows, bucket_cap) for _ in range(2)] if bucket_cap >= 0 else [None, None],
                 calls=0)
             cls._cache.put(key, buf)
-        if buf is None:
-            lib = _lib.load_library()
-            groups = K // 256
-            buf = dict(
-                tiled=torch.empty(lib.mi355q_bfp_tiled_bytes(rows, K), dtype=torch.int8, device=device),
-                exp=torch.empty(rows * (K // 16), dtype=torch.uint8, device=device),
-                flag=torch.empty(rows, groups, dtype=torch.uint8, device=device),
-                gscale=torch.empty(groups, lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=device),
-                sparse=[_new_exception_list(device) for _ in range(2)],
-                calls=0)
-            cls._cache.put(key, buf)
         return buf
-
-
-def block_fp_quantize_aligned(x: torch.Tensor, width: int, exponent_width: int, exponent_bias) -> AlignedOperand:
-    """Fused activation path: x [rows, K] fp32 -> quantise ([1,16] blocks) + pack + align + tile in one
-    kernel (K % 256 == 0).  The returned operand lives in buffers that the next call with the same
-    shape on the same stream reuses: consume it (bfp_gemm_aligned) before quantising again."""
-    _require_device(x, "block_fp_quantize_aligned")
-    assert x.ndim == 2 and x.shape[1] % 256 == 0
-    rows, K = x.shape
-    xc = x.contiguous()
-    buf = _ActivationBuffers.get(x.device, rows, K)
-    bias = _default_bias(exponent_bias)
-    lib = _lib.load_library()
-    if _capturing():
-        cur, nxt = _new_exception_list(x.device), None     # (see block_fp_quantize_aligned_rows)
-    else:
-        cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
-        buf["calls"] += 1
-    with _on_device(x.device):
-        rc = lib.mi355q_block_fp_quantize_aligned(_ptr(xc), _ptr(buf["tiled"]), _ptr(buf["exp"]), _ptr(buf["flag"]),
-                                                  _ptr(buf["gscale"]), _ptr(cur), SPARSE_LIST_CAP, _ptr(nxt), rows, K,
-                                                  int(width), int(exponent_width), bias, _stream_ptr(x.device))
-    _lib.check(rc, "mi355q_block_fp_quantize_aligned")
-    eb = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
-    return AlignedOperand(rows, K, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur,
-                          int(width) - 1, eb)
 
 
 # Several layers often take the SAME activation (q / k / v projections of an attention block, gate / up of a gated MLP):

@@ -110,8 +110,9 @@ class _LinearBase(nn.Linear):
         self.x_quantizer = self.w_quantizer = self.b_quantizer = None
         self._packed = None          # (aligned W operand, its tiled mantissas, weight._version, bias._version)
         # exponent alignment of the packed operands (an implementation knob, not part of the reference config):
-        # "rows" = one exponent per row (row-scale int8 GEMM), "groups" = per 256 values, "auto" = rows when the
-        # weights and the first activations fit it, re-checked on a doubling schedule
+        # "rows" = one exponent per row (row-scale int8 GEMM), "blocks" = every block keeps its exponent (bf16 tile GEMM),
+        # "auto" = rows when the weights and the first activations fit it, re-checked on a doubling schedule
+        # (the alignment per 256-value group, "groups", went in round 5 with its int32-chain kernel)
         self.align = config.get("mi355q_align", "auto")
         self._align_mode, self._calls, self._row_overflows = None, 0, 0
         self._w_bf16 = None          # (tiled bf16 weights, weight._version) of the per-block-exponent route
@@ -266,8 +267,12 @@ class _LinearBase(nn.Linear):
         return 2 ** (c["weight_exponent_width"] - 1) - 1 if wb in (None, "none", "None") else wb
 
     def _choose_align_mode(self, wm, we, x_sample):
-        if self.align == "groups" or not ops.row_align_supported(self.in_features):
-            return "groups"
+        if self.align == "groups":
+            raise ValueError('mi355q_align = "groups" was removed in round 5 (use "auto", "rows", "rows_post" or "blocks")')
+        if not ops.row_align_supported(self.in_features):
+            # contractions past the row format's 16384 (Llama-30B/65B down_proj): every block keeps its exponent
+            self._x_cap = ops.ROW_NO_ALIGN
+            return "rows"
         if self.align in ("rows", "rows_post", "blocks"):
             return "rows"
         c = self.config
@@ -305,15 +310,16 @@ class _LinearBase(nn.Linear):
     def _uses_bf16_route(self) -> bool:
         c = self.config
         return (self._align_mode == "rows" and self._x_cap == ops.ROW_NO_ALIGN and self.in_features % 32 == 0
-                and c.get("mi355q_blocks_gemm", "bf16") == "bf16" and c["data_in_width"] <= 9 and c["weight_width"] <= 9)
+                and (c.get("mi355q_blocks_gemm", "bf16") == "bf16" or not ops.row_align_supported(self.in_features))
+                and c["data_in_width"] <= 9 and c["weight_width"] <= 9)
 
     def _align_weights(self, wm, we, mode):
         c = self.config
-        if mode == "rows":
-            wa = ops.bfp_align_rows(wm, we, c["weight_width"] - 1, self._weight_bias_value())
-        else:
-            wa = ops.bfp_align(wm, we, c["weight_width"] - 1, self._weight_bias_value(), inplace=True)
         self._align_mode = mode
+        if not ops.row_align_supported(self.in_features):     # (bf16 route only: `_pack_operands` sets the operand)
+            self._packed = (None, None, self.weight._version, None if self.bias is None else self.bias._version)
+            return
+        wa = ops.bfp_align_rows(wm, we, c["weight_width"] - 1, self._weight_bias_value())
         self._packed = (wa, wa.tiled, self.weight._version, None if self.bias is None else self.bias._version)
 
     def _packed_is_current(self) -> bool:
@@ -662,21 +668,13 @@ class _LinearBase(nn.Linear):
                                                   c["data_in_exponent_bias"], pre=pre)
             y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias)
             return y.reshape(*x.shape[:-1], self.out_features)
-        if self._align_mode == "rows":       # one fused kernel: quantise + pack + row-align + tile
-            xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
-                                                    c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre,
-                                                    segments=segments)
-        elif self.in_features % 256 == 0:    # the same per 256-value group
-            xa = ops.block_fp_quantize_aligned(x2, c["data_in_width"], c["data_in_exponent_width"],
-                                               c["data_in_exponent_bias"])
-        else:
-            _, xm, xe = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"],
-                                              c["data_in_exponent_bias"], [1, 16], True, want_fake=False,
-                                              want_packed=True, fast_zero_blocks=True)
-            xa = ops.bfp_align(xm, xe, x_mbits, xb, inplace=True)
+        # one fused kernel: quantise + pack + row-align + tile
+        xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
+                                                c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre,
+                                                segments=segments)
         wa = self._w_packed.expand() if self._w_packed is not None else self._packed[0]
         y = ops.bfp_gemm_aligned(xa, wa, self.bias)
-        if self._align_mode == "rows" and self.align == "auto" and self._x_cap != ops.ROW_NO_ALIGN:
+        if self.align == "auto" and self._x_cap != ops.ROW_NO_ALIGN:
             # results never depend on the mode (an overflowing exception bucket only sends the GEMM to its slow
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats
             # (not while a HIP graph is being recorded: the read is a host synchronisation)

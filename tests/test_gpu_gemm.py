@@ -48,7 +48,8 @@ def _run(x, w, b, cfg, aligned=False, x_cap=0):
     if b is not None:
         bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), cfg["bias_width"], 8, 127, [16], False)
     if aligned:
-        align = ops.bfp_align_rows if aligned == "rows" else ops.bfp_align
+        assert aligned == "rows"
+        align = ops.bfp_align_rows
         xa = (align(xm, xe, cfg["data_in_width"] - 1, 127, bucket_cap=x_cap) if x_cap
               else align(xm, xe, cfg["data_in_width"] - 1, 127))
         wa = align(wm, we, cfg["weight_width"] - 1, 127)
@@ -106,161 +107,6 @@ def test_gemm_matches_reference_semantics_fp32_linear():
     bq = ops.block_fp_quantize(torch.from_numpy(b).to(dev), 6, 8, 127, [16], False)
     ref = (xq.double() @ wq.double().T + bq.double()).float().cpu().numpy()
     np.testing.assert_allclose(y, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
-
-
-@pytest.mark.parametrize("M,N,K", [(128, 128, 256), (256, 384, 512), (100, 72, 320), (33, 16, 64), (300, 130, 1024),
-                                   (64, 64, 192)])
-@pytest.mark.parametrize("style", ["randn", "rowscale", "outlier", "sparse"])
-@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 4), (8, 8), (6, 4)])
-def test_aligned_gemm_vs_oracle(M, N, K, style, wx, ww):
-    """the fast variant: flagged K-groups take the int32-chain path, the others the blockwise path;
-    `outlier` inputs force unflagged groups, W8 has no spare bits (flagged only when exponents agree)"""
-    from oracle import np_oracle as O
-    x, w, b = _inputs(M, N, K, 2000 + M + N + K, style)
-    cfg = _cfg(wx, ww)
-    y = _run(x, w, b, cfg, aligned=True)
-    ref = O.bfp_linear_int(x, w, b, cfg)
-    scale = np.abs(ref).max() + 1e-30
-    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
-
-
-def _exceptions(lst, rows, nkb):
-    """decode an exception list (include/mi355q.h) -> dense (mant [rows,nkb,16], exp [rows,nkb], mask)"""
-    lst = np.asarray(lst)
-    n = int(lst[0])
-    ent = lst[8:8 + 8 * n].reshape(n, 8)
-    mant = np.zeros((rows, nkb, 16), np.int64)
-    exp = np.zeros((rows, nkb), np.int64)
-    mask = np.zeros((rows, nkb), bool)
-    for e in ent:
-        if e[0] < 0:
-            continue
-        assert not mask[e[0], e[1]], "a block is listed once"
-        mask[e[0], e[1]] = True
-        exp[e[0], e[1]] = e[2]
-        mant[e[0], e[1]] = e[4:8].astype(np.int32).view(np.int8)
-    return mant, exp, mask
-
-
-def test_align_is_value_preserving_and_flags_make_sense():
-    import torch
-    from mi355q import ops
-    dev = torch.device("cuda:0")
-    x, _, _ = _inputs(96, 8, 1024, 5, "rowscale")
-    x[:, 256:272] *= 300.0            # one block per row of group 1 far above its neighbours
-    _, xm, xe = ops.block_fp_quantize(torch.from_numpy(x).to(dev), 6, 8, 127, [1, 16], True, want_fake=False,
-                                      want_packed=True)
-    al = ops.bfp_align(xm, xe, 5, 127, keep_row_major=True)
-    xm2, xe2, xf = al.mant, al.exp, al.rowflag
-    lst = al.sparse.cpu().numpy()
-    assert lst[0] <= ops.SPARSE_LIST_CAP
-    em, ee, emask = _exceptions(lst, 96, 64)
-    v1 = xm.cpu().numpy().reshape(96, 64, 16).astype(np.float64) * np.exp2(xe.cpu().numpy().reshape(96, 64, 1).astype(np.float64))
-    m2 = xm2.cpu().numpy().reshape(96, 64, 16)
-    v2 = m2.astype(np.float64) * np.exp2(xe2.cpu().numpy().reshape(96, 64, 1).astype(np.float64))
-    v2 = v2 + em.astype(np.float64) * np.exp2(ee[..., None].astype(np.float64))
-    assert np.array_equal(v1, v2), "aligned operand + its exception blocks denote the input exactly"
-    assert np.all(m2[emask] == 0), "exception blocks are zeroed in the operand"
-    assert emask[:, 16].all() and emask.sum() < 96 + 24, "the far-off block of every row is the exception"
-    f = xf.cpu().numpy()
-    assert f.shape == (96, 4) and f.all()
-    e2 = xe2.cpu().numpy().reshape(96, 4, 16)
-    assert np.all(e2 == e2[:, :, :1]), "flagged row-groups carry one exponent"
-    gs = al.gscale.cpu().numpy()[:, :96].T
-    assert np.array_equal(gs, np.exp2(e2[:, :, 0].astype(np.float64) - 132))
-    # without a list nothing may be taken out: such row-groups stay as they were, unflagged
-    lib_al = ops.bfp_align(xm, xe, 5, 127, keep_row_major=True, with_list=False)
-    f0 = lib_al.rowflag.cpu().numpy()
-    assert f0[:, 1].sum() == 0 and f0[:, [0, 2, 3]].mean() > 0.9
-    v3 = lib_al.mant.cpu().numpy().reshape(96, 64, 16).astype(np.float64) * np.exp2(lib_al.exp.cpu().numpy().reshape(96, 64, 1).astype(np.float64))
-    assert np.array_equal(v1, v3)
-    assert np.all(lib_al.gscale.cpu().numpy()[:, :96].T[f0 == 0] == 0)
-
-
-@pytest.mark.parametrize("variant", [0, 2])
-@pytest.mark.parametrize("wx,ww", [(6, 6), (4, 6), (8, 8)])
-def test_aligned_gemm_exceptions_of_both_operands_share_blocks(variant, wx, ww):
-    """exception blocks of x and w at the same K position: the exception x exception products count too"""
-    from mi355q import ops
-    from oracle import np_oracle as O
-    x, w, b = _inputs(200, 136, 768, 17, "rowscale")
-    x[:, 256:272] *= 300.0
-    w[:, 256:272] *= 300.0
-    x[::3, 512:528] *= 1e-3
-    w[1::2, 512:528] *= 1e-3
-    cfg = _cfg(wx, ww)
-    prev = ops.set_gemm_variant(variant)
-    try:
-        y = _run(x, w, b, cfg, aligned=True)
-    finally:
-        ops.set_gemm_variant(prev)
-    assert _run.last_counts[0] >= 200 and _run.last_counts[1] >= 136
-    ref = O.bfp_linear_int(x, w, b, cfg)
-    np.testing.assert_allclose(y, ref, rtol=0, atol=6e-6 * np.abs(ref).max())
-
-
-def test_aligned_gemm_uses_fast_path_on_benchmark_data():
-    """the synthetic BASELINE data must be (almost) entirely flagged"""
-    x, w, b = _inputs(256, 256, 1024, 3, "rowscale")
-    _run(x, w, b, _cfg(6, 6), aligned=True)
-    fx, fw = _run.last_flags
-    assert fx > 0.95 and fw > 0.95, (fx, fw)
-
-
-def test_aligned_gemm_overflowing_lists_take_the_fallback_kernel():
-    """more exception blocks than the lists hold: decided on the device, same result (the row-groups stored
-    before the list ran out keep their exceptions, the others stay unaligned)"""
-    import torch
-    from mi355q import ops
-    from oracle import np_oracle as O
-    r = np.random.default_rng(11)
-    M, N, K = 2304, 128, 512
-    x = r.normal(size=(M, K)).astype(np.float32)
-    x[:, 7::64] *= 500.0                       # every row-group of every row has a far-off block
-    w = (r.normal(size=(N, K)) * 0.02).astype(np.float32)
-    cfg = _cfg(6, 6)
-    y = _run(x, w, None, cfg, aligned=True)
-    assert _run.last_flags[0] < 0.1 and _run.last_counts[0] > ops.SPARSE_LIST_CAP
-    ref = O.bfp_linear_int(x, w, None, cfg)
-    np.testing.assert_allclose(y, ref, rtol=0, atol=4e-6 * np.abs(ref).max())
-
-
-@pytest.mark.parametrize("style", ["rowscale", "outlier", "sparse"])
-@pytest.mark.parametrize("width", [6, 4, 8])
-def test_fused_quantize_align_equals_two_step(style, width):
-    """mi355q_block_fp_quantize_aligned == mi355q_block_fp_quantize (fast zero blocks) + mi355q_bfp_align"""
-    import torch
-    from mi355q import ops
-    dev = torch.device("cuda:0")
-    rows = 48 if style == "outlier" else 200      # outlier rows carry ~20 exception blocks each: stay inside the list
-    x, _, _ = _inputs(rows, 8, 1024, 31 + width, style)
-    xt = torch.from_numpy(x).to(dev)
-    _, xm, xe = ops.block_fp_quantize(xt, width, 8, 127, [1, 16], True, want_fake=False, want_packed=True,
-                                      fast_zero_blocks=True)
-    ref = ops.bfp_align(xm, xe, width - 1, 127)
-    got = ops.block_fp_quantize_aligned(xt, width, 8, 127)
-    torch.cuda.synchronize()
-    n = int(ref.sparse[0])
-    assert int(got.sparse[0]) == n
-    if n > ops.SPARSE_LIST_CAP:       # overflow (W8 has no head-room): which row-groups got stored depends on arrival order
-        assert width == 8
-        return
-    full = (rows // 16) * 16 * 1024               # whole 16-row pieces (the last piece has padding rows)
-    assert torch.equal(got.tiled[:full], ref.tiled[:full])
-    assert torch.equal(got.exp, ref.exp.reshape(-1)) and torch.equal(got.rowflag, ref.rowflag)
-    assert torch.equal(got.gscale[:, :rows], ref.gscale[:, :rows])
-    ent = lambda t: set(map(tuple, t.sparse[8:8 + 8 * n].cpu().numpy().reshape(-1, 8)))
-    assert ent(got) == ent(ref)
-    if style == "outlier" and width < 8:
-        assert n > 0
-    # the two per-shape lists alternate: the next call's list was zeroed by this call, and calling again
-    # (same data) fills it with the same entries
-    again = ops.block_fp_quantize_aligned(xt, width, 8, 127)
-    torch.cuda.synchronize()
-    assert again.sparse.data_ptr() != got.sparse.data_ptr() and int(again.sparse[0]) == n
-    third = ops.block_fp_quantize_aligned(xt, width, 8, 127)
-    torch.cuda.synchronize()
-    assert third.sparse.data_ptr() == got.sparse.data_ptr() and int(third.sparse[0]) == n and ent(third) == ent(ref)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -109,7 +109,7 @@ def test_linear_block_fp_with_in_features_not_a_multiple_of_64(K):
     assert np.array_equal(lin.weight.detach().cpu().numpy(), wq) and np.array_equal(lin.bias.detach().cpu().numpy(), bq)
 
 
-@pytest.mark.parametrize("align", ["auto", "rows", "rows_post", "blocks", "groups"])
+@pytest.mark.parametrize("align", ["auto", "rows", "rows_post", "blocks"])
 @pytest.mark.parametrize("outliers", [False, True])
 def test_linear_int8_align_modes(align, outliers):
     """the exponent-alignment flavour of the packed operands is an implementation knob: every choice gives the
@@ -133,8 +133,7 @@ def test_linear_int8_align_modes(align, outliers):
         y = lin(x.to("cuda:0"))
         ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(3, 100, 192)
         np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
-    want = {"rows": "rows", "rows_post": "rows", "blocks": "rows", "groups": "groups", "auto": "rows"}[align]
-    assert lin._align_mode == want
+    assert lin._align_mode == "rows"
     if align == "auto":                      # 300 rows x 1 exception: too many for a tile's LDS add-back -> no alignment
         assert lin._x_cap == (-1 if outliers else 120)
     if align == "rows_post":
@@ -1077,3 +1076,31 @@ def test_non_fp32_masks_take_the_generic_route():
     assert QF._mask_2d(m, 8, 8) is None
     assert QF._mask_2d(m.to(torch.float16), 8, 8) is None
     assert QF._mask_2d(m.to(torch.float32), 8, 8) is not None
+
+
+def test_linear_past_the_row_format_contraction_length():
+    """in_features > 16384 (Llama-30B/65B down_proj: 17920, 22016) is past the row-aligned format: the layer keeps every
+    block's exponent and runs on the bf16 tile GEMM (round 5; before, the 256-value-group flavour took these); and the removed
+    flavour's knob value is refused by name"""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    K, N = 17920, 64
+    cfg = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8,
+               data_in_exponent_bias=127, data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8,
+               weight_exponent_bias=127, weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8,
+               bias_exponent_bias=127, bias_block_size=[16])
+    torch.manual_seed(3)
+    fp = torch.nn.Linear(K, N, bias=True)
+    w0, b0 = fp.weight.detach().numpy().copy(), fp.bias.detach().numpy().copy()
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    x = torch.randn(40, K) * torch.exp(torch.randn(40, 1))
+    for _ in range(2):
+        y = lin(x.to("cuda:0"))
+    assert lin._uses_bf16_route()
+    ref = O.bfp_linear_int(x.numpy(), w0, b0, cfg)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+    bad = dict(cfg, mi355q_align="groups")
+    lin = Q.get_quantized_cls("linear", bad).from_float(torch.nn.Linear(256, 64), bad).to("cuda:0")
+    with pytest.raises(ValueError, match="groups"):
+        lin(torch.randn(4, 256, device="cuda:0"))

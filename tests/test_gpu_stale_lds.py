@@ -69,7 +69,7 @@ def _lin_cfg(width, **extra):
     (256, 4096, 256, "rows", "uniform"),        # split-K slices
     (512, 2048, 512, "rows", "overflow"),       # bucket overflow -> the blockwise product inside the launch
     (1024, 1024, 1024, "auto", "silu"),         # per-block-exponent route (bf16 tile GEMM)
-    (300, 512, 272, "groups", "plain"),         # group flavour
+    (300, 512, 272, "blocks", "plain"),         # every block keeps its exponent (bf16 tile GEMM)
 ])
 def test_linear_routes(poison, M, K, N, align, act):
     import torch

@@ -43,7 +43,6 @@ def test_aligned_operand_entry_points_validate_without_a_gpu():
     E_BADARG, E_UNSUPPORTED, E_ALIGN = -1, -2, -3
     assert lib.mi355q_bfp_rows_pad(4096) == 4096 + 256 and lib.mi355q_bfp_rows_pad(1) == 512 and lib.mi355q_bfp_rows_pad(0) == 0
     assert lib.mi355q_bfp_tiled_bytes(100, 192) == 128 * 192 and lib.mi355q_bfp_tiled_bytes(0, 64) == 0
-    assert lib.mi355q_bfp_list_bytes(1024) == (8 + 8 * 1024) * 4
     assert lib.mi355q_bfp_row_list_bytes(4096, 0) == (8 + 16 * (8 + 8 * 120)) * 4 and lib.mi355q_bfp_row_list_bytes(1, 120) == (8 + 968) * 4
     assert lib.mi355q_bfp_row_list_bytes(512, 1016) == (8 + 2 * (8 + 8 * 1016)) * 4 and lib.mi355q_bfp_row_list_bytes(512, 1017) == 0
     one = C.create_string_buffer(64)
@@ -59,13 +58,15 @@ def test_aligned_operand_entry_points_validate_without_a_gpu():
     assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, p, None, 4, 64, 6, 8, 127, -2, None) == E_BADARG  # bucket_cap
     assert lib.mi355q_block_fp_quantize_aligned_rows(p, p, p, p, p, None, None, 4, 64, 6, 8, 127, 0, None) == E_BADARG   # list required unless NO_ALIGN
     assert lib.mi355q_block_fp_quantize_aligned_rows(p + 4, p, p, p, p, p, None, 4, 64, 6, 8, 127, 0, None) == E_ALIGN
-    assert lib.mi355q_block_fp_quantize_aligned(p, p, p, p, p, p, 8, None, 4, 192, 6, 8, 127, None) == E_UNSUPPORTED  # K % 256
     # GEMM: both operands in the same flavour, K % 64
     x, w = _lib.BfpOperand(p, p, p, p, p, 0, 5, 127, 1), _lib.BfpOperand(p, p, p, p, p, 8, 5, 127, 0)
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 4, None) == E_BADARG
     w.row_aligned, w.list_cap = 1, 2000
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 4, None) == E_BADARG       # bucket cap
     w.list_cap = 0
+    x.row_aligned = w.row_aligned = 0
+    assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 4, None) == E_UNSUPPORTED     # group flavour: removed
+    x.row_aligned = w.row_aligned = 1
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 48, 4, None) == E_UNSUPPORTED
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 0, 4, 128, 4, None) == 0
     assert lib.mi355q_bfp_gemm_aligned(C.addressof(x), C.addressof(w), None, p, 4, 4, 128, 2, None) == E_BADARG       # ldy < N

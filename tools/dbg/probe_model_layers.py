@@ -21,16 +21,9 @@ def hook(name):
         xr = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127)
         over, mx = ops.row_list_fill(xr.sparse, xr.rows)
         line = f"{name:28s} M={x.shape[0]} K={mod.in_features} N={mod.out_features} mode={mod._align_mode} x rows: overflow={over} fullest={mx}"
-        if mod.in_features % 256 == 0:
-            xg = ops.block_fp_quantize_aligned(x, 6, 8, 127)
-            torch.cuda.synchronize()
-            line += f" | x groups: list={int(xg.sparse[0])} flagged={float(xg.rowflag.float().mean()):.4f}"
-        if mod._packed is not None:
+        if mod._packed is not None and mod._packed[0] is not None:
             wa = mod._packed[0]
-            if wa.row_aligned:
-                line += f" | w rows fill={ops.row_list_fill(wa.sparse, wa.rows)}"
-            else:
-                line += f" | w groups list={int(wa.sparse[0])} flagged={float(wa.rowflag.float().mean()):.4f}"
+            line += f" | w rows fill={ops.row_list_fill(wa.sparse, wa.rows)}"
         zeros = float((x == 0).float().mean())
         print(line, f"| zeros={zeros:.3f}")
     return f

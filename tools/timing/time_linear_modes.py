@@ -18,7 +18,7 @@ for name, (M, K, N), act in (("OPT-125m fc2 (ReLU)", (2048, 3072, 768), "relu"),
     fp = torch.nn.Linear(K, N, bias=True)
     with torch.no_grad(): fp.weight.normal_(0, 0.02)
     out = []
-    for align in ("auto", "rows", "rows_post", "blocks", "groups"):
+    for align in ("auto", "rows", "rows_post", "blocks"):
         lin = Q.get_quantized_cls("linear", cfg(align)).from_float(fp, cfg(align)).to(dev)
         with torch.no_grad():
             for _ in range(5): lin(x)

@@ -7,7 +7,8 @@ import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the l
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
 x = (torch.randn(4096, 4096, generator=g) * torch.exp(torch.randn(4096, 1, generator=g))).to(dev)
-fns = {"rows": lambda: ops.block_fp_quantize_aligned_rows(x, 6, 8, 127), "groups": lambda: ops.block_fp_quantize_aligned(x, 6, 8, 127)}
+fns = {"rows": lambda: ops.block_fp_quantize_aligned_rows(x, 6, 8, 127),
+       "bf16": lambda: ops.block_fp_quantize_bf16_tiled(x, 6, 8, 127)}
 acc = {k: [] for k in fns}
 for rnd in range(5):
     for k, fn in fns.items():
