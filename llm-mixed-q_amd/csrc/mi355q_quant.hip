@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
     bool saw_zero = false;
     unsigned inv = 0u;          // max over non-zero blocks of ~bits(block max) = the smallest non-zero block max
     const float guess = zero_fill_guess(a.ws, exact);
+    const int mbits = FMT == FMT_BM ? (int)__builtin_log2f(a.shift) : 0;
 
+    // (tried: block_log staging only the ceil table and reading its two rounding tables from memory on the rare table walk -- one
+    //  wave-step in ~260 takes that walk, and eight dependent L2 round trips there cost more than the staging saves: 16.7 -> 18.1 us)
+    auto stage_lut = [&]() { load_lut<FMT>(lut); };
     auto process = [&](const long long i, const float4 v) {
         const bool valid = i < n4;
         float bmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -112,12 +116,46 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
         }
         unsigned code;
         const BlockParam bp = block_param<FMT>(bmax, a, lut, code);
-        int q0, q1, q2, q3;
+        int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
         float4 o;
-        o.x = quant_elem<FMT>(v.x, bp, a, lut, q0);
-        o.y = quant_elem<FMT>(v.y, bp, a, lut, q1);
-        o.z = quant_elem<FMT>(v.z, bp, a, lut, q2);
-        o.w = quant_elem<FMT>(v.w, bp, a, lut, q3);
+        if constexpr (FMT == FMT_BFP) {
+            o.x = quant_elem<FMT>(v.x, bp, a, lut, q0);
+            o.y = quant_elem<FMT>(v.y, bp, a, lut, q1);
+            o.z = quant_elem<FMT>(v.z, bp, a, lut, q2);
+            o.w = quant_elem<FMT>(v.w, bp, a, lut, q3);
+        } else {
+            // minifloat / log elements by the short forms (14-18 operations, no table: mi355q_quant_dev.h); a wave with an element
+            // inside one of the bands where torch's fp32 log2 decides (a few ulps under a power of two / the 125 fractions around
+            // sqrt(2); subnormals) redoes its four with the table walk, one after the other (about one wave-step in a thousand;
+            // kept out of each other's way: interleaved they cost the kernel 84 registers and three waves a SIMD)
+            bool near = false;
+            const int eminb = 127 - bp.p, emaxb = 127 + a.span - bp.p;
+            if constexpr (FMT == FMT_BM) {
+                o.x = bm_elem_fused(v.x, eminb, emaxb, mbits, a.shift, a.mant_max, near);
+                o.y = bm_elem_fused(v.y, eminb, emaxb, mbits, a.shift, a.mant_max, near);
+                o.z = bm_elem_fused(v.z, eminb, emaxb, mbits, a.shift, a.mant_max, near);
+                o.w = bm_elem_fused(v.w, eminb, emaxb, mbits, a.shift, a.mant_max, near);
+                // (the reference's mask arithmetic turns a passed-through -0.0 into +0.0; a value flushed to zero keeps its sign)
+                o.x = fabsf(v.x) <= ATOL ? v.x + 0.0f : o.x;
+                o.y = fabsf(v.y) <= ATOL ? v.y + 0.0f : o.y;
+                o.z = fabsf(v.z) <= ATOL ? v.z + 0.0f : o.z;
+                o.w = fabsf(v.w) <= ATOL ? v.w + 0.0f : o.w;
+            } else {
+                o.x = bl_elem_fused(v.x, bp.eps, eminb, emaxb, near);
+                o.y = bl_elem_fused(v.y, bp.eps, eminb, emaxb, near);
+                o.z = bl_elem_fused(v.z, bp.eps, eminb, emaxb, near);
+                o.w = bl_elem_fused(v.w, bp.eps, eminb, emaxb, near);
+            }
+            if (__any(near)) {
+                o.x = quant_elem<FMT>(v.x, bp, a, lut, q0);
+                __builtin_amdgcn_sched_barrier(0);
+                o.y = quant_elem<FMT>(v.y, bp, a, lut, q1);
+                __builtin_amdgcn_sched_barrier(0);
+                o.z = quant_elem<FMT>(v.z, bp, a, lut, q2);
+                __builtin_amdgcn_sched_barrier(0);
+                o.w = quant_elem<FMT>(v.w, bp, a, lut, q3);
+            }
+        }
         if (valid) {
             if (a.y) y4[i] = o;
             if (a.ybf)          // (block_fp of <= 9 bits, minifloats of <= 7 mantissa bits, signed powers of two: exact in bf16)
@@ -132,7 +170,7 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
         // tensors that stay in the 256-MiB memory-side cache between calls (activations, weights of one layer): the
         // grid-stride loop of <= 2048 workgroups -- tables and zero-state once per workgroup, which is what these
         // launch-bound sizes feel
-        load_lut<FMT>(lut);
+        stage_lut();
         const long long stride = (long long)gridDim.x * blockDim.x;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4_pad; i += stride) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -149,7 +187,7 @@ __global__ __launch_bounds__(256) void quant_vec_kernel(const QuantArgs a) {
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (iu < n4) v[u] = x4[iu];
         }
-        load_lut<FMT>(lut);         // (behind the loads of x: the tables' round trip -- L2 hits -- hides under theirs)
+        stage_lut();         // (behind the loads of x: the tables' round trip -- L2 hits -- hides under theirs)
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const long long iu = i + u * 256;           // (a wave's 64 slots are in or out of the padded range together)

@@ -40,11 +40,23 @@ struct Lut {
 
 template <int FMT>
 __device__ __forceinline__ void load_lut(Lut& lut) {
-    for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
-        lut.a[i] = (FMT == FMT_BM) ? mi355q_log2_floor_thr[i] : mi355q_log2_ceil_thr[i];
+    // (one entry per thread and trip, NOT unrolled: left to itself the compiler runs eight trips' loads together with 64-bit
+    //  addresses -- 84 registers for block_log's three tables, which set the streaming quantiser's occupancy at 5 waves a SIMD)
+#pragma unroll 1
+    for (int i = threadIdx.x; i < LUT_N; i += 2 * blockDim.x) {     // (two entries a trip, their loads together: 277 entries = one trip of 256 threads)
+        const int j = i + blockDim.x, jc = j < LUT_N ? j : i;
+        const unsigned a0 = (FMT == FMT_BM) ? mi355q_log2_floor_thr[i] : mi355q_log2_ceil_thr[i];
+        const unsigned a1 = (FMT == FMT_BM) ? mi355q_log2_floor_thr[jc] : mi355q_log2_ceil_thr[jc];
+        unsigned l0 = 0u, h0 = 0u, l1 = 0u, h1 = 0u;
         if (FMT == FMT_BL) {
-            lut.lo[i] = mi355q_log2_rnd_lo[i];
-            lut.hi[i] = mi355q_log2_rnd_hi[i];
+            l0 = mi355q_log2_rnd_lo[i]; h0 = mi355q_log2_rnd_hi[i];
+            l1 = mi355q_log2_rnd_lo[jc]; h1 = mi355q_log2_rnd_hi[jc];
+        }
+        lut.a[i] = a0;
+        lut.a[jc] = a1;
+        if (FMT == FMT_BL) {
+            lut.lo[i] = l0; lut.hi[i] = h0;
+            lut.lo[jc] = l1; lut.hi[jc] = h1;
         }
     }
     __syncthreads();
@@ -153,6 +165,48 @@ __device__ __forceinline__ float quant_elem(float x, const BlockParam& bp, const
         mant = 0;
         return __builtin_ldexpf(s, clampi(r, e_min, e_max));
     }
+}
+
+// One block_fp element given its block's exponent p, in 8 VALU operations instead of quant_elem's 14, with the same
+// result for every input (mi355q_quant_dev.h, block_fp.py:69-94):
+//   * sign(x + 1e-9) is only used where |x| > 1e-8 (smaller |x| pass through as x), and there it is the sign of x;
+//   * ldexp(v, -p) * 2^mb = ldexp(v, mb - p): where the first product would round (a subnormal intermediate), both are
+//     far below 0.5 and round to mantissa 0;  rint of a positive number needs no lower clamp;
+//   * sign * 2^p * (m * 2^-mb) = copysign(ldexp(m, p - mb), x): m 2^(p - mb) is a multiple of 2^-149 and below 2^128,
+//     so both forms are exact.
+__device__ __forceinline__ float quant_elem_fused(float x, int up, int down, float mant_max) {
+    const float m = fminf(__builtin_rintf(__builtin_ldexpf(fabsf(x) + EPS9, up)), mant_max);
+    const float q = __builtin_copysignf(__builtin_ldexpf(m, down), x);
+    return fabsf(x) <= ATOL ? x : q;
+}
+
+// One block_minifloat element given its block's bias, biased-exponent bounds eminb = 127 - bias, emaxb = 127 + span - bias
+// (minifloat.py:165-194 with exponent_bias = the block's), in ~18 VALU operations instead of quant_elem's ~40, same result:
+//   * floor(log2(v)) of the normal v = |x| + 1e-9 is its exponent field, except within a few ulps below a power of two where
+//     torch's fp32 log2 rounds up (the table's band, M >= FLOOR_THR_MIN): `near` reports those and the caller redoes the step
+//     with quant_elem -- about one step in a thousand;
+//   * mn * shift = ldexp(|x|, mbits - e) in one exact scaling (overflow gives inf either way, clamped to the top mantissa);
+//   * 2^e (1 + sm / shift) = ldexp(shift + sm, e - mbits), 2^e (sm / shift) 2 = ldexp(2 sm, e - mbits): integers below 2^9.
+__device__ __forceinline__ float bm_elem_fused(float x, int eminb, int emaxb, int mbits, float shift, float mant_max, bool& near) {
+    const float ax = fabsf(x);
+    const unsigned vb = __float_as_uint(ax + EPS9);
+    near |= (vb | 0xFF800000u) >= (MI355Q_LOG2_FLOOR_THR_MIN | 0xFF800000u);
+    const int eb = min(max((int)(vb >> 23), eminb), emaxb);
+    const float t = __builtin_ldexpf(ax, mbits + 127 - eb);
+    const float un = fminf(fmaxf(__builtin_rintf(t - shift), 0.f), mant_max) + shift;
+    const float us = fminf(__builtin_rintf(t * 0.5f), mant_max) * 2.0f;
+    const float q = __builtin_copysignf(__builtin_ldexpf(eb != eminb ? un : us, eb - 127 - mbits), x);
+    return ax <= ATOL ? x : q;                  // (callers that hand the value on as a RESULT add + 0.0f: -0.0 -> +0.0)
+}
+// One block_log element (log.py:47-56 with exponent_bias = the block's; eps = 0.1 * 2^-bias): sign(x + eps) * 2^clamp(round(
+// log2(|x| + eps))).  round(log2(v)) is the exponent field plus one when the fraction lies above sqrt(2)'s band; inside the
+// band ([RND_LO_MIN, RND_HI_MAX], 125 fraction values where torch's fp32 log2 decides) and for subnormal v: `near`, as above.
+__device__ __forceinline__ float bl_elem_fused(float x, float eps, int eminb, int emaxb, bool& near) {
+    const float sg = x + eps;
+    const unsigned vb = __float_as_uint(fabsf(x) + eps);
+    near |= ((vb & 0x7FFFFFu) - MI355Q_LOG2_RND_LO_MIN) <= (unsigned)(MI355Q_LOG2_RND_HI_MAX - MI355Q_LOG2_RND_LO_MIN) || vb < 0x00800000u;
+    const int rb = min(max((int)((vb + (0x7FFFFFu - MI355Q_LOG2_RND_HI_MAX)) >> 23), eminb), emaxb);
+    return __builtin_ldexpf(__builtin_copysignf(sg != 0.f ? 1.0f : 0.0f, sg), rb - 127);
 }
 
 template <int CTRL>

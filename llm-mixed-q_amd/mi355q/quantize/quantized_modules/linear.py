@@ -463,7 +463,7 @@ class _LinearBase(nn.Linear):
         <= 7 mantissa bits, powers of two) and every contraction length is a whole number of 64-byte K-steps.
         config["mi355q_qat_gemm"] = "fp32" keeps F.linear."""
         c = self.config
-        if c.get("mi355q_qat_gemm", "bf16") != "bf16" or not (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32):
+        if c.get("mi355q_qat_gemm", "bf16") not in ("bf16", "bf16_always") or not (xq.is_cuda and xq.dtype == torch.float32 and self.weight.dtype == torch.float32):
             return False
         if self.arith == "block_fp":
             if not (2 <= c["data_in_width"] <= 9 and 2 <= c["weight_width"] <= 9):
@@ -471,7 +471,12 @@ class _LinearBase(nn.Linear):
         elif not self._values_exact_in_bf16(xq):
             return False
         M = xq.numel() // self.in_features
-        return self.in_features % 32 == 0 and self.out_features % 32 == 0 and M % 32 == 0 and M > 0
+        if not (self.in_features % 32 == 0 and self.out_features % 32 == 0 and M % 32 == 0 and M > 0):
+            return False
+        # three products + the tiling / plane-split launches around them: ahead of the fp32 library GEMM from ~2^34 multiply-adds a
+        # product (profiles/r05_qat_gemm.jsonl: 2048 x 1024 x 4096 0.97-1.09x, 2048 x 4096 x 4096 2.0x, 512 x 1024 x 4096 0.4-0.6x);
+        # mi355q_qat_gemm = "bf16_always" takes it regardless (tests)
+        return c.get("mi355q_qat_gemm", "bf16") == "bf16_always" or M * self.in_features * self.out_features >= (1 << 34)
 
     # -- W4A4 on the MX scaled matrix instruction ------------------------------------------------------------------------
     def _mx_config_ok(self) -> bool:

@@ -242,6 +242,7 @@ def test_qat_on_the_tile_gemm_gradients(arith):
     M, K, N = 512, 1024, 4096
     torch.manual_seed(3)
     scale = 4.0 if arith == "block_minifloat" else 1.0           # (block_minifloat flushes |w| << 1 to zero: SURVEY quirk 5)
+    cfg = dict(cfg, mi355q_qat_gemm="bf16_always")               # (the default takes the tile GEMM from 2^34 multiply-adds on)
     lin = Q.get_quantized_cls("linear", cfg)(K, N, config=cfg).to("cuda:0")
     with torch.no_grad():
         lin.weight.mul_(32.0 * scale)

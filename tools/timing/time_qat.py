@@ -12,7 +12,7 @@ base = dict(name="block_fp", is_ptq=False, bypass=False, data_in_width=6, data_i
 for M, K, N in shapes:
     row = {"M": M, "K": K, "N": N}
     for route in ("bf16", "fp32"):
-        cfg = dict(base, mi355q_qat_gemm=route)
+        cfg = dict(base, mi355q_qat_gemm="bf16_always" if route == "bf16" else route)
         torch.manual_seed(0)
         lin = Q.get_quantized_cls("linear", cfg)(K, N, config=cfg).to(dev)
         x = torch.randn(M, K, device=dev, requires_grad=True)
