@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, c
                                                            long long vsb, long long vst, int kw) {
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) uint16_t buf[AT_MAX_D / 16 * 4 * 512];
-    load_lut<FMT_BFP>(lut);
+    load_lut<FMT_BFP, true>(lut);
     if ((int)blockIdx.x < kblocks) attn_pack_k(ak, lut, buf, k, kf, T, D, NT, blockIdx.x, ksb, kst);
     else attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst, kw);
 }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     __shared__ Lut lut;
     __shared__ float stat_[QG][KW][16];
     __shared__ f32x4 red_[QG][KW][DT][64];
-    load_lut<FMT_BFP>(lut);
+    load_lut<FMT_BFP, true>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_all % KW, grp = wave_all / KW;
     float (&stat)[KW][16] = stat_[grp];
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
     using lptr_t = __attribute__((address_space(3))) void*;
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) unsigned char stage[2][STEP];
-    load_lut<FMT_BFP>(lut);
+    load_lut<FMT_BFP, true>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, lg = lane >> 4;
     const long long b = blockIdx.y;

@@ -38,8 +38,19 @@ struct Lut {
     unsigned hi[LUT_N]; // bl: rnd_hi
 };
 
-template <int FMT>
+template <int FMT, bool PLAIN = false>
 __device__ __forceinline__ void load_lut(Lut& lut) {
+    if constexpr (PLAIN) {      // (the loop as the compiler likes it: the one-pass attention kernels, whose register budget was tuned around it)
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
+            lut.a[i] = (FMT == FMT_BM) ? mi355q_log2_floor_thr[i] : mi355q_log2_ceil_thr[i];
+            if (FMT == FMT_BL) {
+                lut.lo[i] = mi355q_log2_rnd_lo[i];
+                lut.hi[i] = mi355q_log2_rnd_hi[i];
+            }
+        }
+        __syncthreads();
+        return;
+    }
     // (one entry per thread and trip, NOT unrolled: left to itself the compiler runs eight trips' loads together with 64-bit
     //  addresses -- 84 registers for block_log's three tables, which set the streaming quantiser's occupancy at 5 waves a SIMD)
 #pragma unroll 1
