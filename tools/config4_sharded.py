@@ -14,12 +14,13 @@ import torch
 import torch.distributed as dist
 
 
-def quant_config(layers: int, knobs: bool):
+def quant_config(layers: int, knobs: bool, mx="auto"):
     """[default] W4A4 (bfp_4bit.toml / opt_1.3b_sst2.toml:39-52) + per-layer overrides of the kind the search writes"""
     d = dict(name="block_fp", bypass=False, is_ptq=True,
              data_in_width=4, data_in_exponent_width=8, data_in_exponent_bias=127, data_in_block_size=[1, 16],
              weight_width=4, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
              bias_width=4, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+    d["mi355q_mx"] = {"auto": "auto", "off": False, "on": True}[mx]      # (W4A4 on the MX scaled MFMA: DESIGN 5c)
     if knobs:
         d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
                  mi355q_token_major_output=True)
@@ -38,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--tokens", type=int, default=2048)
+    ap.add_argument("--mx", choices=["auto", "off", "on"], default="auto", help="config[\"mi355q_mx\"] of every layer")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--hidden", type=int, default=2048)
     ap.add_argument("--ffn", type=int, default=8192)
@@ -57,7 +59,7 @@ def main():
     torch.manual_seed(0)                                   # every rank builds the same full-precision model
     cfg = harness.TinyOPTConfig(vocab_size=a.vocab, hidden_size=a.hidden, ffn_dim=a.ffn, num_layers=a.layers, num_heads=a.heads,
                                 max_positions=a.tokens)
-    model = harness.TinyOPTForCausalLM(cfg, harness.expand_quant_config(quant_config(a.layers, not a.no_knobs), a.layers))
+    model = harness.TinyOPTForCausalLM(cfg, harness.expand_quant_config(quant_config(a.layers, not a.no_knobs, a.mx), a.layers))
     # (weights with per-channel spread, like trained ones: rows of different magnitude)
     with torch.no_grad():
         for p in model.parameters():
