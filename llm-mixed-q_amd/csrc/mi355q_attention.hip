@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, c
 
 // ---- the attention pass ------------------------------------------------------------------------------------------------
 // NTW = score tiles per wave (KW = 4: 8, 16, 32 <-> T <= 512, 1024, 2048; KW = 8: half of that), DC = D / 32.
+static unsigned long long* g_attn_stamps = nullptr;     // diagnostic (-DATTN_STAMPS builds)
 struct AttnArgs {
     const float* q;
     const uint16_t* kf;
@@ -213,7 +214,13 @@ struct AttnArgs {
     int D;
     long long qsb, qsm;       // element strides of q's batch (head) and row
     long long osb, osm;       // ... of out's
+    unsigned long long* stamps;   // diagnostic (-DATTN_STAMPS builds, tools/dbg/attn_stamps.py): [workgroup][8] realtime words
 };
+#ifdef ATTN_STAMPS
+#define ATTN_STAMP(k) ast_[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define ATTN_STAMP(k)
+#endif
 
 // QG = 16-query groups per workgroup (4 waves each).  Two groups walk the same key tiles in step: the second request for
 // a K / V fragment is served by the compute unit's L1 instead of the L2 (the kernel is L2-bandwidth bound at long T: every
@@ -227,6 +234,10 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     __shared__ Lut lut;
     __shared__ float stat_[QG][KW][16];
     __shared__ f32x4 red_[QG][KW][DT][64];
+#ifdef ATTN_STAMPS
+    unsigned long long ast_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ATTN_STAMP(0);
     load_lut<FMT_BFP, true>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_all % KW, grp = wave_all / KW;
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
             qf[c] = __builtin_bit_cast(bf16x8, pk);
         }
     }
+    ATTN_STAMP(1);
     // tiles this workgroup needs: up to the horizon of its last query
     const long long kvis = g.causal_off >= 0 ? qrow + g.causal_off : g.T - 1;           // this lane's query
     long long need = g.NT;
@@ -278,12 +290,21 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     const long long tlast = need - 1;
     uint4 kb[2][G][DC];
     float4 mb[2][HASMASK ? G : 1];                         // (the additive mask's values ride with the K fragments)
+    // (round 5: through a buffer descriptor that ends behind the last NEEDED tile -- a fragment behind the causal horizon is out of
+    //  range: zeros, no cache access.  Before, such a request re-read the last needed tile.  Stamps (tools/dbg/attn_stamps.py) and three
+    //  experiments put the two loops' floor elsewhere, though: the compute unit's vector-memory front end takes 16 clocks per 64-lane
+    //  dwordx4 request -- hit, miss or out of range -- and 8 waves x 128 requests a loop are 16 k clocks of a 24-us workgroup at head_dim
+    //  128; a deeper prefetch through private LDS-DMA rings changes nothing, fragments SHARED by the two query groups through LDS (one
+    //  barrier a group) make the walk proportional to the causal horizon but the full-length workgroups slower: profiles/r05_attention.txt)
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kfb), 0, (int)(need * DC * 1024), 0x00020000);
     auto load_group = [&](int gi, uint4 (&dst)[G][DC], float4 (&mdst)[HASMASK ? G : 1]) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            const long long t = min((long long)(KW * (gi * G + j) + wave), tlast);
+            const int tu = KW * (gi * G + j) + wave;
+            const long long t = min((long long)tu, tlast);
 #pragma unroll
-            for (int c = 0; c < DC; ++c) dst[j][c] = *reinterpret_cast<const uint4*>(kfb + ((t * DC + c) * 64 + lane) * 8);
+            for (int c = 0; c < DC; ++c)
+                dst[j][c] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(krs, (tu * DC + c) * 1024 + lane * 16, 0, 0));
             if (HASMASK) mdst[j] = *reinterpret_cast<const float4*>(mrow + t * 16 + 4 * lg);
         }
     };
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
             acc[i] = s;
         }
     }
+    ATTN_STAMP(2);
     mx = at_max4(mx);
     if (lg == 0) stat[wave][c16] = mx;
     __syncthreads();
@@ -328,6 +350,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
 #pragma unroll
     for (int w = 1; w < KW; ++w) row_max = fmaxf(row_max, stat[w][c16]);
     __syncthreads();
+    ATTN_STAMP(3);
     // ---- exponentials in place, row sum
     float sm = 0.f;
 #pragma unroll
@@ -341,6 +364,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
             }
         }
     }
+    ATTN_STAMP(4);
     sm = at_sum4(sm);
     if (lg == 0) stat[wave][c16] = sm;
     __syncthreads();
@@ -348,6 +372,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     if (KW == 8) row_sum += (stat[4][c16] + stat[5][c16]) + (stat[6][c16] + stat[7][c16]);
     const float row_inv = 1.0f / row_sum;
 
+    ATTN_STAMP(5);
     // ---- probabilities, quantised per tile row (one [1,16] block = the 4 lanes c16 + 16 g'), times V
     f32x4 o[DT];
 #pragma unroll
@@ -355,13 +380,16 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     const int mbp = (int)__builtin_log2f(ap.shift);
     const uint16_t* __restrict__ vfb = g.vf + b * DT * g.NPAIR * 512;
     // (V fragments one pair ahead and unconditional, like the K fragments; a pair behind the horizon re-reads the last one)
-    const long long slast = max((tlast - wave) / (2 * KW), 0ll);
+    // (pair KW s + w holds key tiles 2 KW s + w and 2 KW s + KW + w: the pairs with a visible key are 0 .. KW s' + min(KW - 1, r),
+    //  tlast = 2 KW s' + r -- a contiguous range, so one descriptor bounds them)
+    const long long s_full = tlast / (2 * KW), r_last = tlast - 2 * KW * s_full;
+    const long long pairs_needed = min((long long)g.NPAIR, KW * s_full + min((long long)KW - 1, r_last) + 1);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vfb), 0, (int)(pairs_needed * DT * 1024), 0x00020000);
     uint4 vb[2][DT];
     auto load_pair = [&](int sp, uint4 (&dst)[DT]) {
-        const long long sc = min((long long)sp, slast);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            dst[dt] = *reinterpret_cast<const uint4*>(vfb + (((KW * sc + wave) * DT + dt) * 64 + lane) * 8);
+            dst[dt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(vrs, ((KW * sp + wave) * DT + dt) * 1024 + lane * 16, 0, 0));
     };
     load_pair(0, vb[0]);
 #pragma unroll
@@ -395,6 +423,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vb[s & 1][dt]), pf, o[dt], 0, 0, 0);
         }
     }
+    ATTN_STAMP(6);
     // ---- sum the four waves' partial outputs in wave order, store
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) red[wave][dt][lane] = o[dt];
@@ -407,6 +436,13 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
         if (m < g.M)
             *reinterpret_cast<float4*>(g.out + b * g.osb + m * g.osm + 16 * dt + 4 * lg) = make_float4(sum[0], sum[1], sum[2], sum[3]);
     }
+#ifdef ATTN_STAMPS
+    ATTN_STAMP(7);
+    if (g.stamps && lane == 0 && wave_all == 0) {
+        unsigned long long* d = g.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int k = 0; k < 8; ++k) d[k] = ast_[k];
+    }
+#endif
 }
 
 // ---- the same pass for any number of keys: scores are not kept but formed twice ----------------------------------------
@@ -627,7 +663,7 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                        (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm};
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps};
     if (stream) {
         const dim3 sgrid((unsigned)((M + 63) / 64), (unsigned)B);
 #define MI355Q_ATTN_S(DC_)                                                                                          \
@@ -676,3 +712,6 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
 }
 
 }  // namespace mi355q
+
+// diagnostic hook, not part of include/mi355q.h: the buffer ([workgroups][8] 64-bit words) a -DATTN_STAMPS build fills
+extern "C" __attribute__((visibility("default"))) void mi355q_debug_attn_stamps(void* buf) { mi355q::g_attn_stamps = static_cast<unsigned long long*>(buf); }

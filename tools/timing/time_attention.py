@@ -29,6 +29,7 @@ def timed(fn, n=20):
 
 for name, H, T, hd, scale in (("OPT-125m", 12, 2048, 64, None), ("OPT-1.3B", 32, 2048, 64, None), ("Llama-7B", 32, 2048, 128, math.sqrt(128)),
                               ("OPT-125m T=1024", 12, 1024, 64, None), ("OPT-125m T=512", 12, 512, 64, None),
+                              ("Llama-7B T=1024", 32, 1024, 128, math.sqrt(128)), ("Llama-7B T=512", 32, 512, 128, math.sqrt(128)),
                               ("Llama-2-7B T=4096", 32, 4096, 128, math.sqrt(128))):
     g = torch.Generator().manual_seed(0)
     q, k, v = (torch.randn(H, T, hd, generator=g).to(dev) for _ in range(3))
