@@ -903,8 +903,12 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
         static const int v10_auto = getenv("MI355Q_V10_AUTO") ? atoi(getenv("MI355Q_V10_AUTO")) : 1;
         if (v10_auto && !force && !getenv("MI355Q_V8_SPLITS") && a.x_segs <= 1 && a.K % 64 == 0) {
             const long long g3 = ((a.M + 127) / 128) * ((a.N + 127) / 128), g1 = ((a.M + 127) / 128) * ((a.N + 255) / 256);
-            const double est3 = nsteps_all * 0.19 * (double)((g3 + 255) / 256) + 8.0, est1 = g1 <= 256 ? nsteps_all * 0.39 + 8.0 : 1e30;
-            if (est3 < best_t || est1 < best_t) {
+            // (128 x 128: 0.23 us a K-step alone on a compute unit, 0.43 for two side by side -- rounds of 512 tiles; beyond ~1000 tiles the
+            //  256 x 256 kernel is ahead again although the line says otherwise: 2048 x 11008 x 4096 took 200 us here against its 165-179,
+            //  hence the margin.  profiles/r05_shard_shapes.txt, r05_column_offsets.txt)
+            const double est3 = (g3 <= 256 ? nsteps_all * 0.23 : nsteps_all * 0.43 * (double)((g3 + 511) / 512)) + 8.0;
+            const double est1 = g1 <= 256 ? nsteps_all * 0.39 + 8.0 : 1e30;
+            if (est3 * 1.12 < best_t || est1 * 1.12 < best_t) {
                 a.splits = 1;
                 return launch_bfp_gemm_v10(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, est1 < est3 ? 1 : 3);
             }
