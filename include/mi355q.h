@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 21
+#define MI355Q_ABI_VERSION 22
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -150,6 +150,13 @@ int mi355q_block_minifloat_quantize_bf16_tiled(const float* x, uint16_t* y_tiled
 int mi355q_block_fp_quantize_bf16_tiled_pre(const float* x, const float* x2, int32_t pre_op, float* y, uint16_t* y_tiled,
                                             int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
                                             int32_t exponent_bias, void* workspace, void* stream);
+/* ... and with LlamaRMSNorm in front (ABI 22): pre_op = MI355Q_PRE_RMSNORM, x2 = the norm's weight [K], eps its epsilon; the row's
+ * mean of squares is summed in the row quantiser's fixed order (mi355q_block_fp_quantize_aligned_rows_norm), so a layer sees the same
+ * normalised values on either route; the other pre_op values as above.  The layers of a group that share the input (q / k / v,
+ * gate / up) on the per-block-exponent route take ONE such operand (mi355q.quantize: grouped_linear). */
+int mi355q_block_fp_quantize_bf16_tiled_norm(const float* x, const float* x2, int32_t pre_op, float eps, float* y, uint16_t* y_tiled,
+                                             int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                             int32_t exponent_bias, void* workspace, void* stream);
 int mi355q_block_fp_quantize_aligned_rows_pre(const float* x, const float* x2, int32_t pre_op, int8_t* mant_tiled,
                                               uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list,
                                               int32_t* list_to_clear, int64_t rows, int64_t K, int32_t width,

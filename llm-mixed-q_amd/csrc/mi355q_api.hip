@@ -138,13 +138,22 @@ int mi355q_block_fp_quantize_bf16_tiled(const float* x, float* y, uint16_t* y_ti
 int mi355q_block_fp_quantize_bf16_tiled_pre(const float* x, const float* x2, int32_t pre_op, float* y, uint16_t* y_tiled,
                                             int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
                                             int32_t exponent_bias, void* workspace, void* stream) {
-    if (!pre_op_ok(pre_op, x2)) return MI355Q_E_BADARG;
+    if (pre_op == MI355Q_PRE_RMSNORM) return MI355Q_E_BADARG;            // (mi355q_block_fp_quantize_bf16_tiled_norm)
+    return mi355q_block_fp_quantize_bf16_tiled_norm(x, x2, pre_op, 0.f, y, y_tiled, rows, K, width, exponent_width, exponent_bias,
+                                                    workspace, stream);
+}
+
+int mi355q_block_fp_quantize_bf16_tiled_norm(const float* x, const float* x2, int32_t pre_op, float eps, float* y, uint16_t* y_tiled,
+                                             int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                             int32_t exponent_bias, void* workspace, void* stream) {
+    if (pre_op == MI355Q_PRE_LAYERNORM || !pre_op_ok(pre_op, x2, pre_op == MI355Q_PRE_RMSNORM) || !(eps >= 0.f)) return MI355Q_E_BADARG;
     QuantArgs a;
     const int rc = fill_common(a, x, y, workspace, 1, rows, K, 1, 16, MI355Q_ZERO_BLOCK_FAST);
     if (rc == (1 << 30)) return 0;
     if (rc) return rc;
     a.x2 = x2;
     a.pre_op = pre_op;
+    a.pre_eps = eps;
     if (y_tiled == nullptr) return MI355Q_E_BADARG;
     if (exponent_width < 1 || exponent_width > 8 || width < 2) return MI355Q_E_BADARG;
     if (width > 9 || K % 32 != 0) return MI355Q_E_UNSUPPORTED;   // bf16's 8 significant bits; whole 64-byte K-steps

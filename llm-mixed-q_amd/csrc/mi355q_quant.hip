@@ -950,6 +950,7 @@ int launch_quant_mx_rows(const QuantArgs& a, uint8_t* c16, uint8_t* c8, uint8_t*
 template <int FMT>          // FMT_BFP, or FMT_BM: block_minifloat with the same [1,16] blocks (values of <= 7 mantissa bits: exact in bf16)
 __global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantArgs a, uint16_t* __restrict__ yt, int cast_only) {
     __shared__ Lut lut;
+    __shared__ float norm_part[4];
     load_lut<FMT>(lut);
     const long long K = a.cols, kp = (K * 2) >> 6;
     const int nhalf = (int)(K >> 3);                      // 8-value half blocks: one lane each, 16 bytes of bf16
@@ -965,12 +966,37 @@ __global__ __launch_bounds__(256) void bfp_quant_bf16_tiled_kernel(const QuantAr
         const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x + row * K);
         float4* __restrict__ y4 = a.y ? reinterpret_cast<float4*>(a.y + row * K) : nullptr;
         unsigned char* prow = reinterpret_cast<unsigned char*>(yt) + (row >> 4) * kp * 1024 + (row & 15) * 16;
+        // LlamaRMSNorm in front of the quantiser (MI355Q_PRE_RMSNORM; a.x2 = the norm's weight [K]): the row's mean of squares first --
+        // the row quantiser's arithmetic and summation order (lane partials over float4 tid, tid + 256, ..., xor tree over the wave,
+        // the four waves in turn: bfp_quant_align_rows_kernel), so both routes of a layer see the same normalised values -- then
+        // w * (x * rsqrt(mean + eps)), two roundings, on the row's second pass (an L2 hit)
+        float rs = 0.f;
+        if (a.pre_op == MI355Q_PRE_RMSNORM) {                          // (uniform)
+            float ss = 0.f;
+            for (int f = (int)threadIdx.x; f < (int)(K >> 2); f += 256) {
+                const float4 v = x4[f];
+                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) norm_part[threadIdx.x >> 6] = ss;
+            __syncthreads();
+            rs = rsqrtf((((norm_part[0] + norm_part[1]) + norm_part[2]) + norm_part[3]) * (1.0f / (float)K) + a.pre_eps);
+        }
         for (int j0 = 0; j0 < nhalf; j0 += 256) {                     // uniform trip count (pair exchange inside)
             const int j = j0 + (int)threadIdx.x;
             const bool valid = j < nhalf;
             float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
             if (valid) { v0 = x4[2 * j]; v1 = x4[2 * j + 1]; }
-            if (valid && a.pre_op) {
+            if (valid && a.pre_op == MI355Q_PRE_RMSNORM) {
+                const float4* __restrict__ w4 = reinterpret_cast<const float4*>(a.x2);
+                const float4 w0 = w4[2 * j], w1 = w4[2 * j + 1];
+                float4 h0 = make_float4(v0.x * rs, v0.y * rs, v0.z * rs, v0.w * rs), h1 = make_float4(v1.x * rs, v1.y * rs, v1.z * rs, v1.w * rs);
+                asm volatile("" : "+v"(h0.x), "+v"(h0.y), "+v"(h0.z), "+v"(h0.w), "+v"(h1.x), "+v"(h1.y), "+v"(h1.z), "+v"(h1.w));   // (two roundings, as two ops)
+                v0 = make_float4(w0.x * h0.x, w0.y * h0.y, w0.z * h0.z, w0.w * h0.w);
+                v1 = make_float4(w1.x * h1.x, w1.y * h1.y, w1.z * h1.z, w1.w * h1.w);
+            } else if (valid && a.pre_op) {
                 const float4* __restrict__ u4 = reinterpret_cast<const float4*>(a.x2 + row * K);
                 v0 = apply_pre(a, v0, u4, 2 * j);
                 v1 = apply_pre(a, v1, u4, 2 * j + 1);

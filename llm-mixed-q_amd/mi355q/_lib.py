@@ -19,6 +19,7 @@ SIGNATURES = {
     "mi355q_block_log_quantize_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize_bf16_tiled": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize_bf16_tiled_pre": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "mi355q_block_fp_quantize_bf16_tiled_norm": (C.c_int, [_vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "mi355q_block_fp_quantize_aligned_rows_pre": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
                                                             _i32, _i32, _i32, _vp]),
     "mi355q_block_fp_quantize_aligned_rows_norm": (C.c_int, [_vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
@@ -80,7 +81,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

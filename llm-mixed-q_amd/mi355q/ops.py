@@ -283,12 +283,14 @@ def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: in
             yt = _BF16_TILED_BUFFERS.put(key, torch.empty(nbytes, dtype=torch.int8, device=x.device))
     else:
         yt = torch.empty(nbytes, dtype=torch.int8, device=x.device)
-    pre_op, other, _, _ = _pre_args(x, pre)        # (`pre`: quantise relu(x) / silu(x) * other instead of x, one pass)
+    # (`pre`: quantise relu(x) / silu(x) * other / LlamaRMSNorm(x) instead of x, one pass -- ("rmsnorm", weight, eps))
+    pre_op, other, eps, third = _pre_args(x, pre)
+    assert pre_op != PRE_LAYERNORM and third is None, "the bf16 tiled quantiser applies relu, silu_mul and rmsnorm"
     with _on_device(x.device):
-        rc = lib.mi355q_block_fp_quantize_bf16_tiled_pre(_ptr(x), _ptr(other), pre_op, _ptr(out_fake), _ptr(yt), rows, K,
-                                                         int(width), int(exponent_width), _default_bias(exponent_bias),
-                                                         _ptr(_workspace(x.device)), _stream_ptr(x.device))
-    _lib.check(rc, "mi355q_block_fp_quantize_bf16_tiled_pre")
+        rc = lib.mi355q_block_fp_quantize_bf16_tiled_norm(_ptr(x), _ptr(other), pre_op, eps, _ptr(out_fake), _ptr(yt), rows, K,
+                                                          int(width), int(exponent_width), _default_bias(exponent_bias),
+                                                          _ptr(_workspace(x.device)), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_block_fp_quantize_bf16_tiled_norm")
     if out_fake is not None:
         _wrote_into(out_fake)
     return yt

@@ -648,6 +648,16 @@ class _LinearBase(nn.Linear):
                 return self._forward_int8(x, plan, pre=(op, o2))
         return self(F.relu(x) if op == "relu" else F.silu(x) * other)
 
+    def _bf16_weight_operand(self, device):
+        """the quantised weights as the tiled bf16 operand of the per-block-exponent route"""
+        if self._w_packed is not None and not self._w_packed.row_scale_flavour:
+            return self._w_packed.expand()                   # width-bit storage -> scratch tiled bf16
+        if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != device:
+            if self._fp32_released:
+                raise RuntimeError("mi355q: the fp32 weights were released; this layer cannot switch routes any more")
+            self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
+        return self._w_bf16[0]
+
     def _forward_int8(self, x, plan, pre=None):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
@@ -661,14 +671,7 @@ class _LinearBase(nn.Linear):
             # quantised weights tiled once.  |x| <= 1e-8 pass-through elements are rounded to bf16 there (<= 2e-11 each).
             # config["mi355q_blocks_gemm"] = "int8": the blockwise-exact int8 kernel instead (exact integer block dots,
             # several times slower).
-            if self._w_packed is not None and not self._w_packed.row_scale_flavour:
-                wt = self._w_packed.expand()                 # width-bit storage -> scratch tiled bf16
-            else:
-                if self._w_bf16 is None or self._w_bf16[1] != self.weight._version or self._w_bf16[0].device != x.device:
-                    if self._fp32_released:
-                        raise RuntimeError("mi355q: the fp32 weights were released; this layer cannot switch routes any more")
-                    self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
-                wt = self._w_bf16[0]
+            wt = self._bf16_weight_operand(x.device)
             xt = ops.block_fp_quantize_bf16_tiled(x2.contiguous(), c["data_in_width"], c["data_in_exponent_width"],
                                                   c["data_in_exponent_bias"], pre=pre)
             y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias)
@@ -776,6 +779,30 @@ def grouped_linear(x, layers, norm=None):
                 outs.extend(ys)
         if outs is not None:
             return [y.reshape(*x.shape[:-1], first.out_features) for y in outs]
+    # The per-block-exponent route (bf16 tile GEMM: inputs no row window fits -- every Linear of a model whose hidden channels
+    # differ in magnitude): ONE activation operand for the group, LlamaRMSNorm applied by its quantiser; the products stay separate
+    # launches.  (Before round 5 such a group fell back to the torch norm -- six elementwise kernels -- and quantised x once per layer.)
+    if (len(layers) >= 1 and (norm is None or len(norm) == 2) and x.is_cuda and x.dtype == torch.float32 and 2 <= x.ndim <= 3
+            and not (torch.is_grad_enabled() and x.requires_grad)
+            and all(isinstance(l, _LinearBase) and l.arith == "block_fp" and l.is_ptq and not l.bypass and not l.weight_requires_quantisation
+                    and l._pending_flavour is None for l in layers)):
+        plan = first._int8_plan(x)
+        if (plan is not None and all(l._packed_is_current() and l._uses_bf16_route() and l.in_features == first.in_features
+                                     and (l._w_packed is None or not l._w_packed.row_scale_flavour or len(layers) == 1)
+                                     and l._int8_plan(x) == plan
+                                     and all(l.config[k] == first.config[k] for k in ("data_in_width", "data_in_exponent_width", "data_in_exponent_bias"))
+                                     for l in layers)
+                and (norm is not None or len(layers) > 1)):
+            c = first.config
+            x2 = x.reshape(-1, first.in_features).contiguous()
+            with torch.no_grad():
+                xt = ops.block_fp_quantize_bf16_tiled(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                                      pre=None if norm is None else ("rmsnorm", norm[0], norm[1]))
+                outs = []
+                for l in layers:           # (a packed layer's expand() shares one scratch operand: each product before the next expand)
+                    y = ops.bf16_gemm_tiled(xt, l._bf16_weight_operand(x.device), x2.shape[0], l.out_features, l.in_features, l.bias)
+                    outs.append(y.reshape(*x.shape[:-1], l.out_features))
+            return outs
     h = x if norm is None else normed()
     return [l(h) for l in layers]
 

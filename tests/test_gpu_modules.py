@@ -1105,3 +1105,50 @@ def test_linear_past_the_row_format_contraction_length():
     lin = Q.get_quantized_cls("linear", bad).from_float(torch.nn.Linear(256, 64), bad).to("cuda:0")
     with pytest.raises(ValueError, match="groups"):
         lin(torch.randn(4, 256, device="cuda:0"))
+
+
+@pytest.mark.parametrize("with_norm", [True, False])
+@pytest.mark.parametrize("M,K,Ns", [(300, 512, (256, 256, 256)), (2048, 4096, (512, 768)), (77, 1024, (256,))])
+def test_grouped_linear_on_the_per_block_route(M, K, Ns, with_norm):
+    """layers on the per-block-exponent route (bf16 tile GEMM) that share their input: ONE activation operand for the group, LlamaRMSNorm
+    applied by its quantiser (mi355q_block_fp_quantize_bf16_tiled_norm) -- against the layers called one by one on the separately
+    normalised tensor (identical without the norm; with it, up to the elements the last bit of the mean moves across a rounding
+    boundary) and against the oracle's norm + quantiser + float64 product"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    from oracle import np_oracle as O
+    if not with_norm and len(Ns) == 1:
+        pytest.skip("a single layer without a norm is the plain call")
+    dev = "cuda:0"
+    cfg = _lin_cfg(6, mi355q_align="blocks")
+    torch.manual_seed(M + K)
+    layers = [Q.get_quantized_cls("linear", cfg)(K, n, bias=True, config=dict(cfg)).to(dev) for n in Ns]
+    x = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev)) * torch.exp(0.7 * torch.randn(1, K, device=dev))
+    w, eps = (1 + 0.1 * torch.randn(K, device=dev)).contiguous(), 1e-6
+    norm = (w, eps) if with_norm else None
+    with torch.no_grad():
+        h = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)) if with_norm else x
+        first = Q.grouped_linear(x, layers, norm=norm)            # first PTQ forward: separate calls
+        ref = [l(h).clone() for l in layers]
+        assert all(l._uses_bf16_route() for l in layers)
+        calls, real = [], ops.block_fp_quantize_bf16_tiled
+        ops.block_fp_quantize_bf16_tiled = lambda *a, **k: (calls.append(k.get("pre")), real(*a, **k))[1]
+        try:
+            got = Q.grouped_linear(x, layers, norm=norm)
+            again = Q.grouped_linear(x, layers, norm=norm)
+        finally:
+            ops.block_fp_quantize_bf16_tiled = real
+        assert len(calls) == 2 and all((c is not None and c[0] == "rmsnorm") == with_norm for c in calls)
+    for a, b, c in zip(ref, got, again):
+        assert torch.equal(b, c)
+        if not with_norm:
+            assert torch.equal(a, b)
+        else:
+            scale = a.abs().max().item()
+            assert (a - b).abs().max().item() <= 2e-3 * scale
+            assert ((a - b).abs() > 1e-6 * scale).float().mean().item() < 0.2
+    hq = O.block_fp_quantize(h.cpu().numpy(), 6, 8, 127, [1, 16], skip_first_dim=False).astype(np.float64)
+    wq = layers[0].weight.detach().cpu().numpy().astype(np.float64)
+    want = hq @ wq.T + layers[0].bias.detach().cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got[0].cpu().numpy(), want, rtol=0, atol=2e-3 * float(np.abs(want).max()))
