@@ -541,3 +541,44 @@ def test_small_tile_bf16_gemm_vs_oracle(M, N, K, geom, ns, monkeypatch):
     ref = O.linear_ptq(x, w, b, cfg)[0]
     scale = np.abs(ref).max() + 1e-30
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6 * scale * max(1, K // 256))
+
+
+@pytest.mark.parametrize("geom,splits", [(3, 2), (3, 4), (1, 2), (3, 8)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_split_k_protocol_under_repetition(geom, splits, bf16, monkeypatch):
+    """the split-K hand-over of the small-tile kernel (round 5: slabs stored / loaded at agent scope instead of behind release /
+    acquire fences; order-free sums take the ticket first and only the non-final slices publish) relies on what the hardware does
+    with sc1 accesses: 300 launches per setting over grids of 32-512 workgroups, every one bit-equal to the unsplit launch (int32
+    sums, and two fp32 slices, are order-free; more fp32 slices are summed in slice order) -- a stale slab or a missed ticket
+    would show"""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    M, N, K = 1024, 512, 4096
+    x, w, b = _exception_rich_operands(M, N, K, seed=99)
+    xt, wt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    monkeypatch.setenv("MI355Q_V10", str(geom))
+    if bf16:
+        xa = ops.block_fp_quantize_bf16_tiled(xt, 6, 8, 127, reuse=False)
+        wa = ops.block_fp_quantize_bf16_tiled(wt, 6, 8, 127, reuse=False)
+        run = lambda: ops.bf16_gemm_tiled(xa, wa, M, N, K, None)
+    else:
+        _, wm, we = ops.block_fp_quantize(wt, 6, 8, 127, [1, 16], False, want_fake=False, want_packed=True, fast_zero_blocks=True)
+        wa = ops.bfp_align_rows(wm, we, 5, 127)
+        xa = ops.block_fp_quantize_aligned_rows(xt, 6, 8, 127)
+        run = lambda: ops.bfp_gemm_aligned(xa, wa, None)
+    unsplit = run().clone()
+    monkeypatch.setenv("MI355Q_V8_SPLITS", str(splits))
+    # (int32 slices: the unsplit launch's bits.  fp32 slices: their own -- another association of the same terms -- but the same every
+    #  launch: two slices are order-free, more are summed in slice order)
+    ref = unsplit if not bf16 else run().clone()
+    bad = 0
+    for it in range(300):
+        y = run()
+        if it % 25 == 24 or it < 3:
+            bad += 0 if torch.equal(y, ref) else 1
+        del y
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of the compared launches differ"
+    if bf16:
+        torch.testing.assert_close(ref, unsplit, rtol=1e-5, atol=1e-5 * float(unsplit.abs().max()))
