@@ -173,6 +173,87 @@ __global__ __launch_bounds__(256) void loop_pf(const char* __restrict__ src, uns
     if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
 }
 
+// The same again with the barrier every KS K-steps (a stage = KS steps) and NWV waves a workgroup (8: two a SIMD inside ONE workgroup, in
+// lockstep at its barriers -- what an eight-wave tile gets instead of two free-running workgroups).  Placement 1, LDS-DMA, P pieces a wave-step.
+// SHARE: 0 = every workgroup its own stream; 1 = the GEMM's pattern: the first half of a wave's pieces from a stream shared by the 16
+// workgroups of a tile row (blockIdx / 16), the second half from one shared by a tile column (blockIdx % 16)
+template <int P, int KS, int NWV, int SHARE = 0>
+__global__ __launch_bounds__(64 * NWV) void loop_ks(const char* __restrict__ src, unsigned span, int steps, float* out, unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];      // 3 stages x KS x 16 KiB (the fragment addresses wrap inside 16 KiB)
+    constexpr int STG = KS * 16384;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 3 * STG / 4; i += 64 * NWV) reinterpret_cast<unsigned*>(sm)[i] = 0x01010101u * (i & 3);
+    __syncthreads();
+    const i32x4 rs = {(int)(unsigned)(unsigned long long)src, (int)(unsigned)((unsigned long long)src >> 32), (int)span, 0x00020000};
+    const int voff = lane * 16;
+    const int lbase = (int)(unsigned long long)(sm);
+    const int va = lbase + ((wave >> 1) & 1) * 4096 + lane * 16, vb = lbase + 8192 + (wave & 1) * 4096 + lane * 16;
+    i32x4 acc[4][4], fa[2][4], fb[2][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+    unsigned piece = (blockIdx.x * 37u + wave * P) * 1024u;
+    const unsigned pa = ((blockIdx.x / 16u) * 4099u + wave * P) * 1024u, pb = ((blockIdx.x % 16u) * 8209u + 1000003u + wave * P) * 1024u;
+    sfor<0, 4>([&](auto ji) { constexpr int j = decltype(ji)::value; dsr<j * 1024>(fb[0][j], vb); dsr<j * 1024>(fa[0][j], va); });
+    // sub-step u of stage C; fragments of the next sub-step (same stage, or sub-step 0 of stage C + 1) are read during it
+    auto sub = [&](auto ci, auto ui) {
+        constexpr int C = decltype(ci)::value, U = decltype(ui)::value, B = (C * KS + U) & 1;
+        constexpr int NC = U + 1 < KS ? C : (C + 1) % 3, NU = U + 1 < KS ? U + 1 : 0, F = (C + 2) % 3;
+        if constexpr (U == 0) {
+            waitv<P * KS>();                                                // stage C + 1 has landed (fetched during stage C - 1)
+            waitl<0>();
+            __builtin_amdgcn_s_barrier();
+        } else {
+            waitl<0>();
+        }
+        const int an = va + NC * STG + NU * 16384, bn = vb + NC * STG + NU * 16384;
+        sfor<0, 4>([&](auto gi) {
+            constexpr int g = decltype(gi)::value;
+            SB();
+            sfor<0, 4>([&](auto ji) {
+                constexpr int j = decltype(ji)::value;
+                acc[g][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[B][g], fb[B][j], acc[g][j], 0, 0, 0);
+                if constexpr (g == 0) dsr<j * 1024>(fb[B ^ 1][j], bn);
+                if constexpr (g == 1) dsr<j * 1024>(fa[B ^ 1][j], an);
+                if constexpr (j == 1) sfor<0, P>([&](auto qi) {
+                    constexpr int q = decltype(qi)::value;
+                    const unsigned from = SHARE == 0 ? piece : (q < (P + 1) / 2 ? pa : pb) + (piece - (blockIdx.x * 37u + wave * P) * 1024u);
+                    if constexpr (q % 4 == g) ldma(voff, rs, (from + q * 1024u) & (span - 1), lbase + F * STG + U * 16384 + (wave * P + q) % 16 * 1024);
+                });
+            });
+            SB();
+        });
+        piece += (unsigned)NWV * P * 1024u;
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s + 3 * KS <= steps; s += 3 * KS) {
+        sfor<0, 3>([&](auto ci) { sfor<0, KS>([&](auto ui) { sub(ci, ui); }); });
+    }
+    waitv<0>();
+    waitl<0>();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    int x = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int q = 0; q < 4; ++q) x += acc[i][j][q];
+    if (x == 0x12345677) out[0] = (float)x;
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+
+template <int P, int KS, int NWV, int SHARE = 0> static void run_ks(const char* src, unsigned span) {
+    float* out; unsigned long long* clk;
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&clk, 64));
+    const int steps = 768;
+    const int lds = 3 * KS * 16384 > 96 * 1024 ? 3 * KS * 16384 : 96 * 1024;          // (one workgroup a compute unit)
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&loop_ks<P, KS, NWV, SHARE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((loop_ks<P, KS, NWV, SHARE>), 256, 64 * NWV, lds, 0, src, span, steps, out, clk);
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((loop_ks<P, KS, NWV, SHARE>), 256, 64 * NWV, lds, 0, src, span, steps, out, clk);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    unsigned long long c; CK(hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost));
+    printf("%s span %u MiB: barrier every %d K-steps, %d waves a workgroup, %d pieces a wave-step:  %6.1f cycles per K-step of a wave   launch %7.1f us = %6.1f ns per K-step (MFMA bound: %d clocks per SIMD-step)\n",
+           SHARE ? "shared streams," : "private streams,", span >> 20, KS, NWV, P, (double)c / steps, ms * 1e3, ms * 1e6 / steps, 256 * NWV / 4);
+    CK(hipFree(out)); CK(hipFree(clk));
+}
+
 template <int DMA, int P, int PLACE> static void run_pf(const char* src, unsigned span, int wgs) {
     float* out; unsigned long long* clk;
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&clk, 64));
@@ -224,5 +305,11 @@ int main() {
         run_pf<0, 0, 1>(src, span, wgs); run_pf<1, 4, 1>(src, span, wgs); run_pf<1, 6, 1>(src, span, wgs);
         run_pf<1, 4, 2>(src, span, wgs); run_pf<1, 6, 2>(src, span, wgs);
     }
+    run_ks<4, 1, 4>(src, span); run_ks<4, 2, 4>(src, span);
+    run_ks<3, 1, 8>(src, span); run_ks<3, 2, 8>(src, span); run_ks<2, 2, 8>(src, span);
+    // the GEMM's sharing pattern, and a source larger than the L2s (64 MiB: from the memory-side cache)
+    run_ks<3, 1, 8, 1>(src, span); run_ks<4, 1, 8, 1>(src, span);
+    char* big; const unsigned bspan = 64u << 20; CK(hipMalloc(&big, bspan + 4096)); CK(hipMemset(big, 1, bspan + 4096));
+    run_ks<3, 1, 8, 0>(big, bspan); run_ks<3, 1, 8, 1>(big, bspan); run_ks<4, 1, 8, 1>(big, bspan); run_ks<4, 1, 4, 1>(big, bspan);
     return 0;
 }
