@@ -95,6 +95,18 @@ __device__ __forceinline__ int at_block_exponent(float bmax, const QuantArgs& a,
     }
     return clampi((int)E - 127 + (f != 0u ? 1 : 0), a.e_min, a.e_max);
 }
+// the same with the rare walk reading its threshold from MEMORY (an L2 hit; one block maximum in 2 x 10^5 takes it): a kernel that uses
+// only this form need not stage the 277-entry table in LDS in front of its first instruction -- the one-pass attention kernel's
+// workgroups live 13-24 us and spent 1 of them on that (tools/dbg/attn_stamps.py)
+__device__ __forceinline__ int at_block_exponent_mem(float bmax, const QuantArgs& a) {
+    const unsigned bits = __float_as_uint(bmax), E = bits >> 23, f = bits & 0x7FFFFFu;
+    if (__any((E == 0u && bits != 0u) || (f != 0u && f < MI355Q_LOG2_CEIL_THR_MAX))) {
+        int k; unsigned m;
+        split_pos(bmax != 0.f ? bmax : 1.0f, k, m);
+        return clampi(k + ((m != 0u && m >= mi355q_log2_ceil_thr[lut_index(k)]) ? 1 : 0), a.e_min, a.e_max);
+    }
+    return clampi((int)E - 127 + (f != 0u ? 1 : 0), a.e_min, a.e_max);
+}
 // block_fp element for x >= 0 (probabilities) given the block's scales 2^up, 2^-up (block_fp.py:69-94 with sign = +1)
 __device__ __forceinline__ float at_quant_pos(float x, float sc_up, float sc_dn, float mant_max) {
     const float m = fminf(__builtin_rintf((x + EPS9) * sc_up), mant_max);
@@ -231,14 +243,12 @@ template <int NTW, int DC, int QG, bool HASMASK, int KW = 4>
 __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
     constexpr int DT = DC * 2;
     constexpr float FMIN = -3.4028234663852886e38f;
-    __shared__ Lut lut;
     __shared__ float stat_[QG][KW][16];
     __shared__ f32x4 red_[QG][KW][DT][64];
 #ifdef ATTN_STAMPS
     unsigned long long ast_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     ATTN_STAMP(0);
-    load_lut<FMT_BFP, true>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_all % KW, grp = wave_all / KW;
     float (&stat)[KW][16] = stat_[grp];
@@ -260,8 +270,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
             float bmax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(lo.w))),
                                fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fmaxf(fabsf(hi.z), fabsf(hi.w))));
             bmax = at_max2_16(bmax);
-            unsigned code;
-            const int p = block_param<FMT_BFP>(bmax != 0.f ? bmax : 1.0f, aq, lut, code).p;
+            const int p = at_block_exponent_mem(bmax, aq);
             const int up = mb - p, dn = p - mb;
             uint4 pk;
             pk.x = pack_bf16(at_quant(lo.x, up, dn, aq.mant_max), at_quant(lo.y, up, dn, aq.mant_max));
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
                     bmax = fmaxf(bmax, pr[e]);
                 }
                 bmax = at_max4(bmax);
-                const int p = at_block_exponent(bmax, ap, lut);
+                const int p = at_block_exponent_mem(bmax, ap);
                 const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pq[4 * h + e] = at_quant_pos(pr[e], sc_up, sc_dn, ap.mant_max);

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Kernel trace of the full-depth config-3 forward (eager, 4 layers are enough for the per-layer sequence): one decoder layer's dispatches in order with
-# durations and gaps, and the per-kernel totals of the whole run.  Run on the GPU box from the repo root:  bash tools/prof/config3_sequence.sh [layers]
+# durations and gaps, and the per-kernel totals of the whole run.  Run on the GPU box from the repo root:  bash tools/prof/config3_sequence.sh [layers [--no-spread]]
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-L=${1:-4}
+L=${1:-4}; shift
 rm -rf gpurun_out/_c3
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/_c3 -o p -- python3 tools/config3_full_depth.py --layers $L --steps 3 --no-graph --no-parity > gpurun_out/c3_seq.json 2> gpurun_out/c3_seq.err
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/_c3 -o p -- python3 tools/config3_full_depth.py --layers $L --steps 3 --no-graph --no-parity "$@" > gpurun_out/c3_seq.json 2> gpurun_out/c3_seq.err
 F=$(find gpurun_out/_c3 -name '*kernel_trace.csv' | head -1)
 python3 - "$F" "$L" <<'PY'
 import csv, sys, collections
