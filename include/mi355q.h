@@ -213,6 +213,11 @@ int mi355q_bfp_expand(const uint8_t* packed, const uint8_t* codes, void* out_til
 int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, void* stream);
 int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
                            int64_t K, int64_t ldy, void* stream);
+/* ... with the residual add of the caller's decoder layer in the store (ABI 22): y = (x . w^T + bias) + residual, the two sums rounded
+ * like F.linear followed by `residual + hidden_states` (modeling_llama.py:259, 265; modeling_opt.py:375, 425): the same bits, one
+ * pass over [M, N] less.  residual [M, >= N] fp32, ldr elements a row (ldr % 4 == 0), 16-byte aligned; y may be residual itself. */
+int mi355q_bf16_gemm_tiled_res(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, const float* residual, int64_t ldr,
+                               float* y, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream);
 /* The same with x as `x_segments` COLUMN segments (ABI 20): segment s is the tiled bf16 operand of columns
  * [s K / x_segments, (s + 1) K / x_segments) of x -- [row piece][K-steps of the segment][1 KiB], what
  * mi355q_block_fp_quantize_bf16_tiled writes for that slice -- and the segments lie x_segment_stride_bytes apart: the

@@ -223,11 +223,19 @@ int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K,
 }
 
 static int bf16_gemm_tiled_impl(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
-                                int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream);
+                                int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream,
+                                const float* residual = nullptr, int64_t ldr = 0);
 
 int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
                            int64_t K, int64_t ldy, void* stream) {
     return bf16_gemm_tiled_impl(x_tiled, w_tiled, bias, y, M, N, K, ldy, 1, 0, stream);
+}
+
+int mi355q_bf16_gemm_tiled_res(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, const float* residual, int64_t ldr,
+                               float* y, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
+    if (!residual || ldr < N || ldr % 4 != 0) return MI355Q_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(residual) % 16) return MI355Q_E_ALIGN;
+    return bf16_gemm_tiled_impl(x_tiled, w_tiled, bias, y, M, N, K, ldy, 1, 0, stream, residual, ldr);
 }
 
 int mi355q_bf16_gemm_tiled_seg(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
@@ -240,7 +248,8 @@ int mi355q_bf16_gemm_tiled_seg(const uint16_t* x_tiled, const uint16_t* w_tiled,
 }
 
 static int bf16_gemm_tiled_impl(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
-                                int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream) {
+                                int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream,
+                                const float* residual, int64_t ldr) {
     if (M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
     if (M == 0 || N == 0) return 0;
     if (!y || (K > 0 && (!x_tiled || !w_tiled))) return MI355Q_E_BADARG;
@@ -254,6 +263,8 @@ static int bf16_gemm_tiled_impl(const uint16_t* x_tiled, const uint16_t* w_tiled
     a.M = M; a.N = N; a.K = 2 * K; a.ldy = ldy;      // (the tile kernel counts the contraction in bytes)
     a.x_segs = x_segments;
     a.x_seg_stride = x_segment_stride_bytes;
+    a.resid = residual;
+    a.ldr = ldr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t te = g_timing.begin(st);
     const int rc = launch_bf16_gemm_tiled(a, st);

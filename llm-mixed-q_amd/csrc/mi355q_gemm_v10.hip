@@ -645,13 +645,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     //      wm * WM + 16 i + l16 and the four columns wn * WN + 16 j + 4 lq + 0..3: one 16-byte store.
     V10_STAMP(5);
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.y) | (uintptr_t)(a.ldy * 4)) & 15) == 0;
-    auto store4 = [&](float* yrow, const f32x4& val, int col) {
+    auto store4 = [&](float* yrow, f32x4 val, int col, const float* rrow) {
         if (vec_ok && col + 3 < Ni) {
+            if (rrow) val += *reinterpret_cast<const f32x4*>(rrow);
             *reinterpret_cast<f32x4*>(yrow) = val;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (col + r < Ni) yrow[r] = val[r];
+                if (col + r < Ni) yrow[r] = rrow ? val[r] + rrow[r] : val[r];
         }
     };
     unsigned cany = 0;                  // bit j: some column of the wave's column fragment j has a vector
@@ -711,8 +712,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
                     }
             }
             if (row < a.M) {
+                const float* rrow = a.resid ? a.resid + row * a.ldr + n0 + wn * WN + lq * 4 : nullptr;
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) store4(yrow + j * 16, val[j], n0 + wn * WN + j * 16 + lq * 4);
+                for (int j = 0; j < TJ; ++j) store4(yrow + j * 16, val[j], n0 + wn * WN + j * 16 + lq * 4, rrow ? rrow + j * 16 : nullptr);
             }
             V10_SB();
         }

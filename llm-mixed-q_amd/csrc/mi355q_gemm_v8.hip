@@ -654,9 +654,10 @@ __global__ __launch_bounds__(V8_NT, 1) void bfp_gemm_v8(const GemmArgs a_in, con
         for (int r = 0; r < 4; ++r) {
             const long long row = m0 + wm * WM + i * 16 + lq * 4 + r;
             float* yrow = a.y + row * a.ldy + n0 + wn * 64 + l16;
+            const float* rrow = a.resid ? a.resid + row * a.ldr + n0 + wn * 64 + l16 : nullptr;      // (the caller's residual add, in the store)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                if (n0 + wn * 64 + j * 16 + l16 < a.N && row < a.M) yrow[j * 16] = val[j][r];
+                if (n0 + wn * 64 + j * 16 + l16 < a.N && row < a.M) yrow[j * 16] = rrow ? val[j][r] + rrow[j * 16] : val[j][r];
         }
     }
     if (FIXMODE_ == 3) {

@@ -582,6 +582,14 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             }
             if (row < a.M) {
                 const int col = n0 + cl;
+                if (a.resid) {                                   // (uniform) the caller's residual add, in the store
+                    const float* rr = a.resid + row * a.ldr + col;
+                    if (col + 3 < Ni) val += *reinterpret_cast<const f32x4*>(rr);
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < Ni) val[r] += rr[r];
+                }
                 if (vec_ok && col + 3 < Ni) {
                     // (experiment, MI355Q_V9_DBG bits 8 / 16 / 32: write-through / system-scope / non-temporal stores)
                     if (a.dbg & 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(yrow + j * 16), "v"(val) : "memory");

@@ -98,6 +98,10 @@ struct GemmArgs {
     float* g_y[3];
     int x_mbits, w_mbits;         // mantissa bits of the operands (0: not given) -- the launcher's choice of kernel
     unsigned long long* stamps;   // diagnostic builds of the 256 x 256 tile kernel (MI355Q_V9_STAMPS): [workgroup][2][8] phase times
+    // y = (x . w^T + bias) + resid: the residual add the callers' decoder layers put behind o_proj / fc2 / down_proj, in the store
+    // (bf16 flavour: mi355q_bf16_gemm_tiled_res); [M, >= N] fp32, ldr elements a row, 16-byte aligned rows; null: none
+    const float* resid;
+    long long ldr;
     // bf16 flavour: x as `x_segs` column segments (the rank-major result of an all-gather of per-rank quantised slices,
     // mi355q_bf16_gemm_tiled_seg): segment s holds K-steps s * steps / x_segs .. of every row piece, x_seg_stride bytes apart
     int x_segs;

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mi355q_bfp_expand": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mi355q_bf16_tile": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "mi355q_bf16_gemm_tiled": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "mi355q_bf16_gemm_tiled_res": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_bf16_gemm_tiled_seg": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i64, _vp]),
     "mi355q_block_fp_quantize": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                            _i32, _i32, _i32, _u32, _vp, _vp]),

@@ -50,7 +50,10 @@ class _Attention(nn.Module):
         for name in ("q_proj", "k_proj", "v_proj", "out_proj"):
             setattr(self, name, get_quantized_cls("linear", qc[name])(self.h, self.h, bias=True, config=qc[name]))
 
-    def forward(self, x, mask, norm=None):
+    def forward(self, x, mask, norm=None, residual=None):
+        """`residual`: returns residual + attention (config["mi355q_fused_residual"] of out_proj: the add in out_proj's stores where
+        that layer's route has it, Linear.forward_residual)"""
+        out = lambda o: self.out_proj(o) if residual is None else self.out_proj.forward_residual(o, residual)
         B, T, _ = x.shape
         shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2).contiguous().view(B * self.nh, T, self.hd)
         c1 = self.qc["bmm_1"]
@@ -64,7 +67,7 @@ class _Attention(nn.Module):
                 qp, kp, vp = self.q_proj(x), self.k_proj(x), self.v_proj(x)
             o = get_quantized_func("attention", c1)(heads(qp * self.scaling), heads(kp), heads(vp), self.qc["bmm_0"], c1,
                                                     causal=True)
-            return self.out_proj(o.transpose(1, 2).reshape(B, T, self.h))
+            return out(o.transpose(1, 2).reshape(B, T, self.h))
         q = shape(self.q_proj(x) * self.scaling)
         k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
         w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
@@ -77,7 +80,7 @@ class _Attention(nn.Module):
             p = F.softmax(w, dim=-1)
             o = get_quantized_func("bmm", c1)(p, v, config=c1)
         o = o.view(B, self.nh, T, self.hd).transpose(1, 2).reshape(B, T, self.h)
-        return self.out_proj(o)
+        return out(o)
 
 
 class _DecoderLayer(nn.Module):
@@ -94,10 +97,11 @@ class _DecoderLayer(nn.Module):
         fused_norm = (self.fc1.config.get("mi355q_fused_norm", False) and c1.get("mi355q_grouped_linear", False)
                       and c1.get("mi355q_fused_attention", False) and c1["name"] == "block_fp")
         ln = lambda m: (m.weight, m.bias, m.eps)
+        fres = self.fc2.config.get("mi355q_fused_residual", False)      # the residual adds in out_proj's / fc2's stores
         if fused_norm:      # the LayerNorms are applied by the quantiser of the projections they feed (grouped_linear(norm=...))
-            x = x + self.self_attn(x, mask, norm=ln(self.self_attn_layer_norm))
+            x = self.self_attn(x, mask, norm=ln(self.self_attn_layer_norm), residual=x) if fres else x + self.self_attn(x, mask, norm=ln(self.self_attn_layer_norm))
         else:
-            x = x + self.self_attn(self.self_attn_layer_norm(x), mask)
+            x = self.self_attn(self.self_attn_layer_norm(x), mask, residual=x) if fres else x + self.self_attn(self.self_attn_layer_norm(x), mask)
         shape = x.shape
         h = x.reshape(-1, shape[-1])                       # the MLP sees a 2-D activation (modeling_opt.py:412)
         if fused_norm:
@@ -105,7 +109,8 @@ class _DecoderLayer(nn.Module):
         else:
             f1 = None
         if self.fc2.config.get("mi355q_fused_activation", False):    # relu read by fc2's x quantiser (Linear.forward_after)
-            h = h + self.fc2.forward_after(f1 if fused_norm else self.fc1(self.final_layer_norm(h)), "relu")
+            f = f1 if fused_norm else self.fc1(self.final_layer_norm(h))
+            h = self.fc2.forward_after(f, "relu", residual=h.contiguous()) if fres else h + self.fc2.forward_after(f, "relu")
         elif fused_norm:
             h = h + self.fc2(F.relu(f1))
         else:
@@ -214,7 +219,8 @@ class _LlamaAttention(nn.Module):
         self.register_buffer("cos", emb.cos()[None, None], persistent=False)       # [1, 1, pos, hd]
         self.register_buffer("sin", emb.sin()[None, None], persistent=False)
 
-    def forward(self, x, mask, position_ids, norm=None):
+    def forward(self, x, mask, position_ids, norm=None, residual=None):
+        out = lambda o: self.o_proj(o) if residual is None else self.o_proj.forward_residual(o, residual)
         B, T, _ = x.shape
         shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
         if self.qc["matmul_1"].get("mi355q_grouped_linear", False):
@@ -233,7 +239,7 @@ class _LlamaAttention(nn.Module):
         c1 = self.qc["matmul_1"]
         if c1["name"] == "block_fp" and c1.get("mi355q_fused_attention", False):
             o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd))
-            return self.o_proj(o.transpose(1, 2).reshape(B, T, self.h))
+            return out(o.transpose(1, 2).reshape(B, T, self.h))
         w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])
         if c1["name"] in ("block_fp", "block_minifloat") and c1.get("mi355q_fused_softmax", False):
             o = get_quantized_func("softmax_matmul", c1)(w / math.sqrt(self.hd), v, config=c1, causal=True)
@@ -242,7 +248,7 @@ class _LlamaAttention(nn.Module):
             w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min))
             p = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
             o = get_quantized_func("matmul", c1)(p, v, config=c1)
-        return self.o_proj(o.transpose(1, 2).reshape(B, T, self.h))
+        return out(o.transpose(1, 2).reshape(B, T, self.h))
 
 
 class _LlamaLayer(nn.Module):
@@ -259,21 +265,23 @@ class _LlamaLayer(nn.Module):
     def forward(self, x, mask, position_ids):
         gc = self.gate_proj.config
         fused_norm = gc.get("mi355q_grouped_linear", False) and gc.get("mi355q_fused_norm", False)
+        fres = self.down_proj.config.get("mi355q_fused_residual", False)      # the residual adds in o_proj's / down_proj's stores
         if fused_norm:      # the norms are applied by the quantiser of the projections they feed (grouped_linear(norm=...))
             n1, n2 = self.input_layernorm, self.post_attention_layernorm
-            x = x + self.self_attn(x, mask, position_ids, norm=(n1.weight, n1.eps))
+            x = (self.self_attn(x, mask, position_ids, norm=(n1.weight, n1.eps), residual=x) if fres
+                 else x + self.self_attn(x, mask, position_ids, norm=(n1.weight, n1.eps)))
             gate, up = grouped_linear(x, (self.gate_proj, self.up_proj), norm=(n2.weight, n2.eps))
             if self.down_proj.config.get("mi355q_fused_activation", False):
-                return x + self.down_proj.forward_after(gate, "silu_mul", up)
+                return self.down_proj.forward_after(gate, "silu_mul", up, residual=x) if fres else x + self.down_proj.forward_after(gate, "silu_mul", up)
             return x + self.down_proj(F.silu(gate) * up)
-        x = x + self.self_attn(self.input_layernorm(x), mask, position_ids)
+        x = self.self_attn(self.input_layernorm(x), mask, position_ids, residual=x) if fres else x + self.self_attn(self.input_layernorm(x), mask, position_ids)
         h = self.post_attention_layernorm(x)
         if self.gate_proj.config.get("mi355q_grouped_linear", False):
             gate, up = grouped_linear(h, (self.gate_proj, self.up_proj))
         else:
             gate, up = self.gate_proj(h), self.up_proj(h)
         if self.down_proj.config.get("mi355q_fused_activation", False):    # silu(gate) * up read by down_proj's x quantiser
-            return x + self.down_proj.forward_after(gate, "silu_mul", up)
+            return self.down_proj.forward_after(gate, "silu_mul", up, residual=x) if fres else x + self.down_proj.forward_after(gate, "silu_mul", up)
         return x + self.down_proj(F.silu(gate) * up)                      # (modeling_llama.py:208-240)
 
 

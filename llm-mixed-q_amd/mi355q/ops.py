@@ -418,10 +418,12 @@ def bf16_tile(x: torch.Tensor) -> torch.Tensor:
 
 
 def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, bias=None, out: torch.Tensor = None,
-                    segments: int = 1):
+                    segments: int = 1, residual: torch.Tensor = None):
     """y[M, N] = x . w^T (+ bias) on tiled bf16 operands (block_fp_quantize_bf16_tiled), fp32 accumulation and output:
     the tile GEMM's bf16 arithmetic -- operands whose blocks keep their own exponents.  `segments` > 1: xt is [segments,
-    bytes] -- column segment s of x as its own tiled operand, rank-major as an all-gather leaves them (sharded.py)."""
+    bytes] -- column segment s of x as its own tiled operand, rank-major as an all-gather leaves them (sharded.py).
+    `residual` [M, N] fp32: y = (x . w^T + bias) + residual, the decoder layer's residual add in the store (the same bits as
+    the separate add; mi355q_bf16_gemm_tiled_res)."""
     if not (xt.is_cuda and wt.is_cuda):
         raise RuntimeError("mi355q.bf16_gemm_tiled: operands must be on a HIP device; there is no CPU fallback")
     given = out is not None
@@ -436,6 +438,11 @@ def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, 
             assert xt.shape[1] * xt.element_size() == _lib.load_library().mi355q_bfp_tiled_bytes(M, 2 * K // segments), (xt.shape, M, K, segments)
             rc = _lib.load_library().mi355q_bf16_gemm_tiled_seg(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy, int(segments),
                                                                xt.stride(0) * xt.element_size(), _stream_ptr(xt.device))
+        elif residual is not None:
+            assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1 and residual.device == out.device
+            rc = _lib.load_library().mi355q_bf16_gemm_tiled_res(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(residual),
+                                                               residual.stride(0) if M > 1 else max(N, residual.stride(0)),
+                                                               _ptr(out), M, N, K, ldy, _stream_ptr(xt.device))
         else:
             rc = _lib.load_library().mi355q_bf16_gemm_tiled(_ptr(xt), _ptr(wt), _ptr(bias), _ptr(out), M, N, K, ldy,
                                                            _stream_ptr(xt.device))

@@ -606,13 +606,22 @@ class _LinearBase(nn.Linear):
         y = ops.bf16_gemm_tiled(xt, self._w_bf16[0], x2.shape[0], self.out_features, self.in_features, self.bias)
         return y.reshape(*x.shape[:-1], self.out_features)
 
-    def forward_after(self, x, op, other=None):
+    def forward_after(self, x, op, other=None, residual=None):
         """self(relu(x)) (op = "relu": OPT's fc2 behind its activation_fn, modeling_opt.py:412-420) or
         self(silu(x) * other) (op = "silu_mul": Llama's down_proj, modeling_llama.py:216) with the elementwise step read by
         the layer's x quantiser itself -- the reference runs it as torch kernels whose result the quantiser reads back
         (three passes over the [tokens, ffn] tensor instead of one).  Same arithmetic, rounded to fp32 operation by
         operation; whenever the fused quantisers do not apply (first PTQ forward, QAT, bypass, other arithmetics, the
-        group flavour) the step runs as torch ops in front of forward()."""
+        group flavour) the step runs as torch ops in front of forward().  `residual`: residual + the result (forward_residual)."""
+        from ...sharded import ShardedRows, ShardedTiledBf16
+        if residual is not None:
+            if isinstance(x, (ShardedRows, ShardedTiledBf16)):
+                return residual + self.forward_after(x, op, other)
+            y = self._forward_after(x, op, other, residual)
+            return y
+        return self._forward_after(x, op, other, None)
+
+    def _forward_after(self, x, op, other, residual):
         from ...sharded import ShardedRows, ShardedTiledBf16
         if op not in ("relu", "silu_mul") or ((op == "silu_mul") != (other is not None) and not isinstance(x, ShardedTiledBf16)):
             raise ValueError("forward_after: op is 'relu' (no other) or 'silu_mul' (with other)")
@@ -645,8 +654,12 @@ class _LinearBase(nn.Linear):
         if fused:
             with torch.no_grad():
                 o2 = None if other is None else other.reshape(-1, self.in_features)
-                return self._forward_int8(x, plan, pre=(op, o2))
-        return self(F.relu(x) if op == "relu" else F.silu(x) * other)
+                if residual is not None and self._residual_fits(x, residual):
+                    return self._forward_int8(x, plan, pre=(op, o2), residual=residual)
+                y = self._forward_int8(x, plan, pre=(op, o2))
+            return y if residual is None else residual + y
+        y = self(F.relu(x) if op == "relu" else F.silu(x) * other)
+        return y if residual is None else residual + y
 
     def _bf16_weight_operand(self, device):
         """the quantised weights as the tiled bf16 operand of the per-block-exponent route"""
@@ -658,7 +671,25 @@ class _LinearBase(nn.Linear):
             self._w_bf16 = (ops.bf16_tile(self.weight.data), self.weight._version)
         return self._w_bf16[0]
 
-    def _forward_int8(self, x, plan, pre=None):
+    def _residual_fits(self, x, residual) -> bool:
+        """can `residual + self(x)` run as one launch?  (the per-block-exponent route's product adds it in its stores)"""
+        return (residual is not None and self.is_ptq and not self.bypass and not self.weight_requires_quantisation
+                and self._pending_flavour is None and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
+                and self._packed_is_current() and self._uses_bf16_route() and self._int8_plan(x) is not None
+                and residual.dtype == torch.float32 and residual.device == x.device
+                and tuple(residual.shape) == tuple(x.shape[:-1]) + (self.out_features,) and residual.is_contiguous()
+                and self.out_features % 4 == 0 and residual.data_ptr() % 16 == 0
+                and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)))
+
+    def forward_residual(self, x, residual):
+        """residual + self(x) (modeling_llama.py:259, modeling_opt.py:375, 425: the add a decoder layer puts behind o_proj / fc2) --
+        in the product's stores where the layer runs on the per-block-exponent route (same bits), as two steps otherwise"""
+        if self._residual_fits(x, residual):
+            with torch.no_grad():
+                return self._forward_int8(x, self._int8_plan(x), residual=residual)
+        return residual + self(x)
+
+    def _forward_int8(self, x, plan, pre=None, residual=None):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
         from ...sharded import ShardedRows
@@ -674,8 +705,10 @@ class _LinearBase(nn.Linear):
             wt = self._bf16_weight_operand(x.device)
             xt = ops.block_fp_quantize_bf16_tiled(x2.contiguous(), c["data_in_width"], c["data_in_exponent_width"],
                                                   c["data_in_exponent_bias"], pre=pre)
-            y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias)
+            y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias,
+                                    residual=None if residual is None else residual.reshape(-1, self.out_features))
             return y.reshape(*x.shape[:-1], self.out_features)
+        assert residual is None, "the residual add is fused on the per-block-exponent route only"
         # one fused kernel: quantise + pack + row-align + tile
         xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                 c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre,

@@ -159,9 +159,18 @@ class RowShardedLinear(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.gather_output(self.local(x))
 
-    def forward_after(self, x, op, other=None):
-        """the wrapped layer's fused elementwise step (quantized_modules.linear.forward_after) on this rank's shard"""
-        return self.gather_output(self.local.forward_after(x, op, other))
+    def forward_after(self, x, op, other=None, residual=None):
+        """the wrapped layer's fused elementwise step (quantized_modules.linear.forward_after) on this rank's shard; `residual`: added
+        behind the gather (the shard's product sees a column slice of it at best: two steps here)"""
+        y = self.gather_output(self.local.forward_after(x, op, other))
+        if residual is None:
+            return y
+        return residual + (y.dense() if hasattr(y, "dense") else y)
+
+    def forward_residual(self, x, residual):
+        """residual + self(x) (quantized_modules.linear.forward_residual): behind the gather"""
+        y = self(x)
+        return residual + (y.dense() if hasattr(y, "dense") else y)
 
     # what the harness reads of a projection
     @property

@@ -1152,3 +1152,34 @@ def test_grouped_linear_on_the_per_block_route(M, K, Ns, with_norm):
     wq = layers[0].weight.detach().cpu().numpy().astype(np.float64)
     want = hq @ wq.T + layers[0].bias.detach().cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(got[0].cpu().numpy(), want, rtol=0, atol=2e-3 * float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (2048, 4096, 4096), (64, 1024, 776), (2048, 4096, 11008), (2048, 8192, 256), (4096, 4096, 4096)])
+@pytest.mark.parametrize("after", [None, "relu", "silu_mul"])
+def test_linear_with_the_residual_add_in_its_stores(M, K, N, after):
+    """residual + layer(x) (the add a decoder layer puts behind o_proj / fc2 / down_proj) as ONE launch on the per-block-exponent
+    route (mi355q_bf16_gemm_tiled_res): the same bits as the two steps -- F.linear's result rounded, then the add --; on the
+    row-scale route forward_residual is the two steps"""
+    import torch
+    import mi355q.quantize as Q
+    from mi355q import ops
+    dev = "cuda:0"
+    for align in ("blocks", "rows"):
+        cfg = _lin_cfg(6, mi355q_align=align)
+        torch.manual_seed(M + N)
+        lin = Q.get_quantized_cls("linear", cfg)(K, N, bias=True, config=cfg).to(dev)
+        x = torch.randn(3 if M % 3 == 0 else 1, M // (3 if M % 3 == 0 else 1), K, device=dev)
+        other = torch.randn_like(x) if after == "silu_mul" else None
+        res = torch.randn(*x.shape[:-1], N, device=dev)
+        with torch.no_grad():
+            pre = (lambda t: t) if after is None else ((lambda t: torch.relu(t)) if after == "relu" else (lambda t: torch.nn.functional.silu(t) * other))
+            lin(pre(x))                                         # first PTQ forward
+            want = res + (lin(x) if after is None else lin.forward_after(x, after, other))
+            calls, real = [], ops.bf16_gemm_tiled
+            ops.bf16_gemm_tiled = lambda *a, **k: (calls.append(k.get("residual") is not None), real(*a, **k))[1]
+            try:
+                got = lin.forward_residual(x, res) if after is None else lin.forward_after(x, after, other, residual=res)
+            finally:
+                ops.bf16_gemm_tiled = real
+        assert torch.equal(got, want)
+        assert calls == ([True] if align == "blocks" else []), (align, calls)

@@ -22,7 +22,7 @@ def quant_config(storage: str, knobs: bool = True):
              bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
     if knobs:
         d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
-                 mi355q_token_major_output=True)
+                 mi355q_token_major_output=True, mi355q_fused_residual=True)
     if storage == "packed":
         d.update(mi355q_weight_storage="packed")
     # the rotary tables of every shipped TOML: 8-bit fixed point (configs/quantization/bfp_6bit.toml)

@@ -23,7 +23,7 @@ def quant_config(layers: int, knobs: bool, mx="auto"):
     d["mi355q_mx"] = {"auto": "auto", "off": False, "on": True}[mx]      # (W4A4 on the MX scaled MFMA: DESIGN 5c)
     if knobs:
         d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
-                 mi355q_token_major_output=True)
+                 mi355q_token_major_output=True, mi355q_fused_residual=True)
     cfg = {"default": d}
     # mixed precision: every third layer keeps its attention projections at 6 / 5 bits, every fourth its fc2 at 3-bit weights
     for i in range(layers):
