@@ -1181,5 +1181,10 @@ def test_linear_with_the_residual_add_in_its_stores(M, K, N, after):
                 got = lin.forward_residual(x, res) if after is None else lin.forward_after(x, after, other, residual=res)
             finally:
                 ops.bf16_gemm_tiled = real
-        assert torch.equal(got, want)
+        if align == "blocks":
+            assert torch.equal(got, want)
+        else:
+            # (post-ReLU inputs forced onto the row-scale route overflow their exception buckets: the launch's blockwise fallback adds
+            #  back with fp32 atomics whose order is not fixed -- DESIGN 2 "Reproducibility" -- so two launches agree to the last bits only)
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
         assert calls == ([True] if align == "blocks" else []), (align, calls)
