@@ -38,7 +38,8 @@
  *     not, with or without exception lists, the bf16 flavour too, with K % 128 == 0 and >= 4 K-steps per slice takes
  *     mi355q_gemm_v9.hip; MI355Q_V9_FIX=0 sends the launches with lists back to v8; MI355Q_V10=1|2|3 (+ MI355Q_V10_NS) pins a
  *     geometry of the small-tile kernel (mi355q_gemm_v10.hip), MI355Q_V10_AUTO=0 keeps launches off it; MI355Q_V8_TILE_ROWS,
- *     MI355Q_V8_SPLITS pin the tile GEMM's tile height / split-K (tests do); MI355Q_MATMUL_TILE=0 sends the plain attention
+ *     MI355Q_V8_SPLITS pin the tile GEMM's tile height / split-K (tests do); MI355Q_MATMUL_RW=1|2 the row groups
+ *     per wave of the short-contraction tile product; MI355Q_MATMUL_TILE=0 sends the plain attention
  *     products back to kernel 2 of mi355q_matmul.hip; MI355Q_V8_STAMPS / MI355Q_V8_CLOCK / MI355Q_V9_STAMPS / MI355Q_V9_DBG /
  *     MI355Q_MATMUL_DBG are the phase-stamp diagnostics behind DESIGN.md section 5.  (Round 5 removed MI355Q_V8_SCHED,
  *     MI355Q_V8_SMALL_SCHED, MI355Q_V8_DBG, MI355Q_V9_GROUPS, MI355Q_QROWS_GRID, MI355Q_QV_PIECES, MI355Q_FIXUP_GRID, MI355Q_CORR.)

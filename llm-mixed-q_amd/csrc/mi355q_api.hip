@@ -842,7 +842,7 @@ int mi355q_block_minifloat_softmax_matmul(const float* scores, const float* mask
 
 size_t mi355q_block_log_matmul_workspace_bytes(int64_t B, int64_t K, int64_t N) {
     if (B <= 0 || K <= 0 || N <= 0) return 0;
-    return 3 * (size_t)B * (size_t)((K + 63) / 64 * 64) * (size_t)N * 2 + 64;      // three bf16 planes of y + the statistics word
+    return 3 * (size_t)B * (size_t)((K + 63) / 64 * 64) * (size_t)N * 2 + 4096 + 64;      // three bf16 planes of y + the statistics slots (BL_STATS_SLOTS words)
 }
 
 int mi355q_block_log_matmul(const float* x, const float* y, float* out, void* workspace, int64_t B, int64_t M, int64_t K,

@@ -366,6 +366,26 @@ __device__ __forceinline__ void mask_scores(XBlk& s, const float* __restrict__ m
     }
 }
 
+// block_log's statistics over x (bl_block_stats_kernel below): BL_STATS_SLOTS words, one per workgroup of that pass -- the smallest
+// non-zero [1,16]-block maximum it saw, as its bit pattern, all ones if none.  The product kernels take the minimum themselves (4 KiB
+// from the L2 per workgroup): no atomics on one word, no memset launch in front, and the pass can run ahead of the y pack.
+constexpr int BL_STATS_SLOTS = 1024;
+template <int NTHREADS>
+__device__ __forceinline__ float bl_zero_fill(const unsigned* __restrict__ stats) {
+    __shared__ unsigned part[NTHREADS / 64];
+    unsigned best = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < BL_STATS_SLOTS; i += NTHREADS) best = min(best, stats[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+    __syncthreads();
+    best = part[0];
+#pragma unroll
+    for (int w = 1; w < NTHREADS / 64; ++w) best = min(best, part[w]);
+    const unsigned u = __builtin_amdgcn_readfirstlane(best);
+    return u == 0xFFFFFFFFu ? 1.0f : __uint_as_float(u);       // (every block zero: the reference's fill is 1)
+}
+
 // FMT: x's block format (block_fp, block_minifloat, block_log); PLANES: bf16 planes of y (3 for block_log's raw y, else 1)
 template <bool RESIDENT, int NT, bool SOFTMAX = false, int FMT = FMT_BFP, int PLANES = 1>
 __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, const float* __restrict__ x,
@@ -378,10 +398,7 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
     __shared__ float stat[4][16];
     load_lut<FMT>(lut);
     float zfill = 1.0f;                                   // (block_log: the fill of all-zero blocks, bl_block_stats_kernel)
-    if (FMT == FMT_BL) {
-        const unsigned u = __builtin_amdgcn_readfirstlane(xstats[0]);
-        zfill = u == 0xFFFFFFFFu ? 1.0f : __uint_as_float(u);
-    }
+    if (FMT == FMT_BL) zfill = bl_zero_fill<256>(xstats);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const long long b = blockIdx.y, m0 = (long long)blockIdx.x * 16;
@@ -570,8 +587,8 @@ constexpr int TP_WAVES = 8;
 #define MM_GLDS16(gp, lds) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds) : "memory")
 #define MM_WAITV(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <bool STREAM, int NTNS, int FMT, int PLANES>
-__global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(const QuantArgs a, const float* __restrict__ x,
+template <bool STREAM, int NTNS, int FMT, int PLANES, int RW = 1, int CW = TP_WAVES>
+__global__ __launch_bounds__((CW + 1) * 64) void bfp_qmatmul_tile_kernel(const QuantArgs a, const float* __restrict__ x,
                                                                          const uint16_t* __restrict__ yt, float* __restrict__ out,
                                                                          long long M, long long K, long long Kp, long long N,
                                                                          long long plane_stride, const unsigned* __restrict__ xstats,
@@ -579,27 +596,32 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
     constexpr int NT = STREAM ? NTNS : 4;                 // column tiles of a piece
     constexpr int NS = STREAM ? 1 : NTNS;                 // 64-steps of a piece
     constexpr int SUB = NT * NS * 2;                      // 1-KiB sub-pieces of a piece
-    constexpr int BW = STREAM ? SUB / TP_WAVES : SUB;     // DMA instructions per issuing wave and piece
-    static_assert(SUB % TP_WAVES == 0, "a piece is shared evenly by the waves");
-    constexpr int DB = STREAM ? 3 : 2;                    // ring depth in pieces (RESIDENT: two -- with the patches two workgroups still
-                                                          // share a compute unit's LDS up to 128 columns of x)
+    constexpr int BW = STREAM ? SUB / CW : SUB;     // DMA instructions per issuing wave and piece
+    static_assert(!STREAM || SUB % CW == 0, "a piece is shared evenly by the waves");
+    constexpr int DB = STREAM ? 3 : (RW == 1 ? 2 : (CW == 4 ? 3 : 4));   // ring depth in pieces (RESIDENT: two -- with the patches two
+                                                          // workgroups still share a compute unit's LDS up to 128 columns of x; two row
+                                                          // groups a wave: the compute unit's one or two workgroups take a deeper ring --
+                                                          // with one piece in flight the waves spent 60 % of a piece at its barrier)
     constexpr int XD = FMT == FMT_BFP ? 3 : 2;            // STREAM: x slabs in rotation, XD - 1 steps ahead (the other formats' element
                                                           // functions leave no registers for a third)
     constexpr int PIECE = SUB * 1024;
+    // RW (RESIDENT): 16-row groups of x per compute wave.  Two: every yt fragment read from LDS feeds two MFMAs and a workgroup's
+    // pass over yt[b] serves 256 rows -- with one group a piece's fragment reads (8 waves x the whole piece) take twice the LDS
+    // time of the MFMAs they feed, three planes three times that (round 5)
+    // CW: compute waves of a workgroup (RESIDENT with RW = 2 and three planes: four, so that two workgroups share a compute unit
+    // and one's MFMAs run under the other's output stores)
+    static_assert(RW == 1 || !STREAM, "the streamed form keeps one row group per wave");
+    static_assert(CW == TP_WAVES || !STREAM, "the streamed form shares its pieces among eight waves");
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) unsigned char bring[DB * PIECE];
-    __shared__ __attribute__((aligned(16))) unsigned char xring[TP_WAVES * 4096];     // the waves' transpose patches (STREAM: x in, RESIDENT: out)
+    __shared__ __attribute__((aligned(16))) unsigned char xring[CW * 4096];     // the waves' transpose patches (STREAM: x in, RESIDENT: out)
     load_lut<FMT>(lut);
     float zfill = 1.0f;
-    if (FMT == FMT_BL) {
-        const unsigned u = __builtin_amdgcn_readfirstlane(xstats[0]);
-        zfill = u == 0xFFFFFFFFu ? 1.0f : __uint_as_float(u);
-    }
+    if (FMT == FMT_BL) zfill = bl_zero_fill<(CW + 1) * 64>(xstats);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
-    const long long b = blockIdx.y, m0 = ((long long)blockIdx.x * TP_WAVES + min(wave, TP_WAVES - 1)) * 16;
+    const long long b = blockIdx.y, m0 = ((long long)blockIdx.x * CW + min(wave, CW - 1)) * 16 * RW;
     const long long mrow = min(m0 + (lane & 15), M - 1);                 // (rows past M: the last row again)
-    const float* __restrict__ row = x + (b * M + mrow) * K;
     const uint16_t* __restrict__ ytb = yt + b * (N >> 4) * Kp * 1024;
     float* __restrict__ orow = out + (b * M + mrow) * N + 4 * g;
     const int mbits = (int)__builtin_log2f(a.shift);
@@ -608,7 +630,7 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
     const unsigned bring0 = (unsigned)(size_t)(lptr_t)bring;       // (the object's own LDS address)
 
     if (STREAM) {
-        if (wave == TP_WAVES) {
+        if (wave == CW) {
             // the feeder of the yt ring: plain loads into registers, ds_write into the slot.  (LDS-DMA moves ~22 bytes a clock
             // and compute unit -- measured: 805 MB of DMA, x and yt, took 70 us with every byte in cache -- so the DMA path is
             // left to the x slabs, which have no other way into LDS without passing the consumers' registers.)
@@ -732,7 +754,7 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // (the group's last reads of the ring are through)
-            if (stamps && lane == 0 && (wave == 0 || wave == TP_WAVES - 1)) {      // diagnostic: cycles in the loop, waiting for loads, at barriers
+            if (stamps && lane == 0 && (wave == 0 || wave == CW - 1)) {      // diagnostic: cycles in the loop, waiting for loads, at barriers
                 unsigned long long* d = stamps + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 4;
                 d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_wait; d[2] = t_bar; d[3] = nsteps;
             }
@@ -741,7 +763,7 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
     }
     // RESIDENT: wave 8 feeds the ring, waves 0..7 quantise their 16 rows once and take the pieces as they land
     const int nchunks = (ntiles + 3) >> 2, niter = nchunks * PLANES;
-    if (wave == TP_WAVES) {
+    if (wave == CW) {
         auto issue = [&](int j) {
             int itp = j + DB - 1;
             itp = itp < 0 ? 0 : (itp > niter - 1 ? niter - 1 : itp);
@@ -764,22 +786,28 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
         MM_WAITV(0);
         return;
     }
-    bf16x8 res[NS][2];
+    bf16x8 res[RW][NS][2];
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        f32x4 xv[4];
-        const long long kk = st * 64 + 16 * g;              // lane (r, g): block g of the step, whole
+    for (int rg = 0; rg < RW; ++rg) {
+        const float* __restrict__ rowg = x + (b * M + min(m0 + 16 * rg + (lane & 15), M - 1)) * K;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(row + (kk < K ? kk : 0) + 4 * j);
-        if (kk >= K) {
+        for (int st = 0; st < NS; ++st) {
+            f32x4 xv[4];
+            const long long kk = st * 64 + 16 * g;          // lane (r, g): block g of the step, whole
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(rowg + (kk < K ? kk : 0) + 4 * j);
+            if (kk >= K) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            quantise_lane<FMT>(xv, a, lut, mbits, zfill, res[rg][st]);
         }
-        quantise_lane<FMT>(xv, a, lut, mbits, zfill, res[st]);
     }
-    f32x4 acc[4];
+    f32x4 acc[RW][4];
     unsigned char* opatch = xring + wave * 4096;
-    char* obase = reinterpret_cast<char*>(out + (b * M + min(m0, M - 1)) * N);      // (scalar base + constant 32-bit lane offsets)
+    char* obase[RW];                                        // (scalar bases + constant 32-bit lane offsets)
+#pragma unroll
+    for (int rg = 0; rg < RW; ++rg) obase[rg] = reinterpret_cast<char*>(out + (b * M + min(m0 + 16 * rg, M - 1)) * N);
     unsigned ooff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) ooff[j] = (unsigned)(((long long)(4 * j + g) * N + 4 * ((lane & 15) ^ (4 * j + g))) * 4);
@@ -796,7 +824,9 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
             asm volatile("" ::: "memory");
             if (pl == 0) {
 #pragma unroll
-                for (int tile = 0; tile < 4; ++tile) acc[tile] = f32x4{0, 0, 0, 0};
+                for (int rg = 0; rg < RW; ++rg)
+#pragma unroll
+                    for (int tile = 0; tile < 4; ++tile) acc[rg][tile] = f32x4{0, 0, 0, 0};
             }
             const unsigned char* bs = bring + (it % DB) * PIECE + lane * 16;
 #pragma unroll
@@ -804,28 +834,34 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
 #pragma unroll
                 for (int st = 0; st < NS; ++st)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + ((tile * NS + st) * 2 + t) * 1024)), res[st][t], acc[tile], 0, 0, 0);
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16x8 bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + ((tile * NS + st) * 2 + t) * 1024));
+#pragma unroll
+                        for (int rg = 0; rg < RW; ++rg) acc[rg][tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, res[rg][st][t], acc[rg][tile], 0, 0, 0);
+                    }
             if (pl == PLANES - 1) {
                 // The chunk's 16 x 64 outputs through the wave's 4-KiB patch of LDS, so that a store instruction writes four
                 // rows x 256 contiguous bytes instead of sixteen rows x 64 (the MFMA layout): whole cache lines per request.
                 // Chunks of 16 bytes XOR (row & 15): no bank twice either way.  (Non-temporal stores: no difference.)
+                // (row groups one after the other through the same patch: a wave's LDS operations complete in order)
                 const int r = lane & 15;
 #pragma unroll
-                for (int tile = 0; tile < 4; ++tile)
-                    *reinterpret_cast<f32x4*>(opatch + r * 256 + (((tile * 4 + g) ^ r) << 4)) = acc[tile];
+                for (int rg = 0; rg < RW; ++rg) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rw = 4 * j + g, ch = (lane & 15) ^ rw;              // this lane's row and (logical) chunk of it
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(opatch + rw * 256 + ((lane & 15) << 4));
-                    if (m0 + rw < M && c * 4 + (ch >> 2) < ntiles)
-                        *reinterpret_cast<f32x4*>(obase + ooff[j] + (unsigned)c * 256u) = v4;
+                    for (int tile = 0; tile < 4; ++tile)
+                        *reinterpret_cast<f32x4*>(opatch + r * 256 + (((tile * 4 + g) ^ r) << 4)) = acc[rg][tile];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rw = 4 * j + g, ch = (lane & 15) ^ rw;          // this lane's row and (logical) chunk of it
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(opatch + rw * 256 + ((lane & 15) << 4));
+                        if (m0 + 16 * rg + rw < M && c * 4 + (ch >> 2) < ntiles)
+                            *reinterpret_cast<f32x4*>(obase[rg] + ooff[j] + (unsigned)c * 256u) = v4;
+                    }
                 }
             }
         }
     }
-    if (stamps && lane == 0 && (wave == 0 || wave == TP_WAVES - 1)) {
+    if (stamps && lane == 0 && (wave == 0 || wave == CW - 1)) {
         unsigned long long* d = stamps + ((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave != 0)) * 4;
         d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = 0; d[2] = t_bar; d[3] = niter;
     }
@@ -833,6 +869,7 @@ __global__ __launch_bounds__((TP_WAVES + 1) * 64) void bfp_qmatmul_tile_kernel(c
 
 // block_log's statistics pass over x: the smallest non-zero [1,16]-block maximum of the whole tensor (as its bit pattern:
 // positive floats order like unsigned integers), the fill the reference gives all-zero blocks (block_fp.py:54-58).
+// Launched with BL_STATS_SLOTS workgroups, one slot each (bl_zero_fill).
 __global__ __launch_bounds__(256) void bl_block_stats_kernel(const float4* __restrict__ x4, long long n4, unsigned* __restrict__ stats) {
     __shared__ unsigned part[4];
     unsigned best = 0xFFFFFFFFu;
@@ -845,13 +882,7 @@ __global__ __launch_bounds__(256) void bl_block_stats_kernel(const float4* __res
     for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
     __syncthreads();
-    // one atomic per workgroup, and only where it can lower the word (atomics on ONE word are served one after the other:
-    // 16 k of them -- one per wave of a 4096-workgroup grid -- took 200 us)
-    if (threadIdx.x == 0) {
-        best = min(min(part[0], part[1]), min(part[2], part[3]));
-        if (best < __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            __hip_atomic_fetch_min(stats, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) stats[blockIdx.x] = min(min(part[0], part[1]), min(part[2], part[3]));      // (this workgroup's slot)
 }
 
 static bool tile_route() {
@@ -869,15 +900,22 @@ static int launch_qmatmul_fmt(const QuantArgs& ax, const float* x, const uint16_
     static const bool pack_only = []() { const char* e = getenv("MI355Q_MATMUL_DBG"); return e && e[0] == '1'; }();
     if (pack_only) return 0;
     if (!softmax && tile_route()) {
-        dim3 g3((unsigned)((M + TP_WAVES * 16 - 1) / (TP_WAVES * 16)), (unsigned)B);
-#define MI355Q_TP_LAUNCH(STREAM_, NTNS_)                                                                                   \
-        hipLaunchKernelGGL((bfp_qmatmul_tile_kernel<STREAM_, NTNS_, FMT, PLANES>), g3, (TP_WAVES + 1) * 64, 0, st, ax, x, yt, out, M, K, \
+        // (short contraction: two row groups per wave -- see RW)
+        static const int rw_env = []() { const char* e = getenv("MI355Q_MATMUL_RW"); return e ? atoi(e) : 0; }();
+        const int rw = Kp <= 3 ? (rw_env ? rw_env : (PLANES > 1 ? 2 : 1)) : 1;
+        const int rows = TP_WAVES * 16 * rw;
+        dim3 g3((unsigned)((M + rows - 1) / rows), (unsigned)B);
+#define MI355Q_TP_LAUNCH(STREAM_, NTNS_, RW_)                                                                              \
+        hipLaunchKernelGGL((bfp_qmatmul_tile_kernel<STREAM_, NTNS_, FMT, PLANES, RW_>), g3, (TP_WAVES + 1) * 64, 0, st, ax, x, yt, out, M, K, \
                            Kp, N, plane_stride, xstats, g_tp_stamps)
-        if (Kp == 1) MI355Q_TP_LAUNCH(false, 1);
-        else if (Kp == 2) MI355Q_TP_LAUNCH(false, 2);
-        else if (Kp == 3) MI355Q_TP_LAUNCH(false, 3);
-        else if (N <= 64) MI355Q_TP_LAUNCH(true, 4);
-        else MI355Q_TP_LAUNCH(true, 8);
+        if (Kp == 1 && rw == 2) MI355Q_TP_LAUNCH(false, 1, 2);
+        else if (Kp == 2 && rw == 2) MI355Q_TP_LAUNCH(false, 2, 2);
+        else if (Kp == 3 && rw == 2) MI355Q_TP_LAUNCH(false, 3, 2);
+        else if (Kp == 1) MI355Q_TP_LAUNCH(false, 1, 1);
+        else if (Kp == 2) MI355Q_TP_LAUNCH(false, 2, 1);
+        else if (Kp == 3) MI355Q_TP_LAUNCH(false, 3, 1);
+        else if (N <= 64) MI355Q_TP_LAUNCH(true, 4, 1);
+        else MI355Q_TP_LAUNCH(true, 8, 1);
 #undef MI355Q_TP_LAUNCH
         return (int)hipGetLastError();
     }
@@ -909,7 +947,7 @@ static int launch_qmatmul_fmt(const QuantArgs& ax, const float* x, const uint16_
 }
 
 // fmt: 0 block_fp, 1 block_minifloat (x and y), 2 block_log (x; y raw, as three exact bf16 planes).  `yt`: the workspace of
-// mi355q_bfp_matmul_workspace_bytes (block_log: mi355q_block_log_matmul_workspace_bytes: three planes + the statistics word).
+// mi355q_bfp_matmul_workspace_bytes (block_log: mi355q_block_log_matmul_workspace_bytes: three planes + the statistics slots).
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
                        long long B, long long M, long long K, long long N, hipStream_t st, bool softmax, const float* mask,
                        long long causal_off, int fmt) {
@@ -920,6 +958,7 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
     const long long plane = B * Kp * 64 * N;               // elements of one plane
     uint16_t* ytp = static_cast<uint16_t*>(yt);
     hipError_t e;
+    unsigned* stats = fmt == FMT_BL ? reinterpret_cast<unsigned*>(ytp + 3 * plane) : nullptr;      // (block_log: BL_STATS_SLOTS words behind the three planes)
     const bool lane_order = !softmax && tile_route();       // which product kernel follows: its K order inside a 64-step
 #define MI355Q_PACK(FMT_)                                                                                                  \
     if (lane_order) hipLaunchKernelGGL((bfp_quant_pack_t_kernel<FMT_, true>), g1, 256, 0, st, ay, y, ytp, K, Kp, N, plane);   \
@@ -935,11 +974,7 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
         return launch_qmatmul_fmt<FMT_BM, 1>(ax, x, ytp, out, B, M, K, Kp, N, st, softmax, mask, causal_off, plane, nullptr);
     }
     if (fmt != FMT_BL) return MI355Q_E_BADARG;
-    unsigned* stats = reinterpret_cast<unsigned*>(ytp + 3 * plane);
-    if ((e = hipMemsetAsync(stats, 0xFF, 4, st)) != hipSuccess) return (int)e;
-    const long long n4 = B * M * K / 4;
-    const unsigned gs = (unsigned)std::min<long long>((n4 + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(bl_block_stats_kernel, dim3(gs), 256, 0, st, reinterpret_cast<const float4*>(x), n4, stats);
+    hipLaunchKernelGGL(bl_block_stats_kernel, dim3(BL_STATS_SLOTS), 256, 0, st, reinterpret_cast<const float4*>(x), B * M * K / 4, stats);
     MI355Q_PACK(FMT_RAW);
 #undef MI355Q_PACK
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
