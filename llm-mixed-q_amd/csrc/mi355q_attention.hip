@@ -227,7 +227,11 @@ struct AttnArgs {
     long long qsb, qsm;       // element strides of q's batch (head) and row
     long long osb, osm;       // ... of out's
     unsigned long long* stamps;   // diagnostic (-DATTN_STAMPS builds, tools/dbg/attn_stamps.py): [workgroup][8] realtime words
+    int nxb, nb;              // query blocks (of a workgroup's queries) per head, heads: the work items of a launch
 };
+#ifndef ATTN_EARLY_EXIT
+#define ATTN_EARLY_EXIT 1
+#endif
 #ifdef ATTN_STAMPS
 #define ATTN_STAMP(k) ast_[k] = __builtin_amdgcn_s_memrealtime()
 #else
@@ -254,8 +258,13 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     float (&stat)[KW][16] = stat_[grp];
     f32x4 (&red)[KW][DT][64] = red_[grp];
     const int c16 = lane & 15, lg = lane >> 4;
-    // (causal: the query blocks with the most visible keys first -- the launch then ends on its cheapest workgroups)
-    const long long b = blockIdx.y, m0 = ((long long)(g.causal_off >= 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * QG + grp) * 16;
+    // Work items = (query block, head) in ONE grid dimension, sorted by visible keys: causal launches start the last query block of
+    // EVERY head first and end on the first blocks (round 5; before, the order was heavy to light within a head, head after head:
+    // the chip was never short of heavy blocks to end on -- [32, 1024, 128] 87 -> 68 us, [32, 2048, 128] 215 -> 204).
+    // (The same list walked by a chip-filling persistent launch in a snake was measured too: 201 us -- and 40 more registers for
+    //  the item loop, which cost the 8-key-wave variant its occupancy: not kept.)
+    const int item = (int)blockIdx.x, xrank = item / g.nb;
+    const long long b = item - xrank * g.nb, m0 = ((long long)(g.causal_off >= 0 ? g.nxb - 1 - xrank : xrank) * QG + grp) * 16;
     const long long qrow = min(m0 + c16, g.M - 1);
 
     // Q fragments: lane (query c16, g) holds d = 32 c + 8 g .. + 7; a [1,16] block = the lanes g, g ^ 1 of a chunk
@@ -320,6 +329,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     load_group(0, kb[0], mb[0]);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
+        if (ATTN_EARLY_EXIT && gi > 0 && KW * gi * G >= need) break;      // (uniform: every tile from here on lies behind the horizon)
         if (gi + 1 < NG) load_group(gi + 1, kb[(gi + 1) & 1], mb[(gi + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -403,6 +413,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     load_pair(0, vb[0]);
 #pragma unroll
     for (int s = 0; s < NTW / 2; ++s) {
+        if (ATTN_EARLY_EXIT && s > 0 && KW * 2 * s >= need) break;        // (uniform)
         if (s + 1 < NTW / 2) load_pair(s + 1, vb[(s + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         if (KW * (2 * s) + wave < need) {                  // (uniform; tiles are needed in order)
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
 #ifdef ATTN_STAMPS
     ATTN_STAMP(7);
     if (g.stamps && lane == 0 && wave_all == 0) {
-        unsigned long long* d = g.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        unsigned long long* d = g.stamps + (long long)item * 8;
         for (int k = 0; k < 8; ++k) d[k] = ast_[k];
     }
 #endif
@@ -474,8 +485,10 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
     load_lut<FMT_BFP, true>(lut);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, lg = lane >> 4;
-    const long long b = blockIdx.y;
-    const long long wg0 = (long long)(g.causal_off >= 0 ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 64;   // heavy blocks first
+    // (work items (query block, head) in one grid dimension, the heaviest query block of every head first: see the resident kernel)
+    const int xrank = (int)blockIdx.x / g.nb;
+    const long long b = (int)blockIdx.x - xrank * g.nb;
+    const long long wg0 = (long long)(g.causal_off >= 0 ? g.nxb - 1 - xrank : xrank) * 64;
     const long long m0 = wg0 + 16 * wave;
     const long long qrow = min(m0 + c16, g.M - 1);
     bf16x8 qf[DC];
@@ -672,9 +685,11 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                        (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps};
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0};
     if (stream) {
-        const dim3 sgrid((unsigned)((M + 63) / 64), (unsigned)B);
+        g.nxb = (int)((M + 63) / 64);
+        g.nb = (int)B;
+        const dim3 sgrid((unsigned)((long long)g.nxb * B));
 #define MI355Q_ATTN_S(DC_)                                                                                          \
     if (mask) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, true>), sgrid, 256, 0, st, aq, ap, g);           \
     else hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, false>), sgrid, 256, 0, st, aq, ap, g)
@@ -687,24 +702,28 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
 #undef MI355Q_ATTN_S
         return (int)hipGetLastError();
     }
+    // the resident kernel's launch: one workgroup per work item (query block, head), heaviest items first (see the kernel)
+    g.nb = (int)B;
+#define MI355Q_ATTN_GO(QPB_, ...)                                                                                         \
+    {                                                                                                                     \
+        g.nxb = (int)((M + (QPB_) - 1) / (QPB_));                                                                         \
+        hipLaunchKernelGGL((bfp_attention_kernel<__VA_ARGS__>), dim3((unsigned)((long long)g.nxb * B)), 512, 0, st, aq, ap, g); \
+    }
     if (kw8) {
-        const dim3 grid8((unsigned)((M + 15) / 16), (unsigned)B);
-        const int ntw8 = T <= 1024 ? 8 : 16;
 #define MI355Q_ATTN8(NTW_, DC_)                                                                                  \
-    if (mask) hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 1, true, 8>), grid8, 512, 0, st, aq, ap, g);   \
-    else hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 1, false, 8>), grid8, 512, 0, st, aq, ap, g)
+    if (mask) MI355Q_ATTN_GO(16, NTW_, DC_, 1, true, 8)                                                          \
+    else MI355Q_ATTN_GO(16, NTW_, DC_, 1, false, 8)
+        const int ntw8 = T <= 1024 ? 8 : 16;
         if (ntw8 == 8) { if (D == 32) { MI355Q_ATTN8(8, 1); } else { MI355Q_ATTN8(8, 2); } }
         else { if (D == 32) { MI355Q_ATTN8(16, 1); } else { MI355Q_ATTN8(16, 2); } }
 #undef MI355Q_ATTN8
         return (int)hipGetLastError();
     }
     // two 16-query groups per workgroup (measured at T = 2048: 70 vs 101 us at 12 heads x 64, 235 vs 342 us at 32 x 128)
-    const int qg = 2;
-    const dim3 grid((unsigned)(((M + 15) / 16 + qg - 1) / qg), (unsigned)B);
     const int ntw = T <= 512 ? 8 : (T <= 1024 ? 16 : 32);
 #define MI355Q_ATTN(NTW_, DC_)                                                                                \
-    if (mask) hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 2, true>), grid, 512, 0, st, aq, ap, g);    \
-    else hipLaunchKernelGGL((bfp_attention_kernel<NTW_, DC_, 2, false>), grid, 512, 0, st, aq, ap, g)
+    if (mask) MI355Q_ATTN_GO(32, NTW_, DC_, 2, true)                                                          \
+    else MI355Q_ATTN_GO(32, NTW_, DC_, 2, false)
 #define MI355Q_ATTN_D(NTW_)                                     \
     switch (D / 32) {                                          \
         case 1: MI355Q_ATTN(NTW_, 1); break;                   \
@@ -717,6 +736,7 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     else { MI355Q_ATTN_D(32) }
 #undef MI355Q_ATTN_D
 #undef MI355Q_ATTN
+#undef MI355Q_ATTN_GO
     return (int)hipGetLastError();
 }
 

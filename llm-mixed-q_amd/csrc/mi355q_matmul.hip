@@ -401,7 +401,11 @@ __global__ __launch_bounds__(256) void bfp_qmatmul_kernel(const QuantArgs a, con
     if (FMT == FMT_BL) zfill = bl_zero_fill<256>(xstats);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
-    const long long b = blockIdx.y, m0 = (long long)blockIdx.x * 16;
+    // (causal softmax: the grid is (heads, row blocks) and the row blocks run from the last one down -- the row blocks with the most
+    //  visible keys of EVERY head are dispatched first and the launch ends on its cheapest workgroups; round 5, see mi355q_attention.hip)
+    const bool heavy_first = SOFTMAX && causal_off >= 0;
+    const long long b = heavy_first ? blockIdx.x : blockIdx.y;
+    const long long m0 = (heavy_first ? (long long)(gridDim.y - 1 - blockIdx.y) : (long long)blockIdx.x) * 16;
     const long long mrow = min(m0 + (lane & 15), M - 1);                 // (rows past M: loaded again, never stored)
     const float* __restrict__ row = x + (b * M + mrow) * K;
     const uint16_t* __restrict__ ytb = yt + b * (N >> 4) * Kp * 1024;   // (Kp = 64-steps per row of tiles)
@@ -920,6 +924,7 @@ static int launch_qmatmul_fmt(const QuantArgs& ax, const float* x, const uint16_
         return (int)hipGetLastError();
     }
     dim3 g2((unsigned)((M + 15) / 16), (unsigned)B);
+    if (softmax && causal_off >= 0) g2 = dim3((unsigned)B, (unsigned)((M + 15) / 16));      // (see the kernel: heavy_first)
 #define MI355Q_MM_LAUNCH(...)                                                                                              \
     hipLaunchKernelGGL((bfp_qmatmul_kernel<__VA_ARGS__, FMT, PLANES>), g2, 256, 0, st, ax, x, yt, out, M, K, Kp, N, mask,   \
                        causal_off, plane_stride, xstats)
