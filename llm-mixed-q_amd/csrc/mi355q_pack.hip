@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void bfp_expand_kernel(const uint16_t* __restr
             }
         }
         const int code = codes[blk];
-        if (MODE == 0 && exp_out) exp_out[blk] = rowexp[row];          // (the aligned operand's per-block exponent: its row's)
+        // (the aligned operand's per-block exponents: its row's -- the four blocks of this row and piece as one dword by the first
+        //  of their four lanes; K % 64 == 0, so blk is a multiple of four there)
+        if (MODE == 0 && exp_out && c == 0) *reinterpret_cast<unsigned*>(exp_out + blk) = 0x01010101u * rowexp[row];
         if (MODE == 0) {
             if (code != 0xFF) {
                 unsigned wds[4];

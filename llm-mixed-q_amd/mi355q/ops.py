@@ -344,7 +344,8 @@ def _expand_scratch(device, nbytes, tag):
 class PackedWeights:
     """A weight operand at rest: width-bit mantissas + one code byte per block (width + 0.5 bits per value) and the few
     per-row words of its flavour; `expand()` streams it into a scratch operand shared by every layer on the stream
-    (consume it -- run the GEMM -- before the next layer expands)."""
+    (consume it -- run the GEMM -- before the next layer expands into the same `slot`; the members of a grouped launch take
+    slots 0, 1, 2)."""
 
     def __init__(self, packed, codes, rows, K, width, exp_bias, *, rowflag=None, rowscale=None, rowexp=None, sparse=None):
         self.packed, self.codes = packed, codes
@@ -358,13 +359,13 @@ class PackedWeights:
             n += 0 if t is None else t.numel() * t.element_size()
         return 8.0 * n / (self.rows * self.K)
 
-    def expand(self):
+    def expand(self, slot: int = 0):
         lib = _lib.load_library()
         dev = self.packed.device
         off = self.exp_bias + self.width - 1
         if self.row_scale_flavour:                      # int8 row-scale operand
-            tiled = _expand_scratch(dev, lib.mi355q_bfp_tiled_bytes(self.rows, self.K), "i8")
-            exp = _expand_scratch(dev, self.rows * (self.K // 16), "exp").view(torch.uint8)
+            tiled = _expand_scratch(dev, lib.mi355q_bfp_tiled_bytes(self.rows, self.K), f"i8{slot or ''}")
+            exp = _expand_scratch(dev, self.rows * (self.K // 16), f"exp{slot or ''}").view(torch.uint8)
             with _on_device(dev):
                 rc = lib.mi355q_bfp_expand(_ptr(self.packed), _ptr(self.codes), _ptr(tiled), self.rows, self.K, self.width, 0, off,
                                            _ptr(self.rowexp), _ptr(exp), _stream_ptr(dev))

@@ -783,7 +783,8 @@ def grouped_linear(x, layers, norm=None):
     if ok:
         plan = first._int8_plan(x)
         ok = plan is not None and (norm is None or (x.is_cuda and x.dtype == torch.float32)) and all(
-            l._packed_is_current() and l._align_mode == "rows" and not l._uses_bf16_route() and l._w_packed is None
+            l._packed_is_current() and l._align_mode == "rows" and not l._uses_bf16_route()
+            and (l._w_packed is None or (l._w_packed.row_scale_flavour and l._pending_flavour is None))
             and l.in_features == first.in_features and l.out_features == first.out_features and l._x_cap == first._x_cap
             and l._x_cap == ops.ROW_BUCKET_CAP and l._int8_plan(x) == plan
             and all(l.config[k] == first.config[k] for k in ("data_in_width", "data_in_exponent_width", "data_in_exponent_bias"))
@@ -798,14 +799,17 @@ def grouped_linear(x, layers, norm=None):
                                                         ("rmsnorm", norm[0], norm[1]) if len(norm) == 2 else
                                                         ("layernorm", norm[0], norm[2], norm[1])))
             # one launch, or the split of the group that takes fewer rounds over the chip (ops.grouped_launch_plan)
+            # (width-bit storage: a launch's members expand into scratch slots 0 .. g - 1 first -- round 5; before, a packed layer
+            #  kept its group off this path: separate launches, the norm by six torch kernels)
             outs, at = [], 0
             for g in ops.grouped_launch_plan(x2.shape[0], first.out_features, len(layers)):
                 part = layers[at:at + g]
                 at += g
+                was = [l._w_packed.expand(i) if l._w_packed is not None else l._packed[0] for i, l in enumerate(part)]
                 if g == 1:
-                    ys = [ops.bfp_gemm_aligned(xa, part[0]._packed[0], part[0].bias)]
+                    ys = [ops.bfp_gemm_aligned(xa, was[0], part[0].bias)]
                 else:
-                    ys = ops.bfp_gemm_aligned_multi(xa, [l._packed[0] for l in part], [l.bias for l in part])
+                    ys = ops.bfp_gemm_aligned_multi(xa, was, [l.bias for l in part])
                 if ys is None:
                     outs = None
                     break
