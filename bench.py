@@ -437,8 +437,10 @@ def main():
         wa = ops.bfp_align_rows(wm, we, ww - 1, 127)
         bq = ops.block_fp_quantize(b, CFG["bias_width"], 8, 127, [16], False)
         n_out = w.shape[0]
-        y = torch.empty(M, n_out, dtype=torch.float32, device=device)
         gathered = torch.empty(world, M, n_out, dtype=torch.float32, device=device) if shard_w else None
+        # (sharded: the product is stored straight into this rank's segment of the gather buffer and the all-gather runs in place
+        #  -- sendbuff == recvbuff + rank * count: the collective moves the OTHER ranks' segments only, no local copy)
+        y = gathered[rank] if shard_w else torch.empty(M, n_out, dtype=torch.float32, device=device)
 
         def step():
             xa = quantize_x(x, xw, 8, 127)

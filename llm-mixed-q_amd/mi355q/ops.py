@@ -891,15 +891,17 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     return out
 
 
-def bfp_gemm_aligned_multi(x: AlignedOperand, ws, biases=None):
+def bfp_gemm_aligned_multi(x: AlignedOperand, ws, biases=None, outs=None):
     """[x . w^T + bias for w in ws] in ONE launch of the tile GEMM (equally shaped row-aligned weight operands: q / k / v,
-    gate / up); returns None when the library does not take the group (callers then use bfp_gemm_aligned per weight)."""
+    gate / up); returns None when the library does not take the group (callers then use bfp_gemm_aligned per weight).
+    `outs`: where to store the products (contiguous [M, N] fp32 each; None entries are allocated)."""
     import ctypes
     M, K, N = x.rows, x.K, ws[0].rows
     n = len(ws)
     if not (1 <= n <= 3) or any(w.K != K or w.rows != N for w in ws):
         return None
-    outs = [torch.empty(M, N, dtype=torch.float32, device=x.tiled.device) for _ in range(n)]
+    outs = [o if o is not None and o.shape == (M, N) and o.dtype == torch.float32 and o.is_contiguous()
+            else torch.empty(M, N, dtype=torch.float32, device=x.tiled.device) for o in (outs or [None] * n)]
     x.c_struct()
     for w in ws:
         w.c_struct()

@@ -689,6 +689,14 @@ class _LinearBase(nn.Linear):
                 return self._forward_int8(x, self._int8_plan(x), residual=residual)
         return residual + self(x)
 
+    def _take_out(self, rows):
+        """where the caller wants this call's product stored (sharded.RowShardedLinear: its rank's segment of the all-gather buffer,
+        so that the collective runs in place), once; None: a fresh tensor"""
+        out, self._out_hint = self.__dict__.get("_out_hint"), None
+        if out is not None and out.shape == (rows, self.out_features) and out.dtype == torch.float32 and out.is_contiguous():
+            return out
+        return None
+
     def _forward_int8(self, x, plan, pre=None, residual=None):
         x_mbits, w_mbits, xb, wb = plan
         c = self.config
@@ -705,7 +713,7 @@ class _LinearBase(nn.Linear):
             wt = self._bf16_weight_operand(x.device)
             xt = ops.block_fp_quantize_bf16_tiled(x2.contiguous(), c["data_in_width"], c["data_in_exponent_width"],
                                                   c["data_in_exponent_bias"], pre=pre)
-            y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias,
+            y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias, out=self._take_out(x2.shape[0]),
                                     residual=None if residual is None else residual.reshape(-1, self.out_features))
             return y.reshape(*x.shape[:-1], self.out_features)
         assert residual is None, "the residual add is fused on the per-block-exponent route only"
@@ -714,7 +722,7 @@ class _LinearBase(nn.Linear):
                                                 c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre,
                                                 segments=segments)
         wa = self._w_packed.expand() if self._w_packed is not None else self._packed[0]
-        y = ops.bfp_gemm_aligned(xa, wa, self.bias)
+        y = ops.bfp_gemm_aligned(xa, wa, self.bias, out=self._take_out(x2.shape[0]))
         if self.align == "auto" and self._x_cap != ops.ROW_NO_ALIGN:
             # results never depend on the mode (an overflowing exception bucket only sends the GEMM to its slow
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats
@@ -762,7 +770,13 @@ def grouped_linear(x, layers, norm=None):
     from ...sharded import RowShardedLinear
     if all(isinstance(l, RowShardedLinear) for l in layers):
         # row-sharded projections (sharded.shard_model): this rank's shards as one group, one all-gather per projection
-        ys = grouped_linear(x, [l.local for l in layers], norm=norm)
+        for l in layers:                                       # (each product straight into its rank's segment of its gather buffer)
+            l._aim_at_gather_buffer(x)
+        try:
+            ys = grouped_linear(x, [l.local for l in layers], norm=norm)
+        finally:
+            for l in layers:
+                l.local._out_hint = None
         if len(layers) == 2 and layers[0].gather == "quantised" and layers[0].consumer_pre == "silu_mul":
             # Llama's gate / up in front of down_proj (sharded.shard_model(gather="quantised")): both shards of a rank cover the
             # same columns, so silu(gate) * up and down_proj's quantiser run on the rank's own slice; ONE all-gather, of the
@@ -806,10 +820,11 @@ def grouped_linear(x, layers, norm=None):
                 part = layers[at:at + g]
                 at += g
                 was = [l._w_packed.expand(i) if l._w_packed is not None else l._packed[0] for i, l in enumerate(part)]
+                hints = [l._take_out(x2.shape[0]) for l in part]
                 if g == 1:
-                    ys = [ops.bfp_gemm_aligned(xa, was[0], part[0].bias)]
+                    ys = [ops.bfp_gemm_aligned(xa, was[0], part[0].bias, out=hints[0])]
                 else:
-                    ys = ops.bfp_gemm_aligned_multi(xa, was, [l.bias for l in part])
+                    ys = ops.bfp_gemm_aligned_multi(xa, was, [l.bias for l in part], outs=hints)
                 if ys is None:
                     outs = None
                     break
@@ -837,7 +852,8 @@ def grouped_linear(x, layers, norm=None):
                                                       pre=None if norm is None else ("rmsnorm", norm[0], norm[1]))
                 outs = []
                 for l in layers:           # (a packed layer's expand() shares one scratch operand: each product before the next expand)
-                    y = ops.bf16_gemm_tiled(xt, l._bf16_weight_operand(x.device), x2.shape[0], l.out_features, l.in_features, l.bias)
+                    y = ops.bf16_gemm_tiled(xt, l._bf16_weight_operand(x.device), x2.shape[0], l.out_features, l.in_features, l.bias,
+                                            out=l._take_out(x2.shape[0]))
                     outs.append(y.reshape(*x.shape[:-1], l.out_features))
             return outs
     h = x if norm is None else normed()
