@@ -511,8 +511,8 @@ def main():
 
             def step_q():
                 ops.bf16_gemm_tiled(segs if world > 1 else segs[0], wt_q, M, n_loc, K, None, out=y_q, segments=world)
-                mine = ops.block_fp_quantize_bf16_tiled(y_q, xw, 8, 127).reshape(-1)
-                dist.all_gather_into_tensor(segs.view(-1), mine)          # (the next link's operand: the chain feeds itself)
+                mine = ops.block_fp_quantize_bf16_tiled(y_q, xw, 8, 127, out=segs[rank])      # (straight into this rank's segment:
+                dist.all_gather_into_tensor(segs.view(-1), mine)          #  the collective in place; the chain feeds itself)
             dt_q = timed(torch, dist, world, device, step_q, args.steps, args.warmup)
             qgather = {"value": round(2.0 * M * N * K * args.steps / dt_q / 1e12, 2), "unit": "TFLOP/s", "scaling": "strong",
                        "ms_per_step": round(dt_q / args.steps * 1e3, 4), "gathered_MiB_per_rank": round(segs.numel() * (world - 1) / world / 2**20, 1),

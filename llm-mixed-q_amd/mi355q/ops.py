@@ -265,18 +265,27 @@ def _pre_args(x, pre):
     return code, None, 0.0, None
 
 
+def bfp_tiled_bytes(rows: int, row_bytes: int) -> int:
+    """bytes of a tiled operand of `rows` rows of `row_bytes` bytes each (mi355q_bfp_tiled_bytes: rows padded to whole tiles)"""
+    return int(_lib.load_library().mi355q_bfp_tiled_bytes(int(rows), int(row_bytes)))
+
+
 def block_fp_quantize_bf16_tiled(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, *, out_fake: torch.Tensor = None,
-                                 reuse: bool = True, pre=None) -> torch.Tensor:
+                                 reuse: bool = True, pre=None, out: torch.Tensor = None) -> torch.Tensor:
     """x [rows, K] fp32 ([1,16] blocks along K) -> bf16 in the tile order of `bf16_gemm_tiled` (a flat int8 buffer of
     mi355q_bfp_tiled_bytes(rows, 2 K) bytes).  `out_fake`: also write the fp32 fake-quantised values there (may be x
     itself).  `reuse`: the buffer is shared by calls with the same shape on the same stream (activations; consume it
-    before quantising again), else freshly allocated (weights)."""
+    before quantising again), else freshly allocated (weights).  `out`: the operand's bytes go there instead (a contiguous int8
+    tensor of exactly that many bytes: a rank's segment of an all-gather buffer, sharded.py)."""
     _require_device(x, "block_fp_quantize_bf16_tiled")
     assert x.ndim == 2 and x.shape[1] % 32 == 0 and int(width) <= 9 and x.is_contiguous()
     rows, K = x.shape
     lib = _lib.load_library()
     nbytes = lib.mi355q_bfp_tiled_bytes(rows, 2 * K)
-    if reuse:
+    if out is not None:
+        assert out.dtype == torch.int8 and out.numel() == nbytes and out.is_contiguous() and out.device == x.device
+        yt = out.view(-1)
+    elif reuse:
         key = (x.device.index, _stream_ptr(x.device), rows, K)
         yt = _BF16_TILED_BUFFERS.get(key)
         if yt is None:

@@ -151,12 +151,14 @@ class RowShardedLinear(nn.Module):
         if (self.consumer_pre == "silu_mul") != (other is not None):
             raise RuntimeError("gather='quantised': consumer_pre 'silu_mul' needs the partner projection's local output (grouped_linear)")
         o2 = None if other is None else other.detach().reshape(-1, other.shape[-1]).contiguous()
-        mine = ops.block_fp_quantize_bf16_tiled(y2, w, ew, eb, reuse=True,
-                                                pre=None if self.consumer_pre is None else (self.consumer_pre, o2)).reshape(-1)
+        pre = None if self.consumer_pre is None else (self.consumer_pre, o2)
         if world == 1 and not (self.always_gather and dist.is_initialized()):
-            buf = mine.reshape(1, -1)
+            buf = ops.block_fp_quantize_bf16_tiled(y2, w, ew, eb, reuse=True, pre=pre).reshape(1, -1)
         else:
-            buf = torch.empty(world, mine.numel(), dtype=mine.dtype, device=mine.device)
+            # (the operand is written straight into this rank's segment of the gather buffer; the collective runs in place)
+            nbytes = ops.bfp_tiled_bytes(y2.shape[0], 2 * y2.shape[1])
+            buf = torch.empty(world, nbytes, dtype=torch.int8, device=y2.device)
+            mine = ops.block_fp_quantize_bf16_tiled(y2, w, ew, eb, pre=pre, out=buf[dist.get_rank(self.group)])
             dist.all_gather_into_tensor(buf.view(-1), mine, group=self.group)
             COLLECTIVES["all_gather"] += 1
             COLLECTIVES["bytes"] += buf.numel() * buf.element_size()
