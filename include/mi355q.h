@@ -36,7 +36,7 @@
  *   - Environment switches (diagnostics and A/B runs only; the default route never needs one): MI355Q_V9=0 keeps every
  *     launch on the round-2 tile kernel (mi355q_gemm_v8.hip) -- by default every launch of the 256 x 256 tile, grouped or
  *     not, with or without exception lists, the bf16 flavour too, with K % 128 == 0 and >= 4 K-steps per slice takes
- *     mi355q_gemm_v9.hip; MI355Q_V9_FIX=0 sends the launches with lists back to v8; MI355Q_V10=1|2|3 (+ MI355Q_V10_NS) pins a
+ *     mi355q_gemm_v9.hip; MI355Q_V9_FIX=0 sends the launches with lists back to v8; MI355Q_V10=1|2|3|4 (+ MI355Q_V10_NS) pins a
  *     geometry of the small-tile kernel (mi355q_gemm_v10.hip), MI355Q_V10_AUTO=0 keeps launches off it; MI355Q_V8_TILE_ROWS,
  *     MI355Q_V8_SPLITS pin the tile GEMM's tile height / split-K (tests do); MI355Q_MATMUL_RW=1|2 the row groups
  *     per wave of the short-contraction tile product; MI355Q_MATMUL_TILE=0 sends the plain attention

@@ -83,7 +83,7 @@ __device__ __forceinline__ i32x4 v10_desc(const void* base, int bytes) {
 // B fragment j of the next step is read in group gb(j): TI = 8: groups 2..5, one each; TI = 4: groups 0 and 1, two each.
 template <int TI, int TJ>
 struct V10Sched {
-    static_assert(TJ == 4 && (TI == 8 || TI == 4), "geometry");
+    static_assert((TJ == 4 && (TI == 8 || TI == 4)) || (TJ == 2 && TI == 4), "geometry (TI = 4 runs the DEEP schedule, not this one)");
     static constexpr int gb(int j) { return TI == 8 ? 2 + j : j / 2; }
     static constexpr int sb(int j) { return TI == 8 ? 0 : (j & 1) * 2; }       // behind which MFMA of its group
     static constexpr int nb_before(int g) {                                   // B reads issued in groups < g
@@ -434,7 +434,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
                     acc[g][j] = v10_mma(fb[C][j], fa[C * TI + g], acc[g][j]);
                     V10_SB();
                     if constexpr (g == 0) v10_dsr<j * 1024>(fb[1 - C][j], bn);
-                    if constexpr (g == 1) v10_dsr<j * 1024>(fa[(1 - C) * TI + j], an);
+                    // (TJ = 4: all four in group 1; TJ = 2 -- the 128 x 64 tile -- two in group 1, two in group 2)
+                    if constexpr (g >= 1 && (g - 1) * TJ + j < TI)
+                        v10_dsr<((g - 1) * TJ + j < TI ? (g - 1) * TJ + j : 0) * 1024>(fa[(1 - C) * TI + ((g - 1) * TJ + j < TI ? (g - 1) * TJ + j : 0)], an);
                     if constexpr (j == 1 && g < LPW) piece(std::integral_constant<int, g>{}, t + NS - 1, sd);
                     if constexpr (j == 3 && g + TI < LPW) piece(std::integral_constant<int, (g + TI < LPW ? g + TI : 0)>{}, t + NS - 1, sd);
                 });
@@ -757,28 +759,29 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-// geometry: 1 = 128 x 256 (1 x 4 waves of 128 x 64), 2 = 256 x 128 (2 x 2 of 128 x 64), 3 = 128 x 128 (2 x 2 of 64 x 64)
+// geometry: 1 = 128 x 256 (1 x 4 waves of 128 x 64), 2 = 256 x 128 (2 x 2 of 128 x 64), 3 = 128 x 128 (2 x 2 of 64 x 64),
+// 4 = 128 x 64 (2 x 2 of 64 x 32: grids that 128 x 128 tiles leave on half the compute units or fewer)
 void v10_tile_shape(int geom, int& bm, int& bn) {
     bm = geom == 2 ? 256 : 128;
-    bn = geom == 1 ? 256 : 128;
+    bn = geom == 1 ? 256 : (geom == 4 ? 64 : 128);
 }
 
-template <int NWM, int NWN, int TI, int NS, int OCC>
+template <int NWM, int NWN, int TI, int NS, int OCC, int TJ = 4>
 static int v10_launch(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                       const uint8_t* xf, const uint8_t* wf, bool bf16, unsigned grid) {
     const bool fix = xlist && wlist;
-    constexpr int RING = NS * (NWM * TI + NWN * 4) * 1024;
+    constexpr int RING = NS * (NWM * TI + NWN * TJ) * 1024;
     // (dynamic shared memory beyond 64 KiB has to be asked for once per kernel)
     static const bool ready = [] {
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, 4, NS, OCC, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess;
-        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, 4, NS, OCC, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
-        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, 4, NS, OCC, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess;
+        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
+        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
         return ok;
     }();
     if (!ready) return (int)hipErrorInvalidValue;
-    if (bf16) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, 4, NS, OCC, 0, true>), grid, 256, RING, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (fix) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, 4, NS, OCC, 1, false>), grid, 256, RING, st, a, sx, sw, xlist, wlist, xf, wf);
-    else hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, 4, NS, OCC, 0, false>), grid, 256, RING, st, a, sx, sw, xlist, wlist, xf, wf);
+    if (bf16) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, true>), grid, 256, RING, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else if (fix) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 1, false>), grid, 256, RING, st, a, sx, sw, xlist, wlist, xf, wf);
+    else hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, false>), grid, 256, RING, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();
 }
 
@@ -816,6 +819,10 @@ int launch_bfp_gemm_v10(const GemmArgs& a_in, const float* sx, const float* sw, 
         if (ns == 8) return v10_launch<2, 2, 4, 8, 1>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid);
         return deep ? v10_launch<2, 2, 4, 6, 1>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid)
                     : v10_launch<2, 2, 4, 4, 2>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid);
+    }
+    if (geom == 4) {
+        return deep ? v10_launch<2, 2, 4, 6, 1, 2>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid)
+                    : v10_launch<2, 2, 4, 4, 2, 2>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid);
     }
 #else
     (void)deep; (void)ns;

@@ -742,7 +742,7 @@ int choose_splits(long long tiles, int nsteps_all, bool need_even, int min_steps
     return best;
 }
 
-// the small tiles of mi355q_gemm_v10.hip under a forced geometry (MI355Q_V10 = 1 | 2 | 3; sweeps and tests) -- split-K as the
+// the small tiles of mi355q_gemm_v10.hip under a forced geometry (MI355Q_V10 = 1 | 2 | 3 | 4; sweeps and tests) -- split-K as the
 // environment pins it (MI355Q_V8_SPLITS) or none
 static int v10_forced_launch(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                              const uint8_t* xf, const uint8_t* wf, bool bf16, int geom) {
@@ -768,7 +768,7 @@ static int v10_forced_launch(const GemmArgs& a_in, const float* sx, const float*
 static int v10_forced() {                       // (read per launch: the tests pin one geometry after the other in one process)
     const char* e = getenv("MI355Q_V10");
     const int g = e ? atoi(e) : 0;
-    return g >= 1 && g <= 3 ? g : 0;
+    return g >= 1 && g <= 4 ? g : 0;
 }
 
 int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
@@ -787,7 +787,10 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
             !getenv("MI355Q_V8_CLOCK") && !getenv("MI355Q_V8_STAMPS")) {
             GemmArgs a = a_in;
             a.splits = 1;
-            return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, false, 3);
+            // (128 x 64 tiles where 128 x 128 ones would fill half the compute units or fewer -- end of round 5:
+            //  4096 x 512 x 4096 26.4 -> 22.4 us at W6A6, 20.1 -> 16.7 at W4A4; level from ~176 tiles of 128 x 128 on)
+            const long long g3 = ((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.ngroup > 1 ? a.ngroup : 1);
+            return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, false, g3 <= 128 ? 4 : 3);
         }
     }
     GemmArgs a = a_in;
@@ -907,11 +910,13 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
             // (128 x 128: 0.23 us a K-step alone on a compute unit, 0.43 for two side by side -- rounds of 512 tiles; beyond ~1000 tiles the
             //  256 x 256 kernel is ahead again although the line says otherwise: 2048 x 11008 x 4096 took 200 us here against its 165-179,
             //  hence the margin.  profiles/r05_shard_shapes.txt, r05_column_offsets.txt)
-            const double est3 = (g3 <= 256 ? nsteps_all * 0.23 : nsteps_all * 0.43 * (double)((g3 + 511) / 512)) + 8.0;
+            // (end of round 5: 128 x 64 tiles where 128 x 128 ones fill half the compute units or fewer -- 0.12 us a K-step:
+            //  4096 x 512 x 4096 30.1 -> 23.1 us, 2048 x 768 x 3072 22.7 -> 17.4, 2048 x 256 x 2048 16.0 -> 11.9)
+            const double est3 = (g3 <= 128 ? nsteps_all * 0.12 : g3 <= 256 ? nsteps_all * 0.23 : nsteps_all * 0.43 * (double)((g3 + 511) / 512)) + 8.0;
             const double est1 = g1 <= 256 ? nsteps_all * 0.39 + 8.0 : 1e30;
             if (est3 * 1.12 < best_t || est1 * 1.12 < best_t) {
                 a.splits = 1;
-                return launch_bfp_gemm_v10(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, est1 < est3 ? 1 : 3);
+                return launch_bfp_gemm_v10(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, est1 < est3 ? 1 : (g3 <= 128 ? 4 : 3));
             }
         }
     }
