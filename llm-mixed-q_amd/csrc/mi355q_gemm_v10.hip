@@ -237,13 +237,20 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
 
     // ---- the operand stream.  Piece p of a K-step: 16 rows of A (p < PA) or of B; this wave stages pieces wave + NW q.
     const long long row_bytes = (long long)kp * 1024;           // one piece row (16 rows x K bytes)
+    // (bf16 flavour, a.x_segs > 1: x lies as column segments -- [segment][row piece][K-steps of the segment], a.x_seg_stride bytes
+    //  apart -- where an all-gather of per-rank quantised slices left them (mi355q_bf16_gemm_tiled_seg; mi355q_gemm_v8.hip had the only
+    //  kernel that read them until the end of round 5): a K-step of a row piece is found through its segment)
+    const bool xseg = BF16 && a.x_segs > 1;
+    const int sps = xseg ? kp / a.x_segs : kp;                  // K-steps per segment
+    const unsigned sps_inv = xseg && sps > 1 ? 0xFFFFFFFFu / (unsigned)sps + 1u : 0u;   // (ks / sps == umulhi(ks, sps_inv) for the few thousand K-steps there are)
+    const long long row_bytes_a = (long long)sps * 1024;        // (== row_bytes without segments)
     const int pa_rows = min(PA, ((Mi + 127) >> 7) * 8 - (m0 >> 4)), pb_rows = min(PB, ((Ni + 127) >> 7) * 8 - (n0 >> 4));
-    const int8_t* xbase = a.xm + (long long)(m0 >> 4) * row_bytes + (long long)kstep0 * 1024;
+    const int8_t* xbase = a.xm + (long long)(m0 >> 4) * row_bytes_a + (xseg ? 0ll : (long long)kstep0 * 1024);
     const int8_t* wbase = a.wm + (long long)(n0 >> 4) * row_bytes + (long long)kstep0 * 1024;
-    const int x_nrec = (int)(pa_rows * row_bytes), w_nrec = (int)(pb_rows * row_bytes);
+    const int x_nrec = (int)(pa_rows * row_bytes_a), w_nrec = (int)(pb_rows * row_bytes);
     int voff[LPW];
 #pragma unroll
-    for (int q = 0; q < LPW; ++q) voff[q] = (wave + NW * (q < LPA ? q : q - LPA)) * (int)row_bytes + lane * 16;
+    for (int q = 0; q < LPW; ++q) voff[q] = (wave + NW * (q < LPA ? q : q - LPA)) * (int)(q < LPA ? row_bytes_a : row_bytes) + lane * 16;
     // piece q (literal) of K-step `step` into the stage at byte offset `so`; a step past the slice's end is requested through
     // descriptors of zero bytes (no memory traffic, zeros land)
     auto piece = [&](auto qi, int step, int so) {
@@ -251,8 +258,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
         constexpr bool isa = q < LPA;
         // (operands of the asm statement as locals of the lambda: an asm operand does not capture by itself)
         const int vo = voff[q];
-        const i32x4 rd = v10_desc(isa ? xbase : wbase, step < nsteps ? (isa ? x_nrec : w_nrec) : 0);
-        const int soff = step * 1024;
+        const int8_t* src = isa ? xbase : wbase;
+        int soff = step * 1024;
+        if (BF16 && isa && xseg) {                              // (uniform)
+            const unsigned ks = (unsigned)(kstep0 + step), sg = sps > 1 ? __umulhi(ks, sps_inv) : ks;
+            src = xbase + (long long)sg * a.x_seg_stride;
+            soff = (int)(ks - sg * (unsigned)sps) * 1024;
+        }
+        const i32x4 rd = v10_desc(src, step < nsteps ? (isa ? x_nrec : w_nrec) : 0);
         const int dst = ring_lds + so + ((isa ? 0 : PA) + wave + NW * (isa ? q : q - LPA)) * 1024;
         V10_BLDS16(vo, rd, soff, dst);
     };

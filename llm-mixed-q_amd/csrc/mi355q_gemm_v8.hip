@@ -874,7 +874,7 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
 // y = x . w^T (+ bias) on TILED bf16 operands (the same 1-KiB pieces: 16 rows x 32 values): a.xm / a.wm point at the
 // bf16 pieces and a.K is the contraction length IN BYTES (2 K).  K % 32 == 0.
 int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
-    if (v10_forced() && a_in.K % 64 == 0 && a_in.x_segs <= 1) return v10_forced_launch(a_in, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, v10_forced());
+    if (v10_forced() && a_in.K % 64 == 0) return v10_forced_launch(a_in, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, v10_forced());
     GemmArgs a = a_in;
     const long long tn = (a.N + V8_BN - 1) / V8_BN;
     const long long t256 = ((a.M + 255) / 256) * tn, t128 = ((a.M + 127) / 128) * tn;
@@ -905,7 +905,7 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
     // (profiles/r05_small_tiles.txt: 2048 x 2048 x 8192 81.3 -> 59.0 us, Llama-7B o_proj 74.8 -> 54.6, down_proj 156 -> 142)
     {
         static const int v10_auto = getenv("MI355Q_V10_AUTO") ? atoi(getenv("MI355Q_V10_AUTO")) : 1;
-        if (v10_auto && !force && !getenv("MI355Q_V8_SPLITS") && a.x_segs <= 1 && a.K % 64 == 0) {
+        if (v10_auto && !force && !getenv("MI355Q_V8_SPLITS") && a.K % 64 == 0) {
             const long long g3 = ((a.M + 127) / 128) * ((a.N + 127) / 128), g1 = ((a.M + 127) / 128) * ((a.N + 255) / 256);
             // (128 x 128: 0.23 us a K-step alone on a compute unit, 0.43 for two side by side -- rounds of 512 tiles; beyond ~1000 tiles the
             //  256 x 256 kernel is ahead again although the line says otherwise: 2048 x 11008 x 4096 took 200 us here against its 165-179,

@@ -416,14 +416,18 @@ def test_bf16_tiled_gemm_vs_oracle(M, N, K, style, wx, ww):
 
 
 @pytest.mark.parametrize("M,K,N,P", [(300, 512, 272, 2), (300, 512, 272, 4), (1024, 2048, 512, 8), (130, 192, 64, 2), (4096, 1024, 256, 4),
-                                     (77, 256, 48, 8)])
-def test_bf16_tile_gemm_with_x_in_column_segments(M, K, N, P):
+                                     (77, 256, 48, 8), (4096, 4096, 512, 8)])
+@pytest.mark.parametrize("geom", [0, 1, 2, 3, 4])
+def test_bf16_tile_gemm_with_x_in_column_segments(M, K, N, P, geom, monkeypatch):
     """mi355q_bf16_gemm_tiled_seg (ABI 20): x handed over as P column segments, each its own tiled bf16 operand, rank-major --
     what an all-gather of per-rank quantised output slices leaves (sharded.py, gather = "quantised") -- gives the plain call's
-    result on the re-assembled operand, and the oracle's"""
+    result on the re-assembled operand, and the oracle's.  geom: the launcher's choice (0) or a pinned small-tile geometry (the
+    small tiles read segments since the end of round 5)"""
     import torch
     from mi355q import ops
     from oracle import np_oracle as O
+    if geom:
+        monkeypatch.setenv("MI355Q_V10", str(geom))
     r = np.random.default_rng(M + K + P)
     x = (r.normal(size=(M, K)) * np.exp(r.normal(size=(M, 1)))).astype(np.float32)
     w = (r.normal(size=(N, K)) * 0.05).astype(np.float32)
