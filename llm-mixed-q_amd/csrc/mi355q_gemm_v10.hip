@@ -281,6 +281,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     // (grids of <= 256 workgroups: every launch this tile is chosen for) has no partner whose MFMAs cover the ~130 clocks of an LDS
     // round trip, and a two-group window leaves them exposed (tools/ubench/vmem_issue.hip: 455 -> 355 clocks a K-step)
     constexpr bool DEEP = TI == 4;
+#ifndef V10_PAIR
+#define V10_PAIR 1
+#endif
+    constexpr bool PAIR = V10_PAIR && DEEP && NS >= 6;          // (see `body`)
     i32x4 fa[DEEP ? 2 * TI : 4], fb[2][TJ];
 
     // ---- exception bookkeeping state.  Buckets: LDS copies of the tile's two buckets (EARLY: beside the ring, else in the ring
@@ -429,11 +433,17 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     // goes to.  C: which B register set holds step t's fragments.
     // (the gathers requested in front of the loop are younger than the first stages' pieces: the first step's counted wait covers
     //  them too -- a peeled first step with its own count cost more registers than the half microsecond it would save)
-    auto body = [&](auto ci, int t, int sc, int sn, int sd) {
-        constexpr int C = decltype(ci)::value;
-        v10_waitv<(NS - 3) * LPW>();
+    // PH (PAIR: the 64-row wave tile with a ring of >= 6 stages): K-steps two to a barrier.  0: a step on its own (as before);
+    // 1: the first of a pair -- waits for this wave's pieces of BOTH following steps; 2: the second -- no wait for pieces, no barrier
+    // (what it reads landed before the pair's barrier; the stage it refills, step t - 1's, was read into registers by every wave
+    // before that barrier too).  A lone wave per SIMD pays ~170 clocks of barrier and LDS round trip a K-step whatever its MFMAs
+    // (128 x 64 tile: 300 clocks a step for 128 of MFMA); pairs halve the number of those.
+    auto body = [&](auto ci, auto phi, int t, int sc, int sn, int sd) {
+        constexpr int C = decltype(ci)::value, PH = decltype(phi)::value;
+        if constexpr (PH == 1) v10_waitv<(NS - 4 > 0 ? NS - 4 : 0) * LPW>();
+        else if constexpr (PH == 0) v10_waitv<(NS - 3) * LPW>();
         if constexpr (DEEP) v10_lgkm<0>();                      // this step's fragments, read during the last one
-        __builtin_amdgcn_s_barrier();
+        if constexpr (PH != 2) __builtin_amdgcn_s_barrier();
         const int ac = va + sc, an = va + sn, bn = vb + sn;
         if constexpr (DEEP) {
             // group 0: the next step's four B fragments, one behind each MFMA; group 1: its four A fragments; one LDS-DMA piece a
@@ -492,13 +502,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
         auto nxt = [&](int s_) { return s_ + 1 == NS ? 0 : s_ + 1; };
         auto prv = [&](int s_) { return s_ == 0 ? NS - 1 : s_ - 1; };
         int t = 0;
+        constexpr int P1 = PAIR ? 1 : 0, P2 = PAIR ? 2 : 0;
         for (; t + 1 < nsteps; t += 2) {
-            body(std::integral_constant<int, 0>{}, t, cur * STAGE, nxt(cur) * STAGE, prv(cur) * STAGE);
+            body(std::integral_constant<int, 0>{}, std::integral_constant<int, P1>{}, t, cur * STAGE, nxt(cur) * STAGE, prv(cur) * STAGE);
             cur = nxt(cur);
-            body(std::integral_constant<int, 1>{}, t + 1, cur * STAGE, nxt(cur) * STAGE, prv(cur) * STAGE);
+            body(std::integral_constant<int, 1>{}, std::integral_constant<int, P2>{}, t + 1, cur * STAGE, nxt(cur) * STAGE, prv(cur) * STAGE);
             cur = nxt(cur);
         }
-        if (t < nsteps) body(std::integral_constant<int, 0>{}, t, cur * STAGE, nxt(cur) * STAGE, prv(cur) * STAGE);   // (odd slices: K % 128 == 64)
+        if (t < nsteps) body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, t, cur * STAGE, nxt(cur) * STAGE, prv(cur) * STAGE);   // (odd slices: K % 128 == 64)
     }
     v10_waitv<0>();
     v10_lgkm<0>();                                              // (the compiler does not know these reads are in flight)
