@@ -6,14 +6,19 @@ import torch
 from mi355q import ops
 import mi355q.ops as _ops_mod; _ops_mod.REUSE_QUANTISED_INPUT = False   # (the loop below re-quantises ONE tensor on purpose)
 dev = torch.device('cuda:0')
-def t(fn, n=50):
+def t(fn, n=50, reps=3):
+    """us per call: the best of `reps` timed runs of n calls (a box now and then stalls a stream for tens of ms: one such stall in a run
+    of 50 short launches would be the whole figure)"""
     for _ in range(5): fn()
-    torch.cuda.synchronize()
-    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n): fn()
-    e.record(); torch.cuda.synchronize()
-    return a.elapsed_time(e) / n * 1e3
+    best = float("inf")
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n): fn()
+        e.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(e) / n * 1e3)
+    return best
 for name, M, N, K in (("bench P=8", 4096, 512, 4096), ("bench P=4", 4096, 1024, 4096), ("bench P=2", 4096, 2048, 4096),
                       ("OPT-1.3B fc1 P=8", 2048, 1024, 2048), ("OPT-1.3B q_proj P=8", 2048, 256, 2048), ("Llama-7B q_proj P=8", 2048, 512, 4096),
                       ("Llama-7B up P=8", 2048, 1376, 4096)):
@@ -26,4 +31,15 @@ for name, M, N, K in (("bench P=8", 4096, 512, 4096), ("bench P=4", 4096, 1024, 
     xa = ops.block_fp_quantize_aligned_rows(x, 6, 8, 127)
     tg = t(lambda: ops.bfp_gemm_aligned(xa, wa, None, out=y))
     tq = t(lambda: ops.block_fp_quantize_aligned_rows(x, 6, 8, 127))
-    print(json.dumps({"shape": name, "M": M, "N": N, "K": K, "gemm_us": round(tg, 1), "gemm_TOPS": round(2.0 * M * N * K / tg / 1e6), "quantise_us": round(tq, 1)}))
+    # the same launch 50 times in a HIP graph: launch to launch on the device, without the host's share of an eager call (a launch of
+    # 15-25 us is as short as the Python + ctypes path that issues it)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3): ops.bfp_gemm_aligned(xa, wa, None, out=y)
+        s.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            for _ in range(50): ops.bfp_gemm_aligned(xa, wa, None, out=y)
+        tgg = t(gr.replay, n=10) / 50
+    print(json.dumps({"shape": name, "M": M, "N": N, "K": K, "gemm_us": round(tg, 1), "gemm_TOPS": round(2.0 * M * N * K / tg / 1e6),
+                      "gemm_us_graph": round(tgg, 1), "gemm_TOPS_graph": round(2.0 * M * N * K / tgg / 1e6), "quantise_us": round(tq, 1)}))
