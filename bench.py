@@ -185,14 +185,16 @@ def robustness_summary(torch, ops, device, steps=50):
     with torch.no_grad():
         for _ in range(6):                                    # (the policy reads its overflow word on a doubling schedule of calls)
             y = lin(x)
-        torch.cuda.synchronize()
-        a_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a_ev.record()
-        for _ in range(steps):
-            y = lin(x)
-        e_ev.record()
-        torch.cuda.synchronize()
-    ms = a_ev.elapsed_time(e_ev) / steps
+        ms = float("inf")
+        for _ in range(3):                                    # (the best of three passes of `steps` calls: see config5_summary)
+            torch.cuda.synchronize()
+            a_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_ev.record()
+            for _ in range(steps):
+                y = lin(x)
+            e_ev.record()
+            torch.cuda.synchronize()
+            ms = min(ms, a_ev.elapsed_time(e_ev) / steps)
     route = "bf16 per-block exponents (tile GEMM on bf16 MFMA)" if lin._uses_bf16_route() else f"int8 {lin._align_mode}"
     pick = np.sort(np.random.default_rng(6).choice(M, size=32, replace=False))
     ref = O.bfp_linear_int(x.cpu().numpy()[pick], w.numpy(), b.numpy(), CFG)
@@ -215,6 +217,7 @@ def config5_summary(torch, ops, args, device, with_cpu):
         pass
     q = A()
     q.steps, q.warmup, q.clock_ramp_ms = 30, 5, 0.0            # (the GPU is at its working clocks already)
+    q.passes = 3                                               # (each case: the best of three passes of 30 calls)
     r = quantizer_workload(torch, ops, q, device)
     worst = min(r["cases"], key=lambda c: c["GB/s"])
     per = {}
@@ -223,7 +226,7 @@ def config5_summary(torch, ops, args, device, with_cpu):
         d["min_GB/s"] = min(d["min_GB/s"], c["GB/s"]); d["max_GB/s"] = max(d["max_GB/s"], c["GB/s"])
     out = {"metric": r["metric"], "aggregate_GB/s": r["value"], "aggregate_frac_of_8TBs": round(r["value"] / HBM_PEAK_GBS, 3),
            "worst_case": {k: worst[k] for k in ("quantizer", "shape", "us", "GB/s", "frac_of_8TBs", "copy_GB/s", "frac_of_copy")},
-           "per_quantizer": per, "cases": len(r["cases"]), "steps": q.steps,
+           "per_quantizer": per, "cases": len(r["cases"]), "steps": q.steps, "passes": q.passes, "timing": "best of `passes` passes of `steps` calls per case",
            "shapes": "act[2048,4096], act[2048,11008], probs / causal_probs[32,2048,2048], w[4096,4096], w[11008,4096]"}
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_config5(torch)
@@ -333,14 +336,16 @@ def quantizer_workload(torch, ops, args, device):
         for fname, fn in fns.items():
             for _ in range(args.warmup):
                 fn(x, skip)
-            torch.cuda.synchronize()
-            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(args.steps):
-                fn(x, skip)
-            e.record()
-            torch.cuda.synchronize()
-            ms = a.elapsed_time(e) / args.steps
+            ms = float("inf")
+            for _ in range(getattr(args, "passes", 1)):        # (config5_summary: the best of three passes -- a box now and then stalls a
+                torch.cuda.synchronize()                       #  stream for tens of ms, which inside a 0.5-ms pass would be the figure)
+                a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(args.steps):
+                    fn(x, skip)
+                e.record()
+                torch.cuda.synchronize()
+                ms = min(ms, a.elapsed_time(e) / args.steps)
             gbs = 8.0 * x.numel() / (ms * 1e-3) / 1e9
             rows.append({"quantizer": fname, "shape": sname, "us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
                          "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 3), "copy_GB/s": round(copy_gbs, 1),
