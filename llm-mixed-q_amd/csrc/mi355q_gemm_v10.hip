@@ -456,10 +456,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
                     V10_SB();
                     acc[g][j] = v10_mma(fb[C][j], fa[C * TI + g], acc[g][j]);
                     V10_SB();
-                    if constexpr (g == 0) v10_dsr<j * 1024>(fb[1 - C][j], bn);
-                    // (TJ = 4: all four in group 1; TJ = 2 -- the 128 x 64 tile -- two in group 1, two in group 2)
-                    if constexpr (g >= 1 && (g - 1) * TJ + j < TI)
-                        v10_dsr<((g - 1) * TJ + j < TI ? (g - 1) * TJ + j : 0) * 1024>(fa[(1 - C) * TI + ((g - 1) * TJ + j < TI ? (g - 1) * TJ + j : 0)], an);
+                    // the next step's TJ + TI fragment reads, in order B then A, behind the first MFMAs: one a MFMA with TJ = 4 (B in
+                    // group 0, A in group 1), two a MFMA with TJ = 2 (the 128 x 64 tile: all six behind its first three MFMAs of
+                    // eight -- a lone wave has only its own MFMAs to cover the reads' way back)
+                    constexpr int RPS = TJ == 2 ? 2 : 1, slot = g * TJ + j;
+                    v10_for<0, RPS>([&](auto ri) {
+                        constexpr int r = slot * RPS + decltype(ri)::value;
+                        if constexpr (r < TJ) v10_dsr<(r < TJ ? r : 0) * 1024>(fb[1 - C][r < TJ ? r : 0], bn);
+                        else if constexpr (r < TJ + TI) v10_dsr<(r >= TJ && r < TJ + TI ? r - TJ : 0) * 1024>(fa[(1 - C) * TI + (r >= TJ && r < TJ + TI ? r - TJ : 0)], an);
+                    });
                     if constexpr (j == 1 && g < LPW) piece(std::integral_constant<int, g>{}, t + NS - 1, sd);
                     if constexpr (j == 3 && g + TI < LPW) piece(std::integral_constant<int, (g + TI < LPW ? g + TI : 0)>{}, t + NS - 1, sd);
                 });
