@@ -349,8 +349,9 @@ int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operan
  *   mi355q_mx_plane_bytes(rows, K, plane) bytes (plane 0: 16 of a lane's 24 code bytes, 1: the other 8, 2: scales); 16-byte
  *   aligned.  The two blocks of a 32-group share a scale; the block with the larger exponent carries its mantissas shifted
  *   left by the difference.  A group whose blocks lie too far apart for that (> 3 exponents at W4, > 2 at W5) RAISES *bad
- *   (never cleared by the call that raises it; `bad_to_clear`, nullable, != bad, is zeroed: callers alternate between two
- *   words, each call clearing the next call's).
+ *   (`bad_to_clear`, != bad, is zeroed by the kernel: callers alternate between two words, each call clearing the next
+ *   call's; with bad_to_clear == NULL -- a caller recording a HIP graph, whose words cannot alternate between replays -- the
+ *   call zeroes *bad itself by a stream-ordered memset in front of its kernel).
  * mi355q_mx_gemm: y = x_q . w_q^T (+ bias), fp32 accumulation.  bad2[0] / bad2[1]: the flag words of x / w.  If either is
  *   raised the launch forms the exact product from x_fp32 (quantised in registers with x's parameters) and w_fp32 (the
  *   fake-quantised weights) itself -- decided on the device, uniform over the grid, ~10x slower: callers move such a layer to

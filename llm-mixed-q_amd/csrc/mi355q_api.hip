@@ -644,6 +644,12 @@ int mi355q_block_fp_quantize_mx(const float* x, uint8_t* codes16, uint8_t* codes
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(codes16) | reinterpret_cast<uintptr_t>(codes8) | reinterpret_cast<uintptr_t>(scales)) % 16)
         return MI355Q_E_ALIGN;
     if (bad_to_clear == bad) return MI355Q_E_BADARG;
+    // no "next call's word" to clear (a caller recording a HIP graph: the flag words cannot alternate between replays): this
+    // call clears its OWN word in front of the kernel -- a memset node in the graph -- so that a replay whose activations fit
+    // the format is never sent to the exact route by an earlier replay's flag
+    if (!bad_to_clear) {
+        if (hipMemsetAsync(bad, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)) != hipSuccess) return (int)hipGetLastError();
+    }
     return launch_quant_mx_rows(a, codes16, codes8, scales, bad, bad_to_clear, static_cast<hipStream_t>(stream));
 }
 

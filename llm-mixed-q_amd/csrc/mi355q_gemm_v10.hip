@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
                         if constexpr (r < TJ) v10_dsr<(r < TJ ? r : 0) * 1024>(fb[1 - C][r < TJ ? r : 0], bn);
                         else if constexpr (r < TJ + TI) v10_dsr<(r >= TJ && r < TJ + TI ? r - TJ : 0) * 1024>(fa[(1 - C) * TI + (r >= TJ && r < TJ + TI ? r - TJ : 0)], an);
                     });
-                    if constexpr (j == 1 && g < LPW) piece(std::integral_constant<int, g>{}, t + NS - 1, sd);
+                    if constexpr (j == 1 && g < LPW) piece(std::integral_constant<int, (g < LPW ? g : 0)>{}, t + NS - 1, sd);
                     if constexpr (j == 3 && g + TI < LPW) piece(std::integral_constant<int, (g + TI < LPW ? g + TI : 0)>{}, t + NS - 1, sd);
                 });
             });

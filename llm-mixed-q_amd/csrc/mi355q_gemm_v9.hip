@@ -864,7 +864,9 @@ static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/dbg
 int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        hipStream_t st, const uint8_t* xf, const uint8_t* wf, bool bf16) {
     GemmArgs a = a_in;
-    static const bool want_stamps = getenv("MI355Q_V9_STAMPS") != nullptr;
+    // (stamps build: while a buffer is registered through mi355q_debug_v9_stamps -- bench.py's `roofline.loop_clock_GHz`,
+    //  tools/dbg/v9_stamps.py; no stamp executes in the kernel every other launch runs)
+    const bool want_stamps = g_v9_stamps != nullptr;
     if (want_stamps) a.stamps = g_v9_stamps;
     const bool fix = xlist && wlist;
     if (fix && (!xf || !wf)) return MI355Q_E_BADARG;

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .quantize import get_quantized_cls, get_quantized_func, grouped_linear
 from .quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
 
@@ -166,6 +167,7 @@ class TinyOPTForCausalLM(nn.Module):
         mask = torch.full((T, T), torch.finfo(x.dtype).min, device=x.device).triu(1)[None, None]
         for layer in self.layers:
             x = layer(x, mask)
+        ops.count_vendor_gemm("harness.lm_head (unquantised, modeling_opt.py:942-944)")
         logits = self.lm_head(self.final_layer_norm(x))
         loss = None
         if labels is not None:
@@ -325,6 +327,7 @@ class TinyLlamaForCausalLM(nn.Module):
         mask = torch.full((T, T), torch.finfo(x.dtype).min, device=x.device).triu(1)[None, None]
         for layer in self.layers:
             x = layer(x, mask, position_ids)
+        ops.count_vendor_gemm("harness.lm_head (unquantised, modeling_llama.py)")
         logits = self.lm_head(self.norm(x))
         loss = None
         if labels is not None:

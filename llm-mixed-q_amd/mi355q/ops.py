@@ -700,10 +700,13 @@ def mx_supported(K: int, x_width: int, w_width: int) -> bool:
     return K % 128 == 0 and 0 < K <= ROW_ALIGN_MAX_K and 2 <= int(x_width) <= 5 and 2 <= int(w_width) <= 5
 
 
-def block_fp_quantize_mx(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, reuse: bool = True) -> MxOperand:
+def block_fp_quantize_mx(x: torch.Tensor, width: int, exponent_width: int, exponent_bias, reuse: bool = True,
+                         keep_source: bool = True) -> MxOperand:
     """x [rows, K] fp32 ([1,16] blocks along K) -> MxOperand.  `reuse`: the planes are shared by calls of the same shape on the
     same stream (activations: consume before quantising again), else freshly allocated (weights).  The operand keeps `x`
-    (`source`): the product launch reads it if a flag is raised."""
+    (`source`): the product launch reads it if a flag is raised -- an ACTIVATION operand's; a weights' operand is built with
+    keep_source = False (mx_gemm is handed the fake-quantised weights themselves, and a kept alias of the fp32 storage would
+    defeat release_fp32_weight())."""
     _require_device(x, "block_fp_quantize_mx")
     assert x.ndim == 2 and x.is_contiguous() and x.dtype == torch.float32 and x.shape[1] % 128 == 0 and 2 <= int(width) <= 5
     rows, K = x.shape
@@ -726,7 +729,7 @@ def block_fp_quantize_mx(x: torch.Tensor, width: int, exponent_width: int, expon
     op.bad, nxt = buf["bad"][2 * par:2 * par + 2], buf["bad"][2 * (1 - par):2 * (1 - par) + 1]
     op._wbad_of = buf.get("wbad_of")
     op._buf = buf
-    op.width, op.exponent_width, op.exponent_bias, op.source = int(width), int(exponent_width), _default_bias(exponent_bias), x
+    op.width, op.exponent_width, op.exponent_bias, op.source = int(width), int(exponent_width), _default_bias(exponent_bias), (x if keep_source else None)
     with _on_device(x.device):
         rc = lib.mi355q_block_fp_quantize_mx(_ptr(x), _ptr(op.c16), _ptr(op.c8), _ptr(op.sc), _ptr(op.bad), _ptr(nxt) if not _capturing() else None, rows, K, int(width),
                                             int(exponent_width), op.exponent_bias, sp)
@@ -739,6 +742,7 @@ def mx_gemm(x: MxOperand, w: MxOperand, w_fp32: torch.Tensor, bias=None, out: to
     (read only if a flag word is raised).  x.bad / w.bad: word 0 of each."""
     M, K, N = x.rows, x.K, w.rows
     assert w.K == K and w_fp32.shape == (N, K) and w_fp32.is_contiguous() and w_fp32.dtype == torch.float32
+    assert x.source is not None, "mx_gemm: the activation operand must keep its fp32 source (the exact in-launch fallback reads it)"
     given = out is not None
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.c16.device)
@@ -756,6 +760,25 @@ def mx_gemm(x: MxOperand, w: MxOperand, w_fp32: torch.Tensor, bias=None, out: to
     _lib.check(rc, "mi355q_mx_gemm")
     if given:
         _wrote_into(out)
+    return out
+
+
+# ---- vendor-library GEMM calls: the decline routes keep the reference's semantics through torch's own
+#      GEMMs (F.linear, torch.matmul / bmm: bypass mode, QAT on fp32, shapes / arithmetics no kernel of this library takes).
+#      Never the default route of a quantised layer -- this counter says how often a forward took them, and where.
+VENDOR_GEMM_CALLS: dict = {}
+
+
+def count_vendor_gemm(site: str) -> None:
+    VENDOR_GEMM_CALLS[site] = VENDOR_GEMM_CALLS.get(site, 0) + 1
+
+
+def vendor_gemm_calls(reset: bool = False) -> dict:
+    """{site: calls} since the last reset; sites: "linear.bypass", "linear.ptq_fallthrough", "linear.qat_fp32",
+    "matmul.bypass", "matmul.generic" (quantized_functions), and whatever a harness adds (the unquantised lm_head)"""
+    out = dict(VENDOR_GEMM_CALLS)
+    if reset:
+        VENDOR_GEMM_CALLS.clear()
     return out
 
 

@@ -16,6 +16,12 @@ import torch
 from ..quantizers import QUANTIZER_MAP
 
 _MATMUL = {"matmul": torch.matmul, "bmm": torch.bmm}
+
+
+def _ops():
+    from ... import ops
+    return ops
+
 _KEYS = {
     "block_fp": ("width", "exponent_width", "exponent_bias", "block_size"),
     "block_minifloat": ("width", "exponent_width", "exponent_bias_width", "block_size"),
@@ -97,6 +103,7 @@ def _fused_values_matmul(x, y, config, arith, softmax=False, mask=None, causal=F
 def _generic_matmul(x, y, config, arith, style):
     mm = _MATMUL[style]
     if config.get("bypass", False):
+        _ops().count_vendor_gemm("matmul.bypass")
         return mm(x, y)
     # read y's keys first-to-last like the reference does (KeyError parity) even where unused
     for k in _KEYS[arith]:
@@ -111,6 +118,7 @@ def _generic_matmul(x, y, config, arith, style):
             return out
     xq = _quantise_operand(x, arith, config, "data_in")
     yq = y if arith == "block_log" else _quantise_operand(y, arith, config, "weight")
+    _ops().count_vendor_gemm("matmul.generic")
     return mm(xq, yq)
 
 

@@ -212,7 +212,7 @@ class _LinearBase(nn.Linear):
             # W4A4 on the MX scaled MFMA (csrc/mi355q_mx.hip): the operand from the RAW weights (block_fp is not idempotent), kept
             # only if every 32-group of W fits the format (one host read, here where the weights are packed anyway)
             mw = ops.block_fp_quantize_mx(self.weight.data.contiguous(), c["weight_width"], c["weight_exponent_width"], c["weight_exponent_bias"],
-                                          reuse=False)
+                                          reuse=False, keep_source=False)
             if _capturing_graph() or int(mw.bad[0]) == 0:
                 self._mx_w = mw
         if pack:
@@ -388,6 +388,8 @@ class _LinearBase(nn.Linear):
         only the packed routes work afterwards (requantize() brings the weights back if a master copy is kept)."""
         if self._packed is None:
             raise RuntimeError("mi355q: nothing packed yet (run a forward or pack_now() first)")
+        # the MX route's exact in-launch fallback reads the fp32 weights: that operand goes with them (ADVICE r5)
+        self._mx_w = None
         self.weight.data = torch.empty(0, dtype=self.weight.dtype, device=self.weight.device)
         self._packed = (self._packed[0], self._packed[1], self.weight._version, self._packed[3])
         if self._w_bf16 is not None:
@@ -426,6 +428,7 @@ class _LinearBase(nn.Linear):
                 raise RuntimeError(f"mi355q: a quantised gather that applied {x.pre_applied!r} reached forward(); call forward_after")
             return self._forward_quantised_gather(x)
         if self.bypass:
+            ops.count_vendor_gemm("linear.bypass")
             return F.linear(x, self.weight, self.bias)
         if self.is_ptq:
             plan = self._int8_plan(x)
@@ -448,12 +451,14 @@ class _LinearBase(nn.Linear):
                 if not differentiated and self._padded_block_fp_ok(x):
                     return self._forward_block_fp_padded(x)
                 x = self.x_quantizer(x)
+            ops.count_vendor_gemm("linear.ptq_fallthrough")
             return F.linear(x, self.weight, self.bias)
         x = self.x_quantizer(x)
         w = self.w_quantizer(self.weight)
         bias = self.b_quantizer(self.bias) if self.bias is not None else None
         if self._qat_on_tile_gemm(x):
             return _TileLinear.apply(x, w, bias)
+        ops.count_vendor_gemm("linear.qat_fp32")
         return F.linear(x, w, bias)
 
     def _qat_on_tile_gemm(self, xq) -> bool:
@@ -494,7 +499,7 @@ class _LinearBase(nn.Linear):
                 and c.get("mi355q_weight_storage", "int8") != "packed" and not getattr(self, "_fp32_released", False))
 
     def _mx_takes(self, x) -> bool:
-        if not (x.is_cuda and x.dtype == torch.float32 and 2 <= x.ndim <= 3) or self._mx_w is None:
+        if not (x.is_cuda and x.dtype == torch.float32 and 2 <= x.ndim <= 3) or self._mx_w is None or self._fp32_released:
             return False
         if self._mx_w.c16.device != x.device or self._mx_version != self.weight._version:
             return False

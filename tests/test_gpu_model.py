@@ -587,3 +587,62 @@ def test_perplexity_on_trained_weights(tag, name, knobs):
     assert abs(d_ppl) <= spread and d_chunk <= spread_chunk, (d_ppl, spread, d_chunk, spread_chunk)
     assert abs(d_ppl) < 1e-3 * ev["perplexity"]                       # (and in any case a per-mille of the perplexity)
     assert ppl < 1.05 * m["evals"]["bypass"]["perplexity"]            # (the quantised model is still the language model it was)
+
+
+def test_opt125m_shape_twelve_layers_vs_oracle():
+    """BASELINE config 0's MODEL SHAPE on the GPU (configuration_opt.py:100-112 -- hidden 768, FFN 3072, 12 heads x 64,
+    12 layers) at the perplexity loop's sequence length (T = 2048, eval_wikitext2.sh:51-52), W6A6 block_fp [1,16], random seeded
+    weights (no checkpoint offline): (1) EVERY quantised Linear of the run -- the six per layer, 72 in all, at M = 2048 tokens --
+    against the oracle's steady-state PTQ Linear on sampled rows of the very input it saw (teacher-forced: summation-order noise
+    only, <= 1e-6); the four projections fed by a LayerNorm and fc1 must be on the int8 row-scale route; (2) the end-to-end loss
+    against the numpy oracle's forward of the same network.  At this depth fp32 arithmetic itself does not pin the loss more
+    tightly than 4e-4 ... 5e-3 (the oracle against itself under 1-ulp jitter, profiles/r02_depth_control.jsonl; measured GPU
+    against oracle: 3.1e-3, profiles/r03_teacher_forced_depth.jsonl): the bound here is 8e-3."""
+    import torch
+    from mi355q.harness import TinyOPTConfig, TinyOPTForCausalLM, expand_quant_config
+    from mi355q.quantize.quantized_modules.linear import _LinearBase
+    from oracle import np_oracle as O
+    W6A6 = dict(name="block_fp", is_ptq=True, bypass=False, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+                data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127,
+                weight_block_size=[1, 16], bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
+    torch.manual_seed(0)
+    T = 2048
+    cfg = TinyOPTConfig(vocab_size=2048, hidden_size=768, ffn_dim=3072, num_layers=12, num_heads=12, max_positions=T)
+    model = TinyOPTForCausalLM(cfg, expand_quant_config(W6A6, cfg.num_layers))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim == 2 and "embed" not in n:
+                p.mul_(2.0)
+    ids = torch.randint(0, cfg.vocab_size, (1, T))
+    w0 = {n: (m.weight.detach().clone().numpy(), None if m.bias is None else m.bias.detach().clone().numpy())
+          for n, m in model.named_modules() if isinstance(m, _LinearBase) and n.startswith("layers.")}
+    assert len(w0) == 72
+    ref_loss = _oracle_forward(model, W6A6, ids.numpy())
+    dev = torch.device("cuda:0")
+    model = model.to(dev)
+    rng = np.random.default_rng(3)
+    io, routes = {}, {}
+
+    def tap(name):
+        def hook(mod, inp, out):
+            x2, y2 = inp[0].detach().reshape(-1, inp[0].shape[-1]), out.detach().reshape(-1, out.shape[-1])
+            pick = np.sort(rng.choice(x2.shape[0], size=24, replace=False))
+            pt = torch.from_numpy(pick).to(x2.device)
+            io[name] = (x2[pt].cpu().numpy(), y2[pt].cpu().numpy())
+            routes[name] = "bf16" if mod._uses_bf16_route() else ("int8" if mod._packed is not None and mod._packed[0] is not None else "other")
+        return hook
+    for n, m in model.named_modules():
+        if n in w0:
+            m.register_forward_hook(tap(n))
+    with torch.no_grad():
+        loss = float(model(ids.to(dev), labels=ids.to(dev))[1])
+    assert len(io) == 72
+    worst = 0.0
+    for n, (xin, yout) in io.items():
+        w, b = w0[n]
+        want = O.linear_ptq(xin, w, b, W6A6)[0]
+        worst = max(worst, float(np.abs(yout - want).max() / np.abs(want).max()))
+        if not n.endswith(("fc2", "out_proj")):              # q / k / v / fc1: fed by a LayerNorm -- rows fit one exponent window
+            assert routes[n] == "int8", (n, routes[n])
+    assert worst <= 1e-6, worst
+    assert abs(loss - ref_loss) <= 8e-3, (loss, ref_loss)

@@ -159,3 +159,33 @@ def test_linear_block_fp_leaves_the_mx_route_when_the_activations_do_not_fit():
         y2 = lin(x.to(dev))
     for y in (y1, y2):
         assert np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max() < 5e-6
+
+
+def test_release_fp32_weight_takes_the_layer_off_the_mx_route():
+    """release_fp32_weight() on a W4A4 layer whose launches are large enough for the MX route (>= 192 tiles).  The MX
+    product's exact in-launch fallback reads the fp32 weights, so the MX operand goes with them: the forward after the release runs
+    on the int8 operand, equals the forward before it to the oracle's tolerance, and frees the fp32 storage (no alias kept)."""
+    import torch
+    import mi355q.quantize as Q
+    from oracle import np_oracle as O
+    dev = torch.device("cuda:0")
+    M, K, N = 4096, 512, 4096
+    cfg = _lin_cfg(4, 4)
+    torch.manual_seed(21)
+    fp = torch.nn.Linear(K, N)
+    with torch.no_grad():
+        fp.weight.mul_(8.0)
+    w0, b0 = fp.weight.detach().numpy().copy(), fp.bias.detach().numpy().copy()
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to(dev)
+    x = (torch.randn(M, K) * torch.exp(torch.randn(M, 1))).to(dev)
+    with torch.no_grad():
+        lin.pack_now(x)
+        assert lin._mx_w is not None and lin._mx_w.source is None, "a weights' MX operand keeps no alias of the fp32 storage"
+        y_mx = lin(x)
+        lin.release_fp32_weight()
+        assert lin._mx_w is None and lin.weight.numel() == 0 and not lin._mx_takes(x)
+        y_int8 = lin(x)
+    pick = np.sort(np.random.default_rng(5).choice(M, size=48, replace=False))
+    ref = O.bfp_linear_int(x.cpu().numpy()[pick], w0, b0, cfg)
+    for y in (y_mx, y_int8):
+        assert np.abs(y.cpu().numpy()[pick] - ref).max() / np.abs(ref).max() < 5e-6

@@ -63,12 +63,15 @@ def run(layers=32, tokens=2048, steps=5, storage="resident", graph=True, parity=
         # (each forward timed on its own, the median reported: a box now and then stalls a stream for tens of ms, which in a mean
         #  over five 30-ms forwards would be a third of the figure)
         per = []
+        from mi355q import ops as _ops
+        _ops.vendor_gemm_calls(reset=True)
         for _ in range(steps):
             t0 = time.perf_counter()
             logits, loss = model(ids, labels=ids)
             torch.cuda.synchronize()
             per.append((time.perf_counter() - t0) * 1e3)
         ms_eager = sorted(per)[len(per) // 2]
+        vendor = {k: v // steps for k, v in sorted(_ops.vendor_gemm_calls().items())}
         from mi355q.quantize.quantized_modules.linear import _LinearBase as _LB
         routes = {}
         for m in model.modules():
@@ -80,7 +83,9 @@ def run(layers=32, tokens=2048, steps=5, storage="resident", graph=True, parity=
                "loss": round(float(loss), 5), "timing": "median of the per-forward times", "ms_per_forward_eager": round(ms_eager, 2),
                "tokens_per_s_eager": round(tokens / ms_eager * 1e3, 1),
                "resident_GiB_after_packing": round(mem_after_pack, 2),
-               "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2), "linear_routes": routes}
+               "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2), "linear_routes": routes,
+               # (torch's own GEMMs an eager forward called: the unquantised lm_head -- as in the reference -- and nothing else)
+               "vendor_gemm_calls_per_forward": vendor}
         if graph:
             g = graphs.GraphedForward(lambda t: model(t)[0], (ids,))
             for _ in range(2):

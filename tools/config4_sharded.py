@@ -74,6 +74,8 @@ def main():
             logits, loss = model(ids, labels=ids)
         torch.cuda.synchronize()
         sharded.COLLECTIVES.update(all_gather=0, bytes=0)
+        from mi355q import ops as _ops
+        _ops.vendor_gemm_calls(reset=True)
         if world > 1 or force:
             dist.barrier()
         t0 = time.perf_counter()
@@ -91,6 +93,8 @@ def main():
                           "all_gathers_per_forward": sharded.COLLECTIVES["all_gather"] // a.steps,
                           "gathered_MiB_per_forward": round(sharded.COLLECTIVES["bytes"] / a.steps / 2**20, 1),
                           "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+                          # (torch's own GEMMs a forward called: the unquantised lm_head -- as in the reference -- and nothing else)
+                          "vendor_gemm_calls_per_forward": {k: v // a.steps for k, v in sorted(_ops.vendor_gemm_calls().items())},
                           "logits_checksum": round(float(logits.double().abs().mean()), 8)}), flush=True)
     if world > 1 or force:
         dist.destroy_process_group()
