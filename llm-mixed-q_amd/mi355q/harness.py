@@ -54,21 +54,30 @@ class _Attention(nn.Module):
     def forward(self, x, mask, norm=None, residual=None):
         """`residual`: returns residual + attention (config["mi355q_fused_residual"] of out_proj: the add in out_proj's stores where
         that layer's route has it, Linear.forward_residual)"""
-        out = lambda o: self.out_proj(o) if residual is None else self.out_proj.forward_residual(o, residual)
+        out_ = lambda o: self.out_proj(o) if residual is None else self.out_proj.forward_residual(o, residual)
+        # head-sharded (sharded.shard_model(heads=True)): q / k / v arrive as this rank's heads only, the core runs on those, and
+        # ONE all-gather of its output stands in front of out_proj
+        hs = getattr(self, "mi355q_head_shard", None)
+        if hs is None:
+            out = out_
+        else:
+            from .sharded import gather_heads
+            out = lambda o: out_(gather_heads(o, hs[0], hs[1]))
         B, T, _ = x.shape
-        shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2).contiguous().view(B * self.nh, T, self.hd)
+        nh = self.nh if hs is None else self.q_proj.local.out_features // self.hd
+        shape = lambda t: t.view(B, T, nh, self.hd).transpose(1, 2).contiguous().view(B * nh, T, self.hd)
         c1 = self.qc["bmm_1"]
         if c1["name"] == "block_fp" and c1.get("mi355q_fused_attention", False):
             # both products, the mask and the softmax in one pass per 16 queries (the harness' mask is the causal one); the
             # kernel reads the [heads, T, hd] views of the projections in place: no `_shape(...).contiguous()` copies
-            heads = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
+            heads = lambda t: t.view(B, T, nh, self.hd).transpose(1, 2)
             if c1.get("mi355q_grouped_linear", False):       # q / k / v projections: one quantisation, one GEMM launch
                 qp, kp, vp = grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj), norm=norm)
             else:
                 qp, kp, vp = self.q_proj(x), self.k_proj(x), self.v_proj(x)
             o = get_quantized_func("attention", c1)(heads(qp * self.scaling), heads(kp), heads(vp), self.qc["bmm_0"], c1,
                                                     causal=True)
-            return out(o.transpose(1, 2).reshape(B, T, self.h))
+            return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
         q = shape(self.q_proj(x) * self.scaling)
         k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
         w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
@@ -76,11 +85,11 @@ class _Attention(nn.Module):
             # mask add, clamp and softmax folded into the product kernel (the harness' mask is the causal one)
             o = get_quantized_func("softmax_bmm", c1)(w, v, config=c1, causal=True)
         else:
-            w = w.view(B, self.nh, T, T) + mask
-            w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min)).view(B * self.nh, T, T)
+            w = w.view(B, nh, T, T) + mask
+            w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min)).view(B * nh, T, T)
             p = F.softmax(w, dim=-1)
             o = get_quantized_func("bmm", c1)(p, v, config=c1)
-        o = o.view(B, self.nh, T, self.hd).transpose(1, 2).reshape(B, T, self.h)
+        o = o.view(B, nh, T, self.hd).transpose(1, 2).reshape(B, T, nh * self.hd)
         return out(o)
 
 
@@ -222,9 +231,16 @@ class _LlamaAttention(nn.Module):
         self.register_buffer("sin", emb.sin()[None, None], persistent=False)
 
     def forward(self, x, mask, position_ids, norm=None, residual=None):
-        out = lambda o: self.o_proj(o) if residual is None else self.o_proj.forward_residual(o, residual)
+        out_ = lambda o: self.o_proj(o) if residual is None else self.o_proj.forward_residual(o, residual)
+        hs = getattr(self, "mi355q_head_shard", None)         # (head-sharded: see _Attention.forward)
+        if hs is None:
+            out = out_
+        else:
+            from .sharded import gather_heads
+            out = lambda o: out_(gather_heads(o, hs[0], hs[1]))
         B, T, _ = x.shape
-        shape = lambda t: t.view(B, T, self.nh, self.hd).transpose(1, 2)
+        nh = self.nh if hs is None else self.q_proj.local.out_features // self.hd
+        shape = lambda t: t.view(B, T, nh, self.hd).transpose(1, 2)
         if self.qc["matmul_1"].get("mi355q_grouped_linear", False):
             q, k, v = (shape(t) for t in grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj), norm=norm))
         else:
@@ -241,7 +257,7 @@ class _LlamaAttention(nn.Module):
         c1 = self.qc["matmul_1"]
         if c1["name"] == "block_fp" and c1.get("mi355q_fused_attention", False):
             o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd))
-            return out(o.transpose(1, 2).reshape(B, T, self.h))
+            return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
         w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])
         if c1["name"] in ("block_fp", "block_minifloat") and c1.get("mi355q_fused_softmax", False):
             o = get_quantized_func("softmax_matmul", c1)(w / math.sqrt(self.hd), v, config=c1, causal=True)
@@ -250,7 +266,7 @@ class _LlamaAttention(nn.Module):
             w = torch.max(w, w.new_full((), torch.finfo(w.dtype).min))
             p = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
             o = get_quantized_func("matmul", c1)(p, v, config=c1)
-        return out(o.transpose(1, 2).reshape(B, T, self.h))
+        return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
 
 
 class _LlamaLayer(nn.Module):

@@ -774,6 +774,9 @@ def grouped_linear(x, layers, norm=None):
     layers = list(layers)
     from ...sharded import RowShardedLinear
     if all(isinstance(l, RowShardedLinear) for l in layers):
+        if all(l.keep_local for l in layers):
+            # head-sharded q / k / v (sharded.shard_model(heads=True)): the rank's own heads, no collective here
+            return grouped_linear(x, [l.local for l in layers], norm=norm)
         # row-sharded projections (sharded.shard_model): this rank's shards as one group, one all-gather per projection
         for l in layers:                                       # (each product straight into its rank's segment of its gather buffer)
             l._aim_at_gather_buffer(x)

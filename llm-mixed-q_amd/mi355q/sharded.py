@@ -92,6 +92,10 @@ class RowShardedLinear(nn.Module):
         # (width, exponent_width, exponent_bias) of its data_in, and None or "relu"
         self.consumer_quantiser = None
         self.consumer_pre = None
+        # head-sharded attention (round 6, shard_model(heads=True)): a q / k / v projection whose row shard is a whole number of
+        # heads hands on this rank's [.., O/P] as it is -- the attention core runs on the rank's own heads and ONE all-gather of
+        # its output (gather_heads) feeds out_proj -- instead of one all-gather per projection
+        self.keep_local = False
 
     @classmethod
     def from_full(cls, cls_quantized, linear_fp32: nn.Linear, config: dict, group=None, always_gather: bool = False,
@@ -182,6 +186,8 @@ class RowShardedLinear(nn.Module):
         self.local._out_hint = self._gather_buf[rank * rows:(rank + 1) * rows]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.keep_local:
+            return self.local(x)
         self._aim_at_gather_buffer(x)
         try:
             y = self.local(x)
@@ -217,6 +223,26 @@ class RowShardedLinear(nn.Module):
         return self.local.in_features
 
 
+def gather_heads(o_loc: torch.Tensor, group=None, always_gather: bool = False, segments: bool = False):
+    """The ONE collective of a head-sharded attention block ("attention bmms could shard by head, independent units,
+    no collective until out_proj"; modeling_opt.py:206-328): this rank's heads' output [.., H/P] -> the block's [.., H] in
+    front of out_proj / o_proj.  Rank r's columns are heads r nh/P .. (r + 1) nh/P - 1 -- the rows of its q / k / v shards --
+    so the rank-major gather buffer [P, M, H/P] IS the column-segmented [M, H].  `segments`: hand on the ShardedRows (an int8
+    row-route consumer reads it in place), else the dense tensor."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not (always_gather and dist.is_initialized()):
+        return o_loc
+    lead = o_loc.shape[:-1]
+    o2 = o_loc.detach().reshape(-1, o_loc.shape[-1]).contiguous()
+    gathered = torch.empty(world * o2.shape[0], o2.shape[1], dtype=o2.dtype, device=o2.device)
+    dist.all_gather_into_tensor(gathered, o2, group=group)
+    COLLECTIVES["all_gather"] += 1
+    COLLECTIVES["bytes"] += gathered.numel() * gathered.element_size()
+    if segments:
+        return ShardedRows(gathered.view(world, o2.shape[0], o2.shape[1]), lead)
+    return gathered.view(world, o2.shape[0], o2.shape[1]).permute(1, 0, 2).reshape(*lead, world * o2.shape[1])
+
+
 # collectives issued by the sharded layers of this process (tests and the config-4 script read and reset it)
 COLLECTIVES = {"all_gather": 0, "bytes": 0}
 
@@ -242,7 +268,7 @@ def _quantised_gather_fits(consumer, features: int, group) -> bool:
             and list(bs)[-1] == 16 and all(b == 1 for b in list(bs)[:-1]) and features % (32 * world) == 0)
 
 
-def shard_model(model: nn.Module, group=None, always_gather: bool = False, gather: str = "dense") -> nn.Module:
+def shard_model(model: nn.Module, group=None, always_gather: bool = False, gather: str = "dense", heads: bool = True) -> nn.Module:
     """Row-shard every quantised Linear of a harness model (mi355q.harness.TinyOPTForCausalLM / TinyLlamaForCausalLM) in place:
     rank r keeps rows [r O/P, (r + 1) O/P) of each projection's weight and bias -- never cutting a [1,16] weight block or a
     [16] bias block -- quantises and packs only those, and one all-gather per projection rebuilds its output.  Call it on the
@@ -254,9 +280,15 @@ def shard_model(model: nn.Module, group=None, always_gather: bool = False, gathe
     "quantised" -- fc1 (OPT) applies fc2's relu and fc2's activation quantiser to ITS OWN slice and gathers the tiled bf16
     operand (2 bytes per value instead of 4, 1 / P of the quantiser's work per rank); fc2 then multiplies on the bf16 flavour
     of the tile GEMM with x in column segments (results as the per-block route's: exact products, fp32 accumulation).  Llama:
-    gate / up (grouped) -> silu(gate) * up and down_proj's quantiser on the rank's slice, ONE gather for the pair."""
+    gate / up (grouped) -> silu(gate) * up and down_proj's quantiser on the rank's slice, ONE gather for the pair.
+    `heads` (round 6, default): where a rank's row shard of q / k / v is a whole number of heads (num_heads % P == 0) the
+    attention core runs on THOSE heads -- the three projections are not gathered at all -- and one all-gather of the attention
+    output stands in front of out_proj / o_proj (gather_heads): OPT 6 -> 4 collectives a layer, Llama 7 -> 5, a third of the
+    gathered bytes and (P - 1) / P of the attention work gone; the [1,16] blocks of all four attention operands lie inside one
+    head, so every head's result is the unsharded model's, bit for bit."""
     from .quantize.quantized_modules.linear import _LinearBase
     family = "llama" if hasattr(model.layers[0], "gate_proj") else "opt"
+    world_ = dist.get_world_size(group) if dist.is_initialized() else 1
     for layer in model.layers:
         for owner_name, names in SHARDED_PROJECTIONS[family]:
             owner = layer if owner_name is None else getattr(layer, owner_name)
@@ -294,6 +326,10 @@ def shard_model(model: nn.Module, group=None, always_gather: bool = False, gathe
                     c2 = nxt.local.config if isinstance(nxt, RowShardedLinear) else nxt.config
                     wrapped.consumer_quantiser = (c2["data_in_width"], c2["data_in_exponent_width"], c2["data_in_exponent_bias"])
                     wrapped.consumer_pre = "silu_mul" if gated else "relu"
+                if (heads and owner_name == "self_attn" and name in ("q_proj", "k_proj", "v_proj")
+                        and owner.nh % world_ == 0 and (lin.out_features // world_) % owner.hd == 0):
+                    wrapped.keep_local = True
+                    owner.mi355q_head_shard = (group, always_gather)
                 setattr(owner, name, wrapped)
     model.mi355q_sharded = True
     return model

@@ -127,8 +127,11 @@ def _model_worker(rank, world, port, q):
     try:
         from mi355q import harness, sharded
         res = []
-        for family, width, mixed, knobs, gather in (("opt", 4, True, False, "dense"), ("opt", 4, True, True, "segments"),
-                                                    ("llama", 6, False, True, "dense")):
+        # heads: the attention core on the rank's own heads, one all-gather of its output in front of out_proj / o_proj (round 6:
+        # OPT 4 collectives a layer, Llama 5) -- or heads replicated and q, k, v gathered one by one (6 / 7)
+        for family, width, mixed, knobs, gather, heads in (("opt", 4, True, False, "dense", True), ("opt", 4, True, True, "segments", True),
+                                                           ("llama", 6, False, True, "dense", True), ("opt", 4, True, True, "dense", False),
+                                                           ("llama", 6, False, False, "dense", True), ("llama", 6, False, True, "dense", False)):
             def build():
                 torch.manual_seed(11)
                 if family == "opt":
@@ -149,13 +152,14 @@ def _model_worker(rank, world, port, q):
                 whole = build()
                 for _ in range(2):
                     ref, ref_loss = whole(ids, labels=ids)
-                model = sharded.shard_model(build(), always_gather=True, gather=gather)
+                model = sharded.shard_model(build(), always_gather=True, gather=gather, heads=heads)
                 for _ in range(2):                      # (first forward packs, the second runs the settled routes)
                     sharded.COLLECTIVES.update(all_gather=0, bytes=0)
                     got, loss = model(ids, labels=ids)
-            n_proj = 6 if family == "opt" else 7
+            n_proj = (4 if family == "opt" else 5) if heads else (6 if family == "opt" else 7)
             packed = model.layers[0].self_attn.q_proj.local._packed is not None
-            res.append((family, knobs, gather, bool(torch.equal(got, ref)), float(loss) == float(ref_loss),
+            assert model.layers[0].self_attn.q_proj.keep_local == heads
+            res.append((family, knobs, f"{gather} heads={heads}", bool(torch.equal(got, ref)), float(loss) == float(ref_loss),
                         sharded.COLLECTIVES["all_gather"] == 2 * n_proj, packed))
         q.put((rank, res))
     except Exception as e:
@@ -169,7 +173,9 @@ def _model_worker(rank, world, port, q):
 def test_row_sharded_model_nccl(world):
     """row (h): every quantised Linear of a harness model row-sharded (sharded.shard_model), real RCCL all-gathers (at world size
     1 too), QUANTISED layers -- W4A4 with mixed per-layer widths (BASELINE config 4's kind) and W6A6 Llama: logits and loss equal
-    the unsharded model's bit for bit, one all-gather per projection"""
+    the unsharded model's bit for bit; with the attention core head-sharded (round 6: each rank its own heads, ONE all-gather of
+    the attention output in front of out_proj / o_proj -- OPT 6 -> 4 collectives a layer, Llama 7 -> 5) and with the heads
+    replicated (one all-gather per projection)"""
     import torch
     import torch.multiprocessing as mp
     if torch.cuda.device_count() < world:
@@ -275,7 +281,7 @@ def _quantised_gather_worker(rank, world, port, q):
                 sharded.COLLECTIVES.update(all_gather=0, bytes=0)
                 got, loss = model(ids, labels=ids)
         res["llama_modes"] = [model.layers[i].gate_proj.gather for i in range(2)] + [model.layers[i].down_proj.gather for i in range(2)]
-        res["llama_collectives"] = sharded.COLLECTIVES["all_gather"]          # q, k, v, o, (gate + up as one), down per layer
+        res["llama_collectives"] = sharded.COLLECTIVES["all_gather"]          # attention heads, o, (gate + up as one), down per layer
         res["llama_logits_err"] = float((got - ref).abs().max() / ref.abs().max())
         res["llama_loss_err"] = abs(float(loss) - float(ref_loss))
         q.put((rank, res))
@@ -311,7 +317,7 @@ def test_quantised_gather_nccl(world):
         assert res["gathered"] and res["dense_raises"] and res["fc1_exact"], res
         assert 2.0 <= res["bytes_per_value"] <= 2.7, res
         assert res["err_vs_oracle"] <= 4e-6 and res["err_vs_unsharded"] <= 4e-6, res
-        assert res["model_modes"] == ["quantised", "quantised"] and res["model_collectives"] == 12, res
+        assert res["model_modes"] == ["quantised", "quantised"] and res["model_collectives"] == 8, res     # (heads + out_proj + fc1 + fc2 a layer)
         assert res["model_logits_err"] <= 5e-2 and res["model_loss_err"] <= 5e-3, res
-        assert res["llama_modes"] == ["quantised", "quantised", "dense", "dense"] and res["llama_collectives"] == 12, res
+        assert res["llama_modes"] == ["quantised", "quantised", "dense", "dense"] and res["llama_collectives"] == 8, res   # (heads, o, gate + up as one, down)
         assert res["llama_logits_err"] <= 5e-2 and res["llama_loss_err"] <= 5e-3, res

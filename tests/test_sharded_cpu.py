@@ -119,14 +119,17 @@ def _model_worker(rank, world, port, out_q):
         for family in ("opt",):
             ids = torch.randint(0, 96, (2, 16), generator=torch.Generator().manual_seed(3))
             ref, ref_loss = _build_model(family, torch, harness)(ids, labels=ids)
-            model = sharded.shard_model(_build_model(family, torch, harness))
-            lin = model.layers[0].self_attn.q_proj
-            assert isinstance(lin, sharded.RowShardedLinear) and lin.local.out_features == 64 // world
-            sharded.COLLECTIVES.update(all_gather=0, bytes=0)
-            got, loss = model(ids, labels=ids)
-            n_proj = 6 if family == "opt" else 7
-            res.append((family, bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-6)), abs(float(loss) - float(ref_loss)) < 1e-5,
-                        sharded.COLLECTIVES["all_gather"] == 2 * n_proj))
+            # heads = True (default, round 6): q / k / v keep this rank's two heads, ONE all-gather of the attention output in front
+            # of out_proj -- 4 collectives a layer; heads = False: heads replicated, one all-gather per projection -- 6
+            for heads, per_layer in ((True, 4), (False, 6 if family == "opt" else 7)):
+                model = sharded.shard_model(_build_model(family, torch, harness), heads=heads)
+                lin = model.layers[0].self_attn.q_proj
+                assert isinstance(lin, sharded.RowShardedLinear) and lin.local.out_features == 64 // world
+                assert lin.keep_local == heads and (getattr(model.layers[0].self_attn, "mi355q_head_shard", None) is not None) == heads
+                sharded.COLLECTIVES.update(all_gather=0, bytes=0)
+                got, loss = model(ids, labels=ids)
+                res.append((f"{family} heads={heads}", bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-6)), abs(float(loss) - float(ref_loss)) < 1e-5,
+                            sharded.COLLECTIVES["all_gather"] == 2 * per_layer))
         out_q.put((rank, res))
     except Exception as e:
         out_q.put((rank, repr(e)))
@@ -135,8 +138,9 @@ def _model_worker(rank, world, port, out_q):
 
 
 def test_row_sharded_model_gloo_world2():
-    """row (h): a sharded MODEL -- every quantised Linear of the OPT harness split over two gloo ranks, heads and norms
-    replicated -- gives the unsharded logits and loss, with one all-gather per projection"""
+    """row (h): a sharded MODEL -- every quantised Linear of the OPT harness split over two gloo ranks -- gives the unsharded
+    logits and loss: with the attention core head-sharded (each rank two of the four heads, one all-gather of the attention
+    output in front of out_proj: four collectives a layer) and with the heads replicated (one all-gather per projection: six)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

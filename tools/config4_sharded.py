@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=50272)
     ap.add_argument("--no-knobs", action="store_true", help="the reference's step-by-step attention / separate launches")
     ap.add_argument("--gather", default="dense", choices=["dense", "segments", "quantised"])
+    ap.add_argument("--no-heads", action="store_true", help="heads replicated, q / k / v gathered one by one (round 5's partition) "
+                                                             "instead of the attention core on the rank's own heads")
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     force = world == 1 and os.environ.get("MI355Q_FORCE_DIST") == "1"
@@ -67,7 +69,7 @@ def main():
                 p.mul_(torch.exp(0.5 * torch.randn(p.shape[0], 1)))
     model = model.to(dev).eval()
     if world > 1 or force:
-        sharded.shard_model(model, always_gather=force, gather=a.gather)
+        sharded.shard_model(model, always_gather=force, gather=a.gather, heads=not a.no_heads)
     ids = torch.randint(0, a.vocab, (1, a.tokens), generator=torch.Generator().manual_seed(1)).to(dev)
     with torch.no_grad():
         for _ in range(2):                                  # first forward packs the weights, second settles the routes
@@ -87,7 +89,7 @@ def main():
         ms = (time.perf_counter() - t0) / a.steps * 1e3
     if rank == 0:
         print(json.dumps({"config": "BASELINE config 4: OPT-1.3B width, W4A4 block_fp + mixed [model_layer_i] sections",
-                          "layers": a.layers, "tokens": a.tokens, "world": world, "forced_dist": force, "gather": a.gather,
+                          "layers": a.layers, "tokens": a.tokens, "world": world, "forced_dist": force, "gather": a.gather, "head_sharded_attention": not a.no_heads,
                           "knobs": not a.no_knobs, "loss": round(float(loss), 6), "ms_per_forward": round(ms, 3),
                           "tokens_per_s": round(a.tokens / ms * 1e3, 1),
                           "all_gathers_per_forward": sharded.COLLECTIVES["all_gather"] // a.steps,
