@@ -878,32 +878,39 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_align_rows_kernel(const Qu
         int8_t* dst = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + ((lane >> 2) & 3) * 256 +
                       (row & 15) * 16 + (lane & 3) * 4;
         uint8_t* cdst = a.code + row * nkb + wave * 16 + (lane >> 2);
-        if constexpr (ST16 && FULL && MAXIT == 4) {
-            // 16-byte stores (round 6): the quad's four lanes hold bytes 4 q .. 4 q + 3 of the quad's block in each of the four
-            // slabs; a 4 x 4 transpose inside the quad (two butterfly stages of DPP quad permutes) leaves lane q with the WHOLE
-            // block of slab q: one dwordx4 store per lane and row instead of four dword stores (a quarter of the store
-            // instructions, every one of them 16 bytes a lane), and one exponent byte per lane instead of four per quad leader.
+        if constexpr (ST16) {
+            // 16-byte stores (round 6): the quad's four lanes hold bytes 4 q .. 4 q + 3 of the quad's block in each of four
+            // consecutive slabs; a 4 x 4 transpose inside the quad (two butterfly stages of DPP quad permutes) leaves lane q with the
+            // WHOLE block of slab 4 g + q: one dwordx4 store per lane and four slabs instead of four dword stores (a quarter of the
+            // store instructions, every one of them 16 bytes a lane), and one exponent byte per lane instead of four per quad
+            // leader (20.6 -> 19.5 us at 4096 x 4096, profiles/r06_qrows_variants.txt).
             const int q = lane & 3;
-            unsigned r0 = pk[0], r1 = pk[1], r2 = pk[2], r3 = pk[3];
-            {   // stage 1: lanes q ^ 1 exchange (r0 <-> r1) and (r2 <-> r3) off-diagonal halves
-                const bool odd = q & 1;
-                const unsigned s01 = odd ? r0 : r1, s23 = odd ? r2 : r3;
-                const unsigned g01 = (unsigned)__builtin_amdgcn_mov_dpp((int)s01, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-                const unsigned g23 = (unsigned)__builtin_amdgcn_mov_dpp((int)s23, 0xB1, 0xF, 0xF, true);
-                if (odd) { r0 = g01; r2 = g23; } else { r1 = g01; r3 = g23; }
+            int8_t* d16 = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + ((lane >> 2) & 3) * 256 + (row & 15) * 16;
+#pragma unroll
+            for (int g = 0; g < MAXIT / 4; ++g) {
+                unsigned r0 = pk[4 * g], r1 = pk[4 * g + 1], r2 = pk[4 * g + 2], r3 = pk[4 * g + 3];
+                {   // stage 1: lanes q ^ 1 exchange the off-diagonal halves of (r0, r1) and of (r2, r3)
+                    const bool odd = q & 1;
+                    const unsigned s01 = odd ? r0 : r1, s23 = odd ? r2 : r3;
+                    const unsigned g01 = (unsigned)__builtin_amdgcn_mov_dpp((int)s01, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                    const unsigned g23 = (unsigned)__builtin_amdgcn_mov_dpp((int)s23, 0xB1, 0xF, 0xF, true);
+                    if (odd) { r0 = g01; r2 = g23; } else { r1 = g01; r3 = g23; }
+                }
+                {   // stage 2: lanes q ^ 2 exchange (r0, r2) and (r1, r3)
+                    const bool hi = q & 2;
+                    const unsigned s02 = hi ? r0 : r2, s13 = hi ? r1 : r3;
+                    const unsigned g02 = (unsigned)__builtin_amdgcn_mov_dpp((int)s02, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                    const unsigned g13 = (unsigned)__builtin_amdgcn_mov_dpp((int)s13, 0x4E, 0xF, 0xF, true);
+                    if (hi) { r0 = g02; r1 = g13; } else { r2 = g02; r3 = g13; }
+                }
+                // lane q now holds dwords 0..3 (= bytes 0..15) of the block of slab 4 g + q
+                const int it = 4 * g + q, kb = it * 64 + wave * 16 + (lane >> 2);
+                const int cq = q == 0 ? code[4 * g] : q == 1 ? code[4 * g + 1] : q == 2 ? code[4 * g + 2] : code[4 * g + 3];
+                if (FULL || (it < nit && kb < nkb)) {
+                    *reinterpret_cast<uint4*>(d16 + it * 16384) = make_uint4(r0, r1, r2, r3);
+                    cdst[it * 64] = (uint8_t)(flagged ? E : cq);
+                }
             }
-            {   // stage 2: lanes q ^ 2 exchange (r0 <-> r2) and (r1 <-> r3)
-                const bool hi = q & 2;
-                const unsigned s02 = hi ? r0 : r2, s13 = hi ? r1 : r3;
-                const unsigned g02 = (unsigned)__builtin_amdgcn_mov_dpp((int)s02, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-                const unsigned g13 = (unsigned)__builtin_amdgcn_mov_dpp((int)s13, 0x4E, 0xF, 0xF, true);
-                if (hi) { r0 = g02; r1 = g13; } else { r2 = g02; r3 = g13; }
-            }
-            // lane q now holds dwords 0..3 (= bytes 0..15) of the block of slab q
-            int8_t* d16 = mt + ((row >> 4) * (K >> 6) + wave * 4 + (lane >> 4)) * 1024 + ((lane >> 2) & 3) * 256 + (row & 15) * 16 + q * 16384;
-            *reinterpret_cast<uint4*>(d16) = make_uint4(r0, r1, r2, r3);
-            const int cq = q == 0 ? code[0] : q == 1 ? code[1] : q == 2 ? code[2] : code[3];
-            cdst[q * 64] = (uint8_t)(flagged ? E : cq);
         } else {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
@@ -922,36 +929,29 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_align_rows_kernel(const Qu
     }
 }
 
-constexpr int QROWS_DEFAULT_VARIANT = 0;     // (the A/B of round 6 decides: profiles/r06_qrows_variants.txt)
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
                             int* list_to_clear, hipStream_t st, int bcap) {
     long long grid = a.rows;
     if (grid > 65536) grid = 65536;
-    // plain rows: a fixed grid of 4 workgroups per compute unit, several rows each with the next row's loads in flight
-    // (MI355Q_QROWS_GRID / MI355Q_QROWS_VARIANT: A/B runs of tools/dbg/qrows_time.py -- bit 0: 16-byte stores, bit 1: the build
-    //  without the pre-op code)
+    // plain rows: a fixed grid of SIX workgroups per compute unit (what the build without the pre-op code admits: 77 registers),
+    // several rows each with the next row's loads in flight.  Round 6, tools/dbg/qrows_ab.py -> profiles/r06_qrows_variants.txt, at
+    // 4096 x 4096: 20.6 us (round 5: 121 registers, 4 workgroups a compute unit, dword stores) -> 19.2 (no pre-op code, 16-byte
+    // stores) -> 18.0 (six workgroups a compute unit).  MI355Q_QROWS_GRID / MI355Q_QROWS_VARIANT = 0 (round 5's kernel): A/B runs.
     const int qgrid_env = getenv("MI355Q_QROWS_GRID") ? atoi(getenv("MI355Q_QROWS_GRID")) : 0;
-    const int qvariant = getenv("MI355Q_QROWS_VARIANT") ? atoi(getenv("MI355Q_QROWS_VARIANT")) : QROWS_DEFAULT_VARIANT;
-    const int qgrid = qgrid_env > 0 ? qgrid_env : 1024;
+    const bool old = getenv("MI355Q_QROWS_VARIANT") && atoi(getenv("MI355Q_QROWS_VARIANT")) == 0;
+    const int qgrid = qgrid_env > 0 ? qgrid_env : (old ? 1024 : 1536);
     if (qgrid > 0 && a.pre_op == 0 && !a.seg_len && grid > qgrid) grid = qgrid;
     if (grid < 1) grid = 1;
-    if (a.cols == 4096 && a.pre_op == 0 && !a.seg_len && qvariant != 0) {
-#define MI355Q_LAUNCH_ROWS_V(PRE_, ST16_)                                                                             \
-        hipLaunchKernelGGL((bfp_quant_align_rows_kernel<4, true, false, false, PRE_, ST16_>), (unsigned)grid, 256, 0, st, a, mt, flag, \
-                           rscale, exp_offset, list, list_to_clear, bcap)
-        if (qvariant == 1) MI355Q_LAUNCH_ROWS_V(true, true);
-        else if (qvariant == 2) MI355Q_LAUNCH_ROWS_V(false, false);
-        else if (qvariant == 3) MI355Q_LAUNCH_ROWS_V(false, true);
-        else if (qvariant == 6) hipLaunchKernelGGL((bfp_quant_align_rows_kernel<4, true, false, false, false, false, 8>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear, bcap);
-        else hipLaunchKernelGGL((bfp_quant_align_rows_kernel<4, true, false, false, false, true, 8>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, list_to_clear, bcap);
-#undef MI355Q_LAUNCH_ROWS_V
-        return (int)hipGetLastError();
-    }
+    // segmented rows: the round-5 build; rows with a pre-op in front: its code compiled in; plain rows: the lean build.  16-byte
+    // stores where every lane holds a block in every slab (the guarded flavour of that transpose put its scalars in scratch memory)
+#define MI355Q_LAUNCH_ROWS_T(...)                                                                                     \
+    hipLaunchKernelGGL((bfp_quant_align_rows_kernel<__VA_ARGS__>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, \
+                       list_to_clear, bcap)
 #define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
-    if (a.seg_len) hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, false, true>), (unsigned)grid, 256, 0, st, a, mt, flag,  \
-                                      rscale, exp_offset, list, list_to_clear, bcap);                                  \
-    else hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_, false>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, \
-                            exp_offset, list, list_to_clear, bcap)
+    if (a.seg_len) MI355Q_LAUNCH_ROWS_T(MAXIT_, false, true);                                                         \
+    else if (old) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false);                                                         \
+    else if (a.pre_op) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, true, FULL_);                                \
+    else MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, false, FULL_)
     if (a.cols == 4096) MI355Q_LAUNCH_ROWS(4, true);            // every lane holds a block in every slab: no guards
     else if (a.cols <= 4096) MI355Q_LAUNCH_ROWS(4, false);
     else if (a.cols == 8192) MI355Q_LAUNCH_ROWS(8, true);
@@ -961,6 +961,7 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     else
         return MI355Q_E_UNSUPPORTED;
 #undef MI355Q_LAUNCH_ROWS
+#undef MI355Q_LAUNCH_ROWS_T
     return (int)hipGetLastError();
 }
 
