@@ -195,7 +195,14 @@ def robustness_summary(torch, ops, device, steps=50):
             e_ev.record()
             torch.cuda.synchronize()
             ms = min(ms, a_ev.elapsed_time(e_ev) / steps)
-    route = "bf16 per-block exponents (tile GEMM on bf16 MFMA)" if lin._uses_bf16_route() else f"int8 {lin._align_mode}"
+    if lin._uses_bf16_route():
+        route = "bf16 per-block exponents (tile GEMM on bf16 MFMA)"
+    elif getattr(lin, "_mixed", None) is not None:
+        cl = lin._mixed["classes"]
+        route = (f"mixed contraction, one launch: {cl.K0} of {K} columns row-aligned on the int8 MFMA, {cl.K1} (the block columns with "
+                 "outlier channels) as per-block bf16 on the bf16 MFMA")
+    else:
+        route = f"int8 {lin._align_mode}"
     pick = np.sort(np.random.default_rng(6).choice(M, size=32, replace=False))
     ref = O.bfp_linear_int(x.cpu().numpy()[pick], w.numpy(), b.numpy(), CFG)
     err = float(np.abs(y[torch.from_numpy(pick).to(device)].cpu().numpy() - ref).max() / np.abs(ref).max())

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 22
+#define MI355Q_ABI_VERSION 23
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -363,6 +363,33 @@ int mi355q_block_fp_quantize_mx(const float* x, uint8_t* codes16, uint8_t* codes
 int mi355q_mx_gemm(const uint8_t* x16, const uint8_t* x8, const uint8_t* xs, const uint8_t* w16, const uint8_t* w8, const uint8_t* ws,
                    const int32_t* bad2, const float* x_fp32, const float* w_fp32, const float* bias, float* y, int64_t M, int64_t N,
                    int64_t K, int64_t ldy, int32_t x_width, int32_t x_exponent_width, int32_t x_exponent_bias, void* stream);
+
+/* The contraction in TWO COLUMN CLASSES in one launch (round 6, ABI 23) -- for activations with OUTLIER CHANNELS, the case the
+ * reference's README (README.md:9-11, docs/images/fig-1.png) is about: a few input channels tens of times larger than the rest.
+ * The block columns that hold such a channel lie several exponents above their rows' window and their exponents follow ONE
+ * element's magnitude, so no row window of the int8 container holds them (K / 64 channels x 60: 20 % of all blocks are
+ * exceptions) and the whole layer had to take the bf16 flavour at half the int8 rate.  Here the caller splits the columns of x
+ * and W (quantized_modules/linear.py:59-76: F.linear contracts over in_features in any order) into class 0 -- K0 values, row-
+ * aligned int8 operands with their exception lists, exactly what mi355q_bfp_gemm_aligned takes -- and class 1 -- K1 values as
+ * tiled bf16 operands (mi355q_block_fp_quantize_bf16_tiled / mi355q_bf16_tile), every block with its own exponent:
+ *     y = sx sw (x0 . w0^T) [int8 MFMA, int32 sums turned into fp32 in place] + x1 . w1^T [bf16 MFMA, same registers] + bias
+ * K0 % 128 == 0, K0 >= 256, K1 % 64 == 0, K1 >= 128, 120-entry buckets on both class-0 operands, else MI355Q_E_UNSUPPORTED.
+ * Exact products, fp32 accumulation across the class boundary (the reference's fp32 GEMM sums in fp32 throughout); an
+ * overflowed class-0 bucket turns the launch into its own exact tile-by-tile fallback like mi355q_bfp_gemm_aligned's. */
+/* ... and the activation side of it in ONE pass over x [rows, K] fp32: every [1,16] block quantised exactly as
+ * mi355q_block_fp_quantize_aligned_rows does, then sent where the caller's column map says -- colmap[kb] (uint16, one word per
+ * block column) = position | class << 15: class 0 -> block `position` of the row-aligned int8 operand [rows, 16 n0_blocks]
+ * (mant_tiled / exp_out / rowflag / rowscale / list as for mi355q_block_fp_quantize_aligned_rows; the row's exponent is decided
+ * over its class-0 blocks only; exception entries record the block's position in THAT operand), class 1 -> block `position` of
+ * the tiled bf16 operand [rows, 16 n1_blocks] (mi355q_bfp_tiled_bytes(rows, 32 n1_blocks) bytes), every block with its own
+ * exponent.  n0_blocks % 4 == 0, n1_blocks % 2 == 0 (whole 64-byte K-steps); positions are a permutation within each class;
+ * buffers zero-initialised once by the caller (rows past `rows` up to the next multiple of 128 are read by the product). */
+int mi355q_block_fp_quantize_classes(const float* x, const uint16_t* colmap, int64_t n0_blocks, int64_t n1_blocks, int8_t* mant_tiled,
+                                     uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list, int32_t* list_to_clear,
+                                     void* x1_bf16_tiled, int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                     int32_t exponent_bias, int32_t bucket_cap, void* stream);
+int mi355q_bfp_gemm_mixed(const mi355q_bfp_operand* x0, const mi355q_bfp_operand* w0, const void* x1_bf16_tiled, const void* w1_bf16_tiled,
+                          const float* bias, float* y, int64_t M, int64_t N, int64_t K0, int64_t K1, int64_t ldy, void* stream);
 
 /* Several weight operands of the SAME shape against ONE activation operand in one launch (the q / k / v projections of an
  * attention block, gate / up of a gated MLP: reference modules called one after the other on the same input,

@@ -51,10 +51,12 @@ __device__ __forceinline__ unsigned shl_packed(unsigned pk, int s) {
 
 // Returns true when the row carries one exponent (E); pk[] is rewritten in place (shifted / zeroed).
 // When it returns false nothing was changed.  All 256 threads must call it (workgroup barriers inside).
-template <int MAXIT, bool FULL = false>
-__device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&amax)[MAXIT], const int (&code)[MAXIT], int nit,
-                                          int nkb, long long row, int* __restrict__ list, RowAlignSmem& sm, int& E,
-                                          int bcap = ROW_BCAP) {
+// MAPPED (round 6, the class-aware quantiser of the mixed contraction): the block index an exception entry records is kbd[it]
+// -- the block's position in the operand it is written to -- instead of its position in the row it was read from
+template <int MAXIT, bool FULL, bool MAPPED>
+__device__ __forceinline__ bool align_row_impl(unsigned (&pk)[MAXIT], const int (&amax)[MAXIT], const int (&code)[MAXIT], int nit,
+                                               int nkb, long long row, int* __restrict__ list, RowAlignSmem& sm, int& E,
+                                               int bcap, const int (&kbd)[MAXIT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int BIG = 1 << 20;
     bool has[MAXIT];
@@ -137,7 +139,7 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
     for (int it = 0; it < MAXIT; ++it) {
         if (exc[it]) {
             int* e = bucket + EXC_HEADER + EXC_ENTRY * (base + slot[it]);
-            if ((lane & 3) == 0) { e[0] = (int)row; e[1] = it * 64 + wave * 16 + (lane >> 2); e[2] = code[it]; e[3] = 0; }
+            if ((lane & 3) == 0) { e[0] = (int)row; e[1] = MAPPED ? kbd[it] : it * 64 + wave * 16 + (lane >> 2); e[2] = code[it]; e[3] = 0; }
             e[4 + (lane & 3)] = (int)pk[it];
             pk[it] = 0u;
         } else if (has[it]) {
@@ -146,6 +148,13 @@ __device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&ama
     }
     E = best;
     return true;
+}
+
+template <int MAXIT, bool FULL = false>
+__device__ __forceinline__ bool align_row(unsigned (&pk)[MAXIT], const int (&amax)[MAXIT], const int (&code)[MAXIT], int nit,
+                                          int nkb, long long row, int* __restrict__ list, RowAlignSmem& sm, int& E,
+                                          int bcap = ROW_BCAP) {
+    return align_row_impl<MAXIT, FULL, false>(pk, amax, code, nit, nkb, row, list, sm, E, bcap, code);     // (kbd unused)
 }
 
 }  // namespace mi355q

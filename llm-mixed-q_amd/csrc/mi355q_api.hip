@@ -515,6 +515,41 @@ int mi355q_block_fp_quantize_aligned_rows_seg(const float* x, const float* x2, c
                                       seg_len, seg_stride, width, exponent_width, exponent_bias, bucket_cap, stream);
 }
 
+// the class-aware activation quantiser of the mixed contraction (mi355q.h; mi355q_quant_cls.hip)
+int mi355q_block_fp_quantize_classes(const float* x, const uint16_t* colmap, int64_t n0_blocks, int64_t n1_blocks, int8_t* mant_tiled,
+                                     uint8_t* exp_out, uint8_t* rowflag, float* rowscale, int32_t* list, int32_t* list_to_clear,
+                                     void* x1_bf16_tiled, int64_t rows, int64_t K, int32_t width, int32_t exponent_width,
+                                     int32_t exponent_bias, int32_t bucket_cap, void* stream) {
+    if (rows < 0 || K < 0 || n0_blocks < 0 || n1_blocks < 0 || bucket_cap < 0 || bucket_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!x || !colmap || !mant_tiled || !exp_out || !rowflag || !rowscale || !list || !x1_bf16_tiled || list_to_clear == list)
+        return MI355Q_E_BADARG;
+    // whole 64-byte K-steps in both operands: class 0 a multiple of 4 blocks, class 1 a multiple of 2
+    if (K % 64 != 0 || K > MI355Q_ROW_ALIGN_MAX_K || (n0_blocks + n1_blocks) * 16 != K || n0_blocks % 4 || n1_blocks % 2 || n0_blocks >= 32768 ||
+        n1_blocks >= 32768)
+        return MI355Q_E_UNSUPPORTED;
+    if (exponent_width < 1 || exponent_width > 8 || width < 2 || width > 8) return MI355Q_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(mant_tiled) | reinterpret_cast<uintptr_t>(x1_bf16_tiled)) % 16) return MI355Q_E_ALIGN;
+    if (exponent_bias == MI355Q_BIAS_DEFAULT) exponent_bias = (1 << (exponent_width - 1)) - 1;
+    if (exponent_bias < 0) return MI355Q_E_UNSUPPORTED;
+    QuantArgs a{};
+    a.x = x;
+    a.code = exp_out;
+    a.lead = 1; a.rows = rows; a.cols = K;
+    a.b0 = 1; a.b1 = 16;
+    a.n_elems = rows * K;
+    a.nbr = rows; a.nbc = K / 16;
+    a.n_blocks = rows * (K / 16);
+    a.flags = MI355Q_ZERO_BLOCK_FAST;
+    a.code_bias = exponent_bias;
+    a.e_min = -exponent_bias;
+    a.e_max = (1 << exponent_width) - 1 - exponent_bias;
+    set_mantissa(a, width - 1);
+    return launch_quant_classes(a, colmap, (int)n0_blocks, (int)n1_blocks, mant_tiled, rowflag, rowscale, exponent_bias + width - 1, list,
+                                list_to_clear, static_cast<uint16_t*>(x1_bf16_tiled), static_cast<hipStream_t>(stream),
+                                bucket_cap_of(bucket_cap));
+}
+
 static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
                             int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     if (!x || !w || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
@@ -566,6 +601,38 @@ static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_opera
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
                             int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     return gemm_aligned_impl(x, w, bias, y, M, N, K, ldy, stream);
+}
+
+// y = x . w^T + bias with the contraction in two column classes (mi355q.h): class 0 = K0 values as row-aligned int8 operands with
+// their exception lists (what mi355q_bfp_gemm_aligned multiplies), class 1 = K1 values as tiled bf16 operands (what
+// mi355q_bf16_gemm_tiled multiplies) -- one launch of the 256 x 256 tile kernel
+int mi355q_bfp_gemm_mixed(const mi355q_bfp_operand* x0, const mi355q_bfp_operand* w0, const void* x1, const void* w1, const float* bias,
+                          float* y, int64_t M, int64_t N, int64_t K0, int64_t K1, int64_t ldy, void* stream) {
+    if (!x0 || !w0 || M < 0 || N < 0 || K0 < 0 || K1 < 0 || ldy < N) return MI355Q_E_BADARG;
+    if (M == 0 || N == 0) return 0;
+    if (!y || !x1 || !w1 || !x0->mant || !x0->exp || !w0->mant || !w0->exp || !x0->rowflag || !w0->rowflag || !x0->gscale || !w0->gscale ||
+        !x0->list || !w0->list)
+        return MI355Q_E_BADARG;
+    if (x0->mbits < 1 || x0->mbits > 7 || w0->mbits < 1 || w0->mbits > 7) return MI355Q_E_BADARG;
+    if (x0->row_aligned != 1 || w0->row_aligned != 1 || bucket_cap_of(x0->list_cap) != ROW_BCAP || bucket_cap_of(w0->list_cap) != ROW_BCAP ||
+        K0 % 128 != 0 || K0 < 256 || K0 > MI355Q_ROW_ALIGN_MAX_K || K1 % 64 != 0 || K1 < 128 || K1 > MI355Q_ROW_ALIGN_MAX_K)
+        return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x0->mant) | reinterpret_cast<uintptr_t>(w0->mant) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(w1)) % 16)
+        return MI355Q_E_ALIGN;
+    GemmArgs a{x0->mant, x0->exp, w0->mant, w0->exp, bias, y, M, N, K0, ldy,
+               x0->exp_bias + x0->mbits + w0->exp_bias + w0->mbits, 1,
+               x0->exp_bias + x0->mbits, w0->exp_bias + w0->mbits,
+               ROW_BCAP, ROW_BCAP, 0};
+    a.x_mbits = x0->mbits;
+    a.w_mbits = w0->mbits;
+    a.xm1 = static_cast<const int8_t*>(x1);
+    a.wm1 = static_cast<const int8_t*>(w1);
+    a.K1 = K1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t te = g_timing.begin(st);
+    const int rc = launch_bfp_gemm_v9_mixed(a, x0->gscale, w0->gscale, x0->list, w0->list, st, x0->rowflag, w0->rowflag);
+    g_timing.end(te, st);
+    return rc;
 }
 
 static int gemm_aligned_multi_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const float* const* bias,

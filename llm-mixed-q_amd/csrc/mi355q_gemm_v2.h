@@ -224,7 +224,8 @@ __device__ __forceinline__ void bfp_gemm_v2_tile(const GemmArgs& a, const uint8_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long row = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                if (row < a.M) a.y[row * a.ldy + col] = acc[i][j][r] + bv;
+                // (a.resid: the caller's residual -- the mixed contraction's class-1 product, mi355q_gemm_v9.hip -- in the store)
+                if (row < a.M) a.y[row * a.ldy + col] = acc[i][j][r] + bv + (a.resid ? a.resid[row * a.ldr + col] : 0.f);
             }
         }
 }

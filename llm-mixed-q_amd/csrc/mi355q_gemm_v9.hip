@@ -33,6 +33,18 @@
 
 #include "mi355q_gemm_tile.h"
 
+// The mixed contraction (MIXED below) is built as its OWN translation unit, mi355q_gemm_v9m.hip = this file with V9_MIXED_TU
+// defined: the accumulators become a parameter of the K-step body there (it runs on int32 and on fp32 registers), which in this
+// unit would change the register allocation of the kernels that ship since round 3 -- here the text of their K loop is untouched.
+#ifdef V9_MIXED_TU
+#define bfp_gemm_v9 bfp_gemm_v9m
+#define V9_ACCP auto& acc,
+#define V9_ACCA(x) x,
+#else
+#define V9_ACCP
+#define V9_ACCA(x)
+#endif
+
 namespace mi355q {
 
 constexpr int V9_HALF = 256 * 64, V9_NA = 4, V9_NB = 3, V9_NT = 512, V9_NW = 8;
@@ -79,7 +91,14 @@ __device__ __forceinline__ i32x4 v9_desc(const void* base, int bytes) {       //
 
 // FIX_ 1: with the exception add-back formed by the tile itself behind its K loop.  STAMP: diagnostic build, phase times go
 // to a.stamps.
-template <int FIX_, bool BF16, bool STAMP>
+// MIXED (round 6): the contraction in TWO column classes in one launch -- class 0 (a.K values: a.xm / a.wm, row-aligned int8 with
+// their exception lists) on the int8 MFMA into int32 accumulators, which are then turned into fp32 IN PLACE (times the row and
+// column scales), and class 1 (a.K1 values: a.xm1 / a.wm1, tiled bf16, every block its own exponent) on the bf16 MFMA into the
+// same registers.  For activations with OUTLIER CHANNELS (README.md:9-11, figure 1: a few input channels tens of times larger
+// than the rest): the block columns that hold such a channel lie several exponents above their rows' window and their exponents
+// follow one element's magnitude -- no row window of the int8 container holds them (20 % of all blocks at K / 64 channels x 60),
+// so the whole layer used to run at the bf16 rate.  Here only those columns do: K1 / K of the MFMA work at half rate.
+template <int FIX_, bool BF16, bool STAMP, bool MIXED = false>
 __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, const float* __restrict__ sx,
                                                         const float* __restrict__ sw_in, const int* __restrict__ xlist,
                                                         const int* __restrict__ wlist_in, const uint8_t* __restrict__ xf,
@@ -87,6 +106,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     constexpr int FIX = FIX_ != 0 ? 1 : 0;
     constexpr bool TPF = FIX_ == 1;                       // the tile's gathers ride in the K-steps past the end (round 4)
     static_assert(!BF16 || FIX_ == 0, "the bf16 arithmetic has no exception lists");
+    static_assert(!MIXED || (FIX_ == 1 && !BF16), "the mixed contraction is the int8 kernel with its lists + a bf16 tail");
     // Two LDS objects: the operand rings (filled by LDS-DMA, read by inline-asm ds_read_b128 only) and everything else.
     // The compiler orders its own LDS reads behind every LDS-DMA that may alias them -- with one array each of its reads
     // in the K loop (the exception service) would drain the operand stream (s_waitcnt vmcnt(0)).
@@ -130,7 +150,10 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     const int m0 = tm * 256, n0 = tn * 256;
     const int kp = (int)(a.K >> 6);                             // 1-KiB pieces per 16 rows
     const int kstep0 = S > 1 ? (int)((long long)kp * split / S) : 0;       // this workgroup's slice of the K-steps
-    const int nsteps = S > 1 ? (int)((long long)kp * (split + 1) / S) - kstep0 : kp;
+    // (MIXED: no split-K; nsteps0 int8 K-steps of 64 values, then kp1 bf16 K-steps of 32 values -- both even, kp1 >= 4)
+    const int kp1 = MIXED ? (int)(a.K1 >> 5) : 0;
+    const int nsteps0 = S > 1 ? (int)((long long)kp * (split + 1) / S) - kstep0 : kp;
+    const int nsteps = nsteps0 + kp1;
 
     int* xb = reinterpret_cast<int*>(smem + V9_XB);
     int* wb = reinterpret_cast<int*>(smem + V9_WB);
@@ -191,16 +214,26 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // (the range check covers the lane's offset only, not the scalar one: a K-step past the end of the slice is requested
     //  through a descriptor of zero bytes -- no memory traffic, zeros land in the slot)
     const int x_nrec = (int)(pa_rows * row_bytes), w_nrec = (int)(pb_rows * row_bytes);
+    // MIXED: the class-1 operands (tiled bf16: kp1 pieces of 16 rows x 32 values per piece row)
+    const long long row_bytes1 = (long long)kp1 * 1024;
+    const int8_t* xbase1 = MIXED ? a.xm1 + (long long)(m0 >> 4) * row_bytes1 : nullptr;
+    const int8_t* wbase1 = MIXED ? a.wm1 + (long long)(n0 >> 4) * row_bytes1 : nullptr;
+    const int x_nrec1 = (int)(pa_rows * row_bytes1), w_nrec1 = (int)(pb_rows * row_bytes1);
     int voff[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) voff[q] = (wave + 8 * (q & 1)) * (int)row_bytes + lane * 16;
+    // (the lane offsets of a class-1 piece differ only in the piece row's length: one scalar add per piece)
+    const int dvo0 = MIXED ? wave * (int)(row_bytes1 - row_bytes) : 0, dvo1 = MIXED ? (wave + 8) * (int)(row_bytes1 - row_bytes) : 0;
     // piece q (literal) of K-step `step` into ring slots at byte offsets sa (A) / sb (B)
 #define V9_PIECE(q, rxd, rwd, soff, sa, sb)                                                                             \
-    V9_BLDS16(voff[q], (q) < 2 ? rxd : rwd, soff, ring_lds + ((q) < 2 ? (sa) : V9_B0 + (sb)) + (wave + 8 * ((q) & 1)) * 1024)
+    V9_BLDS16(MIXED ? voff[(q) & 3] + (c1_ ? (((q) & 1) ? dvo1 : dvo0) : 0) : voff[q], (q) < 2 ? rxd : rwd, soff,           \
+              ring_lds + ((q) < 2 ? (sa) : V9_B0 + (sb)) + (wave + 8 * ((q) & 1)) * 1024)
 #define V9_DESCS(step)                                                                                                  \
     const bool more_ = (step) < nsteps;                                                                                 \
-    const i32x4 rxd_ = v9_desc(xbase, more_ ? x_nrec : 0), rwd_ = v9_desc(wbase, more_ ? w_nrec : 0);                   \
-    const int soff_ = (step) * 1024;
+    const bool c1_ = MIXED && (step) >= nsteps0;                                                                        \
+    const i32x4 rxd_ = v9_desc(c1_ ? xbase1 : xbase, more_ ? (c1_ ? x_nrec1 : x_nrec) : 0),                             \
+                rwd_ = v9_desc(c1_ ? wbase1 : wbase, more_ ? (c1_ ? w_nrec1 : w_nrec) : 0);                             \
+    const int soff_ = (c1_ ? (step) - nsteps0 : (step)) * 1024;
 #define V9_STAGE(step, sa, sb) { V9_DESCS(step) V9_PIECE(0, rxd_, rwd_, soff_, sa, sb); V9_PIECE(1, rxd_, rwd_, soff_, sa, sb); V9_PIECE(2, rxd_, rwd_, soff_, sa, sb); V9_PIECE(3, rxd_, rwd_, soff_, sa, sb); }
     V9_STAGE(0, 0, 0)
     V9_STAGE(1, V9_HALF, V9_HALF)
@@ -268,6 +301,64 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         if (__builtin_amdgcn_readfirstlane(ovf[0] | ovf[64]) != 0) {
             V9_WAITV(0);
             __syncthreads();
+            if constexpr (MIXED) {
+                // the mixed contraction's own fallback, tile by tile (no other workgroup touches this tile): first the class-1
+                // product of this 256 x 256 tile -- fragments straight from memory (the tiled pieces ARE fragments: lane = (row,
+                // 16-byte group)), no ring, slow and rare -- stored as it is; then the class-0 product blockwise-exact on top of
+                // it (bfp_gemm_v2_tile with the stored values as its residual) and the tile's exception blocks (tile_fix_body)
+                f32x4 fac[8][4];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fac[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int lo_ = lq * 256 + l16 * 16;
+                for (int t = 0; t < kp1; ++t) {
+                    i32x4 fx[8], fw[4];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int pr = wm * 8 + i;                 // piece row of the tile (rows past the operand: zero)
+                        fx[i] = pr < pa_rows ? *reinterpret_cast<const i32x4*>(xbase1 + (long long)pr * row_bytes1 + (long long)t * 1024 + lo_) : i32x4{0, 0, 0, 0};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int pr = wn * 4 + j;
+                        fw[j] = pr < pb_rows ? *reinterpret_cast<const i32x4*>(wbase1 + (long long)pr * row_bytes1 + (long long)t * 1024 + lo_) : i32x4{0, 0, 0, 0};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fac[i][j] = v9_mma(fw[j], fx[i], fac[i][j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long long row = (long long)m0 + wm * 128 + i * 16 + l16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = n0 + wn * 64 + j * 16 + lq * 4 + r;
+                            if (row < a.M && col < Ni) a.y[row * a.ldy + col] = fac[i][j][r];
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __threadfence();
+                __syncthreads();
+                if (threadIdx.x >= 256) return;            // (terminated waves do not take part in the barriers below)
+                GemmArgs a2 = a;
+                a2.resid = a.y;
+                a2.ldr = a.ldy;
+                for (int sub = 0; sub < 4; ++sub) {
+                    const long long sm0 = m0 + (sub >> 1) * V2_BM, sn0 = n0 + (sub & 1) * V2_BN;
+                    if (sm0 >= a.M || sn0 >= a.N) continue;        // (uniform)
+                    bfp_gemm_v2_tile(a2, xf, wf, *reinterpret_cast<V2Smem*>(ring), sm0, sn0, (int)threadIdx.x);
+                    __threadfence();
+                    __syncthreads();
+                    tile_fix_body(a, row_bucket(xlist, sm0, a.x_bcap), row_bucket(wlist, sn0, a.w_bcap), a.x_bcap, a.w_bcap, sm0, sn0,
+                                  (int)threadIdx.x, 256);
+                    __syncthreads();
+                }
+                return;
+            }
             v8_fallback(a, xf, wf, xlist, wlist, ring, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
                         ngroup > 1 ? tiles_m * tiles_n1 * S : nwg);
             return;
@@ -277,6 +368,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     V9_DSR(fa[0], va, 0); V9_DSR(fa[1], va, 1024);
     V9_SB();
     acc_t acc[8][4];
+    f32x4 accf[MIXED ? 8 : 1][MIXED ? 4 : 1];               // MIXED: the same registers after the class boundary
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -304,7 +396,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         tcx = a.x_post ? 0 : __builtin_amdgcn_readfirstlane(min(xb[0], ROW_BCAP));
         tnent = tcx + __builtin_amdgcn_readfirstlane(min(wb[0], ROW_BCAP));
     }
-    auto body = [&](i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db, const int tail) {
+    auto body = [&](V9_ACCP i32x4 (&fb)[4], i32x4 (&fbn)[4], int t, int sa_c, int sa_n, int sb_n, int da, int db, const int tail) {
         V9_LGKM(2);                                             // (the B reads of the slot about to be refilled)
         V9_WAITV(4);
         __builtin_amdgcn_s_barrier();
@@ -339,20 +431,69 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     // B half of step t + 1 in b1, the slot step t + 3 goes to (= where step t's B half was) in b0
     int a0 = 0, a1 = V9_HALF, a2 = 2 * V9_HALF, a3 = 3 * V9_HALF, b0 = 0, b1 = V9_HALF, b2 = 2 * V9_HALF;
     // (the first two K-steps apart: their counted waits differ when a record is in flight)
-#define V9_PAIR(t_, tl0, tl1)                                                                                            \
-    body(fb0, fb1, t_, a0, a1, b1, a3, b0, tl0);                                                                         \
+#define V9_PAIR(ac_, t_, tl0, tl1)                                                                                       \
+    body(V9_ACCA(ac_) fb0, fb1, t_, a0, a1, b1, a3, b0, tl0);                                                            \
     { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
     { const int o = b0; b0 = b1; b1 = b2; b2 = o; }                                                                      \
-    body(fb1, fb0, (t_) + 1, a0, a1, b1, a3, b0, tl1);                                                                   \
+    body(V9_ACCA(ac_) fb1, fb0, (t_) + 1, a0, a1, b1, a3, b0, tl1);                                                      \
     { const int o = a0; a0 = a1; a1 = a2; a2 = a3; a3 = o; }                                                             \
     { const int o = b0; b0 = b1; b1 = b2; b2 = o; }
     // (nsteps is even and >= 4: K % 128 == 0, even slices; TPF: the last two pairs request the gathers)
+    if constexpr (MIXED) {
+        // (the ring positions as functions of the step -- A half of step t in slot t % 4, B half in slot t % 3 -- instead of seven
+        //  scalars rotated through three loops: with those the compiler lost track of their uniformity and handed the LDS-DMA
+        //  statements vector registers for M0)
+        int tb = 0;                                                 // t % 3
+#define V9_PAIR_M(ac_, t_, tl0, tl1)                                                                                     \
+        {                                                                                                                \
+            const int ta_ = (t_);                                                                                        \
+            const int A0_ = (ta_ & 3) * V9_HALF, A1_ = ((ta_ + 1) & 3) * V9_HALF, A2_ = ((ta_ + 2) & 3) * V9_HALF,       \
+                      A3_ = ((ta_ + 3) & 3) * V9_HALF;                                                                   \
+            const int tb1_ = tb == 2 ? 0 : tb + 1, tb2_ = tb1_ == 2 ? 0 : tb1_ + 1;                                      \
+            body(V9_ACCA(ac_) fb0, fb1, ta_, A0_, A1_, tb1_ * V9_HALF, A3_, tb * V9_HALF, tl0);                          \
+            body(V9_ACCA(ac_) fb1, fb0, ta_ + 1, A1_, A2_, tb2_ * V9_HALF, A0_, tb1_ * V9_HALF, tl1);                    \
+            tb = tb2_;                                                                                                   \
+        }
+        // class 0 on the int8 MFMA (the requests three steps ahead run on into class 1's pieces by themselves) ...
+        for (int t = 0; t < nsteps0; t += 2) {
+            V9_PAIR_M(acc, t, 0, 0)
+        }
+        // ... the int32 sums become fp32 values where they stand (the fragments of class 1's first step are already on their
+        // way into registers: let them land before the compiler's own code runs) ...
+        V9_LGKM(0);
+        V9_SB();
+        {
+            float sxr_[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sxr_[i] = sxt[wm * 128 + i * 16 + l16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 swv = *reinterpret_cast<const f32x4*>(&swt[wn * 64 + j * 16 + lq * 4]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accf[i][j][r] = (float)acc[i][j][r] * sxr_[i] * swv[r];
+            }
+        }
+        V9_SB();
+        // ... and class 1 goes on in the same registers on the bf16 MFMA, every block with its own exponent
+        for (int t = nsteps0; t < nsteps - 4; t += 2) {
+            V9_PAIR_M(accf, t, 0, 0)
+        }
+        V9_PAIR_M(accf, nsteps - 4, 0, 3)
+        V9_PAIR_M(accf, nsteps - 2, 4, 5)
+#undef V9_PAIR_M
+        // (what the code behind the loop reads of the rotation: the slots of the three steps past the end and of the last step)
+        a0 = (nsteps & 3) * V9_HALF; a1 = ((nsteps + 1) & 3) * V9_HALF; a2 = ((nsteps + 2) & 3) * V9_HALF; a3 = ((nsteps + 3) & 3) * V9_HALF;
+        b0 = tb * V9_HALF; b1 = (tb == 2 ? 0 : tb + 1) * V9_HALF; b2 = (tb == 0 ? 2 : tb - 1) * V9_HALF;
+    } else {
     for (int t = 0; t < (TPF ? nsteps - 4 : nsteps); t += 2) {
-        V9_PAIR(t, 0, 0)
+        V9_PAIR(acc, t, 0, 0)
     }
     if (TPF) {
-        V9_PAIR(nsteps - 4, 0, 3)
-        V9_PAIR(nsteps - 2, 4, 5)
+        V9_PAIR(acc, nsteps - 4, 0, 3)
+        V9_PAIR(acc, nsteps - 2, 4, 5)
+    }
     }
     const int dead_a = a3;            // (the A half of the last K-step: nothing was requested into it, dead behind the loop)
     // ring slots (byte offsets) of the steps past the end: step nsteps + j went to a_j / b_j (the rotation above)
@@ -364,6 +505,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     V9_SB();
     if (STAMP) { st_t[3] = __builtin_amdgcn_s_memrealtime(); c_loop = __builtin_amdgcn_s_memtime() - c_loop; }
     __builtin_amdgcn_s_barrier();                               // (every wave is out of the rings)
+    if constexpr (!MIXED)           // (the mixed contraction is never split: its int32 accumulators are dead behind the class boundary)
     if (S > 1) {
         // ---- split-K: every slice leaves its raw accumulators in its slab (16 bytes a lane, 1 KiB a wave instruction);
         //      the slice that arrives last at the tile's ticket sums all slabs IN SLICE ORDER (reproducible for the fp32
@@ -562,7 +704,10 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
             const f32x4 bv = *reinterpret_cast<const f32x4*>(&bst[cl]);
             f32x4 val;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) val[r] = BF16 ? (float)acc[i][j][r] + bv[r] : (float)acc[i][j][r] * sxv * swv[r] + bv[r];
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (MIXED) val[r] = accf[i][j][r] + bv[r];
+                else val[r] = BF16 ? (float)acc[i][j][r] + bv[r] : (float)acc[i][j][r] * sxv * swv[r] + bv[r];
+            }
             if (pass == 1) {
                 if (rowv) {                                      // the row's vector: 256 products, one per tile column
                     const int rs0 = max(rs, 0);
@@ -795,7 +940,10 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) val[j][r] = (float)acc[i][j][r] * sxr[i] * swr[j][r] + bvr[j][r];
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (MIXED) val[j][r] = accf[i][j][r] + bvr[j][r];
+                    else val[j][r] = (float)acc[i][j][r] * sxr[i] * swr[j][r] + bvr[j][r];
+                }
             }
             if (rowv) {
 #pragma unroll
@@ -858,9 +1006,24 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     }
 }
 
+#ifndef V9_MIXED_TU
 static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/dbg/v9_stamps.py): where the stamps build writes
+#endif
 
 // 256 x 256 tiles, K % 128 == 0, at least four K-steps per slice (even slices under split-K).
+#ifdef V9_MIXED_TU
+// the mixed contraction (MIXED above): a.K / a.xm / a.wm = class 0 (row-aligned int8, K % 128 == 0), a.K1 / a.xm1 / a.wm1 = class 1
+// (tiled bf16, K1 % 64 == 0, K1 >= 128)
+int launch_bfp_gemm_v9_mixed(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
+                             hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
+    if (!xlist || !wlist || !xf || !wf || !a.xm1 || !a.wm1) return MI355Q_E_BADARG;
+    if (a.K % 128 != 0 || a.K < 256 || a.K1 % 64 != 0 || a.K1 < 128 || a.splits > 1 || a.ngroup > 1 || a.x_post) return MI355Q_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256));
+    hipLaunchKernelGGL((bfp_gemm_v9<1, false, false, true>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    return (int)hipGetLastError();
+}
+
+#else
 int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        hipStream_t st, const uint8_t* xf, const uint8_t* wf, bool bf16) {
     GemmArgs a = a_in;
@@ -878,8 +1041,11 @@ int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, c
     else hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();
 }
+#endif
 
 }  // namespace mi355q
 
+#ifndef V9_MIXED_TU
 // diagnostic hook, not part of include/mi355q.h: the buffer ([workgroups][2][8] 64-bit words) the MI355Q_V9_STAMPS build fills
 extern "C" __attribute__((visibility("default"))) void mi355q_debug_v9_stamps(void* buf) { mi355q::g_v9_stamps = static_cast<unsigned long long*>(buf); }
+#endif

@@ -43,6 +43,9 @@ int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
 int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only = false, int fmt = 0 /* FMT_BFP; 1 = FMT_BM */);
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
                             int* list_to_clear, hipStream_t st, int bcap);
+// the class-aware activation quantiser of the mixed contraction (mi355q_quant_cls.hip): cmap[kb] = position | class << 15
+int launch_quant_classes(const QuantArgs& a, const uint16_t* cmap, int n0, int n1, int8_t* mt, uint8_t* flag, float* rscale,
+                         int exp_offset, int* list, int* list_to_clear, uint16_t* bt, hipStream_t st, int bcap);
 int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x, const float* y, float* out, void* yt,
                        long long B, long long M, long long K, long long N, hipStream_t st, bool softmax = false,
                        const float* mask = nullptr, long long causal_off = -1, int fmt = 0);
@@ -106,6 +109,11 @@ struct GemmArgs {
     // mi355q_bf16_gemm_tiled_seg): segment s holds K-steps s * steps / x_segs .. of every row piece, x_seg_stride bytes apart
     int x_segs;
     long long x_seg_stride;
+    // the mixed contraction (mi355q_gemm_v9.hip, MIXED; mi355q_bfp_gemm_mixed): class 1 of the columns as tiled bf16 operands --
+    // xm1 [M, K1], wm1 [N, K1] -- behind the row-aligned int8 class 0 (xm / wm over K values); K1 = 0: off
+    const int8_t* xm1;
+    const int8_t* wm1;
+    long long K1;
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
@@ -116,6 +124,9 @@ int launch_bfp_gemm_rowpost(const GemmArgs& a, const int* xlist, const int* wlis
                             hipStream_t st);
 int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        int list_cap, hipStream_t st, const uint8_t* xf = nullptr, const uint8_t* wf = nullptr);
+// the mixed contraction of the 256 x 256 tile kernel (mi355q_gemm_v9m.hip): a.K1 / a.xm1 / a.wm1 set
+int launch_bfp_gemm_v9_mixed(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
+                             const uint8_t* xf, const uint8_t* wf);
 int launch_bfp_pack_bits(const int8_t* mant, uint16_t* out, long long rows, long long K, int width, hipStream_t st);
 int launch_bfp_expand(int mode, const uint16_t* packed, const uint8_t* codes, void* out, long long rows, long long K, int width,
                       int off, hipStream_t st, const uint8_t* rowexp = nullptr, uint8_t* exp_out = nullptr);

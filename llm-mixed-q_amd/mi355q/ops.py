@@ -903,6 +903,80 @@ def block_fp_quantize_aligned_rows(x: torch.Tensor, width: int, exponent_width: 
     return operand
 
 
+class ColumnClasses:
+    """the split of a layer's in_features into two classes of [1,16] block columns for the mixed contraction (bfp_gemm_mixed):
+    `blocks0` / `blocks1` -- the block columns of class 0 (row-aligned int8) / class 1 (tiled bf16), in the order the operands
+    hold them; `cols0` / `cols1` -- the same as element indices (what index_select takes to split the weights); `cmap` -- the
+    uint16 word per block column the class-aware quantiser reads (position | class << 15)."""
+
+    def __init__(self, K: int, blocks1, device):
+        nb = K // 16
+        b1 = torch.as_tensor(sorted(int(b) for b in blocks1), dtype=torch.long)
+        mask = torch.ones(nb, dtype=torch.bool)
+        mask[b1] = False
+        b0 = torch.nonzero(mask).flatten()
+        self.K, self.n0, self.n1 = K, int(b0.numel()), int(b1.numel())
+        assert self.n0 % 8 == 0 and self.n1 % 8 == 0 and self.n1 >= 8 and self.n0 >= 16, "whole pairs of 64-byte K-steps in both classes"
+        cmap = torch.zeros(nb, dtype=torch.int32)
+        cmap[b0] = torch.arange(self.n0, dtype=torch.int32)
+        cmap[b1] = torch.arange(self.n1, dtype=torch.int32) | 0x8000
+        ar = torch.arange(16)
+        self.blocks0, self.blocks1 = b0.to(device), b1.to(device)
+        self.cols0 = (b0[:, None] * 16 + ar[None]).reshape(-1).to(device)
+        self.cols1 = (b1[:, None] * 16 + ar[None]).reshape(-1).to(device)
+        self.cmap = cmap.to(torch.uint16).to(device)
+
+    @property
+    def K0(self):
+        return 16 * self.n0
+
+    @property
+    def K1(self):
+        return 16 * self.n1
+
+
+_CLASS_BUFFERS = _StreamCache(16)
+
+
+def block_fp_quantize_classes(x: torch.Tensor, classes: ColumnClasses, width: int, exponent_width: int, exponent_bias,
+                              bucket_cap: int = None):
+    """x [rows, K] fp32 -> (class-0 AlignedOperand [rows, K0], class-1 tiled bf16 operand [rows, K1]) in ONE pass
+    (include/mi355q.h, mi355q_block_fp_quantize_classes): the activation side of bfp_gemm_mixed.  Buffers are shared by calls of
+    the same shape on the same stream (consume before quantising again)."""
+    bucket_cap = ACTIVATION_BUCKET_CAP if bucket_cap is None else int(bucket_cap)
+    _require_device(x, "block_fp_quantize_classes")
+    assert x.ndim == 2 and x.dtype == torch.float32 and x.shape[1] == classes.K
+    rows, K = x.shape
+    xc = x.contiguous()
+    lib = _lib.load_library()
+    sp = _stream_ptr(x.device)
+    key = (x.device.index, sp, "cls", rows, K, classes.n0, bucket_cap)
+    buf = _CLASS_BUFFERS.get(key)
+    if buf is None:
+        buf = dict(tiled=torch.zeros(lib.mi355q_bfp_tiled_bytes(rows, classes.K0), dtype=torch.int8, device=x.device),
+                   exp=torch.zeros(rows * classes.n0, dtype=torch.uint8, device=x.device),
+                   flag=torch.zeros(rows, dtype=torch.uint8, device=x.device),
+                   gscale=torch.zeros(lib.mi355q_bfp_rows_pad(rows), dtype=torch.float32, device=x.device),
+                   x1=torch.zeros(lib.mi355q_bfp_tiled_bytes(rows, 2 * classes.K1), dtype=torch.int8, device=x.device),
+                   sparse=[_new_row_list(x.device, rows, bucket_cap) for _ in range(2)], calls=0)
+        _CLASS_BUFFERS.put(key, buf)
+    if _capturing():
+        cur, nxt = _new_row_list(x.device, rows, bucket_cap), None          # (a captured node keeps a list of its own: block_fp_quantize_aligned_rows)
+    else:
+        cur, nxt = buf["sparse"][buf["calls"] & 1], buf["sparse"][(buf["calls"] + 1) & 1]
+        buf["calls"] += 1
+    bias = _default_bias(exponent_bias)
+    with _on_device(x.device):
+        rc = lib.mi355q_block_fp_quantize_classes(_ptr(xc), _ptr(classes.cmap), classes.n0, classes.n1, _ptr(buf["tiled"]), _ptr(buf["exp"]),
+                                                  _ptr(buf["flag"]), _ptr(buf["gscale"]), _ptr(cur), _ptr(nxt), _ptr(buf["x1"]), rows, K,
+                                                  int(width), int(exponent_width), bias, bucket_cap, sp)
+    _lib.check(rc, "mi355q_block_fp_quantize_classes")
+    eb = 2 ** (int(exponent_width) - 1) - 1 if bias == BIAS_DEFAULT else bias
+    x0 = AlignedOperand(rows, classes.K0, None, buf["tiled"], buf["exp"], buf["flag"], buf["gscale"], cur, int(width) - 1, eb,
+                        row_aligned=True, bucket_cap=bucket_cap)
+    return x0, buf["x1"]
+
+
 def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):
     """bfp_gemm on operands rewritten by bfp_align."""
     M, K, N = x.rows, x.K, w.rows
@@ -918,6 +992,33 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     with _on_device(x.tiled.device):
         rc = lib.mi355q_bfp_gemm_aligned(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(out), M, N, K, ldy, sp)
     _lib.check(rc, "mi355q_bfp_gemm_aligned")
+    if given:
+        _wrote_into(out)
+    return out
+
+
+def bfp_gemm_mixed(x0: AlignedOperand, w0: AlignedOperand, x1: torch.Tensor, w1: torch.Tensor, K1: int, bias=None,
+                   out: torch.Tensor = None):
+    """y = x . w^T + bias with the contraction in two column classes, ONE launch (include/mi355q.h, mi355q_bfp_gemm_mixed): class 0
+    = the row-aligned int8 operands x0 [M, K0], w0 [N, K0] (int8 MFMA, exception lists), class 1 = the tiled bf16 operands x1
+    [M, K1], w1 [N, K1] (block_fp_quantize_bf16_tiled / bf16_tile: every block its own exponent, bf16 MFMA) -- activations with
+    outlier channels keep three quarters and more of their MFMA work at the int8 rate.  None when the library does not take the
+    shapes (callers use the per-block route)."""
+    M, K0, N = x0.rows, x0.K, w0.rows
+    assert w0.K == K0 and x1.dtype == torch.int8 and w1.dtype == torch.int8
+    given = out is not None
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x0.tiled.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1
+    ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    lib = _lib.load_library()
+    x0.c_struct(), w0.c_struct()
+    with _on_device(x0.tiled.device):
+        rc = lib.mi355q_bfp_gemm_mixed(x0._cs_addr, w0._cs_addr, _ptr(x1), _ptr(w1), _ptr(bias), _ptr(out), M, N, K0, int(K1), ldy,
+                                       _stream_ptr(x0.tiled.device))
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "mi355q_bfp_gemm_mixed")
     if given:
         _wrote_into(out)
     return out

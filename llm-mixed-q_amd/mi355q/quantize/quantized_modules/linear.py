@@ -122,6 +122,11 @@ class _LinearBase(nn.Linear):
         #       (width + 0.5 bits per value, ops.PackedWeights) and stream them into a shared scratch operand every forward;
         #   mi355q_keep_master = True: keep the fp32 weights / bias the layer was given, so that requantize() can quantise
         #       them again (other widths included) without a checkpoint reload (the search loop)
+        #   mi355q_mixed = "auto" (default) / False: layers whose activations (or weights) carry OUTLIER CHANNELS -- block columns that
+        #       lie outside their rows' exponent window in a large share of the rows -- split in_features into two classes of block
+        #       columns and run ONE launch of the mixed contraction (ops.bfp_gemm_mixed: class 0 on the int8 MFMA, class 1 on the
+        #       bf16 MFMA) instead of the whole layer on the bf16 flavour (round 6)
+        self._mixed = None           # dict(classes, wa0, w1): the column split and the weights' two operands
         self._w_packed = None
         self._pending_flavour = None
         self._master = None
@@ -147,7 +152,7 @@ class _LinearBase(nn.Linear):
     def _loaded_new_weights(self):
         with torch.no_grad():
             self.weight_requires_quantisation = True          # (fresh fp32 values: quantise them again)
-            self._packed, self._w_bf16, self._w_packed, self._pending_flavour = None, None, None, None
+            self._packed, self._w_bf16, self._w_packed, self._pending_flavour, self._mixed = None, None, None, None, None
             if self._master is not None:
                 self._master = (self.weight.detach().clone(), None if self.bias is None else self.bias.detach().clone())
             self._pack_if_arrived()
@@ -236,6 +241,8 @@ class _LinearBase(nn.Linear):
         c = self.config
         self._align_weights(wm, we, self._choose_align_mode(wm, we, x_sample))
         versions = (self.weight._version, None if self.bias is None else self.bias._version)
+        if self._mixed is not None:
+            self._mixed["version"] = versions
         packed_storage = c.get("mi355q_weight_storage", "int8") == "packed" and self._align_mode == "rows"
         self._w_packed = None
         if self._uses_bf16_route():
@@ -282,8 +289,10 @@ class _LinearBase(nn.Linear):
         w_over, w_max = ops.row_list_fill(wa.sparse, self.out_features)
         if w_over != 0 or w_max > ops.ROW_TILE_ENTRIES_FAST:
             # weights whose exception blocks do not fit a tile's LDS add-back (outlier input channels put one in every
-            # row): no alignment -- the blockwise / bf16 product does not care how exponents are distributed
-            self._x_cap = ops.ROW_NO_ALIGN
+            # row): the outlier block columns as class 1 of the mixed contraction if that leaves a class 0 that fits, else no
+            # alignment -- the blockwise / bf16 product does not care how exponents are distributed
+            if not self._try_mixed(wm, we, x_sample):
+                self._x_cap = ops.ROW_NO_ALIGN
             return "rows"
         if x_sample is not None:
             # activations: the GEMM's in-LDS add-back while a tile's entries fit it; otherwise (post-activation inputs:
@@ -305,7 +314,61 @@ class _LinearBase(nn.Linear):
             fits = x_over == 0 and (n_tile <= ops.ROW_TILE_ENTRIES_FAST or
                                     (tile_rows == 256 and n_tile <= ops.ROW_TILE_ENTRIES_SLOW - 8))
             self._x_cap = ops.ROW_BUCKET_CAP if fits else ops.ROW_NO_ALIGN
+            if not fits and self._try_mixed(wm, we, x_sample):
+                self._x_cap = ops.ROW_BUCKET_CAP
         return "rows"
+
+    @staticmethod
+    def _outlier_share(codes, spare: int):
+        """codes [rows, blocks] (biased block exponents): per block column, the share of the rows in which the block lies
+        outside a window of spare + 1 exponents centred on the row's median exponent"""
+        c = codes.to(torch.int16)
+        med = c.median(dim=1, keepdim=True).values
+        out = (c < med - spare // 2) | (c > med + (spare - spare // 2))
+        return out.float().mean(0)
+
+    def _try_mixed(self, wm, we, x_sample) -> bool:
+        """The mixed contraction for a layer whose rows fit no exponent window AS A WHOLE (README.md:9-11 of the reference: a few
+        input channels tens of times larger than the rest): block columns that are outliers in more than a quarter of the rows --
+        of the sample activations or of the weights -- become class 1 (tiled bf16, every block its own exponent); if they are at
+        most half of the columns and the remaining class 0 fits the row-scale route's exception buckets on both operands, the layer
+        runs ONE launch with class 0 on the int8 MFMA (ops.bfp_gemm_mixed) instead of all of it on the bf16 flavour.  Decided once
+        per packing from the first activations, like the row / block decision itself; results never depend on it."""
+        c, K = self.config, self.in_features
+        self._mixed = None
+        if (c.get("mi355q_mixed", "auto") in (False, "off", None) or self.align != "auto" or x_sample is None or K % 128 or K < 512
+                or not ops.row_align_supported(K) or c.get("mi355q_weight_storage", "int8") == "packed"
+                or c["data_in_width"] > 8 or c["weight_width"] > 8 or not x_sample.is_cuda or x_sample.dtype != torch.float32):
+            return False
+        nb = K // 16
+        x2 = x_sample.reshape(-1, K)
+        _, _, xe = ops.block_fp_quantize(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"], [1, 16], True,
+                                         want_fake=False, want_packed=True)
+        share = torch.maximum(self._outlier_share(xe.view(-1, nb), 8 - c["data_in_width"]),
+                              self._outlier_share(we.view(-1, nb), 8 - c["weight_width"]))
+        n1 = int((share > 0.25).sum())
+        if n1 == 0:
+            return False
+        n1 = -(-n1 // 8) * 8                                  # whole pairs of 64-byte K-steps in both classes
+        if n1 > nb // 2 or nb - n1 < 16:
+            return False
+        blocks1 = torch.topk(share, n1).indices.cpu().tolist()
+        classes = ops.ColumnClasses(K, blocks1, x2.device)
+        N = self.out_features
+        wa0 = ops.bfp_align_rows(wm.view(N, K)[:, classes.cols0].contiguous(), we.view(N, nb)[:, classes.blocks0].contiguous(),
+                                 c["weight_width"] - 1, self._weight_bias_value())
+        w_over, w_max = ops.row_list_fill(wa0.sparse, N)
+        if w_over != 0 or w_max > ops.ROW_TILE_ENTRIES_FAST:
+            return False
+        x0, _ = ops.block_fp_quantize_classes(x2, classes, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                              bucket_cap=ops.ROW_BUCKET_CAP_MAX)
+        x_over, x_max = ops.row_list_fill(x0.sparse, x0.rows, x0.list_cap)
+        if x_over != 0 or w_max + x_max > ops.ROW_TILE_ENTRIES_FAST:
+            return False
+        # (the weights' class-1 operand: the fake-quantised values already in .weight, as tiled bf16)
+        w1 = ops.bf16_tile(self.weight.data[:, classes.cols1].contiguous())
+        self._mixed = dict(classes=classes, wa0=wa0, w1=w1, version=None)
+        return True
 
     def _uses_bf16_route(self) -> bool:
         c = self.config
@@ -336,7 +399,7 @@ class _LinearBase(nn.Linear):
         requantize()."""
         if self.in_features % 32 or self.config["weight_width"] > 9 or self.config["data_in_width"] > 9:
             return False
-        self._align_mode, self._x_cap = "rows", ops.ROW_NO_ALIGN
+        self._align_mode, self._x_cap, self._mixed = "rows", ops.ROW_NO_ALIGN, None
         self._w_bf16 = (ops.bf16_tile(self.weight.data.contiguous()), self.weight._version)
         self._packed = (None, self._w_bf16[0], self.weight._version, None if self.bias is None else self.bias._version)
         return True
@@ -368,7 +431,7 @@ class _LinearBase(nn.Linear):
             raise RuntimeError("mi355q: requantize() needs fp32 weights: they were released and no master copy is kept")
         self.weight_requires_quantisation = True if self.is_ptq else False
         self._packed, self._align_mode, self._calls, self._row_overflows = None, None, 0, 0
-        self._w_bf16, self._w_packed, self._pending_flavour = None, None, None
+        self._w_bf16, self._w_packed, self._pending_flavour, self._mixed = None, None, None, None
         self._x_cap = {"rows_post": ops.ROW_BUCKET_CAP_MAX, "blocks": ops.ROW_NO_ALIGN}.get(self.align, ops.ACTIVATION_BUCKET_CAP)
 
     @torch.no_grad()
@@ -721,6 +784,8 @@ class _LinearBase(nn.Linear):
             y = ops.bf16_gemm_tiled(xt, wt, x2.shape[0], self.out_features, self.in_features, self.bias, out=self._take_out(x2.shape[0]),
                                     residual=None if residual is None else residual.reshape(-1, self.out_features))
             return y.reshape(*x.shape[:-1], self.out_features)
+        if self._mixed is not None and self._mixed["version"] == (self.weight._version, None if self.bias is None else self.bias._version):
+            return self._forward_mixed(x, x2, segments, pre, residual)
         assert residual is None, "the residual add is fused on the per-block-exponent route only"
         # one fused kernel: quantise + pack + row-align + tile
         xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
@@ -738,6 +803,30 @@ class _LinearBase(nn.Linear):
                 if self._row_overflows >= 2:
                     self._x_cap = ops.ROW_NO_ALIGN                # activations stopped fitting: no alignment from now on
         return y.reshape(*x.shape[:-1], self.out_features)
+
+    def _forward_mixed(self, x, x2, segments, pre, residual):
+        """the mixed contraction: one pass of the class-aware quantiser over x, one launch of the tile kernel (class 0 on the int8
+        MFMA, class 1 on the bf16 MFMA); an elementwise step in front, row segments or a residual behind run as torch ops here"""
+        c, m = self.config, self._mixed
+        if segments:
+            x2 = x.dense().reshape(-1, self.in_features)
+        if pre is not None:
+            x2 = F.relu(x2) if pre[0] == "relu" else F.silu(x2) * pre[1].reshape(-1, self.in_features)
+        x0, x1 = ops.block_fp_quantize_classes(x2, m["classes"], c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                               bucket_cap=self._x_cap)
+        y = ops.bfp_gemm_mixed(x0, m["wa0"], x1, m["w1"], m["classes"].K1, self.bias, out=self._take_out(x2.shape[0]))
+        assert y is not None, "mi355q: the mixed contraction was chosen for a shape the library does not take"
+        if self.align == "auto":
+            # (as on the row route: an overflowing class-0 bucket only sends the launch to its exact fallback; look at the overflow
+            #  word on a doubling schedule of calls and leave for the per-block route if it repeats)
+            self._calls += 0 if ops._capturing() else 1
+            if not ops._capturing() and self._calls & (self._calls - 1) == 0 and int(x0.sparse[0]) != 0:
+                self._row_overflows += 1
+                if self._row_overflows >= 2:
+                    self._mixed, self._x_cap = None, ops.ROW_NO_ALIGN
+        lead = x.shape[:-1]
+        y = y.reshape(*lead, self.out_features)
+        return y if residual is None else residual + y
 
     @classmethod
     def from_float(cls, linear_fp32: nn.Linear, config: dict):
@@ -805,7 +894,7 @@ def grouped_linear(x, layers, norm=None):
     if ok:
         plan = first._int8_plan(x)
         ok = plan is not None and (norm is None or (x.is_cuda and x.dtype == torch.float32)) and all(
-            l._packed_is_current() and l._align_mode == "rows" and not l._uses_bf16_route()
+            l._packed_is_current() and l._align_mode == "rows" and not l._uses_bf16_route() and l._mixed is None
             and (l._w_packed is None or (l._w_packed.row_scale_flavour and l._pending_flavour is None))
             and l.in_features == first.in_features and l.out_features == first.out_features and l._x_cap == first._x_cap
             and l._x_cap == ops.ROW_BUCKET_CAP and l._int8_plan(x) == plan

@@ -134,8 +134,11 @@ def test_linear_int8_align_modes(align, outliers):
         ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(3, 100, 192)
         np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
     assert lin._align_mode == "rows"
-    if align == "auto":                      # 300 rows x 1 exception: too many for a tile's LDS add-back -> no alignment
-        assert lin._x_cap == (-1 if outliers else 120)
+    if align == "auto":
+        # 300 rows x 1 exception: too many for a tile's LDS add-back.  Round 6: the outlier block column becomes class 1 of the
+        # mixed contraction (the rest of the row fits its window again: int8 MFMA for class 0, bf16 MFMA for class 1, one launch);
+        # before: no alignment at all, the whole layer on the bf16 flavour
+        assert lin._x_cap == 120 and (lin._mixed is not None) == outliers
     if align == "rows_post":
         assert lin._x_cap == 1016
     if align == "blocks":                    # nothing aligned: bf16 GEMM on the exactly representable quantised values
@@ -403,9 +406,18 @@ def test_linear_auto_takes_blocks_for_weights_with_outlier_input_channels():
     x = torch.randn(2, 70, 512) * torch.exp(torch.randn(2, 70, 1))
     for _ in range(2):
         y = lin(x.to("cuda:0"))
-    assert lin._align_mode == "rows" and lin._x_cap == -1 and lin._w_bf16 is not None
+    # round 6: the two outlier block columns go to class 1 of the mixed contraction, the other thirty stay on the int8 MFMA
+    assert lin._align_mode == "rows" and lin._x_cap == 120 and lin._mixed is not None
+    assert {2, 20} <= set(lin._mixed["classes"].blocks1.cpu().tolist())
     ref = O.bfp_linear_int(x.numpy().reshape(-1, 512), w0, b0, cfg).reshape(2, 70, 320)
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+    # mi355q_mixed = False: as before round 6 -- no alignment, the exactly representable quantised values on the bf16 MFMA
+    cfg2 = dict(cfg, mi355q_mixed=False)
+    lin2 = Q.get_quantized_cls("linear", cfg2).from_float(fp, cfg2).to("cuda:0")
+    for _ in range(2):
+        y2 = lin2(x.to("cuda:0"))
+    assert lin2._align_mode == "rows" and lin2._x_cap == -1 and lin2._w_bf16 is not None and lin2._mixed is None
+    np.testing.assert_allclose(y2.detach().cpu().numpy(), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
 
 
 def _lin_cfg(width, **extra):

@@ -76,7 +76,8 @@ def run(layers=32, tokens=2048, steps=5, storage="resident", graph=True, parity=
         routes = {}
         for m in model.modules():
             if isinstance(m, _LB):
-                r = "bf16 per-block" if m._uses_bf16_route() else f"int8 {m._align_mode}"
+                r = ("bf16 per-block" if m._uses_bf16_route() else
+                     "mixed (int8 class 0 + bf16 class 1)" if getattr(m, "_mixed", None) is not None else f"int8 {m._align_mode}")
                 routes[r] = routes.get(r, 0) + 1
         out = {"config": "BASELINE config 3 at full depth: Llama-7B shape, W6A6 block_fp [1,16], seeded random weights",
                "layers": layers, "tokens": tokens, "weight_storage": storage, "knobs": knobs, "row_spread_weights": spread,
