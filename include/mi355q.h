@@ -391,6 +391,23 @@ int mi355q_block_fp_quantize_classes(const float* x, const uint16_t* colmap, int
 int mi355q_bfp_gemm_mixed(const mi355q_bfp_operand* x0, const mi355q_bfp_operand* w0, const void* x1_bf16_tiled, const void* w1_bf16_tiled,
                           const float* bias, float* y, int64_t M, int64_t N, int64_t K0, int64_t K1, int64_t ldy, void* stream);
 
+/* The gated MLP's first half as ONE launch with the consumer's operand as its only output (round 6, ABI 23; reference:
+ * modeling_llama.py:216  down_proj(act_fn(gate_proj(x)) * up_proj(x)),  quantized_modules/linear.py:59-76 for each Linear).
+ * `w`: gate_proj's and up_proj's row-aligned operands INTERLEAVED in chunks of 16 rows -- rows 32 c .. 32 c + 15 = gate rows
+ * 16 c .. 16 c + 15, rows 32 c + 16 .. 32 c + 31 = the same rows of up (tiled mantissas, exponents, row flags / scales and the
+ * exception list's row numbers alike; `bias` interleaved the same way or NULL) -- so that a lane of the tile kernel holds matching
+ * elements of both products.  The store epilogue forms h = silu(gate) * up from the fp32 values the plain epilogue would have
+ * stored (torch's arithmetic: x / (1 + exp(-x)), then the product, each rounded to fp32), runs the CONSUMER's block_fp quantiser
+ * (q_width / q_exponent_width / q_exponent_bias of down_proj's data_in, [1,16] blocks along I = a fragment pair's 16 columns)
+ * and writes the tiled bf16 operand [M, I] (mi355q_bfp_tiled_bytes(M, 2 I) bytes, zero-initialised once) that
+ * mi355q_bf16_gemm_tiled reads -- bit for bit what mi355q_block_fp_quantize_bf16_tiled_pre(gate, up, silu_mul) makes of the two
+ * fp32 tensors, which are never written.  `scratch`: fp32 [M, 2 I], touched on the slow paths only (an overflowed bucket, more
+ * exception entries than a tile's LDS holds: the product lands there and the tile is converted behind its add-backs).
+ * K % 128 == 0, K >= 256, I % 32 == 0, 120-entry buckets, q_width <= 9, else MI355Q_E_UNSUPPORTED. */
+int mi355q_bfp_gemm_aligned_gated(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w_gate_up, const float* bias_gate_up, float* scratch,
+                                  void* out_bf16_tiled, int64_t M, int64_t I, int64_t K, int32_t q_width, int32_t q_exponent_width,
+                                  int32_t q_exponent_bias, void* stream);
+
 /* Several weight operands of the SAME shape against ONE activation operand in one launch (the q / k / v projections of an
  * attention block, gate / up of a gated MLP: reference modules called one after the other on the same input,
  * modeling_opt.py:231-245, modeling_llama.py:216,283-287): y[i] = x . w[i]^T + bias[i].  The column tiles of all of them

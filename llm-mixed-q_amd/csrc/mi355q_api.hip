@@ -635,6 +635,42 @@ int mi355q_bfp_gemm_mixed(const mi355q_bfp_operand* x0, const mi355q_bfp_operand
     return rc;
 }
 
+// x . [gate; up]^T with the gated MLP's elementwise step and the consumer's quantiser in the store epilogue (mi355q.h)
+int mi355q_bfp_gemm_aligned_gated(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* scratch,
+                                  void* out_bf16_tiled, int64_t M, int64_t I, int64_t K, int32_t q_width, int32_t q_exponent_width,
+                                  int32_t q_exponent_bias, void* stream) {
+    if (!x || !w || M < 0 || I < 0 || K < 0) return MI355Q_E_BADARG;
+    if (M == 0 || I == 0) return 0;
+    if (!scratch || !out_bf16_tiled || !x->mant || !x->exp || !w->mant || !w->exp || !x->rowflag || !w->rowflag || !x->gscale || !w->gscale ||
+        !x->list || !w->list)
+        return MI355Q_E_BADARG;
+    if (x->mbits < 1 || x->mbits > 7 || w->mbits < 1 || w->mbits > 7) return MI355Q_E_BADARG;
+    if (q_exponent_width < 1 || q_exponent_width > 8 || q_width < 2 || q_width > 9) return MI355Q_E_UNSUPPORTED;     // (exact in bf16: <= 8 mantissa bits)
+    if (q_exponent_bias == MI355Q_BIAS_DEFAULT) q_exponent_bias = (1 << (q_exponent_width - 1)) - 1;
+    if (x->row_aligned != 1 || w->row_aligned != 1 || bucket_cap_of(x->list_cap) != ROW_BCAP || bucket_cap_of(w->list_cap) != ROW_BCAP ||
+        K % 128 != 0 || K < 256 || K > MI355Q_ROW_ALIGN_MAX_K || I % 32 != 0)
+        return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant) | reinterpret_cast<uintptr_t>(out_bf16_tiled) |
+         reinterpret_cast<uintptr_t>(scratch)) % 16)
+        return MI355Q_E_ALIGN;
+    const int64_t N = 2 * I;
+    GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, scratch, M, N, K, N,
+               x->exp_bias + x->mbits + w->exp_bias + w->mbits, 1,
+               x->exp_bias + x->mbits, w->exp_bias + w->mbits,
+               ROW_BCAP, ROW_BCAP, 0};
+    a.x_mbits = x->mbits;
+    a.w_mbits = w->mbits;
+    a.yb = out_bf16_tiled;
+    a.q_mbits = q_width - 1;
+    a.q_emin = -q_exponent_bias;
+    a.q_emax = (1 << q_exponent_width) - 1 - q_exponent_bias;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t te = g_timing.begin(st);
+    const int rc = launch_bfp_gemm_v9_gated(a, x->gscale, w->gscale, x->list, w->list, st, x->rowflag, w->rowflag);
+    g_timing.end(te, st);
+    return rc;
+}
+
 static int gemm_aligned_multi_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const float* const* bias,
                                   float* const* y, int32_t count, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     if (!x || !w || !y || count < 1 || count > 3 || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;

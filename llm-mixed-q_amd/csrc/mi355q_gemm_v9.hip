@@ -32,6 +32,9 @@
 #include <utility>
 
 #include "mi355q_gemm_tile.h"
+#ifdef V9_GATED_TU
+#include "mi355q_quant_dev.h"
+#endif
 
 // The mixed contraction (MIXED below) is built as its OWN translation unit, mi355q_gemm_v9m.hip = this file with V9_MIXED_TU
 // defined: the accumulators become a parameter of the K-step body there (it runs on int32 and on fp32 registers), which in this
@@ -44,8 +47,22 @@
 #define V9_ACCP
 #define V9_ACCA(x)
 #endif
+// The GATED epilogue (round 6, mi355q_bfp_gemm_aligned_gated) is a third unit, mi355q_gemm_v9g.hip = this file with V9_GATED_TU
+// defined: the product of x against the INTERLEAVED gate / up weights of a gated MLP (modeling_llama.py:216: down_proj(act(gate(x))
+// * up(x))) never leaves as fp32 -- the store epilogue forms silu(gate) * up from the accumulators (a lane holds matching elements
+// of both: rows of the two weights alternate in chunks of 16), runs the CONSUMER's block_fp quantiser on the [1,16] blocks (= the
+// 16 columns of a fragment pair) and writes the tiled bf16 operand down_proj's product reads: 2 bytes per value instead of two fp32
+// tensors written and read back by a separate quantiser launch.
+#ifdef V9_GATED_TU
+#define bfp_gemm_v9 bfp_gemm_v9g
+#endif
 
 namespace mi355q {
+#ifdef V9_GATED_TU
+constexpr bool V9_GATED = true;
+#else
+constexpr bool V9_GATED = false;
+#endif
 
 constexpr int V9_HALF = 256 * 64, V9_NA = 4, V9_NB = 3, V9_NT = 512, V9_NW = 8;
 constexpr int V9_B0 = V9_NA * V9_HALF;                       // B ring behind the A ring
@@ -54,14 +71,16 @@ constexpr int V9_XB = 0, V9_WB = V9_XB + 4096, V9_MAP = V9_WB + 4096;      // (o
 constexpr int V9_SXT = V9_MAP + 2048, V9_SWT = V9_SXT + 1024, V9_BIAS = V9_SWT + 1024;
 constexpr int V9_FLAGS = V9_BIAS + 1024, V9_OVF = V9_FLAGS + 256, V9_HDR = V9_OVF + 512, V9_CORR = V9_HDR + 256;
 constexpr int V9_LDS = 159 * 1024, V9_SIDE = V9_LDS - V9_STAGES;
-constexpr int V9_FAST_MAX = (V9_SIDE - V9_CORR) / 1024;       // entries (x + w) whose vectors fit beside the rings
+constexpr int V9_GLUT_BYTES = V9_GATED ? 1280 : 0;            // (gated epilogue: the consumer quantiser's log2 threshold table, at the end of the side area)
+[[maybe_unused]] constexpr int V9_GLUT = V9_SIDE - V9_GLUT_BYTES;
+constexpr int V9_FAST_MAX = (V9_SIDE - V9_CORR - V9_GLUT_BYTES) / 1024;       // entries (x + w) whose vectors fit beside the rings
 constexpr int V9_TPRE = 24;                                  // entries whose gathers ride in the three K-steps past the end (96 pieces)
 constexpr int V9_TVEC = 16;                                  // ... vectors beyond V9_FAST_MAX: in the ring half the last K-step leaves dead
 constexpr int V9_NB_ENT = 2;                                 // entries a wave gathers per batch behind the K loop
 constexpr int V9_GSCR = V9_NW * V9_NB_ENT * 4096;            // ... their blocks: scratch at the start of the ring area
 constexpr int V9_SLOW_MAX = (V9_STAGES - V9_GSCR) / 1024;    // vectors that fit the ring area behind the K loop
 static_assert(ROW_BUCKET_WORDS * 4 <= 4096, "bucket copy");
-static_assert(V9_FAST_MAX >= 32, "spare LDS for correction vectors");
+static_assert(V9_FAST_MAX >= (V9_GATED ? 31 : 32), "spare LDS for correction vectors");
 
 typedef __bf16 v9_bf16x8 __attribute__((ext_vector_type(8)));
 // (w fragment as the MFMA's A operand, x fragment as its B operand: D[n = 4 (lane / 16) + r][m = lane % 16])
@@ -88,6 +107,72 @@ __device__ __forceinline__ i32x4 v9_desc(const void* base, int bytes) {       //
     const unsigned long long b = reinterpret_cast<unsigned long long>(base);
     return i32x4{(int)(unsigned)b, (int)(unsigned)(b >> 32), bytes, 0x00020000};
 }
+
+#ifdef V9_GATED_TU
+// ---- the gated epilogue's quantiser: the arithmetic of bfp_quant_bf16_tiled_kernel (mi355q_quant.hip: block_fp.py:54-96 with the
+//      all-zero-block fill 1) on values a caller holds in registers.  `m`: the block's largest |value| as a bit pattern; the N
+//      values of `h` that this lane holds of it become their fake-quantised selves (exact in bf16 for widths <= 9).
+struct GatedQ { int mbits, e_min, e_max; float mant_max, shift, inv_shift; };
+template <int N>
+__device__ __forceinline__ void gated_quant(float (&h)[N], unsigned m, const unsigned* __restrict__ glut, const GatedQ& q) {
+    const float bm1 = m != 0u ? __uint_as_float(m) : 1.0f;
+    const int k = __builtin_amdgcn_frexp_expf(bm1) - 1;
+    const unsigned f = __float_as_uint(__builtin_amdgcn_frexp_mantf(bm1)) & 0x7FFFFFu;
+    const int e = clampi(k + ((f != 0u && f >= glut[lut_index(k)]) ? 1 : 0), q.e_min, q.e_max);
+    const int up = q.mbits - e;
+    if (up >= 28) {                                       // blocks below 2^-23: the general rule (quant_elem<FMT_BFP>)
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float x = h[t], ax = fabsf(x), sg = sgn(x + EPS9);
+            const float r = __builtin_ldexpf(ax + EPS9, -e) * q.shift;
+            const float mm = clampf(__builtin_rintf(r), 0.f, q.mant_max);
+            const float v = __builtin_ldexpf(sg, e) * (mm * q.inv_shift);
+            h[t] = ax <= ATOL ? x + 0.0f : v;
+        }
+    } else {
+        constexpr float MAGIC = 12582912.0f;
+        const float sc = __builtin_ldexpf(1.0f, up), es = EPS9 * sc, inv = __builtin_ldexpf(1.0f, -up);
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float x = h[t];
+            const float r = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, sc, __builtin_copysignf(es, x)), -q.mant_max, q.mant_max);
+            const float v = __builtin_fmaf(r + MAGIC, inv, -MAGIC * inv);
+            h[t] = fabsf(x) <= ATOL ? x : v;
+        }
+    }
+}
+// where the 8 bytes of the four values at h column hc (a multiple of 4) of `row` go in the consumer's tiled bf16 operand
+// [rows, I]: pieces of 16 rows x 32 values, [8-value group 0..3][row][16 bytes]
+__device__ __forceinline__ unsigned gated_offset(unsigned row, unsigned hc, unsigned kpI) {
+    return ((row >> 4) * kpI + (hc >> 5)) * 1024u + ((hc & 31u) >> 3) * 256u + (row & 15u) * 16u + ((hc & 7u) >> 2) * 8u;
+}
+// Slow paths (an overflowed bucket: the blockwise-exact product; more entries than a tile's LDS holds: atomics behind the stores):
+// the fp32 tile [m0, m0 + bm) x [n0, n0 + bn) of the interleaved product lies in the scratch a.y; one thread per (row, 16 h
+// columns) reads its gate and up values back and does what the register epilogue does.
+__device__ __forceinline__ void gated_post_tile(const GemmArgs& a, const unsigned* __restrict__ glut, const GatedQ& q, long long m0,
+                                                long long n0, int bm, int bn, int tid, int nthreads) {
+    const int hb = bn >> 5;                                       // h blocks per tile row
+    const unsigned kpI = (unsigned)(a.N >> 6);                    // I / 32 pieces per 16 rows (I = N / 2)
+    for (int it = tid; it < bm * hb; it += nthreads) {
+        const long long row = m0 + it / hb, col = n0 + (long long)(it % hb) * 32;      // (gate: col .. col + 15, up: col + 16 .. + 31)
+        if (row >= a.M || col >= a.N) continue;
+        const float* yr = a.y + row * a.ldy + col;
+        float h[16];
+        unsigned m = 0u;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            h[t] = pre_silu_mul(yr[t], yr[16 + t]);
+            m = max(m, __float_as_uint(h[t]) & 0x7FFFFFFFu);
+        }
+        gated_quant<16>(h, m, glut, q);
+        const unsigned hc = (unsigned)(col >> 1);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(a.yb) + gated_offset((unsigned)row, hc + 4 * g4, kpI)) =
+                make_uint2(pack_bf16(h[4 * g4], h[4 * g4 + 1]), pack_bf16(h[4 * g4 + 2], h[4 * g4 + 3]));
+    }
+}
+#endif
 
 // FIX_ 1: with the exception add-back formed by the tile itself behind its K loop.  STAMP: diagnostic build, phase times go
 // to a.stamps.
@@ -164,6 +249,13 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     float* bst = reinterpret_cast<float*>(smem + V9_BIAS);
     float* corr = reinterpret_cast<float*>(smem + V9_CORR);
 
+#ifdef V9_GATED_TU
+    // (the consumer quantiser's log2 thresholds, read behind the K loop only; loaded by plain code BEFORE any LDS-DMA is in flight:
+    //  the compiler waits for its own loads with vmcnt(0), which would drain the operand stream anywhere later)
+    unsigned* const glut = reinterpret_cast<unsigned*>(smem + V9_GLUT);
+    if (tid < LUT_N) glut[tid] = mi355q_log2_ceil_thr[tid];
+    const GatedQ gq{a.q_mbits, a.q_emin, a.q_emax, (float)((1 << a.q_mbits) - 1), (float)(1 << a.q_mbits), 1.0f / (float)(1 << a.q_mbits)};
+#endif
     // ---- in front of the operand stream (same queue, so landed by the first counted wait): the tile's scale / bias
     //      slices, its two exception buckets and the lists' overflow words
     const int ring_lds = (int)(size_t)(lptr_t)ring, side_lds = (int)(size_t)(lptr_t)side;     // the objects' own LDS addresses
@@ -359,9 +451,33 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
                 }
                 return;
             }
+#ifdef V9_GATED_TU
+            // (the blockwise-exact product into the fp32 scratch, tile by tile as v8_fallback does it, each tile turned into the
+            //  consumer's operand right behind its exception blocks)
+            if (xlist[0] == 0 && wlist[0] == 0) return;
+            if (threadIdx.x >= 256) return;
+            {
+                const int ntiles_ = (int)(((a.M + V2_BM - 1) / V2_BM) * ((a.N + V2_BN - 1) / V2_BN));
+                for (int tile = (int)blockIdx.x; tile < ntiles_; tile += nwg) {
+                    bfp_gemm_v2_body(a, xf, wf, *reinterpret_cast<V2Smem*>(ring), tile);
+                    long long fm0, fn0;
+                    v2_tile_origin(a, tile, fm0, fn0);
+                    __threadfence();
+                    __syncthreads();
+                    tile_fix_body(a, row_bucket(xlist, fm0, a.x_bcap), row_bucket(wlist, fn0, a.w_bcap), a.x_bcap, a.w_bcap, fm0, fn0,
+                                  (int)threadIdx.x, 256);
+                    __threadfence();
+                    __syncthreads();
+                    gated_post_tile(a, glut, gq, fm0, fn0, V2_BM, V2_BN, (int)threadIdx.x, 256);
+                    __syncthreads();
+                }
+            }
+            return;
+#else
             v8_fallback(a, xf, wf, xlist, wlist, ring, ngroup > 1 ? (tm * tiles_n1 + tn) * S + split : (int)blockIdx.x,
                         ngroup > 1 ? tiles_m * tiles_n1 * S : nwg);
             return;
+#endif
         }
     }
     V9_DSR(fb0[0], vb, 0); V9_DSR(fb0[1], vb, 1024); V9_DSR(fb0[2], vb, 2048); V9_DSR(fb0[3], vb, 3072);
@@ -892,6 +1008,75 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     if (STAMP) st_x[2] = __builtin_amdgcn_s_memrealtime();
     if (look) __builtin_amdgcn_s_barrier();
     if (STAMP) st_t[4] = __builtin_amdgcn_s_memrealtime();
+#ifdef V9_GATED_TU
+    // (4g) the gated epilogue: every fragment row's values as the plain epilogue forms them (scales, bias, the tile's correction
+    //      vectors), then silu(gate) * up on the fragment pairs (2 jp, 2 jp + 1) -- the lane's four columns of both --, the
+    //      consumer's quantiser over the pair's 16 h columns (= one [1,16] block of row l16: the four lanes l16 + 16 lq) and 8 bytes
+    //      of bf16 a lane into the consumer's tiled operand.  Nothing is stored as fp32.
+    if (!(FIX && mode == 3)) {
+        int rs[8];
+        float sxr[8];
+        int4 cs[4];
+        f32x4 swr[4], bvr[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = wm * 128 + i * 16 + l16;
+            rs[i] = look ? rslot_r[rl] : -1;
+            sxr[i] = sxt[rl];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cl = wn * 64 + j * 16 + lq * 4;
+            cs[j] = look ? *reinterpret_cast<const int4*>(&cslot_r[cl]) : int4{-1, -1, -1, -1};
+            swr[j] = *reinterpret_cast<const f32x4*>(&swt[cl]);
+            bvr[j] = *reinterpret_cast<const f32x4*>(&bst[cl]);
+        }
+        const unsigned kpI = (unsigned)(Ni >> 6);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = wm * 128 + i * 16 + l16;
+            const long long row = (long long)m0 + rl;
+            f32x4 val[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[j][r] = (float)acc[i][j][r] * sxr[i] * swr[j][r] + bvr[j][r];
+            }
+            if (look) {
+                const float* rv = V9_VEC(max(rs[i], 0)) + wn * 64 + lq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(rv + j * 16);
+                    const int cc[4] = {cs[j].x, cs[j].y, cs[j].z, cs[j].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        val[j][r] += rs[i] >= 0 ? c4[r] : 0.f;
+                        val[j][r] += cc[r] >= 0 ? V9_VEC(max(cc[r], 0))[rl] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                float h[4];
+                unsigned m = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h[r] = pre_silu_mul(val[2 * jp][r], val[2 * jp + 1][r]);
+                    m = max(m, __float_as_uint(h[r]) & 0x7FFFFFFFu);
+                }
+                m = max(m, (unsigned)__shfl_xor((int)m, 16));
+                m = max(m, (unsigned)__shfl_xor((int)m, 32));
+                gated_quant<4>(h, m, glut, gq);
+                const int hc = ((n0 + wn * 64) >> 1) + jp * 16 + lq * 4;
+                if (row < a.M && 2 * hc < Ni)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(a.yb) + gated_offset((unsigned)row, (unsigned)hc, kpI)) =
+                        make_uint2(pack_bf16(h[0], h[1]), pack_bf16(h[2], h[3]));
+            }
+            V9_SB();
+        }
+        return;
+    }
+#endif
     // (4) the stores: fragment by fragment, first its tiles that no vector touches, then the others
     if (FIX && look && mode != 3) {
         // with corrections (the tile's own vectors, or the producers'): ONE pass, a row of four fragments at a time.  The wave's slots, scales and bias go to
@@ -1003,15 +1188,32 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
         V9_WAITV(0);
         __syncthreads();
         v8_fix_atomic(a, xb, wb, cx, cw, sxt, swt, m0, n0, 256);
+#ifdef V9_GATED_TU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence();
+        __syncthreads();
+        gated_post_tile(a, glut, gq, m0, n0, 256, 256, tid, V9_NT);
+#endif
     }
 }
 
-#ifndef V9_MIXED_TU
+#if !defined(V9_MIXED_TU) && !defined(V9_GATED_TU)
 static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/dbg/v9_stamps.py): where the stamps build writes
 #endif
 
 // 256 x 256 tiles, K % 128 == 0, at least four K-steps per slice (even slices under split-K).
-#ifdef V9_MIXED_TU
+#ifdef V9_GATED_TU
+// the gated epilogue: a.wm / sw / wlist = the INTERLEAVED gate / up operand (a.N = 2 I rows), a.y = fp32 scratch [M, 2 I] (slow paths
+// only), a.yb = the consumer's tiled bf16 operand [M, I], a.q_* = its quantiser
+int launch_bfp_gemm_v9_gated(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
+                             hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
+    if (!xlist || !wlist || !xf || !wf || !a.yb || !a.y) return MI355Q_E_BADARG;
+    if (a.K % 128 != 0 || a.K < 256 || a.N % 64 != 0 || a.splits > 1 || a.ngroup > 1 || a.x_post) return MI355Q_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256));
+    hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    return (int)hipGetLastError();
+}
+#elif defined(V9_MIXED_TU)
 // the mixed contraction (MIXED above): a.K / a.xm / a.wm = class 0 (row-aligned int8, K % 128 == 0), a.K1 / a.xm1 / a.wm1 = class 1
 // (tiled bf16, K1 % 64 == 0, K1 >= 128)
 int launch_bfp_gemm_v9_mixed(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
@@ -1045,7 +1247,7 @@ int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, c
 
 }  // namespace mi355q
 
-#ifndef V9_MIXED_TU
+#if !defined(V9_MIXED_TU) && !defined(V9_GATED_TU)
 // diagnostic hook, not part of include/mi355q.h: the buffer ([workgroups][2][8] 64-bit words) the MI355Q_V9_STAMPS build fills
 extern "C" __attribute__((visibility("default"))) void mi355q_debug_v9_stamps(void* buf) { mi355q::g_v9_stamps = static_cast<unsigned long long*>(buf); }
 #endif

@@ -114,6 +114,10 @@ struct GemmArgs {
     const int8_t* xm1;
     const int8_t* wm1;
     long long K1;
+    // the gated epilogue (mi355q_gemm_v9g.hip, mi355q_bfp_gemm_aligned_gated): yb = the consumer's tiled bf16 operand [M, N / 2],
+    // q_* = its block_fp quantiser (mantissa bits, clamp range of the shared exponent); null: off
+    void* yb;
+    int q_mbits, q_emin, q_emax;
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,
@@ -126,6 +130,8 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
                        int list_cap, hipStream_t st, const uint8_t* xf = nullptr, const uint8_t* wf = nullptr);
 // the mixed contraction of the 256 x 256 tile kernel (mi355q_gemm_v9m.hip): a.K1 / a.xm1 / a.wm1 set
 int launch_bfp_gemm_v9_mixed(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
+                             const uint8_t* xf, const uint8_t* wf);
+int launch_bfp_gemm_v9_gated(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                              const uint8_t* xf, const uint8_t* wf);
 int launch_bfp_pack_bits(const int8_t* mant, uint16_t* out, long long rows, long long K, int width, hipStream_t st);
 int launch_bfp_expand(int mode, const uint16_t* packed, const uint8_t* codes, void* out, long long rows, long long K, int width,

@@ -19,8 +19,8 @@
 
 namespace mi355q {
 
-template <int MAXIT>
-__global__ __launch_bounds__(256) void bfp_quant_classes_kernel(const QuantArgs a, const uint16_t* __restrict__ cmap, int n0, int n1,
+template <int MAXIT, bool FULL, int WPS>
+__global__ __launch_bounds__(256, WPS) void bfp_quant_classes_kernel(const QuantArgs a, const uint16_t* __restrict__ cmap, int n0, int n1,
                                                                 int8_t* __restrict__ mt, uint8_t* __restrict__ flag,
                                                                 float* __restrict__ rscale, int exp_offset, int* __restrict__ list,
                                                                 int* __restrict__ list_to_clear, int bcap, uint16_t* __restrict__ bt) {
@@ -36,23 +36,19 @@ __global__ __launch_bounds__(256) void bfp_quant_classes_kernel(const QuantArgs 
         const long long grp = wi >> 7, in = wi & 127;
         return (grp << 7) + ((in & 7) << 4) + (in >> 3);
     };
-    auto valid = [&](int it) { return it < nit && it * 64 + wave * 16 + (lane >> 2) < nkb; };
+    auto valid = [&](int it) { return FULL || (it < nit && it * 64 + wave * 16 + (lane >> 2) < nkb); };     // (FULL: K = 1024 MAXIT, no guards)
     auto load_raw = [&](float4 (&v)[MAXIT], long long row) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)
-            v[it] = valid(it) ? *(reinterpret_cast<const float4*>(a.x + row * K) + it * 256 + tid) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[it] = valid(it) ? reinterpret_cast<const float4*>(a.x)[(unsigned)row * (unsigned)(K >> 2) + (unsigned)(it * 256 + tid)] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float4 v[MAXIT];
     if ((long long)blockIdx.x < a.rows) load_raw(v, row_of(blockIdx.x));
     // the lane's block columns never change: their classes and positions once, in registers
-    int pos[MAXIT];
-    bool c1[MAXIT];
+    int pos[MAXIT];                                            // position | class << 15, decoded where it is used
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const unsigned m = valid(it) ? cmap[it * 64 + wave * 16 + (lane >> 2)] : 0u;
-        pos[it] = (int)(m & 0x7FFFu);
-        c1[it] = (m >> 15) != 0u;
-    }
+    for (int it = 0; it < MAXIT; ++it) pos[it] = valid(it) ? (int)cmap[it * 64 + wave * 16 + (lane >> 2)] : 0;
+#define CLS_C1(it) ((pos[it] >> 15) != 0)
     load_lut<FMT_BFP>(lut);
     if (list_to_clear && blockIdx.x == 0) {
         const int cb = bcap < 0 ? ROW_BCAP : bcap;
@@ -130,32 +126,34 @@ __global__ __launch_bounds__(256) void bfp_quant_classes_kernel(const QuantArgs 
         // operand is 16 rows x 32 values = two blocks, [8-value group 0..3][row][16 bytes]
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            if (valid(it) && c1[it]) {
+            if (valid(it) && CLS_C1(it)) {
                 const int e = code[it] - a.code_bias;
                 const float s = __builtin_ldexpf(1.0f, e - mbits_int);
                 const float f0 = (float)(int)(signed char)(pk[it]), f1 = (float)(int)(signed char)(pk[it] >> 8);
                 const float f2 = (float)(int)(signed char)(pk[it] >> 16), f3 = (float)(int)(signed char)(pk[it] >> 24);
                 const unsigned h0 = __float_as_uint(f0 * s) >> 16, h1 = __float_as_uint(f1 * s) >> 16;       // (exact: <= 7 significant bits)
                 const unsigned h2 = __float_as_uint(f2 * s) >> 16, h3 = __float_as_uint(f3 * s) >> 16;
-                const int p = pos[it], q = lane & 3;
-                uint8_t* d = reinterpret_cast<uint8_t*>(bt) + ((row >> 4) * kp1 + (p >> 1)) * 1024 + ((p & 1) * 2 + (q >> 1)) * 256 +
-                             (row & 15) * 16 + (q & 1) * 8;
-                *reinterpret_cast<uint2*>(d) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                const int p = pos[it] & 0x7FFF, q = lane & 3;
+                // (32-bit offsets from the uniform base: rows * K < 2^31, checked by the launcher)
+                const unsigned o = (((unsigned)row >> 4) * (unsigned)kp1 + ((unsigned)p >> 1)) * 1024u + (((unsigned)p & 1u) * 2u + ((unsigned)q >> 1)) * 256u +
+                                   ((unsigned)row & 15u) * 16u + ((unsigned)q & 1u) * 8u;
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(bt) + o) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
             }
         }
         // class 0: the row's exponent over ITS blocks (a class-1 block takes no part: largest mantissa 0 = "no block here")
-        int am0[MAXIT];
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) am0[it] = c1[it] ? 0 : amax[it];
+        for (int it = 0; it < MAXIT; ++it) amax[it] = CLS_C1(it) ? 0 : amax[it];
         int E = 0;
-        const bool flagged = bcap < 0 ? false : align_row_impl<MAXIT, false, true>(pk, am0, code, nit, nkb, row, list, rsm, E, bcap, pos);
+        // (an exception entry records pos[it]: for a class-0 block its position in the int8 operand -- the class bit is clear)
+        const bool flagged = bcap < 0 ? false : align_row_impl<MAXIT, FULL, true>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap, pos);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            if (valid(it) && !c1[it]) {
+            if (valid(it) && !CLS_C1(it)) {
                 const int p = pos[it];
-                int8_t* d = mt + ((row >> 4) * kp0 + (p >> 2)) * 1024 + (p & 3) * 256 + (row & 15) * 16 + (lane & 3) * 4;
-                *reinterpret_cast<unsigned*>(d) = pk[it];
-                if ((lane & 3) == 0) a.code[row * n0 + p] = (uint8_t)(flagged ? E : code[it]);
+                const unsigned o = (((unsigned)row >> 4) * (unsigned)kp0 + ((unsigned)p >> 2)) * 1024u + ((unsigned)p & 3u) * 256u + ((unsigned)row & 15u) * 16u +
+                                   ((unsigned)lane & 3u) * 4u;
+                *reinterpret_cast<unsigned*>(mt + o) = pk[it];
+                if ((lane & 3) == 0) a.code[(unsigned)row * (unsigned)n0 + (unsigned)p] = (uint8_t)(flagged ? E : code[it]);
             }
         }
         if (tid == 0) {
@@ -168,19 +166,23 @@ __global__ __launch_bounds__(256) void bfp_quant_classes_kernel(const QuantArgs 
 
 int launch_quant_classes(const QuantArgs& a, const uint16_t* cmap, int n0, int n1, int8_t* mt, uint8_t* flag, float* rscale,
                          int exp_offset, int* list, int* list_to_clear, uint16_t* bt, hipStream_t st, int bcap) {
+    if (a.rows * a.cols >= (1ll << 30)) return MI355Q_E_UNSUPPORTED;       // (32-bit byte offsets inside the kernel)
     long long grid = a.rows;
-    if (grid > 1024) grid = 1024;
+    const long long cap = a.cols == 4096 ? 1280 : 1024;          // (K = 4096: 87 registers, five workgroups a compute unit)
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
-#define MI355Q_LAUNCH_CLS(MAXIT_)                                                                                     \
-    hipLaunchKernelGGL((bfp_quant_classes_kernel<MAXIT_>), (unsigned)grid, 256, 0, st, a, cmap, n0, n1, mt, flag, rscale, exp_offset, \
-                       list, list_to_clear, bcap, bt)
-    if (a.cols <= 4096) MI355Q_LAUNCH_CLS(4);
-    else if (a.cols <= 8192) MI355Q_LAUNCH_CLS(8);
-    else if (a.cols <= 16384) MI355Q_LAUNCH_CLS(16);
+#define MI355Q_LAUNCH_CLS(MAXIT_, FULL_, WPS_)                                                                        \
+    hipLaunchKernelGGL((bfp_quant_classes_kernel<MAXIT_, FULL_, WPS_>), (unsigned)grid, 256, 0, st, a, cmap, n0, n1, mt, flag, rscale, \
+                       exp_offset, list, list_to_clear, bcap, bt)
+    if (a.cols == 4096) MI355Q_LAUNCH_CLS(4, true, 1);
+    else if (a.cols <= 4096) MI355Q_LAUNCH_CLS(4, false, 1);
+    else if (a.cols <= 8192) MI355Q_LAUNCH_CLS(8, false, 1);
+    else if (a.cols <= 16384) MI355Q_LAUNCH_CLS(16, false, 1);
     else
         return MI355Q_E_UNSUPPORTED;
 #undef MI355Q_LAUNCH_CLS
     return (int)hipGetLastError();
 }
+#undef CLS_C1
 
 }  // namespace mi355q

@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .quantize import get_quantized_cls, get_quantized_func, grouped_linear
+from .quantize import gated_mlp, get_quantized_cls, get_quantized_func, grouped_linear
 from .quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
 
 
@@ -288,6 +288,12 @@ class _LlamaLayer(nn.Module):
             n1, n2 = self.input_layernorm, self.post_attention_layernorm
             x = (self.self_attn(x, mask, position_ids, norm=(n1.weight, n1.eps), residual=x) if fres
                  else x + self.self_attn(x, mask, position_ids, norm=(n1.weight, n1.eps)))
+            if self.down_proj.config.get("mi355q_fused_activation", False):
+                # round 6: gate / up interleaved in ONE product whose epilogue writes down_proj's quantised operand (gated_mlp); None
+                # when the layers do not qualify: the grouped launch + the quantiser that reads silu(gate) * up, as before
+                y = gated_mlp(x, self.gate_proj, self.up_proj, self.down_proj, norm=(n2.weight, n2.eps), residual=x if fres else None)
+                if y is not None:
+                    return y if fres else x + y
             gate, up = grouped_linear(x, (self.gate_proj, self.up_proj), norm=(n2.weight, n2.eps))
             if self.down_proj.config.get("mi355q_fused_activation", False):
                 return self.down_proj.forward_after(gate, "silu_mul", up, residual=x) if fres else x + self.down_proj.forward_after(gate, "silu_mul", up)

@@ -1024,6 +1024,78 @@ def bfp_gemm_mixed(x0: AlignedOperand, w0: AlignedOperand, x1: torch.Tensor, w1:
     return out
 
 
+def interleave_gate_up(wg: AlignedOperand, wu: AlignedOperand):
+    """gate_proj's and up_proj's row-aligned operands [I, K] as ONE operand [2 I, K] with their rows interleaved in chunks of 16
+    (rows 32 c .. 32 c + 15 = gate rows 16 c .., rows 32 c + 16 .. = the same rows of up): what bfp_gemm_aligned_gated multiplies.
+    Tiled mantissas are copied piece row by piece row, exponents / flags / scales row chunk by row chunk, the exception lists
+    are re-bucketed on the host with their row numbers mapped (a one-off per pair of layers).  None when the pair does not
+    qualify (I % 128, different formats, overflowed lists, a re-bucketed bucket beyond its 120 entries)."""
+    import numpy as np
+    I, K = wg.rows, wg.K
+    if (wu.rows != I or wu.K != K or I % 128 or K % 64 or wg.mbits != wu.mbits or wg.exp_bias != wu.exp_bias
+            or wg.list_cap != ROW_BUCKET_CAP or wu.list_cap != ROW_BUCKET_CAP or wg.unaligned or wu.unaligned):
+        return None
+    dev = wg.tiled.device
+    nb = K // 16
+    pr = K * 16                                               # bytes of one piece row (16 rows x K)
+    il = lambda a, b, unit: torch.stack((a.reshape(I // 16, unit), b.reshape(I // 16, unit)), dim=1).reshape(-1).contiguous()
+    tiled = il(wg.tiled[: I * K], wu.tiled[: I * K], pr)
+    exp = il(wg.exp.reshape(-1)[: I * nb], wu.exp.reshape(-1)[: I * nb], 16 * nb)
+    flag = il(wg.rowflag[:I], wu.rowflag[:I], 16)
+    gscale = il(wg.gscale[:I], wu.gscale[:I], 16)
+    og, eg = row_list_entries(wg.sparse, I)
+    ou, eu = row_list_entries(wu.sparse, I)
+    if og or ou:
+        return None
+    eg, eu = eg.copy(), eu.copy()
+    eg[:, 0] = (eg[:, 0] // 16) * 32 + eg[:, 0] % 16
+    eu[:, 0] = (eu[:, 0] // 16) * 32 + 16 + eu[:, 0] % 16
+    ent = np.concatenate([eg, eu]) if len(eg) + len(eu) else np.zeros((0, 8), np.int32)
+    words = 8 + 8 * ROW_BUCKET_CAP
+    nbk = (2 * I + ROW_BUCKET_ROWS - 1) // ROW_BUCKET_ROWS
+    lst = np.zeros(8 + nbk * words, np.int32)
+    for b in range(nbk):
+        mine = ent[(ent[:, 0] // ROW_BUCKET_ROWS) == b]
+        mine = mine[np.lexsort((mine[:, 1], mine[:, 0]))]
+        if len(mine) > ROW_BUCKET_CAP:
+            return None
+        base = 8 + b * words
+        lst[base] = len(mine)
+        lst[base + 8: base + 8 + 8 * len(mine)] = mine.reshape(-1)
+    sparse = torch.from_numpy(lst).to(dev)
+    return AlignedOperand(2 * I, K, None, tiled, exp, flag, gscale, sparse, wg.mbits, wg.exp_bias, row_aligned=True, bucket_cap=ROW_BUCKET_CAP)
+
+
+_GATED_BUFFERS = _StreamCache(8)
+
+
+def bfp_gemm_aligned_gated(x: AlignedOperand, w_gu: AlignedOperand, q_width: int, q_exponent_width: int, q_exponent_bias, bias_gu=None):
+    """x [M, K] against the interleaved gate / up operand (interleave_gate_up) with silu(gate) * up and the CONSUMER's block_fp
+    quantiser in the store epilogue (include/mi355q.h, mi355q_bfp_gemm_aligned_gated): returns the tiled bf16 operand [M, I] that
+    bf16_gemm_tiled multiplies against down_proj's weights -- the buffer is shared by calls of the same shape on the same stream
+    (consume before the next call).  None when the library does not take the shapes."""
+    M, K, I = x.rows, x.K, w_gu.rows // 2
+    assert w_gu.K == K
+    lib = _lib.load_library()
+    dev = x.tiled.device
+    sp = _stream_ptr(dev)
+    key = (dev.index, sp, "gated", M, I)
+    buf = _GATED_BUFFERS.get(key)
+    if buf is None:
+        # (the fp32 scratch is touched on the kernel's slow paths only; the pages of an untouched allocation cost nothing)
+        buf = dict(out=torch.zeros(lib.mi355q_bfp_tiled_bytes(M, 2 * I), dtype=torch.int8, device=dev),
+                   scratch=torch.empty(M, 2 * I, dtype=torch.float32, device=dev))
+        _GATED_BUFFERS.put(key, buf)
+    x.c_struct(), w_gu.c_struct()
+    with _on_device(dev):
+        rc = lib.mi355q_bfp_gemm_aligned_gated(x._cs_addr, w_gu._cs_addr, _ptr(bias_gu), _ptr(buf["scratch"]), _ptr(buf["out"]), M, I, K,
+                                               int(q_width), int(q_exponent_width), _default_bias(q_exponent_bias), sp)
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "mi355q_bfp_gemm_aligned_gated")
+    return buf["out"]
+
+
 def bfp_gemm_aligned_multi(x: AlignedOperand, ws, biases=None, outs=None):
     """[x . w^T + bias for w in ws] in ONE launch of the tile GEMM (equally shaped row-aligned weight operands: q / k / v,
     gate / up); returns None when the library does not take the group (callers then use bfp_gemm_aligned per weight).

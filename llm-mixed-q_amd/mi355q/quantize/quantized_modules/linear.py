@@ -749,6 +749,12 @@ class _LinearBase(nn.Linear):
                 and self.out_features % 4 == 0 and residual.data_ptr() % 16 == 0
                 and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)))
 
+    def _residual_operand_ok(self, residual, lead) -> bool:
+        """`residual` can ride in the bf16 product's stores (mi355q_bf16_gemm_tiled_res): fp32, contiguous, [.., out_features]"""
+        return (torch.is_tensor(residual) and residual.is_cuda and residual.dtype == torch.float32 and residual.is_contiguous()
+                and tuple(residual.shape) == tuple(lead) + (self.out_features,) and self.out_features % 4 == 0
+                and residual.data_ptr() % 16 == 0 and not (torch.is_grad_enabled() and residual.requires_grad))
+
     def forward_residual(self, x, residual):
         """residual + self(x) (modeling_llama.py:259, modeling_opt.py:375, 425: the add a decoder layer puts behind o_proj / fc2) --
         in the product's stores where the layer runs on the per-block-exponent route (same bits), as two steps otherwise"""
@@ -843,6 +849,70 @@ class _LinearBase(nn.Linear):
             self.__class__.__name__, self.in_features, self.out_features, self.bias is not None, self.bypass,
             self.is_ptq, self.config["data_in_width"], self.config["weight_width"],
             self.config.get("bias_width", "NA"))
+
+
+def gated_mlp(x, gate, up, down, norm=None, residual=None):
+    """down(silu(gate(x)) * up(x)) [+ residual] for block_fp PTQ layers (modeling_llama.py:216, the Llama MLP) as TWO launches
+    behind the activation quantiser instead of four: x -- with LlamaRMSNorm applied by its quantiser when `norm` = (weight, eps) --
+    against gate's and up's weights INTERLEAVED in chunks of 16 rows (ops.interleave_gate_up, built once per pair), whose store
+    epilogue forms silu(gate) * up in registers, quantises it with down's activation quantiser and writes down's tiled bf16
+    operand (ops.bfp_gemm_aligned_gated: the two [tokens, intermediate] fp32 tensors are never written, the separate
+    silu-mul-quantise launch -- 180 MB read, 45 MB written per Llama-7B layer at 2048 tokens -- is gone); then down's product on the
+    bf16 flavour of the tile GEMM, the residual in its stores.  Same bits as grouped_linear + down.forward_after.  Returns None
+    whenever the pair / the consumer does not qualify (first PTQ forward, gate / up not on the row-scale int8 route, down not on
+    the per-block route, shapes, autograd ...): the caller then takes that path."""
+    from ...sharded import RowShardedLinear
+    layers = (gate, up, down)
+    if any(isinstance(l, RowShardedLinear) or not isinstance(l, _LinearBase) for l in layers):
+        return None
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and 2 <= x.ndim <= 3) or (torch.is_grad_enabled() and x.requires_grad):
+        return None
+    if not all(l.arith == "block_fp" and l.is_ptq and not l.bypass and not l.weight_requires_quantisation and l._pending_flavour is None
+               and l._packed_is_current() for l in layers):
+        return None
+    c, dc = gate.config, down.config
+    if (c.get("mi355q_fused_gate_up", True) in (False, "off") or not dc.get("mi355q_fused_activation", False) or dc["data_in_width"] > 9
+            or gate.in_features != up.in_features or gate.out_features != up.out_features or down.in_features != gate.out_features
+            or gate.in_features % 128 or gate.out_features % 128 or (gate.bias is None) != (up.bias is None)
+            or (norm is not None and len(norm) != 2)):
+        return None
+    plan = gate._int8_plan(x)
+    if plan is None or up._int8_plan(x) != plan or down._int8_plan(x.new_empty((1, down.in_features))) is None:
+        return None
+    if not all(l._align_mode == "rows" and not l._uses_bf16_route() and l._mixed is None and l._w_packed is None
+               and l._x_cap == ops.ROW_BUCKET_CAP for l in (gate, up)):
+        return None
+    if not all(gate.config[k] == up.config[k] for k in ("data_in_width", "data_in_exponent_width", "data_in_exponent_bias")):
+        return None
+    if not down._uses_bf16_route() or (down._w_packed is not None and down._w_packed.row_scale_flavour):
+        return None
+    with torch.no_grad():
+        pair = gate.__dict__.get("_gated_pair")
+        key = (id(up), gate.weight._version, up.weight._version, gate._packed[0].tiled.data_ptr(), up._packed[0].tiled.data_ptr())
+        if pair is None or pair[0] != key:
+            w_gu = ops.interleave_gate_up(gate._packed[0], up._packed[0])
+            b_gu = None
+            if w_gu is not None and gate.bias is not None:
+                I = gate.out_features
+                b_gu = torch.stack((gate.bias.data.reshape(I // 16, 16), up.bias.data.reshape(I // 16, 16)), dim=1).reshape(-1).contiguous()
+            pair = gate.__dict__["_gated_pair"] = (key, w_gu, b_gu)
+        _, w_gu, b_gu = pair
+        if w_gu is None:
+            return None
+        x2 = x.reshape(-1, gate.in_features)
+        xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                                bucket_cap=gate._x_cap, pre=None if norm is None else ("rmsnorm", norm[0], norm[1]))
+        xt = ops.bfp_gemm_aligned_gated(xa, w_gu, dc["data_in_width"], dc["data_in_exponent_width"], dc["data_in_exponent_bias"], b_gu)
+        if xt is None:
+            return None
+        M = x2.shape[0]
+        res2 = None
+        if residual is not None and down._residual_operand_ok(residual, x.shape[:-1]):
+            res2 = residual.reshape(-1, down.out_features)
+        y = ops.bf16_gemm_tiled(xt, down._bf16_weight_operand(x.device), M, down.out_features, down.in_features, down.bias,
+                                out=down._take_out(M), residual=res2)
+        y = y.reshape(*x.shape[:-1], down.out_features)
+        return y if residual is None or res2 is not None else residual + y
 
 
 def grouped_linear(x, layers, norm=None):

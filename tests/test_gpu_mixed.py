@@ -243,10 +243,10 @@ def test_mixed_layer_serves_the_fused_steps_and_leaves_when_class_0_stops_fittin
             b = free[int(r.integers(len(free)))]
             wild[row, b * 16:b * 16 + 16] *= 4096.0
         ref = O.bfp_linear_int(wild.numpy(), w0, b0, cfg)
-        for call in range(4):                       # (the overflow word is read at calls 2 and 4 of the doubling schedule)
+        for call in range(12):                      # (the overflow word is read on a doubling schedule of calls: here at 8 and 16)
             yw = lin(wild.to("cuda:0"))
             assert np.abs(yw.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
-        assert lin._mixed is None and lin._uses_bf16_route()
+        assert lin._calls >= 16 and lin._mixed is None and lin._uses_bf16_route()
         lin2, _, _ = _lin(K, N, dict(cfg, mi355q_keep_master=True), seed=7)
         lin2(xd)
         assert lin2._mixed is not None
