@@ -1064,8 +1064,12 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
                     h[r] = pre_silu_mul(val[2 * jp][r], val[2 * jp + 1][r]);
                     m = max(m, __float_as_uint(h[r]) & 0x7FFFFFFFu);
                 }
-                m = max(m, (unsigned)__shfl_xor((int)m, 16));
-                m = max(m, (unsigned)__shfl_xor((int)m, 32));
+                {   // the block's four lanes (l16 + 16 lq) by lane swaps on the VALU (gfx950; no LDS crossbar round trip)
+                    auto sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+                    m = max(sw[0], sw[1]);
+                    sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+                    m = max(sw[0], sw[1]);
+                }
                 gated_quant<4>(h, m, glut, gq);
                 const int hc = ((n0 + wn * 64) >> 1) + jp * 16 + lq * 4;
                 if (row < a.M && 2 * hc < Ni)

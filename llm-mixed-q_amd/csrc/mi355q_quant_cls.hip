@@ -122,8 +122,13 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_classes_kernel(const Quant
             }
         }
         if (wi + gridDim.x < a.rows) load_raw(v, row_of(wi + gridDim.x));          // (the next row's loads behind the mantissas)
+        // WIDE (K = 4096, every lane a block in every slab): behind the row decision a 4 x 4 transpose inside the quad leaves lane q
+        // with the WHOLE block of slab q (bfp_quant_align_rows_kernel, ST16) -- one 16-byte store for a class-0 block, two for a
+        // class-1 block (its sixteen bf16 values) instead of four dword + up to four 8-byte stores a lane
+        constexpr bool WIDE = FULL && MAXIT == 4;
         // class 1 first: the block's values as bf16 (mantissa x 2^(e - mbits), exact), 8 bytes a lane; a piece of the bf16
         // operand is 16 rows x 32 values = two blocks, [8-value group 0..3][row][16 bytes]
+        if constexpr (!WIDE)
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             if (valid(it) && CLS_C1(it)) {
@@ -146,6 +151,43 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_classes_kernel(const Quant
         int E = 0;
         // (an exception entry records pos[it]: for a class-0 block its position in the int8 operand -- the class bit is clear)
         const bool flagged = bcap < 0 ? false : align_row_impl<MAXIT, FULL, true>(pk, amax, code, nit, nkb, row, list, rsm, E, bcap, pos);
+        if constexpr (WIDE) {
+            const int q = lane & 3;
+            unsigned r0 = pk[0], r1 = pk[1], r2 = pk[2], r3 = pk[3];
+            {
+                const bool odd = q & 1;
+                const unsigned s01 = odd ? r0 : r1, s23 = odd ? r2 : r3;
+                const unsigned g01 = (unsigned)__builtin_amdgcn_mov_dpp((int)s01, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                const unsigned g23 = (unsigned)__builtin_amdgcn_mov_dpp((int)s23, 0xB1, 0xF, 0xF, true);
+                if (odd) { r0 = g01; r2 = g23; } else { r1 = g01; r3 = g23; }
+            }
+            {
+                const bool hi = q & 2;
+                const unsigned s02 = hi ? r0 : r2, s13 = hi ? r1 : r3;
+                const unsigned g02 = (unsigned)__builtin_amdgcn_mov_dpp((int)s02, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                const unsigned g13 = (unsigned)__builtin_amdgcn_mov_dpp((int)s13, 0x4E, 0xF, 0xF, true);
+                if (hi) { r0 = g02; r1 = g13; } else { r2 = g02; r3 = g13; }
+            }
+            // lane q: bytes 0..15 of the block of slab q; its map word and exponent (the same in all four lanes of the quad)
+            const int pq = q == 0 ? pos[0] : q == 1 ? pos[1] : q == 2 ? pos[2] : pos[3];
+            const int cq = q == 0 ? code[0] : q == 1 ? code[1] : q == 2 ? code[2] : code[3];
+            const int p = pq & 0x7FFF;
+            if ((pq >> 15) == 0) {
+                const unsigned o = (((unsigned)row >> 4) * (unsigned)kp0 + ((unsigned)p >> 2)) * 1024u + ((unsigned)p & 3u) * 256u + ((unsigned)row & 15u) * 16u;
+                *reinterpret_cast<uint4*>(mt + o) = make_uint4(r0, r1, r2, r3);
+                a.code[(unsigned)row * (unsigned)n0 + (unsigned)p] = (uint8_t)(flagged ? E : cq);
+            } else {
+                const float sc1 = __builtin_ldexpf(1.0f, cq - a.code_bias - mbits_int);
+                auto two = [&](unsigned w, int b) {          // bytes b, b + 1 of w as two bf16 (exact: <= 7 significant bits)
+                    const float lo = (float)(int)(signed char)(w >> (8 * b)) * sc1, hi2 = (float)(int)(signed char)(w >> (8 * b + 8)) * sc1;
+                    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi2) & 0xFFFF0000u);
+                };
+                const unsigned o = (((unsigned)row >> 4) * (unsigned)kp1 + ((unsigned)p >> 1)) * 1024u + ((unsigned)p & 1u) * 512u + ((unsigned)row & 15u) * 16u;
+                uint8_t* d = reinterpret_cast<uint8_t*>(bt) + o;
+                *reinterpret_cast<uint4*>(d) = make_uint4(two(r0, 0), two(r0, 2), two(r1, 0), two(r1, 2));              // values 0..7: group 2 (p & 1)
+                *reinterpret_cast<uint4*>(d + 256) = make_uint4(two(r2, 0), two(r2, 2), two(r3, 0), two(r3, 2));        // values 8..15: the next group
+            }
+        } else
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             if (valid(it) && !CLS_C1(it)) {
@@ -168,7 +210,7 @@ int launch_quant_classes(const QuantArgs& a, const uint16_t* cmap, int n0, int n
                          int exp_offset, int* list, int* list_to_clear, uint16_t* bt, hipStream_t st, int bcap) {
     if (a.rows * a.cols >= (1ll << 30)) return MI355Q_E_UNSUPPORTED;       // (32-bit byte offsets inside the kernel)
     long long grid = a.rows;
-    const long long cap = a.cols == 4096 ? 1280 : 1024;          // (K = 4096: 87 registers, five workgroups a compute unit)
+    const long long cap = a.cols == 4096 ? 1536 : 1024;          // (K = 4096: 75 registers, six workgroups a compute unit)
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
 #define MI355Q_LAUNCH_CLS(MAXIT_, FULL_, WPS_)                                                                        \

@@ -15,6 +15,9 @@ import numpy as np
 import torch
 
 
+GATED = True          # (--no-gated: the grouped gate / up launch + the quantiser that reads silu(gate) * up, as before round 6)
+
+
 def quant_config(storage: str, knobs: bool = True):
     d = dict(name="block_fp", bypass=False, is_ptq=True,
              data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127, data_in_block_size=[1, 16],
@@ -22,7 +25,7 @@ def quant_config(storage: str, knobs: bool = True):
              bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
     if knobs:
         d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
-                 mi355q_token_major_output=True, mi355q_fused_residual=True)
+                 mi355q_token_major_output=True, mi355q_fused_residual=True, mi355q_fused_gate_up=GATED)
     if storage == "packed":
         d.update(mi355q_weight_storage="packed")
     # the rotary tables of every shipped TOML: 8-bit fixed point (configs/quantization/bfp_6bit.toml)
@@ -86,7 +89,7 @@ def run(layers=32, tokens=2048, steps=5, storage="resident", graph=True, parity=
                "resident_GiB_after_packing": round(mem_after_pack, 2),
                "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2), "linear_routes": routes,
                # (torch's own GEMMs an eager forward called: the unquantised lm_head -- as in the reference -- and nothing else)
-               "vendor_gemm_calls_per_forward": vendor}
+               "vendor_gemm_calls_per_forward": vendor, "gated_mlp": GATED}
         if graph:
             g = graphs.GraphedForward(lambda t: model(t)[0], (ids,))
             for _ in range(2):
@@ -152,5 +155,7 @@ if __name__ == "__main__":
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-knobs", action="store_true")
     ap.add_argument("--no-spread", action="store_true", help="plain N(0, 0.02) weights instead of rows of different magnitude")
+    ap.add_argument("--no-gated", action="store_true", help="without the gated epilogue (mi355q_fused_gate_up = False)")
     a = ap.parse_args()
+    GATED = not a.no_gated
     print(json.dumps(run(a.layers, a.tokens, a.steps, a.storage, not a.no_graph, not a.no_parity, not a.no_knobs, not a.no_spread)), flush=True)
