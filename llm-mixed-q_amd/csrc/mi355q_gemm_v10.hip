@@ -10,6 +10,12 @@
 //     128 x 256:  1 x 4 waves of 128 x 64  (the 256 x 256 kernel's wave tile: 384 B of LDS fragment reads per MFMA)
 //     256 x 128:  2 x 2 waves of 128 x 64
 //     128 x 128:  2 x 2 waves of  64 x 64  (512 B per MFMA: for grids that would otherwise leave SIMDs idle)
+// KG = 2 (round 6): TWO K-GROUPS in one 8-wave workgroup -- waves 0-3 take the even K-steps, waves 4-7 the odd ones of the SAME tile,
+// each group through its own ring on the same barriers; behind the loop the groups swap half of their accumulators through LDS
+// (int32 sums: exact in any order; fp32: two terms) and each stores its half of the tile.  For grids of at most one workgroup a
+// compute unit, where a four-wave workgroup leaves every wave ALONE on its SIMD (355 clocks a K-step against 256 of MFMA,
+// tools/ubench/vmem_issue.hip) and splitting K ACROSS workgroups costs a 4-us exchange between XCDs: two waves a SIMD, one prologue,
+// one epilogue, the exchange inside the compute unit.
 // FOUR waves a workgroup and <= 80 KiB of LDS, so that TWO workgroups share a compute unit (two waves per SIMD, as in the
 // 256 x 256 kernel, but each pair of tiles runs its own barriers: one workgroup's prologue / store epilogue hides behind the
 // other's K loop), THREE for the 128 x 128 tile.  The 128-row tile of mi355q_gemm_v8.hip (8 waves of 64 x 64, one workgroup a
@@ -122,21 +128,25 @@ static_assert(V10Sched<8, 4>::wait(0) == 2 && V10Sched<8, 4>::wait(1) == 2 && V1
 constexpr int V10_SXT = 0, V10_SWT = 1024, V10_BIAS = 2048, V10_FLAGS = 3072, V10_OVF = V10_FLAGS + 256;
 constexpr int V10_HEAD = V10_OVF + 512, V10_LIVE = V10_HEAD + 512, V10_MAP = V10_LIVE + 512;     // (the maps: (BM + BN) words, last)
 
-template <int NWM, int NWN, int TI, int TJ, int NS, int OCC, int FIX, bool BF16>
-__global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu((OCC < 2 ? 2 : OCC), (OCC < 2 ? 2 : OCC)))) void bfp_gemm_v10(const GemmArgs a_in, const float* __restrict__ sx,
+template <int NWM, int NWN, int TI, int TJ, int NS, int OCC, int FIX, bool BF16, int KG = 1>
+__global__ __launch_bounds__(64 * NWM * NWN * KG) __attribute__((amdgpu_waves_per_eu((OCC < 2 ? 2 : OCC), (OCC < 2 ? 2 : OCC)))) void bfp_gemm_v10(const GemmArgs a_in, const float* __restrict__ sx,
                                                                     const float* __restrict__ sw_in, const int* __restrict__ xlist,
                                                                     const int* __restrict__ wlist_in, const uint8_t* __restrict__ xf,
                                                                     const uint8_t* __restrict__ wf_in) {
     static_assert(!BF16 || FIX == 0, "the bf16 arithmetic has no exception lists");
-    constexpr int NW = NWM * NWN, NT = 64 * NW, WM = TI * 16, WN = TJ * 16, BM = NWM * WM, BN = NWN * WN;
-    constexpr int PA = BM / 16, PB = BN / 16, NP = PA + PB, LPW = NP / NW, LPA = PA / NW;
-    static_assert(NP % NW == 0 && PA % NW == 0, "a wave stages whole pieces of one operand per index");
+    static_assert(KG == 1 || (KG == 2 && OCC == 1 && TI % 2 == 0), "K-groups: two, one workgroup a compute unit");
+    // NWG: waves of one K-group (they own the tile's wave tiles and stage its ring); NW / NT: all waves / threads of the workgroup
+    // (the bookkeeping, the exception vectors and the fallback are shared work)
+    constexpr int NWG = NWM * NWN, NW = NWG * KG, NT = 64 * NW, WM = TI * 16, WN = TJ * 16, BM = NWM * WM, BN = NWN * WN;
+    constexpr int PA = BM / 16, PB = BN / 16, NP = PA + PB, LPW = NP / NWG, LPA = PA / NWG;
+    static_assert(NP % NWG == 0 && PA % NWG == 0, "a wave stages whole pieces of one operand per index");
     constexpr int STAGE = NP * 1024, RING = NS * STAGE;
     static_assert(NS >= 3 && (NS - 3) * LPW <= 63, "ring: NS - 2 K-steps of LDS-DMA in flight, counted by vmcnt");
     constexpr int V10_SIDE = V10_MAP + (BM + BN) * 4;
-    static_assert(RING + V10_SIDE <= 160 * 1024 / OCC, "LDS for OCC workgroups a compute unit");
+    static_assert(KG * RING + V10_SIDE <= 160 * 1024 / OCC, "LDS for OCC workgroups a compute unit");
+    static_assert(KG == 1 || NW * (TI / 2) * TJ * 1024 <= KG * RING, "the accumulator exchange of the two K-groups fits the rings");
     static_assert(RING >= 40 * 1024, "the blockwise fallback's LDS, the buckets and vectors behind the K loop");
-    static_assert(NT == 256, "the blockwise fallback runs a 256-thread team");
+    static_assert(NT == 256 * KG, "the blockwise fallback runs a 256-thread team (the waves beyond it leave)");
     using S = V10Sched<TI, TJ>;
     constexpr int VLEN = BM > BN ? BM : BN;                     // floats of a correction vector
     // EARLY: LDS to spare for the tile's two exception buckets beside the ring -- they arrive in front of the operand stream,
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     // every wave requests the gathers of its first UE entries BEFORE the K loop and keeps them in registers across it: behind the
     // loop only the vectors remain to be formed.  Otherwise the buckets are fetched behind the loop into the ring (two dependent
     // round trips exposed: ~10 of the 28 us of 4096 x 512 x 4096 were this, profiles/r05_small_tiles.txt).
-    constexpr bool EARLY = FIX && RING + V10_SIDE + 8192 <= 160 * 1024 / OCC;
+    constexpr bool EARLY = FIX && KG * RING + V10_SIDE + 8192 <= 160 * 1024 / OCC;
     constexpr int UE = EARLY && TI == 4 ? 6 : 0, VC = VLEN / 64, G = UE * VC;      // G: gather loads a wave issues in front of the loop
     constexpr int VOFF = EARLY ? 0 : 8192;                      // vectors behind the K loop: the ring (behind the bucket copies)
     constexpr int VCAP = (RING - VOFF) / (VLEN * 4) < 128 ? (RING - VOFF) / (VLEN * 4) : 128;
@@ -158,7 +168,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     static_assert(V10_SIDE % 16 == 0, "the dynamic part starts 16-byte aligned");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / NWN, wn = wave % NWN, l16 = lane & 15, lq = lane >> 4;
+    const int grp = KG > 1 ? wave / NWG : 0, wv = KG > 1 ? wave % NWG : wave;       // K-group, wave inside it
+    const int wm = wv / NWN, wn = wv % NWN, l16 = lane & 15, lq = lane >> 4;
 
 #ifdef V10_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -198,7 +209,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     const int m0 = tm * BM, n0 = tn * BN;
     const int kp = (int)(a.K >> 6);                             // 1-KiB pieces per 16 rows
     const int kstep0 = S_ > 1 ? (int)((long long)kp * split / S_) : 0;      // this workgroup's slice of the K-steps
-    const int nsteps = S_ > 1 ? (int)((long long)kp * (split + 1) / S_) - kstep0 : kp;
+    // (KG = 2: never split across workgroups; this group's K-steps are kstep0 + 2 s + grp, nsteps of them -- K % 128 == 0)
+    const int nsteps = (S_ > 1 ? (int)((long long)kp * (split + 1) / S_) - kstep0 : kp) / KG;
 
     float* sxt = reinterpret_cast<float*>(side + V10_SXT);
     float* swt = reinterpret_cast<float*>(side + V10_SWT);
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
 
     // ---- in front of the operand stream: the tile's scale / bias slices (bounds-checked by their descriptors: rows and
     //      columns past the operand read as zero), the lists' header words, the first words of the tile's two buckets
-    {
+    if (grp == 0) {
         const int w4 = wave & 3;
         if (!BF16 && w4 == 0) V10_BLDS16(lane * 16, v10_desc(sx + m0, (Mi - m0) * 4), 0, side_lds + V10_SXT);
         if (!BF16 && w4 == 1) V10_BLDS16(lane * 16, v10_desc(sw + n0, (Ni - n0) * 4), 0, side_lds + V10_SWT);
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     const int x_nrec = (int)(pa_rows * row_bytes_a), w_nrec = (int)(pb_rows * row_bytes);
     int voff[LPW];
 #pragma unroll
-    for (int q = 0; q < LPW; ++q) voff[q] = (wave + NW * (q < LPA ? q : q - LPA)) * (int)(q < LPA ? row_bytes_a : row_bytes) + lane * 16;
+    for (int q = 0; q < LPW; ++q) voff[q] = (wv + NWG * (q < LPA ? q : q - LPA)) * (int)(q < LPA ? row_bytes_a : row_bytes) + lane * 16;
     // piece q (literal) of K-step `step` into the stage at byte offset `so`; a step past the slice's end is requested through
     // descriptors of zero bytes (no memory traffic, zeros land)
     auto piece = [&](auto qi, int step, int so) {
@@ -259,14 +271,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
         // (operands of the asm statement as locals of the lambda: an asm operand does not capture by itself)
         const int vo = voff[q];
         const int8_t* src = isa ? xbase : wbase;
-        int soff = step * 1024;
+        int soff = (KG * step + grp) * 1024;
         if (BF16 && isa && xseg) {                              // (uniform)
-            const unsigned ks = (unsigned)(kstep0 + step), sg = sps > 1 ? __umulhi(ks, sps_inv) : ks;
+            const unsigned ks = (unsigned)(kstep0 + KG * step + grp), sg = sps > 1 ? __umulhi(ks, sps_inv) : ks;
             src = xbase + (long long)sg * a.x_seg_stride;
             soff = (int)(ks - sg * (unsigned)sps) * 1024;
         }
         const i32x4 rd = v10_desc(src, step < nsteps ? (isa ? x_nrec : w_nrec) : 0);
-        const int dst = ring_lds + so + ((isa ? 0 : PA) + wave + NW * (isa ? q : q - LPA)) * 1024;
+        const int dst = ring_lds + grp * RING + so + ((isa ? 0 : PA) + wv + NWG * (isa ? q : q - LPA)) * 1024;
         V10_BLDS16(vo, rd, soff, dst);
     };
     v10_for<0, NS - 1>([&](auto si) {
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
 
     using acc_t = typename std::conditional<BF16, f32x4, i32x4>::type;
     // lane-constant part of the fragment addresses; fragment i is i KiB further (immediate offset)
-    const int va = ring_lds + piece_lds_off(wm * WM + l16, lq), vb = ring_lds + PA * 1024 + piece_lds_off(wn * WN + l16, lq);
+    const int va = ring_lds + grp * RING + piece_lds_off(wm * WM + l16, lq), vb = ring_lds + grp * RING + PA * 1024 + piece_lds_off(wn * WN + l16, lq);
     // DEEP (the 64-row wave tile): ALL of the next K-step's fragments are read during this step -- a wave that is alone on its SIMD
     // (grids of <= 256 workgroups: every launch this tile is chosen for) has no partner whose MFMAs cover the ~130 clocks of an LDS
     // round trip, and a two-group window leaves them exposed (tools/ubench/vmem_issue.hip: 455 -> 355 clocks a K-step)
@@ -522,6 +534,28 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     V10_STAMP(4);
     __builtin_amdgcn_s_barrier();                               // (every wave is out of the ring)
 
+    if constexpr (KG == 2) {
+        // ---- the two K-groups' accumulators: group g keeps fragment rows g TI / 2 .. and hands the others to its partner wave
+        //      (same wave tile, other group) through the ring area; every wave then owns complete sums for half of its wave tile
+        constexpr int HI = TI / 2;
+        acc_t* const xbuf = reinterpret_cast<acc_t*>(ring);
+#pragma unroll
+        for (int i = 0; i < HI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) xbuf[((wave * HI + i) * TJ + j) * 64 + lane] = grp == 0 ? acc[HI + i][j] : acc[i][j];
+        __syncthreads();
+        const int pw = grp == 0 ? wave + NWG : wave - NWG;
+#pragma unroll
+        for (int i = 0; i < HI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const acc_t part = xbuf[((pw * HI + i) * TJ + j) * 64 + lane];
+                if (grp == 0) acc[i][j] += part;
+                else acc[HI + i][j] += part;
+            }
+        __syncthreads();                                        // (the ring area is about to hold buckets / vectors)
+    }
+    if constexpr (KG == 1)
     if (S_ > 1) {
         // ---- split-K.  a.tickets holds two words a tile: arrivals, published slabs.
         // Order-free sums (int32: exact whatever the order; two slices of fp32: a + b == b + a): a slice takes its ticket FIRST; every
@@ -711,6 +745,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
+            if (KG == 2 && (i / (TI / 2)) != grp) continue;     // (uniform: the fragment rows this K-group holds complete sums for)
             const int rl = wm * WM + i * 16 + l16;
             const long long row = (long long)m0 + rl;
             const float sxv = sxr[i];
@@ -790,27 +825,28 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
 
 // geometry: 1 = 128 x 256 (1 x 4 waves of 128 x 64), 2 = 256 x 128 (2 x 2 of 128 x 64), 3 = 128 x 128 (2 x 2 of 64 x 64),
 // 4 = 128 x 64 (2 x 2 of 64 x 32: grids that 128 x 128 tiles leave on half the compute units or fewer)
+// 5 / 6 (round 6): 128 x 128 / 128 x 256 with TWO K-GROUPS in an 8-wave workgroup -- grids of at most one workgroup a compute unit
 void v10_tile_shape(int geom, int& bm, int& bn) {
     bm = geom == 2 ? 256 : 128;
-    bn = geom == 1 ? 256 : (geom == 4 ? 64 : 128);
+    bn = (geom == 1 || geom == 6) ? 256 : (geom == 4 ? 64 : 128);
 }
 
-template <int NWM, int NWN, int TI, int NS, int OCC, int TJ = 4>
+template <int NWM, int NWN, int TI, int NS, int OCC, int TJ = 4, int KG = 1>
 static int v10_launch(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                       const uint8_t* xf, const uint8_t* wf, bool bf16, unsigned grid) {
     const bool fix = xlist && wlist;
-    constexpr int RING = NS * (NWM * TI + NWN * TJ) * 1024;
+    constexpr int RING = KG * NS * (NWM * TI + NWN * TJ) * 1024;          // (KG = 2: one ring a K-group)
     // (dynamic shared memory beyond 64 KiB has to be asked for once per kernel)
     static const bool ready = [] {
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess;
-        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
-        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, true, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess;
+        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 1, false, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
+        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, false, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) == hipSuccess && ok;
         return ok;
     }();
     if (!ready) return (int)hipErrorInvalidValue;
-    if (bf16) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, true>), grid, 256, RING, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (fix) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 1, false>), grid, 256, RING, st, a, sx, sw, xlist, wlist, xf, wf);
-    else hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, false>), grid, 256, RING, st, a, sx, sw, xlist, wlist, xf, wf);
+    if (bf16) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, true, KG>), grid, 256 * KG, RING, st, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else if (fix) hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 1, false, KG>), grid, 256 * KG, RING, st, a, sx, sw, xlist, wlist, xf, wf);
+    else hipLaunchKernelGGL((bfp_gemm_v10<NWM, NWN, TI, TJ, NS, OCC, 0, false, KG>), grid, 256 * KG, RING, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();
 }
 
@@ -852,6 +888,11 @@ int launch_bfp_gemm_v10(const GemmArgs& a_in, const float* sx, const float* sw, 
     if (geom == 4) {
         return deep ? v10_launch<2, 2, 4, 6, 1, 2>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid)
                     : v10_launch<2, 2, 4, 4, 2, 2>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid);
+    }
+    if (geom == 5 || geom == 6) {
+        if (a.splits > 1 || (a.K % 128) != 0) return MI355Q_E_UNSUPPORTED;
+        return geom == 5 ? v10_launch<2, 2, 4, 4, 1, 4, 2>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid)
+                         : v10_launch<1, 4, 8, 3, 1, 4, 2>(a, sx, sw, xlist, wlist, st, xf, wf, bf16, grid);
     }
 #else
     (void)deep; (void)ns;

@@ -755,6 +755,10 @@ static int v10_forced_launch(const GemmArgs& a_in, const float* sx, const float*
     int S = forced > 1 ? forced : 1;
     while (S > 1 && (nsteps_all % S || nsteps_all / S < 2)) --S;
     a.splits = 1;
+    if (geom >= 5) {                                // (the K-group geometries: never split across workgroups; whole pairs of K-steps)
+        S = 1;
+        if (a.K % 128) geom = geom == 5 ? 3 : 1;
+    }
     if (S > 1) {
         SplitWorkspace* w = split_workspace(st, (size_t)tiles * S * bm * bn * 4, 2 * (int)tiles);      // (two ticket words a tile)
         if (w) {
@@ -768,7 +772,7 @@ static int v10_forced_launch(const GemmArgs& a_in, const float* sx, const float*
 static int v10_forced() {                       // (read per launch: the tests pin one geometry after the other in one process)
     const char* e = getenv("MI355Q_V10");
     const int g = e ? atoi(e) : 0;
-    return g >= 1 && g <= 4 ? g : 0;
+    return g >= 1 && g <= 6 ? g : 0;
 }
 
 int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
@@ -790,7 +794,12 @@ int launch_bfp_gemm_v8(const GemmArgs& a_in, const float* sx, const float* sw, c
             // (128 x 64 tiles where 128 x 128 ones would fill half the compute units or fewer -- end of round 5:
             //  4096 x 512 x 4096 26.4 -> 22.4 us at W6A6, 20.1 -> 16.7 at W4A4; level from ~176 tiles of 128 x 128 on)
             const long long g3 = ((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.ngroup > 1 ? a.ngroup : 1);
-            return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, false, g3 <= 128 ? 4 : 3);
+            // (round 6: 129 .. 256 tiles of 128 x 128 -- one four-wave workgroup a compute unit, every wave alone on its SIMD -- as
+            //  8-wave workgroups of two K-groups: 4096 x 1024 x 4096 30.2 -> 27.4 us, Llama up / P = 8 27.5 -> 25.1, 2048^3 20.2 -> 19.5;
+            //  profiles/r06_shard_shapes.txt.  MI355Q_V10_KG=0: the round-5 choice, A/B runs)
+            static const int kg_auto = getenv("MI355Q_V10_KG") ? atoi(getenv("MI355Q_V10_KG")) : 1;
+            const int geom = g3 <= 128 ? 4 : (kg_auto && g3 <= 256 && a.K % 128 == 0 && a.ngroup <= 1 ? 5 : 3);
+            return launch_bfp_gemm_v10(a, sx, sw, xlist, wlist, st, xf, wf, false, geom);
         }
     }
     GemmArgs a = a_in;
@@ -914,9 +923,14 @@ int launch_bf16_gemm_tiled(const GemmArgs& a_in, hipStream_t st) {
             //  4096 x 512 x 4096 30.1 -> 23.1 us, 2048 x 768 x 3072 22.7 -> 17.4, 2048 x 256 x 2048 16.0 -> 11.9)
             const double est3 = (g3 <= 128 ? nsteps_all * 0.12 : g3 <= 256 ? nsteps_all * 0.23 : nsteps_all * 0.43 * (double)((g3 + 511) / 512)) + 8.0;
             const double est1 = g1 <= 256 ? nsteps_all * 0.39 + 8.0 : 1e30;
-            if (est3 * 1.12 < best_t || est1 * 1.12 < best_t) {
+            // (round 6: two K-groups in an 8-wave workgroup for 129 .. 256 tiles of 128 x 128 -- 0.20 us a K-step: 2048 x 2048 x 8192
+            //  64.0 -> 58.4 us, profiles/r06_shard_shapes.txt)
+            static const int kg_auto = getenv("MI355Q_V10_KG") ? atoi(getenv("MI355Q_V10_KG")) : 1;
+            const double est5 = kg_auto && g3 > 128 && g3 <= 256 && a.K % 128 == 0 && a.x_segs <= 1 ? nsteps_all * 0.20 + 8.0 : 1e30;
+            if (est3 * 1.12 < best_t || est1 * 1.12 < best_t || est5 * 1.12 < best_t) {
                 a.splits = 1;
-                return launch_bfp_gemm_v10(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, est1 < est3 ? 1 : (g3 <= 128 ? 4 : 3));
+                const int geom = est5 < est3 && est5 < est1 ? 5 : (est1 < est3 ? 1 : (g3 <= 128 ? 4 : 3));
+                return launch_bfp_gemm_v10(a, nullptr, nullptr, nullptr, nullptr, st, nullptr, nullptr, true, geom);
             }
         }
     }

@@ -449,7 +449,8 @@ def test_bf16_tile_gemm_with_x_in_column_segments(M, K, N, P, geom, monkeypatch)
 
 
 # ---- round 5: the small tiles (csrc/mi355q_gemm_v10.hip) ----------------------------------------------------------------
-V10_GEOMS = [(1, 0), (1, 6), (2, 0), (3, 0), (3, 4), (3, 8), (4, 0), (4, 4)]          # (geometry, ring stages; 0 = the launcher's depth rule)
+# (geometry, ring stages; 0 = the launcher's depth rule); 5 / 6 (round 6): 128 x 128 / 128 x 256 with two K-groups in an 8-wave workgroup
+V10_GEOMS = [(1, 0), (1, 6), (2, 0), (3, 0), (3, 4), (3, 8), (4, 0), (4, 4), (5, 0), (6, 0)]
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 130, 1024), (100, 72, 384), (33, 16, 128), (520, 260, 512), (64, 64, 192),
