@@ -331,7 +331,7 @@ def measured_ceiling(torch, ops, device, xa, wa, bq, y):
 def committed_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (counters cannot be read inside a timed
     run: one counter per rocprofv3 pass over tools/cdriver/step_driver, which runs the same step through the C ABI)."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(ROOT / "profiles" / name) as f:
                 return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]), name

@@ -873,7 +873,7 @@ def gated_mlp(x, gate, up, down, norm=None, residual=None):
     c, dc = gate.config, down.config
     if (c.get("mi355q_fused_gate_up", True) in (False, "off") or not dc.get("mi355q_fused_activation", False) or dc["data_in_width"] > 9
             or gate.in_features != up.in_features or gate.out_features != up.out_features or down.in_features != gate.out_features
-            or gate.in_features % 128 or gate.out_features % 128 or (gate.bias is None) != (up.bias is None)
+            or gate.in_features % 128 or gate.in_features < 256 or gate.out_features % 128 or (gate.bias is None) != (up.bias is None)
             or (norm is not None and len(norm) != 2)):
         return None
     plan = gate._int8_plan(x)

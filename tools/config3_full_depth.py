@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 
+MIXED = "auto"        # (--no-mixed: mi355q_mixed = False -- layers whose rows fit no window go to the per-block route as a whole)
 GATED = True          # (--no-gated: the grouped gate / up launch + the quantiser that reads silu(gate) * up, as before round 6)
 
 
@@ -25,7 +26,7 @@ def quant_config(storage: str, knobs: bool = True):
              bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
     if knobs:
         d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
-                 mi355q_token_major_output=True, mi355q_fused_residual=True, mi355q_fused_gate_up=GATED)
+                 mi355q_token_major_output=True, mi355q_fused_residual=True, mi355q_fused_gate_up=GATED, mi355q_mixed=MIXED)
     if storage == "packed":
         d.update(mi355q_weight_storage="packed")
     # the rotary tables of every shipped TOML: 8-bit fixed point (configs/quantization/bfp_6bit.toml)
@@ -155,7 +156,9 @@ if __name__ == "__main__":
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-knobs", action="store_true")
     ap.add_argument("--no-spread", action="store_true", help="plain N(0, 0.02) weights instead of rows of different magnitude")
+    ap.add_argument("--no-mixed", action="store_true", help="mi355q_mixed = False")
     ap.add_argument("--no-gated", action="store_true", help="without the gated epilogue (mi355q_fused_gate_up = False)")
     a = ap.parse_args()
     GATED = not a.no_gated
+    MIXED = False if a.no_mixed else "auto"
     print(json.dumps(run(a.layers, a.tokens, a.steps, a.storage, not a.no_graph, not a.no_parity, not a.no_knobs, not a.no_spread)), flush=True)
