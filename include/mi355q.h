@@ -408,6 +408,14 @@ int mi355q_bfp_gemm_aligned_gated(const mi355q_bfp_operand* x, const mi355q_bfp_
                                   void* out_bf16_tiled, int64_t M, int64_t I, int64_t K, int32_t q_width, int32_t q_exponent_width,
                                   int32_t q_exponent_bias, void* stream);
 
+/* ... and OPT's MLP the same way (modeling_opt.py:412-420: fc2(activation_fn(fc1(x))), relu): x . w^T + bias, relu and the CONSUMER's
+ * block_fp quantiser in the store epilogue (a fragment's 16 columns are one [1,16] block), the consumer's tiled bf16 operand [M, N]
+ * (mi355q_bfp_tiled_bytes(M, 2 N) bytes) as the only output -- bit for bit mi355q_block_fp_quantize_bf16_tiled_pre(relu) of the
+ * product.  `scratch` fp32 [M, N]: slow paths only.  K % 128 == 0, K >= 256, N % 32 == 0. */
+int mi355q_bfp_gemm_aligned_relu(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* scratch,
+                                 void* out_bf16_tiled, int64_t M, int64_t N, int64_t K, int32_t q_width, int32_t q_exponent_width,
+                                 int32_t q_exponent_bias, void* stream);
+
 /* Several weight operands of the SAME shape against ONE activation operand in one launch (the q / k / v projections of an
  * attention block, gate / up of a gated MLP: reference modules called one after the other on the same input,
  * modeling_opt.py:231-245, modeling_llama.py:216,283-287): y[i] = x . w[i]^T + bias[i].  The column tiles of all of them

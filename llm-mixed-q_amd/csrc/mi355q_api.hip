@@ -635,10 +635,11 @@ int mi355q_bfp_gemm_mixed(const mi355q_bfp_operand* x0, const mi355q_bfp_operand
     return rc;
 }
 
-// x . [gate; up]^T with the gated MLP's elementwise step and the consumer's quantiser in the store epilogue (mi355q.h)
-int mi355q_bfp_gemm_aligned_gated(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* scratch,
-                                  void* out_bf16_tiled, int64_t M, int64_t I, int64_t K, int32_t q_width, int32_t q_exponent_width,
-                                  int32_t q_exponent_bias, void* stream) {
+// x . [gate; up]^T with the gated MLP's elementwise step and the consumer's quantiser in the store epilogue (mi355q.h); epi_op 2:
+// x . w^T with relu and the consumer's quantiser there (I = the layer's out_features)
+static int gemm_aligned_epilogue_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* scratch,
+                                      void* out_bf16_tiled, int64_t M, int64_t I, int64_t K, int32_t q_width, int32_t q_exponent_width,
+                                      int32_t q_exponent_bias, void* stream, int epi_op) {
     if (!x || !w || M < 0 || I < 0 || K < 0) return MI355Q_E_BADARG;
     if (M == 0 || I == 0) return 0;
     if (!scratch || !out_bf16_tiled || !x->mant || !x->exp || !w->mant || !w->exp || !x->rowflag || !w->rowflag || !x->gscale || !w->gscale ||
@@ -653,7 +654,7 @@ int mi355q_bfp_gemm_aligned_gated(const mi355q_bfp_operand* x, const mi355q_bfp_
     if ((reinterpret_cast<uintptr_t>(x->mant) | reinterpret_cast<uintptr_t>(w->mant) | reinterpret_cast<uintptr_t>(out_bf16_tiled) |
          reinterpret_cast<uintptr_t>(scratch)) % 16)
         return MI355Q_E_ALIGN;
-    const int64_t N = 2 * I;
+    const int64_t N = epi_op == 2 ? I : 2 * I;
     GemmArgs a{x->mant, x->exp, w->mant, w->exp, bias, scratch, M, N, K, N,
                x->exp_bias + x->mbits + w->exp_bias + w->mbits, 1,
                x->exp_bias + x->mbits, w->exp_bias + w->mbits,
@@ -664,11 +665,24 @@ int mi355q_bfp_gemm_aligned_gated(const mi355q_bfp_operand* x, const mi355q_bfp_
     a.q_mbits = q_width - 1;
     a.q_emin = -q_exponent_bias;
     a.q_emax = (1 << q_exponent_width) - 1 - q_exponent_bias;
+    a.epi_op = epi_op;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t te = g_timing.begin(st);
     const int rc = launch_bfp_gemm_v9_gated(a, x->gscale, w->gscale, x->list, w->list, st, x->rowflag, w->rowflag);
     g_timing.end(te, st);
     return rc;
+}
+
+int mi355q_bfp_gemm_aligned_gated(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* scratch,
+                                  void* out_bf16_tiled, int64_t M, int64_t I, int64_t K, int32_t q_width, int32_t q_exponent_width,
+                                  int32_t q_exponent_bias, void* stream) {
+    return gemm_aligned_epilogue_impl(x, w, bias, scratch, out_bf16_tiled, M, I, K, q_width, q_exponent_width, q_exponent_bias, stream, 1);
+}
+
+int mi355q_bfp_gemm_aligned_relu(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* scratch,
+                                 void* out_bf16_tiled, int64_t M, int64_t N, int64_t K, int32_t q_width, int32_t q_exponent_width,
+                                 int32_t q_exponent_bias, void* stream) {
+    return gemm_aligned_epilogue_impl(x, w, bias, scratch, out_bf16_tiled, M, N, K, q_width, q_exponent_width, q_exponent_bias, stream, 2);
 }
 
 static int gemm_aligned_multi_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* const* w, const float* const* bias,

@@ -151,6 +151,28 @@ __device__ __forceinline__ unsigned gated_offset(unsigned row, unsigned hc, unsi
 // columns) reads its gate and up values back and does what the register epilogue does.
 __device__ __forceinline__ void gated_post_tile(const GemmArgs& a, const unsigned* __restrict__ glut, const GatedQ& q, long long m0,
                                                 long long n0, int bm, int bn, int tid, int nthreads) {
+    if (a.epi_op == 2) {                                          // relu: h = max(y, 0), a block = 16 columns of y itself
+        const int hb1 = bn >> 4;
+        const unsigned kpN = (unsigned)(a.N >> 5);
+        for (int it = tid; it < bm * hb1; it += nthreads) {
+            const long long row = m0 + it / hb1, col = n0 + (long long)(it % hb1) * 16;
+            if (row >= a.M || col >= a.N) continue;
+            const float* yr = a.y + row * a.ldy + col;
+            float h[16];
+            unsigned m = 0u;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                h[t] = pre_relu(yr[t]);
+                m = max(m, __float_as_uint(h[t]) & 0x7FFFFFFFu);
+            }
+            gated_quant<16>(h, m, glut, q);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(a.yb) + gated_offset((unsigned)row, (unsigned)col + 4 * g4, kpN)) =
+                    make_uint2(pack_bf16(h[4 * g4], h[4 * g4 + 1]), pack_bf16(h[4 * g4 + 2], h[4 * g4 + 3]));
+        }
+        return;
+    }
     const int hb = bn >> 5;                                       // h blocks per tile row
     const unsigned kpI = (unsigned)(a.N >> 6);                    // I / 32 pieces per 16 rows (I = N / 2)
     for (int it = tid; it < bm * hb; it += nthreads) {
@@ -1055,6 +1077,31 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
                     }
                 }
             }
+            if (a.epi_op == 2) {                                 // (uniform) relu: every fragment's 16 columns are a block of their own
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float h[4];
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h[r] = pre_relu(val[j][r]);
+                        m = max(m, __float_as_uint(h[r]) & 0x7FFFFFFFu);
+                    }
+                    {
+                        auto sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+                        m = max(sw[0], sw[1]);
+                        sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+                        m = max(sw[0], sw[1]);
+                    }
+                    gated_quant<4>(h, m, glut, gq);
+                    const int hc = n0 + wn * 64 + j * 16 + lq * 4;
+                    if (row < a.M && hc < Ni)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(a.yb) + gated_offset((unsigned)row, (unsigned)hc, (unsigned)(Ni >> 5))) =
+                            make_uint2(pack_bf16(h[0], h[1]), pack_bf16(h[2], h[3]));
+                }
+                V9_SB();
+                continue;
+            }
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 float h[4];
@@ -1212,7 +1259,8 @@ static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/dbg
 int launch_bfp_gemm_v9_gated(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
                              hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
     if (!xlist || !wlist || !xf || !wf || !a.yb || !a.y) return MI355Q_E_BADARG;
-    if (a.K % 128 != 0 || a.K < 256 || a.N % 64 != 0 || a.splits > 1 || a.ngroup > 1 || a.x_post) return MI355Q_E_UNSUPPORTED;
+    if (a.K % 128 != 0 || a.K < 256 || a.N % (a.epi_op == 2 ? 32 : 64) != 0 || a.splits > 1 || a.ngroup > 1 || a.x_post || (a.epi_op != 1 && a.epi_op != 2))
+        return MI355Q_E_UNSUPPORTED;
     const unsigned grid = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256));
     hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
     return (int)hipGetLastError();

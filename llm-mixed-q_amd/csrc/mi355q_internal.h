@@ -118,6 +118,7 @@ struct GemmArgs {
     // q_* = its block_fp quantiser (mantissa bits, clamp range of the shared exponent); null: off
     void* yb;
     int q_mbits, q_emin, q_emax;
+    int epi_op;       // 1: silu(gate) * up on interleaved gate / up columns (yb [M, N / 2]); 2: relu (yb [M, N])
 };
 int launch_bfp_gemm(const GemmArgs& a, int variant, hipStream_t st);
 int launch_bfp_gemm_aligned(const GemmArgs& a, const uint8_t* xf, const uint8_t* wf, const int* xlist,

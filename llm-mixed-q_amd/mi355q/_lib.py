@@ -69,6 +69,7 @@ SIGNATURES = {
     "mi355q_bfp_gemm_aligned_multi": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_block_fp_quantize_classes": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_gemm_aligned_gated": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "mi355q_bfp_gemm_aligned_relu": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_gemm_mixed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_mx_plane_bytes": (C.c_size_t, [_i64, _i64, _i32]),
     "mi355q_block_fp_quantize_mx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),

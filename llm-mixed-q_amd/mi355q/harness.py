@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .quantize import gated_mlp, get_quantized_cls, get_quantized_func, grouped_linear
+from .quantize import gated_mlp, get_quantized_cls, get_quantized_func, grouped_linear, relu_mlp
 from .quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
 
 
@@ -114,6 +114,13 @@ class _DecoderLayer(nn.Module):
             x = self.self_attn(self.self_attn_layer_norm(x), mask, residual=x) if fres else x + self.self_attn(self.self_attn_layer_norm(x), mask)
         shape = x.shape
         h = x.reshape(-1, shape[-1])                       # the MLP sees a 2-D activation (modeling_opt.py:412)
+        if fused_norm and self.fc2.config.get("mi355q_fused_activation", False):
+            # round 6: fc1's product with relu and fc2's quantiser in its store epilogue (relu_mlp); None when the layers do not
+            # qualify (fc1 not on the row-scale int8 route, fc2 not on the per-block route ...): the launches below, as before
+            hr = h.contiguous()
+            y = relu_mlp(h, self.fc1, self.fc2, norm=ln(self.final_layer_norm), residual=hr if fres else None)
+            if y is not None:
+                return (y if fres else h + y).view(shape)
         if fused_norm:
             f1 = grouped_linear(h, (self.fc1,), norm=ln(self.final_layer_norm))[0]
         else:

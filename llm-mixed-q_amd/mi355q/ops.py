@@ -1096,6 +1096,31 @@ def bfp_gemm_aligned_gated(x: AlignedOperand, w_gu: AlignedOperand, q_width: int
     return buf["out"]
 
 
+def bfp_gemm_aligned_relu(x: AlignedOperand, w: AlignedOperand, q_width: int, q_exponent_width: int, q_exponent_bias, bias=None):
+    """relu(x . w^T + bias) quantised with the CONSUMER's block_fp quantiser in the product's store epilogue (include/mi355q.h,
+    mi355q_bfp_gemm_aligned_relu; OPT's fc1 in front of fc2): returns the tiled bf16 operand [M, N] that bf16_gemm_tiled multiplies
+    against the consumer's weights (buffer shared per shape and stream).  None when the library does not take the shapes."""
+    M, K, N = x.rows, x.K, w.rows
+    assert w.K == K
+    lib = _lib.load_library()
+    dev = x.tiled.device
+    sp = _stream_ptr(dev)
+    key = (dev.index, sp, "relu", M, N)
+    buf = _GATED_BUFFERS.get(key)
+    if buf is None:
+        buf = dict(out=torch.zeros(lib.mi355q_bfp_tiled_bytes(M, 2 * N), dtype=torch.int8, device=dev),
+                   scratch=torch.empty(M, N, dtype=torch.float32, device=dev))
+        _GATED_BUFFERS.put(key, buf)
+    x.c_struct(), w.c_struct()
+    with _on_device(dev):
+        rc = lib.mi355q_bfp_gemm_aligned_relu(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(buf["scratch"]), _ptr(buf["out"]), M, N, K,
+                                              int(q_width), int(q_exponent_width), _default_bias(q_exponent_bias), sp)
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "mi355q_bfp_gemm_aligned_relu")
+    return buf["out"]
+
+
 def bfp_gemm_aligned_multi(x: AlignedOperand, ws, biases=None, outs=None):
     """[x . w^T + bias for w in ws] in ONE launch of the tile GEMM (equally shaped row-aligned weight operands: q / k / v,
     gate / up); returns None when the library does not take the group (callers then use bfp_gemm_aligned per weight).

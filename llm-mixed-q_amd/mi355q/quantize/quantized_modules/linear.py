@@ -915,6 +915,49 @@ def gated_mlp(x, gate, up, down, norm=None, residual=None):
         return y if residual is None or res2 is not None else residual + y
 
 
+def relu_mlp(x, fc1, fc2, norm=None, residual=None):
+    """fc2(relu(fc1(x))) [+ residual] for block_fp PTQ layers (modeling_opt.py:412-420, the OPT MLP) as TWO launches behind the
+    activation quantiser: fc1's product with relu and fc2's activation quantiser in its store epilogue (ops.bfp_gemm_aligned_relu:
+    the [tokens, ffn] fp32 tensor is never written, the relu-quantise launch is gone), then fc2's product on the bf16 flavour of the
+    tile GEMM.  `norm` = (weight, bias, eps): OPT's final_layer_norm applied by fc1's quantiser.  Same bits as fc1 + fc2.forward_after.
+    Returns None whenever the layers do not qualify (the caller then takes that path): gated_mlp's conditions with one producer."""
+    from ...sharded import RowShardedLinear
+    if any(isinstance(l, RowShardedLinear) or not isinstance(l, _LinearBase) for l in (fc1, fc2)):
+        return None
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and 2 <= x.ndim <= 3) or (torch.is_grad_enabled() and x.requires_grad):
+        return None
+    if not all(l.arith == "block_fp" and l.is_ptq and not l.bypass and not l.weight_requires_quantisation and l._pending_flavour is None
+               and l._packed_is_current() for l in (fc1, fc2)):
+        return None
+    c, dc = fc1.config, fc2.config
+    if (c.get("mi355q_fused_gate_up", True) in (False, "off") or not dc.get("mi355q_fused_activation", False) or dc["data_in_width"] > 9
+            or fc2.in_features != fc1.out_features or fc1.in_features % 128 or fc1.in_features < 256 or fc1.out_features % 32
+            or (norm is not None and len(norm) != 3)):
+        return None
+    if fc1._int8_plan(x) is None or fc2._int8_plan(x.new_empty((1, fc2.in_features))) is None:
+        return None
+    if not (fc1._align_mode == "rows" and not fc1._uses_bf16_route() and fc1._mixed is None and fc1._w_packed is None
+            and fc1._x_cap == ops.ROW_BUCKET_CAP):
+        return None
+    if not fc2._uses_bf16_route() or (fc2._w_packed is not None and fc2._w_packed.row_scale_flavour):
+        return None
+    with torch.no_grad():
+        x2 = x.reshape(-1, fc1.in_features)
+        xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"],
+                                                bucket_cap=fc1._x_cap,
+                                                pre=None if norm is None else ("layernorm", norm[0], norm[2], norm[1]))
+        xt = ops.bfp_gemm_aligned_relu(xa, fc1._packed[0], dc["data_in_width"], dc["data_in_exponent_width"], dc["data_in_exponent_bias"],
+                                       fc1.bias)
+        if xt is None:
+            return None
+        M = x2.shape[0]
+        res2 = residual.reshape(-1, fc2.out_features) if residual is not None and fc2._residual_operand_ok(residual, x.shape[:-1]) else None
+        y = ops.bf16_gemm_tiled(xt, fc2._bf16_weight_operand(x.device), M, fc2.out_features, fc2.in_features, fc2.bias,
+                                out=fc2._take_out(M), residual=res2)
+        y = y.reshape(*x.shape[:-1], fc2.out_features)
+        return y if residual is None or res2 is not None else residual + y
+
+
 def grouped_linear(x, layers, norm=None):
     """[layer(x) for layer in layers] for block_fp PTQ Linear layers that take the SAME input and have the same shape and
     widths -- the q / k / v projections of an attention block, gate / up of a gated MLP, which the reference's modules

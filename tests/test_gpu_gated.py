@@ -117,3 +117,54 @@ def test_llama_harness_with_the_gated_mlp_is_bit_identical():
     if all(not g and d for g, d in routes):
         assert n_fused == 2, (n_fused, routes)          # (second forward: both layers; the first one packs the weights)
     assert torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("M,N,K,bias,qw", [(512, 512, 512, True, 6), (300, 384, 1024, True, 6), (1024, 1408, 2048, False, 4), (256, 96, 256, True, 8)])
+def test_relu_epilogue_equals_the_separate_launches(M, N, K, bias, qw):
+    """mi355q_bfp_gemm_aligned_relu (OPT's fc1 in front of fc2, modeling_opt.py:412-420): the consumer's tiled bf16 operand from the
+    product's store epilogue, bit for bit the int8 product followed by the quantiser that reads relu(.)"""
+    import torch
+    from mi355q import ops
+    xa, wa, _, bg, _ = _operands(M, N, K, seed=M + N + K + 1, bias=bias, x_exc=10, w_exc=16)
+    xt = ops.bfp_gemm_aligned_relu(xa, wa, qw, 8, 127, bg)
+    assert xt is not None
+    xt = xt.clone()
+    y = ops.bfp_gemm_aligned(xa, wa, bg)
+    ref = ops.block_fp_quantize_bf16_tiled(y, qw, 8, 127, pre=("relu", None), out=torch.zeros_like(xt))
+    torch.cuda.synchronize()
+    assert torch.equal(xt, ref)
+
+
+def test_opt_harness_with_the_relu_mlp_is_bit_identical():
+    """the OPT-style harness, every knob on, W6A6 (fc2 behind a relu: per-block route): fc1's product writing fc2's operand itself
+    (relu_mlp) against the fc1 launch + the quantiser that reads relu(.) -- the same logits, bit for bit; the fused path is taken"""
+    import torch
+    from mi355q import harness as H, ops
+    knobs = dict(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
+                 mi355q_token_major_output=True, mi355q_fused_residual=True)
+
+    def build(extra):
+        d = dict(name="block_fp", bypass=False, is_ptq=True, data_in_width=6, data_in_exponent_width=8, data_in_exponent_bias=127,
+                 data_in_block_size=[1, 16], weight_width=6, weight_exponent_width=8, weight_exponent_bias=127, weight_block_size=[1, 16],
+                 bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16], **knobs, **extra)
+        c = H.TinyOPTConfig(vocab_size=512, hidden_size=512, ffn_dim=2048, num_layers=2, num_heads=8, max_positions=256)
+        torch.manual_seed(4)
+        return H.TinyOPTForCausalLM(c, H.expand_quant_config(d, 2)).to("cuda:0").eval()
+    ids = torch.randint(0, 512, (1, 256), generator=torch.Generator().manual_seed(6)).to("cuda:0")
+    calls, real = [], ops.bfp_gemm_aligned_relu
+    ops.bfp_gemm_aligned_relu = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            m1 = build({})
+            for _ in range(2):
+                l1 = m1(ids)[0]
+            n_fused = len(calls)
+            m2 = build(dict(mi355q_fused_gate_up=False))
+            for _ in range(2):
+                l2 = m2(ids)[0]
+    finally:
+        ops.bfp_gemm_aligned_relu = real
+    assert len(calls) == n_fused
+    if all(not l.fc1._uses_bf16_route() and l.fc2._uses_bf16_route() for l in m1.layers):
+        assert n_fused == 2, n_fused
+    assert torch.equal(l1, l2)
