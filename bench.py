@@ -334,7 +334,11 @@ def committed_traffic(kernel):
     for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(ROOT / "profiles" / name) as f:
-                return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]), name
+                kernels = json.load(f)["kernels"]
+            # (round 6 added a fourth template argument to the tile kernel: both spellings name the same launch)
+            for k in (kernel, kernel.replace("<1, false, false>", "<1, false, false, false>")):
+                if k in kernels:
+                    return int(kernels[k]["hbm_bytes_per_launch"]), name
         except (OSError, KeyError, ValueError):
             continue
     return None, None

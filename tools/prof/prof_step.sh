@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 TAG=${1:-prof}; shift
 rm -rf gpurun_out/_prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_prof_$TAG -o p -- python3 bench.py --no-cpu-baseline --no-verify --steps 100 --warmup 10 "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_prof_$TAG -o p -- python3 bench.py --no-cpu-baseline --no-verify --no-ceiling --steps 100 --warmup 10 "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_prof.err
 F=$(find gpurun_out/_prof_$TAG -name '*kernel_stats.csv' | head -1)
 cp "$F" gpurun_out/${TAG}_kernel_stats.csv
 python3 tools/prof/kstats.py gpurun_out/${TAG}_kernel_stats.csv | head -12
