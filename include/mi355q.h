@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 23
+#define MI355Q_ABI_VERSION 24
 #define MI355Q_WORKSPACE_BYTES 16384
 
 /* negative error codes (positive values are hipError_t) */
@@ -214,6 +214,16 @@ int mi355q_bfp_expand(const uint8_t* packed, const uint8_t* codes, void* out_til
 int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, void* stream);
 int mi355q_bf16_gemm_tiled(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
                            int64_t K, int64_t ldy, void* stream);
+/* An fp32 operand [rows, K] as the tiled bf16 operand of an fp32-EQUIVALENT product (round 6, ABI 24) -- for the layers the reference
+ * leaves unquantised: the language-model head, nn.Linear in fp32 (models/llama_quantized/modeling_llama.py:772,866,
+ * models/opt_quantized/modeling_opt.py:942-944), 14 % of a Llama-7B forward on the vendor library's fp32 GEMM.  Every value becomes three bf16
+ * parts h + m + l (24 significand bits); the operand written is [rows, 6 K]: role 0 (left, activations) = [m | l | h | m | h | h],
+ * role 1 (right, weights) = [m | h | l | h | m | h], so that mi355q_bf16_gemm_tiled(x6, w6, bias, y, M, N, 6 K, ...) adds the six part
+ * products of weight >= 2^-18 in fp32, smallest first (the three dropped ones weigh <= 2^-26 of a product).  Against an fp64 product the
+ * result is CLOSER than the vendor fp32 GEMM's (3.4e-7 vs 1.0e-6 of the mean magnitude at [2048, 4096] x [32000, 4096]^T) and 1.7 x
+ * faster (profiles/r06_lm_head_split.json).  y_tiled: mi355q_bfp_tiled_bytes(rows, 12 K) bytes; K % 32 == 0; |x| within bf16's finite
+ * range.  mi355q_split.hip. */
+int mi355q_fp32_split_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t role, void* stream);
 /* ... with the residual add of the caller's decoder layer in the store (ABI 22): y = (x . w^T + bias) + residual, the two sums rounded
  * like F.linear followed by `residual + hidden_states` (modeling_llama.py:259, 265; modeling_opt.py:375, 425): the same bits, one
  * pass over [M, N] less.  residual [M, >= N] fp32, ldr elements a row (ldr % 4 == 0), 16-byte aligned; y may be residual itself. */

@@ -222,6 +222,15 @@ int mi355q_bf16_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K,
     return launch_quant_bf16_tiled(a, y_tiled, static_cast<hipStream_t>(stream), /*cast_only=*/true);
 }
 
+int mi355q_fp32_split_tile(const float* x, uint16_t* y_tiled, int64_t rows, int64_t K, int32_t role, void* stream) {
+    if (rows < 0 || K < 0 || (role != 0 && role != 1)) return MI355Q_E_BADARG;
+    if (rows == 0 || K == 0) return 0;
+    if (!x || !y_tiled) return MI355Q_E_BADARG;
+    if (K % 32 != 0) return MI355Q_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y_tiled)) % 16) return MI355Q_E_ALIGN;
+    return launch_fp32_split_tile(x, y_tiled, rows, K, role, static_cast<hipStream_t>(stream));
+}
+
 static int bf16_gemm_tiled_impl(const uint16_t* x_tiled, const uint16_t* w_tiled, const float* bias, float* y, int64_t M, int64_t N,
                                 int64_t K, int64_t ldy, int32_t x_segments, int64_t x_segment_stride_bytes, void* stream,
                                 const float* residual = nullptr, int64_t ldr = 0);

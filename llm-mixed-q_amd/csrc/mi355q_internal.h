@@ -43,6 +43,8 @@ int launch_quant(const QuantArgs& a, int fmt, bool needs_fixup, hipStream_t st);
 int launch_quant_bf16_tiled(const QuantArgs& a, uint16_t* yt, hipStream_t st, bool cast_only = false, int fmt = 0 /* FMT_BFP; 1 = FMT_BM */);
 int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float* rscale, int exp_offset, int* list,
                             int* list_to_clear, hipStream_t st, int bcap);
+// fp32 -> three bf16 parts, six column segments, tile order (mi355q_split.hip)
+int launch_fp32_split_tile(const float* x, uint16_t* yt, long long rows, long long K, int role, hipStream_t st);
 // the class-aware activation quantiser of the mixed contraction (mi355q_quant_cls.hip): cmap[kb] = position | class << 15
 int launch_quant_classes(const QuantArgs& a, const uint16_t* cmap, int n0, int n1, int8_t* mt, uint8_t* flag, float* rscale,
                          int exp_offset, int* list, int* list_to_clear, uint16_t* bt, hipStream_t st, int bcap);

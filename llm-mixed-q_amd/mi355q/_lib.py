@@ -31,6 +31,7 @@ SIGNATURES = {
     "mi355q_bfp_pack_bits": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
     "mi355q_bfp_expand": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mi355q_bf16_tile": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "mi355q_fp32_split_tile": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
     "mi355q_bf16_gemm_tiled": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_bf16_gemm_tiled_res": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_bf16_gemm_tiled_seg": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i64, _vp]),
@@ -86,7 +87,7 @@ class BfpOperand(C.Structure):
                 ("list_cap", _i32), ("mbits", _i32), ("exp_bias", _i32), ("row_aligned", _i32)]
 
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 WORKSPACE_BYTES = 16384
 ZERO_BLOCK_EXACT, ZERO_BLOCK_FAST = 0, 1
 

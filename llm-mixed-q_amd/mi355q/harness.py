@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .quantize import gated_mlp, get_quantized_cls, get_quantized_func, grouped_linear, relu_mlp
+from .quantize import fp32_linear, gated_mlp, get_quantized_cls, get_quantized_func, grouped_linear, relu_mlp
 from .quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
 
 
@@ -144,6 +144,7 @@ class TinyOPTForCausalLM(nn.Module):
         self.layers = nn.ModuleList(_DecoderLayer(cfg, quant_config[f"model_layer_{i}"]) for i in range(cfg.num_layers))
         self.final_layer_norm = nn.LayerNorm(cfg.hidden_size)
         self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)     # not quantised (modeling_opt.py:942-944)
+        self.mi355q_lm_head = "split"
         self.apply(self._init)
 
     def _init(self, m):
@@ -183,8 +184,8 @@ class TinyOPTForCausalLM(nn.Module):
         mask = torch.full((T, T), torch.finfo(x.dtype).min, device=x.device).triu(1)[None, None]
         for layer in self.layers:
             x = layer(x, mask)
-        ops.count_vendor_gemm("harness.lm_head (unquantised, modeling_opt.py:942-944)")
-        logits = self.lm_head(self.final_layer_norm(x))
+        # (unquantised, modeling_opt.py:942-944: fp32-equivalent on the bf16 MFMA -- quantized_modules.linear.fp32_linear; "vendor" = F.linear)
+        logits = fp32_linear(self.final_layer_norm(x), self.lm_head, self.mi355q_lm_head)
         loss = None
         if labels is not None:
             loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1))
@@ -324,6 +325,7 @@ class TinyLlamaForCausalLM(nn.Module):
         self.layers = nn.ModuleList(_LlamaLayer(cfg, quant_config[f"model_layer_{i}"]) for i in range(cfg.num_layers))
         self.norm = _RMSNorm(cfg.hidden_size, cfg.rms_eps)
         self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+        self.mi355q_lm_head = "split"
         for m in self.modules():
             if isinstance(m, (nn.Linear, nn.Embedding)):
                 m.weight.data.normal_(0.0, cfg.init_std)
@@ -356,8 +358,8 @@ class TinyLlamaForCausalLM(nn.Module):
         mask = torch.full((T, T), torch.finfo(x.dtype).min, device=x.device).triu(1)[None, None]
         for layer in self.layers:
             x = layer(x, mask, position_ids)
-        ops.count_vendor_gemm("harness.lm_head (unquantised, modeling_llama.py)")
-        logits = self.lm_head(self.norm(x))
+        # (unquantised, modeling_llama.py:772,866: fp32-equivalent on the bf16 MFMA -- quantized_modules.linear.fp32_linear; "vendor" = F.linear)
+        logits = fp32_linear(self.norm(x), self.lm_head, self.mi355q_lm_head)
         loss = None
         if labels is not None:
             loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1))

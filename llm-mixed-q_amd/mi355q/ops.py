@@ -427,6 +427,26 @@ def bf16_tile(x: torch.Tensor) -> torch.Tensor:
     return yt
 
 
+def fp32_split_tile(x: torch.Tensor, role: int) -> torch.Tensor:
+    """fp32 [rows, K] -> the tiled bf16 operand [rows, 6 K] of an fp32-equivalent product: three bf16 parts per value, the six column
+    segments of mi355q_split.hip (role 0 = left operand / activations, 1 = right operand / weights).  `fp32_gemm_split` multiplies two of them."""
+    _require_device(x, "fp32_split_tile")
+    assert x.ndim == 2 and x.dtype == torch.float32 and x.shape[1] % 32 == 0 and x.is_contiguous() and role in (0, 1)
+    rows, K = x.shape
+    lib = _lib.load_library()
+    yt = torch.empty(lib.mi355q_bfp_tiled_bytes(rows, 12 * K), dtype=torch.int8, device=x.device)
+    with _on_device(x.device):
+        rc = lib.mi355q_fp32_split_tile(_ptr(x), _ptr(yt), rows, K, int(role), _stream_ptr(x.device))
+    _lib.check(rc, "mi355q_fp32_split_tile")
+    return yt
+
+
+def fp32_gemm_split(x6: torch.Tensor, w6: torch.Tensor, M: int, N: int, K: int, bias=None, out: torch.Tensor = None):
+    """y[M, N] = x . w^T (+ bias) of two fp32 matrices given as their split operands (fp32_split_tile, roles 0 and 1): one launch of the bf16
+    tile GEMM over 6 K, fp32 accumulation -- the unquantised lm_head (modeling_llama.py:866) on the MFMA instead of a vendor fp32 GEMM."""
+    return bf16_gemm_tiled(x6, w6, M, N, 6 * K, bias=bias, out=out)
+
+
 def bf16_gemm_tiled(xt: torch.Tensor, wt: torch.Tensor, M: int, N: int, K: int, bias=None, out: torch.Tensor = None,
                     segments: int = 1, residual: torch.Tensor = None):
     """y[M, N] = x . w^T (+ bias) on tiled bf16 operands (block_fp_quantize_bf16_tiled), fp32 accumulation and output:

@@ -8,7 +8,7 @@ from .stat_profile_to_quant_config import transform_stat_profile_to_int_quant_co
 from .quantized_functions import QUANTIZED_FUNC_MAP
 from .quantized_layer_profiler import (profile_linear_layer, profile_matmul_layer, register_a_stat_hook,
                                        update_profile)
-from .quantized_modules import QUANTIZED_MODULE_MAP, gated_mlp, grouped_linear, relu_mlp      # grouped_linear: an addition (q / k / v in one launch)
+from .quantized_modules import QUANTIZED_MODULE_MAP, fp32_linear, gated_mlp, grouped_linear, relu_mlp      # grouped_linear: an addition (q / k / v in one launch)
 from .quantizers import QUANTIZER_MAP
 
 

@@ -1,5 +1,5 @@
 from .linear import (LinearBlockFP, LinearBlockLog, LinearBlockMinifloat, LinearInteger, LinearLog,
-                     LinearMinifloatDenorm, LinearMinifloatIEEE, gated_mlp, grouped_linear, relu_mlp)
+                     LinearMinifloatDenorm, LinearMinifloatIEEE, fp32_linear, gated_mlp, grouped_linear, relu_mlp)
 
 # same keys as the reference's quantized_modules/__init__.py:5-15
 QUANTIZED_MODULE_MAP = {

@@ -958,6 +958,36 @@ def relu_mlp(x, fc1, fc2, norm=None, residual=None):
         return y if residual is None or res2 is not None else residual + y
 
 
+FP32_SPLIT_MIN_ROWS = 128     # (fewer tokens: the product is bound by the weight bytes, and the split operand is 3 x the fp32 one)
+
+
+def fp32_linear(x, linear: nn.Linear, mode: str = "split"):
+    """F.linear(x, linear.weight, linear.bias) for a layer the reference leaves UNQUANTISED -- the language-model head
+    (modeling_llama.py:772,866; modeling_opt.py:942-944: nn.Linear in fp32) -- as an fp32-equivalent product on the bf16 MFMA:
+    both operands as three bf16 parts, the six part products side by side along K in ONE launch of the bf16 tile GEMM
+    (ops.fp32_split_tile / fp32_gemm_split; csrc/mi355q_split.hip).  Closer to an fp64 product than the vendor fp32 GEMM and 1.7 x
+    faster at Llama-7B's head.  The weights' operand is built once and kept on the module (rebuilt when the parameter is written).
+    `mode` "vendor", gradients wanted, a CPU tensor, fewer than FP32_SPLIT_MIN_ROWS tokens or in_features % 32 != 0: torch's
+    F.linear, counted as a vendor GEMM."""
+    w = linear.weight
+    M = x.numel() // max(1, x.shape[-1])
+    ok = (mode == "split" and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.device == x.device
+          and linear.in_features % 32 == 0 and M >= FP32_SPLIT_MIN_ROWS and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)))
+    if not ok:
+        ops.count_vendor_gemm("fp32_linear (unquantised layer, vendor fp32 GEMM)")
+        return F.linear(x, w, linear.bias)
+    key = (w.data_ptr(), w._version, str(w.device))
+    cached = linear.__dict__.get("_mi355q_split_weight")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            cached = (key, ops.fp32_split_tile(w.detach().contiguous(), 1))
+        linear.__dict__["_mi355q_split_weight"] = cached
+    with torch.no_grad():
+        x2 = x.reshape(-1, linear.in_features).contiguous()
+        y = ops.fp32_gemm_split(ops.fp32_split_tile(x2, 0), cached[1], M, linear.out_features, linear.in_features, bias=linear.bias)
+    return y.reshape(*x.shape[:-1], linear.out_features)
+
+
 def grouped_linear(x, layers, norm=None):
     """[layer(x) for layer in layers] for block_fp PTQ Linear layers that take the SAME input and have the same shape and
     widths -- the q / k / v projections of an attention block, gate / up of a gated MLP, which the reference's modules

@@ -16,6 +16,7 @@ import torch
 
 
 MIXED = "auto"        # (--no-mixed: mi355q_mixed = False -- layers whose rows fit no window go to the per-block route as a whole)
+LM_HEAD = "split"     # (--vendor-head: the unquantised lm_head on torch's fp32 GEMM, as before round 6, instead of the split-bf16 product)
 GATED = True          # (--no-gated: the grouped gate / up launch + the quantiser that reads silu(gate) * up, as before round 6)
 
 
@@ -44,6 +45,7 @@ def build(layers, tokens, storage, vocab=32000, hidden=4096, inter=11008, heads=
             for p in model.parameters():
                 if p.ndim == 2 and spread:
                     p.mul_(torch.exp(0.5 * torch.randn(p.shape[0], 1)))
+    model.mi355q_lm_head = LM_HEAD
     return model.eval()
 
 
@@ -90,7 +92,8 @@ def run(layers=32, tokens=2048, steps=5, storage="resident", graph=True, parity=
                "resident_GiB_after_packing": round(mem_after_pack, 2),
                "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2), "linear_routes": routes,
                # (torch's own GEMMs an eager forward called: the unquantised lm_head -- as in the reference -- and nothing else)
-               "vendor_gemm_calls_per_forward": vendor, "gated_mlp": GATED}
+               "vendor_gemm_calls_per_forward": vendor, "gated_mlp": GATED,
+               "lm_head": "fp32-equivalent split-bf16 product (mi355q_fp32_split_tile)" if LM_HEAD == "split" else "vendor fp32 GEMM"}
         if graph:
             g = graphs.GraphedForward(lambda t: model(t)[0], (ids,))
             for _ in range(2):
@@ -158,7 +161,9 @@ if __name__ == "__main__":
     ap.add_argument("--no-spread", action="store_true", help="plain N(0, 0.02) weights instead of rows of different magnitude")
     ap.add_argument("--no-mixed", action="store_true", help="mi355q_mixed = False")
     ap.add_argument("--no-gated", action="store_true", help="without the gated epilogue (mi355q_fused_gate_up = False)")
+    ap.add_argument("--vendor-head", action="store_true", help="lm_head on torch's fp32 GEMM (before round 6)")
     a = ap.parse_args()
+    LM_HEAD = "vendor" if a.vendor_head else "split"
     GATED = not a.no_gated
     MIXED = False if a.no_mixed else "auto"
     print(json.dumps(run(a.layers, a.tokens, a.steps, a.storage, not a.no_graph, not a.no_parity, not a.no_knobs, not a.no_spread)), flush=True)

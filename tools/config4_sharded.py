@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--gather", default="dense", choices=["dense", "segments", "quantised"])
     ap.add_argument("--no-heads", action="store_true", help="heads replicated, q / k / v gathered one by one (round 5's partition) "
                                                              "instead of the attention core on the rank's own heads")
+    ap.add_argument("--vendor-head", action="store_true", help="lm_head on torch's fp32 GEMM (before round 6) instead of the split-bf16 product")
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     force = world == 1 and os.environ.get("MI355Q_FORCE_DIST") == "1"
@@ -68,6 +69,7 @@ def main():
             if p.ndim == 2:
                 p.mul_(torch.exp(0.5 * torch.randn(p.shape[0], 1)))
     model = model.to(dev).eval()
+    model.mi355q_lm_head = "vendor" if a.vendor_head else "split"
     if world > 1 or force:
         sharded.shard_model(model, always_gather=force, gather=a.gather, heads=not a.no_heads)
     ids = torch.randint(0, a.vocab, (1, a.tokens), generator=torch.Generator().manual_seed(1)).to(dev)
@@ -95,7 +97,8 @@ def main():
                           "all_gathers_per_forward": sharded.COLLECTIVES["all_gather"] // a.steps,
                           "gathered_MiB_per_forward": round(sharded.COLLECTIVES["bytes"] / a.steps / 2**20, 1),
                           "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2),
-                          # (torch's own GEMMs a forward called: the unquantised lm_head -- as in the reference -- and nothing else)
+                          "lm_head": "vendor fp32 GEMM" if a.vendor_head else "split-bf16 product",
+                          # (torch's own GEMMs a forward called: none with the split-bf16 head; --vendor-head: the unquantised lm_head)
                           "vendor_gemm_calls_per_forward": {k: v // a.steps for k, v in sorted(_ops.vendor_gemm_calls().items())},
                           "logits_checksum": round(float(logits.double().abs().mean()), 8)}), flush=True)
     if world > 1 or force:
