@@ -519,6 +519,19 @@ int mi355q_bfp_attention(const float* q, const float* k, const float* v, const f
 int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                                  float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D,
                                  const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides, void* stream);
+/* ... with the ROTARY POSITION EMBEDDING of q and k applied on load (round 6, ABI 24) -- modeling_llama.py:289-299 turns q and k between
+ * the projections and the first product (quantized_functions/rotary_positional_encoding.py:59-82):
+ *     x' = x * cos[p] + rotate_half(x) * sin[p],   p = position_ids[batch][row]
+ * mi355q_rope_apply does that as one launch that moves q and k through memory once more (8 B per element, 27 us per Llama-7B layer at
+ * 2048 tokens); here the K pack applies it to the values it is about to quantise and the attention kernels to their Q fragments --
+ * the same fp32 arithmetic (both products rounded on their own, then the sum): the same bits as mi355q_rope_apply followed by
+ * mi355q_bfp_attention_strided, and the turned q / k never exist in memory.  cos / sin: the caller's quantised tables, fp32
+ * [table_rows, D]; position_ids int64 [B / heads, M] (clamped into the table); q, k are [B = batch x heads, rows, D].  cos == NULL: no
+ * embedding (= mi355q_bfp_attention_strided).  M == T and D = 64 or 128, else MI355Q_E_UNSUPPORTED. */
+int mi355q_bfp_attention_rope(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                              float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
+                              const int32_t* pv_params, const int64_t* strides, const float* cos, const float* sin,
+                              const int64_t* position_ids, int64_t table_rows, int32_t heads, void* stream);
 
 /* ---- the un-blocked quantisers -------------------------------------------------------------------------------------
  * replaces: quantizers/minifloat.py:134-196 (minifloat_ieee_quantizer: implicit leading one, subnormals at the lowest

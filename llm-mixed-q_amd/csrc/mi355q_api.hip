@@ -883,6 +883,18 @@ int mi355q_bfp_attention(const float* q, const float* k, const float* v, const f
 int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
                                  float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D,
                                  const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides, void* stream) {
+    return mi355q_bfp_attention_rope(q, k, v, mask, causal, scale_div, out, workspace, B, M, T, D, qk_params, pv_params, strides, nullptr,
+                                     nullptr, nullptr, 0, 1, stream);
+}
+
+int mi355q_bfp_attention_rope(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                              float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
+                              const int32_t* pv_params, const int64_t* strides, const float* cos, const float* sin,
+                              const int64_t* position_ids, int64_t table_rows, int32_t heads, void* stream) {
+    if (cos || sin || position_ids) {
+        if (!cos || !sin || !position_ids || table_rows < 1 || heads < 1) return MI355Q_E_BADARG;
+        if ((reinterpret_cast<uintptr_t>(cos) | reinterpret_cast<uintptr_t>(sin)) % 16 || reinterpret_cast<uintptr_t>(position_ids) % 8) return MI355Q_E_ALIGN;
+    }
     if (B < 0 || M < 0 || T < 0 || D < 0) return MI355Q_E_BADARG;
     if (B == 0 || M == 0 || D == 0) return 0;
     if (!q || !k || !v || !out || !workspace || !qk_params || !pv_params || T == 0 || B > 65535) return MI355Q_E_BADARG;
@@ -913,7 +925,8 @@ int mi355q_bfp_attention_strided(const float* q, const float* k, const float* v,
             st6[i] = strides[i];
         }
     return launch_bfp_attention(a[0], a[1], a[2], a[3], q, k, v, mask, out, workspace, B, M, T, D, causal ? T - M : -1,
-                                scale_div, static_cast<hipStream_t>(stream), strides ? st6 : nullptr);
+                                scale_div, static_cast<hipStream_t>(stream), strides ? st6 : nullptr, cos, sin,
+                                reinterpret_cast<const long long*>(position_ids), table_rows, heads);
 }
 
 // block_minifloat (fmt 1) / block_log (fmt 2) products: the same two kernels with the other quantisers' block parameters

@@ -113,12 +113,37 @@ __device__ __forceinline__ float at_quant_pos(float x, float sc_up, float sc_dn,
     return x <= ATOL ? x : m * sc_dn;
 }
 
+// ---- rotary position embedding on the way in (round 6) ------------------------------------------------------------------
+// modeling_llama.py:289-299 turns q and k with quantised cos / sin tables between the projections and the first product
+// (quantized_functions/rotary_positional_encoding.py:59-82; rope_kernel in mi355q_rope.hip does that as one launch: 8 B per element
+// of q and k through memory, 30 us per Llama-7B layer at 2048 tokens).  With `cos` set the PACK launch below does it on the values it
+// is about to quantise -- k in attn_pack_k, and q in attn_pack_q, which then leaves the quantised Q fragments of the first product
+// for the attention kernels to load (instead of q itself to quantise) -- the same fp32 arithmetic (two products rounded on their own,
+// then the sum), so the same bits, and the turned q / k never exist in memory.
+//     x'[d] = x[d] cos[p][d] + rot[d] sin[p][d],   rot[d] = d < D / 2 ? -x[d + D / 2] : x[d - D / 2],   p = position_ids[batch][row]
+// (Measured first, round 6: q turned inside the attention kernels' own Q load -- every one of a query group's four key-waves forms all
+//  Q fragments, so tables and q were read four times over by a workgroup that is alone on its compute unit: 172 -> 204 us at
+//  [32, 2048, 128], more than the launch it saved.)  heads: q / k are [batch x heads, rows, D]; position_ids [batch, rows].
+struct RopeIn {
+    const float* cos;            // [table_rows, D] quantised tables; null = no rotary embedding here
+    const float* sin;
+    const long long* pos;        // [batch, rows]
+    long long table_rows;
+    int heads;
+};
+__device__ __forceinline__ float at_rope(float x, float c, float rot, float s) {
+    float p = x * c, q = rot * s;
+    asm volatile("" : "+v"(p), "+v"(q));        // (each product rounded to fp32 on its own: no fma contraction, as mi355q_rope.hip)
+    return p + q;
+}
+
 // ---- k [B, T, D] -> fragments of Qb(k^T): blocks of 16 consecutive keys at a fixed d --------------------------------
 // piece (b, t, c) = 1 KiB: lane (key = lane % 16, g = lane / 16) holds d = 32 c + 8 g .. + 7 of key 16 t + (lane % 16).
 // One workgroup = 256 / D key tiles; thread (tile, d) walks the 16 keys of its block (coalesced over d).
+template <bool ROPE>
 __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, uint16_t* __restrict__ tile,
                                             const float* __restrict__ k, uint16_t* __restrict__ kf, long long T, int D,
-                                            long long NT, long long bx, long long sb, long long st) {
+                                            long long NT, long long bx, long long sb, long long st, const RopeIn& rope) {
     // tile: [sub-tile][c][lane][8] = D * 16 values per sub-tile
     const int tid = threadIdx.x, per = 256 / D, sub = tid / D, d = tid % D;
     const long long b = blockIdx.y, t = bx * per + sub;
@@ -130,8 +155,29 @@ __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, 
         for (int e = 0; e < 16; ++e) {
             const long long key = t * 16 + e;
             v[e] = key < T ? k[b * sb + key * st + d] : 0.f;
-            bmax = fmaxf(bmax, fabsf(v[e]));
         }
+        if (ROPE) {                                        // (the rotary embedding of k, see RopeIn -- all loads of a kind in one
+            const int half = D >> 1, dp = d < half ? d + half : d - half;     //  batch, none inside a per-key branch)
+            long long p[16];
+            float xp[16], cs[16], sn[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long key = min(t * 16 + e, T - 1);
+                p[e] = rope.pos[(b / rope.heads) * T + key];
+                xp[e] = k[b * sb + key * st + dp];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long pe = p[e] < 0 ? 0 : (p[e] >= rope.table_rows ? rope.table_rows - 1 : p[e]);
+                cs[e] = rope.cos[pe * D + d];
+                sn[e] = rope.sin[pe * D + d];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                v[e] = t * 16 + e < T ? at_rope(v[e], cs[e], d < half ? -xp[e] : xp[e], sn[e]) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bmax = fmaxf(bmax, fabsf(v[e]));
         unsigned code;
         const int p = bmax != 0.f ? block_param<FMT_BFP>(bmax, a, lut, code).p : 0;
         const int c = d >> 5, g = (d >> 3) & 3, j = d & 7;
@@ -198,17 +244,71 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
     }
 }
 
-// both small operands in one launch: workgroups [0, kblocks) pack k, the rest v
+// ---- q [B, M, D], turned by the rotary embedding -> the fragments of Qa(q): blocks of 16 along D at a fixed query -----------
+// piece (b, query tile, c) = 1 KiB, the attention kernels' Q operand as they hold it: lane (query = lane % 16, g = lane / 16) has
+// d = 32 c + 8 g .. + 7.  One thread = one [1,16] block (query, 16 d): its values, their partners d +- D / 2, the tables' 16 entries --
+// sixteen consecutive threads are sixteen consecutive queries, so each of a thread's two 16-byte stores lies in a 256-byte run.
+__device__ __forceinline__ void attn_pack_q(const QuantArgs& a, const Lut& lut, const float* __restrict__ q, uint16_t* __restrict__ qf,
+                                            long long M, int D, long long NQT, long long bx, long long sb, long long sm, const RopeIn& rope) {
+    const int tid = threadIdx.x, nblk = D >> 4, QPW = 256 / nblk;          // queries per workgroup: 32 at head_dim 128, 64 at 64
+    const int qi = tid % QPW, blk = tid / QPW;
+    const long long b = blockIdx.y, query = bx * QPW + qi;
+    if (query >= NQT * 16) return;
+    const int mbits = (int)__builtin_log2f(a.shift);
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 0.f;
+    if (query < M) {
+        const int half = nblk >> 1, pblk = blk < half ? blk + half : blk - half;
+        const float* __restrict__ row = q + b * sb + query * sm;
+        long long p = rope.pos[(b / rope.heads) * M + query];
+        p = p < 0 ? 0 : (p >= rope.table_rows ? rope.table_rows - 1 : p);
+        const float4* x4 = reinterpret_cast<const float4*>(row + 16 * blk);
+        const float4* y4 = reinterpret_cast<const float4*>(row + 16 * pblk);
+        const float4* c4 = reinterpret_cast<const float4*>(rope.cos + p * D + 16 * blk);
+        const float4* s4 = reinterpret_cast<const float4*>(rope.sin + p * D + 16 * blk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 xv = x4[i], yv = y4[i], cv = c4[i], sv = s4[i];
+            const float sg = blk < half ? -1.0f : 1.0f;                      // (rotate_half: -x[d + D/2] for the first half, x[d - D/2] behind)
+            x[4 * i] = at_rope(xv.x, cv.x, sg * yv.x, sv.x); x[4 * i + 1] = at_rope(xv.y, cv.y, sg * yv.y, sv.y);
+            x[4 * i + 2] = at_rope(xv.z, cv.z, sg * yv.z, sv.z); x[4 * i + 3] = at_rope(xv.w, cv.w, sg * yv.w, sv.w);
+        }
+    }
+    float bmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bmax = fmaxf(bmax, fabsf(x[i]));
+    unsigned code;
+    const int p = bmax != 0.f ? block_param<FMT_BFP>(bmax, a, lut, code).p : 0;
+    unsigned w[8];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const float q0 = bmax != 0.f ? at_quant(x[i], mbits - p, p - mbits, a.mant_max) : 0.f;
+        const float q1 = bmax != 0.f ? at_quant(x[i + 1], mbits - p, p - mbits, a.mant_max) : 0.f;
+        w[i >> 1] = pack_bf16(q0, q1);
+    }
+    // values 16 blk .. + 15 = chunk c = blk / 2, lane groups g = 2 (blk & 1) and g + 1
+    uint16_t* dst = qf + ((b * NQT + (query >> 4)) * (D >> 5) + (blk >> 1)) * 512 + ((query & 15) + 32 * (blk & 1)) * 8;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(dst + 16 * 8) = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// the small operands in one launch: workgroups [0, kblocks) pack k, the next NPAIR / pairs-per-group pack v, the rest (ROPE: q arrives
+// before the rotary embedding, see RopeIn) pack q
+template <bool ROPE>
 __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, const QuantArgs av, const float* __restrict__ k,
                                                            const float* __restrict__ v, uint16_t* __restrict__ kf,
                                                            uint16_t* __restrict__ vf, long long T, int D, long long NT,
                                                            long long NPAIR, int kblocks, long long ksb, long long kst,
-                                                           long long vsb, long long vst, int kw) {
+                                                           long long vsb, long long vst, int kw, const RopeIn rope, const QuantArgs aq,
+                                                           const float* __restrict__ q, uint16_t* __restrict__ qf, int vblocks,
+                                                           long long qsb, long long qsm) {
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) uint16_t buf[AT_MAX_D / 16 * 4 * 512];
     load_lut<FMT_BFP, true>(lut);
-    if ((int)blockIdx.x < kblocks) attn_pack_k(ak, lut, buf, k, kf, T, D, NT, blockIdx.x, ksb, kst);
-    else attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst, kw);
+    if ((int)blockIdx.x < kblocks) attn_pack_k<ROPE>(ak, lut, buf, k, kf, T, D, NT, blockIdx.x, ksb, kst, rope);
+    else if (!ROPE || (int)blockIdx.x < kblocks + vblocks) attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst, kw);
+    else attn_pack_q(aq, lut, q, qf, T, D, NT, (long long)blockIdx.x - kblocks - vblocks, qsb, qsm, rope);
 }
 
 // ---- the attention pass ------------------------------------------------------------------------------------------------
@@ -228,6 +328,7 @@ struct AttnArgs {
     long long osb, osm;       // ... of out's
     unsigned long long* stamps;   // diagnostic (-DATTN_STAMPS builds, tools/dbg/attn_stamps.py): [workgroup][8] realtime words
     int nxb, nb;              // query blocks (of a workgroup's queries) per head, heads: the work items of a launch
+    const uint16_t* qfrag;    // the quantised Q fragments (attn_pack_q: rotary embedding applied); null: q is quantised here
 };
 #ifndef ATTN_EARLY_EXIT
 #define ATTN_EARLY_EXIT 1
@@ -243,7 +344,10 @@ struct AttnArgs {
 // 16 queries stream their head's whole K and V fragments).
 // KW = waves that share the keys of a query group (4, or 8 with half the strip per wave: 64 accumulator VGPRs, twice the
 // waves per SIMD).
-template <int NTW, int DC, int QG, bool HASMASK, int KW = 4>
+// QF: the Q fragments come packed (attn_pack_q: the rotary embedding applied on the way) instead of q itself -- a template
+// argument, not a branch: the branch alone moved the allocator of the eight-key-wave variant from 127 to 130 VGPRs, one workgroup a
+// compute unit instead of two.
+template <int NTW, int DC, int QG, bool HASMASK, int KW = 4, bool QF = false>
 __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
     constexpr int DT = DC * 2;
     constexpr float FMIN = -3.4028234663852886e38f;
@@ -269,7 +373,11 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
 
     // Q fragments: lane (query c16, g) holds d = 32 c + 8 g .. + 7; a [1,16] block = the lanes g, g ^ 1 of a chunk
     bf16x8 qf[DC];
-    {
+    if constexpr (QF) {                                     // packed in front of this launch: attn_pack_q
+        const uint16_t* __restrict__ qfb = g.qfrag + ((b * g.NT + (m0 >> 4)) * DC) * 512 + lane * 8;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qfb + c * 512);
+    } else {
         const int mb = (int)__builtin_log2f(aq.shift);
         const float* __restrict__ qp = g.q + b * g.qsb + qrow * g.qsm;
 #pragma unroll
@@ -474,7 +582,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
 // operands: the same bits), turns them into probabilities with the final statistics, quantises, multiplies with V.  No
 // cross-wave exchange at all, ~90 VGPRs (4-5 waves per SIMD against 2), any T.  The sum of exponentials is accumulated
 // in a different order than in the resident kernel (and than torch's): 1e-7 relative, inside the functions' tolerance.
-template <int DC, bool HASMASK>
+template <int DC, bool HASMASK, bool QF = false>
 __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
     constexpr int DT = DC * 2, KSTEP = 2 * DC * 1024, VSTEP = DT * 1024, STEP = KSTEP + VSTEP;      // bytes per 32 keys
     constexpr float FMIN = -3.4028234663852886e38f;
@@ -492,7 +600,11 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
     const long long m0 = wg0 + 16 * wave;
     const long long qrow = min(m0 + c16, g.M - 1);
     bf16x8 qf[DC];
-    {
+    if constexpr (QF) {                                     // packed in front of this launch: attn_pack_q
+        const uint16_t* __restrict__ qfb = g.qfrag + ((b * g.NT + (m0 >> 4)) * DC) * 512 + lane * 8;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qfb + c * 512);
+    } else {
         const int mb = (int)__builtin_log2f(aq.shift);
         const float* __restrict__ qp = g.q + b * g.qsb + qrow * g.qsm;
 #pragma unroll
@@ -656,13 +768,18 @@ int attention_set_kernel(int which) {
 
 size_t attention_workspace_bytes(long long B, long long T, long long D) {
     const long long NT = (T + 15) / 16, NPAIR = ((T + 255) / 256) * 8;            // (the widest pair grouping)
-    return (size_t)B * (size_t)(NT * (D / 32) * 1024 + (D / 16) * NPAIR * 1024) + 256;
+    // (K fragments, V fragments, and -- rotary embedding on load -- the Q fragments of as many queries)
+    return (size_t)B * (size_t)(2 * NT * (D / 32) * 1024 + (D / 16) * NPAIR * 1024) + 256;
 }
 
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
-                         const long long* strides) {
+                         const long long* strides, const float* rope_cos, const float* rope_sin, const long long* rope_pos,
+                         long long rope_rows, int rope_heads) {
+    // (the rotary embedding on load: q and k rows are the same positions, whole [1,16] blocks in each half of the head -- see RopeIn)
+    if (rope_cos && (M != T || (D != 64 && D != 128) || !rope_sin || !rope_pos || rope_rows < 1 || rope_heads < 1 || B % rope_heads)) return MI355Q_E_UNSUPPORTED;
+    const RopeIn rope{rope_cos, rope_sin, rope_pos, rope_rows, rope_heads};
     if (D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
     const bool stream = g_attention_kernel == 2 || ((g_attention_kernel == 0 || g_attention_kernel > 3) && T > AT_MAX_T);
     if (!stream && T > AT_MAX_T) return MI355Q_E_UNSUPPORTED;
@@ -681,17 +798,26 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     const long long ksb = strides ? strides[2] : T * D, kst = strides ? strides[3] : D;
     const long long vsb = strides ? strides[4] : T * D, vst = strides ? strides[5] : D;
     const long long osb = strides ? strides[6] : M * D, osm = strides ? strides[7] : D;
-    hipLaunchKernelGGL(attn_pack_kv_kernel, dim3((unsigned)(kblocks + NPAIR / pg), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf, T,
-                       (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw);
+    uint16_t* qfrag = vf + (size_t)B * (D / 16) * NPAIR * 512;
+    const int vblocks = (int)(NPAIR / pg), qpw = 256 / (int)(D / 16), qblocks = (int)((NT * 16 + qpw - 1) / qpw);
+    if (rope_cos)
+        hipLaunchKernelGGL(attn_pack_kv_kernel<true>, dim3((unsigned)(kblocks + vblocks + qblocks), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf,
+                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm);
+    else
+        hipLaunchKernelGGL(attn_pack_kv_kernel<false>, dim3((unsigned)(kblocks + vblocks), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf,
+                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0};
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0, rope_cos ? qfrag : nullptr};
     if (stream) {
         g.nxb = (int)((M + 63) / 64);
         g.nb = (int)B;
         const dim3 sgrid((unsigned)((long long)g.nxb * B));
-#define MI355Q_ATTN_S(DC_)                                                                                          \
-    if (mask) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, true>), sgrid, 256, 0, st, aq, ap, g);           \
+#define MI355Q_ATTN_S(DC_)                                                                                                              \
+    if (g.qfrag) {                                                                                                                      \
+        if (mask) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, true, (DC_) % 2 == 0>), sgrid, 256, 0, st, aq, ap, g);           \
+        else hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, false, (DC_) % 2 == 0>), sgrid, 256, 0, st, aq, ap, g);               \
+    } else if (mask) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, true>), sgrid, 256, 0, st, aq, ap, g);                        \
     else hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, false>), sgrid, 256, 0, st, aq, ap, g)
         switch (D / 32) {
             case 1: MI355Q_ATTN_S(1); break;
@@ -711,7 +837,10 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     }
     if (kw8) {
 #define MI355Q_ATTN8(NTW_, DC_)                                                                                  \
-    if (mask) MI355Q_ATTN_GO(16, NTW_, DC_, 1, true, 8)                                                          \
+    if (g.qfrag) {                                                                                               \
+        if (mask) MI355Q_ATTN_GO(16, NTW_, DC_, 1, true, 8, (DC_) % 2 == 0)                                      \
+        else MI355Q_ATTN_GO(16, NTW_, DC_, 1, false, 8, (DC_) % 2 == 0)                                          \
+    } else if (mask) MI355Q_ATTN_GO(16, NTW_, DC_, 1, true, 8)                                                   \
     else MI355Q_ATTN_GO(16, NTW_, DC_, 1, false, 8)
         const int ntw8 = T <= 1024 ? 8 : 16;
         if (ntw8 == 8) { if (D == 32) { MI355Q_ATTN8(8, 1); } else { MI355Q_ATTN8(8, 2); } }
@@ -722,7 +851,10 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     // two 16-query groups per workgroup (measured at T = 2048: 70 vs 101 us at 12 heads x 64, 235 vs 342 us at 32 x 128)
     const int ntw = T <= 512 ? 8 : (T <= 1024 ? 16 : 32);
 #define MI355Q_ATTN(NTW_, DC_)                                                                                \
-    if (mask) MI355Q_ATTN_GO(32, NTW_, DC_, 2, true)                                                          \
+    if (g.qfrag) {                                                                                            \
+        if (mask) MI355Q_ATTN_GO(32, NTW_, DC_, 2, true, 4, (DC_) % 2 == 0)                                   \
+        else MI355Q_ATTN_GO(32, NTW_, DC_, 2, false, 4, (DC_) % 2 == 0)                                       \
+    } else if (mask) MI355Q_ATTN_GO(32, NTW_, DC_, 2, true)                                                   \
     else MI355Q_ATTN_GO(32, NTW_, DC_, 2, false)
 #define MI355Q_ATTN_D(NTW_)                                     \
     switch (D / 32) {                                          \

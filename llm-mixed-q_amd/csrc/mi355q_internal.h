@@ -56,7 +56,8 @@ int attention_set_kernel(int which);
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
-                         const long long* strides = nullptr);
+                         const long long* strides = nullptr, const float* rope_cos = nullptr, const float* rope_sin = nullptr,
+                         const long long* rope_pos = nullptr, long long rope_rows = 0, int rope_heads = 1);
 struct RopeArgs {
     const float* x[2];          // q, k
     float* y[2];

@@ -260,10 +260,16 @@ class _LlamaAttention(nn.Module):
                 x = weight * (x * torch.rsqrt(var + eps)).to(x.dtype)
             q, k, v = shape(self.q_proj(x)), shape(self.k_proj(x)), shape(self.v_proj(x))
         rc = self.qc["rotary_positional_encoding"]
+        c1 = self.qc["matmul_1"]
+        fused = c1["name"] == "block_fp" and c1.get("mi355q_fused_attention", False)
+        if fused and c1.get("mi355q_fused_rotary", False):
+            # (the rotary embedding applied where the attention pass loads q and k: attention_block_fp(rope=...))
+            o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd),
+                                                    rope=(self.cos[:, :, :T], self.sin[:, :, :T], position_ids, rc))
+            return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
         q, k = get_quantized_func("rotary_positional_encoding", rc)(q, k, self.cos[:, :, :T], self.sin[:, :, :T],
                                                                    position_ids, config=rc)
-        c1 = self.qc["matmul_1"]
-        if c1["name"] == "block_fp" and c1.get("mi355q_fused_attention", False):
+        if fused:
             o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd))
             return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
         w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])

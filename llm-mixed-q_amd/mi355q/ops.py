@@ -1301,14 +1301,17 @@ def bfp_attention_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, w
 
 
 def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, pv_params, *, mask: torch.Tensor = None,
-                  causal: bool = False, scale_div: float = None, token_major: bool = False) -> torch.Tensor:
+                  causal: bool = False, scale_div: float = None, token_major: bool = False, rope=None) -> torch.Tensor:
     """out[b] = Qc(softmax(max(Qa(q[b]) @ Qb(k[b]^T) [/ scale_div] + mask, finfo.min))) @ Qd(v[b]) for q [..., M, D], k and v
     [..., T, D] fp32 (k untransposed; strided head views are read in place), block_fp [1,16] blocks along each operand's
     last dim as the reference's two products apply them (matmul.py:146-196); neither scores nor probabilities are
     written.  qk_params / pv_params: (x width, x exponent width, x exponent bias, y width, y exponent width, y exponent
     bias) of bmm_0 / bmm_1.  Returns a contiguous tensor of q's shape -- or, with `token_major` and q [1, H, M, D], the
     [1, H, M, D] view of a contiguous [1, M, H, D] buffer: what the models' `attn_output.transpose(1, 2).reshape(B, T, H * D)`
-    (modeling_opt.py:318-322, modeling_llama.py:349-350) then takes without a copy."""
+    (modeling_opt.py:318-322, modeling_llama.py:349-350) then takes without a copy.
+    `rope` = (cos_q, sin_q [rows, D] quantised tables, position_ids int64 [batch, M]) for q, k [batch, heads, M, D]: the rotary
+    embedding of q and k (modeling_llama.py:289-299) applied as the pass loads them (bfp_attention_rope_supported; the same bits as
+    rope_apply first)."""
     import ctypes
     _require_device(q, "bfp_attention")
     assert bfp_attention_supported(q, k, v, (qk_params[0], qk_params[3], pv_params[0], pv_params[3]))
@@ -1336,12 +1339,29 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
     pa = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(qk_params)])
     pb = (ctypes.c_int32 * 6)(*[_default_bias(p) if i % 3 == 2 else int(p) for i, p in enumerate(pv_params)])
     strides = (ctypes.c_int64 * 8)(qsb, qsm, ksb, kst, vsb, vst, osb, osm)
+    cos_q = sin_q = pos = None
+    rows = heads = 0
+    if rope is not None:
+        cos_q, sin_q, pos = rope
+        assert bfp_attention_rope_supported(q, k, cos_q, sin_q, pos)
+        rows, heads = cos_q.shape[0], q.shape[1]
     with _on_device(q.device):
-        rc = lib.mi355q_bfp_attention_strided(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)),
-                                              float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(ws), B, M, T, D,
-                                              ctypes.addressof(pa), ctypes.addressof(pb), ctypes.addressof(strides), sp)
-    _lib.check(rc, "mi355q_bfp_attention_strided")
+        rc = lib.mi355q_bfp_attention_rope(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)),
+                                           float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(ws), B, M, T, D,
+                                           ctypes.addressof(pa), ctypes.addressof(pb), ctypes.addressof(strides), _ptr(cos_q), _ptr(sin_q),
+                                           _ptr(pos), rows, max(1, heads), sp)
+    _lib.check(rc, "mi355q_bfp_attention_rope")
     return out
+
+
+def bfp_attention_rope_supported(q, k, cos_q, sin_q, position_ids) -> bool:
+    """what the rotary embedding on load takes (include/mi355q.h, mi355q_bfp_attention_rope): q, k [batch, heads, T, D] over the same
+    positions, head_dim 64 or 128, contiguous fp32 tables [rows, D], int64 position_ids [batch, T]"""
+    return (q.ndim == 4 and k.shape == q.shape and q.shape[-1] in (64, 128) and torch.is_tensor(cos_q) and torch.is_tensor(sin_q)
+            and cos_q.dtype == sin_q.dtype == torch.float32 and cos_q.ndim == 2 and cos_q.shape == sin_q.shape and cos_q.shape[1] == q.shape[-1]
+            and cos_q.is_contiguous() and sin_q.is_contiguous() and cos_q.device == q.device and sin_q.device == q.device
+            and position_ids.dtype == torch.int64 and position_ids.shape == (q.shape[0], q.shape[2]) and position_ids.is_contiguous()
+            and position_ids.device == q.device)
 
 
 def attention_set_kernel(which: int) -> int:

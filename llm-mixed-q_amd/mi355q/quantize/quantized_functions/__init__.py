@@ -169,7 +169,7 @@ def _make_softmax(style, arith="block_fp"):
     return f
 
 
-def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, scale_div=None):
+def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, scale_div=None, rope=None):
     """The reference's quantised attention core as one call (modeling_opt.py:246-312, modeling_llama.py:309-344):
 
         w = bmm_0(q, k^T)  [w = w / scale_div]  w = max(w + mask, finfo.min)  p = softmax(w, -1)  out = bmm_1(p, v)
@@ -181,8 +181,14 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
     arithmetics and autograd fall back to the same steps through the registry's own functions.  With
     `config_pv["mi355q_token_major_output"]` and q [1, heads, T, hd] the result is the [1, heads, T, hd] view of a
     contiguous [1, T, heads, hd] buffer (same values): the `transpose(1, 2).reshape(B, T, hidden)` that follows in both
-    models is then free.  An addition to the registry (key "attention")."""
+    models is then free.  An addition to the registry (key "attention").
+    `rope` = (cos, sin, position_ids, rotary config): q and k are the projections BEFORE the rotary embedding
+    (modeling_llama.py:289-299), which the HIP pass applies as it loads them (ops.bfp_attention(rope=...): the turned q / k are
+    never written); wherever that does not apply, the registry's rotary function runs first -- the same values either way."""
     from ... import ops
+    if rope is not None:
+        cos, sin, position_ids, rope_config = rope
+        rope_fn = QUANTIZED_FUNC_MAP["rotary_positional_encoding"][rope_config["name"]]
     m2 = None if mask is None else _mask_2d(mask, q.shape[-2], k.shape[-2])
     both_fp = config_qk.get("name") == "block_fp" and config_pv.get("name") == "block_fp"
     fused_ok = (both_fp and not config_qk.get("bypass", False) and not config_pv.get("bypass", False)
@@ -202,9 +208,19 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
         if blocks_ok and ops.bfp_attention_supported(q, k, v, widths) and (not causal or tk >= tq):
             par = lambda c: (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"], c["weight_width"],
                              c["weight_exponent_width"], c["weight_exponent_bias"])
+            rope_in = None
+            if rope is not None:
+                cos_q, sin_q = rope_tables(cos, sin, rope_config)
+                if (not (torch.is_grad_enabled() and (cos_q.requires_grad or sin_q.requires_grad))
+                        and ops.bfp_attention_rope_supported(q, k, cos_q.contiguous(), sin_q.contiguous(), position_ids.contiguous())):
+                    rope_in = (cos_q.contiguous(), sin_q.contiguous(), position_ids.contiguous())
+                else:
+                    q, k = rope_fn(q, k, cos, sin, position_ids, config=rope_config)
             return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=m2,
                                      causal=causal, scale_div=scale_div,
-                                     token_major=bool(config_pv.get("mi355q_token_major_output", False)))
+                                     token_major=bool(config_pv.get("mi355q_token_major_output", False)), rope=rope_in)
+    if rope is not None:
+        q, k = rope_fn(q, k, cos, sin, position_ids, config=rope_config)
     style = "bmm" if q.ndim == 3 else "matmul"
     w = QUANTIZED_FUNC_MAP[style][config_qk["name"]](q, k.transpose(-1, -2), config=config_qk)
     if scale_div:
@@ -279,21 +295,33 @@ def _quantised_table(t, quant, sig):
     return hit[1]
 
 
+def _rope_tables(arith, honours_bypass, cos, sin, config):
+    """the two tables as the reference's function quantises them (rotary_positional_encoding.py:59-82), [rows, D]"""
+    if honours_bypass and config.get("bypass", False):
+        quant = lambda t: t
+    else:
+        kw = {key: config[f"data_in_{key}"] for key in _KEYS[arith]}
+        if arith in _BLOCKED:
+            kw["skip_first_dim"] = False
+        elif arith == "integer":
+            kw["is_signed"] = True
+        raw = lambda t: QUANTIZER_MAP[arith](t, **kw)
+        sig = (arith,) + tuple((key, str(val)) for key, val in sorted(kw.items()))
+        wants_grad = torch.is_grad_enabled() and (cos.requires_grad or sin.requires_grad)
+        quant = raw if wants_grad else (lambda t: _quantised_table(t, raw, sig))
+    return quant(cos.squeeze(1).squeeze(0)), quant(sin.squeeze(1).squeeze(0))
+
+
+def rope_tables(cos, sin, config):
+    """(cos_q, sin_q) [rows, D] of `get_quantized_func("rotary_positional_encoding", config)`: what that function multiplies q and k
+    with -- for callers that hand the embedding to the attention pass (attention_block_fp(rope=...)) instead of calling it."""
+    arith = config["name"]
+    return _rope_tables(arith, arith != "block_fp", cos, sin, config)
+
+
 def _make_rope(arith, honours_bypass=True):
     def f(q, k, cos, sin, position_ids, config):
-        if honours_bypass and config.get("bypass", False):
-            quant = lambda t: t
-        else:
-            kw = {key: config[f"data_in_{key}"] for key in _KEYS[arith]}
-            if arith in _BLOCKED:
-                kw["skip_first_dim"] = False
-            elif arith == "integer":
-                kw["is_signed"] = True
-            raw = lambda t: QUANTIZER_MAP[arith](t, **kw)
-            sig = (arith,) + tuple((key, str(val)) for key, val in sorted(kw.items()))
-            wants_grad = torch.is_grad_enabled() and (cos.requires_grad or sin.requires_grad)
-            quant = raw if wants_grad else (lambda t: _quantised_table(t, raw, sig))
-        cos_q, sin_q = quant(cos.squeeze(1).squeeze(0)), quant(sin.squeeze(1).squeeze(0))
+        cos_q, sin_q = _rope_tables(arith, honours_bypass, cos, sin, config)
         if _rope_kernel_applies(q, k, cos_q, sin_q, position_ids):
             # one launch for q and k, position lookup included (ops.rope_apply), instead of ten elementwise kernels
             from ... import ops

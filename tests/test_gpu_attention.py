@@ -276,3 +276,86 @@ def test_attention_error_at_model_shapes(B, T, hd, style):
         pass
     assert rec["max_rel"] <= 1e-3, rec
     assert rec["mean_rel"] <= 2e-5, rec
+
+
+# ---- the rotary embedding applied on load (round 6: mi355q_bfp_attention_rope) -------------------------------------------------
+@pytest.mark.parametrize("Bt,H,T,D,kernel", [(1, 4, 256, 128, 0), (2, 3, 512, 64, 0), (1, 2, 1536, 64, 3), (1, 2, 2048, 128, 1),
+                                              (1, 2, 2304, 128, 2), (1, 3, 320, 64, 2), (1, 32, 2048, 128, 0)])
+@pytest.mark.parametrize("strided", [False, True])
+def test_rotary_on_load_is_rope_apply_then_attention_bit_for_bit(Bt, H, T, D, kernel, strided):
+    """q, k straight from the projections + (quantised tables, position_ids) into the attention pass == mi355q_rope_apply first
+    (modeling_llama.py:289-299) and the same pass on the turned q / k: the same fp32 arithmetic in another place, so the same bits --
+    resident (4 / 8 key-waves) and streaming kernels, [T, heads, D] projections read through strided head views, positions that leave
+    the table (clamped) and that are not the row index."""
+    import torch
+    from mi355q import ops
+    if strided and H * T * D * Bt > 2 ** 23:
+        pytest.skip("one layout at the largest shape")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Bt * 1000 + H * 100 + T + D + kernel)
+    mk = lambda: torch.randn(Bt, T, H, D, generator=g).to(dev).transpose(1, 2) if strided else torch.randn(Bt, H, T, D, generator=g).to(dev)
+    q, k, v = mk() * 1.5, mk(), mk()
+    rows = T + 8
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    emb = torch.cat([torch.outer(torch.arange(rows).float(), inv)] * 2, dim=-1)
+    # (tables quantised as the reference's integer rotary quantiser leaves them: multiples of 2^-7)
+    cos_q = (torch.round(emb.cos() * 128) / 128).to(dev).contiguous()
+    sin_q = (torch.round(emb.sin() * 128) / 128).to(dev).contiguous()
+    pos = torch.stack([torch.randperm(rows, generator=g)[:T] for _ in range(Bt)]).to(dev)
+    pos[:, 0] = -3; pos[:, 1] = rows + 5                                      # clamped into the table, as mi355q_rope_apply does
+    par = (6, 8, 127, 6, 8, 127)
+    prev = ops.attention_set_kernel(kernel)
+    try:
+        qr, kr = ops.rope_apply(q, k, cos_q, sin_q, pos)
+        want = ops.bfp_attention(qr, kr, v, par, par, causal=True, scale_div=math.sqrt(D))
+        got = ops.bfp_attention(q, k, v, par, par, causal=True, scale_div=math.sqrt(D), rope=(cos_q, sin_q, pos))
+        assert torch.equal(got, want)
+        # ... and under an additive mask, token-major output
+        m = (torch.randn(T, T, generator=g) * 2).to(dev)
+        want = ops.bfp_attention(qr, kr, v, par, par, mask=m, token_major=True)
+        got = ops.bfp_attention(q, k, v, par, par, mask=m, token_major=True, rope=(cos_q, sin_q, pos))
+        assert torch.equal(got, want)
+    finally:
+        ops.attention_set_kernel(prev)
+
+
+def test_rotary_on_load_through_the_registry_and_its_declines():
+    """attention_block_fp(rope=...) == the registry's rotary function, then attention_block_fp -- on the HIP pass where it applies
+    (head_dim 64 / 128) and through the rotary function first where it does not (head_dim 32, 96; more keys than queries)."""
+    import torch
+    from mi355q.quantize import get_quantized_func
+    dev = torch.device("cuda:0")
+    c = _cfg(6, mi355q_fused_attention=True)
+    rc = dict(name="integer", bypass=False, data_in_width=8, data_in_frac_width=7)
+    att, rope = get_quantized_func("attention", c), get_quantized_func("rotary_positional_encoding", rc)
+    for H, T, D in ((4, 128, 128), (2, 64, 64), (2, 64, 32), (2, 64, 96)):
+        g = torch.Generator().manual_seed(H + T + D)
+        q, k, v = (torch.randn(1, H, T, D, generator=g).to(dev) for _ in range(3))
+        inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+        emb = torch.cat([torch.outer(torch.arange(T).float(), inv)] * 2, dim=-1).to(dev)
+        cos, sin = emb.cos()[None, None], emb.sin()[None, None]
+        pos = torch.arange(T, device=dev)[None]
+        qr, kr = rope(q, k, cos, sin, pos, config=rc)
+        want = att(qr, kr, v, c, c, causal=True, scale_div=math.sqrt(D))
+        got = att(q, k, v, c, c, causal=True, scale_div=math.sqrt(D), rope=(cos, sin, pos, rc))
+        assert torch.equal(got, want), (H, T, D)
+
+
+def test_llama_layer_with_the_rotary_knob_is_the_same_model():
+    import torch
+    from mi355q import harness
+    dev = torch.device("cuda:0")
+    q = _cfg(6, bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16], mi355q_fused_attention=True,
+             mi355q_grouped_linear=True, mi355q_token_major_output=True)
+    cfg = harness.TinyLlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=4, max_positions=256)
+    outs = []
+    for knob in (False, True):
+        torch.manual_seed(0)
+        qc = {"default": dict(q, mi355q_fused_rotary=knob),
+              "rotary_positional_encoding": dict(name="integer", bypass=False, data_in_width=8, data_in_frac_width=7)}
+        model = harness.TinyLlamaForCausalLM(cfg, harness.expand_llama_quant_config(qc, 2)).to(dev).eval()
+        ids = torch.randint(0, 512, (2, 256), generator=torch.Generator().manual_seed(1)).to(dev)
+        with torch.no_grad():
+            model(ids)
+            outs.append(model(ids, labels=ids))
+    assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][1]) == float(outs[1][1])
