@@ -867,6 +867,7 @@ int mi355q_rope_apply(const float* q, const float* k, const float* cos_q, const 
 }
 
 int mi355q_bfp_attention_set_kernel(int which) { return attention_set_kernel(which); }
+int mi355q_bfp_attention_set_qpack(int on) { return attention_set_qpack(on); }
 
 size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D) {
     if (B <= 0 || T <= 0 || D <= 0) return 0;

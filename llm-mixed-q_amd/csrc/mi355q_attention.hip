@@ -32,6 +32,7 @@
 // GEMMs (order differs: the tolerance of the matmul tests); exp to ~1 ulp, quotient corrected once (mi355q_matmul.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mi355q.h"
 #include "mi355q_internal.h"
@@ -108,8 +109,11 @@ __device__ __forceinline__ int at_block_exponent_mem(float bmax, const QuantArgs
     return clampi((int)E - 127 + (f != 0u ? 1 : 0), a.e_min, a.e_max);
 }
 // block_fp element for x >= 0 (probabilities) given the block's scales 2^up, 2^-up (block_fp.py:69-94 with sign = +1)
-__device__ __forceinline__ float at_quant_pos(float x, float sc_up, float sc_dn, float mant_max) {
-    const float m = fminf(__builtin_rintf((x + EPS9) * sc_up), mant_max);
+// (round 6: (x + 1e-9) 2^up as ONE fused multiply-add with eps_up = 1e-9 2^up -- scaling by a power of two commutes with the
+//  rounding of the sum, so fma(x, 2^up, 1e-9 2^up) is round(x + 1e-9) 2^up bit for bit; blocks whose scale overflows hold only
+//  pass-through values.  One VALU operation of the ~36 per probability.)
+__device__ __forceinline__ float at_quant_pos(float x, float sc_up, float eps_up, float sc_dn, float mant_max) {
+    const float m = fminf(__builtin_rintf(__builtin_fmaf(x, sc_up, eps_up)), mant_max);
     return x <= ATOL ? x : m * sc_dn;
 }
 
@@ -248,17 +252,26 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
 // piece (b, query tile, c) = 1 KiB, the attention kernels' Q operand as they hold it: lane (query = lane % 16, g = lane / 16) has
 // d = 32 c + 8 g .. + 7.  One thread = one [1,16] block (query, 16 d): its values, their partners d +- D / 2, the tables' 16 entries --
 // sixteen consecutive threads are sixteen consecutive queries, so each of a thread's two 16-byte stores lies in a 256-byte run.
+template <bool ROPE>
 __device__ __forceinline__ void attn_pack_q(const QuantArgs& a, const Lut& lut, const float* __restrict__ q, uint16_t* __restrict__ qf,
                                             long long M, int D, long long NQT, long long bx, long long sb, long long sm, const RopeIn& rope) {
     const int tid = threadIdx.x, nblk = D >> 4, QPW = 256 / nblk;          // queries per workgroup: 32 at head_dim 128, 64 at 64
     const int qi = tid % QPW, blk = tid / QPW;
     const long long b = blockIdx.y, query = bx * QPW + qi;
-    if (query >= NQT * 16) return;
+    if (query >= (M + 15) / 16 * 16) return;
     const int mbits = (int)__builtin_log2f(a.shift);
     float x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = 0.f;
-    if (query < M) {
+    if (!ROPE && query < M) {
+        const float4* x4 = reinterpret_cast<const float4*>(q + b * sb + query * sm + 16 * blk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 xv = x4[i];
+            x[4 * i] = xv.x; x[4 * i + 1] = xv.y; x[4 * i + 2] = xv.z; x[4 * i + 3] = xv.w;
+        }
+    }
+    if (ROPE && query < M) {
         const int half = nblk >> 1, pblk = blk < half ? blk + half : blk - half;
         const float* __restrict__ row = q + b * sb + query * sm;
         long long p = rope.pos[(b / rope.heads) * M + query];
@@ -293,8 +306,10 @@ __device__ __forceinline__ void attn_pack_q(const QuantArgs& a, const Lut& lut, 
     *reinterpret_cast<uint4*>(dst + 16 * 8) = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-// the small operands in one launch: workgroups [0, kblocks) pack k, the next NPAIR / pairs-per-group pack v, the rest (ROPE: q arrives
-// before the rotary embedding, see RopeIn) pack q
+// the small operands in one launch: workgroups [0, kblocks) pack k, the next NPAIR / pairs-per-group pack v, the rest (if any) pack q --
+// with the rotary embedding (ROPE, see RopeIn), and without it wherever a launch has enough queries for the fragments to pay: every one
+// of a query group's key-waves forms ALL of the group's Q fragments in the attention kernels (four or eight times the loads and the
+// quantiser arithmetic, on a workgroup that is alone on its compute unit): [32, 2048, 128] 173 -> 148 us with the fragments packed here
 template <bool ROPE>
 __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, const QuantArgs av, const float* __restrict__ k,
                                                            const float* __restrict__ v, uint16_t* __restrict__ kf,
@@ -302,13 +317,13 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, c
                                                            long long NPAIR, int kblocks, long long ksb, long long kst,
                                                            long long vsb, long long vst, int kw, const RopeIn rope, const QuantArgs aq,
                                                            const float* __restrict__ q, uint16_t* __restrict__ qf, int vblocks,
-                                                           long long qsb, long long qsm) {
+                                                           long long qsb, long long qsm, long long M) {
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) uint16_t buf[AT_MAX_D / 16 * 4 * 512];
     load_lut<FMT_BFP, true>(lut);
     if ((int)blockIdx.x < kblocks) attn_pack_k<ROPE>(ak, lut, buf, k, kf, T, D, NT, blockIdx.x, ksb, kst, rope);
-    else if (!ROPE || (int)blockIdx.x < kblocks + vblocks) attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst, kw);
-    else attn_pack_q(aq, lut, q, qf, T, D, NT, (long long)blockIdx.x - kblocks - vblocks, qsb, qsm, rope);
+    else if ((int)blockIdx.x < kblocks + vblocks) attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst, kw);
+    else attn_pack_q<ROPE>(aq, lut, q, qf, M, D, NT, (long long)blockIdx.x - kblocks - vblocks, qsb, qsm, rope);
 }
 
 // ---- the attention pass ------------------------------------------------------------------------------------------------
@@ -533,14 +548,16 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
                 float bmax = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pr[e] = KW * i + wave < need ? at_div(acc[i][e], row_sum, row_inv) : 0.f;
+                    // (a pair's second tile may lie behind the horizon: its strip entries are the exact zeros of a product with
+                    //  out-of-range K fragments, untouched by the exponentials -- and 0 / sum = 0 without a select)
+                    pr[e] = at_div(acc[i][e], row_sum, row_inv);
                     bmax = fmaxf(bmax, pr[e]);
                 }
                 bmax = at_max4(bmax);
                 const int p = at_block_exponent_mem(bmax, ap);
-                const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp);
+                const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp), eps_up = EPS9 * sc_up;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pq[4 * h + e] = at_quant_pos(pr[e], sc_up, sc_dn, ap.mant_max);
+                for (int e = 0; e < 4; ++e) pq[4 * h + e] = at_quant_pos(pr[e], sc_up, eps_up, sc_dn, ap.mant_max);
             }
             uint4 pk;
             pk.x = pack_bf16(pq[0], pq[1]); pk.y = pack_bf16(pq[2], pq[3]);
@@ -736,9 +753,9 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
             }
             bmax = at_max4(bmax);
             const int p = at_block_exponent(bmax, ap, lut);
-            const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp);
+            const float sc_up = __builtin_ldexpf(1.0f, mbp - p), sc_dn = __builtin_ldexpf(1.0f, p - mbp), eps_up = EPS9 * sc_up;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pq[4 * h + e] = at_quant_pos(pr[e], sc_up, sc_dn, ap.mant_max);
+            for (int e = 0; e < 4; ++e) pq[4 * h + e] = at_quant_pos(pr[e], sc_up, eps_up, sc_dn, ap.mant_max);
         }
         uint4 pk;
         pk.x = pack_bf16(pq[0], pq[1]); pk.y = pack_bf16(pq[2], pq[3]);
@@ -760,6 +777,12 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
 
 static int g_attention_kernel = 0;          // 0: by size, 1: resident scores with 4 key-waves (T <= 2048), 2: streaming,
                                             // 3: resident scores with 8 key-waves (head_dim <= 64)   (A/B runs, tests)
+static int g_attention_qpack = getenv("MI355Q_ATTN_QPACK") ? atoi(getenv("MI355Q_ATTN_QPACK")) : 1;
+int attention_set_qpack(int on) {
+    const int prev = g_attention_qpack;
+    if (on >= 0 && on <= 2) g_attention_qpack = on;
+    return prev;
+}
 int attention_set_kernel(int which) {
     const int prev = g_attention_kernel;
     if (which >= 0 && which <= 3) g_attention_kernel = which;
@@ -785,7 +808,15 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     if (!stream && T > AT_MAX_T) return MI355Q_E_UNSUPPORTED;
     // eight key-waves per query group (half the score strip per wave: 127 VGPRs, twice the waves per SIMD) for head_dim <=
     // 64 and long rows: 65 vs 78 us at 12 x 2048 x 64, 135 vs 167 us at 32 x 2048 x 64; no difference at 1024 keys
-    const bool kw8 = !stream && D <= 64 && (g_attention_kernel == 3 || (g_attention_kernel == 0 && T > 1024));
+    // Q fragments packed in front of the kernels (attn_pack_q): always with the rotary embedding; without it where it pays -- head_dim
+    // 128 on the resident kernel from 64 queries up (the area holds NT tiles a head: M <= T).  Pack + attention, us, fragments packed /
+    // q quantised in the kernels (profiles/r06_attention_qpack.jsonl): [32, 2048, 128] 156 / 169, [32, 1024, 128] 64 / 69; head_dim 64
+    // LOSES ([32, 2048, 64] 134 / 109: the eight-key-wave variant needs 130 VGPRs with the fragment loads -- one workgroup a compute
+    // unit instead of two), and so does the streaming kernel, whose waves each own their queries ([32, 4096, 128] 542 / 526).
+    // attention_set_qpack(0): never without the rotary embedding (A/B runs, tests); (2): wherever the fragments fit (tests).
+    const bool qpack = rope_cos || (g_attention_qpack && M >= 64 && M <= T && (g_attention_qpack == 2 ? (D == 64 || D == 128) : (D == 128 && !stream)));
+    // (with packed fragments the four-key-wave variant: [32, 2048, 64] 117 vs 134 us)
+    const bool kw8 = !stream && D <= 64 && (g_attention_kernel == 3 || (g_attention_kernel == 0 && T > 1024 && !qpack));
     const int kw = stream ? 1 : (kw8 ? 8 : 4), pg = kw == 8 ? 8 : 4;
     const long long NT = T / 16, NPAIR = ((T + 32 * pg - 1) / (32 * pg)) * pg;
     uint16_t* kf = static_cast<uint16_t*>(workspace);
@@ -799,16 +830,16 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     const long long vsb = strides ? strides[4] : T * D, vst = strides ? strides[5] : D;
     const long long osb = strides ? strides[6] : M * D, osm = strides ? strides[7] : D;
     uint16_t* qfrag = vf + (size_t)B * (D / 16) * NPAIR * 512;
-    const int vblocks = (int)(NPAIR / pg), qpw = 256 / (int)(D / 16), qblocks = (int)((NT * 16 + qpw - 1) / qpw);
+    const int vblocks = (int)(NPAIR / pg), qpw = 256 / (int)(D / 16), qblocks = qpack ? (int)(((M + 15) / 16 * 16 + qpw - 1) / qpw) : 0;
     if (rope_cos)
         hipLaunchKernelGGL(attn_pack_kv_kernel<true>, dim3((unsigned)(kblocks + vblocks + qblocks), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf,
-                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm);
+                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm, M);
     else
-        hipLaunchKernelGGL(attn_pack_kv_kernel<false>, dim3((unsigned)(kblocks + vblocks), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf,
-                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm);
+        hipLaunchKernelGGL(attn_pack_kv_kernel<false>, dim3((unsigned)(kblocks + vblocks + qblocks), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf,
+                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm, M);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0, rope_cos ? qfrag : nullptr};
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0, qpack ? qfrag : nullptr};
     if (stream) {
         g.nxb = (int)((M + 63) / 64);
         g.nb = (int)B;

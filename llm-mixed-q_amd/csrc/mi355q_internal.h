@@ -53,6 +53,7 @@ int launch_bfp_qmatmul(const QuantArgs& ax, const QuantArgs& ay, const float* x,
                        const float* mask = nullptr, long long causal_off = -1, int fmt = 0);
 size_t attention_workspace_bytes(long long B, long long T, long long D);
 int attention_set_kernel(int which);
+int attention_set_qpack(int on);
 int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantArgs& ap, const QuantArgs& av, const float* q,
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,

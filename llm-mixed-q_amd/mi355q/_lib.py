@@ -61,6 +61,7 @@ SIGNATURES = {
     "mi355q_block_log_matmul_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
     "mi355q_block_log_matmul": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
     "mi355q_bfp_attention_set_kernel": (C.c_int, [C.c_int]),
+    "mi355q_bfp_attention_set_qpack": (C.c_int, [C.c_int]),
     "mi355q_bfp_attention_workspace_bytes": (C.c_size_t, [_i64, _i64, _i64]),
     "mi355q_bfp_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi355q_bfp_attention_strided": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -1369,6 +1369,13 @@ def attention_set_kernel(which: int) -> int:
     return _lib.load_library().mi355q_bfp_attention_set_kernel(int(which))
 
 
+def attention_set_qpack(on: int) -> int:
+    """1 (default): the pack launch in front of the attention kernels also leaves the quantised Q fragments where that pays (head_dim 128,
+    T <= 2048, 64 <= M <= T); 0: q is always quantised inside the attention kernels (before round 6); 2: fragments wherever they fit
+    (head_dim 64 / 128: tests).  The same bits; returns the previous setting."""
+    return _lib.load_library().mi355q_bfp_attention_set_qpack(int(on))
+
+
 def rope_apply(q: torch.Tensor, k: torch.Tensor, cos_q: torch.Tensor, sin_q: torch.Tensor, position_ids: torch.Tensor):
     """(q * cos[pos] + rotate_half(q) * sin[pos], the same for k) for q [B, Hq, T, D], k [B, Hk, T, D] fp32 (any strides
     with a unit innermost one), cos_q / sin_q [rows, D] already quantised, position_ids int64 [B, T]: one launch

@@ -359,3 +359,34 @@ def test_llama_layer_with_the_rotary_knob_is_the_same_model():
             model(ids)
             outs.append(model(ids, labels=ids))
     assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][1]) == float(outs[1][1])
+
+
+@pytest.mark.parametrize("H,M,T,D,kernel,mode", [(4, 256, 256, 128, 0, "causal"), (3, 512, 512, 64, 0, "mask"), (2, 1536, 1536, 64, 3, "causal"),
+                                                 (2, 2048, 2048, 128, 1, "causal"), (2, 2304, 2304, 128, 2, "causal"), (3, 100, 320, 64, 2, "mask"),
+                                                 (2, 72, 256, 128, 1, "causal"), (12, 2048, 2048, 64, 3, "both"), (12, 2048, 2048, 64, 1, "both")])
+def test_packed_q_fragments_equal_the_in_kernel_quantiser(H, M, T, D, kernel, mode):
+    """round 6: the pack launch leaves the quantised Q fragments and the attention kernels load them (ops.attention_set_qpack(2): wherever
+    they fit; 1, the default, where it pays) == every key-wave quantising q itself (0): the same block exponents, the same mantissas, so the same output bits --
+    ragged query counts (zero rows in the last fragment tile), fewer queries than keys, all three kernels."""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + M + T + D)
+    q = (torch.randn(H, M, D, generator=g) * torch.exp(torch.randn(H, M, 1, generator=g))).to(dev)
+    q[0, 0] = 0.0                                                     # an all-zero row: zero blocks
+    q[0, 1, :16] = 2.0 ** -130                                        # a subnormal block maximum
+    k, v = torch.randn(H, T, D, generator=g).to(dev), torch.randn(H, T, D, generator=g).to(dev)
+    m = (torch.randn(M, T, generator=g) * 2).to(dev) if mode in ("mask", "both") else None
+    par = (6, 8, 127, 6, 8, 127)
+    prev_k = ops.attention_set_kernel(kernel)
+    outs = []
+    try:
+        for on in (0, 2):
+            prev = ops.attention_set_qpack(on)
+            try:
+                outs.append(ops.bfp_attention(q, k, v, par, par, mask=m, causal=mode in ("causal", "both"), scale_div=math.sqrt(D)))
+            finally:
+                ops.attention_set_qpack(prev)
+    finally:
+        ops.attention_set_kernel(prev_k)
+    assert torch.equal(outs[0], outs[1])

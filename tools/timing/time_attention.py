@@ -66,6 +66,16 @@ for name, H, T, hd, scale in (("OPT-125m", 12, 2048, 64, None), ("OPT-1.3B", 32,
         finally:
             ops.attention_set_kernel(prev)
     r["one_pass_us"] = round(timed(one_pass), 1)
+    prev = ops.attention_set_qpack(2)
+    try:
+        r["one_pass_q_fragments_packed_us"] = round(timed(one_pass), 1)
+    finally:
+        ops.attention_set_qpack(prev)
+    prev = ops.attention_set_qpack(0)                                  # (round 6: Q fragments packed in front of the kernels, or not)
+    try:
+        r["one_pass_q_quantised_in_kernel_us"] = round(timed(one_pass), 1)
+    finally:
+        ops.attention_set_qpack(prev)
     r["one_pass_vs_steps_max_rel"] = round(err, 6)
     r["speedup_vs_steps"] = round(r["steps_us"] / r["one_pass_us"], 2)
     r["one_pass_TFLOPs_full_count"] = round(flops / r["one_pass_us"] / 1e6, 1)
