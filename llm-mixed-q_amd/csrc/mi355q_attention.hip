@@ -155,30 +155,39 @@ __device__ __forceinline__ void attn_pack_k(const QuantArgs& a, const Lut& lut, 
     if (sub < per && t < NT) {
         float v[16];
         float bmax = 0.f;
+        if (!ROPE) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const long long key = t * 16 + e;
-            v[e] = key < T ? k[b * sb + key * st + d] : 0.f;
-        }
-        if (ROPE) {                                        // (the rotary embedding of k, see RopeIn -- all loads of a kind in one
-            const int half = D >> 1, dp = d < half ? d + half : d - half;     //  batch, none inside a per-key branch)
-            long long p[16];
+            for (int e = 0; e < 16; ++e) {
+                const long long key = t * 16 + e;
+                v[e] = key < T ? k[b * sb + key * st + d] : 0.f;
+            }
+        } else {
+            // the rotary embedding of k, see RopeIn.  A wave's 64 threads share their key tile (D >= 64 here), so the tile index goes
+            // through readfirstlane: the 16 positions become scalar loads and every row / table address a scalar base + the lane's d --
+            // all loads of a kind in one batch, none inside a per-key branch.  (32-bit table offsets: the launcher checks rows x D.)
+            const int half = D >> 1, dp = d < half ? d + half : d - half;
+            const int tu = __builtin_amdgcn_readfirstlane((int)t), Ti = (int)T;
+            const long long* __restrict__ prow = rope.pos + (b / rope.heads) * T;
+            const float* __restrict__ kb = k + b * sb;
+            int pe[16];
             float xp[16], cs[16], sn[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const long long key = min(t * 16 + e, T - 1);
-                p[e] = rope.pos[(b / rope.heads) * T + key];
-                xp[e] = k[b * sb + key * st + dp];
+                const int key = min(tu * 16 + e, Ti - 1);
+                const long long p = prow[key];
+                pe[e] = (int)(p < 0 ? 0 : (p >= rope.table_rows ? rope.table_rows - 1 : p)) * D;
+                const float* __restrict__ row = kb + key * st;
+                v[e] = row[d];
+                xp[e] = row[dp];
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const long long pe = p[e] < 0 ? 0 : (p[e] >= rope.table_rows ? rope.table_rows - 1 : p[e]);
-                cs[e] = rope.cos[pe * D + d];
-                sn[e] = rope.sin[pe * D + d];
+                cs[e] = rope.cos[pe[e] + d];
+                sn[e] = rope.sin[pe[e] + d];
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                v[e] = t * 16 + e < T ? at_rope(v[e], cs[e], d < half ? -xp[e] : xp[e], sn[e]) : 0.f;
+                v[e] = tu * 16 + e < Ti ? at_rope(v[e], cs[e], d < half ? -xp[e] : xp[e], sn[e]) : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) bmax = fmaxf(bmax, fabsf(v[e]));
@@ -801,7 +810,9 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                          const long long* strides, const float* rope_cos, const float* rope_sin, const long long* rope_pos,
                          long long rope_rows, int rope_heads) {
     // (the rotary embedding on load: q and k rows are the same positions, whole [1,16] blocks in each half of the head -- see RopeIn)
-    if (rope_cos && (M != T || (D != 64 && D != 128) || !rope_sin || !rope_pos || rope_rows < 1 || rope_heads < 1 || B % rope_heads)) return MI355Q_E_UNSUPPORTED;
+    if (rope_cos && (M != T || (D != 64 && D != 128) || !rope_sin || !rope_pos || rope_rows < 1 || rope_heads < 1 || B % rope_heads ||
+                     rope_rows * D >= (1ll << 31) || T >= (1ll << 27)))
+        return MI355Q_E_UNSUPPORTED;
     const RopeIn rope{rope_cos, rope_sin, rope_pos, rope_rows, rope_heads};
     if (D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
     const bool stream = g_attention_kernel == 2 || ((g_attention_kernel == 0 || g_attention_kernel > 3) && T > AT_MAX_T);
