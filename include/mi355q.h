@@ -538,6 +538,19 @@ int mi355q_bfp_attention_rope(const float* q, const float* k, const float* v, co
                               float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                               const int32_t* pv_params, const int64_t* strides, const float* cos, const float* sin,
                               const int64_t* position_ids, int64_t table_rows, int32_t heads, void* stream);
+/* ... and with the OUT-PROJECTION's operand as the output (round 6, ABI 24).  Behind the attention core both models reshape to
+ * [tokens, heads x D] and call out_proj / o_proj (modeling_opt.py:318-328, modeling_llama.py:349-353); where that Linear runs on the
+ * per-block-exponent route its first step is mi355q_block_fp_quantize_bf16_tiled on the fp32 attention output.  A [1,16] block of that
+ * quantiser is one query's column tile of one head -- four lanes of the kernels' store epilogue -- so with out_bf16_tiled != NULL the
+ * kernels quantise there (consumer_params = the consumer's data_in {width, exponent width, exponent bias}) and write the tiled bf16 operand
+ * [M, B x D] (head order; mi355q_bfp_tiled_bytes(M, 2 B D) bytes; ONE batch element: B = heads) that mi355q_bf16_gemm_tiled(_res) reads:
+ * bit for bit what the separate quantiser makes of the fp32 output, which is never written (`out` may be NULL then).  cos == NULL: no
+ * rotary embedding; out_bf16_tiled == NULL: = mi355q_bfp_attention_rope. */
+int mi355q_bfp_attention_fused(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                               float* out, void* out_bf16_tiled, const int32_t* consumer_params, void* workspace, int64_t B, int64_t M,
+                               int64_t T, int64_t D, const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides,
+                               const float* cos, const float* sin, const int64_t* position_ids, int64_t table_rows, int32_t heads,
+                               void* stream);
 
 /* ---- the un-blocked quantisers -------------------------------------------------------------------------------------
  * replaces: quantizers/minifloat.py:134-196 (minifloat_ieee_quantizer: implicit leading one, subnormals at the lowest

@@ -892,6 +892,30 @@ int mi355q_bfp_attention_rope(const float* q, const float* k, const float* v, co
                               float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                               const int32_t* pv_params, const int64_t* strides, const float* cos, const float* sin,
                               const int64_t* position_ids, int64_t table_rows, int32_t heads, void* stream) {
+    return mi355q_bfp_attention_fused(q, k, v, mask, causal, scale_div, out, nullptr, nullptr, workspace, B, M, T, D, qk_params, pv_params,
+                                      strides, cos, sin, position_ids, table_rows, heads, stream);
+}
+
+int mi355q_bfp_attention_fused(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
+                               float* out, void* out_bf16_tiled, const int32_t* consumer_params, void* workspace, int64_t B, int64_t M,
+                               int64_t T, int64_t D, const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides,
+                               const float* cos, const float* sin, const int64_t* position_ids, int64_t table_rows, int32_t heads,
+                               void* stream) {
+    QuantArgs ao{};
+    if (out_bf16_tiled) {
+        // the consumer's data_in quantiser {width, exponent width, exponent bias}; its operand is [M, B x D] in head order: ONE batch element
+        if (!consumer_params || consumer_params[0] < 2 || consumer_params[1] < 1 || consumer_params[1] > 8 || (cos && heads != B)) return MI355Q_E_BADARG;
+        if (consumer_params[0] > 9) return MI355Q_E_UNSUPPORTED;
+        if (reinterpret_cast<uintptr_t>(out_bf16_tiled) % 16) return MI355Q_E_ALIGN;
+        int bias = consumer_params[2];
+        if (bias == MI355Q_BIAS_DEFAULT) bias = (1 << (consumer_params[1] - 1)) - 1;
+        ao.b0 = 1; ao.b1 = 16;
+        ao.code_bias = bias;
+        ao.e_min = -bias;
+        ao.e_max = (1 << consumer_params[1]) - 1 - bias;
+        set_mantissa(ao, consumer_params[0] - 1);
+        if (!out) out = reinterpret_cast<float*>(out_bf16_tiled);       // (never written; keeps the argument checks below uniform)
+    }
     if (cos || sin || position_ids) {
         if (!cos || !sin || !position_ids || table_rows < 1 || heads < 1) return MI355Q_E_BADARG;
         if ((reinterpret_cast<uintptr_t>(cos) | reinterpret_cast<uintptr_t>(sin)) % 16 || reinterpret_cast<uintptr_t>(position_ids) % 8) return MI355Q_E_ALIGN;
@@ -927,7 +951,8 @@ int mi355q_bfp_attention_rope(const float* q, const float* k, const float* v, co
         }
     return launch_bfp_attention(a[0], a[1], a[2], a[3], q, k, v, mask, out, workspace, B, M, T, D, causal ? T - M : -1,
                                 scale_div, static_cast<hipStream_t>(stream), strides ? st6 : nullptr, cos, sin,
-                                reinterpret_cast<const long long*>(position_ids), table_rows, heads);
+                                reinterpret_cast<const long long*>(position_ids), table_rows, heads, static_cast<uint16_t*>(out_bf16_tiled),
+                                out_bf16_tiled ? &ao : nullptr);
 }
 
 // block_minifloat (fmt 1) / block_log (fmt 2) products: the same two kernels with the other quantisers' block parameters

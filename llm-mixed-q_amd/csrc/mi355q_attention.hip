@@ -335,6 +335,44 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, c
     else attn_pack_q<ROPE>(aq, lut, q, qf, M, D, NT, (long long)blockIdx.x - kblocks - vblocks, qsb, qsm, rope);
 }
 
+// ---- the consumer's operand in the store epilogue (round 6) -----------------------------------------------------------
+// Behind the attention core both models reshape to [tokens, heads x D] and call the out-projection (modeling_opt.py:318-328,
+// modeling_llama.py:349-353), whose activation quantiser -- where that Linear runs on the per-block-exponent route --
+// is mi355q_block_fp_quantize_bf16_tiled: 4 B read + 2 B written per value in a launch of its own.  Its [1,16] blocks along the
+// hidden dimension are exactly a head's column tile dt of one query, i.e. the four lanes c16 + 16 g of the epilogue: with
+// `out_tiled` set the kernels form the block maximum over those lanes, quantise (the Q fragments' arithmetic with the
+// consumer's parameters) and store 8 bytes of bf16 a lane straight into the consumer's tiled operand (1-KiB pieces of 16 rows
+// x 32 values, [8-value group][row][16 B]: mi355q_quant.hip) -- the fp32 attention output is never written.
+struct AttnConsumer {
+    uint16_t* out_tiled;      // null: fp32 `out` as before
+    long long kp;             // pieces per 16-row tile of the operand: heads x D / 32
+    float mant_max;
+    int mbits, e_min, e_max;
+};
+__device__ __forceinline__ void at_store_consumer(const AttnConsumer& c, const f32x4& v, long long m, long long M, long long col) {
+    float bmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    bmax = at_max4(bmax);
+    const unsigned bits = __float_as_uint(bmax), E = bits >> 23, f = bits & 0x7FFFFFu;
+    int p;
+    if (__any((E == 0u && bits != 0u) || (f != 0u && f < MI355Q_LOG2_CEIL_THR_MAX))) {       // (rare: the table decides, see at_block_exponent_mem)
+        int k; unsigned mm;
+        split_pos(bmax != 0.f ? bmax : 1.0f, k, mm);
+        p = clampi(k + ((mm != 0u && mm >= mi355q_log2_ceil_thr[lut_index(k)]) ? 1 : 0), c.e_min, c.e_max);
+    } else {
+        p = clampi((int)E - 127 + (f != 0u ? 1 : 0), c.e_min, c.e_max);
+    }
+    const int up = c.mbits - p, dn = p - c.mbits;
+    // (+ 0.0f: a value that rounds to zero comes out of at_quant with its sign, out of the streaming quantiser's magic-number rounding as
+    //  +0.0 -- the same operand of a product, but the claim is byte for byte)
+    const unsigned lo = pack_bf16(at_quant(v[0], up, dn, c.mant_max) + 0.0f, at_quant(v[1], up, dn, c.mant_max) + 0.0f);
+    const unsigned hi = pack_bf16(at_quant(v[2], up, dn, c.mant_max) + 0.0f, at_quant(v[3], up, dn, c.mant_max) + 0.0f);
+    if (m < M) {
+        unsigned char* dst = reinterpret_cast<unsigned char*>(c.out_tiled) + ((m >> 4) * c.kp + (col >> 5)) * 1024 + ((col & 31) >> 3) * 256 +
+                             (m & 15) * 16 + (col & 7) * 2;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+    }
+}
+
 // ---- the attention pass ------------------------------------------------------------------------------------------------
 // NTW = score tiles per wave (KW = 4: 8, 16, 32 <-> T <= 512, 1024, 2048; KW = 8: half of that), DC = D / 32.
 static unsigned long long* g_attn_stamps = nullptr;     // diagnostic (-DATTN_STAMPS builds)
@@ -353,6 +391,7 @@ struct AttnArgs {
     unsigned long long* stamps;   // diagnostic (-DATTN_STAMPS builds, tools/dbg/attn_stamps.py): [workgroup][8] realtime words
     int nxb, nb;              // query blocks (of a workgroup's queries) per head, heads: the work items of a launch
     const uint16_t* qfrag;    // the quantised Q fragments (attn_pack_q: rotary embedding applied); null: q is quantised here
+    AttnConsumer cons;        // the out-projection's tiled bf16 operand instead of fp32 `out` (out_tiled == null: fp32)
 };
 #ifndef ATTN_EARLY_EXIT
 #define ATTN_EARLY_EXIT 1
@@ -371,7 +410,8 @@ struct AttnArgs {
 // QF: the Q fragments come packed (attn_pack_q: the rotary embedding applied on the way) instead of q itself -- a template
 // argument, not a branch: the branch alone moved the allocator of the eight-key-wave variant from 127 to 130 VGPRs, one workgroup a
 // compute unit instead of two.
-template <int NTW, int DC, int QG, bool HASMASK, int KW = 4, bool QF = false>
+// OT: the consumer's tiled operand as the output (at_store_consumer) -- a template argument for the same reason.
+template <int NTW, int DC, int QG, bool HASMASK, int KW = 4, bool QF = false, bool OT = false>
 __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
     constexpr int DT = DC * 2;
     constexpr float FMIN = -3.4028234663852886e38f;
@@ -587,7 +627,8 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
         f32x4 sum = red[0][dt][lane];
 #pragma unroll
         for (int w = 1; w < KW; ++w) sum += red[w][dt][lane];
-        if (m < g.M)
+        if constexpr (OT) at_store_consumer(g.cons, sum, m, g.M, b * g.D + 16 * dt + 4 * lg);
+        else if (m < g.M)
             *reinterpret_cast<float4*>(g.out + b * g.osb + m * g.osm + 16 * dt + 4 * lg) = make_float4(sum[0], sum[1], sum[2], sum[3]);
     }
 #ifdef ATTN_STAMPS
@@ -608,7 +649,7 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
 // operands: the same bits), turns them into probabilities with the final statistics, quantises, multiplies with V.  No
 // cross-wave exchange at all, ~90 VGPRs (4-5 waves per SIMD against 2), any T.  The sum of exponentials is accumulated
 // in a different order than in the resident kernel (and than torch's): 1e-7 relative, inside the functions' tolerance.
-template <int DC, bool HASMASK, bool QF = false>
+template <int DC, bool HASMASK, bool QF = false, bool OT = false>
 __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantArgs aq, const QuantArgs ap, const AttnArgs g) {
     constexpr int DT = DC * 2, KSTEP = 2 * DC * 1024, VSTEP = DT * 1024, STEP = KSTEP + VSTEP;      // bytes per 32 keys
     constexpr float FMIN = -3.4028234663852886e38f;
@@ -777,7 +818,10 @@ __global__ __launch_bounds__(256) void bfp_attention_stream_kernel(const QuantAr
         }
     }
     const long long m = m0 + c16;
-    if (m < g.M) {
+    if constexpr (OT) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) at_store_consumer(g.cons, o[dt], m, g.M, b * g.D + 16 * dt + 4 * lg);
+    } else if (m < g.M) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
             *reinterpret_cast<float4*>(g.out + b * g.osb + m * g.osm + 16 * dt + 4 * lg) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
@@ -808,7 +852,12 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
                          const long long* strides, const float* rope_cos, const float* rope_sin, const long long* rope_pos,
-                         long long rope_rows, int rope_heads) {
+                         long long rope_rows, int rope_heads, uint16_t* out_tiled, const QuantArgs* ao) {
+    // (the consumer's operand: rows = queries, columns = head x D in head order -- B is the head count of ONE batch element)
+    if (out_tiled && (!ao || (B * D) % 32 != 0)) return MI355Q_E_BADARG;
+    if (out_tiled && (mask || (D != 64 && D != 128))) return MI355Q_E_UNSUPPORTED;        // (the flavours that are built: OT above)
+    const AttnConsumer cons{out_tiled, out_tiled ? B * D / 32 : 0, ao ? ao->mant_max : 0.f, ao ? (int)__builtin_log2f(ao->shift) : 0,
+                            ao ? ao->e_min : 0, ao ? ao->e_max : 0};
     // (the rotary embedding on load: q and k rows are the same positions, whole [1,16] blocks in each half of the head -- see RopeIn)
     if (rope_cos && (M != T || (D != 64 && D != 128) || !rope_sin || !rope_pos || rope_rows < 1 || rope_heads < 1 || B % rope_heads ||
                      rope_rows * D >= (1ll << 31) || T >= (1ll << 27)))
@@ -850,24 +899,24 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                            T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm, M);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0, qpack ? qfrag : nullptr};
+    AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0, qpack ? qfrag : nullptr, cons};
     if (stream) {
         g.nxb = (int)((M + 63) / 64);
         g.nb = (int)B;
         const dim3 sgrid((unsigned)((long long)g.nxb * B));
-#define MI355Q_ATTN_S(DC_)                                                                                                              \
-    if (g.qfrag) {                                                                                                                      \
-        if (mask) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, true, (DC_) % 2 == 0>), sgrid, 256, 0, st, aq, ap, g);           \
-        else hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, false, (DC_) % 2 == 0>), sgrid, 256, 0, st, aq, ap, g);               \
-    } else if (mask) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, true>), sgrid, 256, 0, st, aq, ap, g);                        \
-    else hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, false>), sgrid, 256, 0, st, aq, ap, g)
+#define MI355Q_ATTN_S1(DC_, M_, QF_, OT_) hipLaunchKernelGGL((bfp_attention_stream_kernel<DC_, M_, QF_, OT_>), sgrid, 256, 0, st, aq, ap, g)
+#define MI355Q_ATTN_S(DC_)                                                                                     \
+    if (mask) { if (g.qfrag) MI355Q_ATTN_S1(DC_, true, (DC_) % 2 == 0, false); else MI355Q_ATTN_S1(DC_, true, false, false); }          \
+    else if (g.cons.out_tiled) { if (g.qfrag) MI355Q_ATTN_S1(DC_, false, (DC_) % 2 == 0, (DC_) % 2 == 0); else MI355Q_ATTN_S1(DC_, false, false, (DC_) % 2 == 0); } \
+    else { if (g.qfrag) MI355Q_ATTN_S1(DC_, false, (DC_) % 2 == 0, false); else MI355Q_ATTN_S1(DC_, false, false, false); }
         switch (D / 32) {
-            case 1: MI355Q_ATTN_S(1); break;
-            case 2: MI355Q_ATTN_S(2); break;
-            case 3: MI355Q_ATTN_S(3); break;
-            default: MI355Q_ATTN_S(4); break;
+            case 1: MI355Q_ATTN_S(1) break;
+            case 2: MI355Q_ATTN_S(2) break;
+            case 3: MI355Q_ATTN_S(3) break;
+            default: MI355Q_ATTN_S(4) break;
         }
 #undef MI355Q_ATTN_S
+#undef MI355Q_ATTN_S1
         return (int)hipGetLastError();
     }
     // the resident kernel's launch: one workgroup per work item (query block, head), heaviest items first (see the kernel)
@@ -878,12 +927,11 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
         hipLaunchKernelGGL((bfp_attention_kernel<__VA_ARGS__>), dim3((unsigned)((long long)g.nxb * B)), 512, 0, st, aq, ap, g); \
     }
     if (kw8) {
-#define MI355Q_ATTN8(NTW_, DC_)                                                                                  \
-    if (g.qfrag) {                                                                                               \
-        if (mask) MI355Q_ATTN_GO(16, NTW_, DC_, 1, true, 8, (DC_) % 2 == 0)                                      \
-        else MI355Q_ATTN_GO(16, NTW_, DC_, 1, false, 8, (DC_) % 2 == 0)                                          \
-    } else if (mask) MI355Q_ATTN_GO(16, NTW_, DC_, 1, true, 8)                                                   \
-    else MI355Q_ATTN_GO(16, NTW_, DC_, 1, false, 8)
+#define MI355Q_ATTN_PICK(QPB_, NTW_, DC_, QG_, KW_)                                                                                       \
+    if (mask) { if (g.qfrag) MI355Q_ATTN_GO(QPB_, NTW_, DC_, QG_, true, KW_, (DC_) % 2 == 0, false) else MI355Q_ATTN_GO(QPB_, NTW_, DC_, QG_, true, KW_, false, false) } \
+    else if (g.cons.out_tiled) { if (g.qfrag) MI355Q_ATTN_GO(QPB_, NTW_, DC_, QG_, false, KW_, (DC_) % 2 == 0, (DC_) % 2 == 0) else MI355Q_ATTN_GO(QPB_, NTW_, DC_, QG_, false, KW_, false, (DC_) % 2 == 0) } \
+    else { if (g.qfrag) MI355Q_ATTN_GO(QPB_, NTW_, DC_, QG_, false, KW_, (DC_) % 2 == 0, false) else MI355Q_ATTN_GO(QPB_, NTW_, DC_, QG_, false, KW_, false, false) }
+#define MI355Q_ATTN8(NTW_, DC_) MI355Q_ATTN_PICK(16, NTW_, DC_, 1, 8)
         const int ntw8 = T <= 1024 ? 8 : 16;
         if (ntw8 == 8) { if (D == 32) { MI355Q_ATTN8(8, 1); } else { MI355Q_ATTN8(8, 2); } }
         else { if (D == 32) { MI355Q_ATTN8(16, 1); } else { MI355Q_ATTN8(16, 2); } }
@@ -892,12 +940,7 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     }
     // two 16-query groups per workgroup (measured at T = 2048: 70 vs 101 us at 12 heads x 64, 235 vs 342 us at 32 x 128)
     const int ntw = T <= 512 ? 8 : (T <= 1024 ? 16 : 32);
-#define MI355Q_ATTN(NTW_, DC_)                                                                                \
-    if (g.qfrag) {                                                                                            \
-        if (mask) MI355Q_ATTN_GO(32, NTW_, DC_, 2, true, 4, (DC_) % 2 == 0)                                   \
-        else MI355Q_ATTN_GO(32, NTW_, DC_, 2, false, 4, (DC_) % 2 == 0)                                       \
-    } else if (mask) MI355Q_ATTN_GO(32, NTW_, DC_, 2, true)                                                   \
-    else MI355Q_ATTN_GO(32, NTW_, DC_, 2, false)
+#define MI355Q_ATTN(NTW_, DC_) MI355Q_ATTN_PICK(32, NTW_, DC_, 2, 4)
 #define MI355Q_ATTN_D(NTW_)                                     \
     switch (D / 32) {                                          \
         case 1: MI355Q_ATTN(NTW_, 1); break;                   \
@@ -911,6 +954,7 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
 #undef MI355Q_ATTN_D
 #undef MI355Q_ATTN
 #undef MI355Q_ATTN_GO
+#undef MI355Q_ATTN_PICK
     return (int)hipGetLastError();
 }
 

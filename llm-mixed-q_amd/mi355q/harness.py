@@ -22,6 +22,23 @@ from .quantize import fp32_linear, gated_mlp, get_quantized_cls, get_quantized_f
 from .quantize.model_quant_config import parse_llama_quantized_config, parse_opt_quantized_config
 
 
+def _attention_consumer(c1: dict, proj, hs, B: int):
+    """(width, exponent width, exponent bias) of the out-projection's activation quantiser when the attention pass may write that
+    layer's operand itself (config["mi355q_fused_attention_output"]; ops.bfp_attention(consumer=...)): one batch element, heads not
+    sharded, the Linear on the per-block route -- else None"""
+    if not c1.get("mi355q_fused_attention_output", False) or hs is not None or B != 1:
+        return None
+    ok = getattr(proj, "accepts_tiled_input", None)
+    return proj.consumer_quantiser() if ok is not None and ok() else None
+
+
+def _project_attention_output(o, proj, out, B, T, width, residual):
+    """out_proj / o_proj behind the attention function: on its tiled operand (ops.TiledBf16) where the pass wrote one"""
+    if isinstance(o, ops.TiledBf16):
+        return proj.forward_tiled(o, (B, T), residual=residual)
+    return out(o.transpose(1, 2).reshape(B, T, width))
+
+
 @dataclass
 class TinyOPTConfig:
     vocab_size: int = 512
@@ -76,8 +93,8 @@ class _Attention(nn.Module):
             else:
                 qp, kp, vp = self.q_proj(x), self.k_proj(x), self.v_proj(x)
             o = get_quantized_func("attention", c1)(heads(qp * self.scaling), heads(kp), heads(vp), self.qc["bmm_0"], c1,
-                                                    causal=True)
-            return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
+                                                    causal=True, consumer=_attention_consumer(c1, self.out_proj, hs, B))
+            return _project_attention_output(o, self.out_proj, out, B, T, nh * self.hd, residual)
         q = shape(self.q_proj(x) * self.scaling)
         k, v = shape(self.k_proj(x)), shape(self.v_proj(x))
         w = get_quantized_func("bmm", self.qc["bmm_0"])(q, k.transpose(1, 2), config=self.qc["bmm_0"])
@@ -265,13 +282,15 @@ class _LlamaAttention(nn.Module):
         if fused and c1.get("mi355q_fused_rotary", False):
             # (the rotary embedding applied where the attention pass loads q and k: attention_block_fp(rope=...))
             o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd),
-                                                    rope=(self.cos[:, :, :T], self.sin[:, :, :T], position_ids, rc))
-            return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
+                                                    rope=(self.cos[:, :, :T], self.sin[:, :, :T], position_ids, rc),
+                                                    consumer=_attention_consumer(c1, self.o_proj, hs, B))
+            return _project_attention_output(o, self.o_proj, out, B, T, nh * self.hd, residual)
         q, k = get_quantized_func("rotary_positional_encoding", rc)(q, k, self.cos[:, :, :T], self.sin[:, :, :T],
                                                                    position_ids, config=rc)
         if fused:
-            o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd))
-            return out(o.transpose(1, 2).reshape(B, T, nh * self.hd))
+            o = get_quantized_func("attention", c1)(q, k, v, self.qc["matmul_0"], c1, causal=True, scale_div=math.sqrt(self.hd),
+                                                    consumer=_attention_consumer(c1, self.o_proj, hs, B))
+            return _project_attention_output(o, self.o_proj, out, B, T, nh * self.hd, residual)
         w = get_quantized_func("matmul", self.qc["matmul_0"])(q, k.transpose(2, 3), config=self.qc["matmul_0"])
         if c1["name"] in ("block_fp", "block_minifloat") and c1.get("mi355q_fused_softmax", False):
             o = get_quantized_func("softmax_matmul", c1)(w / math.sqrt(self.hd), v, config=c1, causal=True)

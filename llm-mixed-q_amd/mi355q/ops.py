@@ -1301,7 +1301,7 @@ def bfp_attention_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, w
 
 
 def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, pv_params, *, mask: torch.Tensor = None,
-                  causal: bool = False, scale_div: float = None, token_major: bool = False, rope=None) -> torch.Tensor:
+                  causal: bool = False, scale_div: float = None, token_major: bool = False, rope=None, consumer=None):
     """out[b] = Qc(softmax(max(Qa(q[b]) @ Qb(k[b]^T) [/ scale_div] + mask, finfo.min))) @ Qd(v[b]) for q [..., M, D], k and v
     [..., T, D] fp32 (k untransposed; strided head views are read in place), block_fp [1,16] blocks along each operand's
     last dim as the reference's two products apply them (matmul.py:146-196); neither scores nor probabilities are
@@ -1311,7 +1311,11 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
     (modeling_opt.py:318-322, modeling_llama.py:349-350) then takes without a copy.
     `rope` = (cos_q, sin_q [rows, D] quantised tables, position_ids int64 [batch, M]) for q, k [batch, heads, M, D]: the rotary
     embedding of q and k (modeling_llama.py:289-299) applied as the pass loads them (bfp_attention_rope_supported; the same bits as
-    rope_apply first)."""
+    rope_apply first).
+    `consumer` = (width, exponent width, exponent bias) of the out-projection's data_in quantiser, q [1, H, M, D], no mask: the result is
+    NOT an fp32 tensor but `TiledBf16` -- that Linear's quantised activations [M, H D] as the tiled bf16 operand of its per-block
+    product, written by the kernels' store epilogue (bfp_attention_consumer_supported; the same bits as block_fp_quantize_bf16_tiled
+    of the fp32 output, which is never written)."""
     import ctypes
     _require_device(q, "bfp_attention")
     assert bfp_attention_supported(q, k, v, (qk_params[0], qk_params[3], pv_params[0], pv_params[3]))
@@ -1329,6 +1333,12 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
         out = torch.empty(*q.shape, dtype=torch.float32, device=q.device)
         osb, osm = M * D, D
     lib = _lib.load_library()
+    tiled = pc = None
+    if consumer is not None:
+        assert bfp_attention_consumer_supported(q, mask)
+        tiled = torch.empty(lib.mi355q_bfp_tiled_bytes(M, 2 * B * D), dtype=torch.int8, device=q.device)
+        pc = (ctypes.c_int32 * 3)(int(consumer[0]), int(consumer[1]), _default_bias(consumer[2]))
+        out = None
     sp = _stream_ptr(q.device)
     key = (q.device.index, sp, B, T, D)
     ws = _ATTN_WS.get(key)
@@ -1346,12 +1356,26 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
         assert bfp_attention_rope_supported(q, k, cos_q, sin_q, pos)
         rows, heads = cos_q.shape[0], q.shape[1]
     with _on_device(q.device):
-        rc = lib.mi355q_bfp_attention_rope(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)),
-                                           float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(ws), B, M, T, D,
-                                           ctypes.addressof(pa), ctypes.addressof(pb), ctypes.addressof(strides), _ptr(cos_q), _ptr(sin_q),
-                                           _ptr(pos), rows, max(1, heads), sp)
-    _lib.check(rc, "mi355q_bfp_attention_rope")
-    return out
+        rc = lib.mi355q_bfp_attention_fused(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)),
+                                            float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(tiled), ctypes.addressof(pc) if pc else None,
+                                            _ptr(ws), B, M, T, D, ctypes.addressof(pa), ctypes.addressof(pb), ctypes.addressof(strides),
+                                            _ptr(cos_q), _ptr(sin_q), _ptr(pos), rows, max(1, heads), sp)
+    _lib.check(rc, "mi355q_bfp_attention_fused")
+    return out if tiled is None else TiledBf16(tiled, M, B * D)
+
+
+class TiledBf16:
+    """quantised activations [rows, cols] as the tiled bf16 operand of the per-block product (block_fp_quantize_bf16_tiled's output with
+    its shape): what a producer hands a Linear that runs on that route (`Linear.forward_tiled`)"""
+
+    def __init__(self, buf: torch.Tensor, rows: int, cols: int):
+        self.buf, self.rows, self.cols = buf, int(rows), int(cols)
+
+
+def bfp_attention_consumer_supported(q, mask) -> bool:
+    """what the consumer's operand as the attention output takes (include/mi355q.h, mi355q_bfp_attention_fused): ONE batch element
+    [1, H, M, D], head_dim 64 or 128, no additive mask (causal is fine)"""
+    return q.ndim == 4 and q.shape[0] == 1 and q.shape[-1] in (64, 128) and mask is None
 
 
 def bfp_attention_rope_supported(q, k, cos_q, sin_q, position_ids) -> bool:

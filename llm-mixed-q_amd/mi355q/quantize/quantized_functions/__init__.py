@@ -169,7 +169,7 @@ def _make_softmax(style, arith="block_fp"):
     return f
 
 
-def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, scale_div=None, rope=None):
+def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, scale_div=None, rope=None, consumer=None):
     """The reference's quantised attention core as one call (modeling_opt.py:246-312, modeling_llama.py:309-344):
 
         w = bmm_0(q, k^T)  [w = w / scale_div]  w = max(w + mask, finfo.min)  p = softmax(w, -1)  out = bmm_1(p, v)
@@ -184,7 +184,10 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
     models is then free.  An addition to the registry (key "attention").
     `rope` = (cos, sin, position_ids, rotary config): q and k are the projections BEFORE the rotary embedding
     (modeling_llama.py:289-299), which the HIP pass applies as it loads them (ops.bfp_attention(rope=...): the turned q / k are
-    never written); wherever that does not apply, the registry's rotary function runs first -- the same values either way."""
+    never written); wherever that does not apply, the registry's rotary function runs first -- the same values either way.
+    `consumer` = (width, exponent width, exponent bias) of the out-projection's data_in block_fp quantiser: where the HIP pass can
+    (one batch element, head_dim 64 / 128, no additive mask) the result is `ops.TiledBf16` -- that Linear's quantised activations
+    [T_q, heads x hd], for `Linear.forward_tiled` -- instead of the fp32 tensor; the caller checks which it got."""
     from ... import ops
     if rope is not None:
         cos, sin, position_ids, rope_config = rope
@@ -218,7 +221,8 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
                     q, k = rope_fn(q, k, cos, sin, position_ids, config=rope_config)
             return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=m2,
                                      causal=causal, scale_div=scale_div,
-                                     token_major=bool(config_pv.get("mi355q_token_major_output", False)), rope=rope_in)
+                                     token_major=bool(config_pv.get("mi355q_token_major_output", False)), rope=rope_in,
+                                     consumer=consumer if consumer is not None and ops.bfp_attention_consumer_supported(q, m2) else None)
     if rope is not None:
         q, k = rope_fn(q, k, cos, sin, position_ids, config=rope_config)
     style = "bmm" if q.ndim == 3 else "matmul"

@@ -763,6 +763,31 @@ class _LinearBase(nn.Linear):
                 return self._forward_int8(x, self._int8_plan(x), residual=residual)
         return residual + self(x)
 
+    def accepts_tiled_input(self) -> bool:
+        """can a producer hand this layer its quantised activations as a tiled bf16 operand (`forward_tiled`)?  block_fp PTQ on the
+        per-block-exponent route with its weights packed: the attention pass then writes o_proj's operand itself."""
+        return (self.arith == "block_fp" and self.is_ptq and not self.bypass and not self.weight_requires_quantisation
+                and self._pending_flavour is None and self._packed_is_current() and self._uses_bf16_route()
+                and self.config["data_in_width"] <= 9 and self.in_features % 32 == 0
+                and ops.resolve_blocking([1, self.in_features], self.config["data_in_block_size"], True)[3:] == (1, 16))
+
+    def consumer_quantiser(self):
+        """(width, exponent width, exponent bias) of this layer's activation quantiser, for a producer that applies it"""
+        c = self.config
+        return (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"])
+
+    def forward_tiled(self, xt, lead, residual=None):
+        """self(x) [+ residual] for x given as `ops.TiledBf16` [rows, in_features] -- this layer's OWN quantised activations, formed by
+        the producer (ops.bfp_attention(consumer=self.consumer_quantiser())): the per-block product alone.  `lead`: the leading shape
+        of the result (rows = prod(lead))."""
+        assert self.accepts_tiled_input() and xt.cols == self.in_features
+        with torch.no_grad():
+            res2 = residual.reshape(-1, self.out_features) if residual is not None and self._residual_operand_ok(residual, lead) else None
+            y = ops.bf16_gemm_tiled(xt.buf, self._bf16_weight_operand(xt.buf.device), xt.rows, self.out_features, self.in_features, self.bias,
+                                    out=self._take_out(xt.rows), residual=res2)
+        y = y.reshape(*lead, self.out_features)
+        return y if residual is None or res2 is not None else residual + y
+
     def _take_out(self, rows):
         """where the caller wants this call's product stored (sharded.RowShardedLinear: its rank's segment of the all-gather buffer,
         so that the collective runs in place), once; None: a fresh tensor"""

@@ -390,3 +390,76 @@ def test_packed_q_fragments_equal_the_in_kernel_quantiser(H, M, T, D, kernel, mo
     finally:
         ops.attention_set_kernel(prev_k)
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- the out-projection's operand as the attention output (round 6: mi355q_bfp_attention_fused) ---------------------------------
+def _valid_rows(buf, rows, cols):
+    """the bytes of rows 0 .. rows - 1 of a tiled bf16 operand [rows, cols] (pieces of 16 rows x 32 values, [8-value group][row][16 B])"""
+    v = buf.view(-1, cols // 32, 4, 16, 16)[: (rows + 15) // 16].cpu().numpy().copy()
+    if rows % 16:
+        v[-1, :, :, rows % 16:] = 0
+    return v
+
+
+@pytest.mark.parametrize("H,M,T,D,kernel,cw,rope", [(4, 256, 256, 128, 0, 6, True), (8, 512, 512, 64, 0, 6, False), (2, 1536, 1536, 64, 3, 5, True),
+                                                    (2, 2048, 2048, 128, 1, 8, False), (2, 2304, 2304, 128, 2, 6, True), (3, 100, 320, 64, 2, 4, False),
+                                                    (2, 72, 256, 128, 1, 6, False), (32, 2048, 2048, 128, 0, 6, True)])
+def test_consumer_operand_from_the_store_epilogue_is_the_separate_quantiser(H, M, T, D, kernel, cw, rope):
+    """ops.bfp_attention(consumer=(width, 8, 127)) -- the out-projection's tiled bf16 operand written by the kernels' store epilogue --
+    == the fp32 attention output [M, H D] (token-major) through mi355q_block_fp_quantize_bf16_tiled, byte for byte over the valid rows:
+    all three kernels, with and without the rotary embedding / packed Q fragments, ragged query counts, consumer widths 4 .. 8."""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * 7 + M + T + D + cw)
+    q = (torch.randn(1, M, H, D, generator=g) * 1.5).to(dev).transpose(1, 2)
+    k, v = (torch.randn(1, T, H, D, generator=g).to(dev).transpose(1, 2) for _ in range(2))
+    v = v * torch.exp(torch.randn(1, H, 1, D, generator=g)).to(dev)         # per-channel spread: block exponents differ along a row
+    par = (6, 8, 127, 6, 8, 127)
+    rp = None
+    if rope:
+        assert M == T
+        inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+        emb = torch.cat([torch.outer(torch.arange(T).float(), inv)] * 2, dim=-1)
+        rp = ((torch.round(emb.cos() * 128) / 128).to(dev).contiguous(), (torch.round(emb.sin() * 128) / 128).to(dev).contiguous(),
+              torch.arange(T, device=dev)[None].contiguous())
+    prev = ops.attention_set_kernel(kernel)
+    try:
+        o = ops.bfp_attention(q, k, v, par, par, causal=True, scale_div=math.sqrt(D), token_major=True, rope=rp)
+        want = ops.block_fp_quantize_bf16_tiled(o.transpose(1, 2).reshape(M, H * D).contiguous(), cw, 8, 127)
+        got = ops.bfp_attention(q, k, v, par, par, causal=True, scale_div=math.sqrt(D), token_major=True, rope=rp, consumer=(cw, 8, 127))
+    finally:
+        ops.attention_set_kernel(prev)
+    assert isinstance(got, ops.TiledBf16) and (got.rows, got.cols) == (M, H * D) and got.buf.numel() == want.numel()
+    assert np.array_equal(_valid_rows(got.buf, M, H * D), _valid_rows(want, M, H * D))
+
+
+@pytest.mark.parametrize("family", ["llama", "opt"])
+def test_model_with_the_attention_output_knob_is_the_same_model(family):
+    """harness models, out_proj / o_proj on the per-block route (mi355q_align = "blocks"): mi355q_fused_attention_output on == off,
+    logits and loss bit for bit -- with the residual add in the product's stores and without"""
+    import torch
+    from mi355q import harness, ops
+    dev = torch.device("cuda:0")
+    base = _cfg(6, bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16], mi355q_fused_attention=True,
+                mi355q_grouped_linear=True, mi355q_token_major_output=True, mi355q_align="blocks")
+    for fres in (False, True):
+        outs = []
+        for knob in (False, True):
+            torch.manual_seed(0)
+            d = dict(base, mi355q_fused_attention_output=knob, mi355q_fused_residual=fres, mi355q_fused_norm=fres, mi355q_fused_activation=fres,
+                     mi355q_fused_rotary=knob)
+            if family == "llama":
+                cfg = harness.TinyLlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=4, max_positions=256)
+                qc = {"default": d, "rotary_positional_encoding": dict(name="integer", bypass=False, data_in_width=8, data_in_frac_width=7)}
+                model = harness.TinyLlamaForCausalLM(cfg, harness.expand_llama_quant_config(qc, 2)).to(dev).eval()
+            else:
+                cfg = harness.TinyOPTConfig(vocab_size=512, hidden_size=512, ffn_dim=1024, num_layers=2, num_heads=8, max_positions=256)
+                model = harness.TinyOPTForCausalLM(cfg, harness.expand_quant_config({"default": d}, 2)).to(dev).eval()
+            ids = torch.randint(0, 512, (1, 256), generator=torch.Generator().manual_seed(1)).to(dev)
+            with torch.no_grad():
+                model(ids)
+                outs.append(model(ids, labels=ids))
+            proj = model.layers[0].self_attn.o_proj if family == "llama" else model.layers[0].self_attn.out_proj
+            assert proj.accepts_tiled_input()
+        assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][1]) == float(outs[1][1]), (family, fres)

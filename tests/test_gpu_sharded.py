@@ -129,9 +129,11 @@ def _model_worker(rank, world, port, q):
         res = []
         # heads: the attention core on the rank's own heads, one all-gather of its output in front of out_proj / o_proj (round 6:
         # OPT 4 collectives a layer, Llama 5) -- or heads replicated and q, k, v gathered one by one (6 / 7)
-        for family, width, mixed, knobs, gather, heads in (("opt", 4, True, False, "dense", True), ("opt", 4, True, True, "segments", True),
-                                                           ("llama", 6, False, True, "dense", True), ("opt", 4, True, True, "dense", False),
-                                                           ("llama", 6, False, False, "dense", True), ("llama", 6, False, True, "dense", False)):
+        # (last field: the rotary embedding applied by the attention pack launch -- on the rank's own heads when head-sharded)
+        for family, width, mixed, knobs, gather, heads, rotary in (("opt", 4, True, False, "dense", True, False), ("opt", 4, True, True, "segments", True, False),
+                                                                   ("llama", 6, False, True, "dense", True, False), ("opt", 4, True, True, "dense", False, False),
+                                                                   ("llama", 6, False, False, "dense", True, False), ("llama", 6, False, True, "dense", False, False),
+                                                                   ("llama", 6, False, True, "dense", True, True), ("llama", 6, False, True, "dense", False, True)):
             def build():
                 torch.manual_seed(11)
                 if family == "opt":
@@ -139,6 +141,7 @@ def _model_worker(rank, world, port, q):
                     m = harness.TinyOPTForCausalLM(c, harness.expand_quant_config(_model_cfg(width, mixed, knobs), 2))
                 else:
                     lc = _model_cfg(width, mixed, knobs)
+                    lc["default"]["mi355q_fused_rotary"] = rotary
                     lc["rotary_positional_encoding"] = dict(name="integer", bypass=False, data_in_width=8, data_in_frac_width=7)
                     c = harness.TinyLlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1536, num_layers=2, num_heads=8, max_positions=256)
                     m = harness.TinyLlamaForCausalLM(c, harness.expand_llama_quant_config(lc, 2))
@@ -159,7 +162,7 @@ def _model_worker(rank, world, port, q):
             n_proj = (4 if family == "opt" else 5) if heads else (6 if family == "opt" else 7)
             packed = model.layers[0].self_attn.q_proj.local._packed is not None
             assert model.layers[0].self_attn.q_proj.keep_local == heads
-            res.append((family, knobs, f"{gather} heads={heads}", bool(torch.equal(got, ref)), float(loss) == float(ref_loss),
+            res.append((family, knobs, f"{gather} heads={heads} rotary={rotary}", bool(torch.equal(got, ref)), float(loss) == float(ref_loss),
                         sharded.COLLECTIVES["all_gather"] == 2 * n_proj, packed))
         q.put((rank, res))
     except Exception as e:

@@ -17,6 +17,7 @@ import torch
 
 MIXED = "auto"        # (--no-mixed: mi355q_mixed = False -- layers whose rows fit no window go to the per-block route as a whole)
 LM_HEAD = "split"     # (--vendor-head: the unquantised lm_head on torch's fp32 GEMM, as before round 6, instead of the split-bf16 product)
+ATTN_OUT = True       # (--no-attn-out: the attention pass writes fp32 and o_proj's quantiser reads it, as before round 6)
 ROTARY = True         # (--no-rotary: the rotary embedding as its own launch in front of the attention pass, as before round 6)
 GATED = True          # (--no-gated: the grouped gate / up launch + the quantiser that reads silu(gate) * up, as before round 6)
 
@@ -28,7 +29,7 @@ def quant_config(storage: str, knobs: bool = True):
              bias_width=6, bias_exponent_width=8, bias_exponent_bias=127, bias_block_size=[16])
     if knobs:
         d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
-                 mi355q_token_major_output=True, mi355q_fused_residual=True, mi355q_fused_gate_up=GATED, mi355q_mixed=MIXED, mi355q_fused_rotary=ROTARY)
+                 mi355q_token_major_output=True, mi355q_fused_residual=True, mi355q_fused_gate_up=GATED, mi355q_mixed=MIXED, mi355q_fused_rotary=ROTARY, mi355q_fused_attention_output=ATTN_OUT)
     if storage == "packed":
         d.update(mi355q_weight_storage="packed")
     # the rotary tables of every shipped TOML: 8-bit fixed point (configs/quantization/bfp_6bit.toml)
@@ -93,7 +94,7 @@ def run(layers=32, tokens=2048, steps=5, storage="resident", graph=True, parity=
                "resident_GiB_after_packing": round(mem_after_pack, 2),
                "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2), "linear_routes": routes,
                # (torch's own GEMMs an eager forward called: the unquantised lm_head -- as in the reference -- and nothing else)
-               "vendor_gemm_calls_per_forward": vendor, "gated_mlp": GATED, "rotary_on_load": ROTARY,
+               "vendor_gemm_calls_per_forward": vendor, "gated_mlp": GATED, "rotary_on_load": ROTARY, "attention_writes_o_proj_operand": ATTN_OUT,
                "lm_head": "fp32-equivalent split-bf16 product (mi355q_fp32_split_tile)" if LM_HEAD == "split" else "vendor fp32 GEMM"}
         if graph:
             g = graphs.GraphedForward(lambda t: model(t)[0], (ids,))
@@ -164,7 +165,9 @@ if __name__ == "__main__":
     ap.add_argument("--no-gated", action="store_true", help="without the gated epilogue (mi355q_fused_gate_up = False)")
     ap.add_argument("--vendor-head", action="store_true", help="lm_head on torch's fp32 GEMM (before round 6)")
     ap.add_argument("--no-rotary", action="store_true", help="mi355q_fused_rotary = False")
+    ap.add_argument("--no-attn-out", action="store_true", help="mi355q_fused_attention_output = False")
     a = ap.parse_args()
+    ATTN_OUT = not a.no_attn_out
     ROTARY = not a.no_rotary
     LM_HEAD = "vendor" if a.vendor_head else "split"
     GATED = not a.no_gated
