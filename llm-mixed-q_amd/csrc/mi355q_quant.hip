@@ -941,6 +941,7 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     const bool old = getenv("MI355Q_QROWS_VARIANT") && atoi(getenv("MI355Q_QROWS_VARIANT")) == 0;
     const int qgrid = qgrid_env > 0 ? qgrid_env : (old ? 1024 : 1536);
     if (qgrid > 0 && a.pre_op == 0 && !a.seg_len && grid > qgrid) grid = qgrid;
+    if (qgrid_env > 0 && a.pre_op != 0 && !a.seg_len && grid > qgrid_env) grid = qgrid_env;       // (A/B: rows behind a pre-op take one workgroup each)
     if (grid < 1) grid = 1;
     // segmented rows: the round-5 build; rows with a pre-op in front: its code compiled in; plain rows: the lean build.  16-byte
     // stores where every lane holds a block in every slab (the guarded flavour of that transpose put its scalars in scratch memory)
