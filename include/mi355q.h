@@ -510,7 +510,8 @@ size_t mi355q_bfp_attention_workspace_bytes(int64_t B, int64_t T, int64_t D);
  * <= 64; otherwise as 1).  Returns the previous setting.  For A/B runs and tests. */
 int mi355q_bfp_attention_set_kernel(int which);
 /* Whether the launch in front of the attention kernels (the one that quantises k and v into MFMA fragments) also leaves the quantised
- * Q fragments of the first product, which the kernels then LOAD -- 1 (default): where it pays, head_dim 128, T <= 2048, 64 <= M <= T
+ * Q fragments of the first product, which the kernels then LOAD -- 1 (default): where it pays, T <= 2048, 64 <= M <= T, head_dim 128 or
+ * head_dim 64 with T > 1024
  * (every key-wave of a query group otherwise forms all of the group's Q fragments from q itself: 169 -> 156 us at [32, 2048, 128]);
  * 0: never (before round 6); 2: wherever the fragments fit (head_dim 64 / 128, 64 <= M <= T; tests).  With the rotary embedding
  * (mi355q_bfp_attention_rope) the fragments are always packed.  The same bits either way.  Returns the previous setting (ABI 24). */

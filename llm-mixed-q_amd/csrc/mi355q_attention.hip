@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64 * KW * QG) void bfp_attention_kernel(const Quant
     //      requested before this one is used, and UNCONDITIONALLY (a tile behind the horizon re-reads the last needed one:
     //      an L1 hit): a load inside a branch makes the compiler drain everything in flight at every tile -- one L2 round
     //      trip per tile was 57 % of the kernel.
-    constexpr int G = DC == 1 ? 8 : (DC == 2 ? 4 : 2), NG = NTW / G;
+    // (eight key-waves at head_dim 64: groups of two tiles like head_dim 128 -- 32 registers of prefetch instead of 64, round 6)
+    constexpr int G = DC == 1 ? 8 : (DC == 2 ? ((KW == 8) ? 2 : 4) : 2), NG = NTW / G;
     f32x4 acc[NTW];
     float mx = -INFINITY;
     const long long tlast = need - 1;
@@ -866,17 +867,21 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     if (D > AT_MAX_D || D % 32 != 0 || T % 16 != 0 || (mask && T % 4 != 0)) return MI355Q_E_UNSUPPORTED;
     const bool stream = g_attention_kernel == 2 || ((g_attention_kernel == 0 || g_attention_kernel > 3) && T > AT_MAX_T);
     if (!stream && T > AT_MAX_T) return MI355Q_E_UNSUPPORTED;
+    // Q fragments packed in front of the kernels (attn_pack_q): always with the rotary embedding; without it where it pays -- on the
+    // resident kernels from 64 queries up (the area holds NT tiles a head: M <= T) at head_dim 128, and at head_dim 64 where the
+    // eight-key-wave variant runs (T > 1024: every one of EIGHT waves formed all Q fragments there).  Pack + attention, us, fragments
+    // packed / q quantised in the kernels (profiles/r06_attention_qpack.jsonl, r06_attention_kw8_qf.jsonl): [32, 2048, 128] 156 / 169,
+    // [32, 1024, 128] 64 / 69, [32, 2048, 64] 106 / 117-121, [12, 2048, 64] 51 / 57, [32, 1536, 64] 73 / 80; NOT at head_dim 64 with
+    // four key-waves ([12, 1024, 64] 37 / 35) nor in the streaming kernel, whose waves each own their queries ([32, 4096, 128] 542 / 526).
+    // (The eight-key-wave flavour that loads fragments needed 130 VGPRs -- one workgroup a compute unit instead of two, 134 us -- until
+    //  its K prefetch went from groups of four tiles to groups of two: 122.)
+    // attention_set_qpack(0): never without the rotary embedding (A/B runs, tests); (2): wherever the fragments fit (tests).
+    const bool kw8_auto = !stream && D <= 64 && g_attention_kernel == 0 && T > 1024;
+    const bool qpack = rope_cos || (g_attention_qpack && M >= 64 && M <= T &&
+                                    (g_attention_qpack == 2 ? (D == 64 || D == 128) : (!stream && (D == 128 || (D == 64 && kw8_auto)))));
     // eight key-waves per query group (half the score strip per wave: 127 VGPRs, twice the waves per SIMD) for head_dim <=
     // 64 and long rows: 65 vs 78 us at 12 x 2048 x 64, 135 vs 167 us at 32 x 2048 x 64; no difference at 1024 keys
-    // Q fragments packed in front of the kernels (attn_pack_q): always with the rotary embedding; without it where it pays -- head_dim
-    // 128 on the resident kernel from 64 queries up (the area holds NT tiles a head: M <= T).  Pack + attention, us, fragments packed /
-    // q quantised in the kernels (profiles/r06_attention_qpack.jsonl): [32, 2048, 128] 156 / 169, [32, 1024, 128] 64 / 69; head_dim 64
-    // LOSES ([32, 2048, 64] 134 / 109: the eight-key-wave variant needs 130 VGPRs with the fragment loads -- one workgroup a compute
-    // unit instead of two), and so does the streaming kernel, whose waves each own their queries ([32, 4096, 128] 542 / 526).
-    // attention_set_qpack(0): never without the rotary embedding (A/B runs, tests); (2): wherever the fragments fit (tests).
-    const bool qpack = rope_cos || (g_attention_qpack && M >= 64 && M <= T && (g_attention_qpack == 2 ? (D == 64 || D == 128) : (D == 128 && !stream)));
-    // (with packed fragments the four-key-wave variant: [32, 2048, 64] 117 vs 134 us)
-    const bool kw8 = !stream && D <= 64 && (g_attention_kernel == 3 || (g_attention_kernel == 0 && T > 1024 && !qpack));
+    const bool kw8 = !stream && D <= 64 && (g_attention_kernel == 3 || kw8_auto);
     const int kw = stream ? 1 : (kw8 ? 8 : 4), pg = kw == 8 ? 8 : 4;
     const long long NT = T / 16, NPAIR = ((T + 32 * pg - 1) / (32 * pg)) * pg;
     uint16_t* kf = static_cast<uint16_t*>(workspace);

@@ -1394,8 +1394,8 @@ def attention_set_kernel(which: int) -> int:
 
 
 def attention_set_qpack(on: int) -> int:
-    """1 (default): the pack launch in front of the attention kernels also leaves the quantised Q fragments where that pays (head_dim 128,
-    T <= 2048, 64 <= M <= T); 0: q is always quantised inside the attention kernels (before round 6); 2: fragments wherever they fit
+    """1 (default): the pack launch in front of the attention kernels also leaves the quantised Q fragments where that pays (T <= 2048,
+    64 <= M <= T, head_dim 128 or head_dim 64 with T > 1024); 0: q is always quantised inside the attention kernels (before round 6); 2: fragments wherever they fit
     (head_dim 64 / 128: tests).  The same bits; returns the previous setting."""
     return _lib.load_library().mi355q_bfp_attention_set_qpack(int(on))
 

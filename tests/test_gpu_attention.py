@@ -363,7 +363,7 @@ def test_llama_layer_with_the_rotary_knob_is_the_same_model():
 
 @pytest.mark.parametrize("H,M,T,D,kernel,mode", [(4, 256, 256, 128, 0, "causal"), (3, 512, 512, 64, 0, "mask"), (2, 1536, 1536, 64, 3, "causal"),
                                                  (2, 2048, 2048, 128, 1, "causal"), (2, 2304, 2304, 128, 2, "causal"), (3, 100, 320, 64, 2, "mask"),
-                                                 (2, 72, 256, 128, 1, "causal"), (12, 2048, 2048, 64, 3, "both"), (12, 2048, 2048, 64, 1, "both")])
+                                                 (2, 72, 256, 128, 1, "causal"), (12, 2048, 2048, 64, 3, "both"), (12, 2048, 2048, 64, 1, "both"), (12, 2048, 2048, 64, 0, "causal"), (4, 1536, 1536, 64, 0, "mask")])
 def test_packed_q_fragments_equal_the_in_kernel_quantiser(H, M, T, D, kernel, mode):
     """round 6: the pack launch leaves the quantised Q fragments and the attention kernels load them (ops.attention_set_qpack(2): wherever
     they fit; 1, the default, where it pays) == every key-wave quantising q itself (0): the same block exponents, the same mantissas, so the same output bits --
