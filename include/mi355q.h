@@ -347,6 +347,12 @@ typedef struct mi355q_bfp_operand {
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w,
                             const float* bias, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy,
                             void* stream);
+/* ... with the residual add of the caller's decoder layer in the store (round 6, ABI 24; the bf16 flavour has had it since ABI 22:
+ * mi355q_bf16_gemm_tiled_res): y = (x . w^T + bias) + residual, the two sums rounded one after the other like the separate torch add
+ * (modeling_opt.py:375, modeling_llama.py:259) -- the same bits.  On the ONE-launch route of row-aligned operands only (120-entry
+ * buckets on both sides, K % 128 == 0), else MI355Q_E_UNSUPPORTED (the caller adds).  residual fp32 [M, ldr], ldr % 4 == 0. */
+int mi355q_bfp_gemm_aligned_res(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, const float* residual,
+                                int64_t ldr, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream);
 
 /* ---- W4A4 / W5A5 block_fp Linear on the MX scaled matrix instruction (ABI 21) -------------------------------------------
  * replaces: quantized_modules/linear.py:59-76 (F.linear(x_q, W_q, b_q)) at the widths of

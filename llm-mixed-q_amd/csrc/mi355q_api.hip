@@ -560,7 +560,7 @@ int mi355q_block_fp_quantize_classes(const float* x, const uint16_t* colmap, int
 }
 
 static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
-                            int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
+                            int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream, const float* residual = nullptr, int64_t ldr = 0) {
     if (!x || !w || M < 0 || N < 0 || K < 0 || ldy < N) return MI355Q_E_BADARG;
     if (M == 0 || N == 0) return 0;
     if (!y || (K > 0 && (!x->mant || !x->exp || !w->mant || !w->exp || !x->rowflag || !w->rowflag)))
@@ -583,6 +583,7 @@ static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_opera
         if (!x->gscale || !w->gscale) return MI355Q_E_BADARG;
         if (w->list_cap < 0 || w->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
         a.w_bcap = bucket_cap_of(w->list_cap);          // (before the early return: the kernel below indexes w's buckets)
+        if (residual && x->row_aligned == 2) return MI355Q_E_UNSUPPORTED;      // (the residual add rides the one-launch route's stores only)
         if (x->row_aligned == 2)            // unaligned activations: the blockwise-exact kernel, w's exception blocks per tile
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, nullptr, w->list, 0, 0, st);
         if (x->list_cap < 0 || x->list_cap > ROW_BCAP_MAX) return MI355Q_E_BADARG;
@@ -590,6 +591,9 @@ static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_opera
         // x's exception blocks: in-LDS vectors of the GEMM (120-entry buckets) or the row post-pass (larger buckets)
         a.x_post = a.x_bcap != ROW_BCAP ? 1 : 0;
         const bool fast_ok = x->list && w->list && K % 128 == 0 && K <= MI355Q_ROW_ALIGN_MAX_K && a.w_bcap == ROW_BCAP;
+        if (residual && (variant == 2 || variant == 8 || !fast_ok || a.x_post)) return MI355Q_E_UNSUPPORTED;
+        a.resid = residual;
+        a.ldr = ldr;
         if (variant == 2 || !fast_ok)
             return launch_bfp_gemm_aligned(a, x->rowflag, w->rowflag, x->list, w->list, 0, 0, st);
         if (variant == 8) return launch_bfp_gemm_v8(a, x->gscale, w->gscale, nullptr, nullptr, 0, st);
@@ -610,6 +614,13 @@ static int gemm_aligned_impl(const mi355q_bfp_operand* x, const mi355q_bfp_opera
 int mi355q_bfp_gemm_aligned(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, float* y,
                             int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
     return gemm_aligned_impl(x, w, bias, y, M, N, K, ldy, stream);
+}
+
+int mi355q_bfp_gemm_aligned_res(const mi355q_bfp_operand* x, const mi355q_bfp_operand* w, const float* bias, const float* residual,
+                                int64_t ldr, float* y, int64_t M, int64_t N, int64_t K, int64_t ldy, void* stream) {
+    if (!residual || ldr < N || ldr % 4 != 0) return MI355Q_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(residual) % 16) return MI355Q_E_ALIGN;
+    return gemm_aligned_impl(x, w, bias, y, M, N, K, ldy, stream, residual, ldr);
 }
 
 // y = x . w^T + bias with the contraction in two column classes (mi355q.h): class 0 = K0 values as row-aligned int8 operands with

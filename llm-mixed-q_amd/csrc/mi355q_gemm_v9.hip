@@ -56,6 +56,12 @@
 #ifdef V9_GATED_TU
 #define bfp_gemm_v9 bfp_gemm_v9g
 #endif
+// The int8 product WITH the caller's residual add in its one-pass store epilogue (round 6, mi355q_bfp_gemm_aligned_res) is a fourth unit,
+// mi355q_gemm_v9r.hip = this file with V9_RESID_TU: four lines in that epilogue, which in this unit moved 2 230 hunks of the headline
+// kernel's text (same register count, another allocation) -- so here they are not compiled.
+#ifdef V9_RESID_TU
+#define bfp_gemm_v9 bfp_gemm_v9r
+#endif
 
 namespace mi355q {
 #ifdef V9_GATED_TU
@@ -1200,6 +1206,20 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
                 }
             }
             if (row < a.M) {
+#ifdef V9_RESID_TU
+                if (a.resid) {                                   // (uniform) the caller's residual add, in the store (see V9_RESID_TU)
+                    const float* rr = a.resid + row * a.ldr + n0 + wn * 64 + lq * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = n0 + wn * 64 + j * 16 + lq * 4;
+                        if (col + 3 < Ni) val[j] += *reinterpret_cast<const f32x4*>(rr + j * 16);
+                        else
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (col + r < Ni) val[j][r] += rr[j * 16 + r];
+                    }
+                }
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = n0 + wn * 64 + j * 16 + lq * 4;
@@ -1248,7 +1268,7 @@ __global__ __launch_bounds__(V9_NT, 1) void bfp_gemm_v9(const GemmArgs a_in, con
     }
 }
 
-#if !defined(V9_MIXED_TU) && !defined(V9_GATED_TU)
+#if !defined(V9_MIXED_TU) && !defined(V9_GATED_TU) && !defined(V9_RESID_TU)
 static unsigned long long* g_v9_stamps = nullptr;       // diagnostic (tools/dbg/v9_stamps.py): where the stamps build writes
 #endif
 
@@ -1277,9 +1297,20 @@ int launch_bfp_gemm_v9_mixed(const GemmArgs& a, const float* sx, const float* sw
     return (int)hipGetLastError();
 }
 
+#elif defined(V9_RESID_TU)
+// the row-scale int8 product with exception lists and a.resid set: the shipping kernel + the residual add in its one-pass stores
+int launch_bfp_gemm_v9_resid(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist,
+                             hipStream_t st, const uint8_t* xf, const uint8_t* wf) {
+    if (!xlist || !wlist || !xf || !wf || !a.resid) return MI355Q_E_BADARG;
+    const unsigned tiles = (unsigned)((a.M + 255) / 256 * ((a.N + 255) / 256));
+    const unsigned grid = tiles * (a.ngroup > 1 ? a.ngroup : 1) * (a.splits > 1 ? a.splits : 1);
+    hipLaunchKernelGGL((bfp_gemm_v9<1, false, false>), grid, V9_NT, 0, st, a, sx, sw, xlist, wlist, xf, wf);
+    return (int)hipGetLastError();
+}
 #else
 int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, const int* xlist, const int* wlist,
                        hipStream_t st, const uint8_t* xf, const uint8_t* wf, bool bf16) {
+    if (a_in.resid && !bf16 && xlist && wlist) return launch_bfp_gemm_v9_resid(a_in, sx, sw, xlist, wlist, st, xf, wf);
     GemmArgs a = a_in;
     // (stamps build: while a buffer is registered through mi355q_debug_v9_stamps -- bench.py's `roofline.loop_clock_GHz`,
     //  tools/dbg/v9_stamps.py; no stamp executes in the kernel every other launch runs)
@@ -1299,7 +1330,7 @@ int launch_bfp_gemm_v9(const GemmArgs& a_in, const float* sx, const float* sw, c
 
 }  // namespace mi355q
 
-#if !defined(V9_MIXED_TU) && !defined(V9_GATED_TU)
+#if !defined(V9_MIXED_TU) && !defined(V9_GATED_TU) && !defined(V9_RESID_TU)
 // diagnostic hook, not part of include/mi355q.h: the buffer ([workgroups][2][8] 64-bit words) the MI355Q_V9_STAMPS build fills
 extern "C" __attribute__((visibility("default"))) void mi355q_debug_v9_stamps(void* buf) { mi355q::g_v9_stamps = static_cast<unsigned long long*>(buf); }
 #endif

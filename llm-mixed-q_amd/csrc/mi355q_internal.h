@@ -139,6 +139,8 @@ int launch_bfp_gemm_v9_mixed(const GemmArgs& a, const float* sx, const float* sw
                              const uint8_t* xf, const uint8_t* wf);
 int launch_bfp_gemm_v9_gated(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                              const uint8_t* xf, const uint8_t* wf);
+int launch_bfp_gemm_v9_resid(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
+                             const uint8_t* xf, const uint8_t* wf);
 int launch_bfp_pack_bits(const int8_t* mant, uint16_t* out, long long rows, long long K, int width, hipStream_t st);
 int launch_bfp_expand(int mode, const uint16_t* packed, const uint8_t* codes, void* out, long long rows, long long K, int width,
                       int off, hipStream_t st, const uint8_t* rowexp = nullptr, uint8_t* exp_out = nullptr);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mi355q_stream_capture_id": (C.c_uint64, [_vp]),
     "mi355q_rope_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi355q_bfp_gemm_aligned": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "mi355q_bfp_gemm_aligned_res": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_bfp_gemm_aligned_multi": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp]),
     "mi355q_block_fp_quantize_classes": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mi355q_bfp_gemm_aligned_gated": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),

@@ -997,8 +997,10 @@ def block_fp_quantize_classes(x: torch.Tensor, classes: ColumnClasses, width: in
     return x0, buf["x1"]
 
 
-def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None):
-    """bfp_gemm on operands rewritten by bfp_align."""
+def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch.Tensor = None, residual: torch.Tensor = None):
+    """bfp_gemm on operands rewritten by bfp_align.  `residual` [M, N] fp32: y = (x . w^T + bias) + residual -- in the product's stores
+    on the one-launch route of row-aligned operands (mi355q_bfp_gemm_aligned_res: the same bits as the separate add), as a torch add
+    behind the product elsewhere."""
     M, K, N = x.rows, x.K, w.rows
     assert w.K == K
     given = out is not None
@@ -1009,9 +1011,19 @@ def bfp_gemm_aligned(x: AlignedOperand, w: AlignedOperand, bias=None, out: torch
     lib = _lib.load_library()
     sp = _stream_ptr(x.tiled.device)
     x.c_struct(), w.c_struct()
+    rc = _lib.E_UNSUPPORTED
     with _on_device(x.tiled.device):
-        rc = lib.mi355q_bfp_gemm_aligned(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(out), M, N, K, ldy, sp)
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1 and residual.device == out.device
+            if residual.stride(0) % 4 == 0 and residual.data_ptr() % 16 == 0:
+                rc = lib.mi355q_bfp_gemm_aligned_res(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(residual),
+                                                     residual.stride(0) if M > 1 else max(N, residual.stride(0)), _ptr(out), M, N, K, ldy, sp)
+        fused = rc != _lib.E_UNSUPPORTED
+        if not fused:
+            rc = lib.mi355q_bfp_gemm_aligned(x._cs_addr, w._cs_addr, _ptr(bias), _ptr(out), M, N, K, ldy, sp)
     _lib.check(rc, "mi355q_bfp_gemm_aligned")
+    if residual is not None and not fused:
+        out.add_(residual)
     if given:
         _wrote_into(out)
     return out

@@ -743,11 +743,18 @@ class _LinearBase(nn.Linear):
         """can `residual + self(x)` run as one launch?  (the per-block-exponent route's product adds it in its stores)"""
         return (residual is not None and self.is_ptq and not self.bypass and not self.weight_requires_quantisation
                 and self._pending_flavour is None and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
-                and self._packed_is_current() and self._uses_bf16_route() and self._int8_plan(x) is not None
+                and self._packed_is_current() and self._int8_plan(x) is not None
+                and (self._uses_bf16_route() or self._residual_rides_the_int8_product())
                 and residual.dtype == torch.float32 and residual.device == x.device
                 and tuple(residual.shape) == tuple(x.shape[:-1]) + (self.out_features,) and residual.is_contiguous()
                 and self.out_features % 4 == 0 and residual.data_ptr() % 16 == 0
                 and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)))
+
+    def _residual_rides_the_int8_product(self) -> bool:
+        """the row-scale int8 route in its one-launch form (ops.bfp_gemm_aligned(residual=...), round 6): 120-entry activation buckets,
+        K a multiple of 128, not the mixed contraction; dense input (a ShardedRows input keeps the separate add)"""
+        return (self._align_mode == "rows" and self._mixed is None and self._x_cap == ops.ROW_BUCKET_CAP and self.in_features % 128 == 0
+                and self._packed is not None)
 
     def _residual_operand_ok(self, residual, lead) -> bool:
         """`residual` can ride in the bf16 product's stores (mi355q_bf16_gemm_tiled_res): fp32, contiguous, [.., out_features]"""
@@ -817,13 +824,14 @@ class _LinearBase(nn.Linear):
             return y.reshape(*x.shape[:-1], self.out_features)
         if self._mixed is not None and self._mixed["version"] == (self.weight._version, None if self.bias is None else self.bias._version):
             return self._forward_mixed(x, x2, segments, pre, residual)
-        assert residual is None, "the residual add is fused on the per-block-exponent route only"
+        assert residual is None or not segments, "a residual behind a segmented input: the caller adds"
         # one fused kernel: quantise + pack + row-align + tile
         xa = ops.block_fp_quantize_aligned_rows(x2, c["data_in_width"], c["data_in_exponent_width"],
                                                 c["data_in_exponent_bias"], bucket_cap=self._x_cap, pre=pre,
                                                 segments=segments)
         wa = self._w_packed.expand() if self._w_packed is not None else self._packed[0]
-        y = ops.bfp_gemm_aligned(xa, wa, self.bias, out=self._take_out(x2.shape[0]))
+        y = ops.bfp_gemm_aligned(xa, wa, self.bias, out=self._take_out(x2.shape[0]),
+                                 residual=None if residual is None else residual.reshape(-1, self.out_features))
         if self.align == "auto" and self._x_cap != ops.ROW_NO_ALIGN:
             # results never depend on the mode (an overflowing exception bucket only sends the GEMM to its slow
             # blockwise kernel); look at the overflow word on a doubling schedule and leave row mode if it repeats

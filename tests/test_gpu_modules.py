@@ -1211,8 +1211,8 @@ def test_grouped_linear_on_the_per_block_route(M, K, Ns, with_norm):
 @pytest.mark.parametrize("after", [None, "relu", "silu_mul"])
 def test_linear_with_the_residual_add_in_its_stores(M, K, N, after):
     """residual + layer(x) (the add a decoder layer puts behind o_proj / fc2 / down_proj) as ONE launch on the per-block-exponent
-    route (mi355q_bf16_gemm_tiled_res): the same bits as the two steps -- F.linear's result rounded, then the add --; on the
-    row-scale route forward_residual is the two steps"""
+    route (mi355q_bf16_gemm_tiled_res) and, since round 6, on the row-scale int8 route's one-launch form
+    (mi355q_bfp_gemm_aligned_res): the same bits as the two steps -- the product's result rounded, then the add"""
     import torch
     import mi355q.quantize as Q
     from mi355q import ops
@@ -1229,13 +1229,17 @@ def test_linear_with_the_residual_add_in_its_stores(M, K, N, after):
             lin(pre(x))                                         # first PTQ forward
             want = res + (lin(x) if after is None else lin.forward_after(x, after, other))
             calls, real = [], ops.bf16_gemm_tiled
+            calls8, real8 = [], ops.bfp_gemm_aligned
             ops.bf16_gemm_tiled = lambda *a, **k: (calls.append(k.get("residual") is not None), real(*a, **k))[1]
+            ops.bfp_gemm_aligned = lambda *a, **k: (calls8.append(k.get("residual") is not None), real8(*a, **k))[1]
             try:
                 got = lin.forward_residual(x, res) if after is None else lin.forward_after(x, after, other, residual=res)
             finally:
-                ops.bf16_gemm_tiled = real
+                ops.bf16_gemm_tiled, ops.bfp_gemm_aligned = real, real8
         if align == "blocks":
             assert torch.equal(got, want)
+        elif after is None:
+            assert calls8 == [True] and torch.equal(got, want)          # (plain inputs fit their buckets: the add rode the int8 product's stores)
         else:
             # (post-ReLU inputs forced onto the row-scale route overflow their exception buckets: the launch's blockwise fallback adds
             #  back with fp32 atomics whose order is not fixed -- DESIGN 2 "Reproducibility" -- so two launches agree to the last bits only)
