@@ -552,9 +552,12 @@ int mi355q_bfp_attention_rope(const float* q, const float* k, const float* v, co
  * kernels quantise there (consumer_params = the consumer's data_in {width, exponent width, exponent bias}) and write the tiled bf16 operand
  * [M, B x D] (head order; mi355q_bfp_tiled_bytes(M, 2 B D) bytes; ONE batch element: B = heads) that mi355q_bf16_gemm_tiled(_res) reads:
  * bit for bit what the separate quantiser makes of the fp32 output, which is never written (`out` may be NULL then).  cos == NULL: no
- * rotary embedding; out_bf16_tiled == NULL: = mi355q_bfp_attention_rope. */
-int mi355q_bfp_attention_fused(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
-                               float* out, void* out_bf16_tiled, const int32_t* consumer_params, void* workspace, int64_t B, int64_t M,
+ * rotary embedding; out_bf16_tiled == NULL: = mi355q_bfp_attention_rope.
+ * q_scale != 0: q is multiplied by it on its way into the Q fragments -- OPT's `self.q_proj(hidden_states) * self.scaling`
+ * (modeling_opt.py:231), one fp32 multiply like the torch kernel that otherwise writes the scaled q: the same bits, 8 B per element of q
+ * less through memory.  Served by the pack launch: head_dim 64 / 128, M <= T, no rotary embedding, else MI355Q_E_UNSUPPORTED. */
+int mi355q_bfp_attention_fused(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float q_scale,
+                               float scale_div, float* out, void* out_bf16_tiled, const int32_t* consumer_params, void* workspace, int64_t B, int64_t M,
                                int64_t T, int64_t D, const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides,
                                const float* cos, const float* sin, const int64_t* position_ids, int64_t table_rows, int32_t heads,
                                void* stream);

@@ -903,12 +903,12 @@ int mi355q_bfp_attention_rope(const float* q, const float* k, const float* v, co
                               float* out, void* workspace, int64_t B, int64_t M, int64_t T, int64_t D, const int32_t* qk_params,
                               const int32_t* pv_params, const int64_t* strides, const float* cos, const float* sin,
                               const int64_t* position_ids, int64_t table_rows, int32_t heads, void* stream) {
-    return mi355q_bfp_attention_fused(q, k, v, mask, causal, scale_div, out, nullptr, nullptr, workspace, B, M, T, D, qk_params, pv_params,
+    return mi355q_bfp_attention_fused(q, k, v, mask, causal, 0.f, scale_div, out, nullptr, nullptr, workspace, B, M, T, D, qk_params, pv_params,
                                       strides, cos, sin, position_ids, table_rows, heads, stream);
 }
 
-int mi355q_bfp_attention_fused(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float scale_div,
-                               float* out, void* out_bf16_tiled, const int32_t* consumer_params, void* workspace, int64_t B, int64_t M,
+int mi355q_bfp_attention_fused(const float* q, const float* k, const float* v, const float* mask, int32_t causal, float q_scale,
+                               float scale_div, float* out, void* out_bf16_tiled, const int32_t* consumer_params, void* workspace, int64_t B, int64_t M,
                                int64_t T, int64_t D, const int32_t* qk_params, const int32_t* pv_params, const int64_t* strides,
                                const float* cos, const float* sin, const int64_t* position_ids, int64_t table_rows, int32_t heads,
                                void* stream) {
@@ -963,7 +963,7 @@ int mi355q_bfp_attention_fused(const float* q, const float* k, const float* v, c
     return launch_bfp_attention(a[0], a[1], a[2], a[3], q, k, v, mask, out, workspace, B, M, T, D, causal ? T - M : -1,
                                 scale_div, static_cast<hipStream_t>(stream), strides ? st6 : nullptr, cos, sin,
                                 reinterpret_cast<const long long*>(position_ids), table_rows, heads, static_cast<uint16_t*>(out_bf16_tiled),
-                                out_bf16_tiled ? &ao : nullptr);
+                                out_bf16_tiled ? &ao : nullptr, q_scale);
 }
 
 // block_minifloat (fmt 1) / block_log (fmt 2) products: the same two kernels with the other quantisers' block parameters

@@ -263,7 +263,8 @@ __device__ __forceinline__ void attn_pack_v(const QuantArgs& a, const Lut& lut, 
 // sixteen consecutive threads are sixteen consecutive queries, so each of a thread's two 16-byte stores lies in a 256-byte run.
 template <bool ROPE>
 __device__ __forceinline__ void attn_pack_q(const QuantArgs& a, const Lut& lut, const float* __restrict__ q, uint16_t* __restrict__ qf,
-                                            long long M, int D, long long NQT, long long bx, long long sb, long long sm, const RopeIn& rope) {
+                                            long long M, int D, long long NQT, long long bx, long long sb, long long sm, const RopeIn& rope,
+                                            float qscale) {
     const int tid = threadIdx.x, nblk = D >> 4, QPW = 256 / nblk;          // queries per workgroup: 32 at head_dim 128, 64 at 64
     const int qi = tid % QPW, blk = tid / QPW;
     const long long b = blockIdx.y, query = bx * QPW + qi;
@@ -278,6 +279,12 @@ __device__ __forceinline__ void attn_pack_q(const QuantArgs& a, const Lut& lut, 
         for (int i = 0; i < 4; ++i) {
             const float4 xv = x4[i];
             x[4 * i] = xv.x; x[4 * i + 1] = xv.y; x[4 * i + 2] = xv.z; x[4 * i + 3] = xv.w;
+        }
+        // (OPT scales q by head_dim^-0.5 between q_proj and the first product, modeling_opt.py:231: one fp32 multiply, the same bits as
+        //  the torch kernel that wrote q * scaling to memory)
+        if (qscale != 0.f) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] *= qscale;
         }
     }
     if (ROPE && query < M) {
@@ -326,13 +333,13 @@ __global__ __launch_bounds__(256) void attn_pack_kv_kernel(const QuantArgs ak, c
                                                            long long NPAIR, int kblocks, long long ksb, long long kst,
                                                            long long vsb, long long vst, int kw, const RopeIn rope, const QuantArgs aq,
                                                            const float* __restrict__ q, uint16_t* __restrict__ qf, int vblocks,
-                                                           long long qsb, long long qsm, long long M) {
+                                                           long long qsb, long long qsm, long long M, float qscale) {
     __shared__ Lut lut;
     __shared__ __attribute__((aligned(16))) uint16_t buf[AT_MAX_D / 16 * 4 * 512];
     load_lut<FMT_BFP, true>(lut);
     if ((int)blockIdx.x < kblocks) attn_pack_k<ROPE>(ak, lut, buf, k, kf, T, D, NT, blockIdx.x, ksb, kst, rope);
     else if ((int)blockIdx.x < kblocks + vblocks) attn_pack_v(av, lut, buf, v, vf, T, D, NPAIR, (long long)blockIdx.x - kblocks, vsb, vst, kw);
-    else attn_pack_q<ROPE>(aq, lut, q, qf, M, D, NT, (long long)blockIdx.x - kblocks - vblocks, qsb, qsm, rope);
+    else attn_pack_q<ROPE>(aq, lut, q, qf, M, D, NT, (long long)blockIdx.x - kblocks - vblocks, qsb, qsm, rope, qscale);
 }
 
 // ---- the consumer's operand in the store epilogue (round 6) -----------------------------------------------------------
@@ -853,7 +860,9 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                          const float* k, const float* v, const float* mask, float* out, void* workspace, long long B,
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
                          const long long* strides, const float* rope_cos, const float* rope_sin, const long long* rope_pos,
-                         long long rope_rows, int rope_heads, uint16_t* out_tiled, const QuantArgs* ao) {
+                         long long rope_rows, int rope_heads, uint16_t* out_tiled, const QuantArgs* ao, float q_scale) {
+    // (q_scale: q multiplied on its way into the Q fragments -- served by the pack launch only, so the fragments must be packable)
+    if (q_scale != 0.f && (rope_cos || (D != 64 && D != 128) || M > T)) return MI355Q_E_UNSUPPORTED;
     // (the consumer's operand: rows = queries, columns = head x D in head order -- B is the head count of ONE batch element)
     if (out_tiled && (!ao || (B * D) % 32 != 0)) return MI355Q_E_BADARG;
     if (out_tiled && (mask || (D != 64 && D != 128))) return MI355Q_E_UNSUPPORTED;        // (the flavours that are built: OT above)
@@ -877,7 +886,7 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     //  its K prefetch went from groups of four tiles to groups of two: 122.)
     // attention_set_qpack(0): never without the rotary embedding (A/B runs, tests); (2): wherever the fragments fit (tests).
     const bool kw8_auto = !stream && D <= 64 && g_attention_kernel == 0 && T > 1024;
-    const bool qpack = rope_cos || (g_attention_qpack && M >= 64 && M <= T &&
+    const bool qpack = rope_cos || q_scale != 0.f || (g_attention_qpack && M >= 64 && M <= T &&
                                     (g_attention_qpack == 2 ? (D == 64 || D == 128) : (!stream && (D == 128 || (D == 64 && kw8_auto)))));
     // eight key-waves per query group (half the score strip per wave: 127 VGPRs, twice the waves per SIMD) for head_dim <=
     // 64 and long rows: 65 vs 78 us at 12 x 2048 x 64, 135 vs 167 us at 32 x 2048 x 64; no difference at 1024 keys
@@ -898,10 +907,10 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
     const int vblocks = (int)(NPAIR / pg), qpw = 256 / (int)(D / 16), qblocks = qpack ? (int)(((M + 15) / 16 * 16 + qpw - 1) / qpw) : 0;
     if (rope_cos)
         hipLaunchKernelGGL(attn_pack_kv_kernel<true>, dim3((unsigned)(kblocks + vblocks + qblocks), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf,
-                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm, M);
+                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm, M, q_scale);
     else
         hipLaunchKernelGGL(attn_pack_kv_kernel<false>, dim3((unsigned)(kblocks + vblocks + qblocks), (unsigned)B), 256, 0, st, ak, av, k, v, kf, vf,
-                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm, M);
+                           T, (int)D, NT, NPAIR, kblocks, ksb, kst, vsb, vst, kw, rope, aq, q, qfrag, vblocks, qsb, qsm, M, q_scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     AttnArgs g{q, kf, vf, mask, out, M, T, NT, NPAIR, causal_off, scale_div, (int)D, qsb, qsm, osb, osm, g_attn_stamps, 0, 0, qpack ? qfrag : nullptr, cons};

@@ -59,7 +59,7 @@ int launch_bfp_attention(const QuantArgs& aq, const QuantArgs& ak, const QuantAr
                          long long M, long long T, long long D, long long causal_off, float scale_div, hipStream_t st,
                          const long long* strides = nullptr, const float* rope_cos = nullptr, const float* rope_sin = nullptr,
                          const long long* rope_pos = nullptr, long long rope_rows = 0, int rope_heads = 1, uint16_t* out_tiled = nullptr,
-                         const QuantArgs* ao = nullptr);
+                         const QuantArgs* ao = nullptr, float q_scale = 0.f);
 struct RopeArgs {
     const float* x[2];          // q, k
     float* y[2];

@@ -67,7 +67,7 @@ SIGNATURES = {
     "mi355q_bfp_attention_strided": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mi355q_bfp_attention_rope": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _i64, _i32, _vp]),
-    "mi355q_bfp_attention_fused": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+    "mi355q_bfp_attention_fused": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                              _vp, _i64, _i32, _vp]),
     "mi355q_stream_capture_id": (C.c_uint64, [_vp]),
     "mi355q_rope_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),

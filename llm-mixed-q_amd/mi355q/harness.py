@@ -92,8 +92,9 @@ class _Attention(nn.Module):
                 qp, kp, vp = grouped_linear(x, (self.q_proj, self.k_proj, self.v_proj), norm=norm)
             else:
                 qp, kp, vp = self.q_proj(x), self.k_proj(x), self.v_proj(x)
-            o = get_quantized_func("attention", c1)(heads(qp * self.scaling), heads(kp), heads(vp), self.qc["bmm_0"], c1,
-                                                    causal=True, consumer=_attention_consumer(c1, self.out_proj, hs, B))
+            # (q * scaling, modeling_opt.py:231: formed where the attention pass packs its Q fragments -- q_scale)
+            o = get_quantized_func("attention", c1)(heads(qp), heads(kp), heads(vp), self.qc["bmm_0"], c1, causal=True,
+                                                    q_scale=self.scaling, consumer=_attention_consumer(c1, self.out_proj, hs, B))
             return _project_attention_output(o, self.out_proj, out, B, T, nh * self.hd, residual)
         q = shape(self.q_proj(x) * self.scaling)
         k, v = shape(self.k_proj(x)), shape(self.v_proj(x))

@@ -1313,7 +1313,8 @@ def bfp_attention_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, w
 
 
 def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, pv_params, *, mask: torch.Tensor = None,
-                  causal: bool = False, scale_div: float = None, token_major: bool = False, rope=None, consumer=None):
+                  causal: bool = False, scale_div: float = None, token_major: bool = False, rope=None, consumer=None,
+                  q_scale: float = None):
     """out[b] = Qc(softmax(max(Qa(q[b]) @ Qb(k[b]^T) [/ scale_div] + mask, finfo.min))) @ Qd(v[b]) for q [..., M, D], k and v
     [..., T, D] fp32 (k untransposed; strided head views are read in place), block_fp [1,16] blocks along each operand's
     last dim as the reference's two products apply them (matmul.py:146-196); neither scores nor probabilities are
@@ -1327,9 +1328,12 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
     `consumer` = (width, exponent width, exponent bias) of the out-projection's data_in quantiser, q [1, H, M, D], no mask: the result is
     NOT an fp32 tensor but `TiledBf16` -- that Linear's quantised activations [M, H D] as the tiled bf16 operand of its per-block
     product, written by the kernels' store epilogue (bfp_attention_consumer_supported; the same bits as block_fp_quantize_bf16_tiled
-    of the fp32 output, which is never written)."""
+    of the fp32 output, which is never written).
+    `q_scale`: q * q_scale (OPT's `q_proj(x) * scaling`, modeling_opt.py:231) formed as the Q fragments are packed instead of by a torch
+    kernel in front (bfp_attention_q_scale_supported; the same bits)."""
     import ctypes
     _require_device(q, "bfp_attention")
+    assert not q_scale or bfp_attention_q_scale_supported(q, k, rope)
     assert bfp_attention_supported(q, k, v, (qk_params[0], qk_params[3], pv_params[0], pv_params[3]))
     M, D = q.shape[-2:]
     T = k.shape[-2]
@@ -1368,7 +1372,7 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
         assert bfp_attention_rope_supported(q, k, cos_q, sin_q, pos)
         rows, heads = cos_q.shape[0], q.shape[1]
     with _on_device(q.device):
-        rc = lib.mi355q_bfp_attention_fused(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)),
+        rc = lib.mi355q_bfp_attention_fused(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(mask), int(bool(causal)), float(q_scale) if q_scale else 0.0,
                                             float(scale_div) if scale_div else 0.0, _ptr(out), _ptr(tiled), ctypes.addressof(pc) if pc else None,
                                             _ptr(ws), B, M, T, D, ctypes.addressof(pa), ctypes.addressof(pb), ctypes.addressof(strides),
                                             _ptr(cos_q), _ptr(sin_q), _ptr(pos), rows, max(1, heads), sp)
@@ -1382,6 +1386,11 @@ class TiledBf16:
 
     def __init__(self, buf: torch.Tensor, rows: int, cols: int):
         self.buf, self.rows, self.cols = buf, int(rows), int(cols)
+
+
+def bfp_attention_q_scale_supported(q, k, rope=None) -> bool:
+    """what q_scale takes (mi355q_bfp_attention_fused): head_dim 64 / 128, no more queries than keys, no rotary embedding"""
+    return rope is None and q.shape[-1] in (64, 128) and q.shape[-2] <= k.shape[-2]
 
 
 def bfp_attention_consumer_supported(q, mask) -> bool:

@@ -169,7 +169,7 @@ def _make_softmax(style, arith="block_fp"):
     return f
 
 
-def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, scale_div=None, rope=None, consumer=None):
+def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, scale_div=None, rope=None, consumer=None, q_scale=None):
     """The reference's quantised attention core as one call (modeling_opt.py:246-312, modeling_llama.py:309-344):
 
         w = bmm_0(q, k^T)  [w = w / scale_div]  w = max(w + mask, finfo.min)  p = softmax(w, -1)  out = bmm_1(p, v)
@@ -187,7 +187,9 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
     never written); wherever that does not apply, the registry's rotary function runs first -- the same values either way.
     `consumer` = (width, exponent width, exponent bias) of the out-projection's data_in block_fp quantiser: where the HIP pass can
     (one batch element, head_dim 64 / 128, no additive mask) the result is `ops.TiledBf16` -- that Linear's quantised activations
-    [T_q, heads x hd], for `Linear.forward_tiled` -- instead of the fp32 tensor; the caller checks which it got."""
+    [T_q, heads x hd], for `Linear.forward_tiled` -- instead of the fp32 tensor; the caller checks which it got.
+    `q_scale`: the core runs on q * q_scale (OPT: `self.q_proj(hidden_states) * self.scaling`, modeling_opt.py:231) -- multiplied where
+    the HIP pass packs its Q fragments, by a torch kernel in front everywhere else: the same values."""
     from ... import ops
     if rope is not None:
         cos, sin, position_ids, rope_config = rope
@@ -211,6 +213,9 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
         if blocks_ok and ops.bfp_attention_supported(q, k, v, widths) and (not causal or tk >= tq):
             par = lambda c: (c["data_in_width"], c["data_in_exponent_width"], c["data_in_exponent_bias"], c["weight_width"],
                              c["weight_exponent_width"], c["weight_exponent_bias"])
+            qs = q_scale if q_scale and rope is None and ops.bfp_attention_q_scale_supported(q, k) else None
+            if q_scale and qs is None:
+                q, q_scale = q * q_scale, None
             rope_in = None
             if rope is not None:
                 cos_q, sin_q = rope_tables(cos, sin, rope_config)
@@ -222,7 +227,10 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
             return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=m2,
                                      causal=causal, scale_div=scale_div,
                                      token_major=bool(config_pv.get("mi355q_token_major_output", False)), rope=rope_in,
-                                     consumer=consumer if consumer is not None and ops.bfp_attention_consumer_supported(q, m2) else None)
+                                     consumer=consumer if consumer is not None and ops.bfp_attention_consumer_supported(q, m2) else None,
+                                     q_scale=qs)
+    if q_scale:
+        q = q * q_scale
     if rope is not None:
         q, k = rope_fn(q, k, cos, sin, position_ids, config=rope_config)
     style = "bmm" if q.ndim == 3 else "matmul"

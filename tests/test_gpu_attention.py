@@ -463,3 +463,24 @@ def test_model_with_the_attention_output_knob_is_the_same_model(family):
             proj = model.layers[0].self_attn.o_proj if family == "llama" else model.layers[0].self_attn.out_proj
             assert proj.accepts_tiled_input()
         assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][1]) == float(outs[1][1]), (family, fres)
+
+
+@pytest.mark.parametrize("H,M,T,D,kernel,scale", [(12, 512, 512, 64, 0, 0.125), (8, 2048, 2048, 64, 0, 0.125), (4, 1024, 1024, 128, 1, 128 ** -0.5),
+                                                  (2, 2304, 2304, 128, 2, 128 ** -0.5), (3, 100, 320, 64, 3, 0.3), (2, 48, 256, 64, 0, 0.125)])
+def test_q_scale_in_the_fragment_pack_is_the_torch_multiply(H, M, T, D, kernel, scale):
+    """OPT's q_proj(x) * scaling (modeling_opt.py:231) formed where the Q fragments are packed (q_scale) == the torch multiply in front of
+    the pass: one fp32 multiply either way -- powers of two and not, fewer than 64 queries (the fragments are packed regardless)"""
+    import torch
+    from mi355q import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + M + D)
+    q = (torch.randn(1, M, H, D, generator=g) * 3).to(dev).transpose(1, 2)
+    k, v = (torch.randn(1, T, H, D, generator=g).to(dev).transpose(1, 2) for _ in range(2))
+    par = (6, 8, 127, 6, 8, 127)
+    prev = ops.attention_set_kernel(kernel)
+    try:
+        want = ops.bfp_attention(q * scale, k, v, par, par, causal=True, token_major=True)
+        got = ops.bfp_attention(q, k, v, par, par, causal=True, token_major=True, q_scale=scale)
+    finally:
+        ops.attention_set_kernel(prev)
+    assert torch.equal(got, want)
