@@ -1009,7 +1009,10 @@ def fp32_linear(x, linear: nn.Linear, mode: str = "split"):
     if not ok:
         ops.count_vendor_gemm("fp32_linear (unquantised layer, vendor fp32 GEMM)")
         return F.linear(x, w, linear.bias)
-    key = (w.data_ptr(), w._version, str(w.device))
+    try:
+        key = (w.data_ptr(), w._version, str(w.device))
+    except RuntimeError:                      # (inference-mode tensors have no version counter: keyed by storage alone)
+        key = (w.data_ptr(), None, str(w.device))
     cached = linear.__dict__.get("_mi355q_split_weight")
     if cached is None or cached[0] != key:
         with torch.no_grad():
