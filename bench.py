@@ -145,7 +145,8 @@ def config3_summary(torch):
     except ValueError as e:
         return {"error": repr(e)[:200]}
     keep = ("layers", "tokens", "loss", "ms_per_forward_eager", "tokens_per_s_eager", "ms_per_forward_graph", "tokens_per_s_graph",
-            "graph_equals_eager", "resident_GiB_after_packing", "peak_GiB", "linear_routes", "vendor_gemm_calls_per_forward")
+            "graph_equals_eager", "resident_GiB_after_packing", "peak_GiB", "linear_routes", "vendor_gemm_calls_per_forward",
+            "lm_head", "gated_mlp", "rotary_on_load", "attention_writes_o_proj_operand")
     out = {"what": "Llama-7B shape, 32 layers, W6A6 block_fp [1,16], B = 1, T = 2048, seeded random weights, every knob on "
                    "(child process: tools/config3_full_depth.py)"}
     out.update({k: r[k] for k in keep if k in r})
