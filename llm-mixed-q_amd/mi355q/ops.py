@@ -1343,10 +1343,10 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
     B = q3.shape[0]
     if token_major and q.ndim == 4 and q.shape[0] == 1:
         H = q.shape[1]
-        out = torch.empty(1, M, H, D, dtype=torch.float32, device=q.device).permute(0, 2, 1, 3)
+        out = None if consumer is not None else torch.empty(1, M, H, D, dtype=torch.float32, device=q.device).permute(0, 2, 1, 3)
         osb, osm = D, H * D
     else:
-        out = torch.empty(*q.shape, dtype=torch.float32, device=q.device)
+        out = None if consumer is not None else torch.empty(*q.shape, dtype=torch.float32, device=q.device)
         osb, osm = M * D, D
     lib = _lib.load_library()
     tiled = pc = None
@@ -1354,7 +1354,6 @@ def bfp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, qk_params, 
         assert bfp_attention_consumer_supported(q, mask)
         tiled = torch.empty(lib.mi355q_bfp_tiled_bytes(M, 2 * B * D), dtype=torch.int8, device=q.device)
         pc = (ctypes.c_int32 * 3)(int(consumer[0]), int(consumer[1]), _default_bias(consumer[2]))
-        out = None
     sp = _stream_ptr(q.device)
     key = (q.device.index, sp, B, T, D)
     ws = _ATTN_WS.get(key)

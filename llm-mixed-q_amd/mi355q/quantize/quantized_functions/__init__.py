@@ -218,10 +218,11 @@ def attention_block_fp(q, k, v, config_qk, config_pv, mask=None, causal=False, s
                 q, q_scale = q * q_scale, None
             rope_in = None
             if rope is not None:
-                cos_q, sin_q = rope_tables(cos, sin, rope_config)
+                cos_q, sin_q = (t.contiguous() for t in rope_tables(cos, sin, rope_config))
+                pos_c = position_ids.contiguous()
                 if (not (torch.is_grad_enabled() and (cos_q.requires_grad or sin_q.requires_grad))
-                        and ops.bfp_attention_rope_supported(q, k, cos_q.contiguous(), sin_q.contiguous(), position_ids.contiguous())):
-                    rope_in = (cos_q.contiguous(), sin_q.contiguous(), position_ids.contiguous())
+                        and ops.bfp_attention_rope_supported(q, k, cos_q, sin_q, pos_c)):
+                    rope_in = (cos_q, sin_q, pos_c)
                 else:
                     q, k = rope_fn(q, k, cos, sin, position_ids, config=rope_config)
             return ops.bfp_attention(q, k, v, par(config_qk), par(config_pv), mask=m2,
