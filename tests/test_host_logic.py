@@ -245,6 +245,50 @@ def test_pre_op_entry_points_validate_without_a_gpu():
     assert lib.mi355q_block_fp_quantize_bf16_tiled_pre(p, None, 1, None, p, 0, 64, 6, 8, 127, p, None) == 0       # nothing to do
 
 
+def test_round6_entry_points_validate_without_a_gpu():
+    """the entry points of ABI 24 reject what they do not take before anything is launched (include/mi355q.h): the split-bf16 operand
+    builder, the fused attention pass, the int8 product with a residual"""
+    import ctypes
+    from mi355q import _lib
+    lib = _lib.load_library()
+    BAD, UNS, ALIGN = _lib.E_BADARG, _lib.E_UNSUPPORTED, _lib.E_ALIGN
+    p = 1 << 20
+    assert lib.mi355q_abi_version() == _lib.ABI_VERSION >= 24
+    # mi355q_fp32_split_tile(x, y, rows, K, role, stream)
+    assert lib.mi355q_fp32_split_tile(p, p, 4, 64, 2, None) == BAD                  # roles are 0 (left) and 1 (right)
+    assert lib.mi355q_fp32_split_tile(None, p, 4, 64, 0, None) == BAD
+    assert lib.mi355q_fp32_split_tile(p, p, 4, 48, 0, None) == UNS                  # K % 32
+    assert lib.mi355q_fp32_split_tile(p + 4, p, 4, 64, 0, None) == ALIGN
+    assert lib.mi355q_fp32_split_tile(p, p, 0, 64, 0, None) == 0                    # nothing to do
+    # mi355q_bfp_gemm_aligned_res(x, w, bias, residual, ldr, y, M, N, K, ldy, stream)
+    assert lib.mi355q_bfp_gemm_aligned_res(p, p, None, None, 64, p, 4, 64, 128, 64, None) == BAD      # no residual
+    assert lib.mi355q_bfp_gemm_aligned_res(p, p, None, p, 32, p, 4, 64, 128, 64, None) == BAD        # ldr < N
+    assert lib.mi355q_bfp_gemm_aligned_res(p, p, None, p, 66, p, 4, 64, 128, 66, None) == BAD        # ldr % 4
+    assert lib.mi355q_bfp_gemm_aligned_res(p, p, None, p + 4, 64, p, 4, 64, 128, 64, None) == ALIGN
+    # mi355q_bfp_attention_fused(q, k, v, mask, causal, q_scale, scale_div, out, out_tiled, consumer, ws, B, M, T, D, qk, pv, strides,
+    #                            cos, sin, pos, table_rows, heads, stream)
+    par = (ctypes.c_int32 * 6)(6, 8, 127, 6, 8, 127)
+    pa = ctypes.addressof(par)
+    call = lambda **kw: lib.mi355q_bfp_attention_fused(*[kw.get(n, d) for n, d in (
+        ("q", p), ("k", p), ("v", p), ("mask", None), ("causal", 1), ("q_scale", 0.0), ("scale_div", 0.0), ("out", p), ("tiled", None), ("cons", None),
+        ("ws", p), ("B", 4), ("M", 64), ("T", 64), ("D", 128), ("qk", pa), ("pv", pa), ("strides", None), ("cos", None), ("sin", None), ("pos", None),
+        ("rows", 0), ("heads", 1), ("stream", None))])
+    assert call(cos=p) == BAD                                                       # tables and positions come together
+    assert call(cos=p, sin=p, pos=p, rows=0, heads=4) == BAD                        # an empty table
+    assert call(cos=p, sin=p + 4, pos=p, rows=64, heads=4) == ALIGN
+    assert call(cos=p, sin=p, pos=p, rows=64, heads=4, D=96) == UNS                 # the embedding on load: head_dim 64 / 128
+    assert call(cos=p, sin=p, pos=p, rows=64, heads=4, M=32) == UNS                 # ... over the same positions for q and k
+    assert call(tiled=p) == BAD                                                     # the consumer's quantiser is missing
+    cons = (ctypes.c_int32 * 3)(10, 8, 127)
+    assert call(tiled=p, cons=ctypes.addressof(cons)) == UNS                        # wider than bf16 holds exactly
+    cons = (ctypes.c_int32 * 3)(6, 8, 127)
+    assert call(tiled=p, cons=ctypes.addressof(cons), mask=p) == UNS                # the operand output: no additive mask
+    assert call(tiled=p, cons=ctypes.addressof(cons), D=32) == UNS
+    assert call(q_scale=0.125, D=32) == UNS                                         # q_scale rides the fragment pack: head_dim 64 / 128
+    assert call(q_scale=0.125, M=128, causal=0) == UNS                              # ... and no more queries than keys
+    assert call(B=0) == 0                                                           # nothing to do
+
+
 def test_stream_cache_evicts_per_stream_and_never_a_captured_streams_buffers():
     """ops._StreamCache: least-recently-used per (device, stream); entries of a stream that recorded a HIP graph
     are never dropped, whatever traffic other streams (or that stream) see afterwards"""
