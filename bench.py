@@ -345,6 +345,23 @@ def committed_traffic(kernel):
     return None, None
 
 
+def committed_profile_launch_us(kernel):
+    """average duration of the dominant kernel in the COMMITTED rocprofv3 kernel stats of this same step (profiles/r06_bench_kernel_stats.csv,
+    tools/prof/prof_step.sh): the figure the event-timed `avg_launch_ms` is to be read against -- an event pair around a launch also
+    times the command processor's way from one marker through the dispatch to the next (5-7 us on the boxes of round 6)"""
+    import csv
+    for name in ("r06_bench_kernel_stats.csv", "r05_bench_kernel_stats.csv"):
+        try:
+            with open(ROOT / "profiles" / name) as f:
+                for row in csv.DictReader(f):
+                    n = row.get("Name", "")
+                    if n.startswith("void " + kernel.replace("<1, false, false>", "<1, false, false")) and "(" in n:
+                        return float(row["AverageNs"]) / 1e3, int(row["Calls"]), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None
+
+
 def clock_ramp(torch, step, ms):
     """Un-timed launches of the step until the GPU has left its idle clocks.  An MI355X that has been idle takes some tens of
     milliseconds of work to reach the clocks it then holds; 20 + 5 steps of this benchmark are 2.5 ms of work, so without
@@ -648,6 +665,13 @@ def main():
                          "back_to_back_launch_ms": None if b2b_ms is None else round(b2b_ms, 4),
                          "back_to_back_note": "the same kernel alone, launch to launch without events (duration + one dispatch gap)"},
         }
+        prof_us, prof_calls, prof_src = committed_profile_launch_us(kname) if rows_mode and not sharded else (None, None, None)
+        if prof_us:
+            out["roofline"]["committed_profile"] = {
+                "avg_launch_us": round(prof_us, 2), "launches": prof_calls, "frac": round(2.0 * M * n_out * K / (prof_us * 1e-6) / 1e12 / INT8_DENSE_PEAK_TFLOPS, 4),
+                "source": f"profiles/{prof_src}: rocprofv3 --kernel-trace --stats of this step (tools/prof/prof_step.sh) on one box of round 6; not "
+                          "measured by this run.  The event pair around a launch (`avg_launch_ms`) also times the command processor's way from "
+                          "marker to dispatch to marker: + 1 us on round 5's boxes, + 5-7 on round 6's (device-scope release events: - 1.3)"}
         if ceiling:
             # nominal AND achievable.  `frac` stays the fraction of the nominal 5 POPS; `frac_of_measured` prices the same
             # launch against what this device's int8 pipes deliver from registers on random operands

@@ -27,7 +27,11 @@ struct GemmTiming {
         if (!enabled || used >= 4096) return nullptr;
         if (used == pool.size()) {
             hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+            // (device-scope release: a default event record releases to SYSTEM scope -- the stop marker then waits for the write-back of
+            //  the kernel's 64 MiB of output to leave the L2s before it takes its timestamp, 5-7 us that are not the kernel's and that
+            //  the step without events never pays; HIP documents this flag for "more precise timings of commands between events")
+            if (hipEventCreateWithFlags(&a, hipEventReleaseToDevice) != hipSuccess || hipEventCreateWithFlags(&b, hipEventReleaseToDevice) != hipSuccess)
+                return nullptr;
             pool.emplace_back(a, b);
         }
         (void)hipEventRecord(pool[used].first, st);
