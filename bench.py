@@ -347,8 +347,7 @@ def committed_traffic(kernel):
 
 def committed_profile_launch_us(kernel):
     """average duration of the dominant kernel in the COMMITTED rocprofv3 kernel stats of this same step (profiles/r06_bench_kernel_stats.csv,
-    tools/prof/prof_step.sh): the figure the event-timed `avg_launch_ms` is to be read against -- an event pair around a launch also
-    times the command processor's way from one marker through the dispatch to the next (5-7 us on the boxes of round 6)"""
+    tools/prof/prof_step.sh): the figure the event-timed `avg_launch_ms` is to be read against"""
     import csv
     for name in ("r06_bench_kernel_stats.csv", "r05_bench_kernel_stats.csv"):
         try:
@@ -659,8 +658,11 @@ def main():
                                             "separate passes over tools/cdriver/step_driver (same step through the C ABI); not "
                                             "measured by this run") if traffic else None,
                          "avg_launch_ms": round(gemm_avg_ms, 4), "min_launch_ms": round(gemm_min_ms, 4), "launches_timed": n_timed,
-                         "measured": f"second pass of {args.steps} steps with a HIP event pair around every launch (library, launch "
-                                     "stream); `value` is the first pass, without them",
+                         "measured": f"second pass of {args.steps} steps with a HIP event pair on every launch of this kernel (library, launch "
+                                     "stream; since round 6 the pair is attached to the kernel's own dispatch -- hipExtLaunchKernelGGL start / stop "
+                                     "events: kernel start to kernel end -- instead of two marker records around it, which also timed the command "
+                                     "processor's way from marker to dispatch to marker: 69-71 us on the same boxes); `value` is the first pass, "
+                                     "without events",
                          "ms_per_step_with_events": round(dt_events / args.steps * 1e3, 4),
                          "back_to_back_launch_ms": None if b2b_ms is None else round(b2b_ms, 4),
                          "back_to_back_note": "the same kernel alone, launch to launch without events (duration + one dispatch gap)"},
@@ -670,8 +672,7 @@ def main():
             out["roofline"]["committed_profile"] = {
                 "avg_launch_us": round(prof_us, 2), "launches": prof_calls, "frac": round(2.0 * M * n_out * K / (prof_us * 1e-6) / 1e12 / INT8_DENSE_PEAK_TFLOPS, 4),
                 "source": f"profiles/{prof_src}: rocprofv3 --kernel-trace --stats of this step (tools/prof/prof_step.sh) on one box of round 6; not "
-                          "measured by this run.  The event pair around a launch (`avg_launch_ms`) also times the command processor's way from "
-                          "marker to dispatch to marker: + 1 us on round 5's boxes, + 5-7 on round 6's (device-scope release events: - 1.3)"}
+                          "measured by this run; `avg_launch_ms` is this run's event-timed figure for the same kernel"}
         if ceiling:
             # nominal AND achievable.  `frac` stays the fraction of the nominal 5 POPS; `frac_of_measured` prices the same
             # launch against what this device's int8 pipes deliver from registers on random operands

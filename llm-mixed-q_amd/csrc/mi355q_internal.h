@@ -137,6 +137,10 @@ int launch_bfp_gemm_v8(const GemmArgs& a, const float* sx, const float* sw, cons
 // the mixed contraction of the 256 x 256 tile kernel (mi355q_gemm_v9m.hip): a.K1 / a.xm1 / a.wm1 set
 int launch_bfp_gemm_v9_mixed(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                              const uint8_t* xf, const uint8_t* wf);
+// benchmark timing (mi355q_gemm_timing): a launcher that can hands these to hipExtLaunchKernelGGL -- the events then carry the DISPATCH's own
+// start / end timestamps (what rocprofv3 reports), not the times two marker packets around it complete -- and clears `start` to say so
+struct KernelEvents { hipEvent_t start, stop; };
+extern KernelEvents g_kernel_events;
 int launch_bfp_gemm_v9_gated(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
                              const uint8_t* xf, const uint8_t* wf);
 int launch_bfp_gemm_v9_resid(const GemmArgs& a, const float* sx, const float* sw, const int* xlist, const int* wlist, hipStream_t st,
