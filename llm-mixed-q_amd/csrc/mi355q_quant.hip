@@ -953,10 +953,16 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     else if (old) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false);                                                         \
     else if (a.pre_op) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, true, FULL_);                                \
     else MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, false, FULL_)
+    // (round 6: rows of <= 1024 / <= 2048 values -- OPT-125m / 350m / 1.3B widths -- hold one / two slabs a lane instead of four guarded
+    //  ones: fewer registers, more rows resident on a compute unit.  MI355Q_QROWS_SHORT=0: the four-slab build for them too, A/B runs)
+    static const int short_rows = getenv("MI355Q_QROWS_SHORT") ? atoi(getenv("MI355Q_QROWS_SHORT")) : 1;
     if (a.cols == 4096) MI355Q_LAUNCH_ROWS(4, true);            // every lane holds a block in every slab: no guards
+    else if (short_rows && !a.seg_len && !old && a.cols <= 1024) MI355Q_LAUNCH_ROWS(1, false);
+    else if (short_rows && !a.seg_len && !old && a.cols <= 2048) MI355Q_LAUNCH_ROWS(2, false);
     else if (a.cols <= 4096) MI355Q_LAUNCH_ROWS(4, false);
     else if (a.cols == 8192) MI355Q_LAUNCH_ROWS(8, true);
     else if (a.cols <= 8192) MI355Q_LAUNCH_ROWS(8, false);
+    else if (short_rows && !a.seg_len && !old && a.cols <= 12288) MI355Q_LAUNCH_ROWS(12, false);      // (Llama-7B's 11008: 11 slabs of 16)
     else if (a.cols == 16384) MI355Q_LAUNCH_ROWS(16, true);
     else if (a.cols <= 16384) MI355Q_LAUNCH_ROWS(16, false);
     else
