@@ -623,7 +623,10 @@ struct MxOut {
     int* bad_clear;   // the flag word of the NEXT call (callers alternate between two): cleared here, by one thread
 };
 
-template <int MAXIT, bool FULL, bool SEG, bool MX = false, bool PRE = true, bool ST16 = false, int WPS = 1>
+// PRE: which step in front of the quantiser is COMPILED IN -- 0 none, 1 any (a.pre_op decides), 2 LlamaRMSNorm only, 3 LayerNorm only,
+// 4 the elementwise ones (relu, silu(x) * x2) only.  Round 6: with every path compiled in, the register count was the maximum over
+// them (silu_mul's second row, LayerNorm's two vectors): a row behind RMSNorm paid for all of it.
+template <int MAXIT, bool FULL, bool SEG, bool MX = false, int PRE = 1, bool ST16 = false, int WPS = 1>
 __global__ __launch_bounds__(256, WPS) void bfp_quant_align_rows_kernel(const QuantArgs a, int8_t* __restrict__ mt,
                                                                    uint8_t* __restrict__ flag, float* __restrict__ rscale,
                                                                    int exp_offset, int* __restrict__ list,
@@ -661,8 +664,9 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_align_rows_kernel(const Qu
     };
     auto load_row = [&](float4 (&v)[MAXIT], long long row) {
         load_raw(v, row);
-        if constexpr (!PRE) return;                            // (plain rows: none of the pre-op code, nor its registers)
-        if (a.pre_op == MI355Q_PRE_RMSNORM) {                                                  // (uniform)
+        if constexpr (PRE == 0) return;                        // (plain rows: none of the pre-op code, nor its registers)
+        const int pre_op = PRE == 2 ? MI355Q_PRE_RMSNORM : (PRE == 3 ? MI355Q_PRE_LAYERNORM : a.pre_op);
+        if ((PRE == 1 || PRE == 2) && pre_op == MI355Q_PRE_RMSNORM) {                          // (uniform)
             // LlamaRMSNorm (modeling_llama.py:88-92): x * rsqrt(mean(x^2) + eps), then weight * that, each product rounded
             // to fp32 like the reference's separate ops.  The mean is summed in a fixed order (lane partials over the
             // row's chunks, xor tree over the wave, the four waves in turn): the same bits run after run, not the bits of
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_align_rows_kernel(const Qu
                     v[it] = make_float4(w.x * h.x, w.y * h.y, w.z * h.z, w.w * h.w);
                 }
             }
-        } else if (a.pre_op == MI355Q_PRE_LAYERNORM) {                                          // (uniform)
+        } else if ((PRE == 1 || PRE == 3) && pre_op == MI355Q_PRE_LAYERNORM) {                  // (uniform)
             // nn.LayerNorm over the row (OPT's self_attn_layer_norm / final_layer_norm, modeling_opt.py:391-415):
             // (x - mean) * rsqrt(var + eps) * weight + bias, biased variance, mean first and the centred squares after it
             // (the row sits in registers), both summed in the fixed order described above.
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_align_rows_kernel(const Qu
                                         v[it].w * rs * w.w + b.w);
                 }
             }
-        } else if (a.pre_op) {                                                                  // (uniform)
+        } else if ((PRE == 1 || PRE == 4) && pre_op) {                                          // (uniform)
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
                 const int kb = it * 64 + wave * 16 + (lane >> 2);
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(256, WPS) void bfp_quant_align_rows_kernel(const Qu
     // Several rows per workgroup (round 4, plain rows: launch_quant_align_rows): the NEXT row is requested as soon as this one's
     // values are dead -- behind the mantissas, in front of the exponent decision, its barriers and the stores -- into the same
     // registers: a row's life was load round trip + arithmetic + decision + stores in sequence, 4 workgroups a compute unit.
-    const bool early = (!PRE || a.pre_op == 0) && !SEG;
+    const bool early = (PRE == 0 || a.pre_op == 0) && !SEG;
     for (long long wi = blockIdx.x; wi < a.rows; wi += gridDim.x) {
         const long long row = row_of(wi);
         if (wi != (long long)blockIdx.x && !early) load_row(v, row);
@@ -951,8 +955,10 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
 #define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
     if (a.seg_len) MI355Q_LAUNCH_ROWS_T(MAXIT_, false, true);                                                         \
     else if (old) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false);                                                         \
-    else if (a.pre_op) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, true, FULL_);                                \
-    else MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, false, FULL_)
+    else if (a.pre_op == MI355Q_PRE_RMSNORM) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, 2, FULL_);             \
+    else if (a.pre_op == MI355Q_PRE_LAYERNORM) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, 3, FULL_);           \
+    else if (a.pre_op) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, 4, FULL_);                                   \
+    else MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, 0, FULL_)
     // (round 6: rows of <= 1024 / <= 2048 values -- OPT-125m / 350m / 1.3B widths -- hold one / two slabs a lane instead of four guarded
     //  ones: fewer registers, more rows resident on a compute unit.  MI355Q_QROWS_SHORT=0: the four-slab build for them too, A/B runs)
     static const int short_rows = getenv("MI355Q_QROWS_SHORT") ? atoi(getenv("MI355Q_QROWS_SHORT")) : 1;
