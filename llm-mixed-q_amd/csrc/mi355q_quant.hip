@@ -981,15 +981,18 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
 // block_fp -> MX operand (mi355q_mx.hip): rows x K fp32, K % 128 == 0, width <= 5; `bad` is RAISED, never cleared here
 int launch_quant_mx_rows(const QuantArgs& a, uint8_t* c16, uint8_t* c8, uint8_t* sc, int* bad, int* bad_clear, hipStream_t st) {
     long long grid = a.rows;
-    constexpr int qgrid = 1024;
+    constexpr int qgrid = 1536;                             // (six resident workgroups a compute unit at 77 registers, like the int8 flavour)
     if (qgrid > 0 && a.pre_op == 0 && grid > qgrid) grid = qgrid;
     if (grid > 65536) grid = 65536;
     if (grid < 1) grid = 1;
     const MxOut mx{c16, c8, sc, bad, bad_clear};
 #define MI355Q_LAUNCH_MX(MAXIT_, FULL_)                                                                               \
-    hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_, false, true>), (unsigned)grid, 256, 0, st, a, nullptr, nullptr, nullptr, \
+    hipLaunchKernelGGL((bfp_quant_align_rows_kernel<MAXIT_, FULL_, false, true, 0>), (unsigned)grid, 256, 0, st, a, nullptr, nullptr, nullptr, \
                        0, nullptr, nullptr, -1, mx)
+    // (round 6: the build without the pre-op code -- this entry never has one -- and the short-row builds, as the int8 flavour)
     if (a.cols == 4096) MI355Q_LAUNCH_MX(4, true);
+    else if (a.cols <= 1024) MI355Q_LAUNCH_MX(1, false);
+    else if (a.cols <= 2048) MI355Q_LAUNCH_MX(2, false);
     else if (a.cols <= 4096) MI355Q_LAUNCH_MX(4, false);
     else if (a.cols == 8192) MI355Q_LAUNCH_MX(8, true);
     else if (a.cols <= 8192) MI355Q_LAUNCH_MX(8, false);
