@@ -953,7 +953,10 @@ int launch_quant_align_rows(const QuantArgs& a, int8_t* mt, uint8_t* flag, float
     hipLaunchKernelGGL((bfp_quant_align_rows_kernel<__VA_ARGS__>), (unsigned)grid, 256, 0, st, a, mt, flag, rscale, exp_offset, list, \
                        list_to_clear, bcap)
 #define MI355Q_LAUNCH_ROWS(MAXIT_, FULL_)                                                                             \
-    if (a.seg_len) MI355Q_LAUNCH_ROWS_T(MAXIT_, false, true);                                                         \
+    if (a.seg_len && a.pre_op == MI355Q_PRE_RMSNORM) MI355Q_LAUNCH_ROWS_T(MAXIT_, false, true, false, 2);             \
+    else if (a.seg_len && a.pre_op == MI355Q_PRE_LAYERNORM) MI355Q_LAUNCH_ROWS_T(MAXIT_, false, true, false, 3);      \
+    else if (a.seg_len && a.pre_op) MI355Q_LAUNCH_ROWS_T(MAXIT_, false, true, false, 4);                              \
+    else if (a.seg_len) MI355Q_LAUNCH_ROWS_T(MAXIT_, false, true, false, 0);                                          \
     else if (old) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false);                                                         \
     else if (a.pre_op == MI355Q_PRE_RMSNORM) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, 2, FULL_);             \
     else if (a.pre_op == MI355Q_PRE_LAYERNORM) MI355Q_LAUNCH_ROWS_T(MAXIT_, FULL_, false, false, 3, FULL_);           \
