@@ -243,12 +243,16 @@ class _LinearBase(nn.Linear):
         versions = (self.weight._version, None if self.bias is None else self.bias._version)
         if self._mixed is not None:
             self._mixed["version"] = versions
-        packed_storage = c.get("mi355q_weight_storage", "int8") == "packed" and self._align_mode == "rows"
+        # "packed": every layer at rest as width-bit mantissas + a byte per block, expanded per forward; "hybrid" (round 6): only the
+        # layers on the per-block-exponent route -- whose resident operand is 16 bits a value, and whose expand pass is a third of a
+        # Llama layer's -- while the row-scale layers keep their int8 operands (8.5 bits a value) and every fused path that needs them
+        storage = c.get("mi355q_weight_storage", "int8")
+        packed_storage = storage == "packed" and self._align_mode == "rows"
         self._w_packed = None
         if self._uses_bf16_route():
             # per-block exponents: the quantised weights (already in .weight) as tiled bf16; the int8 operand is not
             # needed on this route (the exact-integer blockwise kernel, mi355q_blocks_gemm = "int8", keeps it)
-            if packed_storage:
+            if packed_storage or (storage == "hybrid" and self._align_mode == "rows"):
                 self._w_packed = ops.pack_block_exponent_weights(wm, we, c["weight_width"], self._weight_bias_value())
                 self._packed = (None, self._w_packed.packed, *versions)
             else:

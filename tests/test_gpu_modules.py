@@ -466,6 +466,32 @@ def test_packed_weight_storage(width, act):
     np.testing.assert_allclose(lin(x).detach().cpu().numpy(), want, rtol=0, atol=4e-6 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("act", ["plain", "silu"])
+def test_hybrid_weight_storage(act):
+    """mi355q_weight_storage = "hybrid" (round 6): a layer on the per-block-exponent route keeps its weights at width + 0.5 bits and
+    expands them per forward, a layer on the row-scale route keeps its resident int8 operand -- both bit-identical to the resident
+    layer, with the fp32 Parameter released too"""
+    import torch
+    import mi355q.quantize as Q
+    torch.manual_seed(4)
+    K, N, M = 1024, 512, 300
+    fp = torch.nn.Linear(K, N)
+    h = torch.randn(M, K) * torch.exp(torch.randn(M, 1))
+    x = {"plain": h, "silu": torch.nn.functional.silu(h) * torch.randn(M, K)}[act].to("cuda:0")
+    ref_cfg, cfg = _lin_cfg(6), _lin_cfg(6, mi355q_weight_storage="hybrid")
+    ref = Q.get_quantized_cls("linear", ref_cfg).from_float(fp, ref_cfg).to("cuda:0")
+    lin = Q.get_quantized_cls("linear", cfg).from_float(fp, cfg).to("cuda:0")
+    y_ref, y = ref(x), lin(x)
+    assert torch.equal(y, y_ref)
+    assert lin._uses_bf16_route() == ref._uses_bf16_route() == (act == "silu")
+    if act == "silu":
+        assert lin._w_packed is not None and not lin._w_packed.row_scale_flavour and lin.weight_storage_bits() <= 6.75
+    else:
+        assert lin._w_packed is None and lin._packed[0] is not None          # the resident int8 operand
+    lin.release_fp32_weight()
+    assert lin.weight.numel() == 0 and torch.equal(lin(x), y_ref)
+
+
 def test_packed_storage_packs_when_the_weights_arrive():
     """mi355q_weight_storage = "packed": quantised and packed when the module reaches the GPU and when a state dict is loaded,
     before any forward (the loader half); outputs equal a layer that packed at its first forward"""

@@ -30,8 +30,8 @@ def quant_config(storage: str, knobs: bool = True):
     if knobs:
         d.update(mi355q_fused_attention=True, mi355q_grouped_linear=True, mi355q_fused_activation=True, mi355q_fused_norm=True,
                  mi355q_token_major_output=True, mi355q_fused_residual=True, mi355q_fused_gate_up=GATED, mi355q_mixed=MIXED, mi355q_fused_rotary=ROTARY, mi355q_fused_attention_output=ATTN_OUT)
-    if storage == "packed":
-        d.update(mi355q_weight_storage="packed")
+    if storage in ("packed", "hybrid"):
+        d.update(mi355q_weight_storage=storage)
     # the rotary tables of every shipped TOML: 8-bit fixed point (configs/quantization/bfp_6bit.toml)
     return {"default": d, "rotary_positional_encoding": dict(name="integer", bypass=False, data_in_width=8, data_in_frac_width=7)}
 
@@ -60,9 +60,10 @@ def run(layers=32, tokens=2048, steps=5, storage="resident", graph=True, parity=
     want = sorted({0, layers // 2 - 1 if layers > 2 else 0, layers - 1})
     with torch.no_grad():
         model(ids)                                                   # packs every weight (first PTQ forward)
-        if storage == "packed":
+        if storage in ("packed", "hybrid", "released"):
+            # ("released": resident operands, the fp32 copies dropped -- what every storage mode may do once the weights are packed)
             for m in model.modules():
-                if hasattr(m, "release_fp32_weight") and getattr(m, "_w_packed", None) is not None:
+                if hasattr(m, "release_fp32_weight") and getattr(m, "_packed", None) is not None:
                     m.release_fp32_weight()
             torch.cuda.empty_cache()
         model(ids)                                                   # settles the routes
@@ -156,7 +157,7 @@ if __name__ == "__main__":
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--storage", default="resident", choices=["resident", "packed"])
+    ap.add_argument("--storage", default="resident", choices=["resident", "released", "hybrid", "packed"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-knobs", action="store_true")
